@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE on PyTorch-CPU.
+
+Runs ONLY in the survey/build container, where /root/reference exists:
+
+    python tests/golden/make_golden.py
+
+It imports the reference's hot-path modules (mdt.models.edm_diffusion.*, mdt.models.networks.*) behind
+four stub modules (hydra, omegaconf, torchsde, torchdiffeq are import-time-only dependencies that are not
+installed here), fills the reference modules' state_dict from the build's own
+deterministic generator (mdt_policy_amd/synthetic.py), feeds deterministic inputs and stores the
+reference's OUTPUTS (and, for G2, per-stage intermediates) as .npz.  Weights and inputs are NOT stored:
+tests regenerate them from the same generator.  Nothing of the reference's source is copied.
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from mdt_policy_amd import configs, synthetic  # noqa: E402
+
+REF = "/root/reference"
+
+
+def install_stubs():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def instantiate(cfg, *a, **kw):
+        cfg = dict(cfg)
+        tgt = cfg.pop("_target_")
+        cfg.pop("_recursive_", None)
+        mod, cls = tgt.rsplit(".", 1)
+        return getattr(importlib.import_module(mod), cls)(*a, **cfg, **kw)
+
+    hy = stub("hydra")
+    hy.utils = stub("hydra.utils", instantiate=instantiate)
+    stub("omegaconf", DictConfig=dict, OmegaConf=object)
+    stub("torchsde")
+    stub("torchdiffeq", odeint=None)
+    sys.path.insert(0, REF)
+
+
+REF_TARGET = {
+    "mdtv": "mdt.models.networks.mdtv_transformer.MDTVTransformer",
+    "mdt": "mdt.models.networks.mdt_transformer.MDTTransformer",
+}
+
+
+def build_reference(cfg, arch, seed, profile, sigma_data=0.5):
+    from mdt.models.edm_diffusion.score_wrappers import GCDenoiser
+
+    cfg = configs.retarget(cfg, REF_TARGET[arch])
+    if arch == "mdt":
+        cfg.pop("n_obs_token", None)
+    model = GCDenoiser(cfg, sigma_data=sigma_data).eval()
+    sd = model.state_dict()
+    new = synthetic.fill_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed, profile)
+    for k, v in new.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+def make_state(inp, arch, modality):
+    if arch == "mdtv":
+        return {"state_images": torch.from_numpy(inp["state_images"]), "modality": modality}
+    return {"static": torch.from_numpy(inp["static"]), "gripper": torch.from_numpy(inp["gripper"]),
+            "modality": modality}
+
+
+def run_ddim(model, cfg, arch, B, n_steps, modality, in_seed, sigma_min=0.001, sigma_max=80.0, record=False):
+    from mdt.models.edm_diffusion import gc_sampling
+
+    inp = synthetic.sampler_inputs(B, cfg, in_seed, arch)
+    state = make_state(inp, arch, modality)
+    goal = torch.from_numpy(inp["goal"])
+    sigmas = gc_sampling.get_sigmas_exponential(n_steps, sigma_min, sigma_max)
+    x = torch.from_numpy(inp["noise"]) * sigma_max
+    den = []
+    cb = (lambda d: den.append(d["denoised"].clone())) if record else None
+    out = gc_sampling.sample_ddim(model, state, x, goal, sigmas, disable=True, callback=cb)
+    res = {"actions": out.numpy(), "sigmas": sigmas.numpy()}
+    if record:
+        res["denoised_steps"] = torch.stack(den).numpy()
+        res["ctx"] = model.inner_model.latent_encoder_emb.detach().numpy()
+    return res
+
+
+def save(name, meta, **arrays):
+    arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(HERE, name), meta=json.dumps(meta), **arrays)
+    print(f"  wrote {name}: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in arrays.items()))
+
+
+def g1():
+    for arch, cfg in (("mdtv", configs.mdtv_tiny()), ("mdt", configs.mdt_tiny())):
+        model = build_reference(cfg, arch, seed=11, profile="rich")
+        res = run_ddim(model, cfg, arch, B=1, n_steps=4, modality="lang", in_seed=12, record=True)
+        meta = dict(config=f"{arch}_tiny", arch=arch, B=1, n_steps=4, modality="lang", weight_seed=11,
+                    profile="rich", input_seed=12, sigma_min=0.001, sigma_max=80.0)
+        save(f"g1_tiny_{arch}.npz", meta, **res)
+        # MDT forward_context_only honours the modality switch while forward() does not
+        inp = synthetic.sampler_inputs(3, cfg, 13, arch)
+        for modality in ("lang", "vis"):
+            state = make_state(inp, arch, modality)
+            x = torch.from_numpy(inp["noise"])
+            ctx = model.forward_context_only(state, x, torch.from_numpy(inp["goal"]), torch.full((3,), 2.5))
+            meta2 = dict(meta, B=3, input_seed=13, modality=modality)
+            save(f"g1_ctxonly_{arch}_{modality}.npz", meta2, ctx=ctx.detach().numpy())
+
+
+def g2():
+    """Stage-by-stage intermediates of ONE GCDenoiser.forward (B=4, sigma per sample) + DDIM actions."""
+    cfg, arch = configs.mdtv_default(), "mdtv"
+    model = build_reference(cfg, arch, seed=21, profile="rich")
+    inp = synthetic.sampler_inputs(4, cfg, 22, arch)
+    state = make_state(inp, arch, "lang")
+    goal = torch.from_numpy(inp["goal"])
+    sigma = torch.tensor([80.0, 6.5, 0.53, 0.0035])
+    x = torch.from_numpy(inp["noise"]) * sigma[:, None, None]
+    cap = {}
+    hooks = []
+
+    def grab(key):
+        def fn(_m, _i, o):
+            cap[key] = (torch.cat(o, dim=-1) if isinstance(o, tuple) else o).detach().clone().numpy()
+        return fn
+
+    im = model.inner_model
+    hooks.append(im.lang_emb.register_forward_hook(grab("goal_embed")))
+    hooks.append(im.tok_emb.register_forward_hook(grab("state_embed")))
+    for l, b in enumerate(im.encoder.blocks):
+        hooks.append(b.register_forward_hook(grab(f"enc{l}")))
+    hooks.append(im.encoder.register_forward_hook(grab("ctx")))
+    hooks.append(im.sigma_emb.register_forward_hook(grab("sigma_emb")))
+    hooks.append(im.action_emb.register_forward_hook(grab("action_emb")))
+    for l, b in enumerate(im.decoder.blocks):
+        hooks.append(b.adaLN_zero.register_forward_hook(grab(f"dec{l}.mod")))
+        hooks.append(b.attn.register_forward_hook(grab(f"dec{l}.attn")))
+        hooks.append(b.cross_att.register_forward_hook(grab(f"dec{l}.cross_att")))
+        hooks.append(b.mlp.register_forward_hook(grab(f"dec{l}.mlp")))
+        hooks.append(b.register_forward_hook(grab(f"dec{l}")))
+    hooks.append(im.decoder.register_forward_hook(grab("decoder_ln")))
+    hooks.append(im.action_pred.register_forward_hook(grab("action_pred")))
+    with torch.no_grad():
+        out = model(state, x, goal, sigma)
+    for h in hooks:
+        h.remove()
+    res = run_ddim(model, cfg, arch, B=4, n_steps=10, modality="lang", in_seed=22)
+    meta = dict(config="mdtv_default", arch=arch, B=4, n_steps=10, modality="lang", weight_seed=21, profile="rich",
+                input_seed=22, sigma=[80.0, 6.5, 0.53, 0.0035], sigma_min=0.001, sigma_max=80.0)
+    save("g2_stages_mdtv.npz", meta, denoised=out.numpy(), actions=res["actions"], sigmas=res["sigmas"], **cap)
+
+
+def g3():
+    cfg, arch = configs.mdtv_default(), "mdtv"
+    for tag, profile, modality, wseed in (("lang", "rich", "lang", 31), ("vis", "rich", "vis", 31),
+                                          ("init", "init", "lang", 0)):
+        model = build_reference(cfg, arch, seed=wseed, profile=profile)
+        res = run_ddim(model, cfg, arch, B=256, n_steps=10, modality=modality, in_seed=1)
+        meta = dict(config="mdtv_default", arch=arch, B=256, n_steps=10, modality=modality, weight_seed=wseed,
+                    profile=profile, input_seed=1, sigma_min=0.001, sigma_max=80.0)
+        save(f"g3_b256_{tag}.npz", meta, actions=res["actions"], sigmas=res["sigmas"])
+    # eval-time schedule of the released ABCD checkpoints (conf/mdt_evaluate.yaml: sigma_min 1.0), 5 steps
+    model = build_reference(cfg, arch, seed=31, profile="rich")
+    res = run_ddim(model, cfg, arch, B=8, n_steps=5, modality="lang", in_seed=2, sigma_min=1.0)
+    meta = dict(config="mdtv_default", arch=arch, B=8, n_steps=5, modality="lang", weight_seed=31, profile="rich",
+                input_seed=2, sigma_min=1.0, sigma_max=80.0)
+    save("g3_b8_smin1.npz", meta, actions=res["actions"], sigmas=res["sigmas"])
+    # MDT (ResNet-token) default architecture, d=512, 4+6 blocks
+    cfg, arch = configs.mdt_default(), "mdt"
+    model = build_reference(cfg, arch, seed=33, profile="rich")
+    res = run_ddim(model, cfg, arch, B=8, n_steps=10, modality="vis", in_seed=3, record=True)
+    meta = dict(config="mdt_default", arch=arch, B=8, n_steps=10, modality="vis", weight_seed=33, profile="rich",
+                input_seed=3, sigma_min=0.001, sigma_max=80.0)
+    save("g3_b8_mdt.npz", meta, actions=res["actions"], sigmas=res["sigmas"], ctx=res["ctx"])
+
+
+def g4():
+    cfg, arch = configs.mdtv_default(), "mdtv"
+    model = build_reference(cfg, arch, seed=41, profile="rich")
+    B = 32
+    inp = synthetic.sampler_inputs(B, cfg, 42, arch)
+    li = synthetic.loss_inputs(B, cfg, 43)
+    state = make_state(inp, arch, "vis")
+    with torch.no_grad():
+        loss, mo = model.loss(state, torch.from_numpy(li["actions"]), torch.from_numpy(inp["goal"]),
+                              torch.from_numpy(li["noise_train"]), torch.from_numpy(li["sigma"]))
+    meta = dict(config="mdtv_default", arch=arch, B=B, modality="vis", weight_seed=41, profile="rich", input_seed=42,
+                loss_seed=43)
+    save("g4_loss.npz", meta, loss=np.array(loss.item(), np.float32), model_output=mo.numpy(), sigma=li["sigma"])
+
+
+def g5():
+    from mdt.models.edm_diffusion import gc_sampling as gs
+
+    arrays = {}
+    for smin in (0.001, 1.0):
+        for n in (1, 3, 5, 10, 20):
+            s = gs.get_sigmas_exponential(n, smin, 80.0)
+            arrays[f"exp_{smin}_{n}"] = s.numpy()
+            ratios, coefs = [], []
+            for i in range(n):
+                t, tn = s[i].log().neg(), s[i + 1].log().neg()
+                ratios.append((tn.neg().exp() / t.neg().exp()).item())
+                coefs.append((-(-(tn - t)).expm1()).item())
+            arrays[f"ddim_ratio_{smin}_{n}"] = np.array(ratios, np.float32)
+            arrays[f"ddim_coef_{smin}_{n}"] = np.array(coefs, np.float32)
+    arrays["karras_10"] = gs.get_sigmas_karras(10, 0.001, 80.0, 7.0).numpy()
+    arrays["linear_10"] = gs.get_sigmas_linear(10, 0.001, 80.0).numpy()
+    arrays["ve_10"] = gs.get_sigmas_ve(10, 0.001, 80.0).numpy()
+    arrays["vp_10"] = gs.get_sigmas_vp(10).numpy()
+    save("g5_schedules.npz", dict(what="noise schedules + DDIM scalar pairs"), **arrays)
+
+
+def g6():
+    cfg, arch = configs.mdtv_default(use_rot_embed=True), "mdtv"
+    model = build_reference(cfg, arch, seed=61, profile="rich")
+    res = run_ddim(model, cfg, arch, B=4, n_steps=10, modality="lang", in_seed=62, record=True)
+    meta = dict(config="mdtv_default", overrides=dict(use_rot_embed=True), arch=arch, B=4, n_steps=10,
+                modality="lang", weight_seed=61, profile="rich", input_seed=62, sigma_min=0.001, sigma_max=80.0)
+    save("g6_rope.npz", meta, **res)
+
+
+def g7():
+    from mdt.models.edm_diffusion import gc_sampling as gs
+
+    cfg, arch = configs.mdtv_default(), "mdtv"
+    model = build_reference(cfg, arch, seed=71, profile="rich")
+    inp = synthetic.sampler_inputs(4, cfg, 72, arch)
+    state = make_state(inp, arch, "lang")
+    goal = torch.from_numpy(inp["goal"])
+    out = {}
+    for sched, sigmas in (("exp", gs.get_sigmas_exponential(10, 0.001, 80.0)),
+                          ("karras", gs.get_sigmas_karras(10, 0.001, 80.0, 7.0))):
+        for name in ("euler", "heun", "dpmpp_2m", "ddim"):
+            x = torch.from_numpy(inp["noise"]) * 80.0
+            out[f"{name}_{sched}"] = getattr(gs, "sample_" + name)(model, state, x, goal, sigmas, disable=True).numpy()
+    meta = dict(config="mdtv_default", arch=arch, B=4, n_steps=10, modality="lang", weight_seed=71, profile="rich",
+                input_seed=72, sigma_min=0.001, sigma_max=80.0)
+    save("g7_samplers.npz", meta, **out)
+
+
+def manifest():
+    """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
+    out = {}
+    for key, arch, cfg in (("mdtv_default", "mdtv", configs.mdtv_default()),
+                           ("mdtv_rope", "mdtv", configs.mdtv_default(use_rot_embed=True)),
+                           ("mdtv_tiny", "mdtv", configs.mdtv_tiny()),
+                           ("mdt_default", "mdt", configs.mdt_default()),
+                           ("mdt_tiny", "mdt", configs.mdt_tiny())):
+        m = build_reference(cfg, arch, 0, "init")
+        out[key] = {
+            "state_dict": [[k, list(v.shape)] for k, v in m.state_dict().items()],
+            "named_parameters": [k for k, _ in m.named_parameters()],
+        }
+    with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("  wrote state_dict_manifest.json")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
+    install_stubs()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "manifest"]
+    for w in which:
+        print(w)
+        globals()[w]()

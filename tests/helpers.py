@@ -1,0 +1,70 @@
+"""Shared test helpers: fixture loading and regeneration of the synthetic weights/inputs behind them."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from mdt_policy_amd import configs, synthetic
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+with open(os.path.join(GOLDEN, "state_dict_manifest.json")) as _f:
+    MANIFEST = json.load(_f)
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    meta = json.loads(str(z["meta"]))
+    arrays = {k: z[k] for k in z.files if k != "meta"}
+    return meta, arrays
+
+
+def manifest_key(meta):
+    if meta.get("overrides", {}).get("use_rot_embed"):
+        return "mdtv_rope"
+    return meta["config"]
+
+
+def cfg_of(meta):
+    return configs.NAMED[meta["config"]](**meta.get("overrides", {}))
+
+
+def rotary_freqs(rot_dim=32, theta=10000.0):
+    return 1.0 / (theta ** (torch.arange(0, rot_dim, 2)[: rot_dim // 2].float() / rot_dim))
+
+
+def params_of(meta, dtype=torch.float32):
+    """{state_dict name: tensor} regenerated from the deterministic generator (rotary buffers recomputed)."""
+    shapes = [(k, tuple(s)) for k, s in MANIFEST[manifest_key(meta)]["state_dict"]]
+    P = {k: torch.from_numpy(v) for k, v in
+         synthetic.fill_state_dict(shapes, meta["weight_seed"], meta["profile"]).items()}
+    for k, s in shapes:
+        if k.endswith("rotary_pos_emb.freqs"):
+            P[k] = rotary_freqs(2 * s[0])
+    return {k: v.to(dtype) for k, v in P.items()}
+
+
+def inputs_of(meta, dtype=torch.float32, batch=None):
+    cfg = cfg_of(meta)
+    inp = synthetic.sampler_inputs(batch or meta["B"], cfg, meta["input_seed"], meta["arch"])
+    t = {k: torch.from_numpy(v).to(dtype) for k, v in inp.items()}
+    if meta["arch"] == "mdtv":
+        state = {"state_images": t["state_images"], "modality": meta["modality"]}
+    else:
+        state = {"static": t["static"], "gripper": t["gripper"], "modality": meta["modality"]}
+    return state, t["goal"], t["noise"]
+
+
+RTOL, ATOL = 1e-3, 1e-4  # BASELINE.json north_star parity gate
+
+
+def assert_close(got, want, rtol=RTOL, atol=ATOL, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {bad.sum()}/{bad.size} outside rtol={rtol} atol={atol}; "
+                           f"max abs err {err.max():.3e} (|want| max {np.abs(want).max():.3e})")
