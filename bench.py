@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- action-chunks/sec of the MDT denoising hot path on MI355X (BASELINE.json metric).
+
+A "step" is ONE full sampler invocation over one batch: encoder + cross-K/V once, then 10 DDIM denoise steps of the
+MDT-V d=384 4+4-block score network over B=256 action chunks (horizon 10, action dim 7) per GPU -- BASELINE config
+C2 at N=1, C4-shaped (256 per GPU, weak scaling, one RCCL all-gather of the sampled actions per step) at N>1.
+Inputs (state tokens, goal, x_T) and the random-init weights are synthetic and already resident in HBM when the
+timed region starts.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+  roofline     : algorithmic FLOPs (mdt_flops_per_chunk = 1.812 GFLOP/chunk) / HIP-event time of the timed region
+                 against the dense FP32-MFMA peak (157.3 TFLOP/s; bf16/fp16 operands fail the parity gate), plus
+                 the same figure for the dominant kernel (the fused MFMA GEMM) timed alone through the op-level ABI
+  cpu_baseline : the CPU oracle ("port" of the reference algorithm, as-written: encoder re-run every step) timed on
+                 this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense FP32 matrix peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="action chunks per GPU per step")
+    ap.add_argument("--denoise-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def build_model(device):
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    cfg = configs.mdtv_default()
+    model = GCDenoiser(cfg, sigma_data=0.5)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=0, profile="init").items()}
+    model.load_state_dict(P)
+    return cfg, P, model.to(device).eval()
+
+
+def time_dominant_kernel(device, M):
+    """The fused MFMA GEMM is >95 % of the algorithmic FLOPs; time its largest instance (MLP c_fc: LayerNorm +
+    adaLN-modulate prologue, N=1536, K=384, GELU epilogue) alone with HIP events on the launch stream."""
+    from mdt_policy_amd import _lib
+    lib = _lib.load()
+    D, N = 384, 1536
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(M, D, generator=g).to(device)
+    W = (torch.randn(N, D, generator=g) * 0.02).to(device)
+    lw = torch.ones(D, device=device)
+    mod = torch.randn(6 * D, generator=g).to(device)
+    P = torch.zeros(N * D, device=device)
+    out = torch.empty(M, N, device=device)
+    s = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.mdt_op_pack_weight(W.data_ptr(), N, D, P.data_ptr(), 0, N, s))
+    a = _lib.GemmArgs()
+    a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = A.data_ptr(), D, P.data_ptr(), out.data_ptr(), N, M, N, D
+    a.ln, a.ln_w, a.mod, a.mod_stride, a.shift_off, a.scale_off = 1, lw.data_ptr(), mod.data_ptr(), 0, 3 * D, 4 * D
+    a.rows_per_sample, a.act, a.gate_off, a.gin, a.gout, a.goff = 10, _lib.ACT["gelu"], -1, 1, 1, 0
+    for _ in range(10):
+        _lib.check(lib.mdt_op_gemm(C.byref(a), s))
+    reps = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.mdt_op_gemm(C.byref(a), s))
+    e1.record()
+    torch.cuda.synchronize(device)
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    tf = 2.0 * M * N * D / (us * 1e-6) / 1e12
+    return {"name": f"k_gemm LN+mod->c_fc->GELU ({M}x{N}x{D})", "avg_us": round(us, 2), "achieved": round(tf, 2),
+            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
+def cpu_baseline(cfg, P, batch, n_denoise, budget_s):
+    """Oracle (port of the reference's PyTorch-CPU algorithm) on this host, as-written (encoder every step)."""
+    from mdt_policy_amd import synthetic
+    from oracle import mdt_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    inp = {k: torch.from_numpy(v) for k, v in synthetic.sampler_inputs(batch, cfg, seed=1).items()}
+    state = {"state_images": inp["state_images"], "modality": "lang"}
+    sig = O.get_sigmas_exponential(n_denoise, 0.001, 80.0)
+    x = inp["noise"] * 80.0
+    O.sample_ddim(P, cfg, {"state_images": inp["state_images"][:8], "modality": "lang"}, x[:8], inp["goal"][:8], sig)
+    best, spent, reps = float("inf"), 0.0, 0
+    while reps < 5 and (reps == 0 or spent + best < budget_s):
+        t0 = time.perf_counter()
+        O.sample_ddim(P, cfg, state, x, inp["goal"], sig, hoist=False)
+        dt = time.perf_counter() - t0
+        best, spent, reps = min(best, dt), spent + dt, reps + 1
+    return {"value": round(batch / best, 2), "unit": "action-chunks/s", "cores": threads, "kind": "port",
+            "sample": f"oracle sample_ddim, B={batch}, {n_denoise} steps, fp32, encoder re-run every step "
+                      f"(as the reference does), best of {reps} ({best:.2f} s each), torch {torch.__version__}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a ROCm GPU: the hot path has no CPU execution path")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+
+    from mdt_policy_amd import sharding, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+
+    cfg, P, model = build_model(device)
+    B = args.batch
+    inp = {k: torch.from_numpy(v).to(device) for k, v in synthetic.sampler_inputs(B, cfg, seed=1 + rank).items()}
+    state = {"state_images": inp["state_images"], "modality": "lang"}
+    goal, x_T = inp["goal"], inp["noise"] * 80.0
+    sigmas = gs.get_sigmas_exponential(args.denoise_steps, 0.001, 80.0)  # host tensor, like the reference's cpu default
+    eng = model.inner_model.hip_engine(0.5)
+    eng.reserve(B)
+
+    def step():
+        with torch.no_grad():
+            act = gs.sample_ddim(model, state, x_T, goal, sigmas)
+        if world > 1:
+            act = sharding.all_gather_actions(act, B * world)  # ONE collective per sample call
+        return act
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        out = step()
+    e1.record()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    gpu_s = e0.elapsed_time(e1) * 1e-3
+    if dist is not None:
+        t = torch.tensor([wall, gpu_s], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, gpu_s = t[0].item(), t[1].item()
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        flops_chunk = eng.flops_per_chunk(args.denoise_steps)
+        chunks = B * world * args.steps
+        achieved = flops_chunk * B * args.steps / gpu_s / 1e12  # per GPU, HIP-event time of the timed region
+        res = {
+            "metric": "action-chunks/sec (10-step denoise, horizon=10)",
+            "value": round(chunks / wall, 1),
+            "unit": "action-chunks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"MDT-V d=384 4+4 blocks 8 heads, horizon 10, action dim 7, "
+                                   f"{args.denoise_steps} DDIM steps (exponential sigma 80->0.001), "
+                                   f"B={B} synthetic goal/state tokens per GPU (BASELINE configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world, "denoise_steps": args.denoise_steps,
+                       "parallelism": f"batch-sharded x{world}, RCCL all-gather of actions" if world > 1 else "single GPU",
+                       "weights": "random init N(0,0.02) (reference _init_weights distributions), seed 0"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "scope": "whole sampler call (encoder + 10 decoder steps), algorithmic "
+                                  f"{flops_chunk / 1e9:.3f} GFLOP/chunk, HIP-event time of the timed region",
+                         "gpu_ms_per_step": round(gpu_s / args.steps * 1e3, 4)},
+        }
+        try:
+            res["roofline"]["dominant_kernel"] = time_dominant_kernel(device, B * 10)
+        except Exception as e:  # diagnostic leg only; never hides the main number
+            res["roofline"]["dominant_kernel"] = {"error": str(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, P, B, args.denoise_steps, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * mdt_hip.h -- C ABI of libmdt_hip.so: the MI355X (gfx950) implementation of MDT's diffusion-transformer
+ * action-denoising hot path (EDM-preconditioned score network + multi-step sampler loop).
+ *
+ * The reference (intuitive-robots/mdt_policy) is pure Python and has NO FFI boundary for this path; the
+ * operator API the path sits behind is Python.  Each entry point below therefore cites
+ * the reference Python call it stands under; the Python facade in mdt_policy_amd/models/ presents the
+ * reference's own class / function signatures on top of this ABI (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - C linkage, POD arguments only: raw pointers, int64 sizes, an opaque handle, a hipStream_t passed
+ *     as void*.  No exceptions cross the boundary: every call returns an mdt_status; the message of the
+ *     last failure on the calling thread is available from mdt_last_error().
+ *   - All tensors are fp32, row-major, contiguous, batch-major (B, T, C); data pointers are DEVICE
+ *     pointers on the handle's device and must be 16-byte aligned, except where marked "host".
+ *   - All work is enqueued on the caller's stream (e.g. torch.cuda.current_stream().cuda_stream on
+ *     PyTorch-ROCm); nothing synchronises the device except mdt_reserve()/first-use workspace growth,
+ *     which may call hipMalloc.  Inputs are caller-owned and never written; outputs are caller-owned.
+ *   - A handle is bound to one device and is not thread-safe (one handle per GPU / per process rank).
+ */
+#ifndef MDT_HIP_H
+#define MDT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdt_model mdt_model; /* opaque */
+
+typedef enum {
+    MDT_OK = 0,
+    MDT_ERR_INVALID_ARG = 1,   /* bad pointer / size / alignment / unknown parameter name            */
+    MDT_ERR_UNSUPPORTED = 2,   /* configuration outside what the HIP path implements (stated in msg) */
+    MDT_ERR_NOT_LOADED = 3,    /* a parameter needed by the call was never loaded                    */
+    MDT_ERR_HIP = 4,           /* a HIP runtime call failed (message carries hipGetErrorString)      */
+    MDT_ERR_STATE = 5          /* call sequence error, e.g. mdt_denoise_cached() without mdt_encode()  */
+} mdt_status;
+
+enum { MDT_ARCH_MDTV = 0, MDT_ARCH_MDT = 1 };
+enum { MDT_MODALITY_VIS = 0, MDT_MODALITY_LANG = 1 };
+
+/*
+ * Constructor fields of the score network.  Mirrors the Hydra kwargs of
+ *   mdt.models.networks.mdtv_transformer.MDTVTransformer.__init__  (reference mdtv_transformer.py:38-68,
+ *   conf/model/model/mdtv_transformer.yaml:6-35) and
+ *   mdt.models.networks.mdt_transformer.MDTTransformer.__init__    (reference mdt_transformer.py:39-68),
+ * plus GCDenoiser's sigma_data (reference score_wrappers.py:26-29).  Dropout probabilities are not part
+ * of the ABI: this path is the eval-mode forward.
+ */
+typedef struct {
+    int32_t arch;                 /* MDT_ARCH_MDTV | MDT_ARCH_MDT                                   */
+    int32_t embed_dim;            /* d; multiple of 16, <= 512                                      */
+    int32_t n_heads;              /* head dim d/n_heads in {16,32,48,64}                            */
+    int32_t n_enc_layers;
+    int32_t n_dec_layers;
+    int32_t action_dim;           /* <= 16                                                          */
+    int32_t obs_dim;              /* multiple of 16                                                 */
+    int32_t goal_dim;             /* multiple of 16                                                 */
+    int32_t n_obs_token;          /* MDT-V: state tokens per sample (3); MDT: ignored (static+gripper) */
+    int32_t goal_seq_len;         /* 1                                                              */
+    int32_t action_seq_len;       /* Ta <= 16                                                       */
+    int32_t use_mlp_goal;         /* goal_emb / lang_emb are Linear-GELU-Linear                     */
+    int32_t use_modality_encoder; /* separate lang_emb                                              */
+    int32_t use_abs_pos_emb;      /* MDT only: pos_emb added to the encoder tokens                  */
+    int32_t use_rot_embed;        /* RoPE on q/k (rot dim 32, theta 1e4), position_embeddings.py:83 */
+    int32_t use_ada_conditioning; /* must be 1 (adaLN decoder); 0 -> MDT_ERR_UNSUPPORTED            */
+    int32_t use_noise_encoder;    /* must be 0 (NoiseBlock variant) ; 1 -> MDT_ERR_UNSUPPORTED      */
+    int32_t linear_output;        /* must be 1                                                      */
+    int32_t bias;                 /* reference 'bias' flag: biases on c_proj / MLP / LayerNorms     */
+    float   sigma_data;           /* GCDenoiser.sigma_data                                          */
+} mdt_config;
+
+/* Human-readable message of the last failing call on this thread ("" if none). */
+const char *mdt_last_error(void);
+
+/* Library version string and the offload architecture it was compiled for ("gfx950"). */
+const char *mdt_version(void);
+
+/* hydra.utils.instantiate(cfg.model) -> GCDenoiser.__init__ -> MDTVTransformer.__init__
+ * (reference score_wrappers.py:26-29, mdtv_transformer.py:38-195).  Allocates the packed weight arena on
+ * the current HIP device.  Parameters start unloaded. */
+mdt_status mdt_create(const mdt_config *cfg, mdt_model **out);
+mdt_status mdt_destroy(mdt_model *m);
+
+/* Enumeration of the parameters the forward path READS, in the reference's state_dict order (the
+ * checkpoint / positional-EMA contract, reference mdt/evaluation/utils.py:92-103).  Names are GCDenoiser
+ * state_dict keys ("inner_model.…").  Parameters the reference carries but never reads on this path
+ * (pos_emb in MDT-V, proprio_emb.*, *.rotary_pos_emb.freqs; reference mdtv_transformer.py:105,160-164,
+ * 260-266) are not enumerated; mdt_load_param() accepts and ignores them. */
+int64_t     mdt_param_count(const mdt_model *m);
+const char *mdt_param_name(const mdt_model *m, int64_t index);
+int64_t     mdt_param_numel(const mdt_model *m, int64_t index);
+
+/* load_state_dict / optimizer step: copy one fp32 parameter (reference layout, e.g. Linear weight
+ * (out,in) row-major) from `src` (host OR device pointer) into the library's MFMA-fragment-packed
+ * arena.  Stream-ordered on `stream`; a host `src` must stay valid until the stream has passed. */
+mdt_status mdt_load_param(mdt_model *m, const char *name, const float *src, int64_t numel, void *stream);
+
+/* Pre-size the workspace for batches up to max_batch (avoids hipMalloc later, e.g. before graph capture). */
+mdt_status mdt_reserve(mdt_model *m, int64_t max_batch);
+
+/* inner_model.forward_enc_only(state, action, goal, sigma) with use_ada_conditioning
+ * (reference mdtv_transformer.py:213-222; mdt_transformer.py:211-229 / :257-281): goal/state token
+ * embedding, n_enc_layers Blocks, final LayerNorm.  Also projects the per-decoder-block cross-attention
+ * K/V once and keeps ctx + K/V cached in the handle for mdt_denoise_cached()/samplers.
+ *   tokens : MDT-V state['state_images'] (B, n_obs_token, obs_dim); MDT state['static'] (B,1,obs_dim)
+ *   tokens2: MDT state['gripper'] (B,1,obs_dim); NULL for MDT-V
+ *   goal   : (B, 1, goal_dim)
+ *   honour_modality: 1 = pick lang_emb when modality==LANG (MDT-V always; MDT forward_enc_only),
+ *                    0 = always goal_emb (MDT.forward -> enc_only_forward, mdt_transformer.py:215)
+ *   ctx_out: (B, Te, d) or NULL -- the value the reference caches as inner_model.latent_encoder_emb */
+mdt_status mdt_encode(mdt_model *m, const float *tokens, const float *tokens2, const float *goal,
+                      int32_t modality, int32_t honour_modality, int64_t batch, float *ctx_out, void *stream);
+
+/* GCDenoiser.forward(state, action, goal, sigma) given the cached context of the last mdt_encode()
+ * (reference score_wrappers.py:65-80 -> mdtv_transformer.py:224-236): EDM preconditioning, sigma
+ * embedding, adaLN decoder, action head.   x:(B,Ta,A)  sigma:(B,) device  out:(B,Ta,A).
+ * flags: MDT_RAW_OUTPUT returns the network output F instead of F*c_out + x*c_skip (GCDenoiser.loss);
+ *        MDT_RAW_INPUT feeds x to action_emb without the c_in scaling (inner_model.forward_dec_only). */
+enum { MDT_RAW_OUTPUT = 1, MDT_RAW_INPUT = 2 };
+mdt_status mdt_denoise_cached(mdt_model *m, const float *x, const float *sigma, int64_t batch,
+                              int32_t flags, float *out, void *stream);
+
+/* model(state, action, goal, sigma) exactly as the samplers call it (reference gc_sampling.py:945):
+ * mdt_encode + mdt_denoise_cached in one call ("as written": the encoder is re-run). */
+mdt_status mdt_forward(mdt_model *m, const float *tokens, const float *tokens2, const float *goal,
+                       int32_t modality, const float *x, const float *sigma, int64_t batch,
+                       float *out, float *ctx_out, void *stream);
+
+/* sample_ddim(model, state, action, goal, sigmas) (reference gc_sampling.py:922-951) as ONE enqueue:
+ * encoder + cross K/V once, sigma-embedding/adaLN vectors for all steps once, then n_steps decoder
+ * evaluations with the update x <- (s_{i+1}/s_i) x - expm1(-h_i) den fused into the action-head kernel.
+ *   x_T    : (B, Ta, A) initial noisy actions (already multiplied by sigma_max, mdtv_agent.py:546)
+ *   sigmas : HOST array of n_steps+1 floats (get_sigmas_* output, last entry normally 0)
+ *   out    : (B, Ta, A) sampled actions;  ctx_out: optional (B,Te,d) latent_encoder_emb */
+mdt_status mdt_sample_ddim(mdt_model *m, const float *tokens, const float *tokens2, const float *goal,
+                           int32_t modality, const float *x_T, const float *sigmas_host, int32_t n_steps,
+                           int64_t batch, float *out, float *ctx_out, void *stream);
+
+/* GCDenoiser.loss(state, action, goal, noise, sigma) forward value, eval mode (reference
+ * score_wrappers.py:45-63): noised = a + n*sigma; F = inner(noised*c_in); target = (a - c_skip*noised)/c_out;
+ * loss = mean((F - target)^2) over all B*Ta*A elements.  loss_out: 1 float (device); model_output: (B,Ta,A). */
+mdt_status mdt_loss_fwd(mdt_model *m, const float *tokens, const float *tokens2, const float *goal,
+                        int32_t modality, const float *action, const float *noise, const float *sigma,
+                        int64_t batch, float *loss_out, float *model_output, float *ctx_out, void *stream);
+
+/* Algorithmic FLOPs of one sampler call per action chunk (SURVEY.md 8(d) accounting: 2MNK per Linear,
+ * full score matrices, encoder + cross K/V once, n_steps decoder evaluations). */
+double mdt_flops_per_chunk(const mdt_model *m, int32_t n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDT_HIP_H */

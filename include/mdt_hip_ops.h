@@ -1,0 +1,108 @@
+/*
+ * mdt_hip_ops.h -- kernel-level entry points of libmdt_hip.so.
+ *
+ * These launch ONE hand-written gfx950 kernel each on caller-provided device buffers.  The model-level
+ * ABI (mdt_hip.h) is built from exactly these launches; they are exported so that the parity tests can
+ * pin every kernel against a PyTorch fp32 reference of the same op, and so that bench.py can time the
+ * dominant kernel in isolation.  fp32 everywhere, row-major, device pointers 16-byte aligned.
+ *
+ * Reference ops replaced (all in mdt/models/networks/transformers/transformer_blocks.py unless noted):
+ *   mdt_op_gemm       nn.Linear (+ F.layer_norm :38 / nn.LayerNorm :205 prologue, modulate :262,
+ *                     nn.GELU :171 / nn.Mish / nn.SiLU :251 epilogue, gated residual :296-307)
+ *   mdt_op_attention  F.scaled_dot_product_attention :142 (+ RotaryEmbedding position_embeddings.py:138)
+ *   mdt_op_layernorm  LayerNorm.forward :37-38
+ *   mdt_op_head       decoder.ln + action_pred (mdtv_transformer.py:233-235) + GCDenoiser.forward
+ *                     combine (score_wrappers.py:79-80) + sample_ddim update (gc_sampling.py:948-950)
+ *                     + next step's action_emb (mdtv_transformer.py:226)
+ */
+#ifndef MDT_HIP_OPS_H
+#define MDT_HIP_OPS_H
+
+#include <stdint.h>
+#include "mdt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MDT_ACT_NONE = 0, MDT_ACT_GELU = 1, MDT_ACT_MISH = 2, MDT_ACT_SILU = 3 };
+enum { MDT_HEAD_DENOISED = 0, MDT_HEAD_DDIM = 1, MDT_HEAD_RAW = 2 };
+
+/* Number of floats of the fragment-packed image of an (N, K) Linear weight (N, K multiples of 16). */
+int64_t mdt_op_packed_numel(int64_t N, int64_t K);
+
+/* Pack rows [0, n_rows) of a row-major (n_rows, K) weight into rows [n_off, n_off+n_rows) of a packed
+ * (N_total, K) image: for every 16(n) x 16(k) block, lane l = n%16 + 16*((k%16)/4) holds the 4
+ * consecutive-k values W[n][k0 + 4*(l>>4) .. +3] -- the operand order of v_mfma_f32_16x16x4_f32. */
+mdt_status mdt_op_pack_weight(const float *w, int64_t n_rows, int64_t K, float *packed, int64_t n_off,
+                              int64_t N_total, void *stream);
+
+typedef struct {
+    const float *A;        /* (M, K) activations, row stride lda (multiple of 4)                      */
+    int64_t lda;
+    const float *Wp;       /* packed (N, K) weight                                                    */
+    const float *bias;     /* (N) or NULL                                                             */
+    float *out;            /* output rows, row stride ldo                                             */
+    int64_t ldo;
+    int32_t M, N, K;
+    /* prologue: LayerNorm over K (needs K <= 512) and optional modulate shift + x*scale              */
+    int32_t ln;            /* 0 = plain A, 1 = layer_norm(A) * ln_w (+ ln_b)                          */
+    const float *ln_w, *ln_b;
+    const float *mod;      /* NULL, or modulation table: row (m / rows_per_sample) * mod_stride       */
+    int64_t mod_stride;    /* 0 broadcasts one row to the whole batch                                 */
+    int32_t shift_off, scale_off;
+    int32_t rows_per_sample;
+    /* epilogue                                                                                        */
+    int32_t act;           /* MDT_ACT_*  applied after bias                                           */
+    int32_t residual;      /* 1: out = out + gate * value (gate = 1 when gate_off < 0)                */
+    int32_t gate_off;      /* offset of the gate vector inside the mod row, or -1                     */
+    int32_t gin, gout, goff;   /* output row = (m / gin) * gout + m % gin + goff  (1,1,0 = identity)  */
+    const float *rowvec;   /* NULL or (N) vector added to every row after bias (positional embedding) */
+} mdt_gemm_args;
+
+mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);
+
+typedef struct {
+    const float *q; int64_t ldq;       /* (B*Tq, >= H*hd) query rows                                  */
+    const float *k; const float *v;    /* (B*Tk, ...) key / value rows                                */
+    int64_t ldkv;
+    float *out; int64_t ldo;           /* (B*Tq, H*hd)                                                */
+    int32_t B, H, hd, Tq, Tk;          /* hd in {16,32,48,64}; Tq, Tk <= 16                           */
+    int32_t causal;                    /* 1: key j visible to query i iff j <= i (top-left aligned)   */
+    int32_t rope;                      /* 1: rotate q by its position 0..Tq-1 and k by 0..Tk-1        */
+} mdt_attn_args;
+
+mdt_status mdt_op_attention(const mdt_attn_args *args, void *stream);
+
+mdt_status mdt_op_layernorm(const float *in, const float *w, const float *b, float *out, int64_t M, int32_t D,
+                            void *stream);
+
+typedef struct {
+    const float *y;            /* (M, D) decoder residual stream                                      */
+    const float *ln_w;         /* decoder.ln.weight (D), ln_b optional                                */
+    const float *ln_b;
+    const float *Wp, *bp;      /* action_pred.weight (A, D) row-major UNPACKED, bias (A)              */
+    const float *x;            /* (M, A) current noisy actions                                        */
+    const float *sigma;        /* sigma of sample b at sigma[b * sigma_stride]                        */
+    int64_t sigma_stride;
+    float *out;                /* (M, A)                                                              */
+    int32_t M, D, A, rows_per_sample;
+    int32_t mode;              /* MDT_HEAD_*                                                          */
+    const float *step;         /* DDIM: device {ratio, coef, sigma_next}                              */
+    float sigma_data;
+    /* optional fused embedding of the NEXT step's input: y_next = (out * c_in(sigma_next)) Wa^T + ba */
+    float *y_next;             /* NULL or (M, D) (may alias y)                                        */
+    const float *Wa, *ba;      /* action_emb.weight (D, A) row-major, bias (D)                        */
+} mdt_head_args;
+
+mdt_status mdt_op_head(const mdt_head_args *args, void *stream);
+
+/* y = (x * c_in(sigma)) Wa^T + ba   (c_in omitted when sigma == NULL) */
+mdt_status mdt_op_action_embed(const float *x, const float *sigma, int64_t sigma_stride, float sigma_data,
+                               const float *Wa, const float *ba, float *y, int64_t M, int32_t A, int32_t D,
+                               int32_t rows_per_sample, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,124 @@
+"""ctypes binding of libmdt_hip.so (include/mdt_hip.h, include/mdt_hip_ops.h).
+
+The product path has NO fallback: if the HIP library cannot be loaded (or built with hipcc) every entry
+point raises.  PyTorch-ROCm is only used by callers for device memory and streams; nothing here imports torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class MDTHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libmdt_hip status {status}: {message}")
+        self.status = status
+
+
+class MDTConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "arch", "embed_dim", "n_heads", "n_enc_layers", "n_dec_layers", "action_dim", "obs_dim", "goal_dim",
+        "n_obs_token", "goal_seq_len", "action_seq_len", "use_mlp_goal", "use_modality_encoder", "use_abs_pos_emb",
+        "use_rot_embed", "use_ada_conditioning", "use_noise_encoder", "linear_output", "bias")] + [
+        ("sigma_data", C.c_float)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64), ("Wp", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("ldo", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ln", C.c_int32),
+        ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("mod", C.c_void_p), ("mod_stride", C.c_int64),
+        ("shift_off", C.c_int32), ("scale_off", C.c_int32), ("rows_per_sample", C.c_int32), ("act", C.c_int32),
+        ("residual", C.c_int32), ("gate_off", C.c_int32), ("gin", C.c_int32), ("gout", C.c_int32),
+        ("goff", C.c_int32), ("rowvec", C.c_void_p)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", C.c_int64), ("k", C.c_void_p), ("v", C.c_void_p), ("ldkv", C.c_int64),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("hd", C.c_int32),
+        ("Tq", C.c_int32), ("Tk", C.c_int32), ("causal", C.c_int32), ("rope", C.c_int32)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [
+        ("y", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("Wp", C.c_void_p), ("bp", C.c_void_p),
+        ("x", C.c_void_p), ("sigma", C.c_void_p), ("sigma_stride", C.c_int64), ("out", C.c_void_p),
+        ("M", C.c_int32), ("D", C.c_int32), ("A", C.c_int32), ("rows_per_sample", C.c_int32), ("mode", C.c_int32),
+        ("step", C.c_void_p), ("sigma_data", C.c_float), ("y_next", C.c_void_p), ("Wa", C.c_void_p),
+        ("ba", C.c_void_p)]
+
+
+ARCH = {"mdtv": 0, "mdt": 1}
+MODALITY = {"vis": 0, "lang": 1}
+ACT = {"none": 0, "gelu": 1, "mish": 2, "silu": 3}
+HEAD = {"denoised": 0, "ddim": 1, "raw": 2}
+RAW_OUTPUT, RAW_INPUT = 1, 2
+
+# every symbol include/*.h declares: (name, restype, argtypes)
+_VP, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = [
+    ("mdt_last_error", C.c_char_p, []),
+    ("mdt_version", C.c_char_p, []),
+    ("mdt_create", _I32, [C.POINTER(MDTConfig), C.POINTER(_VP)]),
+    ("mdt_destroy", _I32, [_VP]),
+    ("mdt_param_count", _I64, [_VP]),
+    ("mdt_param_name", C.c_char_p, [_VP, _I64]),
+    ("mdt_param_numel", _I64, [_VP, _I64]),
+    ("mdt_load_param", _I32, [_VP, C.c_char_p, _VP, _I64, _VP]),
+    ("mdt_reserve", _I32, [_VP, _I64]),
+    ("mdt_encode", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _I64, _VP, _VP]),
+    ("mdt_denoise_cached", _I32, [_VP, _VP, _VP, _I64, _I32, _VP, _VP]),
+    ("mdt_forward", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _I64, _VP, _VP, _VP]),
+    ("mdt_sample_ddim", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, C.POINTER(C.c_float), _I32, _I64, _VP, _VP, _VP]),
+    ("mdt_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
+    ("mdt_flops_per_chunk", C.c_double, [_VP, _I32]),
+    ("mdt_op_packed_numel", _I64, [_I64, _I64]),
+    ("mdt_op_pack_weight", _I32, [_VP, _I64, _I64, _VP, _I64, _I64, _VP]),
+    ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
+    ("mdt_op_attention", _I32, [C.POINTER(AttnArgs), _VP]),
+    ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
+    ("mdt_op_head", _I32, [C.POINTER(HeadArgs), _VP]),
+    ("mdt_op_action_embed", _I32, [_VP, _VP, _I64, _F, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _VP]),
+]
+
+_lock = threading.Lock()
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load() -> C.CDLL:
+    """Load (building with hipcc if the in-tree .so is missing or stale).  Raises if neither is possible."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB
+        if not os.path.exists(path) or (_build.needs_build() and _build.shutil.which("hipcc")):
+            try:
+                path = _build.build_library()
+            except Exception as e:  # no hipcc and no prebuilt library: there is nothing to run
+                if not os.path.exists(path):
+                    raise RuntimeError(
+                        "libmdt_hip.so is missing and could not be built; the MDT hot path has no CPU/eager "
+                        f"fallback ({e})") from e
+        lib = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise MDTHipError(status, load().mdt_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,631 @@
+// mdt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the MDT action-denoising hot path.
+//
+// Design:
+//   * every dense contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32 MFMA; bf16/fp16 operands fail
+//     the 1e-3 parity gate) in the TRANSPOSED form  D[n][m] = sum_k W[n][k] * X[m][k]:
+//     the weight fragment is the MFMA "A" operand and the activation fragment the "B" operand, so that a
+//     lane ends up with 4 CONSECUTIVE output columns of one row -> 16-byte epilogue loads/stores.
+//   * weights are pre-packed once (k_pack_weight) into fragment-major order: one 16(n) x 16(k) block is
+//     1 KiB, lane l holds W[n0 + l%16][k0 + 4*(l/16) .. +3].  A wave streams its weight fragments with
+//     one fully coalesced global_load_dwordx4 per block straight into VGPRs (each weight element is used
+//     by exactly one wave of a workgroup, so an LDS round trip would be pure overhead) and reuses them
+//     across the workgroup's row tiles from registers.
+//   * the MFMA k-index is a free permutation as long as both operands agree: lane group h = l/16 feeds
+//     k = 4h + j to the j-th of 4 back-to-back MFMAs, so both operands are fetched as float4.
+//   * activations (the small operand: B*10 rows) are staged per workgroup in LDS (row stride K+4 floats ->
+//     ds_read_b128 fragments, at most a 2-way bank conflict on one lane group), with LayerNorm + adaLN
+//     modulation fused into the staging pass and bias / GELU / Mish / SiLU / gate * residual fused into
+//     the epilogue.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdt_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float act_mish(float x) {
+    float sp = x > 20.0f ? x : log1pf(expf(x));  // torch softplus threshold 20
+    return x * tanhf(sp);
+}
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ f32x4 apply_act(f32x4 v, int act) {
+    if (act == MDT_ACT_GELU) {
+        v.x = act_gelu(v.x); v.y = act_gelu(v.y); v.z = act_gelu(v.z); v.w = act_gelu(v.w);
+    } else if (act == MDT_ACT_MISH) {
+        v.x = act_mish(v.x); v.y = act_mish(v.y); v.z = act_mish(v.z); v.w = act_mish(v.w);
+    } else if (act == MDT_ACT_SILU) {
+        v.x = act_silu(v.x); v.y = act_silu(v.y); v.z = act_silu(v.z); v.w = act_silu(v.w);
+    }
+    return v;
+}
+
+// XCD-aware block id: the dispatcher places block b on XCD b % 8 (speed-only assumption); give every XCD a
+// contiguous range of logical tiles so the row tiles it touches stay in its private L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_weight(const float* __restrict__ w, int n_rows, int K, float* __restrict__ packed,
+                              int n_off, int K16) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_rows * K) return;
+    const int n = (int)(idx / K), k = (int)(idx % K);
+    const int nn = n + n_off;
+    const int nt = nn >> 4, ni = nn & 15, kc = k >> 4, h = (k & 15) >> 2, j = k & 3;
+    packed[(((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4 + j] = w[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused GEMM:  out = epilogue( prologue(A) @ W^T )
+//   workgroup = 256 threads (4 waves); tile = (MTILES*16 rows) x (4 waves * NTW * 16 columns); full K.
+//   wave w owns NTW column tiles and ALL row tiles of the workgroup tile.
+// ------------------------------------------------------------------------------------------------
+template <int MTILES, int NTW>
+__global__ __launch_bounds__(256) void k_gemm(mdt_gemm_args a, int kchunk, int grid_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int MT = MTILES * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / grid_n, bx = logical % grid_n;
+    const int m0 = by * MT;
+    const int N16 = a.N >> 4, K16 = a.K >> 4;
+    const int nt0 = (bx * 4 + wave) * NTW;
+    const int stride = kchunk + 4;  // floats; 16-byte aligned rows, breaks the power-of-two bank stride
+
+    f32x4 acc[MTILES][NTW];
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < a.K; k0 += kchunk) {
+        const int klen = min(kchunk, a.K - k0);
+        if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
+        if (a.ln) {
+            // ---- LayerNorm (+ adaLN modulate) prologue: one wave per row, whole row in registers ----
+            constexpr int RPW = MT / 4;  // rows per wave
+            const int n4 = klen >> 2;    // float4 per row (<= 128)
+            f32x4 v[RPW][2];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int m = m0 + wave + 4 * r;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int c4 = lane + 64 * p;
+                    v[r][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (m < a.M && c4 < n4) v[r][p] = *(const f32x4*)(a.A + (int64_t)m * a.lda + 4 * c4);
+                }
+            }
+            const float inv_k = 1.0f / (float)klen;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave + 4 * r, m = m0 + row;
+                float s = 0.f;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) s += (v[r][p].x + v[r][p].y) + (v[r][p].z + v[r][p].w);
+                const float mean = wave_sum(s) * inv_k;
+                float sq = 0.f;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int c4 = lane + 64 * p;
+                    if (c4 < n4) {
+                        v[r][p] -= mean;
+                        sq += (v[r][p].x * v[r][p].x + v[r][p].y * v[r][p].y) +
+                              (v[r][p].z * v[r][p].z + v[r][p].w * v[r][p].w);
+                    }
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_k + 1e-5f);
+                const float* modrow = nullptr;
+                if (a.mod != nullptr && a.shift_off >= 0 && m < a.M)
+                    modrow = a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int c4 = lane + 64 * p;
+                    if (c4 < n4) {
+                        f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (m < a.M) {
+                            y = v[r][p] * rstd * *(const f32x4*)(a.ln_w + 4 * c4);
+                            if (a.ln_b != nullptr) y += *(const f32x4*)(a.ln_b + 4 * c4);
+                            if (modrow != nullptr)
+                                y = *(const f32x4*)(modrow + a.shift_off + 4 * c4) +
+                                    y * *(const f32x4*)(modrow + a.scale_off + 4 * c4);
+                        }
+                        *(f32x4*)(lds + row * stride + 4 * c4) = y;
+                    }
+                }
+            }
+        } else {
+            // ---- plain staging of the (MT x klen) activation chunk ----
+            const int n4 = klen >> 2;
+            for (int idx = tid; idx < MT * n4; idx += 256) {
+                const int row = idx / n4, c4 = idx - row * n4;
+                const int m = m0 + row;
+                f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (m < a.M) y = *(const f32x4*)(a.A + (int64_t)m * a.lda + k0 + 4 * c4);
+                *(f32x4*)(lds + row * stride + 4 * c4) = y;
+            }
+        }
+        __syncthreads();
+
+        if (nt0 < N16) {
+            const int nk = klen >> 4;
+            const float* wp[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int nt = min(nt0 + j, N16 - 1);  // clamp: a partial last wave re-reads a valid tile
+                wp[j] = a.Wp + ((int64_t)nt * K16 + (k0 >> 4)) * 256 + lane * 4;
+            }
+            const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
+
+            // 3-deep register ring of weight fragments: two 1-KiB loads per column tile always in flight
+            f32x4 b0[NTW], b1[NTW], b2[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                b0[j] = *(const f32x4*)(wp[j]);
+                b1[j] = nk > 1 ? *(const f32x4*)(wp[j] + 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#define MDT_KSTEP(BU, BP, KC)                                                                          \
+    {                                                                                                  \
+        if ((KC) + 2 < nk) {                                                                           \
+            _Pragma("unroll") for (int j = 0; j < NTW; ++j) BP[j] =                                    \
+                *(const f32x4*)(wp[j] + ((KC) + 2) * 256);                                             \
+        }                                                                                              \
+        f32x4 av[MTILES];                                                                              \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                     \
+            *(const f32x4*)(ap + i * 16 * stride + (KC) * 16);                                         \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                       \
+                _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                            \
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(BU[j][e], av[i][e], acc[i][j], 0, 0, 0);      \
+            }                                                                                          \
+        }                                                                                              \
+    }
+            int kc = 0;
+            for (; kc + 3 <= nk; kc += 3) {
+                MDT_KSTEP(b0, b2, kc)
+                MDT_KSTEP(b1, b0, kc + 1)
+                MDT_KSTEP(b2, b1, kc + 2)
+            }
+            if (kc < nk) {
+                MDT_KSTEP(b0, b2, kc)
+                if (kc + 1 < nk) MDT_KSTEP(b1, b0, kc + 1)
+            }
+#undef MDT_KSTEP
+        }
+    }
+
+    // ---- epilogue: lane holds out[m0 + i*16 + lane%16][n .. n+3], n = tile*16 + 4*(lane/16) ----
+    if (nt0 >= N16) return;
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i) {
+        const int m = m0 + i * 16 + (lane & 15);
+        if (m >= a.M) continue;
+        const int64_t orow = (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
+        const float* gate = nullptr;
+        if (a.residual && a.gate_off >= 0)
+            gate = a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride + a.gate_off;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            if (nt0 + j >= N16) continue;
+            const int n = (nt0 + j) * 16 + 4 * (lane >> 4);
+            f32x4 v = acc[i][j];
+            if (a.bias != nullptr) v += *(const f32x4*)(a.bias + n);
+            if (a.rowvec != nullptr) v += *(const f32x4*)(a.rowvec + n);
+            v = apply_act(v, a.act);
+            float* o = a.out + orow * a.ldo + n;
+            if (a.residual) {
+                if (gate != nullptr) v *= *(const f32x4*)(gate + n);
+                v += *(const f32x4*)o;
+            }
+            *(f32x4*)o = v;
+        }
+    }
+}
+
+template <int MTILES, int NTW>
+static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
+    const int MT = MTILES * 16, NT = 4 * NTW * 16;
+    const int gn = (a.N + NT - 1) / NT, gm = (a.M + MT - 1) / MT;
+    const size_t lds = (size_t)MT * (kchunk + 4) * sizeof(float);
+    static size_t lds_attr = 0;  // per instantiation
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_gemm<MTILES, NTW>), dim3(gn * gm), dim3(256), lds, s, a, kchunk, gn);
+    return hipGetLastError();
+}
+
+int mdt_gemm_kchunk(int K, int ln) {
+    if (ln || K <= 512) return K;
+    // largest multiple of 16 that divides K and is <= 512 (keeps the activation tile <= 66 KiB of LDS)
+    for (int c = 512; c >= 16; c -= 16)
+        if (K % c == 0) return c;
+    return 16;
+}
+
+hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
+    const int kchunk = mdt_gemm_kchunk(a.K, a.ln);
+    // tile selection: 32 rows x 128 columns (two column tiles per wave) when that still yields >= 2 workgroups
+    // per CU; otherwise 32 x 64 (N = d projections at B = 256 would give only 240 of the larger tiles).
+    const int gm = (a.M + 31) / 32;
+    const int big = ((a.N + 127) / 128) * gm;
+    if (big >= 512) return launch_gemm_t<2, 2>(a, kchunk, s);
+    return launch_gemm_t<2, 1>(a, kchunk, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small attention: one thread per (sample, head, query row); Tq, Tk <= 16; scores live in registers.
+// 10x10 / 10x4 / 4x4 score matrices: 0.1 % of the FLOPs, so this stays on the VALU.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __restrict__ rope_cos,
+                                              const float* __restrict__ rope_sin, float scale) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int total = a.B * a.H * a.Tq;
+    if (gid >= total) return;
+    const int t = gid % a.Tq;
+    const int h = (gid / a.Tq) % a.H;
+    const int b = gid / (a.Tq * a.H);
+    constexpr int ROT = 32;  // rotary dims (position_embeddings.py / transformer_blocks.py:108)
+
+    float q[HD];
+    const float* qp = a.q + (int64_t)(b * a.Tq + t) * a.ldq + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const f32x4 x = *(const f32x4*)(qp + d);
+        q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+    }
+    if (a.rope) {
+        if constexpr (HD >= ROT) {
+#pragma unroll
+            for (int i = 0; i < ROT / 2; ++i) {
+                const float c = rope_cos[t * 16 + i], s = rope_sin[t * 16 + i];
+                const float x1 = q[2 * i], x2 = q[2 * i + 1];
+                q[2 * i] = x1 * c - x2 * s;
+                q[2 * i + 1] = x2 * c + x1 * s;
+            }
+        }
+    }
+    const int nk = a.causal ? min(a.Tk, t + 1) : a.Tk;
+    float sc[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        sc[j] = -INFINITY;
+        if (j < nk) {
+            const float* kp = a.k + (int64_t)(b * a.Tk + j) * a.ldkv + h * HD;
+            float kr[HD];
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const f32x4 x = *(const f32x4*)(kp + d);
+                kr[d] = x.x; kr[d + 1] = x.y; kr[d + 2] = x.z; kr[d + 3] = x.w;
+            }
+            if (a.rope) {
+                if constexpr (HD >= ROT) {
+#pragma unroll
+                    for (int i = 0; i < ROT / 2; ++i) {
+                        const float c = rope_cos[j * 16 + i], s = rope_sin[j * 16 + i];
+                        const float x1 = kr[2 * i], x2 = kr[2 * i + 1];
+                        kr[2 * i] = x1 * c - x2 * s;
+                        kr[2 * i + 1] = x2 * c + x1 * s;
+                    }
+                }
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dot = fmaf(q[d], kr[d], dot);
+            sc[j] = dot * scale;
+            mx = fmaxf(mx, sc[j]);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        sc[j] = j < nk ? expf(sc[j] - mx) : 0.f;
+        sum += sc[j];
+    }
+    const float inv = 1.0f / sum;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < nk) {
+            const float p = sc[j] * inv;
+            const float* vp = a.v + (int64_t)(b * a.Tk + j) * a.ldkv + h * HD;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const f32x4 x = *(const f32x4*)(vp + d);
+                o[d] = fmaf(p, x.x, o[d]); o[d + 1] = fmaf(p, x.y, o[d + 1]);
+                o[d + 2] = fmaf(p, x.z, o[d + 2]); o[d + 3] = fmaf(p, x.w, o[d + 3]);
+            }
+        }
+    }
+    float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
+}
+
+hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin,
+                                hipStream_t s) {
+    const int total = a.B * a.H * a.Tq;
+    const int grid = (total + 255) / 256;
+    const float scale = 1.0f / sqrtf((float)a.hd);
+    switch (a.hd) {
+        case 16: hipLaunchKernelGGL((k_attn<16>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
+        case 32: hipLaunchKernelGGL((k_attn<32>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
+        case 48: hipLaunchKernelGGL((k_attn<48>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
+        case 64: hipLaunchKernelGGL((k_attn<64>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// row LayerNorm (encoder final LN -> ctx): one wave per row, D <= 512
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ln_row(const float* __restrict__ in, int n4, int lane, f32x4 (&v)[2], float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c4 = lane + 64 * p;
+        v[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c4 < n4) v[p] = *(const f32x4*)(in + 4 * c4);
+        s += (v[p].x + v[p].y) + (v[p].z + v[p].w);
+    }
+    const float inv_d = 1.0f / (float)(n4 * 4);
+    const float mean = wave_sum(s) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c4 = lane + 64 * p;
+        if (c4 < n4) {
+            v[p] -= mean;
+            sq += (v[p].x * v[p].x + v[p].y * v[p].y) + (v[p].z * v[p].z + v[p].w * v[p].w);
+        }
+    }
+    rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + 1e-5f);
+}
+
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ out, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int n4 = D >> 2;
+    f32x4 v[2];
+    float rstd;
+    ln_row(in + (int64_t)m * D, n4, lane, v, rstd);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c4 = lane + 64 * p;
+        if (c4 < n4) {
+            f32x4 y = v[p] * rstd * *(const f32x4*)(w + 4 * c4);
+            if (b != nullptr) y += *(const f32x4*)(b + 4 * c4);
+            *(f32x4*)(out + (int64_t)m * D + 4 * c4) = y;
+        }
+    }
+}
+
+hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, in, w, b, out, M, D);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sigma embedding: e[r] = [sin(s f_j) | cos(s f_j)], s = ln(sigma_r)/4     (mdtv_transformer.py:13-25,239)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sigma_emb(const float* __restrict__ sigma, int64_t sstride, const float* __restrict__ freqs,
+                            float* __restrict__ out, int R, int D) {
+    const int half = D >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * half) return;
+    const int r = idx / half, j = idx % half;
+    const float s = logf(sigma[(int64_t)r * sstride]) / 4.0f;
+    const float ang = s * freqs[j];
+    out[(int64_t)r * D + j] = sinf(ang);
+    out[(int64_t)r * D + half + j] = cosf(ang);
+}
+
+hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,
+                                hipStream_t s) {
+    const int n = R * (D / 2);
+    hipLaunchKernelGGL(k_sigma_emb, dim3((n + 255) / 256), dim3(256), 0, s, sigma, sstride, freqs, out, R, D);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// action embedding: y[m][:] = (x[m][:] * c_in(sigma_b)) @ Wa^T + ba          (K = action_dim = 7: VALU)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edm_c_in(float sigma, float sd) { return 1.0f / sqrtf(sigma * sigma + sd * sd); }
+
+__global__ __launch_bounds__(256) void k_action_embed(const float* __restrict__ x, const float* __restrict__ sigma,
+                                                      int64_t sstride, float sd, const float* __restrict__ Wa,
+                                                      const float* __restrict__ ba, float* __restrict__ y, int M,
+                                                      int A, int D, int rps) {
+    const int n4 = D >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+    const float cin = sigma != nullptr ? edm_c_in(sigma[(int64_t)(m / rps) * sstride], sd) : 1.0f;
+    f32x4 acc = *(const f32x4*)(ba + n);
+    for (int c = 0; c < A; ++c) {
+        const float xv = x[(int64_t)m * A + c] * cin;
+        acc.x = fmaf(xv, Wa[(n + 0) * A + c], acc.x);
+        acc.y = fmaf(xv, Wa[(n + 1) * A + c], acc.y);
+        acc.z = fmaf(xv, Wa[(n + 2) * A + c], acc.z);
+        acc.w = fmaf(xv, Wa[(n + 3) * A + c], acc.w);
+    }
+    *(f32x4*)(y + (int64_t)m * D + n) = acc;
+}
+
+hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t sstride, float sd, const float* Wa,
+                                   const float* ba, float* y, int M, int A, int D, int rps, hipStream_t s) {
+    const int64_t n = (int64_t)M * (D / 4);
+    hipLaunchKernelGGL(k_action_embed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, sigma, sstride, sd, Wa,
+                       ba, y, M, A, D, rps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// action head: decoder LN -> action_pred -> EDM combine -> (DDIM update) -> (next step's embedding)
+// one wave per action-token row; A <= 16
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head(mdt_head_args a) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int n4 = a.D >> 2;
+    f32x4 v[2];
+    float rstd;
+    ln_row(a.y + (int64_t)m * a.D, n4, lane, v, rstd);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c4 = lane + 64 * p;
+        if (c4 < n4) {
+            v[p] = v[p] * rstd * *(const f32x4*)(a.ln_w + 4 * c4);
+            if (a.ln_b != nullptr) v[p] += *(const f32x4*)(a.ln_b + 4 * c4);
+        }
+    }
+    const float sigma = a.sigma[(int64_t)(m / a.rows_per_sample) * a.sigma_stride];
+    const float sd = a.sigma_data;
+    const float den2 = sigma * sigma + sd * sd;
+    const float c_skip = sd * sd / den2;
+    const float c_out = sigma * sd / sqrtf(den2);
+    float ratio = 0.f, coef = 0.f, cin_next = 1.f;
+    if (a.mode == MDT_HEAD_DDIM) {
+        ratio = a.step[0];
+        coef = a.step[1];
+        cin_next = edm_c_in(a.step[2], sd);
+    }
+    float res[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        res[c] = 0.f;
+        if (c < a.A) {
+            float part = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int c4 = lane + 64 * p;
+                if (c4 < n4) {
+                    const f32x4 w = *(const f32x4*)(a.Wp + (int64_t)c * a.D + 4 * c4);
+                    part += (v[p].x * w.x + v[p].y * w.y) + (v[p].z * w.z + v[p].w * w.w);
+                }
+            }
+            const float F = wave_sum(part) + a.bp[c];
+            float r = F;
+            if (a.mode != MDT_HEAD_RAW) {
+                const float xin = a.x[(int64_t)m * a.A + c];
+                const float den = F * c_out + xin * c_skip;
+                r = a.mode == MDT_HEAD_DDIM ? ratio * xin + coef * den : den;
+            }
+            res[c] = r;
+        }
+    }
+    // all lanes hold all A results (xor-butterfly sums); lanes 0..A-1 store one each
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (c < a.A && lane == c) a.out[(int64_t)m * a.A + c] = res[c];
+    if (a.y_next != nullptr) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int c4 = lane + 64 * p;
+            if (c4 < n4) {
+                const int n = 4 * c4;
+                f32x4 acc = *(const f32x4*)(a.ba + n);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c < a.A) {
+                        const float xv = res[c] * cin_next;
+                        acc.x = fmaf(xv, a.Wa[(n + 0) * a.A + c], acc.x);
+                        acc.y = fmaf(xv, a.Wa[(n + 1) * a.A + c], acc.y);
+                        acc.z = fmaf(xv, a.Wa[(n + 2) * a.A + c], acc.z);
+                        acc.w = fmaf(xv, a.Wa[(n + 3) * a.A + c], acc.w);
+                    }
+                }
+                *(f32x4*)(a.y_next + (int64_t)m * a.D + n) = acc;
+            }
+        }
+    }
+}
+
+hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_head, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GCDenoiser.loss pieces (score_wrappers.py:59-63)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_noise_input(const float* __restrict__ act, const float* __restrict__ noise,
+                              const float* __restrict__ sigma, float* __restrict__ noised, int64_t n, int per_sample) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    noised[i] = act[i] + noise[i] * sigma[i / per_sample];
+}
+
+// single-workgroup deterministic reduction: loss = mean_i (F_i - (a_i - c_skip*noised_i)/c_out)^2
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ F, const float* __restrict__ act,
+                                                      const float* __restrict__ noised,
+                                                      const float* __restrict__ sigma, float sd, int64_t n,
+                                                      int per_sample, float* __restrict__ loss) {
+    __shared__ float part[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float sg = sigma[i / per_sample];
+        const float den2 = sg * sg + sd * sd;
+        const float c_skip = sd * sd / den2, c_out = sg * sd / sqrtf(den2);
+        const float tgt = (act[i] - c_skip * noised[i]) / c_out;
+        const float d = F[i] - tgt;
+        s = fmaf(d, d, s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        *loss = t / (float)n;
+    }
+}
+
+hipError_t mdt_launch_noise_input(const float* act, const float* noise, const float* sigma, float* noised, int64_t n,
+                                  int per_sample, hipStream_t s) {
+    hipLaunchKernelGGL(k_noise_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act, noise, sigma, noised, n,
+                       per_sample);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float* noised, const float* sigma, float sd,
+                                  int64_t n, int per_sample, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, F, act, noised, sigma, sd, n, per_sample, loss);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* packed, int n_off, hipStream_t s) {
+    const int64_t n = (int64_t)n_rows * K;
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n_rows, K, packed, n_off,
+                       K / 16);
+    return hipGetLastError();
+}

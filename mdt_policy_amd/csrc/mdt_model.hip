@@ -1,0 +1,773 @@
+// mdt_model.hip -- host side of libmdt_hip.so: model handle, fragment-packed weight arena, workspace, and the
+// launch sequences behind the C ABI of include/mdt_hip.h (encoder, adaLN decoder step, fused DDIM loop, loss).
+//
+// Reference call stack replaced:
+//   sample_ddim (gc_sampling.py:922) -> GCDenoiser.forward (score_wrappers.py:65) ->
+//   MDTVTransformer.forward (mdtv_transformer.py:208) = forward_enc_only (:213) + forward_dec_only (:224)
+// Structural facts exploited: with adaLN conditioning the encoder output and the
+// cross-attention K/V do not depend on sigma or the noisy actions -> computed once per sample call; in a
+// sampler sigma is one scalar per step -> sigma-embedding + all adaLN modulation vectors for all steps are
+// one batched M = n_steps GEMM chain before the loop.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mdt_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static mdt_status fail(mdt_status st, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(MDT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));  \
+    } while (0)
+
+#define MDT_TRY(expr)                      \
+    do {                                   \
+        mdt_status _s = (expr);            \
+        if (_s != MDT_OK) return _s;       \
+    } while (0)
+
+extern "C" const char* mdt_last_error(void) { return g_err.c_str(); }
+extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32)"; }
+
+// ------------------------------------------------------------------------------------------------
+// model description
+// ------------------------------------------------------------------------------------------------
+struct Lin {
+    float* wp = nullptr;    // fragment-packed (N, K)
+    float* bias = nullptr;  // (N) or nullptr
+    int N = 0, K = 0;
+};
+
+enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1 };
+
+struct Slot {
+    std::string name;
+    int64_t numel = 0;
+    int kind = SLOT_RAW;
+    float* dst = nullptr;  // packed image base (SLOT_PACK) or raw destination (SLOT_RAW)
+    int rows = 0, K = 0, n_off = 0;
+    bool loaded = false;
+};
+
+struct EncBlock {
+    float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+    Lin qkv, proj, fc, proj2;
+};
+
+struct DecBlock : EncBlock {
+    float *ln3_w = nullptr, *ln3_b = nullptr;
+    Lin xq, xproj;
+};
+
+struct Bump {
+    float* base = nullptr;
+    size_t off = 0;
+    float* take(size_t n) {
+        float* p = base ? base + off : nullptr;
+        off += (n + 63) & ~(size_t)63;  // 256-byte granules keep every buffer 16-byte aligned
+        return p;
+    }
+};
+
+struct mdt_model {
+    mdt_config cfg;
+    int D, H, hd, Te, Ta, A, Le, Ld, G, O, n_tok;
+    // parameters
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    std::vector<Slot> slots;
+    Lin tok, incam, goal0, goal2, lang0, lang2, sig1, sig3, kv_all, mod_all;
+    std::vector<EncBlock> enc;
+    std::vector<DecBlock> dec;
+    float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
+    float *Wa = nullptr, *ba = nullptr, *Wp = nullptr, *bp = nullptr, *pos_emb = nullptr;
+    float *freqs = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;  // constant tables
+    float* staging = nullptr;  // host->device parameter staging
+    size_t staging_floats = 0;
+    // workspace
+    float* ws = nullptr;
+    int64_t cap = 0;
+    float *h_enc, *qkv, *att, *hid, *ctx, *kvx, *y, *qx, *sig_e, *sig_t, *sig_c, *mod, *xbuf, *noised, *Fbuf, *steps;
+    int64_t cached_batch = 0;  // batch of the context currently cached by mdt_encode (0 = none)
+    std::vector<float> steps_host;
+};
+
+static const int MAX_STEPS = 64;
+
+// Parameter map: called twice (count pass with base == nullptr, then with the allocated arena).
+static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
+    const mdt_config& c = m->cfg;
+    const int D = m->D, G = m->G, O = m->O, A = m->A;
+    auto add_slot = [&](const std::string& name, int64_t numel, int kind, float* dst, int rows, int K, int n_off) {
+        if (!fill_slots) return;
+        Slot s;
+        s.name = name; s.numel = numel; s.kind = kind; s.dst = dst; s.rows = rows; s.K = K; s.n_off = n_off;
+        m->slots.push_back(s);
+    };
+    // a Linear made of `parts` reference Linears stacked along N (e.g. query|key|value)
+    auto lin_begin = [&](Lin& l, int N, int K, bool bias) {
+        l.N = N; l.K = K;
+        l.wp = b.take((size_t)N * K);
+        l.bias = bias ? b.take(N) : nullptr;
+    };
+    auto lin_part = [&](Lin& l, const std::string& prefix, int rows, int n_off, bool bias) {
+        add_slot(prefix + ".weight", (int64_t)rows * l.K, SLOT_PACK, l.wp, rows, l.K, n_off);
+        if (bias) add_slot(prefix + ".bias", rows, SLOT_RAW, l.bias ? l.bias + n_off : nullptr, 0, 0, 0);
+    };
+    auto raw = [&](float*& p, const std::string& name, int64_t n) {
+        p = b.take(n);
+        add_slot(name, n, SLOT_RAW, p, 0, 0, 0);
+    };
+    const std::string P = "inner_model.";
+    const bool xb = c.bias != 0;  // reference `bias` flag: c_proj / MLP / custom LayerNorm biases
+
+    if (c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb)
+        raw(m->pos_emb, P + "pos_emb", (int64_t)(c.goal_seq_len + c.action_seq_len) * D);
+    lin_begin(m->tok, D, O, true);
+    lin_part(m->tok, P + "tok_emb", D, 0, true);
+    if (c.arch == MDT_ARCH_MDT) {
+        lin_begin(m->incam, D, O, true);
+        lin_part(m->incam, P + "incam_embed", D, 0, true);
+    }
+    auto goal_mlp = [&](Lin& l0, Lin& l2, const std::string& nm) {
+        if (c.use_mlp_goal) {
+            lin_begin(l0, 2 * D, G, true);
+            lin_part(l0, P + nm + ".0", 2 * D, 0, true);
+            lin_begin(l2, D, 2 * D, true);
+            lin_part(l2, P + nm + ".2", D, 0, true);
+        } else {
+            lin_begin(l2, D, G, true);
+            lin_part(l2, P + nm, D, 0, true);
+        }
+    };
+    goal_mlp(m->goal0, m->goal2, "goal_emb");
+    if (c.use_modality_encoder) goal_mlp(m->lang0, m->lang2, "lang_emb");
+
+    auto attn_qkv = [&](Lin& qkv, const std::string& pre) {
+        // packed row order is q | k | v; the reference registers key, query, value (transformer_blocks.py:85-87)
+        lin_begin(qkv, 3 * D, D, true);
+        lin_part(qkv, pre + ".key", D, D, true);
+        lin_part(qkv, pre + ".query", D, 0, true);
+        lin_part(qkv, pre + ".value", D, 2 * D, true);
+    };
+    auto block_common_a = [&](EncBlock& e, const std::string& pre) {
+        raw(e.ln1_w, pre + ".ln_1.weight", D);
+        if (xb) raw(e.ln1_b, pre + ".ln_1.bias", D);
+        attn_qkv(e.qkv, pre + ".attn");
+        lin_begin(e.proj, D, D, xb);
+        lin_part(e.proj, pre + ".attn.c_proj", D, 0, xb);
+    };
+    auto block_common_b = [&](EncBlock& e, const std::string& pre) {
+        raw(e.ln2_w, pre + ".ln_2.weight", D);
+        if (xb) raw(e.ln2_b, pre + ".ln_2.bias", D);
+        lin_begin(e.fc, 4 * D, D, xb);
+        lin_part(e.fc, pre + ".mlp.c_fc", 4 * D, 0, xb);
+        lin_begin(e.proj2, D, 4 * D, xb);
+        lin_part(e.proj2, pre + ".mlp.c_proj", D, 0, xb);
+    };
+    if (!fill_slots) { m->enc.assign(m->Le, EncBlock()); m->dec.assign(m->Ld, DecBlock()); }
+    for (int l = 0; l < m->Le; ++l) {
+        const std::string pre = P + "encoder.blocks." + std::to_string(l);
+        block_common_a(m->enc[l], pre);
+        block_common_b(m->enc[l], pre);
+    }
+    raw(m->enc_ln_w, P + "encoder.ln.weight", D);
+    if (xb) raw(m->enc_ln_b, P + "encoder.ln.bias", D);
+
+    // stacked across decoder blocks: cross-attention K|V projections of the context, adaLN modulation
+    lin_begin(m->kv_all, m->Ld * 2 * D, D, true);
+    lin_begin(m->mod_all, m->Ld * 6 * D, D, true);
+    for (int l = 0; l < m->Ld; ++l) {
+        const std::string pre = P + "decoder.blocks." + std::to_string(l);
+        DecBlock& d = m->dec[l];
+        block_common_a(d, pre);
+        lin_part(m->kv_all, pre + ".cross_att.key", D, l * 2 * D, true);
+        lin_begin(d.xq, D, D, true);
+        lin_part(d.xq, pre + ".cross_att.query", D, 0, true);
+        lin_part(m->kv_all, pre + ".cross_att.value", D, l * 2 * D + D, true);
+        lin_begin(d.xproj, D, D, xb);
+        lin_part(d.xproj, pre + ".cross_att.c_proj", D, 0, xb);
+        raw(d.ln3_w, pre + ".ln3.weight", D);
+        raw(d.ln3_b, pre + ".ln3.bias", D);
+        block_common_b(d, pre);
+        lin_part(m->mod_all, pre + ".adaLN_zero.modulation.1", 6 * D, l * 6 * D, true);
+    }
+    raw(m->dec_ln_w, P + "decoder.ln.weight", D);
+    if (xb) raw(m->dec_ln_b, P + "decoder.ln.bias", D);
+    lin_begin(m->sig1, 2 * D, D, true);
+    lin_part(m->sig1, P + "sigma_emb.1", 2 * D, 0, true);
+    lin_begin(m->sig3, D, 2 * D, true);
+    lin_part(m->sig3, P + "sigma_emb.3", D, 0, true);
+    raw(m->Wa, P + "action_emb.weight", (int64_t)D * A);
+    raw(m->ba, P + "action_emb.bias", D);
+    raw(m->Wp, P + "action_pred.weight", (int64_t)A * D);
+    raw(m->bp, P + "action_pred.bias", A);
+    // constant tables
+    m->freqs = b.take(D / 2);
+    m->rope_cos = b.take(16 * 16);
+    m->rope_sin = b.take(16 * 16);
+}
+
+static bool is_ignored_param(const mdt_model* m, const std::string& name) {
+    auto ends_with = [&](const char* suf) {
+        const size_t n = strlen(suf);
+        return name.size() >= n && name.compare(name.size() - n, n, suf) == 0;
+    };
+    if (name.rfind("inner_model.proprio_emb.", 0) == 0) return true;
+    if (ends_with(".rotary_pos_emb.freqs")) return true;
+    if (name == "inner_model.pos_emb") return true;  // MDT-V (or MDT without abs pos emb) never reads it
+    if (!m->cfg.use_modality_encoder && name.rfind("inner_model.lang_emb", 0) == 0) return false;
+    return false;
+}
+
+extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
+    if (!cfg || !out) return fail(MDT_ERR_INVALID_ARG, "mdt_create: null argument");
+    const mdt_config& c = *cfg;
+    if (c.arch != MDT_ARCH_MDTV && c.arch != MDT_ARCH_MDT) return fail(MDT_ERR_INVALID_ARG, "unknown arch %d", c.arch);
+    if (!c.use_ada_conditioning)
+        return fail(MDT_ERR_UNSUPPORTED, "use_ada_conditioning=False (sigma token in the encoder, TransformerDecoder) "
+                                         "is not implemented by the HIP path");
+    if (c.use_noise_encoder) return fail(MDT_ERR_UNSUPPORTED, "use_noise_encoder=True (NoiseBlock) is not implemented");
+    if (!c.linear_output) return fail(MDT_ERR_UNSUPPORTED, "linear_output=False (MLP action head) is not implemented");
+    if (c.goal_seq_len != 1) return fail(MDT_ERR_UNSUPPORTED, "goal_seq_len must be 1");
+    if (c.embed_dim <= 0 || c.embed_dim % 16 || c.embed_dim > 512)
+        return fail(MDT_ERR_UNSUPPORTED, "embed_dim %d: need a multiple of 16, <= 512", c.embed_dim);
+    if (c.n_heads <= 0 || c.embed_dim % c.n_heads) return fail(MDT_ERR_INVALID_ARG, "embed_dim %% n_heads != 0");
+    const int hd = c.embed_dim / c.n_heads;
+    if (hd != 16 && hd != 32 && hd != 48 && hd != 64)
+        return fail(MDT_ERR_UNSUPPORTED, "head dim %d: supported 16/32/48/64", hd);
+    if (c.use_rot_embed && hd < 32)
+        return fail(MDT_ERR_INVALID_ARG, "use_rot_embed needs head dim >= 32 (rotary dim is 32; the reference asserts)");
+    if (c.obs_dim % 16 || c.goal_dim % 16 || c.obs_dim <= 0 || c.goal_dim <= 0)
+        return fail(MDT_ERR_UNSUPPORTED, "obs_dim / goal_dim must be positive multiples of 16");
+    if (c.goal_dim == 2 * c.obs_dim)
+        return fail(MDT_ERR_UNSUPPORTED, "goal_dim == 2*obs_dim triggers the reference's goal truncation "
+                                         "(mdtv_transformer.py:252-253); not implemented");
+    if (c.action_dim < 1 || c.action_dim > 16) return fail(MDT_ERR_UNSUPPORTED, "action_dim must be 1..16");
+    if (c.action_seq_len < 1 || c.action_seq_len > 16) return fail(MDT_ERR_UNSUPPORTED, "action_seq_len must be 1..16");
+    const int n_tok = c.arch == MDT_ARCH_MDTV ? c.n_obs_token : 2;
+    if (n_tok < 1 || 1 + n_tok > 16) return fail(MDT_ERR_UNSUPPORTED, "context length must be <= 16 tokens");
+    if (c.n_enc_layers < 0 || c.n_dec_layers < 1) return fail(MDT_ERR_INVALID_ARG, "bad layer counts");
+    if (!(c.sigma_data > 0.f)) return fail(MDT_ERR_INVALID_ARG, "sigma_data must be > 0");
+
+    mdt_model* m = new mdt_model();
+    m->cfg = c;
+    m->D = c.embed_dim; m->H = c.n_heads; m->hd = hd; m->n_tok = n_tok; m->Te = 1 + n_tok; m->Ta = c.action_seq_len;
+    m->A = c.action_dim; m->Le = c.n_enc_layers; m->Ld = c.n_dec_layers; m->G = c.goal_dim; m->O = c.obs_dim;
+
+    Bump count;
+    build_params(m, count, false);
+    m->arena_floats = count.off;
+    hipError_t e = hipMalloc((void**)&m->arena, m->arena_floats * sizeof(float));
+    if (e != hipSuccess) { delete m; return fail(MDT_ERR_HIP, "hipMalloc(arena) failed: %s", hipGetErrorString(e)); }
+    e = hipMemset(m->arena, 0, m->arena_floats * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(m->arena); delete m; return fail(MDT_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
+    Bump real;
+    real.base = m->arena;
+    build_params(m, real, true);
+
+    // constant tables (host fp32 math mirroring the reference's torch fp32 expressions)
+    const int half = m->D / 2;
+    std::vector<float> fr(half), rc(256), rs(256);
+    const float step = (float)(-(std::log(10000.0) / (double)(half - 1)));  // mdtv_transformer.py:21-22
+    for (int j = 0; j < half; ++j) fr[j] = expf((float)j * step);
+    for (int i = 0; i < 16; ++i) {  // position_embeddings.py:104: theta ** -(arange(0,32,2)/32)
+        const float f = 1.0f / powf(10000.0f, (float)(2 * i) / 32.0f);
+        for (int p = 0; p < 16; ++p) {
+            rc[p * 16 + i] = cosf((float)p * f);
+            rs[p * 16 + i] = sinf((float)p * f);
+        }
+    }
+    (void)hipMemcpy(m->freqs, fr.data(), half * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemcpy(m->rope_cos, rc.data(), 256 * sizeof(float), hipMemcpyHostToDevice);
+    e = hipMemcpy(m->rope_sin, rs.data(), 256 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(m->arena); delete m; return fail(MDT_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)); }
+
+    size_t mx = 0;
+    for (const Slot& s : m->slots) mx = std::max(mx, (size_t)s.numel);
+    m->staging_floats = mx;
+    e = hipMalloc((void**)&m->staging, mx * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(m->arena); delete m; return fail(MDT_ERR_HIP, "hipMalloc(staging) failed: %s", hipGetErrorString(e)); }
+    m->steps_host.resize(MAX_STEPS * 4);
+    *out = m;
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_destroy(mdt_model* m) {
+    if (!m) return MDT_OK;
+    (void)hipFree(m->arena);
+    (void)hipFree(m->staging);
+    (void)hipFree(m->ws);
+    delete m;
+    return MDT_OK;
+}
+
+extern "C" int64_t mdt_param_count(const mdt_model* m) { return m ? (int64_t)m->slots.size() : 0; }
+extern "C" const char* mdt_param_name(const mdt_model* m, int64_t i) {
+    return (m && i >= 0 && i < (int64_t)m->slots.size()) ? m->slots[i].name.c_str() : nullptr;
+}
+extern "C" int64_t mdt_param_numel(const mdt_model* m, int64_t i) {
+    return (m && i >= 0 && i < (int64_t)m->slots.size()) ? m->slots[i].numel : -1;
+}
+
+extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float* src, int64_t numel, void* stream) {
+    if (!m || !name || !src) return fail(MDT_ERR_INVALID_ARG, "mdt_load_param: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::string nm(name);
+    if (!m->cfg.use_modality_encoder && nm.rfind("inner_model.lang_emb", 0) == 0)
+        nm.replace(0, strlen("inner_model.lang_emb"), "inner_model.goal_emb");  // same module in the reference
+    Slot* slot = nullptr;
+    for (Slot& c : m->slots)
+        if (c.name == nm) { slot = &c; break; }
+    if (!slot) {
+        if (is_ignored_param(m, nm)) return MDT_OK;
+        return fail(MDT_ERR_INVALID_ARG, "mdt_load_param: unknown parameter '%s'", name);
+    }
+    if (numel != slot->numel)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_load_param: '%s' has %lld elements, expected %lld", name, (long long)numel,
+                    (long long)slot->numel);
+    if (slot->kind == SLOT_RAW) {
+        HIP_TRY(hipMemcpyAsync(slot->dst, src, numel * sizeof(float), hipMemcpyDefault, s));
+    } else {
+        hipPointerAttribute_t attr;
+        const float* dev_src = nullptr;
+        hipError_t pe = hipPointerGetAttributes(&attr, src);
+        if (pe == hipSuccess && attr.type == hipMemoryTypeDevice) {
+            dev_src = src;
+        } else {
+            (void)hipGetLastError();  // unregistered host memory reports an error: clear it
+            HIP_TRY(hipMemcpyAsync(m->staging, src, numel * sizeof(float), hipMemcpyHostToDevice, s));
+            dev_src = m->staging;
+        }
+        HIP_TRY(mdt_launch_pack_weight(dev_src, slot->rows, slot->K, slot->dst, slot->n_off, s));
+    }
+    slot->loaded = true;
+    return MDT_OK;
+}
+
+static mdt_status check_loaded(const mdt_model* m) {
+    for (const Slot& s : m->slots)
+        if (!s.loaded) return fail(MDT_ERR_NOT_LOADED, "parameter '%s' was never loaded", s.name.c_str());
+    return MDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+static void carve_ws(mdt_model* m, Bump& b, int64_t B) {
+    const int64_t Re = (int64_t)m->Te * B, Ra = (int64_t)m->Ta * B, Rx = std::max(Re, Ra);
+    const int64_t Rm = std::max<int64_t>(B, MAX_STEPS);
+    const int D = m->D;
+    m->h_enc = b.take(Re * D);
+    m->qkv = b.take(Rx * 3 * D);
+    m->att = b.take(Rx * D);
+    m->hid = b.take(Rx * 4 * D);
+    m->ctx = b.take(Re * D);
+    m->kvx = b.take(Re * m->Ld * 2 * D);
+    m->y = b.take(Ra * D);
+    m->qx = b.take(Ra * D);
+    m->sig_e = b.take(Rm * D);
+    m->sig_t = b.take(Rm * 2 * D);
+    m->sig_c = b.take(Rm * D);
+    m->mod = b.take(Rm * m->Ld * 6 * D);
+    m->xbuf = b.take(Ra * m->A);
+    m->noised = b.take(Ra * m->A);
+    m->Fbuf = b.take(Ra * m->A);
+    m->steps = b.take(MAX_STEPS * 4);
+}
+
+extern "C" mdt_status mdt_reserve(mdt_model* m, int64_t max_batch) {
+    if (!m || max_batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_reserve: bad argument");
+    if (max_batch <= m->cap) return MDT_OK;
+    if (max_batch * std::max(m->Te, m->Ta) > (int64_t)1 << 24) return fail(MDT_ERR_INVALID_ARG, "batch too large");
+    if (m->ws) {
+        HIP_TRY(hipDeviceSynchronize());  // previous work may still read the old workspace
+        HIP_TRY(hipFree(m->ws));
+        m->ws = nullptr;
+        m->cap = 0;
+        m->cached_batch = 0;
+    }
+    Bump count;
+    carve_ws(m, count, max_batch);
+    HIP_TRY(hipMalloc((void**)&m->ws, count.off * sizeof(float)));
+    Bump real;
+    real.base = m->ws;
+    carve_ws(m, real, max_batch);
+    m->cap = max_batch;
+    return MDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+static mdt_gemm_args gemm_args(const float* A, int64_t lda, const Lin& w, float* out, int64_t ldo, int M) {
+    mdt_gemm_args g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.lda = lda; g.Wp = w.wp; g.bias = w.bias; g.out = out; g.ldo = ldo;
+    g.M = M; g.N = w.N; g.K = w.K;
+    g.shift_off = -1; g.scale_off = -1; g.gate_off = -1; g.rows_per_sample = 1;
+    g.gin = 1; g.gout = 1; g.goff = 0;
+    return g;
+}
+
+#define LAUNCH(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return fail(MDT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));       \
+    } while (0)
+
+static bool misaligned(const void* p) { return ((uintptr_t)p & 15) != 0; }
+
+// one transformer Block on the encoder tokens / the self-attention + MLP halves of a ConditionedBlock
+struct ModRef {
+    const float* mod = nullptr;  // modulation row base for this decoder block (nullptr: encoder Block)
+    int64_t stride = 0;
+};
+
+static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, float* x, int64_t B, int T, bool causal, ModRef mr,
+                                hipStream_t s) {
+    const int D = m->D, M = (int)(B * T);
+    mdt_gemm_args g = gemm_args(x, D, e.qkv, m->qkv, 3 * D, M);
+    g.ln = 1; g.ln_w = e.ln1_w; g.ln_b = e.ln1_b;
+    g.rows_per_sample = T;
+    if (mr.mod) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = 0; g.scale_off = D; }
+    LAUNCH(mdt_launch_gemm(g, s));
+    mdt_attn_args a;
+    memset(&a, 0, sizeof a);
+    a.q = m->qkv; a.ldq = 3 * D; a.k = m->qkv + D; a.v = m->qkv + 2 * D; a.ldkv = 3 * D;
+    a.out = m->att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T;
+    a.causal = causal; a.rope = m->cfg.use_rot_embed;
+    LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
+    mdt_gemm_args p = gemm_args(m->att, D, e.proj, x, D, M);
+    p.residual = 1; p.rows_per_sample = T;
+    if (mr.mod) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = 2 * D; }
+    LAUNCH(mdt_launch_gemm(p, s));
+    return MDT_OK;
+}
+
+static mdt_status run_mlp(mdt_model* m, const EncBlock& e, float* x, int64_t B, int T, ModRef mr, hipStream_t s) {
+    const int D = m->D, M = (int)(B * T);
+    mdt_gemm_args g = gemm_args(x, D, e.fc, m->hid, 4 * D, M);
+    g.ln = 1; g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = MDT_ACT_GELU;
+    g.rows_per_sample = T;
+    if (mr.mod) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = 3 * D; g.scale_off = 4 * D; }
+    LAUNCH(mdt_launch_gemm(g, s));
+    mdt_gemm_args p = gemm_args(m->hid, 4 * D, e.proj2, x, D, M);
+    p.residual = 1; p.rows_per_sample = T;
+    if (mr.mod) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = 5 * D; }
+    LAUNCH(mdt_launch_gemm(p, s));
+    return MDT_OK;
+}
+
+static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tokens2, const float* goal, int modality,
+                             int honour_modality, int64_t B, float* ctx_out, hipStream_t s) {
+    const mdt_config& c = m->cfg;
+    const int D = m->D, Te = m->Te;
+    if (!tokens || !goal) return fail(MDT_ERR_INVALID_ARG, "encode: null tokens/goal");
+    if (c.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "encode: MDT needs the gripper tokens");
+    if (misaligned(tokens) || misaligned(goal) || misaligned(tokens2) || misaligned(ctx_out))
+        return fail(MDT_ERR_INVALID_ARG, "encode: pointers must be 16-byte aligned");
+    MDT_TRY(check_loaded(m));
+    MDT_TRY(mdt_reserve(m, B));
+    m->cached_batch = 0;
+    const bool lang = honour_modality && c.use_modality_encoder && modality == MDT_MODALITY_LANG;
+    const Lin& g0 = lang ? m->lang0 : m->goal0;
+    const Lin& g2 = lang ? m->lang2 : m->goal2;
+    const float* pos0 = (c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb) ? m->pos_emb : nullptr;
+    const float* pos1 = pos0 ? m->pos_emb + (int64_t)c.goal_seq_len * D : nullptr;
+    // goal token -> row 0 of every sample's context            (process_goal_embeddings, mdtv_transformer.py:268)
+    {
+        const float* gin = goal;
+        int64_t ld = m->G;
+        if (c.use_mlp_goal) {
+            mdt_gemm_args a = gemm_args(goal, m->G, g0, m->hid, 2 * D, (int)B);
+            a.act = MDT_ACT_GELU;
+            LAUNCH(mdt_launch_gemm(a, s));
+            gin = m->hid; ld = 2 * D;
+        }
+        mdt_gemm_args a = gemm_args(gin, ld, g2, m->h_enc, D, (int)B);
+        a.gin = 1; a.gout = Te; a.goff = 0; a.rowvec = pos0;
+        LAUNCH(mdt_launch_gemm(a, s));
+    }
+    // state tokens -> rows 1..                                  (process_state_embeddings, :260 / mdt :300)
+    if (c.arch == MDT_ARCH_MDTV) {
+        mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)(B * m->n_tok));
+        a.gin = m->n_tok; a.gout = Te; a.goff = 1;
+        LAUNCH(mdt_launch_gemm(a, s));
+    } else {
+        mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)B);
+        a.gin = 1; a.gout = Te; a.goff = 1; a.rowvec = pos1;
+        LAUNCH(mdt_launch_gemm(a, s));
+        mdt_gemm_args b2 = gemm_args(tokens2, m->O, m->incam, m->h_enc, D, (int)B);
+        b2.gin = 1; b2.gout = Te; b2.goff = 2; b2.rowvec = pos1;
+        LAUNCH(mdt_launch_gemm(b2, s));
+    }
+    for (int l = 0; l < m->Le; ++l) {
+        MDT_TRY(run_self_attn(m, m->enc[l], m->h_enc, B, Te, false, ModRef(), s));
+        MDT_TRY(run_mlp(m, m->enc[l], m->h_enc, B, Te, ModRef(), s));
+    }
+    LAUNCH(mdt_launch_layernorm(m->h_enc, m->enc_ln_w, m->enc_ln_b, m->ctx, (int)(B * Te), D, s));
+    if (ctx_out) HIP_TRY(hipMemcpyAsync(ctx_out, m->ctx, (size_t)B * Te * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // cross-attention K|V of all decoder blocks in one GEMM (sigma independent: hoisted out of the step loop)
+    {
+        mdt_gemm_args a = gemm_args(m->ctx, D, m->kv_all, m->kvx, (int64_t)m->Ld * 2 * D, (int)(B * Te));
+        LAUNCH(mdt_launch_gemm(a, s));
+    }
+    m->cached_batch = B;
+    return MDT_OK;
+}
+
+// sigma embedding + adaLN modulation rows for R sigmas: mod (R, Ld*6D)
+static mdt_status run_modulation(mdt_model* m, const float* sigma, int64_t sstride, int R, hipStream_t s) {
+    const int D = m->D;
+    LAUNCH(mdt_launch_sigma_emb(sigma, sstride, m->freqs, m->sig_e, R, D, s));
+    mdt_gemm_args a = gemm_args(m->sig_e, D, m->sig1, m->sig_t, 2 * D, R);
+    a.act = MDT_ACT_MISH;
+    LAUNCH(mdt_launch_gemm(a, s));
+    mdt_gemm_args b = gemm_args(m->sig_t, 2 * D, m->sig3, m->sig_c, D, R);
+    b.act = MDT_ACT_SILU;  // AdaLNZero applies SiLU to c before its Linear; c itself is used nowhere else
+    LAUNCH(mdt_launch_gemm(b, s));
+    mdt_gemm_args c = gemm_args(m->sig_c, D, m->mod_all, m->mod, (int64_t)m->Ld * 6 * D, R);
+    LAUNCH(mdt_launch_gemm(c, s));
+    return MDT_OK;
+}
+
+// the Ld ConditionedBlocks on the residual stream m->y          (transformer_blocks.py:291-309)
+static mdt_status run_decoder_blocks(mdt_model* m, int64_t B, const float* mod_row, int64_t mod_stride, hipStream_t s) {
+    const int D = m->D, Ta = m->Ta, M = (int)(B * Ta);
+    for (int l = 0; l < m->Ld; ++l) {
+        const DecBlock& d = m->dec[l];
+        ModRef mr;
+        mr.mod = mod_row + (int64_t)l * 6 * D;
+        mr.stride = mod_stride;
+        MDT_TRY(run_self_attn(m, d, m->y, B, Ta, true, mr, s));
+        // cross attention: ln3 (biased LayerNorm) -> q ; K|V precomputed ; NOT gated, NOT modulated
+        mdt_gemm_args q = gemm_args(m->y, D, d.xq, m->qx, D, M);
+        q.ln = 1; q.ln_w = d.ln3_w; q.ln_b = d.ln3_b; q.rows_per_sample = Ta;
+        LAUNCH(mdt_launch_gemm(q, s));
+        mdt_attn_args a;
+        memset(&a, 0, sizeof a);
+        a.q = m->qx; a.ldq = D;
+        a.k = m->kvx + (int64_t)l * 2 * D; a.v = a.k + D; a.ldkv = (int64_t)m->Ld * 2 * D;
+        a.out = m->att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Ta; a.Tk = m->Te;
+        a.causal = 1;  // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
+        a.rope = m->cfg.use_rot_embed;
+        LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
+        mdt_gemm_args p = gemm_args(m->att, D, d.xproj, m->y, D, M);
+        p.residual = 1; p.rows_per_sample = Ta;
+        LAUNCH(mdt_launch_gemm(p, s));
+        MDT_TRY(run_mlp(m, d, m->y, B, Ta, mr, s));
+    }
+    return MDT_OK;
+}
+
+static mdt_head_args head_args(mdt_model* m, int64_t B, const float* x, const float* sigma, int64_t sstride, float* out,
+                               int mode) {
+    mdt_head_args h;
+    memset(&h, 0, sizeof h);
+    h.y = m->y; h.ln_w = m->dec_ln_w; h.ln_b = m->dec_ln_b; h.Wp = m->Wp; h.bp = m->bp;
+    h.x = x; h.sigma = sigma; h.sigma_stride = sstride; h.out = out;
+    h.M = (int)(B * m->Ta); h.D = m->D; h.A = m->A; h.rows_per_sample = m->Ta; h.mode = mode;
+    h.sigma_data = m->cfg.sigma_data;
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: model level
+// ------------------------------------------------------------------------------------------------
+extern "C" mdt_status mdt_encode(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                 int32_t modality, int32_t honour_modality, int64_t batch, float* ctx_out,
+                                 void* stream) {
+    if (!m || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_encode: bad argument");
+    return run_encode(m, tokens, tokens2, goal, modality, honour_modality, batch, ctx_out, (hipStream_t)stream);
+}
+
+extern "C" mdt_status mdt_denoise_cached(mdt_model* m, const float* x, const float* sigma, int64_t batch,
+                                         int32_t flags, float* out, void* stream) {
+    if (!m || !x || !sigma || !out || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_denoise_cached: bad argument");
+    if (m->cached_batch != batch)
+        return fail(MDT_ERR_STATE, "mdt_denoise_cached: no cached context for batch %lld (last mdt_encode batch: %lld)",
+                    (long long)batch, (long long)m->cached_batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t modw = (int64_t)m->Ld * 6 * m->D;
+    MDT_TRY(run_modulation(m, sigma, 1, (int)batch, s));
+    LAUNCH(mdt_launch_action_embed(x, (flags & MDT_RAW_INPUT) ? nullptr : sigma, 1, m->cfg.sigma_data, m->Wa, m->ba,
+                                   m->y, (int)(batch * m->Ta), m->A, m->D, m->Ta, s));
+    MDT_TRY(run_decoder_blocks(m, batch, m->mod, modw, s));
+    mdt_head_args h = head_args(m, batch, x, sigma, 1, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
+    LAUNCH(mdt_launch_head(h, s));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_forward(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                  int32_t modality, const float* x, const float* sigma, int64_t batch, float* out,
+                                  float* ctx_out, void* stream) {
+    if (!m) return fail(MDT_ERR_INVALID_ARG, "mdt_forward: null handle");
+    // MDTTransformer.forward -> enc_only_forward always embeds the goal with goal_emb (mdt_transformer.py:215)
+    const int honour = m->cfg.arch == MDT_ARCH_MDTV;
+    MDT_TRY(mdt_encode(m, tokens, tokens2, goal, modality, honour, batch, ctx_out, stream));
+    return mdt_denoise_cached(m, x, sigma, batch, 0, out, stream);
+}
+
+extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                      int32_t modality, const float* x_T, const float* sigmas, int32_t n_steps,
+                                      int64_t batch, float* out, float* ctx_out, void* stream) {
+    if (!m || !x_T || !sigmas || !out || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_sample_ddim: bad argument");
+    if (n_steps < 1 || n_steps > MAX_STEPS) return fail(MDT_ERR_INVALID_ARG, "n_steps must be 1..%d", MAX_STEPS);
+    hipStream_t s = (hipStream_t)stream;
+    const int honour = m->cfg.arch == MDT_ARCH_MDTV;
+    MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, ctx_out, s));
+    // per-step scalars, fp32 like the reference's 0-dim tensor math (gc_sampling.py:946-950):
+    //   t = -ln(sigma); ratio = exp(-t_next)/exp(-t); coef = -expm1(-(t_next - t))
+    float* sh = m->steps_host.data();
+    for (int i = 0; i < n_steps; ++i) {
+        const float t = -logf(sigmas[i]), tn = -logf(sigmas[i + 1]);
+        const float h = tn - t;
+        sh[4 * i + 0] = expf(-tn) / expf(-t);
+        sh[4 * i + 1] = -expm1f(-h);
+        sh[4 * i + 2] = sigmas[i + 1];
+        sh[4 * i + 3] = sigmas[i];
+    }
+    HIP_TRY(hipMemcpyAsync(m->steps, sh, (size_t)n_steps * 4 * sizeof(float), hipMemcpyHostToDevice, s));
+    const int64_t modw = (int64_t)m->Ld * 6 * m->D;
+    MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));  // one row of adaLN vectors per step
+    const int M = (int)(batch * m->Ta);
+    LAUNCH(mdt_launch_action_embed(x_T, m->steps + 3, 0, m->cfg.sigma_data, m->Wa, m->ba, m->y, M, m->A, m->D, m->Ta, s));
+    for (int i = 0; i < n_steps; ++i) {
+        MDT_TRY(run_decoder_blocks(m, batch, m->mod + (int64_t)i * modw, 0, s));
+        const bool last = i == n_steps - 1;
+        mdt_head_args h = head_args(m, batch, i == 0 ? x_T : m->xbuf, m->steps + 4 * i + 3, 0, last ? out : m->xbuf,
+                                    MDT_HEAD_DDIM);
+        h.step = m->steps + 4 * i;
+        if (!last) { h.y_next = m->y; h.Wa = m->Wa; h.ba = m->ba; }
+        LAUNCH(mdt_launch_head(h, s));
+    }
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_loss_fwd(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                   int32_t modality, const float* action, const float* noise, const float* sigma,
+                                   int64_t batch, float* loss_out, float* model_output, float* ctx_out, void* stream) {
+    if (!m || !action || !noise || !sigma || !loss_out || batch < 1)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_loss_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int honour = m->cfg.arch == MDT_ARCH_MDTV;
+    MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, ctx_out, s));
+    const int per = m->Ta * m->A;
+    const int64_t n = batch * per;
+    LAUNCH(mdt_launch_noise_input(action, noise, sigma, m->noised, n, per, s));
+    float* F = model_output ? model_output : m->Fbuf;
+    MDT_TRY(mdt_denoise_cached(m, m->noised, sigma, batch, MDT_RAW_OUTPUT, F, stream));
+    LAUNCH(mdt_launch_loss_reduce(F, action, m->noised, sigma, m->cfg.sigma_data, n, per, loss_out, s));
+    return MDT_OK;
+}
+
+extern "C" double mdt_flops_per_chunk(const mdt_model* m, int32_t n_steps) {
+    if (!m) return 0.0;
+    const double D = m->D, Te = m->Te, Ta = m->Ta, A = m->A, G = m->G, O = m->O;
+    auto attn = [&](double Tq, double Tk) { return 2.0 * (2.0 * Tq * Tk * D); };
+    double goal = m->cfg.use_mlp_goal ? 2.0 * (G * 2 * D + 2 * D * D) : 2.0 * G * D;
+    double enc = goal + 2.0 * (Te - 1) * O * D +
+                 m->Le * (Te * 2.0 * (4 * D * D + 8 * D * D) + attn(Te, Te));
+    double kv = m->Ld * Te * 2.0 * 2 * D * D;
+    double sig = 2.0 * (D * 2 * D + 2 * D * D);
+    double blk = 2.0 * D * 6 * D + Ta * 2.0 * (4 * D * D) + Ta * 2.0 * (2 * D * D) + Ta * 2.0 * 8 * D * D +
+                 attn(Ta, Ta) + attn(Ta, Te);
+    double step = sig + 2.0 * Ta * A * D * 2 + m->Ld * blk;
+    return enc + kv + n_steps * step;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: kernel level (include/mdt_hip_ops.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t mdt_op_packed_numel(int64_t N, int64_t K) { return N * K; }
+
+extern "C" mdt_status mdt_op_pack_weight(const float* w, int64_t n_rows, int64_t K, float* packed, int64_t n_off,
+                                         int64_t N_total, void* stream) {
+    if (!w || !packed || K % 16 || N_total % 16 || n_off < 0 || n_off + n_rows > N_total)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight: bad argument (N, K must be multiples of 16)");
+    LAUNCH(mdt_launch_pack_weight(w, (int)n_rows, (int)K, packed, (int)n_off, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_gemm(const mdt_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->Wp || !a->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_gemm: null pointer");
+    if (a->N % 16 || a->K % 16 || a->lda % 4 || a->ldo % 4 || a->M < 1)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_gemm: N, K multiples of 16 and lda, ldo multiples of 4 required");
+    if (a->ln && a->K > 512) return fail(MDT_ERR_UNSUPPORTED, "mdt_op_gemm: LayerNorm prologue needs K <= 512");
+    if (a->gin < 1 || a->rows_per_sample < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_op_gemm: gin/rows_per_sample < 1");
+    if (misaligned(a->A) || misaligned(a->Wp) || misaligned(a->out) || misaligned(a->bias) || misaligned(a->mod))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_gemm: pointers must be 16-byte aligned");
+    LAUNCH(mdt_launch_gemm(*a, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_attention(const mdt_attn_args* a, void* stream) {
+    if (!a || !a->q || !a->k || !a->v || !a->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_attention: null pointer");
+    if (a->Tq < 1 || a->Tq > 16 || a->Tk < 1 || a->Tk > 16) return fail(MDT_ERR_UNSUPPORTED, "Tq, Tk must be 1..16");
+    if (a->hd != 16 && a->hd != 32 && a->hd != 48 && a->hd != 64) return fail(MDT_ERR_UNSUPPORTED, "hd must be 16/32/48/64");
+    if (a->rope) {
+        if (a->hd < 32) return fail(MDT_ERR_INVALID_ARG, "rope needs hd >= 32");
+        // stand-alone op calls build the rotary tables on the fly
+        static float *cs = nullptr, *sn = nullptr;
+        if (!cs) {
+            std::vector<float> rc(256), rs(256);
+            for (int i = 0; i < 16; ++i) {
+                const float f = 1.0f / powf(10000.0f, (float)(2 * i) / 32.0f);
+                for (int p = 0; p < 16; ++p) { rc[p * 16 + i] = cosf((float)p * f); rs[p * 16 + i] = sinf((float)p * f); }
+            }
+            HIP_TRY(hipMalloc((void**)&cs, 256 * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&sn, 256 * sizeof(float)));
+            HIP_TRY(hipMemcpy(cs, rc.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(sn, rs.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
+        }
+        LAUNCH(mdt_launch_attention(*a, cs, sn, (hipStream_t)stream));
+        return MDT_OK;
+    }
+    LAUNCH(mdt_launch_attention(*a, nullptr, nullptr, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_layernorm(const float* in, const float* w, const float* b, float* out, int64_t M, int32_t D,
+                                       void* stream) {
+    if (!in || !w || !out || D % 4 || D > 512 || M < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_op_layernorm: bad argument");
+    LAUNCH(mdt_launch_layernorm(in, w, b, out, (int)M, D, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_head(const mdt_head_args* a, void* stream) {
+    if (!a || !a->y || !a->out || a->A < 1 || a->A > 16 || a->D % 4 || a->D > 512)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_head: bad argument");
+    LAUNCH(mdt_launch_head(*a, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_action_embed(const float* x, const float* sigma, int64_t sigma_stride, float sigma_data,
+                                          const float* Wa, const float* ba, float* y, int64_t M, int32_t A, int32_t D,
+                                          int32_t rows_per_sample, void* stream) {
+    if (!x || !Wa || !ba || !y || D % 4) return fail(MDT_ERR_INVALID_ARG, "mdt_op_action_embed: bad argument");
+    LAUNCH(mdt_launch_action_embed(x, sigma, sigma_stride, sigma_data, Wa, ba, y, (int)M, A, D, rows_per_sample,
+                                   (hipStream_t)stream));
+    return MDT_OK;
+}

@@ -1,0 +1,263 @@
+"""Bridge between the nn.Module facades and libmdt_hip.so.
+
+``HipEngine`` owns one ``mdt_model`` handle (include/mdt_hip.h) for one score network on one GPU.  It keeps the
+library's fragment-packed weight arena in sync with the module's ``nn.Parameter``s (re-uploading a parameter
+when its storage pointer or in-place version counter changes, e.g. after ``load_state_dict`` / an EMA copy /
+an optimizer step) and turns tensors into the raw device pointers + stream the C ABI takes.
+
+``HipScoreNetwork`` is the shared base of ``MDTVTransformer`` / ``MDTTransformer`` (reference
+mdt/models/networks/mdtv_transformer.py:35, mdt/models/networks/mdt_transformer.py:38).
+
+There is no eager/CPU fallback here on purpose: a missing library, a CPU tensor, or an unsupported
+configuration raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipEngine:
+    def __init__(self, module: nn.Module, cfg: _lib.MDTConfig, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError(
+                "the MDT denoiser runs only on a ROCm GPU (hand-written gfx950 kernels); move the model with "
+                ".to('cuda') -- there is no CPU execution path in mdt_policy_amd")
+        self.lib = _lib.load()
+        self.module = module
+        self.device = device
+        self.cfg = cfg
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.mdt_create(C.byref(cfg), C.byref(handle)))
+        self.handle = handle
+        n = self.lib.mdt_param_count(handle)
+        self.expected = {self.lib.mdt_param_name(handle, i).decode(): self.lib.mdt_param_numel(handle, i)
+                         for i in range(n)}
+        self._uploaded: Dict[str, tuple] = {}
+        self.Te = 1 + (cfg.n_obs_token if cfg.arch == 0 else 2)
+        self.Ta, self.A, self.D = cfg.action_seq_len, cfg.action_dim, cfg.embed_dim
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                self.lib.mdt_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def sync_params(self) -> None:
+        """Upload every parameter whose storage or version changed since the last upload."""
+        stream = self._stream()
+        seen = 0
+        for name, p in self.module.named_parameters():
+            key = "inner_model." + name
+            if key not in self.expected:
+                continue
+            seen += 1
+            tag = (p.data_ptr(), p._version)
+            if self._uploaded.get(key) == tag:
+                continue
+            if p.device != self.device or p.dtype != torch.float32:
+                raise RuntimeError(f"parameter {name} must be float32 on {self.device}, got {p.dtype} on {p.device}")
+            src = p.detach()
+            if not src.is_contiguous():
+                src = src.contiguous()
+            _lib.check(self.lib.mdt_load_param(self.handle, key.encode(), src.data_ptr(), src.numel(), stream))
+            self._uploaded[key] = tag
+        if seen != len(self.expected):
+            have = {"inner_model." + n for n, _ in self.module.named_parameters()}
+            raise RuntimeError(f"module lacks parameters the HIP path needs: {sorted(set(self.expected) - have)[:5]}")
+
+    def _in(self, t: torch.Tensor, shape=None) -> torch.Tensor:
+        if t.device != self.device:
+            raise RuntimeError(f"input tensor on {t.device}, model on {self.device}")
+        t = t.detach()
+        if t.dtype != torch.float32:
+            t = t.float()
+        if shape is not None:
+            t = t.reshape(shape)
+        if not t.is_contiguous():
+            t = t.contiguous()
+        if t.data_ptr() % 16:
+            t = t.clone()
+        return t
+
+    def _tokens(self, state: dict):
+        if self.cfg.arch == 0:
+            tok = self._in(state["state_images"])
+            if tok.dim() != 3 or tok.shape[1] != self.cfg.n_obs_token or tok.shape[2] != self.cfg.obs_dim:
+                raise ValueError(f"state_images must be (B,{self.cfg.n_obs_token},{self.cfg.obs_dim}), got {tuple(tok.shape)}")
+            return tok, None, tok.shape[0]
+        st, gr = self._in(state["static"]), self._in(state["gripper"])
+        B = st.shape[0]
+        if st.numel() != B * self.cfg.obs_dim or gr.numel() != B * self.cfg.obs_dim:
+            raise ValueError("static / gripper must be (B,1,obs_dim)")
+        return st, gr, B
+
+    def _goal(self, goal: torch.Tensor, B: int) -> torch.Tensor:
+        g = self._in(goal)
+        if g.numel() != B * self.cfg.goal_dim:
+            raise ValueError(f"goal must hold (B,1,{self.cfg.goal_dim}) values, got {tuple(goal.shape)}")
+        return g
+
+    def _modality(self, state: dict) -> int:
+        return _lib.MODALITY["lang"] if state.get("modality", None) == "lang" else _lib.MODALITY["vis"]
+
+    # ------------------------------------------------------------------------------------------
+    def encode(self, state: dict, goal: torch.Tensor, honour_modality: bool) -> torch.Tensor:
+        self.sync_params()
+        tok, tok2, B = self._tokens(state)
+        g = self._goal(goal, B)
+        ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.mdt_encode(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
+                                       int(honour_modality), B, _ptr(ctx), self._stream()))
+        return ctx
+
+    def denoise_cached(self, x: torch.Tensor, sigma: torch.Tensor, flags: int = 0) -> torch.Tensor:
+        x_ = self._in(x)
+        B = x_.shape[0]
+        s = self._in(sigma, (B,))
+        out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.mdt_denoise_cached(self.handle, _ptr(x_), _ptr(s), B, flags, _ptr(out), self._stream()))
+        return out
+
+    def forward(self, state: dict, x: torch.Tensor, goal: torch.Tensor, sigma: torch.Tensor):
+        self.sync_params()
+        tok, tok2, B = self._tokens(state)
+        g, x_, s = self._goal(goal, B), self._in(x, (B, self.Ta, self.A)), self._in(sigma, (B,))
+        out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
+        ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.mdt_forward(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(x_),
+                                        _ptr(s), B, _ptr(out), _ptr(ctx), self._stream()))
+        return out, ctx
+
+    def sample_ddim(self, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas):
+        self.sync_params()
+        tok, tok2, B = self._tokens(state)
+        g, x_ = self._goal(goal, B), self._in(x_T, (B, self.Ta, self.A))
+        sig = [float(v) for v in (sigmas.detach().cpu().tolist() if torch.is_tensor(sigmas) else sigmas)]
+        n = len(sig) - 1
+        arr = (C.c_float * len(sig))(*sig)
+        out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
+        ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.mdt_sample_ddim(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
+                                            _ptr(x_), arr, n, B, _ptr(out), _ptr(ctx), self._stream()))
+        return out, ctx
+
+    def loss_fwd(self, state: dict, action: torch.Tensor, goal: torch.Tensor, noise: torch.Tensor, sigma: torch.Tensor):
+        self.sync_params()
+        tok, tok2, B = self._tokens(state)
+        g = self._goal(goal, B)
+        a, nz = self._in(action, (B, self.Ta, self.A)), self._in(noise, (B, self.Ta, self.A))
+        s = self._in(sigma, (B,))
+        loss = torch.empty((), device=self.device, dtype=torch.float32)
+        mo = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
+        ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.mdt_loss_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(a),
+                                         _ptr(nz), _ptr(s), B, _ptr(loss), _ptr(mo), _ptr(ctx), self._stream()))
+        return loss, mo, ctx
+
+    def reserve(self, max_batch: int) -> None:
+        _lib.check(self.lib.mdt_reserve(self.handle, int(max_batch)))
+
+    def flops_per_chunk(self, n_steps: int) -> float:
+        return float(self.lib.mdt_flops_per_chunk(self.handle, int(n_steps)))
+
+
+class HipScoreNetwork(nn.Module):
+    """Common facade logic of the two score networks; subclasses build the parameter tree in reference order."""
+
+    _arch = "mdtv"
+
+    def _init_common(self):
+        self.latent_encoder_emb = None
+        self._engines: Dict[tuple, HipEngine] = {}
+        self._sigma_data = 1.0
+
+    # -- configuration handed to the library ---------------------------------------------------
+    def _hip_config(self, sigma_data: float) -> _lib.MDTConfig:
+        raise NotImplementedError
+
+    def hip_engine(self, sigma_data: Optional[float] = None) -> HipEngine:
+        """The (lazily created) library handle.  sigma_data defaults to the value the owning GCDenoiser
+        registered (``_sigma_data``); it only matters for the preconditioned entry points."""
+        if sigma_data is None:
+            sigma_data = getattr(self, "_sigma_data", 1.0)
+        p = next(self.parameters())
+        key = (str(p.device), float(sigma_data))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = HipEngine(self, self._hip_config(float(sigma_data)), p.device)
+            self._engines = {key: eng}  # one live handle: a moved / re-scaled model drops the old arena
+        return eng
+
+    def _apply(self, fn, *a, **kw):  # .to()/.cuda()/.float(): parameters are re-created, drop stale handles
+        out = super()._apply(fn, *a, **kw)
+        self._engines = {}
+        return out
+
+    def _guard_mode(self):
+        if self.training and any(float(p) > 0 for p in self._pdrops):
+            raise NotImplementedError(
+                "train() mode with dropout > 0: the HIP path implements the eval-mode forward only "
+                "(training backward + dropout are SURVEY.md 8(f) item 1, not built yet); call .eval()")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # forward values are exact, but no autograd graph is recorded
+            raise NotImplementedError(
+                "autograd through the HIP denoiser is not implemented yet (SURVEY.md 8(f) item 1); wrap the call "
+                "in torch.no_grad() for inference / loss evaluation")
+
+    # -- reference API ---------------------------------------------------------------------------
+    def _goals(self, goals: torch.Tensor, uncond: bool) -> torch.Tensor:
+        """preprocess_goals, eval mode (reference mdtv_transformer.py:246-258)."""
+        if goals.dim() == 2:
+            goals = goals[:, None, :]
+        if goals.shape[1] != 1 and self.goal_seq_len == 1:
+            goals = goals[:, :1, :]
+        if uncond:
+            goals = torch.zeros_like(goals)
+        return goals
+
+    def forward(self, states, actions, goals, sigma, uncond: Optional[bool] = False):
+        """Raw score network F(states, actions, goals, sigma) (reference mdtv_transformer.py:208-211)."""
+        self._guard_mode()
+        eng = self.hip_engine()
+        ctx = eng.encode(states, self._goals(goals, uncond), honour_modality=self._arch == "mdtv")
+        self.latent_encoder_emb = ctx
+        return eng.denoise_cached(actions, sigma, _lib.RAW_OUTPUT | _lib.RAW_INPUT)
+
+    def forward_enc_only(self, states, actions=None, goals=None, sigma=None, uncond: Optional[bool] = False):
+        """Context tokens (reference mdtv_transformer.py:213-222 / mdt_transformer.py:257-281)."""
+        self._guard_mode()
+        ctx = self.hip_engine().encode(states, self._goals(goals, uncond), honour_modality=True)
+        if self._arch == "mdtv":  # MDTTransformer.forward_enc_only does not cache (mdt_transformer.py:257-281)
+            self.latent_encoder_emb = ctx
+        return ctx
+
+    def forward_dec_only(self, context, actions, sigma):
+        """reference mdtv_transformer.py:224-236; only valid on the context produced by the last encoder call."""
+        if context is not self.latent_encoder_emb:
+            raise NotImplementedError("forward_dec_only needs the context tensor returned by the immediately "
+                                      "preceding forward_enc_only()/forward() of this module")
+        self._guard_mode()
+        return self.hip_engine().denoise_cached(actions, sigma, _lib.RAW_OUTPUT | _lib.RAW_INPUT)
+
+    def get_params(self):
+        return self.parameters()
+
+    def get_block_size(self):
+        return self.block_size

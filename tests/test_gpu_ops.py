@@ -1,0 +1,288 @@
+"""Kernel-level parity (run on the MI355X box: pytest -m gpu): every hand-written kernel, called through the
+C ABI of include/mdt_hip_ops.h, against a PyTorch fp32/fp64 CPU reference of the same op."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mdt_policy_amd import _lib
+    return _lib
+
+
+def dev(t):
+    return t.to("cuda", torch.float32).contiguous()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack(lib, W):
+    """Pack a (N, K) weight through the library."""
+    N, K = W.shape
+    Wd = dev(W)
+    P = torch.zeros(N * K, device="cuda")
+    lib.check(lib.load().mdt_op_pack_weight(Wd.data_ptr(), N, K, P.data_ptr(), 0, N, stream()))
+    return P
+
+
+def expected_pack(W):
+    """Fragment-major image: block (nt, kc) = 64 lanes x 4 floats; lane l = n%16 + 16*((k%16)//4), j = k%4."""
+    N, K = W.shape
+    out = np.zeros(N * K, np.float32)
+    n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+    idx = (((n // 16) * (K // 16) + k // 16) * 64 + (n % 16) + 16 * ((k % 16) // 4)) * 4 + k % 4
+    out[idx.ravel()] = W.numpy().ravel()
+    return out
+
+
+def test_pack_layout(lib):
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(48, 64, generator=g)
+    np.testing.assert_array_equal(pack(lib, W).cpu().numpy(), expected_pack(W))
+
+
+def run_gemm(lib, A, W, bias=None, ln_w=None, ln_b=None, mod=None, mod_stride=0, shift_off=-1, scale_off=-1,
+             rps=1, act="none", residual_into=None, gate_off=-1, gin=1, gout=1, goff=0, rowvec=None, out_rows=None):
+    M, K = A.shape
+    N = W.shape[0]
+    Ad, Pd = dev(A), pack(lib, W)
+    keep = [Ad, Pd]
+    out_rows = out_rows or M
+    out = dev(residual_into) if residual_into is not None else torch.full((out_rows, N), float("nan"), device="cuda")
+    a = lib.GemmArgs()
+    a.A, a.lda, a.Wp, a.out, a.ldo = Ad.data_ptr(), K, Pd.data_ptr(), out.data_ptr(), N
+    a.M, a.N, a.K = M, N, K
+    for name, t in (("bias", bias), ("ln_w", ln_w), ("ln_b", ln_b), ("mod", mod), ("rowvec", rowvec)):
+        if t is not None:
+            td = dev(t)
+            keep.append(td)
+            setattr(a, name, td.data_ptr())
+    a.ln = int(ln_w is not None)
+    a.mod_stride, a.shift_off, a.scale_off, a.rows_per_sample = mod_stride, shift_off, scale_off, rps
+    a.act, a.residual, a.gate_off = lib.ACT[act], int(residual_into is not None), gate_off
+    a.gin, a.gout, a.goff = gin, gout, goff
+    lib.check(lib.load().mdt_op_gemm(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def ref_act(x, act):
+    return {"none": lambda v: v, "gelu": F.gelu, "mish": F.mish, "silu": F.silu}[act](x)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 128, 64), (2560, 384, 384), (2560, 1152, 384), (100, 48, 128),
+                                   (10, 2304 * 4, 384), (1024, 3072, 384), (37, 112, 512), (2560, 384, 1536),
+                                   (256, 768, 512), (1, 16, 16)])
+def test_gemm_plain_bias(lib, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    got = run_gemm(lib, A, W, bias=b)
+    want = (A.double() @ W.double().T + b.double()).float()
+    assert_close(got, want, rtol=1e-4, atol=1e-4, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_is_transpose_sensitive(lib):
+    """A = I with an ASYMMETRIC weight: catches a swapped C/D fragment map."""
+    K = N = 64
+    W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 100.0
+    got = run_gemm(lib, torch.eye(K), W)
+    assert_close(got, W.T.contiguous(), rtol=1e-6, atol=1e-6, what="identity gemm")
+
+
+@pytest.mark.parametrize("act", ["gelu", "mish", "silu"])
+def test_gemm_activations(lib, act):
+    g = torch.Generator().manual_seed(5)
+    A, W = torch.randn(70, 128, generator=g) * 2, torch.randn(256, 128, generator=g) / 4
+    b = torch.randn(256, generator=g)
+    got = run_gemm(lib, A, W, bias=b, act=act)
+    want = ref_act(A.double() @ W.double().T + b.double(), act).float()
+    assert_close(got, want, rtol=1e-4, atol=1e-4, what=act)
+
+
+@pytest.mark.parametrize("with_bias,with_mod,D", [(False, False, 384), (True, False, 384), (False, True, 384),
+                                                  (True, True, 128), (False, True, 512)])
+def test_gemm_layernorm_modulate_prologue(lib, with_bias, with_mod, D):
+    g = torch.Generator().manual_seed(11 + D)
+    B, T, N = 7, 10, 3 * D
+    M = B * T
+    A = torch.randn(M, D, generator=g) * 3 + 0.5
+    W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g)
+    lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    mod = torch.randn(B, 6 * D, generator=g)
+    x = F.layer_norm(A.double(), (D,), lw.double(), lb.double() if with_bias else None, 1e-5)
+    if with_mod:
+        sh = mod[:, 3 * D:4 * D].double().repeat_interleave(T, 0)
+        sc = mod[:, 4 * D:5 * D].double().repeat_interleave(T, 0)
+        x = sh + x * sc
+    want = (x @ W.double().T + b.double()).float()
+    got = run_gemm(lib, A, W, bias=b, ln_w=lw, ln_b=lb if with_bias else None, mod=mod if with_mod else None,
+                   mod_stride=6 * D, shift_off=3 * D if with_mod else -1, scale_off=4 * D if with_mod else -1, rps=T)
+    assert_close(got, want, rtol=2e-4, atol=2e-4, what="ln+mod gemm")
+    if with_mod:  # broadcast modulation row (sampler: one sigma for the whole batch)
+        x = F.layer_norm(A.double(), (D,), lw.double(), lb.double() if with_bias else None, 1e-5)
+        x = mod[2, 3 * D:4 * D].double() + x * mod[2, 4 * D:5 * D].double()
+        want = (x @ W.double().T + b.double()).float()
+        got = run_gemm(lib, A, W, bias=b, ln_w=lw, ln_b=lb if with_bias else None, mod=mod[2].clone(), mod_stride=0,
+                       shift_off=3 * D, scale_off=4 * D, rps=T)
+        assert_close(got, want, rtol=2e-4, atol=2e-4, what="ln+broadcast mod gemm")
+
+
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("K", [384, 1536])
+def test_gemm_gated_residual_epilogue(lib, gated, K):
+    g = torch.Generator().manual_seed(3 + K)
+    B, T, D = 9, 10, 384
+    M = B * T
+    A, W = torch.randn(M, K, generator=g), torch.randn(D, K, generator=g) / math.sqrt(K)
+    y0 = torch.randn(M, D, generator=g)
+    mod = torch.randn(B, 6 * D, generator=g)
+    v = A.double() @ W.double().T
+    if gated:
+        v = v * mod[:, 5 * D:].double().repeat_interleave(T, 0)
+    want = (y0.double() + v).float()
+    got = run_gemm(lib, A, W, residual_into=y0, mod=mod if gated else None, mod_stride=6 * D, rps=T,
+                   gate_off=5 * D if gated else -1)
+    assert_close(got, want, rtol=1e-4, atol=1e-4, what="residual gemm")
+
+
+def test_gemm_row_remap_and_rowvec(lib):
+    """Token concatenation: goal row -> slot 0, 3 state rows -> slots 1..3 of each sample's 4-token context."""
+    g = torch.Generator().manual_seed(8)
+    B, D = 6, 128
+    goal, tok = torch.randn(B, 512, generator=g), torch.randn(B * 3, 128, generator=g)
+    Wg, Wt = torch.randn(D, 512, generator=g) / 20, torch.randn(D, 128, generator=g) / 10
+    pos = torch.randn(D, generator=g)
+    h = torch.zeros(B * 4, D)
+    h = run_gemm(lib, goal, Wg, residual_into=None, gin=1, gout=4, goff=0, rowvec=pos, out_rows=B * 4)
+    got_goal = h.reshape(B, 4, D)[:, 0]
+    assert_close(got_goal, (goal.double() @ Wg.double().T + pos.double()).float(), rtol=1e-4, atol=1e-4, what="goal rows")
+    h2 = run_gemm(lib, tok, Wt, gin=3, gout=4, goff=1, out_rows=B * 4)
+    got_tok = h2.reshape(B, 4, D)[:, 1:].reshape(B * 3, D)
+    assert_close(got_tok, (tok.double() @ Wt.double().T).float(), rtol=1e-4, atol=1e-4, what="state rows")
+    assert torch.isnan(h2.reshape(B, 4, D)[:, 0]).all()  # untouched rows stay untouched
+
+
+def run_attn(lib, q, k, v, H, causal, rope=False):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    qd, kd, vd = dev(q.reshape(B * Tq, D)), dev(k.reshape(B * Tk, D)), dev(v.reshape(B * Tk, D))
+    out = torch.full((B * Tq, D), float("nan"), device="cuda")
+    a = lib.AttnArgs()
+    a.q, a.ldq, a.k, a.v, a.ldkv, a.out, a.ldo = qd.data_ptr(), D, kd.data_ptr(), vd.data_ptr(), D, out.data_ptr(), D
+    a.B, a.H, a.hd, a.Tq, a.Tk, a.causal, a.rope = B, H, D // H, Tq, Tk, int(causal), int(rope)
+    lib.check(lib.load().mdt_op_attention(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    return out.cpu().reshape(B, Tq, D)
+
+
+def ref_attn(q, k, v, H, causal, rope=False):
+    from oracle.mdt_oracle import apply_rotary
+    B, Tq, D = q.shape
+    hd = D // H
+    qh, kh, vh = (t.double().view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    if rope:
+        qh, kh = apply_rotary(qh, 32), apply_rotary(kh, 32)
+    att = qh @ kh.transpose(-2, -1) / math.sqrt(hd)
+    if causal:
+        att = att.masked_fill(~torch.ones(Tq, k.shape[1], dtype=torch.bool).tril(), float("-inf"))
+    return (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Tq, D).float()
+
+
+@pytest.mark.parametrize("H,hd,Tq,Tk,causal", [(8, 48, 10, 10, True), (8, 48, 10, 4, True), (8, 48, 4, 4, False),
+                                               (8, 16, 10, 3, True), (8, 64, 10, 10, True), (4, 32, 16, 16, False),
+                                               (8, 48, 1, 1, True)])
+def test_attention(lib, H, hd, Tq, Tk, causal):
+    g = torch.Generator().manual_seed(H + hd + Tq + Tk)
+    B, D = 13, H * hd
+    q, k, v = (torch.randn(B, T, D, generator=g) for T in (Tq, Tk, Tk))
+    assert_close(run_attn(lib, q, k, v, H, causal), ref_attn(q, k, v, H, causal), rtol=1e-4, atol=1e-5, what="attention")
+
+
+def test_attention_matches_sdpa_is_causal_for_rectangular_scores(lib):
+    """The reference calls F.scaled_dot_product_attention(is_causal=True) on 10x4 scores."""
+    g = torch.Generator().manual_seed(77)
+    B, H, hd = 5, 8, 48
+    q, k, v = torch.randn(B, 10, H * hd, generator=g), torch.randn(B, 4, H * hd, generator=g), torch.randn(B, 4, H * hd, generator=g)
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    want = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True).transpose(1, 2).reshape(B, 10, H * hd)
+    assert_close(run_attn(lib, q, k, v, H, True), want, rtol=1e-4, atol=1e-5, what="sdpa causal 10x4")
+
+
+@pytest.mark.parametrize("hd", [48, 64, 32])
+def test_attention_rope(lib, hd):
+    g = torch.Generator().manual_seed(hd)
+    B, H = 4, 8
+    q, k, v = (torch.randn(B, T, H * hd, generator=g) for T in (10, 4, 4))
+    assert_close(run_attn(lib, q, k, v, H, True, rope=True), ref_attn(q, k, v, H, True, rope=True), rtol=1e-4, atol=1e-5,
+                 what="rope attention")
+
+
+@pytest.mark.parametrize("D,with_bias", [(384, False), (128, True), (512, True)])
+def test_layernorm(lib, D, with_bias):
+    g = torch.Generator().manual_seed(D)
+    M = 1027
+    x, w, b = torch.randn(M, D, generator=g) * 4 - 1, torch.randn(D, generator=g), torch.randn(D, generator=g)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    out = torch.empty_like(xd)
+    lib.check(lib.load().mdt_op_layernorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if with_bias else None,
+                                          out.data_ptr(), M, D, stream()))
+    want = F.layer_norm(x.double(), (D,), w.double(), b.double() if with_bias else None, 1e-5).float()
+    assert_close(out.cpu(), want, rtol=1e-4, atol=1e-5, what="layernorm")
+
+
+def test_action_embed(lib):
+    g = torch.Generator().manual_seed(2)
+    B, T, A, D, sd = 11, 10, 7, 384, 0.5
+    x, Wa, ba = torch.randn(B * T, A, generator=g) * 30, torch.randn(D, A, generator=g), torch.randn(D, generator=g)
+    sigma = torch.rand(B, generator=g) * 50 + 0.01
+    xd, Wd, bd, sg = dev(x), dev(Wa), dev(ba), dev(sigma)
+    y = torch.empty(B * T, D, device="cuda")
+    lib.check(lib.load().mdt_op_action_embed(xd.data_ptr(), sg.data_ptr(), 1, sd, Wd.data_ptr(), bd.data_ptr(),
+                                             y.data_ptr(), B * T, A, D, T, stream()))
+    cin = (1 / (sigma.double() ** 2 + sd ** 2).sqrt()).repeat_interleave(T)[:, None]
+    want = ((x.double() * cin) @ Wa.double().T + ba.double()).float()
+    assert_close(y.cpu(), want, rtol=1e-4, atol=1e-5, what="action_embed")
+
+
+@pytest.mark.parametrize("mode", ["denoised", "ddim", "raw"])
+def test_head(lib, mode):
+    g = torch.Generator().manual_seed(4)
+    B, T, A, D, sd = 6, 10, 7, 384, 0.5
+    M = B * T
+    y, lw = torch.randn(M, D, generator=g) * 2, torch.randn(D, generator=g) * 0.1 + 1
+    Wp, bp = torch.randn(A, D, generator=g) / 20, torch.randn(A, generator=g)
+    Wa, ba = torch.randn(D, A, generator=g), torch.randn(D, generator=g)
+    x = torch.randn(M, A, generator=g) * 10
+    sigma = torch.rand(B, generator=g) * 20 + 0.05
+    step = torch.tensor([0.3, 0.7, 2.5])  # ratio, coef, sigma_next
+    t = {k: dev(v) for k, v in dict(y=y, lw=lw, Wp=Wp, bp=bp, Wa=Wa, ba=ba, x=x, sigma=sigma, step=step).items()}
+    out = torch.empty(M, A, device="cuda")
+    y_next = torch.empty(M, D, device="cuda")
+    a = lib.HeadArgs()
+    a.y, a.ln_w, a.Wp, a.bp, a.x = (t[k].data_ptr() for k in ("y", "lw", "Wp", "bp", "x"))
+    a.sigma, a.sigma_stride, a.out = t["sigma"].data_ptr(), 1, out.data_ptr()
+    a.M, a.D, a.A, a.rows_per_sample, a.mode, a.sigma_data = M, D, A, T, lib.HEAD[mode], sd
+    a.step = t["step"].data_ptr()
+    if mode == "ddim":
+        a.y_next, a.Wa, a.ba = y_next.data_ptr(), t["Wa"].data_ptr(), t["ba"].data_ptr()
+    lib.check(lib.load().mdt_op_head(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    Fv = F.layer_norm(y.double(), (D,), lw.double(), None, 1e-5) @ Wp.double().T + bp.double()
+    s = sigma.double().repeat_interleave(T)[:, None]
+    den = Fv * (s * sd / (s ** 2 + sd ** 2).sqrt()) + x.double() * (sd ** 2 / (s ** 2 + sd ** 2))
+    want = {"raw": Fv, "denoised": den, "ddim": 0.3 * x.double() + 0.7 * den}[mode]
+    assert_close(out.cpu(), want.float(), rtol=1e-4, atol=1e-4, what=f"head {mode}")
+    if mode == "ddim":
+        wn = (want / math.sqrt(2.5 ** 2 + sd ** 2)) @ Wa.double().T + ba.double()
+        assert_close(y_next.cpu(), wn.float(), rtol=1e-4, atol=1e-4, what="fused next action_emb")

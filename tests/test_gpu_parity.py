@@ -1,0 +1,232 @@
+"""Model-level parity on the MI355X (pytest -m gpu): the HIP path, driven through the reference-shaped facade
+(GCDenoiser / sample_* -> ctypes -> libmdt_hip.so), against (a) the golden outputs of the reference and
+(b) the CPU oracle on the same seeded inputs.  Gate: rtol 1e-3 / atol 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mdt_oracle as O
+from tests.helpers import assert_close, cfg_of, inputs_of, load_fixture, params_of
+
+pytestmark = pytest.mark.gpu
+
+_MODELS = {}
+
+
+def build(meta, sigma_data=0.5):
+    """Facade model on the GPU carrying the fixture's synthetic weights (cached per fixture config)."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    key = (meta["config"], str(meta.get("overrides")), meta["weight_seed"], meta["profile"])
+    if key not in _MODELS:
+        model = GCDenoiser(cfg_of(meta), sigma_data=sigma_data)
+        missing = model.load_state_dict(params_of(meta), strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        _MODELS[key] = model.cuda().eval()
+    return _MODELS[key]
+
+
+def gpu_inputs(meta):
+    state, goal, noise = inputs_of(meta)
+    state = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    return state, goal.cuda(), noise.cuda()
+
+
+def sampling():
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling
+    return gc_sampling
+
+
+@pytest.mark.parametrize("arch", ["mdtv", "mdt"])
+def test_g1_tiny(arch):
+    meta, fx = load_fixture(f"g1_tiny_{arch}.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    sig = gs.get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    np.testing.assert_allclose(sig.numpy(), fx["sigmas"], rtol=1e-6)
+    with torch.no_grad():
+        out = gs.sample_ddim(model, state, noise * meta["sigma_max"], goal, sig, disable=True)
+        assert_close(model.inner_model.latent_encoder_emb.cpu(), fx["ctx"], what="ctx")
+        assert_close(out.cpu(), fx["actions"], what="actions (fused loop)")
+        steps = []
+        out2 = gs.sample_ddim(model, state, noise * meta["sigma_max"], goal, sig, disable=True,
+                              callback=lambda d: steps.append(d["denoised"].cpu()))
+    assert_close(torch.stack(steps), fx["denoised_steps"], what="per-step denoised")
+    assert_close(out2.cpu(), fx["actions"], what="actions (python loop)")
+
+
+@pytest.mark.parametrize("arch", ["mdtv", "mdt"])
+@pytest.mark.parametrize("modality", ["lang", "vis"])
+def test_g1_forward_context_only(arch, modality):
+    meta, fx = load_fixture(f"g1_ctxonly_{arch}_{modality}.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    with torch.no_grad():
+        ctx = model.forward_context_only(state, noise, goal, torch.full((meta["B"],), 2.5, device="cuda"))
+    assert_close(ctx.cpu(), fx["ctx"], what="ctx")
+
+
+def test_g2_denoiser_forward_per_sample_sigma():
+    meta, fx = load_fixture("g2_stages_mdtv.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sigma = torch.tensor(meta["sigma"], device="cuda")
+    with torch.no_grad():
+        out = model(state, noise * sigma[:, None, None], goal, sigma)
+        assert_close(model.inner_model.latent_encoder_emb.cpu(), fx["ctx"], what="ctx")
+        assert_close(out.cpu(), fx["denoised"], what="denoised")
+        # raw score network (inner_model.forward): input already scaled by c_in, output un-preconditioned
+        c_in = 1 / (sigma ** 2 + 0.25).sqrt()
+        raw = model.inner_model(state, noise * sigma[:, None, None] * c_in[:, None, None], goal, sigma)
+        assert_close(raw.cpu(), fx["action_pred"], what="action_pred")
+        sig = sampling().get_sigmas_exponential(10, meta["sigma_min"], meta["sigma_max"])
+        act = sampling().sample_ddim(model, state, noise * 80.0, goal, sig)
+    assert_close(act.cpu(), fx["actions"], what="actions")
+
+
+@pytest.mark.parametrize("tag", ["lang", "vis", "init"])
+def test_g3_b256_full_size(tag):
+    """BASELINE C2 at full size: B=256, d=384, 10 DDIM steps, vs the reference's own output."""
+    meta, fx = load_fixture(f"g3_b256_{tag}.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    with torch.no_grad():
+        out = sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, torch.from_numpy(fx["sigmas"]))
+    assert_close(out.cpu(), fx["actions"], what=f"B=256 actions ({tag})")
+
+
+def test_g3_eval_schedule_and_hoisting():
+    meta, fx = load_fixture("g3_b8_smin1.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    sig = gs.get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    with torch.no_grad():
+        fused = gs.sample_ddim(model, state, noise * 80.0, goal, sig)
+        # "as written": the encoder is re-run by every model(...) call, like the reference
+        x = noise * 80.0
+        s_in = x.new_ones([x.shape[0]])
+        for i in range(len(sig) - 1):
+            den = model(state, x, goal, sig[i].item() * s_in)
+            t, tn = -sig[i].log(), -sig[i + 1].log()
+            x = ((-tn).exp() / (-t).exp()).item() * x - (-(tn - t)).expm1().item() * den
+    assert_close(fused.cpu(), fx["actions"], what="fused")
+    assert_close(x.cpu(), fx["actions"], what="as-written loop")
+    assert_close(x.cpu(), fused.cpu(), rtol=1e-5, atol=1e-5, what="hoisted vs as-written")
+
+
+def test_g3_mdt_default():
+    meta, fx = load_fixture("g3_b8_mdt.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    with torch.no_grad():
+        out = sampling().sample_ddim(model, state, noise * 80.0, goal, torch.from_numpy(fx["sigmas"]))
+    assert_close(model.inner_model.latent_encoder_emb.cpu(), fx["ctx"], what="ctx")
+    assert_close(out.cpu(), fx["actions"], what="actions")
+
+
+def test_g4_loss_forward():
+    from mdt_policy_amd import synthetic
+    meta, fx = load_fixture("g4_loss.npz")
+    model = build(meta)
+    state, goal, _ = gpu_inputs(meta)
+    li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(meta["B"], cfg_of(meta), meta["loss_seed"]).items()}
+    with torch.no_grad():
+        loss, mo = model.loss(state, li["actions"], goal, li["noise_train"], li["sigma"])
+    assert_close(mo.cpu(), fx["model_output"], what="model_output")
+    assert_close(loss.cpu(), fx["loss"].reshape(()), rtol=1e-3, atol=1e-6, what="loss")
+
+
+def test_g6_rope():
+    meta, fx = load_fixture("g6_rope.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    with torch.no_grad():
+        out = sampling().sample_ddim(model, state, noise * 80.0, goal, torch.from_numpy(fx["sigmas"]))
+    assert_close(model.inner_model.latent_encoder_emb.cpu(), fx["ctx"], what="ctx")
+    assert_close(out.cpu(), fx["actions"], what="actions")
+
+
+@pytest.mark.parametrize("sched", ["exp", "karras"])
+@pytest.mark.parametrize("name", ["ddim", "euler", "heun", "dpmpp_2m"])
+def test_g7_other_samplers(name, sched):
+    meta, fx = load_fixture("g7_samplers.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    sig = (gs.get_sigmas_exponential if sched == "exp" else gs.get_sigmas_karras)(10, 0.001, 80.0)
+    with torch.no_grad():
+        out = getattr(gs, "sample_" + name)(model, state, noise * 80.0, goal, sig)
+    assert_close(out.cpu(), fx[f"{name}_{sched}"], what=f"{name}/{sched}")
+
+
+def test_against_oracle_random_batch_sizes():
+    """HIP vs oracle on fresh seeded inputs at ragged batch sizes (tile-boundary edge cases)."""
+    meta, _ = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    cfg, P = cfg_of(meta), params_of(meta)
+    sig = O.get_sigmas_exponential(3, 0.01, 80.0)
+    for B in (1, 3, 7, 33):
+        m2 = dict(meta, B=B, input_seed=100 + B)
+        state, goal, noise = inputs_of(m2)
+        want = O.sample_ddim(P, cfg, state, noise * 80.0, goal, sig, hoist=True)
+        with torch.no_grad():
+            got = sampling().sample_ddim(model, {"state_images": state["state_images"].cuda(), "modality": "lang"},
+                                         noise.cuda() * 80.0, goal.cuda(), sig)
+        assert_close(got.cpu(), want, what=f"B={B}")
+
+
+def test_full_size_properties():
+    """Size-independent properties at B=256: determinism and batch independence (a sample's actions do not
+    depend on what else is in the batch -- bit-exact, the k-order of every dot product is fixed)."""
+    meta, _ = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sig = sampling().get_sigmas_exponential(10, 0.001, 80.0)
+    with torch.no_grad():
+        a = sampling().sample_ddim(model, state, noise * 80.0, goal, sig)
+        b = sampling().sample_ddim(model, state, noise * 80.0, goal, sig)
+        assert torch.equal(a, b), "non-deterministic"
+        sub = slice(100, 117)
+        st = {"state_images": state["state_images"][sub].contiguous(), "modality": state["modality"]}
+        c = sampling().sample_ddim(model, st, noise[sub] * 80.0, goal[sub], sig)
+    assert torch.equal(a[sub], c), "batch dependence"
+    assert torch.isfinite(a).all()
+
+
+def test_parameter_updates_reach_the_kernels():
+    meta, _ = load_fixture("g2_stages_mdtv.npz")
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    model = GCDenoiser(cfg_of(meta), 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    state, goal, noise = gpu_inputs(meta)
+    sigma = torch.full((4,), 1.5, device="cuda")
+    with torch.no_grad():
+        a = model(state, noise, goal, sigma)
+        model.inner_model.action_pred.bias.add_(1.0)  # in-place update, like an optimizer / EMA copy
+        b = model(state, noise, goal, sigma)
+        new = {k: v * 1.01 for k, v in params_of(meta).items()}
+        model.load_state_dict(new)
+        c = model(state, noise, goal, sigma)
+    c_out = (1.5 * 0.5) / (1.5 ** 2 + 0.25) ** 0.5
+    assert_close((b - a).cpu(), torch.full_like(a, c_out).cpu(), rtol=1e-3, atol=1e-4, what="bias shift")
+    assert not torch.allclose(c, a)
+
+
+def test_fails_loudly_instead_of_falling_back():
+    meta, _ = load_fixture("g1_tiny_mdtv.npz")
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    model = GCDenoiser(cfg_of(meta), 0.5)
+    model.load_state_dict(params_of(meta))
+    state, goal, noise = inputs_of(meta)
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        model.eval()(state, noise, goal, torch.ones(1))  # CPU tensors / CPU model: no CPU path exists
+    model = model.cuda()
+    state = {"state_images": state["state_images"].cuda(), "modality": "lang"}
+    with pytest.raises(NotImplementedError):
+        model.eval()(state, noise.cuda(), goal.cuda(), torch.ones(1, device="cuda"))  # autograd not implemented
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        model.train()(state, noise.cuda(), goal.cuda(), torch.ones(1, device="cuda"))  # dropout not implemented
+    with torch.no_grad(), pytest.raises(Exception):
+        model.eval()(state, noise.cuda(), goal.cuda()[:, :, :100], torch.ones(1, device="cuda"))  # bad goal shape
