@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense FP32 matrix peak (MI355X_MICROARCH.md)
+T_START = time.perf_counter()
 
 
 def parse():
@@ -43,6 +44,7 @@ def parse():
     ap.add_argument("--denoise-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cpu_count, 32))")
     return ap.parse_args()
 
 
@@ -91,26 +93,40 @@ def time_dominant_kernel(device, M):
             "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
 
 
-def cpu_baseline(cfg, P, batch, n_denoise, budget_s):
-    """Oracle (port of the reference's PyTorch-CPU algorithm) on this host, as-written (encoder every step)."""
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, P, batch, n_denoise, budget_s, threads):
+    """Oracle (port of the reference's PyTorch-CPU algorithm) on this host, as-written (encoder every step).
+    Bounded: a B=16 probe sizes the sample so that the leg stays inside ``budget_s`` seconds."""
     from mdt_policy_amd import synthetic
     from oracle import mdt_oracle as O
-    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     inp = {k: torch.from_numpy(v) for k, v in synthetic.sampler_inputs(batch, cfg, seed=1).items()}
-    state = {"state_images": inp["state_images"], "modality": "lang"}
     sig = O.get_sigmas_exponential(n_denoise, 0.001, 80.0)
     x = inp["noise"] * 80.0
-    O.sample_ddim(P, cfg, {"state_images": inp["state_images"][:8], "modality": "lang"}, x[:8], inp["goal"][:8], sig)
+
+    def run(b):
+        st = {"state_images": inp["state_images"][:b], "modality": "lang"}
+        t0 = time.perf_counter()
+        O.sample_ddim(P, cfg, st, x[:b], inp["goal"][:b], sig, hoist=False)
+        return time.perf_counter() - t0
+
+    run(16)  # warm-up (thread pool, allocator)
+    probe = run(16)
+    b = batch
+    while b > 16 and probe * (b / 16) * 2 > budget_s:  # pessimistic linear estimate, 2 repetitions
+        b //= 2
+    log(f"cpu baseline: probe B=16 {probe:.2f}s -> sample B={b}, {threads} threads")
     best, spent, reps = float("inf"), 0.0, 0
     while reps < 5 and (reps == 0 or spent + best < budget_s):
-        t0 = time.perf_counter()
-        O.sample_ddim(P, cfg, state, x, inp["goal"], sig, hoist=False)
-        dt = time.perf_counter() - t0
+        dt = run(b)
         best, spent, reps = min(best, dt), spent + dt, reps + 1
-    return {"value": round(batch / best, 2), "unit": "action-chunks/s", "cores": threads, "kind": "port",
-            "sample": f"oracle sample_ddim, B={batch}, {n_denoise} steps, fp32, encoder re-run every step "
-                      f"(as the reference does), best of {reps} ({best:.2f} s each), torch {torch.__version__}"}
+    return {"value": round(b / best, 2), "unit": "action-chunks/s", "cores": threads, "kind": "port",
+            "sample": f"oracle sample_ddim, B={b}, {n_denoise} steps, fp32, encoder re-run every step "
+                      f"(as the reference does), best of {reps} ({best:.2f} s each), {threads} of "
+                      f"{os.cpu_count()} host threads, torch {torch.__version__}"}
 
 
 def main():
@@ -150,6 +166,7 @@ def main():
             act = sharding.all_gather_actions(act, B * world)  # ONE collective per sample call
         return act
 
+    log(f"model ready on {device}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(device)
@@ -171,6 +188,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, gpu_s = t[0].item(), t[1].item()
     assert torch.isfinite(out).all()
+    log(f"timed {args.steps} steps: wall {wall:.4f}s gpu {gpu_s:.4f}s")
 
     if rank == 0:
         flops_chunk = eng.flops_per_chunk(args.denoise_steps)
@@ -203,10 +221,12 @@ def main():
         }
         try:
             res["roofline"]["dominant_kernel"] = time_dominant_kernel(device, B * 10)
+            log("dominant kernel timed")
         except Exception as e:  # diagnostic leg only; never hides the main number
             res["roofline"]["dominant_kernel"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, P, B, args.denoise_steps, args.cpu_seconds)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
+            res["cpu_baseline"] = cpu_baseline(cfg, P, B, args.denoise_steps, args.cpu_seconds, threads)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

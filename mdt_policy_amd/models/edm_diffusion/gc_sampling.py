@@ -68,7 +68,9 @@ def get_sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3, device='cpu'):
 
 def to_d(action, sigma, denoised):
     """Karras ODE derivative dx/dsigma = (x - D(x; sigma)) / sigma."""
-    return (action - denoised) / utils.append_dims(sigma, action.ndim)
+    if torch.is_tensor(sigma) and sigma.ndim > 0:
+        return (action - denoised) / utils.append_dims(sigma.to(action.device), action.ndim)
+    return (action - denoised) / _f(sigma)
 
 
 def default_noise_sampler(x):
@@ -102,6 +104,21 @@ def _sigma(t):
     return t.neg().exp()
 
 
+def _host(sigmas):
+    """Schedules are tiny: keep their scalar arithmetic on the host (fp32 0-dim CPU tensors, exactly the reference's
+    expressions) so that no step of a sampler loop waits on the device for a scalar."""
+    return sigmas.detach().to("cpu", torch.float32) if torch.is_tensor(sigmas) else torch.tensor(sigmas, dtype=torch.float32)
+
+
+def _f(x):
+    """0-dim fp32 host tensor (or number) -> Python float (exact), usable against tensors on any device."""
+    return x.item() if torch.is_tensor(x) else float(x)
+
+
+def _sig_in(sigma, action):
+    return torch.full((action.shape[0],), _f(sigma), device=action.device, dtype=action.dtype)
+
+
 @torch.no_grad()
 def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
                 eta=1.):
@@ -110,15 +127,15 @@ def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None
     extra_args = {} if extra_args is None else extra_args
     if isinstance(model, GCDenoiser) and scaler is None and callback is None and not extra_args:
         return model.sample_ddim(state, action, goal, sigmas)  # fused native loop
-    s_in = action.new_ones([action.shape[0]])
+    sig = _host(sigmas)
     with _hoist(model, state, goal):
-        for i in range(len(sigmas) - 1):
-            denoised = model(state, action, goal, sigmas[i] * s_in, **extra_args)
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
             if callback is not None:
-                callback({'action': action, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
-            t, t_next = _t(sigmas[i]), _t(sigmas[i + 1])
+                callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            t, t_next = _t(sig[i]), _t(sig[i + 1])
             h = t_next - t
-            action = (_sigma(t_next) / _sigma(t)) * action - (-h).expm1() * denoised
+            action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised
     return action
 
 
@@ -127,19 +144,19 @@ def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=Non
                  s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
     """Karras Algorithm 2 without the 2nd-order correction (reference gc_sampling.py:164-209)."""
     extra_args = {} if extra_args is None else extra_args
-    s_in = action.new_ones([action.shape[0]])
-    n = len(sigmas) - 1
+    sig = _host(sigmas)
+    n = len(sig) - 1
     with _hoist(model, state, goal):
         for i in range(n):
-            gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.
-            sigma_hat = sigmas[i] * (gamma + 1)
+            gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0.
+            sigma_hat = sig[i] * (gamma + 1)
             if gamma > 0:
-                action = action + torch.randn_like(action) * s_noise * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
-            denoised = model(state, action, goal, sigma_hat * s_in, **extra_args)
+                action = action + torch.randn_like(action) * s_noise * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+            denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
             d = to_d(action, sigma_hat, denoised)
             if callback is not None:
-                callback({'x': action, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
-            action = action + d * (sigmas[i + 1] - sigma_hat)
+                callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+            action = action + d * _f(sig[i + 1] - sigma_hat)
             if scaler is not None:
                 action = scaler.clip_output(action)
     return action
@@ -150,17 +167,17 @@ def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extr
                            disable=None, eta=1.):
     """Euler steps to sigma_down plus fresh noise sigma_up (reference gc_sampling.py:213-252)."""
     extra_args = {} if extra_args is None else extra_args
-    s_in = action.new_ones([action.shape[0]])
+    sig = _host(sigmas)
     with _hoist(model, state, goal):
-        for i in range(len(sigmas) - 1):
-            denoised = model(state, action, goal, sigmas[i] * s_in, **extra_args)
-            sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
             if callback is not None:
-                callback({'x': action, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
-            d = to_d(action, sigmas[i], denoised)
-            action = action + d * (sigma_down - sigmas[i])
+                callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            d = to_d(action, sig[i], denoised)
+            action = action + d * _f(sigma_down - sig[i])
             if sigma_down > 0:
-                action = action + torch.randn_like(action) * sigma_up
+                action = action + torch.randn_like(action) * _f(sigma_up)
             if scaler is not None:
                 action = scaler.clip_output(action)
     return action
@@ -172,25 +189,25 @@ def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None
     """Karras Algorithm 2 with Heun's trapezoidal correction; plain Euler on the final step to sigma = 0
     (reference gc_sampling.py:256-312)."""
     extra_args = {} if extra_args is None else extra_args
-    s_in = action.new_ones([action.shape[0]])
-    n = len(sigmas) - 1
+    sig = _host(sigmas)
+    n = len(sig) - 1
     with _hoist(model, state, goal):
         for i in range(n):
-            gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.
-            sigma_hat = sigmas[i] * (gamma + 1)
+            gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0.
+            sigma_hat = sig[i] * (gamma + 1)
             if gamma > 0:
-                action = action + torch.randn_like(action) * s_noise * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
-            denoised = model(state, action, goal, sigma_hat * s_in, **extra_args)
+                action = action + torch.randn_like(action) * s_noise * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+            denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
             d = to_d(action, sigma_hat, denoised)
             if callback is not None:
-                callback({'x': action, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
-            dt = sigmas[i + 1] - sigma_hat
-            if sigmas[i + 1] == 0:
+                callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+            dt = _f(sig[i + 1] - sigma_hat)
+            if sig[i + 1] == 0:
                 action = action + d * dt
             else:
                 action_2 = action + d * dt
-                denoised_2 = model(state, action_2, goal, sigmas[i + 1] * s_in, **extra_args)
-                d_2 = to_d(action_2, sigmas[i + 1], denoised_2)
+                denoised_2 = model(state, action_2, goal, _sig_in(sig[i + 1], action), **extra_args)
+                d_2 = to_d(action_2, sig[i + 1], denoised_2)
                 action = action + (d + d_2) / 2 * dt
             if scaler is not None:
                 action = scaler.clip_output(action)
@@ -201,21 +218,21 @@ def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None
 def sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None):
     """DPM-Solver++(2M) multistep (reference gc_sampling.py:699-734)."""
     extra_args = {} if extra_args is None else extra_args
-    s_in = action.new_ones([action.shape[0]])
+    sig = _host(sigmas)
     old_denoised = None
     with _hoist(model, state, goal):
-        for i in range(len(sigmas) - 1):
-            denoised = model(state, action, goal, sigmas[i] * s_in, **extra_args)
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
             if callback is not None:
-                callback({'action': action, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
-            t, t_next = _t(sigmas[i]), _t(sigmas[i + 1])
+                callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            t, t_next = _t(sig[i]), _t(sig[i + 1])
             h = t_next - t
-            if old_denoised is None or sigmas[i + 1] == 0:
+            if old_denoised is None or sig[i + 1] == 0:
                 denoised_d = denoised
             else:
-                r = (t - _t(sigmas[i - 1])) / h
-                denoised_d = (1 + 1 / (2 * r)) * denoised - (1 / (2 * r)) * old_denoised
-            action = (_sigma(t_next) / _sigma(t)) * action - (-h).expm1() * denoised_d
+                r = (t - _t(sig[i - 1])) / h
+                denoised_d = _f(1 + 1 / (2 * r)) * denoised - _f(1 / (2 * r)) * old_denoised
+            action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised_d
             old_denoised = denoised
     return action
 
@@ -225,21 +242,21 @@ def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=
                     eta=1.):
     """DPM-Solver++(2S) single-step second order (reference gc_sampling.py:955-994)."""
     extra_args = {} if extra_args is None else extra_args
-    s_in = action.new_ones([action.shape[0]])
+    sig = _host(sigmas)
     with _hoist(model, state, goal):
-        for i in range(len(sigmas) - 1):
-            denoised = model(state, action, goal, sigmas[i] * s_in, **extra_args)
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
             if callback is not None:
-                callback({'action': action, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
-            if sigmas[i + 1] == 0:
-                action = action + to_d(action, sigmas[i], denoised) * (sigmas[i + 1] - sigmas[i])
+                callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            if sig[i + 1] == 0:
+                action = action + to_d(action, sig[i], denoised) * _f(sig[i + 1] - sig[i])
             else:
-                t, t_next = _t(sigmas[i]), _t(sigmas[i + 1])
+                t, t_next = _t(sig[i]), _t(sig[i + 1])
                 h = t_next - t
                 s = t + 0.5 * h
-                x_2 = (_sigma(s) / _sigma(t)) * action - (-h * 0.5).expm1() * denoised
-                denoised_2 = model(state, x_2, goal, _sigma(s) * s_in, **extra_args)
-                action = (_sigma(t_next) / _sigma(t)) * action - (-h).expm1() * denoised_2
+                x_2 = _f(_sigma(s) / _sigma(t)) * action - _f((-h * 0.5).expm1()) * denoised
+                denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action), **extra_args)
+                action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised_2
             if scaler is not None:
                 action = scaler.clip_output(action)
     return action
