@@ -76,11 +76,24 @@ __global__ void k_pack_weight(const float* __restrict__ w, int n_rows, int K, fl
 // fused GEMM:  out = epilogue( prologue(A) @ W^T )
 //   workgroup = 256 threads (4 waves); tile = (MTILES*16 rows) x (4 waves * NTW * 16 columns); full K.
 //   wave w owns NTW column tiles and ALL row tiles of the workgroup tile.
+//   Memory-level parallelism rule for every phase: all global loads of a phase are issued back to back from
+//   clamped (always valid) addresses, consumed afterwards; validity is applied by selects / masked stores.  A
+//   branch around a load makes hipcc wait vmcnt(0) right behind it -- one full L2 round trip per load.
 // ------------------------------------------------------------------------------------------------
-template <int MTILES, int NTW>
-__global__ __launch_bounds__(256) void k_gemm(mdt_gemm_args a, int kchunk, int grid_n) {
+// prologue kinds: plain copy | LayerNorm | LayerNorm + modulate with ONE broadcast row (sampler: one sigma per
+// step) | LayerNorm + modulate with a per-sample row (GCDenoiser.forward / loss with per-sample sigma)
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_LN_MOD_BCAST = 2, PRO_LN_MOD_ROWS = 3 };
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a : b; }
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float hsq4(f32x4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+
+template <int MTILES, int NTW, int PRO>
+__global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(mdt_gemm_args a, int kchunk, int grid_n, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MT = MTILES * 16;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int by = logical / grid_n, bx = logical % grid_n;
@@ -93,73 +106,124 @@ __global__ __launch_bounds__(256) void k_gemm(mdt_gemm_args a, int kchunk, int g
 #pragma unroll
     for (int i = 0; i < MTILES; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
 
     for (int k0 = 0; k0 < a.K; k0 += kchunk) {
         const int klen = min(kchunk, a.K - k0);
         if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
-        if (a.ln) {
-            // ---- LayerNorm (+ adaLN modulate) prologue: one wave per row, whole row in registers ----
-            constexpr int RPW = MT / 4;  // rows per wave
-            const int n4 = klen >> 2;    // float4 per row (<= 128)
-            f32x4 v[RPW][2];
+        if constexpr (PRO != PRO_PLAIN) {
+            // ---- LayerNorm (+ adaLN modulate) prologue: each wave owns a slab of RPW consecutive rows, whole
+            //      rows live in registers (K <= 512 -> two float4 per lane) ----
+            constexpr int RPW = MT / 4;
+            const int n4 = klen >> 2;
+            const int r0 = wave * RPW;
+            int cc[2];
+            bool cv[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                cv[p] = lane + 64 * p < n4;
+                cc[p] = 4 * min(lane + 64 * p, n4 - 1);
+            }
+            f32x4 v[RPW][2], w[2], bb[2];
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int m = m0 + wave + 4 * r;
+                const int64_t m = min(m0 + r0 + r, a.M - 1);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) v[r][p] = ldg4(a.A + m * a.lda + cc[p]);
+            }
+            const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                w[p] = ldg4(a.ln_w + cc[p]);
+                bb[p] = ldg4(lnb + cc[p]);
+            }
+            // modulation vectors, fetched up front.  BCAST: one row for the whole batch.  ROWS: a slab of RPW
+            // consecutive rows touches at most 2 samples when rows_per_sample >= RPW -> two candidates.
+            constexpr int NC = PRO == PRO_LN_MOD_ROWS ? 2 : 1;
+            f32x4 sh[NC][2], sc[NC][2];
+            int s_lo = 0;
+            bool slow_mod = false;
+            if constexpr (PRO == PRO_LN_MOD_BCAST) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int c4 = lane + 64 * p;
-                    v[r][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (m < a.M && c4 < n4) v[r][p] = *(const f32x4*)(a.A + (int64_t)m * a.lda + 4 * c4);
+                    sh[0][p] = ldg4(a.mod + a.shift_off + cc[p]);
+                    sc[0][p] = ldg4(a.mod + a.scale_off + cc[p]);
+                }
+            }
+            if constexpr (PRO == PRO_LN_MOD_ROWS) {
+                s_lo = min(m0 + r0, a.M - 1) / a.rows_per_sample;
+                const int s_hi = min(m0 + r0 + RPW - 1, a.M - 1) / a.rows_per_sample;
+                slow_mod = s_hi > s_lo + 1;
+                const float* mlo = a.mod + (int64_t)s_lo * a.mod_stride;
+                const float* mhi = a.mod + (int64_t)min(s_lo + 1, s_hi) * a.mod_stride;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    sh[0][p] = ldg4(mlo + a.shift_off + cc[p]);
+                    sc[0][p] = ldg4(mlo + a.scale_off + cc[p]);
+                    sh[NC - 1][p] = ldg4(mhi + a.shift_off + cc[p]);
+                    sc[NC - 1][p] = ldg4(mhi + a.scale_off + cc[p]);
                 }
             }
             const float inv_k = 1.0f / (float)klen;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int row = wave + 4 * r, m = m0 + row;
+                const int m = m0 + r0 + r;
                 float s = 0.f;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) s += (v[r][p].x + v[r][p].y) + (v[r][p].z + v[r][p].w);
+                for (int p = 0; p < 2; ++p) {
+                    v[r][p] = sel4(cv[p], v[r][p], zero4);
+                    s += hsum4(v[r][p]);
+                }
                 const float mean = wave_sum(s) * inv_k;
                 float sq = 0.f;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int c4 = lane + 64 * p;
-                    if (c4 < n4) {
-                        v[r][p] -= mean;
-                        sq += (v[r][p].x * v[r][p].x + v[r][p].y * v[r][p].y) +
-                              (v[r][p].z * v[r][p].z + v[r][p].w * v[r][p].w);
-                    }
+                    v[r][p] = sel4(cv[p], v[r][p] - mean, zero4);
+                    sq += hsq4(v[r][p]);
                 }
                 const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_k + 1e-5f);
-                const float* modrow = nullptr;
-                if (a.mod != nullptr && a.shift_off >= 0 && m < a.M)
-                    modrow = a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int c4 = lane + 64 * p;
-                    if (c4 < n4) {
-                        f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (m < a.M) {
-                            y = v[r][p] * rstd * *(const f32x4*)(a.ln_w + 4 * c4);
-                            if (a.ln_b != nullptr) y += *(const f32x4*)(a.ln_b + 4 * c4);
-                            if (modrow != nullptr)
-                                y = *(const f32x4*)(modrow + a.shift_off + 4 * c4) +
-                                    y * *(const f32x4*)(modrow + a.scale_off + 4 * c4);
+                    f32x4 y = v[r][p] * rstd * w[p] + bb[p];
+                    if constexpr (PRO == PRO_LN_MOD_BCAST) y = sh[0][p] + y * sc[0][p];
+                    if constexpr (PRO == PRO_LN_MOD_ROWS) {
+                        const int smp = min(m, a.M - 1) / a.rows_per_sample;
+                        f32x4 shv = sel4(smp == s_lo, sh[0][p], sh[NC - 1][p]);
+                        f32x4 scv = sel4(smp == s_lo, sc[0][p], sc[NC - 1][p]);
+                        if (slow_mod) {  // rows_per_sample < RPW: rare generic path, one round trip per row
+                            const float* mr = a.mod + (int64_t)smp * a.mod_stride;
+                            shv = ldg4(mr + a.shift_off + cc[p]);
+                            scv = ldg4(mr + a.scale_off + cc[p]);
                         }
-                        *(f32x4*)(lds + row * stride + 4 * c4) = y;
+                        y = shv + y * scv;
                     }
+                    y = sel4(m < a.M, y, zero4);
+                    if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
                 }
             }
         } else {
-            // ---- plain staging of the (MT x klen) activation chunk ----
+            // ---- plain staging of the (MT x klen) activation chunk, 12 loads in flight per lane ----
+            constexpr int BATCH = 12;
             const int n4 = klen >> 2;
-            for (int idx = tid; idx < MT * n4; idx += 256) {
-                const int row = idx / n4, c4 = idx - row * n4;
-                const int m = m0 + row;
-                f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (m < a.M) y = *(const f32x4*)(a.A + (int64_t)m * a.lda + k0 + 4 * c4);
-                *(f32x4*)(lds + row * stride + 4 * c4) = y;
+            const int total = MT * n4;
+            for (int base = 0; base < total; base += 256 * BATCH) {
+                f32x4 t[BATCH];
+                int off[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int idx = min(base + u * 256 + tid, total - 1);
+                    const int row = idx / n4, c4 = idx - row * n4;
+                    const int64_t m = min(m0 + row, a.M - 1);
+                    t[u] = ldg4(a.A + m * a.lda + k0 + 4 * c4);
+                    off[u] = m0 + row < a.M ? row * stride + 4 * c4 : -(row * stride + 4 * c4) - 1;
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    if (base + u * 256 + tid < total) {
+                        const bool ok = off[u] >= 0;
+                        *(f32x4*)(lds + (ok ? off[u] : -off[u] - 1)) = sel4(ok, t[u], zero4);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -174,19 +238,19 @@ __global__ __launch_bounds__(256) void k_gemm(mdt_gemm_args a, int kchunk, int g
             }
             const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
 
-            // 3-deep register ring of weight fragments: two 1-KiB loads per column tile always in flight
+            // 3-deep register ring of weight fragments: two 1-KiB loads per column tile always in flight;
+            // the prefetch index is clamped (never branches), so the loop body is straight-line code
             f32x4 b0[NTW], b1[NTW], b2[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                b0[j] = *(const f32x4*)(wp[j]);
-                b1[j] = nk > 1 ? *(const f32x4*)(wp[j] + 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                b0[j] = ldg4(wp[j]);
+                b1[j] = ldg4(wp[j] + min(1, nk - 1) * 256);
             }
 #define MDT_KSTEP(BU, BP, KC)                                                                          \
     {                                                                                                  \
-        if ((KC) + 2 < nk) {                                                                           \
-            _Pragma("unroll") for (int j = 0; j < NTW; ++j) BP[j] =                                    \
-                *(const f32x4*)(wp[j] + ((KC) + 2) * 256);                                             \
-        }                                                                                              \
+        const int kpf = min((KC) + 2, nk - 1);                                                         \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j) BP[j] = ldg4(wp[j] + kpf * 256);               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
         f32x4 av[MTILES];                                                                              \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                     \
             *(const f32x4*)(ap + i * 16 * stride + (KC) * 16);                                         \
@@ -213,86 +277,150 @@ __global__ __launch_bounds__(256) void k_gemm(mdt_gemm_args a, int kchunk, int g
 
     // ---- epilogue: lane holds out[m0 + i*16 + lane%16][n .. n+3], n = tile*16 + 4*(lane/16) ----
     if (nt0 >= N16) return;
+    const int nq = 4 * (lane >> 4);
+    int ncol[NTW];
+    f32x4 bias_v[NTW];
+    const float* biasp = a.bias != nullptr ? a.bias : zeros;
+    const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
+        bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
+    }
+    const bool gated = a.residual && a.gate_off >= 0;
+    f32x4 gate_v[MTILES][NTW], res_v[MTILES][NTW];
+    float* optr[MTILES][NTW];
 #pragma unroll
     for (int i = 0; i < MTILES; ++i) {
-        const int m = m0 + i * 16 + (lane & 15);
-        if (m >= a.M) continue;
+        const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
         const int64_t orow = (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
-        const float* gate = nullptr;
-        if (a.residual && a.gate_off >= 0)
-            gate = a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride + a.gate_off;
+        const float* gp = gated ? a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride + a.gate_off : zeros;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            if (nt0 + j >= N16) continue;
-            const int n = (nt0 + j) * 16 + 4 * (lane >> 4);
-            f32x4 v = acc[i][j];
-            if (a.bias != nullptr) v += *(const f32x4*)(a.bias + n);
-            if (a.rowvec != nullptr) v += *(const f32x4*)(a.rowvec + n);
-            v = apply_act(v, a.act);
-            float* o = a.out + orow * a.ldo + n;
-            if (a.residual) {
-                if (gate != nullptr) v *= *(const f32x4*)(gate + n);
-                v += *(const f32x4*)o;
-            }
-            *(f32x4*)o = v;
+            optr[i][j] = a.out + orow * a.ldo + ncol[j];
+            gate_v[i][j] = ldg4(gp + ncol[j]);
+        }
+    }
+    if (a.residual) {
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) res_v[i][j] = ldg4(optr[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i) {
+        const bool mok = m0 + i * 16 + (lane & 15) < a.M;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
+            if (a.residual) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
+            if (mok && nt0 + j < N16) *(f32x4*)optr[i][j] = v;
         }
     }
 }
 
-template <int MTILES, int NTW>
+static float* g_zeros = nullptr;  // 64 KiB of zeros: stands in for absent bias / rowvec / LayerNorm-bias vectors
+static const int ZEROS_FLOATS = 16384;
+
+template <int MTILES, int NTW, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
     const int MT = MTILES * 16, NT = 4 * NTW * 16;
     const int gn = (a.N + NT - 1) / NT, gm = (a.M + MT - 1) / MT;
     const size_t lds = (size_t)MT * (kchunk + 4) * sizeof(float);
     static size_t lds_attr = 0;  // per instantiation
     if (lds > lds_attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_gemm<MTILES, NTW>), dim3(gn * gm), dim3(256), lds, s, a, kchunk, gn);
+    hipLaunchKernelGGL((k_gemm<MTILES, NTW, PRO>), dim3(gn * gm), dim3(256), lds, s, a, kchunk, gn, g_zeros);
     return hipGetLastError();
 }
 
 int mdt_gemm_kchunk(int K, int ln) {
     if (ln || K <= 512) return K;
-    // largest multiple of 16 that divides K and is <= 512 (keeps the activation tile <= 66 KiB of LDS)
-    for (int c = 512; c >= 16; c -= 16)
+    // largest multiple of 16 that divides K and is <= 384 (activation chunk <= 49 KiB of LDS -> 3 workgroups/CU)
+    for (int c = 384; c >= 16; c -= 16)
         if (K % c == 0) return c;
     return 16;
 }
 
+template <int MTILES, int NTW>
+static hipError_t launch_gemm_pro(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
+    if (!a.ln) return launch_gemm_t<MTILES, NTW, PRO_PLAIN>(a, kchunk, s);
+    if (a.mod != nullptr && a.shift_off >= 0)
+        return a.mod_stride == 0 ? launch_gemm_t<MTILES, NTW, PRO_LN_MOD_BCAST>(a, kchunk, s)
+                                 : launch_gemm_t<MTILES, NTW, PRO_LN_MOD_ROWS>(a, kchunk, s);
+    return launch_gemm_t<MTILES, NTW, PRO_LN>(a, kchunk, s);
+}
+
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
+    if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
+    if (g_zeros == nullptr) {
+        hipError_t e = hipMalloc((void**)&g_zeros, ZEROS_FLOATS * sizeof(float));
+        if (e != hipSuccess) return e;
+        e = hipMemset(g_zeros, 0, ZEROS_FLOATS * sizeof(float));
+        if (e != hipSuccess) return e;
+    }
     const int kchunk = mdt_gemm_kchunk(a.K, a.ln);
     // tile selection: 32 rows x 128 columns (two column tiles per wave) when that still yields >= 2 workgroups
     // per CU; otherwise 32 x 64 (N = d projections at B = 256 would give only 240 of the larger tiles).
     const int gm = (a.M + 31) / 32;
     const int big = ((a.N + 127) / 128) * gm;
-    if (big >= 512) return launch_gemm_t<2, 2>(a, kchunk, s);
-    return launch_gemm_t<2, 1>(a, kchunk, s);
+    if (big >= 512) return launch_gemm_pro<2, 2>(a, kchunk, s);
+    return launch_gemm_pro<2, 1>(a, kchunk, s);
 }
 
 // ------------------------------------------------------------------------------------------------
-// small attention: one thread per (sample, head, query row); Tq, Tk <= 16; scores live in registers.
-// 10x10 / 10x4 / 4x4 score matrices: 0.1 % of the FLOPs, so this stays on the VALU.
+// small attention: one workgroup per sample.  The sample's q / k / v rows (all heads) are staged in LDS with
+// batched 16-byte loads, then thread (head, query row) runs softmax(q k^T) v out of LDS with the scores in
+// registers.  10x10 / 10x4 / 4x4 score matrices are 0.1 % of the FLOPs, so this stays on the VALU.
 // ------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __restrict__ rope_cos,
                                               const float* __restrict__ rope_sin, float scale) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int total = a.B * a.H * a.Tq;
-    if (gid >= total) return;
-    const int t = gid % a.Tq;
-    const int h = (gid / a.Tq) % a.H;
-    const int b = gid / (a.Tq * a.H);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ROT = 32;  // rotary dims (position_embeddings.py / transformer_blocks.py:108)
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int D = a.H * HD, d4 = D >> 2;
+    float* qs = lds;                  // [Tq][D]
+    float* ks = qs + a.Tq * D;        // [Tk][D]
+    float* vs = ks + a.Tk * D;        // [Tk][D]
+    const int nq = a.Tq * d4, nkv = a.Tk * d4, total = nq + 2 * nkv;
+    constexpr int BATCH = 12;
+    for (int base = 0; base < total; base += 256 * BATCH) {
+        f32x4 t[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = min(base + u * 256 + tid, total - 1);
+            const float* src;
+            if (idx < nq) {
+                const int r = idx / d4;
+                src = a.q + (int64_t)(b * a.Tq + r) * a.ldq + 4 * (idx - r * d4);
+            } else if (idx < nq + nkv) {
+                const int i2 = idx - nq, r = i2 / d4;
+                src = a.k + (int64_t)(b * a.Tk + r) * a.ldkv + 4 * (i2 - r * d4);
+            } else {
+                const int i2 = idx - nq - nkv, r = i2 / d4;
+                src = a.v + (int64_t)(b * a.Tk + r) * a.ldkv + 4 * (i2 - r * d4);
+            }
+            t[u] = ldg4(src);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < total) *(f32x4*)(lds + 4 * idx) = t[u];  // q | k | v are laid out back to back
+        }
+    }
+    __syncthreads();
+    if (tid >= a.H * a.Tq) return;
+    const int t = tid % a.Tq, h = tid / a.Tq;
 
     float q[HD];
-    const float* qp = a.q + (int64_t)(b * a.Tq + t) * a.ldq + h * HD;
 #pragma unroll
     for (int d = 0; d < HD; d += 4) {
-        const f32x4 x = *(const f32x4*)(qp + d);
+        const f32x4 x = *(const f32x4*)(qs + t * D + h * HD + d);
         q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
     }
     if (a.rope) {
@@ -313,7 +441,7 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     for (int j = 0; j < 16; ++j) {
         sc[j] = -INFINITY;
         if (j < nk) {
-            const float* kp = a.k + (int64_t)(b * a.Tk + j) * a.ldkv + h * HD;
+            const float* kp = ks + j * D + h * HD;
             float kr[HD];
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
@@ -352,7 +480,7 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     for (int j = 0; j < 16; ++j) {
         if (j < nk) {
             const float p = sc[j] * inv;
-            const float* vp = a.v + (int64_t)(b * a.Tk + j) * a.ldkv + h * HD;
+            const float* vp = vs + j * D + h * HD;
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
                 const f32x4 x = *(const f32x4*)(vp + d);
@@ -366,19 +494,29 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     for (int d = 0; d < HD; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
 }
 
+template <int HD>
+static hipError_t launch_attn_t(const mdt_attn_args& a, const float* rc, const float* rs, hipStream_t s) {
+    const size_t lds = (size_t)(a.Tq + 2 * a.Tk) * a.H * HD * sizeof(float);
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_attn<HD>), dim3(a.B), dim3(256), lds, s, a, rc, rs, 1.0f / sqrtf((float)HD));
+    return hipGetLastError();
+}
+
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin,
                                 hipStream_t s) {
-    const int total = a.B * a.H * a.Tq;
-    const int grid = (total + 255) / 256;
-    const float scale = 1.0f / sqrtf((float)a.hd);
+    if (a.H * a.Tq > 256 || (size_t)(a.Tq + 2 * a.Tk) * a.H * a.hd * sizeof(float) > 160 * 1024) return hipErrorInvalidValue;
     switch (a.hd) {
-        case 16: hipLaunchKernelGGL((k_attn<16>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
-        case 32: hipLaunchKernelGGL((k_attn<32>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
-        case 48: hipLaunchKernelGGL((k_attn<48>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
-        case 64: hipLaunchKernelGGL((k_attn<64>), dim3(grid), dim3(256), 0, s, a, rope_cos, rope_sin, scale); break;
+        case 16: return launch_attn_t<16>(a, rope_cos, rope_sin, s);
+        case 32: return launch_attn_t<32>(a, rope_cos, rope_sin, s);
+        case 48: return launch_attn_t<48>(a, rope_cos, rope_sin, s);
+        case 64: return launch_attn_t<64>(a, rope_cos, rope_sin, s);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
