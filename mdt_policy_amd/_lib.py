@@ -102,7 +102,10 @@ def load() -> C.CDLL:
         if _lib is not None:
             return _lib
         path = _build.LIB
-        if not os.path.exists(path) or (_build.needs_build() and _build.shutil.which("hipcc")):
+        override = os.environ.get("MDT_HIP_LIB")  # tuning A/B runs: an experimental build of the same sources
+        if override:
+            path = override
+        elif not os.path.exists(path) or (_build.needs_build() and _build.shutil.which("hipcc")):
             try:
                 path = _build.build_library()
             except Exception as e:  # no hipcc and no prebuilt library: there is nothing to run

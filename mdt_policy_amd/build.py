@@ -34,12 +34,14 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip -> csrc/libmdt_hip.so for gfx950; returns the library path."""
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = False, out: str = None, defines=()) -> str:
+    """Compile csrc/*.hip -> csrc/libmdt_hip.so for gfx950; returns the library path.
+    ``out`` / ``defines`` build an experimental variant next to the product library (tuning A/B runs)."""
+    if out is None and not force and not needs_build():
         return LIB
+    out = out or LIB
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", "-o", LIB]
+           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", "-o", out] + [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -48,8 +50,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
     if verbose and res.stderr.strip():
         print(res.stderr, file=sys.stderr)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build_library(force="--force" in sys.argv, verbose=True, out=outs[0] if outs else None, defines=defs))

@@ -89,10 +89,33 @@ __device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a :
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float hsq4(f32x4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 
+// batched wave reduction: N independent sums advance through the 6 butterfly steps together, so the ~100-cycle
+// ds_bpermute latency of a step is paid once per step instead of once per value
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float t[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], off, WAVE);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += t[i];
+    }
+}
+
+#ifndef MDT_LN_WAVES
+#define MDT_LN_WAVES 3  // workgroups per CU the LayerNorm-prologue variants are register-limited to
+#endif
 template <int MTILES, int NTW, int PRO>
-__global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(mdt_gemm_args a, int kchunk, int grid_n, const float* __restrict__ zeros) {
+__global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : (PRO == PRO_PLAIN ? 3 : MDT_LN_WAVES)) void k_gemm(
+    mdt_gemm_args a, int kchunk, int grid_n, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MT = MTILES * 16;
+    // weight-fragment ring: R-1 k-steps of 1-KiB loads in flight per column tile.  A k-step is 8 MFMAs (256 cycles)
+    // with one column tile per wave and 16 MFMAs with two, so the narrow variant needs the deeper ring.
+    constexpr int R = NTW == 1 ? 6 : 3;
+    constexpr bool EARLY = NTW == 1;     // residual GEMMs: fetch bias/gate/residual under the last MFMA loop
+    constexpr int BATCH = 12;            // activation staging loads in flight per lane
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -100,7 +123,24 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(md
     const int m0 = by * MT;
     const int N16 = a.N >> 4, K16 = a.K >> 4;
     const int nt0 = (bx * 4 + wave) * NTW;
-    const int stride = kchunk + 4;  // floats; 16-byte aligned rows, breaks the power-of-two bank stride
+    const bool active = nt0 < N16;   // wave has at least one real column tile
+    const int stride = kchunk + 4;   // floats; 16-byte aligned rows, breaks the power-of-two bank stride
+
+    // ---- weight stream: one continuous k16 index over the whole K, independent of the LDS chunking ----
+    const float* wp[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = min(nt0 + j, N16 - 1);  // clamp: a partial last wave re-reads a valid tile
+        wp[j] = a.Wp + (int64_t)nt * K16 * 256 + lane * 4;
+    }
+    f32x4 ring[R][NTW];
+    auto ring_preload = [&]() {
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
+    };
+    if constexpr (PRO == PRO_PLAIN) ring_preload();  // LayerNorm variants preload after their register-heavy prologue
 
     f32x4 acc[MTILES][NTW];
 #pragma unroll
@@ -108,12 +148,65 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(md
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
 
+    // ---- epilogue operands (bias, gate, residual); issued under the last MFMA loop when EARLY ----
+    const int nq = 4 * (lane >> 4);
+    const bool gated = a.residual && a.gate_off >= 0;
+    f32x4 bias_v[NTW], gate_v[MTILES][NTW], res_v[MTILES][NTW];
+    auto out_ptr = [&](int i, int j) -> float* {
+        const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
+        return a.out + ((int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff) * a.ldo + min(nt0 + j, N16 - 1) * 16 + nq;
+    };
+    auto epilogue_loads = [&]() {
+        const float* biasp = a.bias != nullptr ? a.bias : zeros;
+        const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = min(nt0 + j, N16 - 1) * 16 + nq;
+            bias_v[j] = ldg4(biasp + n) + ldg4(rvp + n);
+        }
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
+            const float* gp = gated ? a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride + a.gate_off : zeros;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                gate_v[i][j] = ldg4(gp + min(nt0 + j, N16 - 1) * 16 + nq);
+                res_v[i][j] = a.residual ? ldg4(out_ptr(i, j)) : zero4;
+            }
+        }
+    };
+
+    // ---- activation staging helpers (plain prologue) ----
+    f32x4 st[BATCH];
+    auto stage_load = [&](int k0, int klen, int base) {
+        const int n4 = klen >> 2, total = MT * n4;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = min(base + u * 256 + tid, total - 1);
+            const int row = idx / n4, c4 = idx - row * n4;
+            const int64_t m = min(m0 + row, a.M - 1);
+            st[u] = ldg4(a.A + m * a.lda + k0 + 4 * c4);
+        }
+    };
+    auto stage_store = [&](int klen, int base) {
+        const int n4 = klen >> 2, total = MT * n4;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < total) {
+                const int row = idx / n4, c4 = idx - row * n4;
+                *(f32x4*)(lds + row * stride + 4 * c4) = sel4(m0 + row < a.M, st[u], zero4);
+            }
+        }
+    };
+
+    int kg = 0;  // global k16 index of the weight stream
     for (int k0 = 0; k0 < a.K; k0 += kchunk) {
         const int klen = min(kchunk, a.K - k0);
-        if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
+        const bool last_chunk = k0 + kchunk >= a.K;
         if constexpr (PRO != PRO_PLAIN) {
             // ---- LayerNorm (+ adaLN modulate) prologue: each wave owns a slab of RPW consecutive rows, whole
-            //      rows live in registers (K <= 512 -> two float4 per lane) ----
+            //      rows live in registers (K <= 512 -> two float4 per lane); single chunk by construction ----
             constexpr int RPW = MT / 4;
             const int n4 = klen >> 2;
             const int r0 = wave * RPW;
@@ -165,23 +258,32 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(md
                 }
             }
             const float inv_k = 1.0f / (float)klen;
+            float red[RPW];
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int m = m0 + r0 + r;
-                float s = 0.f;
+                red[r] = 0.f;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     v[r][p] = sel4(cv[p], v[r][p], zero4);
-                    s += hsum4(v[r][p]);
+                    red[r] += hsum4(v[r][p]);
                 }
-                const float mean = wave_sum(s) * inv_k;
-                float sq = 0.f;
+            }
+            wave_sum_n<RPW>(red);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float mean = red[r] * inv_k;
+                red[r] = 0.f;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     v[r][p] = sel4(cv[p], v[r][p] - mean, zero4);
-                    sq += hsq4(v[r][p]);
+                    red[r] += hsq4(v[r][p]);
                 }
-                const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_k + 1e-5f);
+            }
+            wave_sum_n<RPW>(red);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int m = m0 + r0 + r;
+                const float rstd = 1.0f / sqrtf(red[r] * inv_k + 1e-5f);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     f32x4 y = v[r][p] * rstd * w[p] + bb[p];
@@ -201,55 +303,35 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(md
                     if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the weight preload (and its registers) behind the prologue
+            ring_preload();
         } else {
-            // ---- plain staging of the (MT x klen) activation chunk, 12 loads in flight per lane ----
-            constexpr int BATCH = 12;
-            const int n4 = klen >> 2;
-            const int total = MT * n4;
-            for (int base = 0; base < total; base += 256 * BATCH) {
-                f32x4 t[BATCH];
-                int off[BATCH];
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int idx = min(base + u * 256 + tid, total - 1);
-                    const int row = idx / n4, c4 = idx - row * n4;
-                    const int64_t m = min(m0 + row, a.M - 1);
-                    t[u] = ldg4(a.A + m * a.lda + k0 + 4 * c4);
-                    off[u] = m0 + row < a.M ? row * stride + 4 * c4 : -(row * stride + 4 * c4) - 1;
-                }
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    if (base + u * 256 + tid < total) {
-                        const bool ok = off[u] >= 0;
-                        *(f32x4*)(lds + (ok ? off[u] : -off[u] - 1)) = sel4(ok, t[u], zero4);
-                    }
-                }
+            // ---- plain staging of the (MT x klen) activation chunk.  First chunk: load + store here (further
+            //      batches only when klen > 384).  Later chunks were prefetched into st[] under the previous
+            //      chunk's MFMA loop (multi-chunk K implies klen <= 384 = one batch). ----
+            if (k0 == 0) stage_load(0, klen, 0);
+            else __syncthreads();  // everyone is done reading the previous chunk
+            stage_store(klen, 0);
+            for (int base = 256 * BATCH; base < MT * (klen >> 2); base += 256 * BATCH) {
+                stage_load(k0, klen, base);
+                stage_store(klen, base);
             }
         }
         __syncthreads();
+        if constexpr (PRO == PRO_PLAIN) {
+            if (!last_chunk) stage_load(k0 + kchunk, min(kchunk, a.K - k0 - kchunk), 0);  // next chunk -> registers
+        }
+        if (last_chunk && EARLY) epilogue_loads();  // epilogue operands travel under the last MFMA loop
 
-        if (nt0 < N16) {
+        if (active) {
             const int nk = klen >> 4;
-            const float* wp[NTW];
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int nt = min(nt0 + j, N16 - 1);  // clamp: a partial last wave re-reads a valid tile
-                wp[j] = a.Wp + ((int64_t)nt * K16 + (k0 >> 4)) * 256 + lane * 4;
-            }
             const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
-
-            // 3-deep register ring of weight fragments: two 1-KiB loads per column tile always in flight;
-            // the prefetch index is clamped (never branches), so the loop body is straight-line code
-            f32x4 b0[NTW], b1[NTW], b2[NTW];
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                b0[j] = ldg4(wp[j]);
-                b1[j] = ldg4(wp[j] + min(1, nk - 1) * 256);
-            }
-#define MDT_KSTEP(BU, BP, KC)                                                                          \
+            // one k-step: prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
+#define MDT_KSTEP(U, KC)                                                                               \
     {                                                                                                  \
-        const int kpf = min((KC) + 2, nk - 1);                                                         \
-        _Pragma("unroll") for (int j = 0; j < NTW; ++j) BP[j] = ldg4(wp[j] + kpf * 256);               \
+        const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                               \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                   \
+            ldg4(wp[j] + kpf * 256);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         f32x4 av[MTILES];                                                                              \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                     \
@@ -257,56 +339,47 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(md
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
             _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                       \
                 _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                            \
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(BU[j][e], av[i][e], acc[i][j], 0, 0, 0);      \
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0); \
             }                                                                                          \
         }                                                                                              \
     }
             int kc = 0;
-            for (; kc + 3 <= nk; kc += 3) {
-                MDT_KSTEP(b0, b2, kc)
-                MDT_KSTEP(b1, b0, kc + 1)
-                MDT_KSTEP(b2, b1, kc + 2)
+            for (; kc + R <= nk; kc += R) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
             }
+            // tail (nk % R steps); chunk lengths that are multiples of 16*R (96 / 64) never get here
             if (kc < nk) {
-                MDT_KSTEP(b0, b2, kc)
-                if (kc + 1 < nk) MDT_KSTEP(b1, b0, kc + 1)
+                const int rem = nk - kc;
+#pragma unroll
+                for (int u = 0; u < R - 1; ++u)
+                    if (u < rem) MDT_KSTEP(u, kc + u)
+                // re-align the ring so that slot 0 is again the next k-step
+                if (!last_chunk) {
+                    f32x4 tmp[R][NTW];
+#pragma unroll
+                    for (int u = 0; u < R; ++u)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) tmp[u][j] = ring[u][j];
+#pragma unroll
+                    for (int u = 0; u < R; ++u)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) {
+                            f32x4 x = tmp[0][j];
+#pragma unroll
+                            for (int q = 1; q < R; ++q) x = sel4((u + rem) % R == q, tmp[q][j], x);
+                            ring[u][j] = x;
+                        }
+                }
             }
 #undef MDT_KSTEP
+            kg += nk;
         }
     }
 
     // ---- epilogue: lane holds out[m0 + i*16 + lane%16][n .. n+3], n = tile*16 + 4*(lane/16) ----
-    if (nt0 >= N16) return;
-    const int nq = 4 * (lane >> 4);
-    int ncol[NTW];
-    f32x4 bias_v[NTW];
-    const float* biasp = a.bias != nullptr ? a.bias : zeros;
-    const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
-        bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
-    }
-    const bool gated = a.residual && a.gate_off >= 0;
-    f32x4 gate_v[MTILES][NTW], res_v[MTILES][NTW];
-    float* optr[MTILES][NTW];
-#pragma unroll
-    for (int i = 0; i < MTILES; ++i) {
-        const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
-        const int64_t orow = (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
-        const float* gp = gated ? a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride + a.gate_off : zeros;
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            optr[i][j] = a.out + orow * a.ldo + ncol[j];
-            gate_v[i][j] = ldg4(gp + ncol[j]);
-        }
-    }
-    if (a.residual) {
-#pragma unroll
-        for (int i = 0; i < MTILES; ++i)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) res_v[i][j] = ldg4(optr[i][j]);
-    }
+    if (!active) return;
+    if constexpr (!EARLY) epilogue_loads();
 #pragma unroll
     for (int i = 0; i < MTILES; ++i) {
         const bool mok = m0 + i * 16 + (lane & 15) < a.M;
@@ -314,13 +387,20 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : 3) void k_gemm(md
         for (int j = 0; j < NTW; ++j) {
             f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
             if (a.residual) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
-            if (mok && nt0 + j < N16) *(f32x4*)optr[i][j] = v;
+            if (mok && nt0 + j < N16) *(f32x4*)out_ptr(i, j) = v;
         }
     }
 }
 
-static float* g_zeros = nullptr;  // 64 KiB of zeros: stands in for absent bias / rowvec / LayerNorm-bias vectors
-static const int ZEROS_FLOATS = 16384;
+static float* g_zeros = nullptr;  // 256 KiB of zeros: stands in for absent bias / rowvec / LayerNorm-bias vectors
+static const int ZEROS_FLOATS = 65536;
+
+static hipError_t ensure_zeros() {
+    if (g_zeros != nullptr) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&g_zeros, ZEROS_FLOATS * sizeof(float));
+    if (e != hipSuccess) return e;
+    return hipMemset(g_zeros, 0, ZEROS_FLOATS * sizeof(float));
+}
 
 template <int MTILES, int NTW, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
@@ -357,12 +437,8 @@ static hipError_t launch_gemm_pro(const mdt_gemm_args& a, int kchunk, hipStream_
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
-    if (g_zeros == nullptr) {
-        hipError_t e = hipMalloc((void**)&g_zeros, ZEROS_FLOATS * sizeof(float));
-        if (e != hipSuccess) return e;
-        e = hipMemset(g_zeros, 0, ZEROS_FLOATS * sizeof(float));
-        if (e != hipSuccess) return e;
-    }
+    hipError_t ze = ensure_zeros();
+    if (ze != hipSuccess) return ze;
     const int kchunk = mdt_gemm_kchunk(a.K, a.ln);
     // tile selection: 32 rows x 128 columns (two column tiles per wave) when that still yields >= 2 workgroups
     // per CU; otherwise 32 x 64 (N = d projections at B = 256 would give only 240 of the larger tiles).
@@ -630,67 +706,97 @@ hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t s
 // action head: decoder LN -> action_pred -> EDM combine -> (DDIM update) -> (next step's embedding)
 // one wave per action-token row; A <= 16
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_head(mdt_head_args a) {
+__global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __restrict__ zeros) {
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= a.M) return;
+    const int mraw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (mraw >= a.M) return;  // wave-uniform
+    const int64_t m = mraw;
     const int n4 = a.D >> 2;
-    f32x4 v[2];
-    float rstd;
-    ln_row(a.y + (int64_t)m * a.D, n4, lane, v, rstd);
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cc[2];
+    bool cv[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int c4 = lane + 64 * p;
-        if (c4 < n4) {
-            v[p] = v[p] * rstd * *(const f32x4*)(a.ln_w + 4 * c4);
-            if (a.ln_b != nullptr) v[p] += *(const f32x4*)(a.ln_b + 4 * c4);
-        }
+        cv[p] = lane + 64 * p < n4;
+        cc[p] = 4 * min(lane + 64 * p, n4 - 1);
     }
-    const float sigma = a.sigma[(int64_t)(m / a.rows_per_sample) * a.sigma_stride];
-    const float sd = a.sigma_data;
-    const float den2 = sigma * sigma + sd * sd;
-    const float c_skip = sd * sd / den2;
-    const float c_out = sigma * sd / sqrtf(den2);
-    float ratio = 0.f, coef = 0.f, cin_next = 1.f;
+    // ---- every global operand of the row is requested up front (clamped addresses, no load behind a branch) ----
+    f32x4 v[2], w[2], bb[2], wp[16][2];
+    float xin[16], bpv[16];
+    const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        v[p] = ldg4(a.y + m * a.D + cc[p]);
+        w[p] = ldg4(a.ln_w + cc[p]);
+        bb[p] = ldg4(lnb + cc[p]);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int ce = min(c, a.A - 1);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wp[c][p] = ldg4(a.Wp + (int64_t)ce * a.D + cc[p]);
+        xin[c] = a.x[m * a.A + ce];
+        bpv[c] = a.bp[ce];
+    }
+    const float sigma = a.sigma[(int64_t)(mraw / a.rows_per_sample) * a.sigma_stride];
+    float ratio = 0.f, coef = 0.f, sig_next = 1.f;
     if (a.mode == MDT_HEAD_DDIM) {
         ratio = a.step[0];
         coef = a.step[1];
-        cin_next = edm_c_in(a.step[2], sd);
+        sig_next = a.step[2];
     }
+    // ---- LayerNorm of the row ----
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        v[p] = sel4(cv[p], v[p], zero4);
+        s += hsum4(v[p]);
+    }
+    const float inv_d = 1.0f / (float)a.D;
+    const float mean = wave_sum(s) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        v[p] = sel4(cv[p], v[p] - mean, zero4);
+        sq += hsq4(v[p]);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + 1e-5f);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) v[p] = sel4(cv[p], v[p] * rstd * w[p] + bb[p], zero4);
+    // ---- action_pred: A dot products reduced together ----
     float res[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         res[c] = 0.f;
-        if (c < a.A) {
-            float part = 0.f;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int c4 = lane + 64 * p;
-                if (c4 < n4) {
-                    const f32x4 w = *(const f32x4*)(a.Wp + (int64_t)c * a.D + 4 * c4);
-                    part += (v[p].x * w.x + v[p].y * w.y) + (v[p].z * w.z + v[p].w * w.w);
-                }
-            }
-            const float F = wave_sum(part) + a.bp[c];
-            float r = F;
-            if (a.mode != MDT_HEAD_RAW) {
-                const float xin = a.x[(int64_t)m * a.A + c];
-                const float den = F * c_out + xin * c_skip;
-                r = a.mode == MDT_HEAD_DDIM ? ratio * xin + coef * den : den;
-            }
-            res[c] = r;
+        for (int p = 0; p < 2; ++p)
+            res[c] += (v[p].x * wp[c][p].x + v[p].y * wp[c][p].y) + (v[p].z * wp[c][p].z + v[p].w * wp[c][p].w);
+    }
+    wave_sum_n<16>(res);
+    const float sd = a.sigma_data;
+    const float den2 = sigma * sigma + sd * sd;
+    const float c_skip = sd * sd / den2;
+    const float c_out = sigma * sd / sqrtf(den2);
+    const float cin_next = edm_c_in(sig_next, sd);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float F = res[c] + bpv[c];
+        float r = F;
+        if (a.mode != MDT_HEAD_RAW) {
+            const float den = F * c_out + xin[c] * c_skip;
+            r = a.mode == MDT_HEAD_DDIM ? ratio * xin[c] + coef * den : den;
         }
+        res[c] = r;
     }
     // all lanes hold all A results (xor-butterfly sums); lanes 0..A-1 store one each
 #pragma unroll
     for (int c = 0; c < 16; ++c)
-        if (c < a.A && lane == c) a.out[(int64_t)m * a.A + c] = res[c];
+        if (c < a.A && lane == c) a.out[m * a.A + c] = res[c];
     if (a.y_next != nullptr) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int c4 = lane + 64 * p;
-            if (c4 < n4) {
-                const int n = 4 * c4;
+            if (cv[p]) {
+                const int n = cc[p];
                 f32x4 acc = *(const f32x4*)(a.ba + n);
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
@@ -702,14 +808,16 @@ __global__ __launch_bounds__(256) void k_head(mdt_head_args a) {
                         acc.w = fmaf(xv, a.Wa[(n + 3) * a.A + c], acc.w);
                     }
                 }
-                *(f32x4*)(a.y_next + (int64_t)m * a.D + n) = acc;
+                *(f32x4*)(a.y_next + m * a.D + n) = acc;
             }
         }
     }
 }
 
 hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_head, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+    hipError_t e = ensure_zeros();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_head, dim3((a.M + 3) / 4), dim3(256), 0, s, a, g_zeros);
     return hipGetLastError();
 }
 
