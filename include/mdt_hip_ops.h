@@ -62,6 +62,11 @@ typedef struct {
 
 mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);
 
+/* Tuning / test hook: force the workgroup geometry of every following GEMM launch in this process.
+ * 0 = heuristic (default); 1 = 4 waves 32x64; 2 = 8 waves 32x128; 3 = 8 waves 32x384; 4 = 8 waves 32x512;
+ * 5 = 4 waves 32x128.  All geometries compute identical results (same k order per output element). */
+void mdt_op_set_gemm_geometry(int32_t geometry);
+
 typedef struct {
     const float *q; int64_t ldq;       /* (B*Tq, >= H*hd) query rows                                  */
     const float *k; const float *v;    /* (B*Tk, ...) key / value rows                                */
@@ -92,14 +97,14 @@ typedef struct {
     float sigma_data;
     /* optional fused embedding of the NEXT step's input: y_next = (out * c_in(sigma_next)) Wa^T + ba */
     float *y_next;             /* NULL or (M, D) (may alias y)                                        */
-    const float *Wa, *ba;      /* action_emb.weight (D, A) row-major, bias (D)                        */
+    const float *Wa, *ba;      /* action_emb.weight TRANSPOSED to (A, D) row-major, bias (D)          */
 } mdt_head_args;
 
 mdt_status mdt_op_head(const mdt_head_args *args, void *stream);
 
-/* y = (x * c_in(sigma)) Wa^T + ba   (c_in omitted when sigma == NULL) */
+/* y = (x * c_in(sigma)) Wa^T + ba   (c_in omitted when sigma == NULL); WaT = action_emb.weight transposed to (A, D) */
 mdt_status mdt_op_action_embed(const float *x, const float *sigma, int64_t sigma_stride, float sigma_data,
-                               const float *Wa, const float *ba, float *y, int64_t M, int32_t A, int32_t D,
+                               const float *WaT, const float *ba, float *y, int64_t M, int32_t A, int32_t D,
                                int32_t rows_per_sample, void *stream);
 
 #ifdef __cplusplus

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("mdt_op_packed_numel", _I64, [_I64, _I64]),
     ("mdt_op_pack_weight", _I32, [_VP, _I64, _I64, _VP, _I64, _I64, _VP]),
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
+    ("mdt_op_set_gemm_geometry", None, [_I32]),
     ("mdt_op_attention", _I32, [C.POINTER(AttnArgs), _VP]),
     ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_head", _I32, [C.POINTER(HeadArgs), _VP]),

@@ -6,7 +6,7 @@
 #include "mdt_hip.h"
 #include "mdt_hip_ops.h"
 
-int mdt_gemm_kchunk(int K, int ln);
+int mdt_gemm_kchunk(int K, int ln, int cap);
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s);
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin, hipStream_t s);
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
@@ -21,3 +21,4 @@ hipError_t mdt_launch_noise_input(const float* act, const float* noise, const fl
 hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float* noised, const float* sigma, float sd,
                                   int64_t n, int per_sample, float* loss, hipStream_t s);
 hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* packed, int n_off, hipStream_t s);
+hipError_t mdt_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t s);

@@ -89,6 +89,28 @@ __device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a :
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float hsq4(f32x4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
 
+#ifdef MDT_DEBUG_TIMING
+// tuning-only build (-DMDT_DEBUG_TIMING): thread 0 of every workgroup records shader-clock stamps of its phases
+__device__ unsigned long long* g_dbg_ts = nullptr;
+#define MDT_TS(i)                                                                         \
+    if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
+        g_dbg_ts[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();            \
+    }
+#define MDT_TS_HWID()                                                                     \
+    if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
+        unsigned hw, xcc;                                                                 \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                  \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                \
+        g_dbg_ts[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;      \
+    }
+extern "C" int mdt_debug_set_timing_buffer(unsigned long long* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p));
+}
+#else
+#define MDT_TS(i)
+#define MDT_TS_HWID()
+#endif
+
 // batched wave reduction: N independent sums advance through the 6 butterfly steps together, so the ~100-cycle
 // ds_bpermute latency of a step is paid once per step instead of once per value
 template <int N>
@@ -103,28 +125,28 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
     }
 }
 
-#ifndef MDT_LN_WAVES
-#define MDT_LN_WAVES 3  // workgroups per CU the LayerNorm-prologue variants are register-limited to
-#endif
-template <int MTILES, int NTW, int PRO>
-__global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : (PRO == PRO_PLAIN ? 3 : MDT_LN_WAVES)) void k_gemm(
-    mdt_gemm_args a, int kchunk, int grid_n, const float* __restrict__ zeros) {
+// Geometry: NWAVES waves (4 or 8); tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns), full K.  Wave w owns NTW
+// column tiles and ALL row tiles of the workgroup tile, so a weight fragment is fetched once per workgroup and
+// reused from registers across the row tiles.  Wide tiles (8 waves x NTW 3..4) keep the number of workgroups that
+// re-read / re-normalise the same activation rows at N / (128*NTW) instead of N / 64.
+template <int MTILES, int NTW, int NWAVES, int PRO>
+__global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchunk, int grid_n,
+                                                      const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    MDT_TS(0)
+    MDT_TS_HWID()
     constexpr int MT = MTILES * 16;
-    // weight-fragment ring: R-1 k-steps of 1-KiB loads in flight per column tile.  A k-step is 8 MFMAs (256 cycles)
-    // with one column tile per wave and 16 MFMAs with two, so the narrow variant needs the deeper ring.
-    constexpr int R = NTW == 1 ? 6 : 3;
-    constexpr bool EARLY = NTW == 1;     // residual GEMMs: fetch bias/gate/residual under the last MFMA loop
-    constexpr int BATCH = 12;            // activation staging loads in flight per lane
+    constexpr int NT = 64 * NWAVES;
+    constexpr int R = 3;  // weight-fragment ring: 2 k-steps of 1-KiB loads in flight per column tile
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int by = logical / grid_n, bx = logical % grid_n;
+    const int by = logical / grid_n, bx = logical - by * grid_n;
     const int m0 = by * MT;
     const int N16 = a.N >> 4, K16 = a.K >> 4;
-    const int nt0 = (bx * 4 + wave) * NTW;
-    const bool active = nt0 < N16;   // wave has at least one real column tile
-    const int stride = kchunk + 4;   // floats; 16-byte aligned rows, breaks the power-of-two bank stride
+    const int nt0 = (bx * NWAVES + wave) * NTW;
+    const bool active = nt0 < N16;  // wave has at least one real column tile
+    const int stride = kchunk + 4;  // floats; 16-byte aligned rows, breaks the power-of-two bank stride
 
     // ---- weight stream: one continuous k16 index over the whole K, independent of the LDS chunking ----
     const float* wp[NTW];
@@ -134,13 +156,10 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : (PRO == PRO_PLAIN
         wp[j] = a.Wp + (int64_t)nt * K16 * 256 + lane * 4;
     }
     f32x4 ring[R][NTW];
-    auto ring_preload = [&]() {
 #pragma unroll
-        for (int u = 0; u < R - 1; ++u)
+    for (int u = 0; u < R - 1; ++u)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
-    };
-    if constexpr (PRO == PRO_PLAIN) ring_preload();  // LayerNorm variants preload after their register-heavy prologue
+        for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
 
     f32x4 acc[MTILES][NTW];
 #pragma unroll
@@ -148,67 +167,15 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : (PRO == PRO_PLAIN
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
 
-    // ---- epilogue operands (bias, gate, residual); issued under the last MFMA loop when EARLY ----
-    const int nq = 4 * (lane >> 4);
-    const bool gated = a.residual && a.gate_off >= 0;
-    f32x4 bias_v[NTW], gate_v[MTILES][NTW], res_v[MTILES][NTW];
-    auto out_ptr = [&](int i, int j) -> float* {
-        const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
-        return a.out + ((int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff) * a.ldo + min(nt0 + j, N16 - 1) * 16 + nq;
-    };
-    auto epilogue_loads = [&]() {
-        const float* biasp = a.bias != nullptr ? a.bias : zeros;
-        const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const int n = min(nt0 + j, N16 - 1) * 16 + nq;
-            bias_v[j] = ldg4(biasp + n) + ldg4(rvp + n);
-        }
-#pragma unroll
-        for (int i = 0; i < MTILES; ++i) {
-            const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
-            const float* gp = gated ? a.mod + (int64_t)(m / a.rows_per_sample) * a.mod_stride + a.gate_off : zeros;
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                gate_v[i][j] = ldg4(gp + min(nt0 + j, N16 - 1) * 16 + nq);
-                res_v[i][j] = a.residual ? ldg4(out_ptr(i, j)) : zero4;
-            }
-        }
-    };
-
-    // ---- activation staging helpers (plain prologue) ----
-    f32x4 st[BATCH];
-    auto stage_load = [&](int k0, int klen, int base) {
-        const int n4 = klen >> 2, total = MT * n4;
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const int idx = min(base + u * 256 + tid, total - 1);
-            const int row = idx / n4, c4 = idx - row * n4;
-            const int64_t m = min(m0 + row, a.M - 1);
-            st[u] = ldg4(a.A + m * a.lda + k0 + 4 * c4);
-        }
-    };
-    auto stage_store = [&](int klen, int base) {
-        const int n4 = klen >> 2, total = MT * n4;
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const int idx = base + u * 256 + tid;
-            if (idx < total) {
-                const int row = idx / n4, c4 = idx - row * n4;
-                *(f32x4*)(lds + row * stride + 4 * c4) = sel4(m0 + row < a.M, st[u], zero4);
-            }
-        }
-    };
-
     int kg = 0;  // global k16 index of the weight stream
     for (int k0 = 0; k0 < a.K; k0 += kchunk) {
         const int klen = min(kchunk, a.K - k0);
-        const bool last_chunk = k0 + kchunk >= a.K;
+        const int n4 = klen >> 2;
+        if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
         if constexpr (PRO != PRO_PLAIN) {
             // ---- LayerNorm (+ adaLN modulate) prologue: each wave owns a slab of RPW consecutive rows, whole
             //      rows live in registers (K <= 512 -> two float4 per lane); single chunk by construction ----
-            constexpr int RPW = MT / 4;
-            const int n4 = klen >> 2;
+            constexpr int RPW = MT / NWAVES;
             const int r0 = wave * RPW;
             int cc[2];
             bool cv[2];
@@ -303,73 +270,73 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : (PRO == PRO_PLAIN
                     if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the weight preload (and its registers) behind the prologue
-            ring_preload();
         } else {
-            // ---- plain staging of the (MT x klen) activation chunk.  First chunk: load + store here (further
-            //      batches only when klen > 384).  Later chunks were prefetched into st[] under the previous
-            //      chunk's MFMA loop (multi-chunk K implies klen <= 384 = one batch). ----
-            if (k0 == 0) stage_load(0, klen, 0);
-            else __syncthreads();  // everyone is done reading the previous chunk
-            stage_store(klen, 0);
-            for (int base = 256 * BATCH; base < MT * (klen >> 2); base += 256 * BATCH) {
-                stage_load(k0, klen, base);
-                stage_store(klen, base);
+            // ---- plain staging of the (MT x klen) activation chunk: 32 lanes sweep a row in 512-byte pieces,
+            //      NT/32 rows at a time; all loads of the chunk are in flight together (no divisions) ----
+            constexpr int RG = NT / 32;      // rows covered per sweep
+            constexpr int U = MT / RG;       // sweeps
+            const int rg = tid >> 5, l32 = tid & 31;
+            const int nv = (n4 + 31) >> 5;   // 512-byte pieces per row (<= 6 for kchunk <= 768)
+            for (int v0 = 0; v0 < nv; v0 += 3) {
+                f32x4 st[U][3];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t m = min(m0 + rg + RG * u, a.M - 1);
+#pragma unroll
+                    for (int v = 0; v < 3; ++v)
+                        st[u][v] = ldg4(a.A + m * a.lda + k0 + 4 * min(l32 + 32 * (v0 + v), n4 - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = rg + RG * u;
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const int c4 = l32 + 32 * (v0 + v);
+                        if (c4 < n4) *(f32x4*)(lds + row * stride + 4 * c4) = sel4(m0 + row < a.M, st[u][v], zero4);
+                    }
+                }
             }
         }
+        MDT_TS(1)
         __syncthreads();
-        if constexpr (PRO == PRO_PLAIN) {
-            if (!last_chunk) stage_load(k0 + kchunk, min(kchunk, a.K - k0 - kchunk), 0);  // next chunk -> registers
-        }
-        if (last_chunk && EARLY) epilogue_loads();  // epilogue operands travel under the last MFMA loop
+        MDT_TS(2)
 
         if (active) {
             const int nk = klen >> 4;
             const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
             // one k-step: prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
-#define MDT_KSTEP(U, KC)                                                                               \
-    {                                                                                                  \
-        const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                               \
-        _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                   \
-            ldg4(wp[j] + kpf * 256);                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        f32x4 av[MTILES];                                                                              \
-        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                     \
-            *(const f32x4*)(ap + i * 16 * stride + (KC) * 16);                                         \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
-            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                       \
-                _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                            \
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0); \
-            }                                                                                          \
-        }                                                                                              \
+#define MDT_KSTEP(U, KC)                                                                                  \
+    {                                                                                                     \
+        const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                      \
+            ldg4(wp[j] + kpf * 256);                                                                      \
+        f32x4 av[MTILES];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                        \
+            *(const f32x4*)(ap + i * 16 * stride + (KC) * 16);                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                          \
+                _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                               \
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0);  \
+            }                                                                                             \
+        }                                                                                                 \
     }
             int kc = 0;
             for (; kc + R <= nk; kc += R) {
 #pragma unroll
                 for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
             }
-            // tail (nk % R steps); chunk lengths that are multiples of 16*R (96 / 64) never get here
-            if (kc < nk) {
+            if (kc < nk) {  // tail: nk % 3 steps, then re-align the ring so that slot 0 is the next k-step again
                 const int rem = nk - kc;
+                MDT_KSTEP(0, kc)
+                if (rem > 1) MDT_KSTEP(1, kc + 1)
+                f32x4 t0[NTW], t1[NTW], t2[NTW];
 #pragma unroll
-                for (int u = 0; u < R - 1; ++u)
-                    if (u < rem) MDT_KSTEP(u, kc + u)
-                // re-align the ring so that slot 0 is again the next k-step
-                if (!last_chunk) {
-                    f32x4 tmp[R][NTW];
+                for (int j = 0; j < NTW; ++j) { t0[j] = ring[0][j]; t1[j] = ring[1][j]; t2[j] = ring[2][j]; }
 #pragma unroll
-                    for (int u = 0; u < R; ++u)
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j) tmp[u][j] = ring[u][j];
-#pragma unroll
-                    for (int u = 0; u < R; ++u)
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j) {
-                            f32x4 x = tmp[0][j];
-#pragma unroll
-                            for (int q = 1; q < R; ++q) x = sel4((u + rem) % R == q, tmp[q][j], x);
-                            ring[u][j] = x;
-                        }
+                for (int j = 0; j < NTW; ++j) {
+                    ring[0][j] = rem == 1 ? t1[j] : t2[j];
+                    ring[1][j] = rem == 1 ? t2[j] : t0[j];
+                    ring[2][j] = rem == 1 ? t0[j] : t1[j];
                 }
             }
 #undef MDT_KSTEP
@@ -378,8 +345,33 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : (PRO == PRO_PLAIN
     }
 
     // ---- epilogue: lane holds out[m0 + i*16 + lane%16][n .. n+3], n = tile*16 + 4*(lane/16) ----
+    MDT_TS(3)
     if (!active) return;
-    if constexpr (!EARLY) epilogue_loads();
+    const int nq = 4 * (lane >> 4);
+    const bool gated = a.residual && a.gate_off >= 0;
+    const float* biasp = a.bias != nullptr ? a.bias : zeros;
+    const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+    int ncol[NTW];
+    f32x4 bias_v[NTW], gate_v[MTILES][NTW], res_v[MTILES][NTW];
+    float* optr[MTILES];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
+        bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i) {
+        const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
+        const int64_t orow = a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
+        optr[i] = a.out + orow * a.ldo;
+        const float* gp = zeros;
+        if (gated) gp = a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            gate_v[i][j] = ldg4(gp + ncol[j]);
+            res_v[i][j] = a.residual ? ldg4(optr[i] + ncol[j]) : zero4;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MTILES; ++i) {
         const bool mok = m0 + i * 16 + (lane & 15) < a.M;
@@ -387,9 +379,10 @@ __global__ __launch_bounds__(256, PRO == PRO_LN_MOD_ROWS ? 2 : (PRO == PRO_PLAIN
         for (int j = 0; j < NTW; ++j) {
             f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
             if (a.residual) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
-            if (mok && nt0 + j < N16) *(f32x4*)out_ptr(i, j) = v;
+            if (mok && nt0 + j < N16) *(f32x4*)(optr[i] + ncol[j]) = v;
         }
     }
+    MDT_TS(4)
 }
 
 static float* g_zeros = nullptr;  // 256 KiB of zeros: stands in for absent bias / rowvec / LayerNorm-bias vectors
@@ -402,51 +395,67 @@ static hipError_t ensure_zeros() {
     return hipMemset(g_zeros, 0, ZEROS_FLOATS * sizeof(float));
 }
 
-template <int MTILES, int NTW, int PRO>
+template <int MTILES, int NTW, int NWAVES, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
-    const int MT = MTILES * 16, NT = 4 * NTW * 16;
-    const int gn = (a.N + NT - 1) / NT, gm = (a.M + MT - 1) / MT;
+    const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
+    const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
     const size_t lds = (size_t)MT * (kchunk + 4) * sizeof(float);
     static size_t lds_attr = 0;  // per instantiation
     if (lds > lds_attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW, PRO>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW, NWAVES, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_gemm<MTILES, NTW, PRO>), dim3(gn * gm), dim3(256), lds, s, a, kchunk, gn, g_zeros);
+    hipLaunchKernelGGL((k_gemm<MTILES, NTW, NWAVES, PRO>), dim3(gn * gm), dim3(64 * NWAVES), lds, s, a, kchunk, gn,
+                       g_zeros);
     return hipGetLastError();
 }
 
-int mdt_gemm_kchunk(int K, int ln) {
+// activation chunk length: whole K when it fits (always for the LayerNorm prologue), else the largest divisor of K
+// that is a multiple of 16 and <= cap (cap 768 = 97 KiB of LDS for the one-workgroup-per-CU wide tiles, else 384)
+int mdt_gemm_kchunk(int K, int ln, int cap) {
     if (ln || K <= 512) return K;
-    // largest multiple of 16 that divides K and is <= 384 (activation chunk <= 49 KiB of LDS -> 3 workgroups/CU)
-    for (int c = 384; c >= 16; c -= 16)
+    for (int c = cap; c >= 16; c -= 16)
         if (K % c == 0) return c;
     return 16;
 }
 
-template <int MTILES, int NTW>
+template <int MTILES, int NTW, int NWAVES>
 static hipError_t launch_gemm_pro(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
-    if (!a.ln) return launch_gemm_t<MTILES, NTW, PRO_PLAIN>(a, kchunk, s);
+    if (!a.ln) return launch_gemm_t<MTILES, NTW, NWAVES, PRO_PLAIN>(a, kchunk, s);
     if (a.mod != nullptr && a.shift_off >= 0)
-        return a.mod_stride == 0 ? launch_gemm_t<MTILES, NTW, PRO_LN_MOD_BCAST>(a, kchunk, s)
-                                 : launch_gemm_t<MTILES, NTW, PRO_LN_MOD_ROWS>(a, kchunk, s);
-    return launch_gemm_t<MTILES, NTW, PRO_LN>(a, kchunk, s);
+        return a.mod_stride == 0 ? launch_gemm_t<MTILES, NTW, NWAVES, PRO_LN_MOD_BCAST>(a, kchunk, s)
+                                 : launch_gemm_t<MTILES, NTW, NWAVES, PRO_LN_MOD_ROWS>(a, kchunk, s);
+    return launch_gemm_t<MTILES, NTW, NWAVES, PRO_LN>(a, kchunk, s);
 }
+
+int g_mdt_gemm_force = 0;  // tuning hook: 0 = heuristic, else 1..5 selects a geometry below
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
     hipError_t ze = ensure_zeros();
     if (ze != hipSuccess) return ze;
-    const int kchunk = mdt_gemm_kchunk(a.K, a.ln);
-    // tile selection: 32 rows x 128 columns (two column tiles per wave) when that still yields >= 2 workgroups
-    // per CU; otherwise 32 x 64 (N = d projections at B = 256 would give only 240 of the larger tiles).
+    // Geometry selection (rows are in tiles of 32).  The decoder at B = 256 has 80 row tiles for 256 CUs:
+    //   wide  (8 waves, 32 x 512 / 32 x 384): N >= 1024 -> 240 workgroups, each activation tile re-read 3x
+    //   mid   (8 waves, 32 x 128)           : N  < 1024 -> 240 workgroups for N = 384
+    //   small (4 waves, 32 x 64)            : few row tiles (small batches): more, smaller workgroups
     const int gm = (a.M + 31) / 32;
-    const int big = ((a.N + 127) / 128) * gm;
-    if (big >= 512) return launch_gemm_pro<2, 2>(a, kchunk, s);
-    return launch_gemm_pro<2, 1>(a, kchunk, s);
+    int geo;
+    if (gm * ((a.N + 127) / 128) < 128) geo = 1;
+    else if (a.N >= 1024) geo = (a.N % 512 == 0 || a.N % 384 != 0) ? 4 : 3;
+    else geo = 2;
+    if (g_mdt_gemm_force) geo = g_mdt_gemm_force;
+    switch (geo) {
+        case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
+        case 2: return launch_gemm_pro<2, 1, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
+        case 3: return launch_gemm_pro<2, 3, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
+        case 4: return launch_gemm_pro<2, 4, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
+        default: return launch_gemm_pro<2, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
+    }
 }
+
+extern "C" void mdt_op_set_gemm_geometry(int32_t geo) { g_mdt_gemm_force = geo; }
 
 // ------------------------------------------------------------------------------------------------
 // small attention: one workgroup per sample.  The sample's q / k / v rows (all heads) are staged in LDS with
@@ -675,7 +684,7 @@ hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float
 __device__ __forceinline__ float edm_c_in(float sigma, float sd) { return 1.0f / sqrtf(sigma * sigma + sd * sd); }
 
 __global__ __launch_bounds__(256) void k_action_embed(const float* __restrict__ x, const float* __restrict__ sigma,
-                                                      int64_t sstride, float sd, const float* __restrict__ Wa,
+                                                      int64_t sstride, float sd, const float* __restrict__ WaT,
                                                       const float* __restrict__ ba, float* __restrict__ y, int M,
                                                       int A, int D, int rps) {
     const int n4 = D >> 2;
@@ -686,12 +695,23 @@ __global__ __launch_bounds__(256) void k_action_embed(const float* __restrict__ 
     f32x4 acc = *(const f32x4*)(ba + n);
     for (int c = 0; c < A; ++c) {
         const float xv = x[(int64_t)m * A + c] * cin;
-        acc.x = fmaf(xv, Wa[(n + 0) * A + c], acc.x);
-        acc.y = fmaf(xv, Wa[(n + 1) * A + c], acc.y);
-        acc.z = fmaf(xv, Wa[(n + 2) * A + c], acc.z);
-        acc.w = fmaf(xv, Wa[(n + 3) * A + c], acc.w);
+        const f32x4 w = *(const f32x4*)(WaT + (int64_t)c * D + n);  // weight stored transposed: (A, D)
+        acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y);
+        acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
     }
     *(f32x4*)(y + (int64_t)m * D + n) = acc;
+}
+
+__global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * Cc) return;
+    const int r = idx / Cc, c = idx % Cc;
+    dst[(int64_t)c * R + r] = src[idx];
+}
+
+hipError_t mdt_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose, dim3((R * Cc + 255) / 256), dim3(256), 0, s, src, dst, R, Cc);
+    return hipGetLastError();
 }
 
 hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t sstride, float sd, const float* Wa,
@@ -793,24 +813,22 @@ __global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __re
     for (int c = 0; c < 16; ++c)
         if (c < a.A && lane == c) a.out[m * a.A + c] = res[c];
     if (a.y_next != nullptr) {
+        f32x4 acc[2], wa[16][2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            if (cv[p]) {
-                const int n = cc[p];
-                f32x4 acc = *(const f32x4*)(a.ba + n);
+        for (int p = 0; p < 2; ++p) acc[p] = ldg4(a.ba + cc[p]);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (c < a.A) {
-                        const float xv = res[c] * cin_next;
-                        acc.x = fmaf(xv, a.Wa[(n + 0) * a.A + c], acc.x);
-                        acc.y = fmaf(xv, a.Wa[(n + 1) * a.A + c], acc.y);
-                        acc.z = fmaf(xv, a.Wa[(n + 2) * a.A + c], acc.z);
-                        acc.w = fmaf(xv, a.Wa[(n + 3) * a.A + c], acc.w);
-                    }
-                }
-                *(f32x4*)(a.y_next + m * a.D + n) = acc;
-            }
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) wa[c][p] = ldg4(a.Wa + (int64_t)min(c, a.A - 1) * a.D + cc[p]);  // (A, D) image
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float xv = c < a.A ? res[c] * cin_next : 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) acc[p] += xv * wa[c][p];
         }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (cv[p]) *(f32x4*)(a.y_next + m * a.D + cc[p]) = acc[p];
     }
 }
 

@@ -59,7 +59,7 @@ struct Lin {
     int N = 0, K = 0;
 };
 
-enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1 };
+enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2 };  // TRANSPOSE: (rows, K) -> (K, rows)
 
 struct Slot {
     std::string name;
@@ -219,7 +219,8 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
     lin_part(m->sig1, P + "sigma_emb.1", 2 * D, 0, true);
     lin_begin(m->sig3, D, 2 * D, true);
     lin_part(m->sig3, P + "sigma_emb.3", D, 0, true);
-    raw(m->Wa, P + "action_emb.weight", (int64_t)D * A);
+    m->Wa = b.take((size_t)D * A);  // stored transposed (A, D): lanes read 16 contiguous bytes per action component
+    add_slot(P + "action_emb.weight", (int64_t)D * A, SLOT_TRANSPOSE, m->Wa, D, A, 0);
     raw(m->ba, P + "action_emb.bias", D);
     raw(m->Wp, P + "action_pred.weight", (int64_t)A * D);
     raw(m->bp, P + "action_pred.bias", A);
@@ -350,6 +351,7 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
     if (slot->kind == SLOT_RAW) {
         HIP_TRY(hipMemcpyAsync(slot->dst, src, numel * sizeof(float), hipMemcpyDefault, s));
     } else {
+        const bool transpose = slot->kind == SLOT_TRANSPOSE;
         hipPointerAttribute_t attr;
         const float* dev_src = nullptr;
         hipError_t pe = hipPointerGetAttributes(&attr, src);
@@ -360,7 +362,8 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
             HIP_TRY(hipMemcpyAsync(m->staging, src, numel * sizeof(float), hipMemcpyHostToDevice, s));
             dev_src = m->staging;
         }
-        HIP_TRY(mdt_launch_pack_weight(dev_src, slot->rows, slot->K, slot->dst, slot->n_off, s));
+        if (transpose) HIP_TRY(mdt_launch_transpose(dev_src, slot->dst, slot->rows, slot->K, s));
+        else HIP_TRY(mdt_launch_pack_weight(dev_src, slot->rows, slot->K, slot->dst, slot->n_off, s));
     }
     slot->loaded = true;
     return MDT_OK;

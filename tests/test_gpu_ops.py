@@ -92,6 +92,28 @@ def test_gemm_plain_bias(lib, M, N, K):
     assert_close(got, want, rtol=1e-4, atol=1e-4, what=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("geo", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K,ln", [(2560, 1152, 384, True), (2560, 384, 1536, False), (100, 528, 128, True),
+                                      (77, 1536, 384, True), (33, 384, 768, False), (64, 1024, 80, False)])
+def test_gemm_every_geometry(lib, geo, M, N, K, ln):
+    """All workgroup geometries give the same (bit-identical) result: the k order of every dot product is fixed."""
+    g = torch.Generator().manual_seed(geo * 0 + M + N + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    lw = torch.randn(K, generator=g) * 0.2 + 1
+    y0 = torch.randn(M, N, generator=g)
+    x = F.layer_norm(A.double(), (K,), lw.double(), None, 1e-5) if ln else A.double()
+    want = (y0.double() + x @ W.double().T + b.double()).float()
+    try:
+        lib.load().mdt_op_set_gemm_geometry(0)
+        ref = run_gemm(lib, A, W, bias=b, ln_w=lw if ln else None, residual_into=y0)
+        lib.load().mdt_op_set_gemm_geometry(geo)
+        got = run_gemm(lib, A, W, bias=b, ln_w=lw if ln else None, residual_into=y0)
+    finally:
+        lib.load().mdt_op_set_gemm_geometry(0)
+    assert_close(got, want, rtol=1e-4, atol=1e-4, what=f"geometry {geo}")
+    assert torch.equal(got, ref), "geometries disagree bitwise"
+
+
 def test_gemm_is_transpose_sensitive(lib):
     """A = I with an ASYMMETRIC weight: catches a swapped C/D fragment map."""
     K = N = 64
@@ -246,7 +268,7 @@ def test_action_embed(lib):
     B, T, A, D, sd = 11, 10, 7, 384, 0.5
     x, Wa, ba = torch.randn(B * T, A, generator=g) * 30, torch.randn(D, A, generator=g), torch.randn(D, generator=g)
     sigma = torch.rand(B, generator=g) * 50 + 0.01
-    xd, Wd, bd, sg = dev(x), dev(Wa), dev(ba), dev(sigma)
+    xd, Wd, bd, sg = dev(x), dev(Wa.T), dev(ba), dev(sigma)  # the library keeps action_emb.weight as (A, D)
     y = torch.empty(B * T, D, device="cuda")
     lib.check(lib.load().mdt_op_action_embed(xd.data_ptr(), sg.data_ptr(), 1, sd, Wd.data_ptr(), bd.data_ptr(),
                                              y.data_ptr(), B * T, A, D, T, stream()))
@@ -266,7 +288,7 @@ def test_head(lib, mode):
     x = torch.randn(M, A, generator=g) * 10
     sigma = torch.rand(B, generator=g) * 20 + 0.05
     step = torch.tensor([0.3, 0.7, 2.5])  # ratio, coef, sigma_next
-    t = {k: dev(v) for k, v in dict(y=y, lw=lw, Wp=Wp, bp=bp, Wa=Wa, ba=ba, x=x, sigma=sigma, step=step).items()}
+    t = {k: dev(v) for k, v in dict(y=y, lw=lw, Wp=Wp, bp=bp, Wa=Wa.T, ba=ba, x=x, sigma=sigma, step=step).items()}
     out = torch.empty(M, A, device="cuda")
     y_next = torch.empty(M, D, device="cuda")
     a = lib.HeadArgs()
