@@ -34,7 +34,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU default).  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding
+// level): one rcp, one exp and a degree-5 Horner chain instead of libm erff's ~40 instructions -- the c_fc
+// epilogue applies it to 32 values per lane and was a quarter of that kernel's time with erff.
+__device__ __forceinline__ float act_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = p * t * __expf(-z * z);          // erfc(z), z >= 0
+    const float cdf = x >= 0.f ? 1.0f - 0.5f * q : 0.5f * q;  // Phi(x) without cancellation on the negative side
+    return x * cdf;
+}
 __device__ __forceinline__ float act_mish(float x) {
     float sp = x > 20.0f ? x : log1pf(expf(x));  // torch softplus threshold 20
     return x * tanhf(sp);
@@ -129,7 +142,7 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 // column tiles and ALL row tiles of the workgroup tile, so a weight fragment is fetched once per workgroup and
 // reused from registers across the row tiles.  Wide tiles (8 waves x NTW 3..4) keep the number of workgroups that
 // re-read / re-normalise the same activation rows at N / (128*NTW) instead of N / 64.
-template <int MTILES, int NTW, int NWAVES, int PRO>
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>
 __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchunk, int grid_n,
                                                       const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -166,6 +179,42 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     for (int i = 0; i < MTILES; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
+
+    // ---- epilogue operands (bias / gate / residual) are requested NOW, in the same latency window as the
+    //      activation tile: vmcnt retires loads in order, so a load issued later would stall the weight ring ----
+    const int nq = 4 * (lane >> 4);
+    const bool gated = RES && a.gate_off >= 0;
+    int ncol[NTW];
+    constexpr int NRES = RES ? NTW : 1;  // residual GEMMs (out += gate * value) also prefetch gate and old value
+    f32x4 bias_v[NTW], gate_v[MTILES][NRES], res_v[MTILES][NRES];
+    float* optr[MTILES];
+    {
+        const float* biasp = a.bias != nullptr ? a.bias : zeros;
+        const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
+            bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
+            const int64_t orow =
+                a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
+            optr[i] = a.out + orow * a.ldo;
+            if constexpr (RES) {
+                const float* gp = zeros;
+                if (gated)
+                    gp = a.mod + a.gate_off +
+                         (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    gate_v[i][j] = ldg4(gp + ncol[j]);
+                    res_v[i][j] = ldg4(optr[i] + ncol[j]);
+                }
+            }
+        }
+    }
 
     int kg = 0;  // global k16 index of the weight stream
     for (int k0 = 0; k0 < a.K; k0 += kchunk) {
@@ -347,38 +396,13 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     // ---- epilogue: lane holds out[m0 + i*16 + lane%16][n .. n+3], n = tile*16 + 4*(lane/16) ----
     MDT_TS(3)
     if (!active) return;
-    const int nq = 4 * (lane >> 4);
-    const bool gated = a.residual && a.gate_off >= 0;
-    const float* biasp = a.bias != nullptr ? a.bias : zeros;
-    const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
-    int ncol[NTW];
-    f32x4 bias_v[NTW], gate_v[MTILES][NTW], res_v[MTILES][NTW];
-    float* optr[MTILES];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
-        bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < MTILES; ++i) {
-        const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
-        const int64_t orow = a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
-        optr[i] = a.out + orow * a.ldo;
-        const float* gp = zeros;
-        if (gated) gp = a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride);
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            gate_v[i][j] = ldg4(gp + ncol[j]);
-            res_v[i][j] = a.residual ? ldg4(optr[i] + ncol[j]) : zero4;
-        }
-    }
 #pragma unroll
     for (int i = 0; i < MTILES; ++i) {
         const bool mok = m0 + i * 16 + (lane & 15) < a.M;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
-            if (a.residual) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
+            if constexpr (RES) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
             if (mok && nt0 + j < N16) *(f32x4*)(optr[i] + ncol[j]) = v;
         }
     }
@@ -395,21 +419,27 @@ static hipError_t ensure_zeros() {
     return hipMemset(g_zeros, 0, ZEROS_FLOATS * sizeof(float));
 }
 
-template <int MTILES, int NTW, int NWAVES, int PRO>
-static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>
+static hipError_t launch_gemm_r(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
     const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
     const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
     const size_t lds = (size_t)MT * (kchunk + 4) * sizeof(float);
     static size_t lds_attr = 0;  // per instantiation
     if (lds > lds_attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW, NWAVES, PRO>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW, NWAVES, PRO, RES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_gemm<MTILES, NTW, NWAVES, PRO>), dim3(gn * gm), dim3(64 * NWAVES), lds, s, a, kchunk, gn,
+    hipLaunchKernelGGL((k_gemm<MTILES, NTW, NWAVES, PRO, RES>), dim3(gn * gm), dim3(64 * NWAVES), lds, s, a, kchunk, gn,
                        g_zeros);
     return hipGetLastError();
+}
+
+template <int MTILES, int NTW, int NWAVES, int PRO>
+static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
+    return a.residual ? launch_gemm_r<MTILES, NTW, NWAVES, PRO, true>(a, kchunk, s)
+                      : launch_gemm_r<MTILES, NTW, NWAVES, PRO, false>(a, kchunk, s);
 }
 
 // activation chunk length: whole K when it fits (always for the LayerNorm prologue), else the largest divisor of K
