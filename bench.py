@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--denoise-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cpu_count, 32))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cpu_count, 16), the best of a 1..128 sweep on the EPYC host)")
     return ap.parse_args()
 
 
@@ -225,7 +225,7 @@ def main():
         except Exception as e:  # diagnostic leg only; never hides the main number
             res["roofline"]["dominant_kernel"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             res["cpu_baseline"] = cpu_baseline(cfg, P, B, args.denoise_steps, args.cpu_seconds, threads)
         print(json.dumps(res), flush=True)
     if dist is not None:
