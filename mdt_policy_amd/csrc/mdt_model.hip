@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -111,7 +112,37 @@ struct mdt_model {
     float *h_enc, *qkv, *att, *hid, *ctx, *kvx, *y, *qx, *sig_e, *sig_t, *sig_c, *mod, *xbuf, *noised, *Fbuf, *steps;
     int64_t cached_batch = 0;  // batch of the context currently cached by mdt_encode (0 = none)
     std::vector<float> steps_host;
+    // sampler pipelining: the batch is cut into `ways` sample-aligned slices whose launch chains run on separate
+    // HIP streams, so one slice's prologue / epilogue / launch gaps overlap another slice's MFMA main loops
+    int ways = 2;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
+
+static const int MAX_WAYS = 4;
+
+// workspace view of a contiguous slice of samples [b0, b0 + nb) for the decoder (Ta rows per sample)
+struct View {
+    float *y, *qkv, *att, *hid, *qx, *kvx;
+};
+
+static View decoder_view(const mdt_model* m, int64_t b0) {
+    View v;
+    const int64_t r = b0 * m->Ta;
+    v.y = m->y + r * m->D;
+    v.qkv = m->qkv + r * 3 * m->D;
+    v.att = m->att + r * m->D;
+    v.hid = m->hid + r * 4 * m->D;
+    v.qx = m->qx + r * m->D;
+    v.kvx = m->kvx + b0 * m->Te * (int64_t)m->Ld * 2 * m->D;
+    return v;
+}
+
+static View encoder_view(const mdt_model* m) {
+    View v;
+    v.y = m->h_enc; v.qkv = m->qkv; v.att = m->att; v.hid = m->hid; v.qx = nullptr; v.kvx = nullptr;
+    return v;
+}
 
 static const int MAX_STEPS = 64;
 
@@ -311,12 +342,30 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     e = hipMalloc((void**)&m->staging, mx * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(m->arena); delete m; return fail(MDT_ERR_HIP, "hipMalloc(staging) failed: %s", hipGetErrorString(e)); }
     m->steps_host.resize(MAX_STEPS * 4);
+    if (const char* w = getenv("MDT_HIP_WAYS")) m->ways = std::max(1, std::min(MAX_WAYS, atoi(w)));
+    for (int i = 0; i < MAX_WAYS - 1; ++i) {
+        if (hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) != hipSuccess) {
+            mdt_destroy(m);
+            return fail(MDT_ERR_HIP, "could not create the sampler's auxiliary streams/events");
+        }
+    }
+    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        mdt_destroy(m);
+        return fail(MDT_ERR_HIP, "could not create the sampler's fork event");
+    }
     *out = m;
     return MDT_OK;
 }
 
 extern "C" mdt_status mdt_destroy(mdt_model* m) {
     if (!m) return MDT_OK;
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < MAX_WAYS - 1; ++i) {
+        if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
+        if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     (void)hipFree(m->arena);
     (void)hipFree(m->staging);
     (void)hipFree(m->ws);
@@ -448,35 +497,37 @@ struct ModRef {
     int64_t stride = 0;
 };
 
-static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, float* x, int64_t B, int T, bool causal, ModRef mr,
-                                hipStream_t s) {
+static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, bool causal,
+                                ModRef mr, hipStream_t s) {
+    float* x = V.y;
     const int D = m->D, M = (int)(B * T);
-    mdt_gemm_args g = gemm_args(x, D, e.qkv, m->qkv, 3 * D, M);
+    mdt_gemm_args g = gemm_args(x, D, e.qkv, V.qkv, 3 * D, M);
     g.ln = 1; g.ln_w = e.ln1_w; g.ln_b = e.ln1_b;
     g.rows_per_sample = T;
     if (mr.mod) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = 0; g.scale_off = D; }
     LAUNCH(mdt_launch_gemm(g, s));
     mdt_attn_args a;
     memset(&a, 0, sizeof a);
-    a.q = m->qkv; a.ldq = 3 * D; a.k = m->qkv + D; a.v = m->qkv + 2 * D; a.ldkv = 3 * D;
-    a.out = m->att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T;
+    a.q = V.qkv; a.ldq = 3 * D; a.k = V.qkv + D; a.v = V.qkv + 2 * D; a.ldkv = 3 * D;
+    a.out = V.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T;
     a.causal = causal; a.rope = m->cfg.use_rot_embed;
     LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
-    mdt_gemm_args p = gemm_args(m->att, D, e.proj, x, D, M);
+    mdt_gemm_args p = gemm_args(V.att, D, e.proj, x, D, M);
     p.residual = 1; p.rows_per_sample = T;
     if (mr.mod) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = 2 * D; }
     LAUNCH(mdt_launch_gemm(p, s));
     return MDT_OK;
 }
 
-static mdt_status run_mlp(mdt_model* m, const EncBlock& e, float* x, int64_t B, int T, ModRef mr, hipStream_t s) {
+static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, ModRef mr, hipStream_t s) {
+    float* x = V.y;
     const int D = m->D, M = (int)(B * T);
-    mdt_gemm_args g = gemm_args(x, D, e.fc, m->hid, 4 * D, M);
+    mdt_gemm_args g = gemm_args(x, D, e.fc, V.hid, 4 * D, M);
     g.ln = 1; g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = MDT_ACT_GELU;
     g.rows_per_sample = T;
     if (mr.mod) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = 3 * D; g.scale_off = 4 * D; }
     LAUNCH(mdt_launch_gemm(g, s));
-    mdt_gemm_args p = gemm_args(m->hid, 4 * D, e.proj2, x, D, M);
+    mdt_gemm_args p = gemm_args(V.hid, 4 * D, e.proj2, x, D, M);
     p.residual = 1; p.rows_per_sample = T;
     if (mr.mod) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = 5 * D; }
     LAUNCH(mdt_launch_gemm(p, s));
@@ -527,8 +578,8 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
         LAUNCH(mdt_launch_gemm(b2, s));
     }
     for (int l = 0; l < m->Le; ++l) {
-        MDT_TRY(run_self_attn(m, m->enc[l], m->h_enc, B, Te, false, ModRef(), s));
-        MDT_TRY(run_mlp(m, m->enc[l], m->h_enc, B, Te, ModRef(), s));
+        MDT_TRY(run_self_attn(m, m->enc[l], encoder_view(m), B, Te, false, ModRef(), s));
+        MDT_TRY(run_mlp(m, m->enc[l], encoder_view(m), B, Te, ModRef(), s));
     }
     LAUNCH(mdt_launch_layernorm(m->h_enc, m->enc_ln_w, m->enc_ln_b, m->ctx, (int)(B * Te), D, s));
     if (ctx_out) HIP_TRY(hipMemcpyAsync(ctx_out, m->ctx, (size_t)B * Te * D * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -557,39 +608,40 @@ static mdt_status run_modulation(mdt_model* m, const float* sigma, int64_t sstri
 }
 
 // the Ld ConditionedBlocks on the residual stream m->y          (transformer_blocks.py:291-309)
-static mdt_status run_decoder_blocks(mdt_model* m, int64_t B, const float* mod_row, int64_t mod_stride, hipStream_t s) {
+static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, const float* mod_row, int64_t mod_stride,
+                                     hipStream_t s) {
     const int D = m->D, Ta = m->Ta, M = (int)(B * Ta);
     for (int l = 0; l < m->Ld; ++l) {
         const DecBlock& d = m->dec[l];
         ModRef mr;
         mr.mod = mod_row + (int64_t)l * 6 * D;
         mr.stride = mod_stride;
-        MDT_TRY(run_self_attn(m, d, m->y, B, Ta, true, mr, s));
+        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, mr, s));
         // cross attention: ln3 (biased LayerNorm) -> q ; K|V precomputed ; NOT gated, NOT modulated
-        mdt_gemm_args q = gemm_args(m->y, D, d.xq, m->qx, D, M);
+        mdt_gemm_args q = gemm_args(V.y, D, d.xq, V.qx, D, M);
         q.ln = 1; q.ln_w = d.ln3_w; q.ln_b = d.ln3_b; q.rows_per_sample = Ta;
         LAUNCH(mdt_launch_gemm(q, s));
         mdt_attn_args a;
         memset(&a, 0, sizeof a);
-        a.q = m->qx; a.ldq = D;
-        a.k = m->kvx + (int64_t)l * 2 * D; a.v = a.k + D; a.ldkv = (int64_t)m->Ld * 2 * D;
-        a.out = m->att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Ta; a.Tk = m->Te;
+        a.q = V.qx; a.ldq = D;
+        a.k = V.kvx + (int64_t)l * 2 * D; a.v = a.k + D; a.ldkv = (int64_t)m->Ld * 2 * D;
+        a.out = V.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Ta; a.Tk = m->Te;
         a.causal = 1;  // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
         a.rope = m->cfg.use_rot_embed;
         LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
-        mdt_gemm_args p = gemm_args(m->att, D, d.xproj, m->y, D, M);
+        mdt_gemm_args p = gemm_args(V.att, D, d.xproj, V.y, D, M);
         p.residual = 1; p.rows_per_sample = Ta;
         LAUNCH(mdt_launch_gemm(p, s));
-        MDT_TRY(run_mlp(m, d, m->y, B, Ta, mr, s));
+        MDT_TRY(run_mlp(m, d, V, B, Ta, mr, s));
     }
     return MDT_OK;
 }
 
-static mdt_head_args head_args(mdt_model* m, int64_t B, const float* x, const float* sigma, int64_t sstride, float* out,
-                               int mode) {
+static mdt_head_args head_args(mdt_model* m, const float* y, int64_t B, const float* x, const float* sigma,
+                               int64_t sstride, float* out, int mode) {
     mdt_head_args h;
     memset(&h, 0, sizeof h);
-    h.y = m->y; h.ln_w = m->dec_ln_w; h.ln_b = m->dec_ln_b; h.Wp = m->Wp; h.bp = m->bp;
+    h.y = y; h.ln_w = m->dec_ln_w; h.ln_b = m->dec_ln_b; h.Wp = m->Wp; h.bp = m->bp;
     h.x = x; h.sigma = sigma; h.sigma_stride = sstride; h.out = out;
     h.M = (int)(B * m->Ta); h.D = m->D; h.A = m->A; h.rows_per_sample = m->Ta; h.mode = mode;
     h.sigma_data = m->cfg.sigma_data;
@@ -617,8 +669,8 @@ extern "C" mdt_status mdt_denoise_cached(mdt_model* m, const float* x, const flo
     MDT_TRY(run_modulation(m, sigma, 1, (int)batch, s));
     LAUNCH(mdt_launch_action_embed(x, (flags & MDT_RAW_INPUT) ? nullptr : sigma, 1, m->cfg.sigma_data, m->Wa, m->ba,
                                    m->y, (int)(batch * m->Ta), m->A, m->D, m->Ta, s));
-    MDT_TRY(run_decoder_blocks(m, batch, m->mod, modw, s));
-    mdt_head_args h = head_args(m, batch, x, sigma, 1, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
+    MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, m->mod, modw, s));
+    mdt_head_args h = head_args(m, m->y, batch, x, sigma, 1, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
     LAUNCH(mdt_launch_head(h, s));
     return MDT_OK;
 }
@@ -655,16 +707,49 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
     HIP_TRY(hipMemcpyAsync(m->steps, sh, (size_t)n_steps * 4 * sizeof(float), hipMemcpyHostToDevice, s));
     const int64_t modw = (int64_t)m->Ld * 6 * m->D;
     MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));  // one row of adaLN vectors per step
-    const int M = (int)(batch * m->Ta);
-    LAUNCH(mdt_launch_action_embed(x_T, m->steps + 3, 0, m->cfg.sigma_data, m->Wa, m->ba, m->y, M, m->A, m->D, m->Ta, s));
+    // ---- cut the batch into sample-aligned slices (multiples of 16 samples = 5 row tiles) on separate streams ----
+    int ways = m->ways;
+    while (ways > 1 && batch / ways < 32) --ways;
+    int64_t b0[MAX_WAYS + 1];
+    b0[0] = 0;
+    for (int w = 0; w < ways; ++w) {
+        int64_t nb = (batch - b0[w]) / (ways - w);
+        if (w + 1 < ways) nb = std::min<int64_t>(batch - b0[w], (nb + 15) / 16 * 16);
+        b0[w + 1] = b0[w] + nb;
+    }
+    hipStream_t st[MAX_WAYS];
+    st[0] = s;
+    if (ways > 1) {
+        HIP_TRY(hipEventRecord(m->ev_fork, s));
+        for (int w = 1; w < ways; ++w) {
+            st[w] = m->aux[w - 1];
+            HIP_TRY(hipStreamWaitEvent(st[w], m->ev_fork, 0));
+        }
+    }
+    const int64_t xs = (int64_t)m->Ta * m->A;  // floats of x per sample
+    for (int w = 0; w < ways; ++w) {
+        const int64_t nb = b0[w + 1] - b0[w];
+        const View V = decoder_view(m, b0[w]);
+        LAUNCH(mdt_launch_action_embed(x_T + b0[w] * xs, m->steps + 3, 0, m->cfg.sigma_data, m->Wa, m->ba, V.y,
+                                       (int)(nb * m->Ta), m->A, m->D, m->Ta, st[w]));
+    }
     for (int i = 0; i < n_steps; ++i) {
-        MDT_TRY(run_decoder_blocks(m, batch, m->mod + (int64_t)i * modw, 0, s));
         const bool last = i == n_steps - 1;
-        mdt_head_args h = head_args(m, batch, i == 0 ? x_T : m->xbuf, m->steps + 4 * i + 3, 0, last ? out : m->xbuf,
-                                    MDT_HEAD_DDIM);
-        h.step = m->steps + 4 * i;
-        if (!last) { h.y_next = m->y; h.Wa = m->Wa; h.ba = m->ba; }
-        LAUNCH(mdt_launch_head(h, s));
+        for (int w = 0; w < ways; ++w) {
+            const int64_t nb = b0[w + 1] - b0[w];
+            const View V = decoder_view(m, b0[w]);
+            MDT_TRY(run_decoder_blocks(m, V, nb, m->mod + (int64_t)i * modw, 0, st[w]));
+            const float* xin = (i == 0 ? x_T : m->xbuf) + b0[w] * xs;
+            float* xout = (last ? out : m->xbuf) + b0[w] * xs;
+            mdt_head_args h = head_args(m, V.y, nb, xin, m->steps + 4 * i + 3, 0, xout, MDT_HEAD_DDIM);
+            h.step = m->steps + 4 * i;
+            if (!last) { h.y_next = V.y; h.Wa = m->Wa; h.ba = m->ba; }
+            LAUNCH(mdt_launch_head(h, st[w]));
+        }
+    }
+    for (int w = 1; w < ways; ++w) {
+        HIP_TRY(hipEventRecord(m->ev_join[w - 1], st[w]));
+        HIP_TRY(hipStreamWaitEvent(s, m->ev_join[w - 1], 0));
     }
     return MDT_OK;
 }
