@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     MDT_TS_HWID()
     constexpr int MT = MTILES * 16;
     constexpr int NT = 64 * NWAVES;
-    constexpr int R = 3;  // weight-fragment ring: 2 k-steps of 1-KiB loads in flight per column tile
+    constexpr int R = 3;  // weight-fragment ring: 2 k-steps of 1-KiB loads in flight per column tile (per wave)
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -529,54 +529,75 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
         }
     }
     __syncthreads();
-    if (tid >= a.H * a.Tq) return;
-    const int t = tid % a.Tq, h = tid / a.Tq;
-
-    float q[HD];
+    // ---- compute: LP lanes share one (head, query row); each owns a DS-wide slice of the head dimension ----
+    constexpr int LP = HD == 48 ? 3 : (HD >= 32 ? 2 : 1);
+    constexpr int DS = HD / LP;  // 16 or 32 dims per lane
+    float* part = vs + a.Tk * D;  // [pairs][16 keys][LP] partial scores
+    const int npairs = a.H * a.Tq;
+    const int pr = tid % npairs, ps = tid / npairs;  // pair, slice (slices of a pair sit in different waves)
+    const bool live = tid < npairs * LP;
+    const int t = pr % a.Tq, h = pr / a.Tq;
+    const int nk = a.causal ? min(a.Tk, t + 1) : a.Tk;
+    const int d0 = h * HD + ps * DS;
+    float q[DS];
+    if (live) {
 #pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-        const f32x4 x = *(const f32x4*)(qs + t * D + h * HD + d);
-        q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
-    }
-    if (a.rope) {
-        if constexpr (HD >= ROT) {
+        for (int d = 0; d < DS; d += 4) {
+            const f32x4 x = *(const f32x4*)(qs + t * D + d0 + d);
+            q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+        }
+        if (a.rope) {
 #pragma unroll
-            for (int i = 0; i < ROT / 2; ++i) {
-                const float c = rope_cos[t * 16 + i], s = rope_sin[t * 16 + i];
-                const float x1 = q[2 * i], x2 = q[2 * i + 1];
-                q[2 * i] = x1 * c - x2 * s;
-                q[2 * i + 1] = x2 * c + x1 * s;
+            for (int i = 0; i < DS / 2; ++i) {
+                const int gi = (ps * DS) / 2 + i;  // rotary pair index inside the head
+                if (gi < ROT / 2) {
+                    const float c = rope_cos[t * 16 + gi], sn = rope_sin[t * 16 + gi];
+                    const float x1 = q[2 * i], x2 = q[2 * i + 1];
+                    q[2 * i] = x1 * c - x2 * sn;
+                    q[2 * i + 1] = x2 * c + x1 * sn;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < nk) {
+                const float* kp = ks + j * D + d0;
+                float kr[DS];
+#pragma unroll
+                for (int d = 0; d < DS; d += 4) {
+                    const f32x4 x = *(const f32x4*)(kp + d);
+                    kr[d] = x.x; kr[d + 1] = x.y; kr[d + 2] = x.z; kr[d + 3] = x.w;
+                }
+                if (a.rope) {
+#pragma unroll
+                    for (int i = 0; i < DS / 2; ++i) {
+                        const int gi = (ps * DS) / 2 + i;
+                        if (gi < ROT / 2) {
+                            const float c = rope_cos[j * 16 + gi], sn = rope_sin[j * 16 + gi];
+                            const float x1 = kr[2 * i], x2 = kr[2 * i + 1];
+                            kr[2 * i] = x1 * c - x2 * sn;
+                            kr[2 * i + 1] = x2 * c + x1 * sn;
+                        }
+                    }
+                }
+                float dot = 0.f;
+#pragma unroll
+                for (int d = 0; d < DS; ++d) dot = fmaf(q[d], kr[d], dot);
+                part[(pr * 16 + j) * LP + ps] = dot;
             }
         }
     }
-    const int nk = a.causal ? min(a.Tk, t + 1) : a.Tk;
+    __syncthreads();
+    if (!live) return;
     float sc[16];
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         sc[j] = -INFINITY;
         if (j < nk) {
-            const float* kp = ks + j * D + h * HD;
-            float kr[HD];
-#pragma unroll
-            for (int d = 0; d < HD; d += 4) {
-                const f32x4 x = *(const f32x4*)(kp + d);
-                kr[d] = x.x; kr[d + 1] = x.y; kr[d + 2] = x.z; kr[d + 3] = x.w;
-            }
-            if (a.rope) {
-                if constexpr (HD >= ROT) {
-#pragma unroll
-                    for (int i = 0; i < ROT / 2; ++i) {
-                        const float c = rope_cos[j * 16 + i], s = rope_sin[j * 16 + i];
-                        const float x1 = kr[2 * i], x2 = kr[2 * i + 1];
-                        kr[2 * i] = x1 * c - x2 * s;
-                        kr[2 * i + 1] = x2 * c + x1 * s;
-                    }
-                }
-            }
             float dot = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) dot = fmaf(q[d], kr[d], dot);
+            for (int u = 0; u < LP; ++u) dot += part[(pr * 16 + j) * LP + u];  // fixed order: deterministic
             sc[j] = dot * scale;
             mx = fmaxf(mx, sc[j]);
         }
@@ -588,30 +609,31 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
         sum += sc[j];
     }
     const float inv = 1.0f / sum;
-    float o[HD];
+    float o[DS];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int d = 0; d < DS; ++d) o[d] = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         if (j < nk) {
             const float p = sc[j] * inv;
-            const float* vp = vs + j * D + h * HD;
+            const float* vp = vs + j * D + d0;
 #pragma unroll
-            for (int d = 0; d < HD; d += 4) {
+            for (int d = 0; d < DS; d += 4) {
                 const f32x4 x = *(const f32x4*)(vp + d);
                 o[d] = fmaf(p, x.x, o[d]); o[d + 1] = fmaf(p, x.y, o[d + 1]);
                 o[d + 2] = fmaf(p, x.z, o[d + 2]); o[d + 3] = fmaf(p, x.w, o[d + 3]);
             }
         }
     }
-    float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + h * HD;
+    float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + d0;
 #pragma unroll
-    for (int d = 0; d < HD; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
+    for (int d = 0; d < DS; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
 }
 
 template <int HD>
 static hipError_t launch_attn_t(const mdt_attn_args& a, const float* rc, const float* rs, hipStream_t s) {
-    const size_t lds = (size_t)(a.Tq + 2 * a.Tk) * a.H * HD * sizeof(float);
+    constexpr int LP = HD == 48 ? 3 : (HD >= 32 ? 2 : 1);
+    const size_t lds = ((size_t)(a.Tq + 2 * a.Tk) * a.H * HD + (size_t)a.H * a.Tq * 16 * LP) * sizeof(float);
     static size_t lds_attr = 0;
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -624,7 +646,9 @@ static hipError_t launch_attn_t(const mdt_attn_args& a, const float* rc, const f
 
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin,
                                 hipStream_t s) {
-    if (a.H * a.Tq > 256 || (size_t)(a.Tq + 2 * a.Tk) * a.H * a.hd * sizeof(float) > 160 * 1024) return hipErrorInvalidValue;
+    const int lp = a.hd == 48 ? 3 : (a.hd >= 32 ? 2 : 1);
+    const size_t need = ((size_t)(a.Tq + 2 * a.Tk) * a.H * a.hd + (size_t)a.H * a.Tq * 16 * lp) * sizeof(float);
+    if (a.H * a.Tq * lp > 256 || need > 160 * 1024) return hipErrorInvalidValue;
     switch (a.hd) {
         case 16: return launch_attn_t<16>(a, rope_cos, rope_sin, s);
         case 32: return launch_attn_t<32>(a, rope_cos, rope_sin, s);

@@ -114,7 +114,7 @@ struct mdt_model {
     std::vector<float> steps_host;
     // sampler pipelining: the batch is cut into `ways` sample-aligned slices whose launch chains run on separate
     // HIP streams, so one slice's prologue / epilogue / launch gaps overlap another slice's MFMA main loops
-    int ways = 2;
+    int ways = 1;
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
