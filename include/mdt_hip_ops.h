@@ -102,6 +102,29 @@ typedef struct {
 
 mdt_status mdt_op_head(const mdt_head_args *args, void *stream);
 
+/* Collapsed cross-attention (see mdt_kernels.hip): fold the sigma-independent context K|V into the query and
+ * output projections once per sampler call ... */
+typedef struct {
+    const float *kv; int64_t ldkv; /* (B*Te, ...) rows holding K at column 0 and V at column D of this block   */
+    const float *Wq;               /* cross_att.query.weight (D, D) row-major (reference layout)               */
+    const float *bq;               /* cross_att.query.bias (D)                                                 */
+    const float *WoT;              /* cross_att.c_proj.weight TRANSPOSED: WoT[d][n] = Wo[n][d]                 */
+    float *U, *Wf;                 /* out: (B, H*Te, D) each                                                   */
+    float *c;                      /* out: (B, H*Te)                                                           */
+    int32_t B, H, hd, D, Te;
+} mdt_xfold_args;
+mdt_status mdt_op_xattn_fold(const mdt_xfold_args *args, void *stream);
+
+/* ... and apply the whole sublayer  y += c_proj(softmax_causal(q K^T / sqrt(hd)) V) + bo  per denoising step. */
+typedef struct {
+    float *y;                      /* (B*Ta, D) residual stream, updated in place                              */
+    const float *ln_w, *ln_b;      /* ln3 weight / bias (D)                                                    */
+    const float *U, *Wf, *c;       /* from mdt_op_xattn_fold                                                   */
+    const float *bo;               /* cross_att.c_proj.bias (D) or NULL                                        */
+    int32_t B, H, D, Te, Ta;
+} mdt_xapply_args;
+mdt_status mdt_op_xattn_apply(const mdt_xapply_args *args, void *stream);
+
 /* y = (x * c_in(sigma)) Wa^T + ba   (c_in omitted when sigma == NULL); WaT = action_emb.weight transposed to (A, D) */
 mdt_status mdt_op_action_embed(const float *x, const float *sigma, int64_t sigma_stride, float sigma_data,
                                const float *WaT, const float *ba, float *y, int64_t M, int32_t A, int32_t D,

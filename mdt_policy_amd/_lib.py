@@ -45,6 +45,18 @@ class AttnArgs(C.Structure):
         ("Tq", C.c_int32), ("Tk", C.c_int32), ("causal", C.c_int32), ("rope", C.c_int32)]
 
 
+class XFoldArgs(C.Structure):
+    _fields_ = [("kv", C.c_void_p), ("ldkv", C.c_int64), ("Wq", C.c_void_p), ("bq", C.c_void_p), ("WoT", C.c_void_p),
+                ("U", C.c_void_p), ("Wf", C.c_void_p), ("c", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32),
+                ("hd", C.c_int32), ("D", C.c_int32), ("Te", C.c_int32)]
+
+
+class XApplyArgs(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("U", C.c_void_p), ("Wf", C.c_void_p),
+                ("c", C.c_void_p), ("bo", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
+                ("Te", C.c_int32), ("Ta", C.c_int32)]
+
+
 class HeadArgs(C.Structure):
     _fields_ = [
         ("y", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("Wp", C.c_void_p), ("bp", C.c_void_p),
@@ -83,6 +95,8 @@ SYMBOLS = [
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
     ("mdt_op_set_gemm_geometry", None, [_I32]),
     ("mdt_op_attention", _I32, [C.POINTER(AttnArgs), _VP]),
+    ("mdt_op_xattn_fold", _I32, [C.POINTER(XFoldArgs), _VP]),
+    ("mdt_op_xattn_apply", _I32, [C.POINTER(XApplyArgs), _VP]),
     ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_head", _I32, [C.POINTER(HeadArgs), _VP]),
     ("mdt_op_action_embed", _I32, [_VP, _VP, _I64, _F, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _VP]),

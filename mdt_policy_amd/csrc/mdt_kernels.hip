@@ -894,6 +894,250 @@ hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Collapsed cross-attention.  The decoder's cross-attention sublayer
+//     y += c_proj( softmax_causal( (ln3(y) Wq^T + bq) K^T / sqrt(hd) ) V )          (transformer_blocks.py:300-302)
+// attends to only Te (= 4) context tokens whose K / V do not depend on sigma or on the actions.  Per sample b,
+// head h and context token j the two projections fold into the context once per sampler call:
+//     U [b][h][j][:] = 1/sqrt(hd) * sum_{d in h} K[b][j][d] * Wq[d][:]        score = ln3(y) . U + c
+//     c [b][h][j]    = 1/sqrt(hd) * sum_{d in h} K[b][j][d] * bq[d]
+//     Wf[b][h][j][:] = sum_{d in h} V[b][j][d] * Wo[:][d]                    out   = sum_{h,j} P[h][j] * Wf
+// (k_xattn_fold), after which every denoising step runs the whole sublayer as ONE kernel per sample
+// (k_xattn_apply): LayerNorm, H*Te dot products of length d, H masked softmaxes over Te values, a
+// (H*Te) x d combination and the residual add -- 12x fewer FLOPs than the two d x d projections and three
+// launches (q GEMM, attention, c_proj GEMM) fewer per block and step.  Exact algebra, fp32 rounding differs.
+// ------------------------------------------------------------------------------------------------
+template <int TE, int SB>
+__global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = threadIdx.x;            // output feature handled by this thread
+    const int h = blockIdx.y;
+    const int bg = blockIdx.x * SB;       // first sample of the group
+    const int HD = a.hd, D = a.D, P = a.H * TE;
+    float* Ks = lds;                      // [SB][TE][HD]
+    float* Vs = Ks + SB * TE * HD;        // [SB][TE][HD]
+    for (int i = threadIdx.x; i < SB * TE * HD; i += blockDim.x) {
+        const int d = i % HD, j = (i / HD) % TE, sb = i / (HD * TE);
+        const int b = min(bg + sb, a.B - 1);
+        const float* row = a.kv + (int64_t)(b * TE + j) * a.ldkv + h * HD + d;
+        Ks[i] = row[0];
+        Vs[i] = row[D];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)HD);
+    if (n < D) {
+        float accU[SB][TE], accW[SB][TE];
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+            for (int j = 0; j < TE; ++j) { accU[sb][j] = 0.f; accW[sb][j] = 0.f; }
+        for (int d = 0; d < HD; ++d) {
+            const float wq = a.Wq[(int64_t)(h * HD + d) * D + n];   // query.weight row (out feature h*hd+d), coalesced over n
+            const float wo = a.WoT[(int64_t)(h * HD + d) * D + n];  // c_proj.weight^T row, coalesced over n
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+                for (int j = 0; j < TE; ++j) {
+                    accU[sb][j] = fmaf(wq, Ks[(sb * TE + j) * HD + d], accU[sb][j]);
+                    accW[sb][j] = fmaf(wo, Vs[(sb * TE + j) * HD + d], accW[sb][j]);
+                }
+        }
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) {
+            if (bg + sb < a.B) {
+#pragma unroll
+                for (int j = 0; j < TE; ++j) {
+                    const int64_t o = ((int64_t)(bg + sb) * P + h * TE + j) * D + n;
+                    a.U[o] = accU[sb][j] * scale;
+                    a.Wf[o] = accW[sb][j];
+                }
+            }
+        }
+    }
+    if (threadIdx.x < SB * TE) {
+        const int sb = threadIdx.x / TE, j = threadIdx.x % TE;
+        if (bg + sb < a.B) {
+            float acc = 0.f;
+            for (int d = 0; d < HD; ++d) acc = fmaf(a.bq[h * HD + d], Ks[(sb * TE + j) * HD + d], acc);
+            a.c[(int64_t)(bg + sb) * P + h * TE + j] = acc * scale;
+        }
+    }
+}
+
+hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s) {
+    constexpr int SB = 4;
+    if (a.D > 512 || a.Te < 1 || a.Te > 4) return hipErrorInvalidValue;
+    const dim3 grid((a.B + SB - 1) / SB, a.H);
+    const int threads = (a.D + 63) / 64 * 64;
+    const size_t lds = (size_t)2 * SB * a.Te * a.hd * sizeof(float);
+    switch (a.Te) {
+        case 1: hipLaunchKernelGGL((k_xattn_fold<1, SB>), grid, dim3(threads), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((k_xattn_fold<2, SB>), grid, dim3(threads), lds, s, a); break;
+        case 3: hipLaunchKernelGGL((k_xattn_fold<3, SB>), grid, dim3(threads), lds, s, a); break;
+        default: hipLaunchKernelGGL((k_xattn_fold<4, SB>), grid, dim3(threads), lds, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+// One workgroup (384 threads) per sample.  Work split:
+//   dots : thread = (pair p = (h, j), segment of 32 features): P * D/32 <= 384 items, U segment in 8 VGPR quads
+//   comb : thread = (float4 column c4, row group tg): D/4 * ntg <= 384 items, all P Wf quads of the column in VGPRs
+// Every global operand (U, Wf, y rows, LayerNorm vectors) is requested before the first dependent instruction.
+template <int NP>
+__global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 384, RMAX = 4;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, D = a.D, Ta = a.Ta, Te = a.Te;
+    const int n4 = D >> 2, NS = D >> 5;                  // float4 per row, 32-feature segments per row
+    float* xn = lds;                                     // [Ta][D] normalised rows
+    float* part = xn + Ta * D;                           // [Ta][NP][NS] partial dots
+    float* prob = part + Ta * NP * NS;                   // [Ta][NP] probabilities
+    const float* Ub = a.U + (int64_t)b * NP * D;
+    const float* Wb = a.Wf + (int64_t)b * NP * D;
+    float* yb = a.y + (int64_t)b * Ta * D;
+
+    // ---- dots operand: U[p][seg*32 .. +31] ----
+    const int dp = min(tid / NS, NP - 1), dsg = tid % NS;
+    const bool dlive = tid < NP * NS;
+    f32x4 u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = ldg4(Ub + (int64_t)dp * D + dsg * 32 + 4 * i);
+    // ---- comb operands: Wf[p][c4] for all p, old y rows of the thread's row group ----
+    const int ntg = NT / n4;                             // row groups (4 for d = 384, 3 for d = 512)
+    const int rpt = (Ta + ntg - 1) / ntg;                // rows per group (<= RMAX, checked by the launcher)
+    const int c4 = tid % n4, tg = tid / n4;
+    const bool clive = tg < ntg;
+    f32x4 wf[NP], yold[RMAX];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) wf[p] = ldg4(Wb + (int64_t)p * D + 4 * c4);
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) yold[r] = ldg4(yb + (int64_t)min(tg * rpt + r, Ta - 1) * D + 4 * c4);
+    const f32x4 bo = ldg4((a.bo != nullptr ? a.bo : zeros) + 4 * c4);
+    // ---- LayerNorm (ln3: weight + bias) of the sample's rows: wave w takes rows w, w+6, ... ----
+    int cc[2];
+    bool cv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        cv[p] = lane + 64 * p < n4;
+        cc[p] = 4 * min(lane + 64 * p, n4 - 1);
+    }
+    constexpr int RW = 3;  // rows per wave (Ta <= 16 < 6 * 3)
+    f32x4 v[RW][2], lw[2], lb[2];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) v[r][p] = ldg4(yb + (int64_t)min(wave + 6 * r, Ta - 1) * D + cc[p]);
+    const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { lw[p] = ldg4(a.ln_w + cc[p]); lb[p] = ldg4(lnb + cc[p]); }
+    const float inv_d = 1.0f / (float)D;
+    float red[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        red[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p], zero4); red[r] += hsum4(v[r][p]); }
+    }
+    wave_sum_n<RW>(red);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float mean = red[r] * inv_d;
+        red[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p] - mean, zero4); red[r] += hsq4(v[r][p]); }
+    }
+    wave_sum_n<RW>(red);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int t = wave + 6 * r;
+        const float rstd = 1.0f / sqrtf(red[r] * inv_d + 1e-5f);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (cv[p] && t < Ta) *(f32x4*)(xn + t * D + cc[p]) = v[r][p] * rstd * lw[p] + lb[p];
+    }
+    __syncthreads();
+    // ---- partial dots: part[t][p][seg] = xn[t][seg*32..] . U[p][seg*32..] ----
+    if (dlive) {
+        for (int t = 0; t < Ta; ++t) {
+            const float* xr = xn + t * D + dsg * 32;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 x = *(const f32x4*)(xr + 4 * i);
+                acc = fmaf(x.x, u[i].x, acc); acc = fmaf(x.y, u[i].y, acc);
+                acc = fmaf(x.z, u[i].z, acc); acc = fmaf(x.w, u[i].w, acc);
+            }
+            part[(t * NP + dp) * NS + dsg] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- masked softmax per (row, head) over the Te context tokens: key j visible iff j <= t (top-left causal) ----
+    if (tid < Ta * a.H) {
+        const int t = tid / a.H, h = tid % a.H;
+        const int nk = min(Te, t + 1);
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = -INFINITY;
+            if (j < nk) {
+                const int p = h * Te + j;
+                float acc = a.c[(int64_t)b * NP + p];
+                for (int sgi = 0; sgi < NS; ++sgi) acc += part[(t * NP + p) * NS + sgi];  // fixed order
+                sc[j] = acc;
+                mx = fmaxf(mx, acc);
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = j < nk ? expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < Te) prob[t * NP + h * Te + j] = sc[j] * inv;
+    }
+    __syncthreads();
+    // ---- combine + residual: y[t][c4] += bo + sum_p prob[t][p] * Wf[p][c4] ----
+    if (clive) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int t = tg * rpt + r;
+            if (r < rpt && t < Ta) {
+                f32x4 acc = bo;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc += prob[t * NP + p] * wf[p];
+                *(f32x4*)(yb + (int64_t)t * D + 4 * c4) = yold[r] + acc;
+            }
+        }
+    }
+}
+
+// which configurations the collapsed path covers (others keep the q GEMM + attention + c_proj GEMM sequence)
+bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta) {
+    const int NP = H * Te, n4 = D / 4;
+    if (D % 32 || D > 512 || Te < 1 || Te > 4 || Ta > 16) return false;
+    if (NP != 32 && NP != 24 && NP != 16) return false;
+    if (NP * (D / 32) > 384 || n4 > 384) return false;
+    const int ntg = 384 / n4;
+    return (Ta + ntg - 1) / ntg <= 4;
+}
+
+hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s) {
+    if (!mdt_xattn_apply_supported(a.D, a.H, a.Te, a.Ta)) return hipErrorInvalidValue;
+    hipError_t e = ensure_zeros();
+    if (e != hipSuccess) return e;
+    const int NP = a.H * a.Te;
+    const size_t lds = ((size_t)a.Ta * a.D + (size_t)a.Ta * NP * (a.D / 32) + (size_t)a.Ta * NP) * sizeof(float);
+    switch (NP) {
+        case 32: hipLaunchKernelGGL((k_xattn_apply<32>), dim3(a.B), dim3(384), lds, s, a, g_zeros); break;
+        case 24: hipLaunchKernelGGL((k_xattn_apply<24>), dim3(a.B), dim3(384), lds, s, a, g_zeros); break;
+        default: hipLaunchKernelGGL((k_xattn_apply<16>), dim3(a.B), dim3(384), lds, s, a, g_zeros); break;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // GCDenoiser.loss pieces (score_wrappers.py:59-63)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_noise_input(const float* __restrict__ act, const float* __restrict__ noise,

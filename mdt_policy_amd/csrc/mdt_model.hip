@@ -79,6 +79,8 @@ struct EncBlock {
 struct DecBlock : EncBlock {
     float *ln3_w = nullptr, *ln3_b = nullptr;
     Lin xq, xproj;
+    float *xq_raw = nullptr;  // cross_att.query.weight, reference layout (collapsed cross-attention fold)
+    float *xo_T = nullptr;    // cross_att.c_proj.weight transposed
 };
 
 struct Bump {
@@ -97,7 +99,8 @@ struct mdt_model {
     // parameters
     float* arena = nullptr;
     size_t arena_floats = 0;
-    std::vector<Slot> slots;
+    std::vector<Slot> slots;   // one per parameter the path reads (enumerated by mdt_param_*)
+    std::vector<Slot> extra;   // additional images of an already listed parameter (same name)
     Lin tok, incam, goal0, goal2, lang0, lang2, sig1, sig3, kv_all, mod_all;
     std::vector<EncBlock> enc;
     std::vector<DecBlock> dec;
@@ -115,6 +118,9 @@ struct mdt_model {
     // sampler pipelining: the batch is cut into `ways` sample-aligned slices whose launch chains run on separate
     // HIP streams, so one slice's prologue / epilogue / launch gaps overlap another slice's MFMA main loops
     int ways = 1;
+    // collapsed cross-attention (k_xattn_fold / k_xattn_apply): folded projections per sample and decoder block
+    bool xfold = false;
+    float *xU = nullptr, *xW = nullptr, *xc = nullptr;  // [Ld][cap][H*Te][D], same, [Ld][cap][H*Te]
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
@@ -124,6 +130,7 @@ static const int MAX_WAYS = 4;
 // workspace view of a contiguous slice of samples [b0, b0 + nb) for the decoder (Ta rows per sample)
 struct View {
     float *y, *qkv, *att, *hid, *qx, *kvx;
+    int64_t b0;  // first sample of the slice
 };
 
 static View decoder_view(const mdt_model* m, int64_t b0) {
@@ -135,12 +142,14 @@ static View decoder_view(const mdt_model* m, int64_t b0) {
     v.hid = m->hid + r * 4 * m->D;
     v.qx = m->qx + r * m->D;
     v.kvx = m->kvx + b0 * m->Te * (int64_t)m->Ld * 2 * m->D;
+    v.b0 = b0;
     return v;
 }
 
 static View encoder_view(const mdt_model* m) {
     View v;
     v.y = m->h_enc; v.qkv = m->qkv; v.att = m->att; v.hid = m->hid; v.qx = nullptr; v.kvx = nullptr;
+    v.b0 = 0;
     return v;
 }
 
@@ -169,6 +178,12 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
     auto raw = [&](float*& p, const std::string& name, int64_t n) {
         p = b.take(n);
         add_slot(name, n, SLOT_RAW, p, 0, 0, 0);
+    };
+    auto add_extra = [&](const std::string& name, int64_t numel, int kind, float* dst, int rows, int K) {
+        if (!fill_slots) return;
+        Slot s;
+        s.name = name; s.numel = numel; s.kind = kind; s.dst = dst; s.rows = rows; s.K = K; s.n_off = 0;
+        m->extra.push_back(s);
     };
     const std::string P = "inner_model.";
     const bool xb = c.bias != 0;  // reference `bias` flag: c_proj / MLP / custom LayerNorm biases
@@ -236,9 +251,13 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         lin_part(m->kv_all, pre + ".cross_att.key", D, l * 2 * D, true);
         lin_begin(d.xq, D, D, true);
         lin_part(d.xq, pre + ".cross_att.query", D, 0, true);
+        d.xq_raw = b.take((size_t)D * D);
+        add_extra(pre + ".cross_att.query.weight", (int64_t)D * D, SLOT_RAW, d.xq_raw, 0, 0);
         lin_part(m->kv_all, pre + ".cross_att.value", D, l * 2 * D + D, true);
         lin_begin(d.xproj, D, D, xb);
         lin_part(d.xproj, pre + ".cross_att.c_proj", D, 0, xb);
+        d.xo_T = b.take((size_t)D * D);
+        add_extra(pre + ".cross_att.c_proj.weight", (int64_t)D * D, SLOT_TRANSPOSE, d.xo_T, D, D);
         raw(d.ln3_w, pre + ".ln3.weight", D);
         raw(d.ln3_b, pre + ".ln3.bias", D);
         block_common_b(d, pre);
@@ -342,6 +361,8 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     e = hipMalloc((void**)&m->staging, mx * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(m->arena); delete m; return fail(MDT_ERR_HIP, "hipMalloc(staging) failed: %s", hipGetErrorString(e)); }
     m->steps_host.resize(MAX_STEPS * 4);
+    m->xfold = !c.use_rot_embed && mdt_xattn_apply_supported(m->D, m->H, m->Te, m->Ta);
+    if (const char* x = getenv("MDT_HIP_XFOLD")) m->xfold = m->xfold && atoi(x) != 0;
     if (const char* w = getenv("MDT_HIP_WAYS")) m->ways = std::max(1, std::min(MAX_WAYS, atoi(w)));
     for (int i = 0; i < MAX_WAYS - 1; ++i) {
         if (hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) != hipSuccess ||
@@ -397,22 +418,29 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
     if (numel != slot->numel)
         return fail(MDT_ERR_INVALID_ARG, "mdt_load_param: '%s' has %lld elements, expected %lld", name, (long long)numel,
                     (long long)slot->numel);
-    if (slot->kind == SLOT_RAW) {
-        HIP_TRY(hipMemcpyAsync(slot->dst, src, numel * sizeof(float), hipMemcpyDefault, s));
-    } else {
-        const bool transpose = slot->kind == SLOT_TRANSPOSE;
-        hipPointerAttribute_t attr;
-        const float* dev_src = nullptr;
-        hipError_t pe = hipPointerGetAttributes(&attr, src);
-        if (pe == hipSuccess && attr.type == hipMemoryTypeDevice) {
-            dev_src = src;
-        } else {
-            (void)hipGetLastError();  // unregistered host memory reports an error: clear it
-            HIP_TRY(hipMemcpyAsync(m->staging, src, numel * sizeof(float), hipMemcpyHostToDevice, s));
-            dev_src = m->staging;
+    std::vector<Slot*> targets;
+    targets.push_back(slot);
+    for (Slot& e : m->extra)
+        if (e.name == nm) targets.push_back(&e);
+    const float* dev_src = nullptr;  // device image of the source, staged at most once
+    for (Slot* t : targets) {
+        if (t->kind == SLOT_RAW) {
+            HIP_TRY(hipMemcpyAsync(t->dst, src, numel * sizeof(float), hipMemcpyDefault, s));
+            continue;
         }
-        if (transpose) HIP_TRY(mdt_launch_transpose(dev_src, slot->dst, slot->rows, slot->K, s));
-        else HIP_TRY(mdt_launch_pack_weight(dev_src, slot->rows, slot->K, slot->dst, slot->n_off, s));
+        if (dev_src == nullptr) {
+            hipPointerAttribute_t attr;
+            hipError_t pe = hipPointerGetAttributes(&attr, src);
+            if (pe == hipSuccess && attr.type == hipMemoryTypeDevice) {
+                dev_src = src;
+            } else {
+                (void)hipGetLastError();  // unregistered host memory reports an error: clear it
+                HIP_TRY(hipMemcpyAsync(m->staging, src, numel * sizeof(float), hipMemcpyHostToDevice, s));
+                dev_src = m->staging;
+            }
+        }
+        if (t->kind == SLOT_TRANSPOSE) HIP_TRY(mdt_launch_transpose(dev_src, t->dst, t->rows, t->K, s));
+        else HIP_TRY(mdt_launch_pack_weight(dev_src, t->rows, t->K, t->dst, t->n_off, s));
     }
     slot->loaded = true;
     return MDT_OK;
@@ -447,6 +475,12 @@ static void carve_ws(mdt_model* m, Bump& b, int64_t B) {
     m->noised = b.take(Ra * m->A);
     m->Fbuf = b.take(Ra * m->A);
     m->steps = b.take(MAX_STEPS * 4);
+    if (m->xfold) {
+        const int64_t np = (int64_t)m->H * m->Te;
+        m->xU = b.take((size_t)m->Ld * B * np * D);
+        m->xW = b.take((size_t)m->Ld * B * np * D);
+        m->xc = b.take((size_t)m->Ld * B * np);
+    }
 }
 
 extern "C" mdt_status mdt_reserve(mdt_model* m, int64_t max_batch) {
@@ -588,6 +622,19 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
         mdt_gemm_args a = gemm_args(m->ctx, D, m->kv_all, m->kvx, (int64_t)m->Ld * 2 * D, (int)(B * Te));
         LAUNCH(mdt_launch_gemm(a, s));
     }
+    if (m->xfold) {  // fold K|V into the cross-attention projections, once per context (sigma independent)
+        const int64_t np = (int64_t)m->H * Te;
+        for (int l = 0; l < m->Ld; ++l) {
+            mdt_xfold_args f;
+            memset(&f, 0, sizeof f);
+            f.kv = m->kvx + (int64_t)l * 2 * D; f.ldkv = (int64_t)m->Ld * 2 * D;
+            f.Wq = m->dec[l].xq_raw; f.bq = m->dec[l].xq.bias; f.WoT = m->dec[l].xo_T;
+            f.U = m->xU + (int64_t)l * m->cap * np * D; f.Wf = m->xW + (int64_t)l * m->cap * np * D;
+            f.c = m->xc + (int64_t)l * m->cap * np;
+            f.B = (int)B; f.H = m->H; f.hd = m->hd; f.D = D; f.Te = Te;
+            LAUNCH(mdt_launch_xattn_fold(f, s));
+        }
+    }
     m->cached_batch = B;
     return MDT_OK;
 }
@@ -618,20 +665,32 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
         mr.stride = mod_stride;
         MDT_TRY(run_self_attn(m, d, V, B, Ta, true, mr, s));
         // cross attention: ln3 (biased LayerNorm) -> q ; K|V precomputed ; NOT gated, NOT modulated
-        mdt_gemm_args q = gemm_args(V.y, D, d.xq, V.qx, D, M);
-        q.ln = 1; q.ln_w = d.ln3_w; q.ln_b = d.ln3_b; q.rows_per_sample = Ta;
-        LAUNCH(mdt_launch_gemm(q, s));
-        mdt_attn_args a;
-        memset(&a, 0, sizeof a);
-        a.q = V.qx; a.ldq = D;
-        a.k = V.kvx + (int64_t)l * 2 * D; a.v = a.k + D; a.ldkv = (int64_t)m->Ld * 2 * D;
-        a.out = V.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Ta; a.Tk = m->Te;
-        a.causal = 1;  // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
-        a.rope = m->cfg.use_rot_embed;
-        LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
-        mdt_gemm_args p = gemm_args(V.att, D, d.xproj, V.y, D, M);
-        p.residual = 1; p.rows_per_sample = Ta;
-        LAUNCH(mdt_launch_gemm(p, s));
+        if (m->xfold) {
+            const int64_t np = (int64_t)m->H * m->Te;
+            mdt_xapply_args x;
+            memset(&x, 0, sizeof x);
+            x.y = V.y; x.ln_w = d.ln3_w; x.ln_b = d.ln3_b; x.bo = d.xproj.bias;
+            x.U = m->xU + ((int64_t)l * m->cap + V.b0) * np * D;
+            x.Wf = m->xW + ((int64_t)l * m->cap + V.b0) * np * D;
+            x.c = m->xc + ((int64_t)l * m->cap + V.b0) * np;
+            x.B = (int)B; x.H = m->H; x.D = D; x.Te = m->Te; x.Ta = Ta;
+            LAUNCH(mdt_launch_xattn_apply(x, s));
+        } else {
+            mdt_gemm_args q = gemm_args(V.y, D, d.xq, V.qx, D, M);
+            q.ln = 1; q.ln_w = d.ln3_w; q.ln_b = d.ln3_b; q.rows_per_sample = Ta;
+            LAUNCH(mdt_launch_gemm(q, s));
+            mdt_attn_args a;
+            memset(&a, 0, sizeof a);
+            a.q = V.qx; a.ldq = D;
+            a.k = V.kvx + (int64_t)l * 2 * D; a.v = a.k + D; a.ldkv = (int64_t)m->Ld * 2 * D;
+            a.out = V.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Ta; a.Tk = m->Te;
+            a.causal = 1;  // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
+            a.rope = m->cfg.use_rot_embed;
+            LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
+            mdt_gemm_args p = gemm_args(V.att, D, d.xproj, V.y, D, M);
+            p.residual = 1; p.rows_per_sample = Ta;
+            LAUNCH(mdt_launch_gemm(p, s));
+        }
         MDT_TRY(run_mlp(m, d, V, B, Ta, mr, s));
     }
     return MDT_OK;
@@ -834,6 +893,23 @@ extern "C" mdt_status mdt_op_attention(const mdt_attn_args* a, void* stream) {
         return MDT_OK;
     }
     LAUNCH(mdt_launch_attention(*a, nullptr, nullptr, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_xattn_fold(const mdt_xfold_args* a, void* stream) {
+    if (!a || !a->kv || !a->Wq || !a->bq || !a->WoT || !a->U || !a->Wf || !a->c)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_fold: null pointer");
+    if (a->H * a->hd != a->D || a->Te < 1 || a->Te > 4 || a->D > 512)
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_fold: need H*hd == D <= 512 and 1 <= Te <= 4");
+    LAUNCH(mdt_launch_xattn_fold(*a, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_xattn_apply(const mdt_xapply_args* a, void* stream) {
+    if (!a || !a->y || !a->ln_w || !a->U || !a->Wf || !a->c) return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_apply: null pointer");
+    if (!mdt_xattn_apply_supported(a->D, a->H, a->Te, a->Ta))
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_apply: unsupported (D, H, Te, Ta) = (%d, %d, %d, %d)", a->D, a->H, a->Te, a->Ta);
+    LAUNCH(mdt_launch_xattn_apply(*a, (hipStream_t)stream));
     return MDT_OK;
 }
 

@@ -308,3 +308,40 @@ def test_head(lib, mode):
     if mode == "ddim":
         wn = (want / math.sqrt(2.5 ** 2 + sd ** 2)) @ Wa.double().T + ba.double()
         assert_close(y_next.cpu(), wn.float(), rtol=1e-4, atol=1e-4, what="fused next action_emb")
+
+
+@pytest.mark.parametrize("D,H,Te,Ta,bias", [(384, 8, 4, 10, False), (512, 8, 3, 10, True), (128, 8, 4, 10, False),
+                                            (384, 8, 3, 7, True), (256, 8, 2, 16, False)])
+def test_collapsed_cross_attention(lib, D, H, Te, Ta, bias):
+    """k_xattn_fold + k_xattn_apply == y + c_proj(softmax_causal((ln3(y) Wq^T + bq) K^T / sqrt(hd)) V) + bo."""
+    g = torch.Generator().manual_seed(D + Te + Ta)
+    B, hd = 9, D // H
+    y = torch.randn(B * Ta, D, generator=g) * 2
+    kv = torch.randn(B * Te, 2 * D + 64, generator=g)           # K at column 0, V at column D, padded row stride
+    Wq, bq = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
+    Wo, bo = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
+    lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    t = {k: dev(v) for k, v in dict(y=y, kv=kv, Wq=Wq, bq=bq, WoT=Wo.T, bo=bo, lw=lw, lb=lb).items()}
+    NP = H * Te
+    U = torch.full((B * NP * D,), float("nan"), device="cuda")
+    Wf = torch.full((B * NP * D,), float("nan"), device="cuda")
+    c = torch.full((B * NP,), float("nan"), device="cuda")
+    f = lib.XFoldArgs()
+    f.kv, f.ldkv, f.Wq, f.bq, f.WoT = t["kv"].data_ptr(), kv.shape[1], t["Wq"].data_ptr(), t["bq"].data_ptr(), t["WoT"].data_ptr()
+    f.U, f.Wf, f.c, f.B, f.H, f.hd, f.D, f.Te = U.data_ptr(), Wf.data_ptr(), c.data_ptr(), B, H, hd, D, Te
+    lib.check(lib.load().mdt_op_xattn_fold(C.byref(f), stream()))
+    a = lib.XApplyArgs()
+    a.y, a.ln_w, a.ln_b, a.U, a.Wf, a.c = t["y"].data_ptr(), t["lw"].data_ptr(), t["lb"].data_ptr(), U.data_ptr(), Wf.data_ptr(), c.data_ptr()
+    a.bo = t["bo"].data_ptr() if bias else None
+    a.B, a.H, a.D, a.Te, a.Ta = B, H, D, Te, Ta
+    lib.check(lib.load().mdt_op_xattn_apply(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    yd, kd = y.double().view(B, Ta, D), kv.double()
+    K, V = kd[:, :D].view(B, Te, D), kd[:, D:2 * D].view(B, Te, D)
+    q = F.layer_norm(yd, (D,), lw.double(), lb.double(), 1e-5) @ Wq.double().T + bq.double()
+    qh, kh, vh = (x.view(B, -1, H, hd).transpose(1, 2) for x in (q, K, V))
+    att = qh @ kh.transpose(-2, -1) / math.sqrt(hd)
+    att = att.masked_fill(~torch.ones(Ta, Te, dtype=torch.bool).tril(), float("-inf"))
+    o = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Ta, D) @ Wo.double().T + (bo.double() if bias else 0)
+    assert_close(t["y"].cpu().view(B, Ta, D), (yd + o).float(), rtol=2e-4, atol=2e-4, what="collapsed cross attention")
+    assert not torch.isnan(U).any() and not torch.isnan(c).any()

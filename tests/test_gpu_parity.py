@@ -230,3 +230,22 @@ def test_fails_loudly_instead_of_falling_back():
         model.train()(state, noise.cuda(), goal.cuda(), torch.ones(1, device="cuda"))  # dropout not implemented
     with torch.no_grad(), pytest.raises(Exception):
         model.eval()(state, noise.cuda(), goal.cuda()[:, :, :100], torch.ones(1, device="cuda"))  # bad goal shape
+
+
+def test_collapsed_and_explicit_cross_attention_paths_agree(monkeypatch):
+    """MDT_HIP_XFOLD=0 keeps the q-GEMM / attention / c_proj-GEMM sequence; both must match the reference golden."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx = load_fixture("g2_stages_mdtv.npz")
+    state, goal, noise = gpu_inputs(meta)
+    sig = sampling().get_sigmas_exponential(10, meta["sigma_min"], meta["sigma_max"])
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MDT_HIP_XFOLD", flag)
+        model = GCDenoiser(cfg_of(meta), 0.5)
+        model.load_state_dict(params_of(meta))
+        model = model.cuda().eval()
+        with torch.no_grad():
+            outs[flag] = sampling().sample_ddim(model, state, noise * 80.0, goal, sig).cpu()
+        assert_close(outs[flag], fx["actions"], what=f"actions (xfold={flag})")
+    assert_close(outs["1"], outs["0"], rtol=1e-4, atol=1e-5, what="collapsed vs explicit")
+    assert not torch.equal(outs["1"], outs["0"])  # different arithmetic: the two paths really are distinct
