@@ -18,6 +18,7 @@
 //     the epilogue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mdt_internal.h"
 
@@ -137,6 +138,23 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
         for (int i = 0; i < N; ++i) v[i] += t[i];
     }
 }
+
+// one k-step of the MFMA main loop (uses the enclosing kernel's ring / wp / ap / stride / acc / kg / K16): prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
+#define MDT_KSTEP(U, KC)                                                                                  \
+    {                                                                                                     \
+        const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                      \
+            ldg4(wp[j] + kpf * 256);                                                                      \
+        f32x4 av[MTILES];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                        \
+            *(const f32x4*)(ap + i * 16 * stride + (KC) * 16);                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                          \
+                _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                               \
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0);  \
+            }                                                                                             \
+        }                                                                                                 \
+    }
 
 // Geometry: NWAVES waves (4 or 8); tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns), full K.  Wave w owns NTW
 // column tiles and ALL row tiles of the workgroup tile, so a weight fragment is fetched once per workgroup and
@@ -353,22 +371,6 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
         if (active) {
             const int nk = klen >> 4;
             const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
-            // one k-step: prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
-#define MDT_KSTEP(U, KC)                                                                                  \
-    {                                                                                                     \
-        const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
-        _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                      \
-            ldg4(wp[j] + kpf * 256);                                                                      \
-        f32x4 av[MTILES];                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                        \
-            *(const f32x4*)(ap + i * 16 * stride + (KC) * 16);                                            \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                          \
-                _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                               \
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0);  \
-            }                                                                                             \
-        }                                                                                                 \
-    }
             int kc = 0;
             for (; kc + R <= nk; kc += R) {
 #pragma unroll
@@ -388,7 +390,6 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
                     ring[2][j] = rem == 1 ? t0[j] : t1[j];
                 }
             }
-#undef MDT_KSTEP
             kg += nk;
         }
     }
@@ -407,6 +408,148 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
         }
     }
     MDT_TS(4)
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_pipe: the plain-prologue GEMM for K that does not fit LDS in one piece (mlp.c_proj, K = 4d), with
+// LW extra LOADER waves.  vmcnt retires a wave's loads in order, so an MFMA wave that also fetched the next
+// activation chunk would stall its weight ring behind those loads; here the NWAVES compute waves only ever
+// wait on weight fragments while the loader waves copy chunk c+1 into the other LDS buffer.  One workgroup
+// barrier per chunk.
+// ------------------------------------------------------------------------------------------------
+template <int MTILES, int NTW, int NWAVES, int LW, bool RES>
+__global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args a, int kchunk, int grid_n,
+                                                                 const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int MT = MTILES * 16;
+    constexpr int R = 3;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= NWAVES;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / grid_n, bx = logical - by * grid_n;
+    const int m0 = by * MT;
+    const int N16 = a.N >> 4, K16 = a.K >> 4;
+    const int nt0 = (bx * NWAVES + min(wave, NWAVES - 1)) * NTW;
+    const bool active = !loader && nt0 < N16;
+    const int stride = kchunk + 4;
+    const int bufsz = MT * stride;       // floats per LDS buffer
+    const int nchunks = (a.K + kchunk - 1) / kchunk;
+
+    // loader: 32 lanes sweep a row in 512-byte pieces, 2*LW rows per sweep (kchunk <= 384 -> 3 pieces)
+    auto stage = [&](int c) {
+        constexpr int RG = 2 * LW, U = MT / RG;
+        const int lt = tid - 64 * NWAVES, rg = lt >> 5, l32 = lt & 31;
+        const int k0 = c * kchunk, n4 = min(kchunk, a.K - k0) >> 2;
+        float* dst = lds + (c & 1) * bufsz;
+        f32x4 st[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = min(m0 + rg + RG * u, a.M - 1);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) st[u][v] = ldg4(a.A + m * a.lda + k0 + 4 * min(l32 + 32 * v, n4 - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = rg + RG * u;
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+                if (l32 + 32 * v < n4) *(f32x4*)(dst + row * stride + 4 * (l32 + 32 * v)) = sel4(m0 + row < a.M, st[u][v], zero4);
+        }
+    };
+
+    const float* wp[NTW];
+    f32x4 ring[R][NTW];
+    f32x4 acc[MTILES][NTW];
+    const int nq = 4 * (lane >> 4);
+    const bool gated = RES && a.gate_off >= 0;
+    int ncol[NTW];
+    constexpr int NRES = RES ? NTW : 1;
+    f32x4 bias_v[NTW], gate_v[MTILES][NRES], res_v[MTILES][NRES];
+    float* optr[MTILES];
+    if (loader) {
+        stage(0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int nt = min(nt0 + j, N16 - 1);
+            wp[j] = a.Wp + (int64_t)nt * K16 * 256 + lane * 4;
+        }
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
+        const float* biasp = a.bias != nullptr ? a.bias : zeros;
+        const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
+            bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
+            const int64_t orow =
+                a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
+            optr[i] = a.out + orow * a.ldo;
+            if constexpr (RES) {
+                const float* gp = zeros;
+                if (gated)
+                    gp = a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    gate_v[i][j] = ldg4(gp + ncol[j]);
+                    res_v[i][j] = ldg4(optr[i] + ncol[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int kg = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        if (loader) {
+            if (c + 1 < nchunks) stage(c + 1);
+        } else if (active) {
+            const int nk = min(kchunk, a.K - c * kchunk) >> 4;
+            const float* ap = lds + (c & 1) * bufsz + (lane & 15) * stride + 4 * (lane >> 4);
+            int kc = 0;
+            for (; kc + R <= nk; kc += R) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
+            }
+            if (kc < nk) {
+                const int rem = nk - kc;
+                MDT_KSTEP(0, kc)
+                if (rem > 1) MDT_KSTEP(1, kc + 1)
+                f32x4 t0[NTW], t1[NTW], t2[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) { t0[j] = ring[0][j]; t1[j] = ring[1][j]; t2[j] = ring[2][j]; }
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    ring[0][j] = rem == 1 ? t1[j] : t2[j];
+                    ring[1][j] = rem == 1 ? t2[j] : t0[j];
+                    ring[2][j] = rem == 1 ? t0[j] : t1[j];
+                }
+            }
+            kg += nk;
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i) {
+        const bool mok = m0 + i * 16 + (lane & 15) < a.M;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
+            if constexpr (RES) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
+            if (mok && nt0 + j < N16) *(f32x4*)(optr[i] + ncol[j]) = v;
+        }
+    }
 }
 
 static float* g_zeros = nullptr;  // 256 KiB of zeros: stands in for absent bias / rowvec / LayerNorm-bias vectors
@@ -436,6 +579,23 @@ static hipError_t launch_gemm_r(const mdt_gemm_args& a, int kchunk, hipStream_t 
     return hipGetLastError();
 }
 
+template <int MTILES, int NTW, int NWAVES, int LW, bool RES>
+static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
+    const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
+    const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
+    const size_t lds = (size_t)2 * MT * (kchunk + 4) * sizeof(float);  // double-buffered activation chunk
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_pipe<MTILES, NTW, NWAVES, LW, RES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_gemm_pipe<MTILES, NTW, NWAVES, LW, RES>), dim3(gn * gm), dim3(64 * (NWAVES + LW)), lds, s, a,
+                       kchunk, gn, g_zeros);
+    return hipGetLastError();
+}
+
 template <int MTILES, int NTW, int NWAVES, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
     return a.residual ? launch_gemm_r<MTILES, NTW, NWAVES, PRO, true>(a, kchunk, s)
@@ -461,6 +621,7 @@ static hipError_t launch_gemm_pro(const mdt_gemm_args& a, int kchunk, hipStream_
 }
 
 int g_mdt_gemm_force = 0;  // tuning hook: 0 = heuristic, else 1..5 selects a geometry below
+static const bool g_mdt_gemm_nopipe = getenv("MDT_HIP_NOPIPE") != nullptr;  // A/B switch for k_gemm_pipe
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
@@ -478,7 +639,13 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (g_mdt_gemm_force) geo = g_mdt_gemm_force;
     switch (geo) {
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
-        case 2: return launch_gemm_pro<2, 1, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
+        case 2:
+            if (!a.ln && a.K > 512 && !g_mdt_gemm_nopipe) {  // multi-chunk K: loader waves double-buffer the activation chunk
+                const int kc = mdt_gemm_kchunk(a.K, 0, 384);
+                return a.residual ? launch_gemm_pipe_r<2, 1, 8, 4, true>(a, kc, s)
+                                  : launch_gemm_pipe_r<2, 1, 8, 4, false>(a, kc, s);
+            }
+            return launch_gemm_pro<2, 1, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 3: return launch_gemm_pro<2, 3, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 4: return launch_gemm_pro<2, 4, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         default: return launch_gemm_pro<2, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
@@ -496,6 +663,8 @@ template <int HD>
 __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __restrict__ rope_cos,
                                               const float* __restrict__ rope_sin, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    MDT_TS(0)
+    MDT_TS_HWID()
     constexpr int ROT = 32;  // rotary dims (position_embeddings.py / transformer_blocks.py:108)
     const int tid = threadIdx.x, b = blockIdx.x;
     const int D = a.H * HD, d4 = D >> 2;
@@ -528,7 +697,9 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
             if (idx < total) *(f32x4*)(lds + 4 * idx) = t[u];  // q | k | v are laid out back to back
         }
     }
+    MDT_TS(1)
     __syncthreads();
+    MDT_TS(2)
     // ---- compute: LP lanes share one (head, query row); each owns a DS-wide slice of the head dimension ----
     constexpr int LP = HD == 48 ? 3 : (HD >= 32 ? 2 : 1);
     constexpr int DS = HD / LP;  // 16 or 32 dims per lane
@@ -587,6 +758,7 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
             }
         }
     }
+    MDT_TS(3)
     __syncthreads();
     if (!live) return;
     float sc[16];
@@ -628,6 +800,7 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + d0;
 #pragma unroll
     for (int d = 0; d < DS; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
+    MDT_TS(4)
 }
 
 template <int HD>
@@ -986,6 +1159,8 @@ template <int NP>
 __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = 384, RMAX = 4;
+    MDT_TS(0)
+    MDT_TS_HWID()
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, D = a.D, Ta = a.Ta, Te = a.Te;
@@ -1056,7 +1231,9 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
         for (int p = 0; p < 2; ++p)
             if (cv[p] && t < Ta) *(f32x4*)(xn + t * D + cc[p]) = v[r][p] * rstd * lw[p] + lb[p];
     }
+    MDT_TS(1)
     __syncthreads();
+    MDT_TS(2)
     // ---- partial dots: part[t][p][seg] = xn[t][seg*32..] . U[p][seg*32..] ----
     if (dlive) {
         for (int t = 0; t < Ta; ++t) {
@@ -1071,6 +1248,7 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
             part[(t * NP + dp) * NS + dsg] = acc;
         }
     }
+    MDT_TS(3)
     __syncthreads();
     // ---- masked softmax per (row, head) over the Te context tokens: key j visible iff j <= t (top-left causal) ----
     if (tid < Ta * a.H) {
@@ -1111,6 +1289,7 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
             }
         }
     }
+    MDT_TS(4)
 }
 
 // which configurations the collapsed path covers (others keep the q GEMM + attention + c_proj GEMM sequence)
