@@ -145,15 +145,16 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
         const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
         _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                      \
             ldg4(wp[j] + kpf * 256);                                                                      \
-        f32x4 av[MTILES];                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] =                                        \
-            *(const f32x4*)(ap + i * 16 * stride + (KC) * 16);                                            \
+        f32x4 avn[MTILES]; /* activation fragments of the NEXT k-step: their LDS latency hides under the MFMAs */ \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
+            *(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16);                           \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
             _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                          \
                 _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                               \
                     __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0);  \
             }                                                                                             \
         }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
     }
 
 // Geometry: NWAVES waves (4 or 8); tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns), full K.  Wave w owns NTW
@@ -168,7 +169,9 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     MDT_TS_HWID()
     constexpr int MT = MTILES * 16;
     constexpr int NT = 64 * NWAVES;
-    constexpr int R = 3;  // weight-fragment ring: 2 k-steps of 1-KiB loads in flight per column tile (per wave)
+    // weight-fragment ring: R-1 k-steps of 1-KiB loads in flight per column tile.  A k-step is only 8 MFMAs
+    // (256 pipe cycles) with one column tile per wave, so the narrow variants need the deeper ring to cover L2 latency.
+    constexpr int R = NTW == 1 ? 6 : (NTW == 2 ? 4 : 3);
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -371,23 +374,27 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
         if (active) {
             const int nk = klen >> 4;
             const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
+            f32x4 av[MTILES];
+#pragma unroll
+            for (int i = 0; i < MTILES; ++i) av[i] = *(const f32x4*)(ap + i * 16 * stride);
             int kc = 0;
             for (; kc + R <= nk; kc += R) {
 #pragma unroll
                 for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
             }
-            if (kc < nk) {  // tail: nk % 3 steps, then re-align the ring so that slot 0 is the next k-step again
+            if (kc < nk) {  // tail: nk % R steps, then rotate the ring so that slot 0 is the next k-step again
                 const int rem = nk - kc;
-                MDT_KSTEP(0, kc)
-                if (rem > 1) MDT_KSTEP(1, kc + 1)
-                f32x4 t0[NTW], t1[NTW], t2[NTW];
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) { t0[j] = ring[0][j]; t1[j] = ring[1][j]; t2[j] = ring[2][j]; }
+                for (int u = 0; u < R - 1; ++u)
+                    if (u < rem) MDT_KSTEP(u, kc + u)
+                for (int r = 0; r < rem; ++r) {
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    ring[0][j] = rem == 1 ? t1[j] : t2[j];
-                    ring[1][j] = rem == 1 ? t2[j] : t0[j];
-                    ring[2][j] = rem == 1 ? t0[j] : t1[j];
+                    for (int j = 0; j < NTW; ++j) {
+                        const f32x4 first = ring[0][j];
+#pragma unroll
+                        for (int u = 0; u + 1 < R; ++u) ring[u][j] = ring[u + 1][j];
+                        ring[R - 1][j] = first;
+                    }
                 }
             }
             kg += nk;
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
                                                                  const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MT = MTILES * 16;
-    constexpr int R = 3;
+    constexpr int R = NTW == 1 ? 6 : (NTW == 2 ? 4 : 3);
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave >= NWAVES;
@@ -516,6 +523,9 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
         } else if (active) {
             const int nk = min(kchunk, a.K - c * kchunk) >> 4;
             const float* ap = lds + (c & 1) * bufsz + (lane & 15) * stride + 4 * (lane >> 4);
+            f32x4 av[MTILES];
+#pragma unroll
+            for (int i = 0; i < MTILES; ++i) av[i] = *(const f32x4*)(ap + i * 16 * stride);
             int kc = 0;
             for (; kc + R <= nk; kc += R) {
 #pragma unroll
@@ -523,16 +533,17 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
             }
             if (kc < nk) {
                 const int rem = nk - kc;
-                MDT_KSTEP(0, kc)
-                if (rem > 1) MDT_KSTEP(1, kc + 1)
-                f32x4 t0[NTW], t1[NTW], t2[NTW];
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) { t0[j] = ring[0][j]; t1[j] = ring[1][j]; t2[j] = ring[2][j]; }
+                for (int u = 0; u < R - 1; ++u)
+                    if (u < rem) MDT_KSTEP(u, kc + u)
+                for (int r = 0; r < rem; ++r) {
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    ring[0][j] = rem == 1 ? t1[j] : t2[j];
-                    ring[1][j] = rem == 1 ? t2[j] : t0[j];
-                    ring[2][j] = rem == 1 ? t0[j] : t1[j];
+                    for (int j = 0; j < NTW; ++j) {
+                        const f32x4 first = ring[0][j];
+#pragma unroll
+                        for (int u = 0; u + 1 < R; ++u) ring[u][j] = ring[u + 1][j];
+                        ring[R - 1][j] = first;
+                    }
                 }
             }
             kg += nk;
