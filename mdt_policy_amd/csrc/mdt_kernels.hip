@@ -643,10 +643,24 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     //   mid   (8 waves, 32 x 128)           : N  < 1024 -> 240 workgroups for N = 384
     //   small (4 waves, 32 x 64)            : few row tiles (small batches): more, smaller workgroups
     const int gm = (a.M + 31) / 32;
-    int geo;
-    if (gm * ((a.N + 127) / 128) < 128) geo = 1;
-    else if (a.N >= 1024) geo = (a.N % 512 == 0 || a.N % 384 != 0) ? 4 : 3;
-    else geo = 2;
+    // widest geometry that still yields >= 200 workgroups (~1 per CU), preferring one whose column tile divides N;
+    // otherwise the one with the most workgroups
+    const int tile_n[5] = {0, 64, 128, 384, 512};
+    int geo = 1, best = -1;
+    for (int g = 4; g >= 1; --g) {
+        const int cnt = gm * ((a.N + tile_n[g] - 1) / tile_n[g]);
+        if (cnt >= 200) {
+            int score = 4 * g + (a.N % tile_n[g] == 0 ? 100 : 0);
+            if (score > best) { best = score; geo = g; }
+        }
+    }
+    if (best < 0) {
+        int most = -1;
+        for (int g = 1; g <= 4; ++g) {
+            const int cnt = gm * ((a.N + tile_n[g] - 1) / tile_n[g]);
+            if (cnt > most) { most = cnt; geo = g; }
+        }
+    }
     if (g_mdt_gemm_force) geo = g_mdt_gemm_force;
     switch (geo) {
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
@@ -964,11 +978,14 @@ hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t s
 // action head: decoder LN -> action_pred -> EDM combine -> (DDIM update) -> (next step's embedding)
 // one wave per action-token row; A <= 16
 // ------------------------------------------------------------------------------------------------
+// Each wave handles RW = 2 rows so that the action_pred / action_emb weight fragments it fetches (2*AMAX float4 each)
+// are used twice; AMAX (8 or 16) bounds the action dimension at compile time so no load sits behind a branch.
+template <int AMAX>
 __global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __restrict__ zeros) {
+    constexpr int RW = 2;
     const int lane = threadIdx.x & 63;
-    const int mraw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (mraw >= a.M) return;  // wave-uniform
-    const int64_t m = mraw;
+    const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (base >= a.M) return;  // wave-uniform
     const int n4 = a.D >> 2;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     int cc[2];
@@ -978,102 +995,136 @@ __global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __re
         cv[p] = lane + 64 * p < n4;
         cc[p] = 4 * min(lane + 64 * p, n4 - 1);
     }
-    // ---- every global operand of the row is requested up front (clamped addresses, no load behind a branch) ----
-    f32x4 v[2], w[2], bb[2], wp[16][2];
-    float xin[16], bpv[16];
+    int64_t row[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) row[r] = min(base + r, a.M - 1);
+    // ---- every global operand is requested up front (clamped addresses, no load behind a branch) ----
+    f32x4 v[RW][2], w[2], bb[2], wp[AMAX][2];
+    float xin[RW][AMAX], bpv[AMAX], sigma[RW];
     const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        v[p] = ldg4(a.y + m * a.D + cc[p]);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) v[r][p] = ldg4(a.y + row[r] * a.D + cc[p]);
         w[p] = ldg4(a.ln_w + cc[p]);
         bb[p] = ldg4(lnb + cc[p]);
     }
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < AMAX; ++c) {
         const int ce = min(c, a.A - 1);
 #pragma unroll
         for (int p = 0; p < 2; ++p) wp[c][p] = ldg4(a.Wp + (int64_t)ce * a.D + cc[p]);
-        xin[c] = a.x[m * a.A + ce];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) xin[r][c] = a.x[row[r] * a.A + ce];
         bpv[c] = a.bp[ce];
     }
-    const float sigma = a.sigma[(int64_t)(mraw / a.rows_per_sample) * a.sigma_stride];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) sigma[r] = a.sigma[(row[r] / a.rows_per_sample) * a.sigma_stride];
+    // operands of the fused next-step embedding travel in the same latency window (Wa is the (A, D) image)
+    const float* Wa = a.y_next != nullptr ? a.Wa : a.Wp;
+    const float* bap = a.y_next != nullptr ? a.ba : zeros;
+    f32x4 wa[AMAX][2], ba4[2];
+#pragma unroll
+    for (int c = 0; c < AMAX; ++c)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wa[c][p] = ldg4(Wa + (int64_t)min(c, a.A - 1) * a.D + cc[p]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ba4[p] = ldg4(bap + cc[p]);
     float ratio = 0.f, coef = 0.f, sig_next = 1.f;
     if (a.mode == MDT_HEAD_DDIM) {
         ratio = a.step[0];
         coef = a.step[1];
         sig_next = a.step[2];
     }
-    // ---- LayerNorm of the row ----
-    float s = 0.f;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        v[p] = sel4(cv[p], v[p], zero4);
-        s += hsum4(v[p]);
-    }
+    // ---- LayerNorm of the rows ----
     const float inv_d = 1.0f / (float)a.D;
-    const float mean = wave_sum(s) * inv_d;
-    float sq = 0.f;
+    float red[RW];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        v[p] = sel4(cv[p], v[p] - mean, zero4);
-        sq += hsq4(v[p]);
+    for (int r = 0; r < RW; ++r) {
+        red[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p], zero4); red[r] += hsum4(v[r][p]); }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + 1e-5f);
+    wave_sum_n<RW>(red);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) v[p] = sel4(cv[p], v[p] * rstd * w[p] + bb[p], zero4);
-    // ---- action_pred: A dot products reduced together ----
-    float res[16];
+    for (int r = 0; r < RW; ++r) {
+        const float mean = red[r] * inv_d;
+        red[r] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        res[c] = 0.f;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            res[c] += (v[p].x * wp[c][p].x + v[p].y * wp[c][p].y) + (v[p].z * wp[c][p].z + v[p].w * wp[c][p].w);
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p] - mean, zero4); red[r] += hsq4(v[r][p]); }
     }
-    wave_sum_n<16>(res);
+    wave_sum_n<RW>(red);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float rstd = 1.0f / sqrtf(red[r] * inv_d + 1e-5f);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) v[r][p] = sel4(cv[p], v[r][p] * rstd * w[p] + bb[p], zero4);
+    }
+    // ---- action_pred: RW * AMAX dot products reduced together ----
+    float res[RW * AMAX];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                s += (v[r][p].x * wp[c][p].x + v[r][p].y * wp[c][p].y) + (v[r][p].z * wp[c][p].z + v[r][p].w * wp[c][p].w);
+            res[r * AMAX + c] = s;
+        }
+    wave_sum_n<RW * AMAX>(res);
     const float sd = a.sigma_data;
-    const float den2 = sigma * sigma + sd * sd;
-    const float c_skip = sd * sd / den2;
-    const float c_out = sigma * sd / sqrtf(den2);
     const float cin_next = edm_c_in(sig_next, sd);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const float F = res[c] + bpv[c];
-        float r = F;
-        if (a.mode != MDT_HEAD_RAW) {
-            const float den = F * c_out + xin[c] * c_skip;
-            r = a.mode == MDT_HEAD_DDIM ? ratio * xin[c] + coef * den : den;
+    for (int r = 0; r < RW; ++r) {
+        const float den2 = sigma[r] * sigma[r] + sd * sd;
+        const float c_skip = sd * sd / den2;
+        const float c_out = sigma[r] * sd / sqrtf(den2);
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c) {
+            const float F = res[r * AMAX + c] + bpv[c];
+            float o = F;
+            if (a.mode != MDT_HEAD_RAW) {
+                const float den = F * c_out + xin[r][c] * c_skip;
+                o = a.mode == MDT_HEAD_DDIM ? ratio * xin[r][c] + coef * den : den;
+            }
+            res[r * AMAX + c] = o;
         }
-        res[c] = r;
     }
-    // all lanes hold all A results (xor-butterfly sums); lanes 0..A-1 store one each
+    // all lanes hold all results (xor-butterfly sums); lanes 0..A-1 store one each
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-        if (c < a.A && lane == c) a.out[m * a.A + c] = res[c];
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c)
+            if (c < a.A && lane == c && base + r < a.M) a.out[row[r] * a.A + c] = res[r * AMAX + c];
     if (a.y_next != nullptr) {
-        f32x4 acc[2], wa[16][2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) acc[p] = ldg4(a.ba + cc[p]);
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) wa[c][p] = ldg4(a.Wa + (int64_t)min(c, a.A - 1) * a.D + cc[p]);  // (A, D) image
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float xv = c < a.A ? res[c] * cin_next : 0.f;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) acc[p] += xv * wa[c][p];
-        }
+        f32x4 acc[RW][2];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            if (cv[p]) *(f32x4*)(a.y_next + m * a.D + cc[p]) = acc[p];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r][p] = ba4[p];
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float xv = c < a.A ? res[r * AMAX + c] * cin_next : 0.f;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) acc[r][p] += xv * wa[c][p];
+            }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (cv[p] && base + r < a.M) *(f32x4*)(a.y_next + row[r] * a.D + cc[p]) = acc[r][p];
     }
 }
 
 hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
     hipError_t e = ensure_zeros();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_head, dim3((a.M + 3) / 4), dim3(256), 0, s, a, g_zeros);
+    const int grid = (a.M + 7) / 8;  // 4 waves x 2 rows per workgroup
+    if (a.A <= 8) hipLaunchKernelGGL((k_head<8>), dim3(grid), dim3(256), 0, s, a, g_zeros);
+    else hipLaunchKernelGGL((k_head<16>), dim3(grid), dim3(256), 0, s, a, g_zeros);
     return hipGetLastError();
 }
 
@@ -1114,16 +1165,22 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_args a) {
         for (int sb = 0; sb < SB; ++sb)
 #pragma unroll
             for (int j = 0; j < TE; ++j) { accU[sb][j] = 0.f; accW[sb][j] = 0.f; }
-        for (int d = 0; d < HD; ++d) {
-            const float wq = a.Wq[(int64_t)(h * HD + d) * D + n];   // query.weight row (out feature h*hd+d), coalesced over n
-            const float wo = a.WoT[(int64_t)(h * HD + d) * D + n];  // c_proj.weight^T row, coalesced over n
+        for (int d0 = 0; d0 < HD; d0 += 8) {  // HD is a multiple of 16: 8 rows of each weight in flight per lane
+            float wq[8], wo[8];
 #pragma unroll
-            for (int sb = 0; sb < SB; ++sb)
+            for (int e = 0; e < 8; ++e) {
+                wq[e] = a.Wq[(int64_t)(h * HD + d0 + e) * D + n];   // query.weight row (out feature h*hd+d), coalesced over n
+                wo[e] = a.WoT[(int64_t)(h * HD + d0 + e) * D + n];  // c_proj.weight^T row, coalesced over n
+            }
 #pragma unroll
-                for (int j = 0; j < TE; ++j) {
-                    accU[sb][j] = fmaf(wq, Ks[(sb * TE + j) * HD + d], accU[sb][j]);
-                    accW[sb][j] = fmaf(wo, Vs[(sb * TE + j) * HD + d], accW[sb][j]);
-                }
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+                    for (int j = 0; j < TE; ++j) {
+                        accU[sb][j] = fmaf(wq[e], Ks[(sb * TE + j) * HD + d0 + e], accU[sb][j]);
+                        accW[sb][j] = fmaf(wo[e], Vs[(sb * TE + j) * HD + d0 + e], accW[sb][j]);
+                    }
         }
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb) {
