@@ -69,6 +69,11 @@ def build_reference(cfg, arch, seed, profile, sigma_data=0.5):
     new = synthetic.fill_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed, profile)
     for k, v in new.items():
         sd[k] = torch.from_numpy(v)
+    # without a modality encoder lang_emb IS goal_emb (one module under two names): keep one set of values
+    if not cfg.get("use_modality_encoder", False):
+        for k in list(sd):
+            if k.startswith("inner_model.lang_emb"):
+                sd[k] = sd[k.replace("inner_model.lang_emb", "inner_model.goal_emb")]
     model.load_state_dict(sd, strict=True)
     return model
 
@@ -253,6 +258,26 @@ def g7():
     save("g7_samplers.npz", meta, **out)
 
 
+G8_VARIANTS = {
+    # name: (arch, config overrides) -- constructor fields of the boundary that the default configs do not exercise
+    "bias": ("mdtv", dict(bias=True)),
+    "plain_goal": ("mdtv", dict(use_mlp_goal=False, use_modality_encoder=False)),
+    "two_tokens": ("mdtv", dict(n_obs_token=2, action_seq_len=7, action_dim=5, n_heads=4)),
+    "mdt_bias_nopos": ("mdt", dict(bias=True, use_abs_pos_emb=False, n_heads=4)),
+}
+
+
+def g8():
+    for name, (arch, ov) in G8_VARIANTS.items():
+        cfg = (configs.mdtv_tiny if arch == "mdtv" else configs.mdt_tiny)(**ov)
+        model = build_reference(cfg, arch, seed=81, profile="rich")
+        res = run_ddim(model, cfg, arch, B=3, n_steps=3, modality="lang", in_seed=82, record=True)
+        meta = dict(config=f"{arch}_tiny", overrides=ov, arch=arch, B=3, n_steps=3, modality="lang", weight_seed=81,
+                    profile="rich", input_seed=82, sigma_min=0.001, sigma_max=80.0,
+                    state_dict=[[k, list(v.shape)] for k, v in model.state_dict().items()])
+        save(f"g8_{name}.npz", meta, **res)
+
+
 def manifest():
     """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
     out = {}
@@ -275,7 +300,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "manifest"]
     for w in which:
         print(w)
         globals()[w]()

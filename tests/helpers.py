@@ -36,12 +36,19 @@ def rotary_freqs(rot_dim=32, theta=10000.0):
 
 def params_of(meta, dtype=torch.float32):
     """{state_dict name: tensor} regenerated from the deterministic generator (rotary buffers recomputed)."""
-    shapes = [(k, tuple(s)) for k, s in MANIFEST[manifest_key(meta)]["state_dict"]]
+    if "state_dict" in meta:  # variant fixtures carry their own name/shape list
+        shapes = [(k, tuple(s)) for k, s in meta["state_dict"]]
+    else:
+        shapes = [(k, tuple(s)) for k, s in MANIFEST[manifest_key(meta)]["state_dict"]]
     P = {k: torch.from_numpy(v) for k, v in
          synthetic.fill_state_dict(shapes, meta["weight_seed"], meta["profile"]).items()}
     for k, s in shapes:
         if k.endswith("rotary_pos_emb.freqs"):
             P[k] = rotary_freqs(2 * s[0])
+    if not cfg_of(meta).get("use_modality_encoder", False):  # lang_emb is goal_emb under a second name
+        for k in list(P):
+            if k.startswith("inner_model.lang_emb"):
+                P[k] = P[k.replace("inner_model.lang_emb", "inner_model.goal_emb")]
     return {k: v.to(dtype) for k, v in P.items()}
 
 

@@ -249,3 +249,24 @@ def test_collapsed_and_explicit_cross_attention_paths_agree(monkeypatch):
         assert_close(outs[flag], fx["actions"], what=f"actions (xfold={flag})")
     assert_close(outs["1"], outs["0"], rtol=1e-4, atol=1e-5, what="collapsed vs explicit")
     assert not torch.equal(outs["1"], outs["0"])  # different arithmetic: the two paths really are distinct
+
+
+@pytest.mark.parametrize("name", ["bias", "plain_goal", "two_tokens", "mdt_bias_nopos"])
+def test_g8_constructor_variants(name):
+    meta, fx = load_fixture(f"g8_{name}.npz")
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    model = GCDenoiser(cfg_of(meta), 0.5)
+    assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == meta["state_dict"]
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    with torch.no_grad():
+        steps = []
+        out2 = gs.sample_ddim(model, state, noise * meta["sigma_max"], goal, torch.from_numpy(fx["sigmas"]),
+                              callback=lambda d: steps.append(d["denoised"].cpu()))
+        out = gs.sample_ddim(model, state, noise * meta["sigma_max"], goal, torch.from_numpy(fx["sigmas"]))
+    assert_close(model.inner_model.latent_encoder_emb.cpu(), fx["ctx"], what="ctx")
+    assert_close(torch.stack(steps), fx["denoised_steps"], what="denoised")
+    assert_close(out.cpu(), fx["actions"], what="actions (fused loop)")
+    assert_close(out2.cpu(), fx["actions"], what="actions (python loop)")
