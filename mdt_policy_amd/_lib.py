@@ -120,14 +120,15 @@ def load() -> C.CDLL:
         override = os.environ.get("MDT_HIP_LIB")  # tuning A/B runs: an experimental build of the same sources
         if override:
             path = override
-        elif not os.path.exists(path) or (_build.needs_build() and _build.shutil.which("hipcc")):
+        elif not os.path.exists(path):
+            # Only a MISSING library is built here (atomically); a stale one is rebuilt by __graft_entry__.build(),
+            # never implicitly at import time -- N ranks importing at once must not race on the same file.
             try:
                 path = _build.build_library()
             except Exception as e:  # no hipcc and no prebuilt library: there is nothing to run
-                if not os.path.exists(path):
-                    raise RuntimeError(
-                        "libmdt_hip.so is missing and could not be built; the MDT hot path has no CPU/eager "
-                        f"fallback ({e})") from e
+                raise RuntimeError(
+                    "libmdt_hip.so is missing and could not be built; the MDT hot path has no CPU/eager "
+                    f"fallback ({e})") from e
         lib = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

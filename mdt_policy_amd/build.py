@@ -40,14 +40,18 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, d
     if out is None and not force and not needs_build():
         return LIB
     out = out or LIB
+    tmp = f"{out}.tmp.{os.getpid()}"  # compile next to the target, then rename: concurrent importers never see a torn file
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", "-o", out] + [f"-D{d}" for d in defines]
+           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", "-o", tmp] + [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, out)
     if verbose and res.stderr.strip():
         print(res.stderr, file=sys.stderr)
     return out

@@ -149,9 +149,10 @@ def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=Non
     with _hoist(model, state, goal):
         for i in range(n):
             gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0.
+            eps = torch.randn_like(action) * s_noise  # drawn every step, like the reference (same generator stream)
             sigma_hat = sig[i] * (gamma + 1)
             if gamma > 0:
-                action = action + torch.randn_like(action) * s_noise * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+                action = action + eps * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
             denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
             d = to_d(action, sigma_hat, denoised)
             if callback is not None:
@@ -194,9 +195,10 @@ def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None
     with _hoist(model, state, goal):
         for i in range(n):
             gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0.
+            eps = torch.randn_like(action) * s_noise  # drawn every step, like the reference (same generator stream)
             sigma_hat = sig[i] * (gamma + 1)
             if gamma > 0:
-                action = action + torch.randn_like(action) * s_noise * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+                action = action + eps * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
             denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
             d = to_d(action, sigma_hat, denoised)
             if callback is not None:
@@ -257,6 +259,140 @@ def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=
                 x_2 = _f(_sigma(s) / _sigma(t)) * action - _f((-h * 0.5).expm1()) * denoised
                 denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action), **extra_args)
                 action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised_2
+            if scaler is not None:
+                action = scaler.clip_output(action)
+    return action
+
+
+@torch.no_grad()
+def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
+                 s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
+    """DPM-Solver-2 flavoured midpoint steps (reference gc_sampling.py:315-371): derivative at sigma_hat, a second
+    evaluation at the log-midpoint sigma, full step with the midpoint derivative; Euler on the last step."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host(sigmas)
+    n = len(sig) - 1
+    with _hoist(model, state, goal):
+        for i in range(n):
+            gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0.
+            eps = torch.randn_like(action) * s_noise  # drawn every step, like the reference (same generator stream)
+            sigma_hat = sig[i] * (gamma + 1)
+            if gamma > 0:
+                action = action + eps * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+            denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
+            d = to_d(action, sigma_hat, denoised)
+            if callback is not None:
+                callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+            if sig[i + 1] == 0:
+                action = action + d * _f(sig[i + 1] - sigma_hat)
+            else:
+                sigma_mid = sigma_hat.log().lerp(sig[i + 1].log(), 0.5).exp()
+                action_2 = action + d * _f(sigma_mid - sigma_hat)
+                denoised_2 = model(state, action_2, goal, _sig_in(sigma_mid, action), **extra_args)
+                d_2 = to_d(action_2, sigma_mid, denoised_2)
+                action = action + d_2 * _f(sig[i + 1] - sigma_hat)
+            if scaler is not None:
+                action = scaler.clip_output(action)
+    return action
+
+
+@torch.no_grad()
+def sample_dpm_2_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
+                           disable=None, eta=1.):
+    """Ancestral sampling with DPM-Solver-2 midpoint steps (reference gc_sampling.py:374-407)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host(sigmas)
+    with _hoist(model, state, goal):
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
+            if callback is not None:
+                callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            d = to_d(action, sig[i], denoised)
+            if sigma_down == 0:
+                action = action + d * _f(sigma_down - sig[i])
+            else:
+                sigma_mid = sig[i].log().lerp(sigma_down.log(), 0.5).exp()
+                action_2 = action + d * _f(sigma_mid - sig[i])
+                denoised_2 = model(state, action_2, goal, _sig_in(sigma_mid, action), **extra_args)
+                d_2 = to_d(action_2, sigma_mid, denoised_2)
+                action = action + d_2 * _f(sigma_down - sig[i])
+                action = action + torch.randn_like(action) * _f(sigma_up)
+            if scaler is not None:
+                action = scaler.clip_output(action)
+    return action
+
+
+def linear_multistep_coeff(order, t, i, j):
+    """Integral over [t_i, t_{i+1}] of the j-th Lagrange basis polynomial through the last `order` nodes
+    (reference gc_sampling.py:410-422; scipy quadrature, epsrel 1e-4)."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f'Order {order} too high for step {i}')
+
+    def basis(tau):
+        prod = 1.
+        for k in range(order):
+            if k != j:
+                prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(basis, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+@torch.no_grad()
+def sample_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None, order=4):
+    """Linear multistep (Adams-Bashforth in sigma) sampler (reference gc_sampling.py:425-460)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host(sigmas)
+    sig_np = sig.numpy()
+    ds = []
+    with _hoist(model, state, goal):
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            ds.append(to_d(action, sig[i], denoised))
+            if len(ds) > order:
+                ds.pop(0)
+            if callback is not None:
+                callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            cur_order = min(i + 1, order)
+            coeffs = [linear_multistep_coeff(cur_order, sig_np, i, j) for j in range(cur_order)]
+            action = action + sum(coeff * d for coeff, d in zip(coeffs, reversed(ds)))
+            if scaler is not None:
+                action = scaler.clip_output(action)
+    return action
+
+
+@torch.no_grad()
+def sample_dpmpp_2_with_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
+                            disable=None):
+    """The reference's second name for DPM-Solver++(2M) (gc_sampling.py:785-816 is line-for-line its :699-734)."""
+    return sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=scaler, extra_args=extra_args,
+                           callback=callback, disable=disable)
+
+
+@torch.no_grad()
+def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
+                              disable=None, eta=1., s_noise=1., noise_sampler=None):
+    """Ancestral sampling with DPM-Solver++(2S) steps (reference gc_sampling.py:864-907)."""
+    extra_args = {} if extra_args is None else extra_args
+    noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    sig = _host(sigmas)
+    with _hoist(model, state, goal):
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
+            if callback is not None:
+                callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            if sigma_down == 0:
+                action = action + to_d(action, sig[i], denoised) * _f(sigma_down - sig[i])
+            else:
+                t, t_next = _t(sig[i]), _t(sigma_down)
+                h = t_next - t
+                s = t + 0.5 * h
+                x_2 = _f(_sigma(s) / _sigma(t)) * action - _f((-h * 0.5).expm1()) * denoised
+                denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action), **extra_args)
+                action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised_2
+            action = action + noise_sampler(sig[i], sig[i + 1]) * s_noise * _f(sigma_up)
             if scaler is not None:
                 action = scaler.clip_output(action)
     return action

@@ -256,6 +256,20 @@ def g7():
     meta = dict(config="mdtv_default", arch=arch, B=4, n_steps=10, modality="lang", weight_seed=71, profile="rich",
                 input_seed=72, sigma_min=0.001, sigma_max=80.0)
     save("g7_samplers.npz", meta, **out)
+    # the rest of sample_loop's dispatch table (mdtv_agent.py:619-655) that runs in the reference; stochastic ones
+    # once deterministic (eta = 0) and once with the CPU generator seeded right before the call
+    out = {}
+    sigmas = gs.get_sigmas_exponential(10, 0.001, 80.0)
+    x0 = torch.from_numpy(inp["noise"]) * 80.0
+    for name in ("lms", "dpm_2", "dpmpp_2_with_lms", "dpmpp_2s"):
+        out[name] = getattr(gs, "sample_" + name)(model, state, x0.clone(), goal, sigmas, disable=True).numpy()
+    for name in ("euler_ancestral", "dpm_2_ancestral", "dpmpp_2s_ancestral"):
+        out[name + "_eta0"] = getattr(gs, "sample_" + name)(model, state, x0.clone(), goal, sigmas, disable=True, eta=0.).numpy()
+        torch.manual_seed(1234)
+        out[name + "_seed1234"] = getattr(gs, "sample_" + name)(model, state, x0.clone(), goal, sigmas, disable=True).numpy()
+    torch.manual_seed(1234)
+    out["euler_churn_seed1234"] = gs.sample_euler(model, state, x0.clone(), goal, sigmas, disable=True, s_churn=4.).numpy()
+    save("g7b_samplers.npz", meta, **out)
 
 
 G8_VARIANTS = {

@@ -144,3 +144,30 @@ def test_flops_accounting_matches_survey():
     step = 2 * (2 * D * D * 2) + 2 * Ta * A * D * 2 + 4 * blk
     total = enc + kv + 10 * step
     assert abs(total / 1e9 - 1.812) < 0.002
+
+
+@pytest.mark.parametrize("name,kw,key", [
+    ("lms", {}, "lms"), ("dpm_2", {}, "dpm_2"), ("dpmpp_2_with_lms", {}, "dpmpp_2_with_lms"), ("dpmpp_2s", {}, "dpmpp_2s"),
+    ("euler_ancestral", dict(eta=0.), "euler_ancestral_eta0"), ("dpm_2_ancestral", dict(eta=0.), "dpm_2_ancestral_eta0"),
+    ("dpmpp_2s_ancestral", dict(eta=0.), "dpmpp_2s_ancestral_eta0"),
+    ("euler_ancestral", dict(seed=1234), "euler_ancestral_seed1234"),
+    ("dpm_2_ancestral", dict(seed=1234), "dpm_2_ancestral_seed1234"),
+    ("dpmpp_2s_ancestral", dict(seed=1234), "dpmpp_2s_ancestral_seed1234"),
+    ("euler", dict(seed=1234, s_churn=4.), "euler_churn_seed1234")])
+def test_remaining_sampler_loops_against_reference_golden(name, kw, key):
+    """The rest of sample_loop's dispatch table (mdtv_agent.py:619-655) on CPU with the oracle denoiser as ``model``;
+    the stochastic samplers consume the torch CPU generator in exactly the reference's order."""
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from oracle import mdt_oracle as O
+    from tests.helpers import assert_close, cfg_of, inputs_of, params_of
+    meta, fx = load_fixture("g7b_samplers.npz")
+    cfg, P = cfg_of(meta), params_of(meta)
+    state, goal, noise = inputs_of(meta)
+    ctx = O.encode(P, cfg, state, goal)
+    model = lambda s, x, g, sigma: O.denoise(P, cfg, s, x, g, sigma, ctx=ctx)
+    sig = gs.get_sigmas_exponential(10, 0.001, 80.0)
+    kw = dict(kw)
+    if "seed" in kw:
+        torch.manual_seed(kw.pop("seed"))
+    out = getattr(gs, "sample_" + name)(model, state, noise * 80.0, goal, sig, **kw)
+    assert_close(out.numpy(), fx[key], rtol=2e-4, atol=2e-4, what=key)

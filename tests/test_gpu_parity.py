@@ -270,3 +270,18 @@ def test_g8_constructor_variants(name):
     assert_close(torch.stack(steps), fx["denoised_steps"], what="denoised")
     assert_close(out.cpu(), fx["actions"], what="actions (fused loop)")
     assert_close(out2.cpu(), fx["actions"], what="actions (python loop)")
+
+
+@pytest.mark.parametrize("name,kw,key", [
+    ("lms", {}, "lms"), ("dpm_2", {}, "dpm_2"), ("dpmpp_2_with_lms", {}, "dpmpp_2_with_lms"), ("dpmpp_2s", {}, "dpmpp_2s"),
+    ("euler_ancestral", dict(eta=0.), "euler_ancestral_eta0"), ("dpm_2_ancestral", dict(eta=0.), "dpm_2_ancestral_eta0"),
+    ("dpmpp_2s_ancestral", dict(eta=0.), "dpmpp_2s_ancestral_eta0")])
+def test_g7b_remaining_samplers(name, kw, key):
+    """The rest of sample_loop's dispatch table with the HIP denoiser step (deterministic settings)."""
+    meta, fx = load_fixture("g7b_samplers.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    with torch.no_grad():
+        out = getattr(gs, "sample_" + name)(model, state, noise * 80.0, goal, gs.get_sigmas_exponential(10, 0.001, 80.0), **kw)
+    assert_close(out.cpu(), fx[key], what=key)
