@@ -139,13 +139,20 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the hot path has no CPU execution path")
-    device = torch.device("cuda", local)
+    # MDT_BENCH_SHARE_GPU=1 (+ MDT_BENCH_BACKEND=gloo) lets the N > 1 code path be exercised on a 1-GPU box: all ranks
+    # use device 0 and gather through gloo.  Never set by the driver; numbers from such a run are meaningless.
+    share = os.environ.get("MDT_BENCH_SHARE_GPU") == "1"
+    device = torch.device("cuda", 0 if share else local)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+        backend = os.environ.get("MDT_BENCH_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mdt_policy_amd import sharding, synthetic
     from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
