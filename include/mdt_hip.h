@@ -118,8 +118,10 @@ mdt_status mdt_encode(mdt_model *m, const float *tokens, const float *tokens2, c
  * (reference score_wrappers.py:65-80 -> mdtv_transformer.py:224-236): EDM preconditioning, sigma
  * embedding, adaLN decoder, action head.   x:(B,Ta,A)  sigma:(B,) device  out:(B,Ta,A).
  * flags: MDT_RAW_OUTPUT returns the network output F instead of F*c_out + x*c_skip (GCDenoiser.loss);
- *        MDT_RAW_INPUT feeds x to action_emb without the c_in scaling (inner_model.forward_dec_only). */
-enum { MDT_RAW_OUTPUT = 1, MDT_RAW_INPUT = 2 };
+ *        MDT_RAW_INPUT feeds x to action_emb without the c_in scaling (inner_model.forward_dec_only);
+ *        MDT_SIGMA_SCALAR: `sigma` points to ONE float shared by the whole batch (what every sampler passes:
+ *        sigmas[i] * s_in) -- one sigma-embedding / adaLN row instead of B, broadcast by the kernels. */
+enum { MDT_RAW_OUTPUT = 1, MDT_RAW_INPUT = 2, MDT_SIGMA_SCALAR = 4 };
 mdt_status mdt_denoise_cached(mdt_model *m, const float *x, const float *sigma, int64_t batch,
                               int32_t flags, float *out, void *stream);
 

@@ -70,7 +70,7 @@ ARCH = {"mdtv": 0, "mdt": 1}
 MODALITY = {"vis": 0, "lang": 1}
 ACT = {"none": 0, "gelu": 1, "mish": 2, "silu": 3}
 HEAD = {"denoised": 0, "ddim": 1, "raw": 2}
-RAW_OUTPUT, RAW_INPUT = 1, 2
+RAW_OUTPUT, RAW_INPUT, SIGMA_SCALAR = 1, 2, 4
 
 # every symbol include/*.h declares: (name, restype, argtypes)
 _VP, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float

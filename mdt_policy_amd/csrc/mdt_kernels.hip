@@ -1240,23 +1240,8 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
     const float* Wb = a.Wf + (int64_t)b * NP * D;
     float* yb = a.y + (int64_t)b * Ta * D;
 
-    // ---- dots operand: U[p][seg*32 .. +31] ----
-    const int dp = min(tid / NS, NP - 1), dsg = tid % NS;
-    const bool dlive = tid < NP * NS;
-    f32x4 u[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = ldg4(Ub + (int64_t)dp * D + dsg * 32 + 4 * i);
-    // ---- comb operands: Wf[p][c4] for all p, old y rows of the thread's row group ----
-    const int ntg = NT / n4;                             // row groups (4 for d = 384, 3 for d = 512)
-    const int rpt = (Ta + ntg - 1) / ntg;                // rows per group (<= RMAX, checked by the launcher)
-    const int c4 = tid % n4, tg = tid / n4;
-    const bool clive = tg < ntg;
-    f32x4 wf[NP], yold[RMAX];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) wf[p] = ldg4(Wb + (int64_t)p * D + 4 * c4);
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) yold[r] = ldg4(yb + (int64_t)min(tg * rpt + r, Ta - 1) * D + 4 * c4);
-    const f32x4 bo = ldg4((a.bo != nullptr ? a.bo : zeros) + 4 * c4);
+    // Loads are requested in the order they are consumed (vmcnt retires in order): the sample's rows and the ln3
+    // vectors first, then the U segment, then the Wf column and the old rows for the residual.
     // ---- LayerNorm (ln3: weight + bias) of the sample's rows: wave w takes rows w, w+6, ... ----
     int cc[2];
     bool cv[2];
@@ -1274,6 +1259,24 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
     const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
 #pragma unroll
     for (int p = 0; p < 2; ++p) { lw[p] = ldg4(a.ln_w + cc[p]); lb[p] = ldg4(lnb + cc[p]); }
+    // ---- dots operand: 8 float4 of U[p], INTERLEAVED over the row (float4 index dsg + NS*i): consecutive lanes read
+    //      consecutive 16-byte pieces both from global memory and, for the normalised rows, from LDS ----
+    const int dp = min(tid / NS, NP - 1), dsg = tid % NS;
+    const bool dlive = tid < NP * NS;
+    f32x4 u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = ldg4(Ub + (int64_t)dp * D + 4 * (dsg + NS * i));
+    // ---- comb operands: Wf[p][c4] for all p, old y rows of the thread's row group ----
+    const int ntg = NT / n4;                             // row groups (4 for d = 384, 3 for d = 512)
+    const int rpt = (Ta + ntg - 1) / ntg;                // rows per group (<= RMAX, checked by the launcher)
+    const int c4 = tid % n4, tg = tid / n4;
+    const bool clive = tg < ntg;
+    f32x4 wf[NP], yold[RMAX];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) wf[p] = ldg4(Wb + (int64_t)p * D + 4 * c4);
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) yold[r] = ldg4(yb + (int64_t)min(tg * rpt + r, Ta - 1) * D + 4 * c4);
+    const f32x4 bo = ldg4((a.bo != nullptr ? a.bo : zeros) + 4 * c4);
     const float inv_d = 1.0f / (float)D;
     float red[RW];
 #pragma unroll
@@ -1305,11 +1308,11 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
     // ---- partial dots: part[t][p][seg] = xn[t][seg*32..] . U[p][seg*32..] ----
     if (dlive) {
         for (int t = 0; t < Ta; ++t) {
-            const float* xr = xn + t * D + dsg * 32;
+            const float* xr = xn + t * D + 4 * dsg;
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const f32x4 x = *(const f32x4*)(xr + 4 * i);
+                const f32x4 x = *(const f32x4*)(xr + 4 * NS * i);
                 acc = fmaf(x.x, u[i].x, acc); acc = fmaf(x.y, u[i].y, acc);
                 acc = fmaf(x.z, u[i].z, acc); acc = fmaf(x.w, u[i].w, acc);
             }
@@ -1352,7 +1355,10 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
             if (r < rpt && t < Ta) {
                 f32x4 acc = bo;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) acc += prob[t * NP + p] * wf[p];
+                for (int p = 0; p < NP; p += 4) {
+                    const f32x4 pr = *(const f32x4*)(prob + t * NP + p);  // broadcast read of 4 probabilities
+                    acc += pr.x * wf[p] + pr.y * wf[p + 1] + pr.z * wf[p + 2] + pr.w * wf[p + 3];
+                }
                 *(f32x4*)(yb + (int64_t)t * D + 4 * c4) = yold[r] + acc;
             }
         }

@@ -724,12 +724,14 @@ extern "C" mdt_status mdt_denoise_cached(mdt_model* m, const float* x, const flo
         return fail(MDT_ERR_STATE, "mdt_denoise_cached: no cached context for batch %lld (last mdt_encode batch: %lld)",
                     (long long)batch, (long long)m->cached_batch);
     hipStream_t s = (hipStream_t)stream;
+    const bool scalar = (flags & MDT_SIGMA_SCALAR) != 0;
     const int64_t modw = (int64_t)m->Ld * 6 * m->D;
-    MDT_TRY(run_modulation(m, sigma, 1, (int)batch, s));
-    LAUNCH(mdt_launch_action_embed(x, (flags & MDT_RAW_INPUT) ? nullptr : sigma, 1, m->cfg.sigma_data, m->Wa, m->ba,
+    const int64_t sst = scalar ? 0 : 1;  // stride of sigma / of the modulation rows across samples
+    MDT_TRY(run_modulation(m, sigma, 1, scalar ? 1 : (int)batch, s));
+    LAUNCH(mdt_launch_action_embed(x, (flags & MDT_RAW_INPUT) ? nullptr : sigma, sst, m->cfg.sigma_data, m->Wa, m->ba,
                                    m->y, (int)(batch * m->Ta), m->A, m->D, m->Ta, s));
-    MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, m->mod, modw, s));
-    mdt_head_args h = head_args(m, m->y, batch, x, sigma, 1, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
+    MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, m->mod, scalar ? 0 : modw, s));
+    mdt_head_args h = head_args(m, m->y, batch, x, sigma, sst, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
     LAUNCH(mdt_launch_head(h, s));
     return MDT_OK;
 }

@@ -115,8 +115,11 @@ def _f(x):
     return x.item() if torch.is_tensor(x) else float(x)
 
 
-def _sig_in(sigma, action):
-    return torch.full((action.shape[0],), _f(sigma), device=action.device, dtype=action.dtype)
+def _sig_in(sigma, action, model=None):
+    """sigma * s_in of the reference.  This package's denoiser takes the single shared value (one adaLN row for the
+    whole batch, broadcast inside the kernels); any other model gets the reference's (B,) vector."""
+    n = 1 if isinstance(model, GCDenoiser) else action.shape[0]
+    return torch.full((n,), _f(sigma), device=action.device, dtype=action.dtype)
 
 
 @torch.no_grad()
@@ -130,7 +133,7 @@ def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None
     sig = _host(sigmas)
     with _hoist(model, state, goal):
         for i in range(len(sig) - 1):
-            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
             if callback is not None:
                 callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
             t, t_next = _t(sig[i]), _t(sig[i + 1])
@@ -153,7 +156,7 @@ def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=Non
             sigma_hat = sig[i] * (gamma + 1)
             if gamma > 0:
                 action = action + eps * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
-            denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sigma_hat, action, model), **extra_args)
             d = to_d(action, sigma_hat, denoised)
             if callback is not None:
                 callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
@@ -171,7 +174,7 @@ def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extr
     sig = _host(sigmas)
     with _hoist(model, state, goal):
         for i in range(len(sig) - 1):
-            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
             sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
             if callback is not None:
                 callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
@@ -199,7 +202,7 @@ def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None
             sigma_hat = sig[i] * (gamma + 1)
             if gamma > 0:
                 action = action + eps * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
-            denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sigma_hat, action, model), **extra_args)
             d = to_d(action, sigma_hat, denoised)
             if callback is not None:
                 callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
@@ -208,7 +211,7 @@ def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None
                 action = action + d * dt
             else:
                 action_2 = action + d * dt
-                denoised_2 = model(state, action_2, goal, _sig_in(sig[i + 1], action), **extra_args)
+                denoised_2 = model(state, action_2, goal, _sig_in(sig[i + 1], action, model), **extra_args)
                 d_2 = to_d(action_2, sig[i + 1], denoised_2)
                 action = action + (d + d_2) / 2 * dt
             if scaler is not None:
@@ -224,7 +227,7 @@ def sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=None, extra_args=
     old_denoised = None
     with _hoist(model, state, goal):
         for i in range(len(sig) - 1):
-            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
             if callback is not None:
                 callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
             t, t_next = _t(sig[i]), _t(sig[i + 1])
@@ -247,7 +250,7 @@ def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=
     sig = _host(sigmas)
     with _hoist(model, state, goal):
         for i in range(len(sig) - 1):
-            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
             if callback is not None:
                 callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
             if sig[i + 1] == 0:
@@ -257,7 +260,7 @@ def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=
                 h = t_next - t
                 s = t + 0.5 * h
                 x_2 = _f(_sigma(s) / _sigma(t)) * action - _f((-h * 0.5).expm1()) * denoised
-                denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action), **extra_args)
+                denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action, model), **extra_args)
                 action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised_2
             if scaler is not None:
                 action = scaler.clip_output(action)
@@ -279,7 +282,7 @@ def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=Non
             sigma_hat = sig[i] * (gamma + 1)
             if gamma > 0:
                 action = action + eps * _f((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
-            denoised = model(state, action, goal, _sig_in(sigma_hat, action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sigma_hat, action, model), **extra_args)
             d = to_d(action, sigma_hat, denoised)
             if callback is not None:
                 callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
@@ -288,7 +291,7 @@ def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=Non
             else:
                 sigma_mid = sigma_hat.log().lerp(sig[i + 1].log(), 0.5).exp()
                 action_2 = action + d * _f(sigma_mid - sigma_hat)
-                denoised_2 = model(state, action_2, goal, _sig_in(sigma_mid, action), **extra_args)
+                denoised_2 = model(state, action_2, goal, _sig_in(sigma_mid, action, model), **extra_args)
                 d_2 = to_d(action_2, sigma_mid, denoised_2)
                 action = action + d_2 * _f(sig[i + 1] - sigma_hat)
             if scaler is not None:
@@ -304,7 +307,7 @@ def sample_dpm_2_ancestral(model, state, action, goal, sigmas, scaler=None, extr
     sig = _host(sigmas)
     with _hoist(model, state, goal):
         for i in range(len(sig) - 1):
-            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
             sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
             if callback is not None:
                 callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
@@ -314,7 +317,7 @@ def sample_dpm_2_ancestral(model, state, action, goal, sigmas, scaler=None, extr
             else:
                 sigma_mid = sig[i].log().lerp(sigma_down.log(), 0.5).exp()
                 action_2 = action + d * _f(sigma_mid - sig[i])
-                denoised_2 = model(state, action_2, goal, _sig_in(sigma_mid, action), **extra_args)
+                denoised_2 = model(state, action_2, goal, _sig_in(sigma_mid, action, model), **extra_args)
                 d_2 = to_d(action_2, sigma_mid, denoised_2)
                 action = action + d_2 * _f(sigma_down - sig[i])
                 action = action + torch.randn_like(action) * _f(sigma_up)
@@ -348,7 +351,7 @@ def sample_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None,
     ds = []
     with _hoist(model, state, goal):
         for i in range(len(sig) - 1):
-            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
             ds.append(to_d(action, sig[i], denoised))
             if len(ds) > order:
                 ds.pop(0)
@@ -379,7 +382,7 @@ def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, e
     sig = _host(sigmas)
     with _hoist(model, state, goal):
         for i in range(len(sig) - 1):
-            denoised = model(state, action, goal, _sig_in(sig[i], action), **extra_args)
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
             sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
             if callback is not None:
                 callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
@@ -390,7 +393,7 @@ def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, e
                 h = t_next - t
                 s = t + 0.5 * h
                 x_2 = _f(_sigma(s) / _sigma(t)) * action - _f((-h * 0.5).expm1()) * denoised
-                denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action), **extra_args)
+                denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action, model), **extra_args)
                 action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised_2
             action = action + noise_sampler(sig[i], sig[i + 1]) * s_noise * _f(sigma_up)
             if scaler is not None:

@@ -130,7 +130,11 @@ class HipEngine:
     def denoise_cached(self, x: torch.Tensor, sigma: torch.Tensor, flags: int = 0) -> torch.Tensor:
         x_ = self._in(x)
         B = x_.shape[0]
-        s = self._in(sigma, (B,))
+        if sigma.numel() == 1 and B > 1:  # one noise level for the whole batch (every sampler): broadcast in-kernel
+            s = self._in(sigma, (1,))
+            flags |= _lib.SIGMA_SCALAR
+        else:
+            s = self._in(sigma, (B,))
         out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         _lib.check(self.lib.mdt_denoise_cached(self.handle, _ptr(x_), _ptr(s), B, flags, _ptr(out), self._stream()))
         return out
@@ -138,6 +142,8 @@ class HipEngine:
     def forward(self, state: dict, x: torch.Tensor, goal: torch.Tensor, sigma: torch.Tensor):
         self.sync_params()
         tok, tok2, B = self._tokens(state)
+        if sigma.numel() == 1 and B > 1:
+            sigma = sigma.reshape(1).expand(B)
         g, x_, s = self._goal(goal, B), self._in(x, (B, self.Ta, self.A)), self._in(sigma, (B,))
         out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
