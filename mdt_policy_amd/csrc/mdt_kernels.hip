@@ -692,7 +692,11 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     MDT_TS_HWID()
     constexpr int ROT = 32;  // rotary dims (position_embeddings.py / transformer_blocks.py:108)
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int D = a.H * HD, d4 = D >> 2;
+    // gridDim.y workgroups share a sample, each taking H / gridDim.y heads (a contiguous column range of q/k/v):
+    // two half-size workgroups per CU overlap each other's load / compute phases
+    const int Hl = a.H / gridDim.y;              // heads of this workgroup
+    const int coff = blockIdx.y * Hl * HD;       // first column
+    const int D = Hl * HD, d4 = D >> 2;          // row length staged in LDS
     float* qs = lds;                  // [Tq][D]
     float* ks = qs + a.Tq * D;        // [Tk][D]
     float* vs = ks + a.Tk * D;        // [Tk][D]
@@ -706,13 +710,13 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
             const float* src;
             if (idx < nq) {
                 const int r = idx / d4;
-                src = a.q + (int64_t)(b * a.Tq + r) * a.ldq + 4 * (idx - r * d4);
+                src = a.q + (int64_t)(b * a.Tq + r) * a.ldq + coff + 4 * (idx - r * d4);
             } else if (idx < nq + nkv) {
                 const int i2 = idx - nq, r = i2 / d4;
-                src = a.k + (int64_t)(b * a.Tk + r) * a.ldkv + 4 * (i2 - r * d4);
+                src = a.k + (int64_t)(b * a.Tk + r) * a.ldkv + coff + 4 * (i2 - r * d4);
             } else {
                 const int i2 = idx - nq - nkv, r = i2 / d4;
-                src = a.v + (int64_t)(b * a.Tk + r) * a.ldkv + 4 * (i2 - r * d4);
+                src = a.v + (int64_t)(b * a.Tk + r) * a.ldkv + coff + 4 * (i2 - r * d4);
             }
             t[u] = ldg4(src);
         }
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     constexpr int LP = HD == 48 ? 3 : (HD >= 32 ? 2 : 1);
     constexpr int DS = HD / LP;  // 16 or 32 dims per lane
     float* part = vs + a.Tk * D;  // [pairs][16 keys][LP] partial scores
-    const int npairs = a.H * a.Tq;
+    const int npairs = Hl * a.Tq;
     const int pr = tid % npairs, ps = tid / npairs;  // pair, slice (slices of a pair sit in different waves)
     const bool live = tid < npairs * LP;
     const int t = pr % a.Tq, h = pr / a.Tq;
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
             }
         }
     }
-    float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + d0;
+    float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + coff + d0;
 #pragma unroll
     for (int d = 0; d < DS; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
     MDT_TS(4)
@@ -831,14 +835,16 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
 template <int HD>
 static hipError_t launch_attn_t(const mdt_attn_args& a, const float* rc, const float* rs, hipStream_t s) {
     constexpr int LP = HD == 48 ? 3 : (HD >= 32 ? 2 : 1);
-    const size_t lds = ((size_t)(a.Tq + 2 * a.Tk) * a.H * HD + (size_t)a.H * a.Tq * 16 * LP) * sizeof(float);
+    const int hs = (a.H % 2 == 0 && a.B >= 64) ? 2 : 1;  // head split: 2 half-size workgroups per sample
+    const int Hl = a.H / hs;
+    const size_t lds = ((size_t)(a.Tq + 2 * a.Tk) * Hl * HD + (size_t)Hl * a.Tq * 16 * LP) * sizeof(float);
     static size_t lds_attr = 0;
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_attn<HD>), dim3(a.B), dim3(256), lds, s, a, rc, rs, 1.0f / sqrtf((float)HD));
+    hipLaunchKernelGGL((k_attn<HD>), dim3(a.B, hs), dim3(256), lds, s, a, rc, rs, 1.0f / sqrtf((float)HD));
     return hipGetLastError();
 }
 

@@ -224,9 +224,10 @@ def ref_attn(q, k, v, H, causal, rope=False):
 @pytest.mark.parametrize("H,hd,Tq,Tk,causal", [(8, 48, 10, 10, True), (8, 48, 10, 4, True), (8, 48, 4, 4, False),
                                                (8, 16, 10, 3, True), (8, 64, 10, 10, True), (4, 32, 16, 16, False),
                                                (8, 48, 1, 1, True)])
-def test_attention(lib, H, hd, Tq, Tk, causal):
+@pytest.mark.parametrize("B", [13, 70])  # >= 64 samples: two half-size workgroups per sample (head split)
+def test_attention(lib, H, hd, Tq, Tk, causal, B):
     g = torch.Generator().manual_seed(H + hd + Tq + Tk)
-    B, D = 13, H * hd
+    D = H * hd
     q, k, v = (torch.randn(B, T, D, generator=g) for T in (Tq, Tk, Tk))
     assert_close(run_attn(lib, q, k, v, H, causal), ref_attn(q, k, v, H, causal), rtol=1e-4, atol=1e-5, what="attention")
 
