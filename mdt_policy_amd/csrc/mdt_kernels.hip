@@ -684,7 +684,10 @@ extern "C" void mdt_op_set_gemm_geometry(int32_t geo) { g_mdt_gemm_force = geo; 
 // batched 16-byte loads, then thread (head, query row) runs softmax(q k^T) v out of LDS with the scores in
 // registers.  10x10 / 10x4 / 4x4 score matrices are 0.1 % of the FLOPs, so this stays on the VALU.
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+// TKC: compile-time bound on the number of keys (4 / 10 / 16, the smallest >= Tk), ROPE: rotary embedding on q/k.
+// With both fixed the score / softmax / PV loops are straight-line code over clamped rows with select masks, so the
+// compiler can batch the LDS reads instead of waiting on each one behind a branch.
+template <int HD, int TKC, bool ROPE>
 __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __restrict__ rope_cos,
                                               const float* __restrict__ rope_sin, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -692,8 +695,7 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     MDT_TS_HWID()
     constexpr int ROT = 32;  // rotary dims (position_embeddings.py / transformer_blocks.py:108)
     const int tid = threadIdx.x, b = blockIdx.x;
-    // gridDim.y workgroups share a sample, each taking H / gridDim.y heads (a contiguous column range of q/k/v):
-    // two half-size workgroups per CU overlap each other's load / compute phases
+    // gridDim.y workgroups share a sample, each taking H / gridDim.y heads (a contiguous column range of q/k/v)
     const int Hl = a.H / gridDim.y;              // heads of this workgroup
     const int coff = blockIdx.y * Hl * HD;       // first column
     const int D = Hl * HD, d4 = D >> 2;          // row length staged in LDS
@@ -734,79 +736,72 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     constexpr int DS = HD / LP;  // 16 or 32 dims per lane
     float* part = vs + a.Tk * D;  // [pairs][16 keys][LP] partial scores
     const int npairs = Hl * a.Tq;
-    const int pr = tid % npairs, ps = tid / npairs;  // pair, slice (slices of a pair sit in different waves)
+    const int pr = min(tid % npairs, npairs - 1), ps = min(tid / npairs, LP - 1);  // pair, slice (clamped: idle lanes recompute)
     const bool live = tid < npairs * LP;
     const int t = pr % a.Tq, h = pr / a.Tq;
     const int nk = a.causal ? min(a.Tk, t + 1) : a.Tk;
     const int d0 = h * HD + ps * DS;
     float q[DS];
-    if (live) {
+#pragma unroll
+    for (int d = 0; d < DS; d += 4) {
+        const f32x4 x = *(const f32x4*)(qs + t * D + d0 + d);
+        q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+    }
+    if constexpr (ROPE) {
+#pragma unroll
+        for (int i = 0; i < DS / 2; ++i) {
+            const int gi = (ps * DS) / 2 + i;  // rotary pair index inside the head
+            if (gi < ROT / 2) {
+                const float c = rope_cos[t * 16 + gi], sn = rope_sin[t * 16 + gi];
+                const float x1 = q[2 * i], x2 = q[2 * i + 1];
+                q[2 * i] = x1 * c - x2 * sn;
+                q[2 * i + 1] = x2 * c + x1 * sn;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) {
+        const int jc = min(j, a.Tk - 1);
+        const float* kp = ks + jc * D + d0;
+        float kr[DS];
 #pragma unroll
         for (int d = 0; d < DS; d += 4) {
-            const f32x4 x = *(const f32x4*)(qs + t * D + d0 + d);
-            q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+            const f32x4 x = *(const f32x4*)(kp + d);
+            kr[d] = x.x; kr[d + 1] = x.y; kr[d + 2] = x.z; kr[d + 3] = x.w;
         }
-        if (a.rope) {
+        if constexpr (ROPE) {
 #pragma unroll
             for (int i = 0; i < DS / 2; ++i) {
-                const int gi = (ps * DS) / 2 + i;  // rotary pair index inside the head
+                const int gi = (ps * DS) / 2 + i;
                 if (gi < ROT / 2) {
-                    const float c = rope_cos[t * 16 + gi], sn = rope_sin[t * 16 + gi];
-                    const float x1 = q[2 * i], x2 = q[2 * i + 1];
-                    q[2 * i] = x1 * c - x2 * sn;
-                    q[2 * i + 1] = x2 * c + x1 * sn;
+                    const float c = rope_cos[jc * 16 + gi], sn = rope_sin[jc * 16 + gi];
+                    const float x1 = kr[2 * i], x2 = kr[2 * i + 1];
+                    kr[2 * i] = x1 * c - x2 * sn;
+                    kr[2 * i + 1] = x2 * c + x1 * sn;
                 }
             }
         }
+        float dot = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < nk) {
-                const float* kp = ks + j * D + d0;
-                float kr[DS];
-#pragma unroll
-                for (int d = 0; d < DS; d += 4) {
-                    const f32x4 x = *(const f32x4*)(kp + d);
-                    kr[d] = x.x; kr[d + 1] = x.y; kr[d + 2] = x.z; kr[d + 3] = x.w;
-                }
-                if (a.rope) {
-#pragma unroll
-                    for (int i = 0; i < DS / 2; ++i) {
-                        const int gi = (ps * DS) / 2 + i;
-                        if (gi < ROT / 2) {
-                            const float c = rope_cos[j * 16 + gi], sn = rope_sin[j * 16 + gi];
-                            const float x1 = kr[2 * i], x2 = kr[2 * i + 1];
-                            kr[2 * i] = x1 * c - x2 * sn;
-                            kr[2 * i + 1] = x2 * c + x1 * sn;
-                        }
-                    }
-                }
-                float dot = 0.f;
-#pragma unroll
-                for (int d = 0; d < DS; ++d) dot = fmaf(q[d], kr[d], dot);
-                part[(pr * 16 + j) * LP + ps] = dot;
-            }
-        }
+        for (int d = 0; d < DS; ++d) dot = fmaf(q[d], kr[d], dot);
+        if (live) part[(pr * 16 + j) * LP + ps] = dot;
     }
     MDT_TS(3)
     __syncthreads();
-    if (!live) return;
-    float sc[16];
+    float sc[TKC];
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        sc[j] = -INFINITY;
-        if (j < nk) {
-            float dot = 0.f;
+    for (int j = 0; j < TKC; ++j) {
+        float dot = 0.f;
 #pragma unroll
-            for (int u = 0; u < LP; ++u) dot += part[(pr * 16 + j) * LP + u];  // fixed order: deterministic
-            sc[j] = dot * scale;
-            mx = fmaxf(mx, sc[j]);
-        }
+        for (int u = 0; u < LP; ++u) dot += part[(pr * 16 + j) * LP + u];  // fixed order: deterministic
+        sc[j] = j < nk ? dot * scale : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
     }
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        sc[j] = j < nk ? expf(sc[j] - mx) : 0.f;
+    for (int j = 0; j < TKC; ++j) {
+        sc[j] = expf(sc[j] - mx);  // exp(-inf) = 0 for masked keys; key 0 is always visible so mx is finite
         sum += sc[j];
     }
     const float inv = 1.0f / sum;
@@ -814,38 +809,53 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
 #pragma unroll
     for (int d = 0; d < DS; ++d) o[d] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (j < nk) {
-            const float p = sc[j] * inv;
-            const float* vp = vs + j * D + d0;
+    for (int j = 0; j < TKC; ++j) {
+        const float p = sc[j] * inv;
+        const float* vp = vs + min(j, a.Tk - 1) * D + d0;
 #pragma unroll
-            for (int d = 0; d < DS; d += 4) {
-                const f32x4 x = *(const f32x4*)(vp + d);
-                o[d] = fmaf(p, x.x, o[d]); o[d + 1] = fmaf(p, x.y, o[d + 1]);
-                o[d + 2] = fmaf(p, x.z, o[d + 2]); o[d + 3] = fmaf(p, x.w, o[d + 3]);
-            }
+        for (int d = 0; d < DS; d += 4) {
+            const f32x4 x = *(const f32x4*)(vp + d);
+            o[d] = fmaf(p, x.x, o[d]); o[d + 1] = fmaf(p, x.y, o[d + 1]);
+            o[d + 2] = fmaf(p, x.z, o[d + 2]); o[d + 3] = fmaf(p, x.w, o[d + 3]);
         }
     }
-    float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + coff + d0;
+    if (live) {
+        float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + coff + d0;
 #pragma unroll
-    for (int d = 0; d < DS; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
+        for (int d = 0; d < DS; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
+    }
     MDT_TS(4)
 }
 
-template <int HD>
-static hipError_t launch_attn_t(const mdt_attn_args& a, const float* rc, const float* rs, hipStream_t s) {
+template <int HD, int TKC, bool ROPE>
+static hipError_t launch_attn_tt(const mdt_attn_args& a, const float* rc, const float* rs, hipStream_t s) {
     constexpr int LP = HD == 48 ? 3 : (HD >= 32 ? 2 : 1);
     const int hs = (a.H % 2 == 0 && a.B >= 64) ? 2 : 1;  // head split: 2 half-size workgroups per sample
     const int Hl = a.H / hs;
     const size_t lds = ((size_t)(a.Tq + 2 * a.Tk) * Hl * HD + (size_t)Hl * a.Tq * 16 * LP) * sizeof(float);
     static size_t lds_attr = 0;
     if (lds > lds_attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_attn<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn<HD, TKC, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_attn<HD>), dim3(a.B, hs), dim3(256), lds, s, a, rc, rs, 1.0f / sqrtf((float)HD));
+    hipLaunchKernelGGL((k_attn<HD, TKC, ROPE>), dim3(a.B, hs), dim3(256), lds, s, a, rc, rs, 1.0f / sqrtf((float)HD));
     return hipGetLastError();
+}
+
+template <int HD>
+static hipError_t launch_attn_t(const mdt_attn_args& a, const float* rc, const float* rs, hipStream_t s) {
+    if constexpr (HD >= 32) {
+        if (a.rope) {
+            if (a.Tk <= 4) return launch_attn_tt<HD, 4, true>(a, rc, rs, s);
+            if (a.Tk <= 10) return launch_attn_tt<HD, 10, true>(a, rc, rs, s);
+            return launch_attn_tt<HD, 16, true>(a, rc, rs, s);
+        }
+    }
+    if (a.Tk <= 4) return launch_attn_tt<HD, 4, false>(a, rc, rs, s);
+    if (a.Tk <= 10) return launch_attn_tt<HD, 10, false>(a, rc, rs, s);
+    return launch_attn_tt<HD, 16, false>(a, rc, rs, s);
 }
 
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin,
