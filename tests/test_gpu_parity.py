@@ -285,3 +285,19 @@ def test_g7b_remaining_samplers(name, kw, key):
     with torch.no_grad():
         out = getattr(gs, "sample_" + name)(model, state, noise * 80.0, goal, gs.get_sigmas_exponential(10, 0.001, 80.0), **kw)
     assert_close(out.cpu(), fx[key], what=key)
+
+
+def test_c4_total_batch_2048_matches_the_b256_golden_slice():
+    """BASELINE config C4's total request (B = 2048) on one GPU: the first 256 chunks are the G3 inputs, the rest
+    fresh seeds; their actions must equal the B=256 reference golden (batch independence at the maximum size)."""
+    meta, fx = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    extra = dict(meta, B=2048 - 256, input_seed=777)
+    s2, g2, n2 = gpu_inputs(extra)
+    big_state = {"state_images": torch.cat([state["state_images"], s2["state_images"]]), "modality": "lang"}
+    with torch.no_grad():
+        out = sampling().sample_ddim(model, big_state, torch.cat([noise, n2]) * 80.0, torch.cat([goal, g2]),
+                                     torch.from_numpy(fx["sigmas"]))
+    assert out.shape == (2048, 10, 7) and torch.isfinite(out).all()
+    assert_close(out[:256].cpu(), fx["actions"], what="first 256 of 2048")
