@@ -161,6 +161,142 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 // column tiles and ALL row tiles of the workgroup tile, so a weight fragment is fetched once per workgroup and
 // reused from registers across the row tiles.  Wide tiles (8 waves x NTW 3..4) keep the number of workgroups that
 // re-read / re-normalise the same activation rows at N / (128*NTW) instead of N / 64.
+// Activation tile -> LDS (shared by the GEMM kernels): plain copy of the (MT x klen) chunk at column k0, or LayerNorm
+// (+ adaLN modulate) of whole rows (k0 = 0, klen = K <= 512).  All global loads of the phase are in flight together.
+template <int MTILES, int NWAVES, int PRO>
+__device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* lds, int stride, int m0, int k0, int klen,
+                                                const float* __restrict__ zeros, int tid, int lane, int wave) {
+    constexpr int MT = MTILES * 16;
+    constexpr int NT = 64 * NWAVES;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int n4 = klen >> 2;
+    if constexpr (PRO != PRO_PLAIN) {
+        // ---- LayerNorm (+ adaLN modulate) prologue: each wave owns a slab of RPW consecutive rows, whole
+        //      rows live in registers (K <= 512 -> two float4 per lane); single chunk by construction ----
+        constexpr int RPW = MT / NWAVES;
+        const int r0 = wave * RPW;
+        int cc[2];
+        bool cv[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            cv[p] = lane + 64 * p < n4;
+            cc[p] = 4 * min(lane + 64 * p, n4 - 1);
+        }
+        f32x4 v[RPW][2], w[2], bb[2];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t m = min(m0 + r0 + r, a.M - 1);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) v[r][p] = ldg4(a.A + m * a.lda + cc[p]);
+        }
+        const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            w[p] = ldg4(a.ln_w + cc[p]);
+            bb[p] = ldg4(lnb + cc[p]);
+        }
+        // modulation vectors, fetched up front.  BCAST: one row for the whole batch.  ROWS: a slab of RPW
+        // consecutive rows touches at most 2 samples when rows_per_sample >= RPW -> two candidates.
+        constexpr int NC = PRO == PRO_LN_MOD_ROWS ? 2 : 1;
+        f32x4 sh[NC][2], sc[NC][2];
+        int s_lo = 0;
+        bool slow_mod = false;
+        if constexpr (PRO == PRO_LN_MOD_BCAST) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                sh[0][p] = ldg4(a.mod + a.shift_off + cc[p]);
+                sc[0][p] = ldg4(a.mod + a.scale_off + cc[p]);
+            }
+        }
+        if constexpr (PRO == PRO_LN_MOD_ROWS) {
+            s_lo = min(m0 + r0, a.M - 1) / a.rows_per_sample;
+            const int s_hi = min(m0 + r0 + RPW - 1, a.M - 1) / a.rows_per_sample;
+            slow_mod = s_hi > s_lo + 1;
+            const float* mlo = a.mod + (int64_t)s_lo * a.mod_stride;
+            const float* mhi = a.mod + (int64_t)min(s_lo + 1, s_hi) * a.mod_stride;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                sh[0][p] = ldg4(mlo + a.shift_off + cc[p]);
+                sc[0][p] = ldg4(mlo + a.scale_off + cc[p]);
+                sh[NC - 1][p] = ldg4(mhi + a.shift_off + cc[p]);
+                sc[NC - 1][p] = ldg4(mhi + a.scale_off + cc[p]);
+            }
+        }
+        const float inv_k = 1.0f / (float)klen;
+        float red[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            red[r] = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                v[r][p] = sel4(cv[p], v[r][p], zero4);
+                red[r] += hsum4(v[r][p]);
+            }
+        }
+        wave_sum_n<RPW>(red);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float mean = red[r] * inv_k;
+            red[r] = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                v[r][p] = sel4(cv[p], v[r][p] - mean, zero4);
+                red[r] += hsq4(v[r][p]);
+            }
+        }
+        wave_sum_n<RPW>(red);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int m = m0 + r0 + r;
+            const float rstd = 1.0f / sqrtf(red[r] * inv_k + 1e-5f);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f32x4 y = v[r][p] * rstd * w[p] + bb[p];
+                if constexpr (PRO == PRO_LN_MOD_BCAST) y = sh[0][p] + y * sc[0][p];
+                if constexpr (PRO == PRO_LN_MOD_ROWS) {
+                    const int smp = min(m, a.M - 1) / a.rows_per_sample;
+                    f32x4 shv = sel4(smp == s_lo, sh[0][p], sh[NC - 1][p]);
+                    f32x4 scv = sel4(smp == s_lo, sc[0][p], sc[NC - 1][p]);
+                    if (slow_mod) {  // rows_per_sample < RPW: rare generic path, one round trip per row
+                        const float* mr = a.mod + (int64_t)smp * a.mod_stride;
+                        shv = ldg4(mr + a.shift_off + cc[p]);
+                        scv = ldg4(mr + a.scale_off + cc[p]);
+                    }
+                    y = shv + y * scv;
+                }
+                y = sel4(m < a.M, y, zero4);
+                if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
+            }
+        }
+    } else {
+        // ---- plain staging of the (MT x klen) activation chunk: 32 lanes sweep a row in 512-byte pieces,
+        //      NT/32 rows at a time; all loads of the chunk are in flight together (no divisions) ----
+        constexpr int RG = NT / 32;      // rows covered per sweep
+        constexpr int U = MT / RG;       // sweeps
+        const int rg = tid >> 5, l32 = tid & 31;
+        const int nv = (n4 + 31) >> 5;   // 512-byte pieces per row (<= 6 for kchunk <= 768)
+        for (int v0 = 0; v0 < nv; v0 += 3) {
+            f32x4 st[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = min(m0 + rg + RG * u, a.M - 1);
+#pragma unroll
+                for (int v = 0; v < 3; ++v)
+                    st[u][v] = ldg4(a.A + m * a.lda + k0 + 4 * min(l32 + 32 * (v0 + v), n4 - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = rg + RG * u;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int c4 = l32 + 32 * (v0 + v);
+                    if (c4 < n4) *(f32x4*)(lds + row * stride + 4 * c4) = sel4(m0 + row < a.M, st[u][v], zero4);
+                }
+            }
+        }
+    }
+}
+
 template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>
 __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchunk, int grid_n,
                                                       const float* __restrict__ zeros) {
@@ -168,7 +304,6 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     MDT_TS(0)
     MDT_TS_HWID()
     constexpr int MT = MTILES * 16;
-    constexpr int NT = 64 * NWAVES;
     // weight-fragment ring: R-1 k-steps of 1-KiB loads in flight per column tile.  A k-step is only 8 MFMAs
     // (256 pipe cycles) with one column tile per wave, so the narrow variants need the deeper ring to cover L2 latency.
     constexpr int R = NTW == 1 ? 6 : (NTW == 2 ? 4 : 3);
@@ -240,133 +375,8 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     int kg = 0;  // global k16 index of the weight stream
     for (int k0 = 0; k0 < a.K; k0 += kchunk) {
         const int klen = min(kchunk, a.K - k0);
-        const int n4 = klen >> 2;
         if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
-        if constexpr (PRO != PRO_PLAIN) {
-            // ---- LayerNorm (+ adaLN modulate) prologue: each wave owns a slab of RPW consecutive rows, whole
-            //      rows live in registers (K <= 512 -> two float4 per lane); single chunk by construction ----
-            constexpr int RPW = MT / NWAVES;
-            const int r0 = wave * RPW;
-            int cc[2];
-            bool cv[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                cv[p] = lane + 64 * p < n4;
-                cc[p] = 4 * min(lane + 64 * p, n4 - 1);
-            }
-            f32x4 v[RPW][2], w[2], bb[2];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int64_t m = min(m0 + r0 + r, a.M - 1);
-#pragma unroll
-                for (int p = 0; p < 2; ++p) v[r][p] = ldg4(a.A + m * a.lda + cc[p]);
-            }
-            const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                w[p] = ldg4(a.ln_w + cc[p]);
-                bb[p] = ldg4(lnb + cc[p]);
-            }
-            // modulation vectors, fetched up front.  BCAST: one row for the whole batch.  ROWS: a slab of RPW
-            // consecutive rows touches at most 2 samples when rows_per_sample >= RPW -> two candidates.
-            constexpr int NC = PRO == PRO_LN_MOD_ROWS ? 2 : 1;
-            f32x4 sh[NC][2], sc[NC][2];
-            int s_lo = 0;
-            bool slow_mod = false;
-            if constexpr (PRO == PRO_LN_MOD_BCAST) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    sh[0][p] = ldg4(a.mod + a.shift_off + cc[p]);
-                    sc[0][p] = ldg4(a.mod + a.scale_off + cc[p]);
-                }
-            }
-            if constexpr (PRO == PRO_LN_MOD_ROWS) {
-                s_lo = min(m0 + r0, a.M - 1) / a.rows_per_sample;
-                const int s_hi = min(m0 + r0 + RPW - 1, a.M - 1) / a.rows_per_sample;
-                slow_mod = s_hi > s_lo + 1;
-                const float* mlo = a.mod + (int64_t)s_lo * a.mod_stride;
-                const float* mhi = a.mod + (int64_t)min(s_lo + 1, s_hi) * a.mod_stride;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    sh[0][p] = ldg4(mlo + a.shift_off + cc[p]);
-                    sc[0][p] = ldg4(mlo + a.scale_off + cc[p]);
-                    sh[NC - 1][p] = ldg4(mhi + a.shift_off + cc[p]);
-                    sc[NC - 1][p] = ldg4(mhi + a.scale_off + cc[p]);
-                }
-            }
-            const float inv_k = 1.0f / (float)klen;
-            float red[RPW];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                red[r] = 0.f;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    v[r][p] = sel4(cv[p], v[r][p], zero4);
-                    red[r] += hsum4(v[r][p]);
-                }
-            }
-            wave_sum_n<RPW>(red);
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const float mean = red[r] * inv_k;
-                red[r] = 0.f;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    v[r][p] = sel4(cv[p], v[r][p] - mean, zero4);
-                    red[r] += hsq4(v[r][p]);
-                }
-            }
-            wave_sum_n<RPW>(red);
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int m = m0 + r0 + r;
-                const float rstd = 1.0f / sqrtf(red[r] * inv_k + 1e-5f);
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    f32x4 y = v[r][p] * rstd * w[p] + bb[p];
-                    if constexpr (PRO == PRO_LN_MOD_BCAST) y = sh[0][p] + y * sc[0][p];
-                    if constexpr (PRO == PRO_LN_MOD_ROWS) {
-                        const int smp = min(m, a.M - 1) / a.rows_per_sample;
-                        f32x4 shv = sel4(smp == s_lo, sh[0][p], sh[NC - 1][p]);
-                        f32x4 scv = sel4(smp == s_lo, sc[0][p], sc[NC - 1][p]);
-                        if (slow_mod) {  // rows_per_sample < RPW: rare generic path, one round trip per row
-                            const float* mr = a.mod + (int64_t)smp * a.mod_stride;
-                            shv = ldg4(mr + a.shift_off + cc[p]);
-                            scv = ldg4(mr + a.scale_off + cc[p]);
-                        }
-                        y = shv + y * scv;
-                    }
-                    y = sel4(m < a.M, y, zero4);
-                    if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
-                }
-            }
-        } else {
-            // ---- plain staging of the (MT x klen) activation chunk: 32 lanes sweep a row in 512-byte pieces,
-            //      NT/32 rows at a time; all loads of the chunk are in flight together (no divisions) ----
-            constexpr int RG = NT / 32;      // rows covered per sweep
-            constexpr int U = MT / RG;       // sweeps
-            const int rg = tid >> 5, l32 = tid & 31;
-            const int nv = (n4 + 31) >> 5;   // 512-byte pieces per row (<= 6 for kchunk <= 768)
-            for (int v0 = 0; v0 < nv; v0 += 3) {
-                f32x4 st[U][3];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int64_t m = min(m0 + rg + RG * u, a.M - 1);
-#pragma unroll
-                    for (int v = 0; v < 3; ++v)
-                        st[u][v] = ldg4(a.A + m * a.lda + k0 + 4 * min(l32 + 32 * (v0 + v), n4 - 1));
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int row = rg + RG * u;
-#pragma unroll
-                    for (int v = 0; v < 3; ++v) {
-                        const int c4 = l32 + 32 * (v0 + v);
-                        if (c4 < n4) *(f32x4*)(lds + row * stride + 4 * c4) = sel4(m0 + row < a.M, st[u][v], zero4);
-                    }
-                }
-            }
-        }
+        gemm_stage_tile<MTILES, NWAVES, PRO>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave);
         MDT_TS(1)
         __syncthreads();
         MDT_TS(2)
@@ -415,6 +425,121 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
         }
     }
     MDT_TS(4)
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_seq: single-chunk GEMM (K <= 512 or LayerNorm prologue) whose waves walk their NTW column tiles ONE AFTER
+// THE OTHER instead of accumulating them together.  The packed weight image stores a column tile's K16 fragments
+// contiguously and consecutive tiles back to back, so the wave's weight ring is one continuous stream over
+// NTW * K16 fragments; every K16 steps the two accumulators are finished, go through the epilogue (bias, GELU,
+// gated residual) and are stored while the SIMD's other wave keeps the MFMA pipe busy.  This hides the epilogue
+// (the erf-GELU of c_fc was ~15 % of that kernel) and spreads the output stores over the kernel instead of leaving
+// the whole tile dirty in L2 for the end-of-kernel write-back.  The activation fragments are re-read from LDS per
+// column tile (LDS is < 15 % utilised).
+// ------------------------------------------------------------------------------------------------
+#define MDT_KSTEP1(U, KC)                                                                                 \
+    {                                                                                                     \
+        ring[((U) + R - 1) % R] = ldg4(wp0 + (int64_t)min(g + (KC) + R - 1, gmax) * 256);                 \
+        f32x4 avn[MTILES];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
+            *(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16);                           \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) acc[i] =                                   \
+                __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][e], av[i][e], acc[i], 0, 0, 0);            \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
+    }
+
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>
+__global__ __launch_bounds__(64 * NWAVES) void k_gemm_seq(mdt_gemm_args a, int grid_n, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int MT = MTILES * 16;
+    constexpr int R = 6;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / grid_n, bx = logical - by * grid_n;
+    const int m0 = by * MT;
+    const int N16 = a.N >> 4, K16 = a.K >> 4;
+    const int nt0 = (bx * NWAVES + wave) * NTW;
+    const int ntiles = min(NTW, N16 - nt0);  // real column tiles of this wave (<= 0: idle wave)
+    const int stride = a.K + 4;
+
+    // continuous weight stream of this wave: fragments [0, ntiles * K16)
+    const float* wp0 = a.Wp + (int64_t)min(nt0, N16 - 1) * K16 * 256 + lane * 4;
+    const int gmax = max(ntiles, 1) * K16 - 1;
+    f32x4 ring[R];
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u) ring[u] = ldg4(wp0 + (int64_t)min(u, gmax) * 256);
+
+    gemm_stage_tile<MTILES, NWAVES, PRO>(a, lds, stride, m0, 0, a.K, zeros, tid, lane, wave);
+    __syncthreads();
+    if (ntiles <= 0) return;
+
+    const int nq = 4 * (lane >> 4);
+    const bool gated = RES && a.gate_off >= 0;
+    const float* biasp = a.bias != nullptr ? a.bias : zeros;
+    const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+    float* optr[MTILES];
+    const float* gptr[MTILES];
+    bool mok[MTILES];
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i) {
+        const int mr = m0 + i * 16 + (lane & 15);
+        const int m = min(mr, a.M - 1);
+        mok[i] = mr < a.M;
+        const int64_t orow =
+            a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
+        optr[i] = a.out + orow * a.ldo;
+        gptr[i] = gated ? a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride)
+                        : zeros;
+    }
+    const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
+    const int nk = K16;
+    int g = 0;  // index of the next fragment in the wave's stream
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int ncol = (nt0 + jt) * 16 + nq;
+        // epilogue operands of this tile ride in the same in-order load queue as the weight ring
+        const f32x4 bias_v = ldg4(biasp + ncol) + ldg4(rvp + ncol);
+        f32x4 gate_v[MTILES], res_v[MTILES];
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < MTILES; ++i) {
+                gate_v[i] = ldg4(gptr[i] + ncol);
+                res_v[i] = ldg4(optr[i] + ncol);
+            }
+        }
+        f32x4 acc[MTILES], av[MTILES];
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            acc[i] = zero4;
+            av[i] = *(const f32x4*)(ap + i * 16 * stride);
+        }
+        int kc = 0;
+        for (; kc + R <= nk; kc += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) MDT_KSTEP1(u, kc + u)
+        }
+        if (kc < nk) {  // tail: nk % R steps, then rotate the ring so that slot 0 is the next fragment again
+            const int rem = nk - kc;
+#pragma unroll
+            for (int u = 0; u < R - 1; ++u)
+                if (u < rem) MDT_KSTEP1(u, kc + u)
+            for (int r = 0; r < rem; ++r) {
+                const f32x4 first = ring[0];
+#pragma unroll
+                for (int u = 0; u + 1 < R; ++u) ring[u] = ring[u + 1];
+                ring[R - 1] = first;
+            }
+        }
+        g += nk;
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            f32x4 v = apply_act(acc[i] + bias_v, a.act);
+            if constexpr (RES) v = res_v[i] + (gated ? gate_v[i] * v : v);
+            if (mok[i]) *(f32x4*)(optr[i] + ncol) = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,8 +732,30 @@ static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStre
     return hipGetLastError();
 }
 
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>
+static hipError_t launch_gemm_seq_r(const mdt_gemm_args& a, hipStream_t s) {
+    const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
+    const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
+    const size_t lds = (size_t)MT * (a.K + 4) * sizeof(float);
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_seq<MTILES, NTW, NWAVES, PRO, RES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_gemm_seq<MTILES, NTW, NWAVES, PRO, RES>), dim3(gn * gm), dim3(64 * NWAVES), lds, s, a, gn,
+                       g_zeros);
+    return hipGetLastError();
+}
+
+static const bool g_mdt_gemm_noseq = getenv("MDT_HIP_NOSEQ") != nullptr;  // A/B switch for k_gemm_seq
+
 template <int MTILES, int NTW, int NWAVES, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
+    if (NTW > 1 && kchunk == a.K && !g_mdt_gemm_noseq)  // single chunk: column tiles one after the other
+        return a.residual ? launch_gemm_seq_r<MTILES, NTW, NWAVES, PRO, true>(a, s)
+                          : launch_gemm_seq_r<MTILES, NTW, NWAVES, PRO, false>(a, s);
     return a.residual ? launch_gemm_r<MTILES, NTW, NWAVES, PRO, true>(a, kchunk, s)
                       : launch_gemm_r<MTILES, NTW, NWAVES, PRO, false>(a, kchunk, s);
 }
