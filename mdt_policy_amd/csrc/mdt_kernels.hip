@@ -99,6 +99,15 @@ __global__ void k_pack_weight(const float* __restrict__ w, int n_rows, int K, fl
 enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_LN_MOD_BCAST = 2, PRO_LN_MOD_ROWS = 3 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
+// output store of the GEMM epilogues.  -DMDT_ST_WT (tuning build) makes it a write-through (sc0 sc1) store so that the
+// tile does not stay dirty in L2 until the end-of-kernel write-back.
+__device__ __forceinline__ void st4(float* p, f32x4 v) {
+#ifdef MDT_ST_WT
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    *(f32x4*)p = v;
+#endif
+}
 __device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a : b; }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float hsq4(f32x4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
@@ -421,125 +430,10 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
         for (int j = 0; j < NTW; ++j) {
             f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
             if constexpr (RES) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
-            if (mok && nt0 + j < N16) *(f32x4*)(optr[i] + ncol[j]) = v;
+            if (mok && nt0 + j < N16) st4(optr[i] + ncol[j], v);
         }
     }
     MDT_TS(4)
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_gemm_seq: single-chunk GEMM (K <= 512 or LayerNorm prologue) whose waves walk their NTW column tiles ONE AFTER
-// THE OTHER instead of accumulating them together.  The packed weight image stores a column tile's K16 fragments
-// contiguously and consecutive tiles back to back, so the wave's weight ring is one continuous stream over
-// NTW * K16 fragments; every K16 steps the two accumulators are finished, go through the epilogue (bias, GELU,
-// gated residual) and are stored while the SIMD's other wave keeps the MFMA pipe busy.  This hides the epilogue
-// (the erf-GELU of c_fc was ~15 % of that kernel) and spreads the output stores over the kernel instead of leaving
-// the whole tile dirty in L2 for the end-of-kernel write-back.  The activation fragments are re-read from LDS per
-// column tile (LDS is < 15 % utilised).
-// ------------------------------------------------------------------------------------------------
-#define MDT_KSTEP1(U, KC)                                                                                 \
-    {                                                                                                     \
-        ring[((U) + R - 1) % R] = ldg4(wp0 + (int64_t)min(g + (KC) + R - 1, gmax) * 256);                 \
-        f32x4 avn[MTILES];                                                                                \
-        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
-            *(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16);                           \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) acc[i] =                                   \
-                __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][e], av[i][e], acc[i], 0, 0, 0);            \
-        }                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
-    }
-
-template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>
-__global__ __launch_bounds__(64 * NWAVES) void k_gemm_seq(mdt_gemm_args a, int grid_n, const float* __restrict__ zeros) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int MT = MTILES * 16;
-    constexpr int R = 6;
-    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int by = logical / grid_n, bx = logical - by * grid_n;
-    const int m0 = by * MT;
-    const int N16 = a.N >> 4, K16 = a.K >> 4;
-    const int nt0 = (bx * NWAVES + wave) * NTW;
-    const int ntiles = min(NTW, N16 - nt0);  // real column tiles of this wave (<= 0: idle wave)
-    const int stride = a.K + 4;
-
-    // continuous weight stream of this wave: fragments [0, ntiles * K16)
-    const float* wp0 = a.Wp + (int64_t)min(nt0, N16 - 1) * K16 * 256 + lane * 4;
-    const int gmax = max(ntiles, 1) * K16 - 1;
-    f32x4 ring[R];
-#pragma unroll
-    for (int u = 0; u < R - 1; ++u) ring[u] = ldg4(wp0 + (int64_t)min(u, gmax) * 256);
-
-    gemm_stage_tile<MTILES, NWAVES, PRO>(a, lds, stride, m0, 0, a.K, zeros, tid, lane, wave);
-    __syncthreads();
-    if (ntiles <= 0) return;
-
-    const int nq = 4 * (lane >> 4);
-    const bool gated = RES && a.gate_off >= 0;
-    const float* biasp = a.bias != nullptr ? a.bias : zeros;
-    const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
-    float* optr[MTILES];
-    const float* gptr[MTILES];
-    bool mok[MTILES];
-#pragma unroll
-    for (int i = 0; i < MTILES; ++i) {
-        const int mr = m0 + i * 16 + (lane & 15);
-        const int m = min(mr, a.M - 1);
-        mok[i] = mr < a.M;
-        const int64_t orow =
-            a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
-        optr[i] = a.out + orow * a.ldo;
-        gptr[i] = gated ? a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride)
-                        : zeros;
-    }
-    const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
-    const int nk = K16;
-    int g = 0;  // index of the next fragment in the wave's stream
-    for (int jt = 0; jt < ntiles; ++jt) {
-        const int ncol = (nt0 + jt) * 16 + nq;
-        // epilogue operands of this tile ride in the same in-order load queue as the weight ring
-        const f32x4 bias_v = ldg4(biasp + ncol) + ldg4(rvp + ncol);
-        f32x4 gate_v[MTILES], res_v[MTILES];
-        if constexpr (RES) {
-#pragma unroll
-            for (int i = 0; i < MTILES; ++i) {
-                gate_v[i] = ldg4(gptr[i] + ncol);
-                res_v[i] = ldg4(optr[i] + ncol);
-            }
-        }
-        f32x4 acc[MTILES], av[MTILES];
-#pragma unroll
-        for (int i = 0; i < MTILES; ++i) {
-            acc[i] = zero4;
-            av[i] = *(const f32x4*)(ap + i * 16 * stride);
-        }
-        int kc = 0;
-        for (; kc + R <= nk; kc += R) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) MDT_KSTEP1(u, kc + u)
-        }
-        if (kc < nk) {  // tail: nk % R steps, then rotate the ring so that slot 0 is the next fragment again
-            const int rem = nk - kc;
-#pragma unroll
-            for (int u = 0; u < R - 1; ++u)
-                if (u < rem) MDT_KSTEP1(u, kc + u)
-            for (int r = 0; r < rem; ++r) {
-                const f32x4 first = ring[0];
-#pragma unroll
-                for (int u = 0; u + 1 < R; ++u) ring[u] = ring[u + 1];
-                ring[R - 1] = first;
-            }
-        }
-        g += nk;
-#pragma unroll
-        for (int i = 0; i < MTILES; ++i) {
-            f32x4 v = apply_act(acc[i] + bias_v, a.act);
-            if constexpr (RES) v = res_v[i] + (gated ? gate_v[i] * v : v);
-            if (mok[i]) *(f32x4*)(optr[i] + ncol) = v;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -683,7 +577,7 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
         for (int j = 0; j < NTW; ++j) {
             f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
             if constexpr (RES) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
-            if (mok && nt0 + j < N16) *(f32x4*)(optr[i] + ncol[j]) = v;
+            if (mok && nt0 + j < N16) st4(optr[i] + ncol[j], v);
         }
     }
 }
@@ -732,30 +626,8 @@ static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStre
     return hipGetLastError();
 }
 
-template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>
-static hipError_t launch_gemm_seq_r(const mdt_gemm_args& a, hipStream_t s) {
-    const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
-    const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
-    const size_t lds = (size_t)MT * (a.K + 4) * sizeof(float);
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_seq<MTILES, NTW, NWAVES, PRO, RES>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_attr = lds;
-    }
-    hipLaunchKernelGGL((k_gemm_seq<MTILES, NTW, NWAVES, PRO, RES>), dim3(gn * gm), dim3(64 * NWAVES), lds, s, a, gn,
-                       g_zeros);
-    return hipGetLastError();
-}
-
-static const bool g_mdt_gemm_noseq = getenv("MDT_HIP_NOSEQ") != nullptr;  // A/B switch for k_gemm_seq
-
 template <int MTILES, int NTW, int NWAVES, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
-    if (NTW > 1 && kchunk == a.K && !g_mdt_gemm_noseq)  // single chunk: column tiles one after the other
-        return a.residual ? launch_gemm_seq_r<MTILES, NTW, NWAVES, PRO, true>(a, s)
-                          : launch_gemm_seq_r<MTILES, NTW, NWAVES, PRO, false>(a, s);
     return a.residual ? launch_gemm_r<MTILES, NTW, NWAVES, PRO, true>(a, kchunk, s)
                       : launch_gemm_r<MTILES, NTW, NWAVES, PRO, false>(a, kchunk, s);
 }
