@@ -65,8 +65,11 @@ typedef struct {
     int32_t use_modality_encoder; /* separate lang_emb                                              */
     int32_t use_abs_pos_emb;      /* MDT only: pos_emb added to the encoder tokens                  */
     int32_t use_rot_embed;        /* RoPE on q/k (rot dim 32, theta 1e4), position_embeddings.py:83 */
-    int32_t use_ada_conditioning; /* must be 1 (adaLN decoder); 0 -> MDT_ERR_UNSUPPORTED            */
-    int32_t use_noise_encoder;    /* must be 0 (NoiseBlock variant) ; 1 -> MDT_ERR_UNSUPPORTED      */
+    int32_t use_ada_conditioning; /* 1: sigma conditions the decoder blocks (adaLN-Zero, shipped configs);
+                                     0: sigma embedding is the first ENCODER token, plain Block decoder
+                                        (mdtv_transformer.py:296-297, transformer_blocks.py:460-506)  */
+    int32_t use_noise_encoder;    /* with use_ada_conditioning: NoiseBlock (ln(x)+c) instead of
+                                     ConditionedBlock (transformer_blocks.py:312-341, :533-544)      */
     int32_t linear_output;        /* must be 1                                                      */
     int32_t bias;                 /* reference 'bias' flag: biases on c_proj / MLP / LayerNorms     */
     float   sigma_data;           /* GCDenoiser.sigma_data                                          */
@@ -101,10 +104,12 @@ mdt_status mdt_load_param(mdt_model *m, const char *name, const float *src, int6
 /* Pre-size the workspace for batches up to max_batch (avoids hipMalloc later, e.g. before graph capture). */
 mdt_status mdt_reserve(mdt_model *m, int64_t max_batch);
 
-/* inner_model.forward_enc_only(state, action, goal, sigma) with use_ada_conditioning
+/* inner_model.forward_enc_only(state, action, goal, sigma)
  * (reference mdtv_transformer.py:213-222; mdt_transformer.py:211-229 / :257-281): goal/state token
  * embedding, n_enc_layers Blocks, final LayerNorm.  Also projects the per-decoder-block cross-attention
  * K/V once and keeps ctx + K/V cached in the handle for mdt_denoise_cached()/samplers.
+ *   sigma  : (B,) device.  Read only when use_ada_conditioning == 0 (the sigma embedding is then the first
+ *            context token, so the cached context is only valid for that sigma); may be NULL otherwise.
  *   tokens : MDT-V state['state_images'] (B, n_obs_token, obs_dim); MDT state['static'] (B,1,obs_dim)
  *   tokens2: MDT state['gripper'] (B,1,obs_dim); NULL for MDT-V
  *   goal   : (B, 1, goal_dim)
@@ -112,7 +117,8 @@ mdt_status mdt_reserve(mdt_model *m, int64_t max_batch);
  *                    0 = always goal_emb (MDT.forward -> enc_only_forward, mdt_transformer.py:215)
  *   ctx_out: (B, Te, d) or NULL -- the value the reference caches as inner_model.latent_encoder_emb */
 mdt_status mdt_encode(mdt_model *m, const float *tokens, const float *tokens2, const float *goal,
-                      int32_t modality, int32_t honour_modality, int64_t batch, float *ctx_out, void *stream);
+                      int32_t modality, int32_t honour_modality, const float *sigma, int64_t batch,
+                      float *ctx_out, void *stream);
 
 /* GCDenoiser.forward(state, action, goal, sigma) given the cached context of the last mdt_encode()
  * (reference score_wrappers.py:65-80 -> mdtv_transformer.py:224-236): EDM preconditioning, sigma
@@ -134,6 +140,8 @@ mdt_status mdt_forward(mdt_model *m, const float *tokens, const float *tokens2, 
 /* sample_ddim(model, state, action, goal, sigmas) (reference gc_sampling.py:922-951) as ONE enqueue:
  * encoder + cross K/V once, sigma-embedding/adaLN vectors for all steps once, then n_steps decoder
  * evaluations with the update x <- (s_{i+1}/s_i) x - expm1(-h_i) den fused into the action-head kernel.
+ * (use_ada_conditioning == 0: the encoder depends on sigma and runs inside the step loop, as in the reference;
+ * ctx_out then receives the LAST step's context, which is what the reference leaves in latent_encoder_emb.)
  *   x_T    : (B, Ta, A) initial noisy actions (already multiplied by sigma_max, mdtv_agent.py:546)
  *   sigmas : HOST array of n_steps+1 floats (get_sigmas_* output, last entry normally 0)
  *   out    : (B, Ta, A) sampled actions;  ctx_out: optional (B,Te,d) latent_encoder_emb */

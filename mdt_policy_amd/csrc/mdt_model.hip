@@ -93,9 +93,18 @@ struct Bump {
     }
 };
 
+// how sigma conditions the decoder (reference constructor flags use_ada_conditioning / use_noise_encoder)
+enum CondMode {
+    COND_ADALN = 0,  // ConditionedBlock + AdaLNZero           (transformer_blocks.py:264-309) -- the shipped configs
+    COND_NOISE = 1,  // NoiseBlock: ln(x) + c before both attentions (transformer_blocks.py:312-341)
+    COND_TOKEN = 2,  // plain Block decoder; sigma embedding is the FIRST encoder token (mdtv_transformer.py:296-297)
+};
+
 struct mdt_model {
     mdt_config cfg;
     int D, H, hd, Te, Ta, A, Le, Ld, G, O, n_tok;
+    int cond = COND_ADALN;
+    int sig_tok = 0;  // 1 when the context starts with the sigma token (COND_TOKEN): Te = sig_tok + 1 + n_tok
     // parameters
     float* arena = nullptr;
     size_t arena_floats = 0;
@@ -113,6 +122,7 @@ struct mdt_model {
     float* ws = nullptr;
     int64_t cap = 0;
     float *h_enc, *qkv, *att, *hid, *ctx, *kvx, *y, *qx, *sig_e, *sig_t, *sig_c, *mod, *xbuf, *noised, *Fbuf, *steps;
+    float* cmod = nullptr;  // COND_NOISE: rows of [c | ones(D)], read as (shift, scale) by the LayerNorm prologue
     int64_t cached_batch = 0;  // batch of the context currently cached by mdt_encode (0 = none)
     std::vector<float> steps_host;
     // sampler pipelining: the batch is cut into `ways` sample-aligned slices whose launch chains run on separate
@@ -243,7 +253,7 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
 
     // stacked across decoder blocks: cross-attention K|V projections of the context, adaLN modulation
     lin_begin(m->kv_all, m->Ld * 2 * D, D, true);
-    lin_begin(m->mod_all, m->Ld * 6 * D, D, true);
+    if (m->cond == COND_ADALN) lin_begin(m->mod_all, m->Ld * 6 * D, D, true);
     for (int l = 0; l < m->Ld; ++l) {
         const std::string pre = P + "decoder.blocks." + std::to_string(l);
         DecBlock& d = m->dec[l];
@@ -261,7 +271,7 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         raw(d.ln3_w, pre + ".ln3.weight", D);
         raw(d.ln3_b, pre + ".ln3.bias", D);
         block_common_b(d, pre);
-        lin_part(m->mod_all, pre + ".adaLN_zero.modulation.1", 6 * D, l * 6 * D, true);
+        if (m->cond == COND_ADALN) lin_part(m->mod_all, pre + ".adaLN_zero.modulation.1", 6 * D, l * 6 * D, true);
     }
     raw(m->dec_ln_w, P + "decoder.ln.weight", D);
     if (xb) raw(m->dec_ln_b, P + "decoder.ln.bias", D);
@@ -296,10 +306,6 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     if (!cfg || !out) return fail(MDT_ERR_INVALID_ARG, "mdt_create: null argument");
     const mdt_config& c = *cfg;
     if (c.arch != MDT_ARCH_MDTV && c.arch != MDT_ARCH_MDT) return fail(MDT_ERR_INVALID_ARG, "unknown arch %d", c.arch);
-    if (!c.use_ada_conditioning)
-        return fail(MDT_ERR_UNSUPPORTED, "use_ada_conditioning=False (sigma token in the encoder, TransformerDecoder) "
-                                         "is not implemented by the HIP path");
-    if (c.use_noise_encoder) return fail(MDT_ERR_UNSUPPORTED, "use_noise_encoder=True (NoiseBlock) is not implemented");
     if (!c.linear_output) return fail(MDT_ERR_UNSUPPORTED, "linear_output=False (MLP action head) is not implemented");
     if (c.goal_seq_len != 1) return fail(MDT_ERR_UNSUPPORTED, "goal_seq_len must be 1");
     if (c.embed_dim <= 0 || c.embed_dim % 16 || c.embed_dim > 512)
@@ -318,13 +324,18 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     if (c.action_dim < 1 || c.action_dim > 16) return fail(MDT_ERR_UNSUPPORTED, "action_dim must be 1..16");
     if (c.action_seq_len < 1 || c.action_seq_len > 16) return fail(MDT_ERR_UNSUPPORTED, "action_seq_len must be 1..16");
     const int n_tok = c.arch == MDT_ARCH_MDTV ? c.n_obs_token : 2;
-    if (n_tok < 1 || 1 + n_tok > 16) return fail(MDT_ERR_UNSUPPORTED, "context length must be <= 16 tokens");
+    // use_noise_encoder only selects the block type of the adaLN-style decoder (TransformerFiLMDecoder); without
+    // use_ada_conditioning the reference builds a plain TransformerDecoder and the flag is never read
+    const int cond = !c.use_ada_conditioning ? COND_TOKEN : (c.use_noise_encoder ? COND_NOISE : COND_ADALN);
+    const int sig_tok = cond == COND_TOKEN ? 1 : 0;
+    if (n_tok < 1 || sig_tok + 1 + n_tok > 16) return fail(MDT_ERR_UNSUPPORTED, "context length must be <= 16 tokens");
     if (c.n_enc_layers < 0 || c.n_dec_layers < 1) return fail(MDT_ERR_INVALID_ARG, "bad layer counts");
     if (!(c.sigma_data > 0.f)) return fail(MDT_ERR_INVALID_ARG, "sigma_data must be > 0");
 
     mdt_model* m = new mdt_model();
     m->cfg = c;
-    m->D = c.embed_dim; m->H = c.n_heads; m->hd = hd; m->n_tok = n_tok; m->Te = 1 + n_tok; m->Ta = c.action_seq_len;
+    m->cond = cond; m->sig_tok = sig_tok;
+    m->D = c.embed_dim; m->H = c.n_heads; m->hd = hd; m->n_tok = n_tok; m->Te = sig_tok + 1 + n_tok; m->Ta = c.action_seq_len;
     m->A = c.action_dim; m->Le = c.n_enc_layers; m->Ld = c.n_dec_layers; m->G = c.goal_dim; m->O = c.obs_dim;
 
     Bump count;
@@ -361,7 +372,8 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     e = hipMalloc((void**)&m->staging, mx * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(m->arena); delete m; return fail(MDT_ERR_HIP, "hipMalloc(staging) failed: %s", hipGetErrorString(e)); }
     m->steps_host.resize(MAX_STEPS * 4);
-    m->xfold = !c.use_rot_embed && mdt_xattn_apply_supported(m->D, m->H, m->Te, m->Ta);
+    // the collapsed cross-attention needs a step-independent context and an unconditioned query input
+    m->xfold = cond == COND_ADALN && !c.use_rot_embed && mdt_xattn_apply_supported(m->D, m->H, m->Te, m->Ta);
     if (const char* x = getenv("MDT_HIP_XFOLD")) m->xfold = m->xfold && atoi(x) != 0;
     if (const char* w = getenv("MDT_HIP_WAYS")) m->ways = std::max(1, std::min(MAX_WAYS, atoi(w)));
     for (int i = 0; i < MAX_WAYS - 1; ++i) {
@@ -470,7 +482,8 @@ static void carve_ws(mdt_model* m, Bump& b, int64_t B) {
     m->sig_e = b.take(Rm * D);
     m->sig_t = b.take(Rm * 2 * D);
     m->sig_c = b.take(Rm * D);
-    m->mod = b.take(Rm * m->Ld * 6 * D);
+    m->mod = b.take(m->cond == COND_ADALN ? Rm * m->Ld * 6 * D : 0);
+    m->cmod = b.take(m->cond == COND_NOISE ? Rm * 2 * D : 0);
     m->xbuf = b.take(Ra * m->A);
     m->noised = b.take(Ra * m->A);
     m->Fbuf = b.take(Ra * m->A);
@@ -500,6 +513,8 @@ extern "C" mdt_status mdt_reserve(mdt_model* m, int64_t max_batch) {
     Bump real;
     real.base = m->ws;
     carve_ws(m, real, max_batch);
+    if (m->cond == COND_NOISE)  // the "scale" half of every [c | ones] row; the c half is rewritten per call
+        HIP_TRY(hipMemsetD32((hipDeviceptr_t)m->cmod, 0x3f800000u, (size_t)std::max<int64_t>(max_batch, MAX_STEPS) * 2 * m->D));
     m->cap = max_batch;
     return MDT_OK;
 }
@@ -527,8 +542,11 @@ static bool misaligned(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
 // one transformer Block on the encoder tokens / the self-attention + MLP halves of a ConditionedBlock
 struct ModRef {
-    const float* mod = nullptr;  // modulation row base for this decoder block (nullptr: encoder Block)
-    int64_t stride = 0;
+    const float* mod = nullptr;  // conditioning row base for this decoder block (nullptr: unconditioned Block)
+    int64_t stride = 0;          // floats between the rows of consecutive samples (0: one row for the whole batch)
+    int shift = -1, scale = -1, gate = -1;  // offsets inside the row; -1 = absent
+    ModRef() {}
+    ModRef(const float* m_, int64_t st, int sh, int sc, int g) : mod(m_), stride(st), shift(sh), scale(sc), gate(g) {}
 };
 
 static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, bool causal,
@@ -538,7 +556,7 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
     mdt_gemm_args g = gemm_args(x, D, e.qkv, V.qkv, 3 * D, M);
     g.ln = 1; g.ln_w = e.ln1_w; g.ln_b = e.ln1_b;
     g.rows_per_sample = T;
-    if (mr.mod) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = 0; g.scale_off = D; }
+    if (mr.mod && mr.shift >= 0) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = mr.shift; g.scale_off = mr.scale; }
     LAUNCH(mdt_launch_gemm(g, s));
     mdt_attn_args a;
     memset(&a, 0, sizeof a);
@@ -548,7 +566,7 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
     LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
     mdt_gemm_args p = gemm_args(V.att, D, e.proj, x, D, M);
     p.residual = 1; p.rows_per_sample = T;
-    if (mr.mod) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = 2 * D; }
+    if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
     LAUNCH(mdt_launch_gemm(p, s));
     return MDT_OK;
 }
@@ -559,20 +577,42 @@ static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_
     mdt_gemm_args g = gemm_args(x, D, e.fc, V.hid, 4 * D, M);
     g.ln = 1; g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = MDT_ACT_GELU;
     g.rows_per_sample = T;
-    if (mr.mod) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = 3 * D; g.scale_off = 4 * D; }
+    if (mr.mod && mr.shift >= 0) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = mr.shift; g.scale_off = mr.scale; }
     LAUNCH(mdt_launch_gemm(g, s));
     mdt_gemm_args p = gemm_args(V.hid, 4 * D, e.proj2, x, D, M);
     p.residual = 1; p.rows_per_sample = T;
-    if (mr.mod) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = 5 * D; }
+    if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
     LAUNCH(mdt_launch_gemm(p, s));
     return MDT_OK;
 }
 
+// sigma_emb: sinusoidal(ln(sigma)/4) -> Linear -> Mish -> Linear for R sigmas (mdtv_transformer.py:105-110,282-288);
+// the second Linear's output rows go to out (leading dimension ldo, row r -> row r*gout) after `act`.
+static mdt_status run_sigma_mlp(mdt_model* m, const float* sigma, int64_t sstride, int R, float* out, int64_t ldo,
+                                int gout, int act, hipStream_t s) {
+    const int D = m->D;
+    LAUNCH(mdt_launch_sigma_emb(sigma, sstride, m->freqs, m->sig_e, R, D, s));
+    mdt_gemm_args a = gemm_args(m->sig_e, D, m->sig1, m->sig_t, 2 * D, R);
+    a.act = MDT_ACT_MISH;
+    LAUNCH(mdt_launch_gemm(a, s));
+    mdt_gemm_args b = gemm_args(m->sig_t, 2 * D, m->sig3, out, ldo, R);
+    b.act = act;
+    b.gin = 1; b.gout = gout; b.goff = 0;
+    LAUNCH(mdt_launch_gemm(b, s));
+    return MDT_OK;
+}
+
+// sigma / sstride: only read when the context starts with the sigma token (COND_TOKEN); sstride 0 = one sigma for
+// the whole batch, 1 = one per sample.
 static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tokens2, const float* goal, int modality,
-                             int honour_modality, int64_t B, float* ctx_out, hipStream_t s) {
+                             int honour_modality, int64_t B, const float* sigma, int64_t sstride, float* ctx_out,
+                             hipStream_t s) {
     const mdt_config& c = m->cfg;
     const int D = m->D, Te = m->Te;
+    const int t0 = m->sig_tok;  // context row of the goal token
     if (!tokens || !goal) return fail(MDT_ERR_INVALID_ARG, "encode: null tokens/goal");
+    if (t0 && !sigma)
+        return fail(MDT_ERR_INVALID_ARG, "encode: use_ada_conditioning=False puts sigma into the context; sigma is required");
     if (c.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "encode: MDT needs the gripper tokens");
     if (misaligned(tokens) || misaligned(goal) || misaligned(tokens2) || misaligned(ctx_out))
         return fail(MDT_ERR_INVALID_ARG, "encode: pointers must be 16-byte aligned");
@@ -584,7 +624,9 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     const Lin& g2 = lang ? m->lang2 : m->goal2;
     const float* pos0 = (c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb) ? m->pos_emb : nullptr;
     const float* pos1 = pos0 ? m->pos_emb + (int64_t)c.goal_seq_len * D : nullptr;
-    // goal token -> row 0 of every sample's context            (process_goal_embeddings, mdtv_transformer.py:268)
+    // sigma token -> row 0 of every sample's context           (concatenate_inputs, mdtv_transformer.py:296-297)
+    if (t0) MDT_TRY(run_sigma_mlp(m, sigma, sstride, (int)B, m->h_enc, D, Te, MDT_ACT_NONE, s));
+    // goal token -> next row                                    (process_goal_embeddings, mdtv_transformer.py:268)
     {
         const float* gin = goal;
         int64_t ld = m->G;
@@ -595,20 +637,20 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
             gin = m->hid; ld = 2 * D;
         }
         mdt_gemm_args a = gemm_args(gin, ld, g2, m->h_enc, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = 0; a.rowvec = pos0;
+        a.gin = 1; a.gout = Te; a.goff = t0; a.rowvec = pos0;
         LAUNCH(mdt_launch_gemm(a, s));
     }
-    // state tokens -> rows 1..                                  (process_state_embeddings, :260 / mdt :300)
+    // state tokens -> the rows after it                         (process_state_embeddings, :260 / mdt :300)
     if (c.arch == MDT_ARCH_MDTV) {
         mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)(B * m->n_tok));
-        a.gin = m->n_tok; a.gout = Te; a.goff = 1;
+        a.gin = m->n_tok; a.gout = Te; a.goff = t0 + 1;
         LAUNCH(mdt_launch_gemm(a, s));
     } else {
         mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = 1; a.rowvec = pos1;
+        a.gin = 1; a.gout = Te; a.goff = t0 + 1; a.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(a, s));
         mdt_gemm_args b2 = gemm_args(tokens2, m->O, m->incam, m->h_enc, D, (int)B);
-        b2.gin = 1; b2.gout = Te; b2.goff = 2; b2.rowvec = pos1;
+        b2.gin = 1; b2.gout = Te; b2.goff = t0 + 2; b2.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(b2, s));
     }
     for (int l = 0; l < m->Le; ++l) {
@@ -639,32 +681,48 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     return MDT_OK;
 }
 
-// sigma embedding + adaLN modulation rows for R sigmas: mod (R, Ld*6D)
+// The decoder's conditioning rows for R sigmas.
+//   COND_ADALN: mod (R, Ld*6D) = adaLN_zero Linear(SiLU(c)) of every block, one stacked GEMM
+//   COND_NOISE: cmod (R, 2D)   = [c | ones]
+//   COND_TOKEN: nothing (sigma lives in the context)
 static mdt_status run_modulation(mdt_model* m, const float* sigma, int64_t sstride, int R, hipStream_t s) {
     const int D = m->D;
-    LAUNCH(mdt_launch_sigma_emb(sigma, sstride, m->freqs, m->sig_e, R, D, s));
-    mdt_gemm_args a = gemm_args(m->sig_e, D, m->sig1, m->sig_t, 2 * D, R);
-    a.act = MDT_ACT_MISH;
-    LAUNCH(mdt_launch_gemm(a, s));
-    mdt_gemm_args b = gemm_args(m->sig_t, 2 * D, m->sig3, m->sig_c, D, R);
-    b.act = MDT_ACT_SILU;  // AdaLNZero applies SiLU to c before its Linear; c itself is used nowhere else
-    LAUNCH(mdt_launch_gemm(b, s));
+    if (m->cond == COND_TOKEN) return MDT_OK;
+    if (m->cond == COND_NOISE) return run_sigma_mlp(m, sigma, sstride, R, m->cmod, 2 * D, 1, MDT_ACT_NONE, s);
+    // AdaLNZero applies SiLU to c before its Linear; c itself is used nowhere else
+    MDT_TRY(run_sigma_mlp(m, sigma, sstride, R, m->sig_c, D, 1, MDT_ACT_SILU, s));
     mdt_gemm_args c = gemm_args(m->sig_c, D, m->mod_all, m->mod, (int64_t)m->Ld * 6 * D, R);
     LAUNCH(mdt_launch_gemm(c, s));
     return MDT_OK;
 }
 
-// the Ld ConditionedBlocks on the residual stream m->y          (transformer_blocks.py:291-309)
+// conditioning rows of step / sigma-row r (see run_modulation) and their stride across samples
+static const float* cond_row(const mdt_model* m, int64_t r) {
+    if (m->cond == COND_ADALN) return m->mod + r * (int64_t)m->Ld * 6 * m->D;
+    if (m->cond == COND_NOISE) return m->cmod + r * 2 * (int64_t)m->D;
+    return nullptr;
+}
+static int64_t cond_width(const mdt_model* m) {
+    return m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * m->D : (m->cond == COND_NOISE ? 2 * (int64_t)m->D : 0);
+}
+
+// the Ld decoder blocks on the residual stream V.y: ConditionedBlock (transformer_blocks.py:291-309), NoiseBlock
+// (:335-341) or the plain cross-attending Block (:209-214), by m->cond
 static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, const float* mod_row, int64_t mod_stride,
                                      hipStream_t s) {
     const int D = m->D, Ta = m->Ta, M = (int)(B * Ta);
     for (int l = 0; l < m->Ld; ++l) {
         const DecBlock& d = m->dec[l];
-        ModRef mr;
-        mr.mod = mod_row + (int64_t)l * 6 * D;
-        mr.stride = mod_stride;
-        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, mr, s));
-        // cross attention: ln3 (biased LayerNorm) -> q ; K|V precomputed ; NOT gated, NOT modulated
+        ModRef ma, mx, mm;  // self-attention half, cross-attention query, MLP half
+        if (m->cond == COND_ADALN) {
+            const float* row = mod_row + (int64_t)l * 6 * D;
+            ma = ModRef(row, mod_stride, 0, D, 2 * D);
+            mm = ModRef(row, mod_stride, 3 * D, 4 * D, 5 * D);
+        } else if (m->cond == COND_NOISE) {
+            ma = mx = ModRef(mod_row, mod_stride, 0, D, -1);  // ln(x)*1 + c, residual ungated; MLP unconditioned
+        }
+        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, ma, s));
+        // cross attention: ln3 (biased LayerNorm) -> q ; K|V precomputed ; never gated
         if (m->xfold) {
             const int64_t np = (int64_t)m->H * m->Te;
             mdt_xapply_args x;
@@ -678,6 +736,7 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
         } else {
             mdt_gemm_args q = gemm_args(V.y, D, d.xq, V.qx, D, M);
             q.ln = 1; q.ln_w = d.ln3_w; q.ln_b = d.ln3_b; q.rows_per_sample = Ta;
+            if (mx.mod) { q.mod = mx.mod; q.mod_stride = mx.stride; q.shift_off = mx.shift; q.scale_off = mx.scale; }
             LAUNCH(mdt_launch_gemm(q, s));
             mdt_attn_args a;
             memset(&a, 0, sizeof a);
@@ -691,7 +750,7 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
             p.residual = 1; p.rows_per_sample = Ta;
             LAUNCH(mdt_launch_gemm(p, s));
         }
-        MDT_TRY(run_mlp(m, d, V, B, Ta, mr, s));
+        MDT_TRY(run_mlp(m, d, V, B, Ta, mm, s));
     }
     return MDT_OK;
 }
@@ -711,10 +770,10 @@ static mdt_head_args head_args(mdt_model* m, const float* y, int64_t B, const fl
 // C ABI: model level
 // ------------------------------------------------------------------------------------------------
 extern "C" mdt_status mdt_encode(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
-                                 int32_t modality, int32_t honour_modality, int64_t batch, float* ctx_out,
-                                 void* stream) {
+                                 int32_t modality, int32_t honour_modality, const float* sigma, int64_t batch,
+                                 float* ctx_out, void* stream) {
     if (!m || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_encode: bad argument");
-    return run_encode(m, tokens, tokens2, goal, modality, honour_modality, batch, ctx_out, (hipStream_t)stream);
+    return run_encode(m, tokens, tokens2, goal, modality, honour_modality, batch, sigma, 1, ctx_out, (hipStream_t)stream);
 }
 
 extern "C" mdt_status mdt_denoise_cached(mdt_model* m, const float* x, const float* sigma, int64_t batch,
@@ -725,12 +784,12 @@ extern "C" mdt_status mdt_denoise_cached(mdt_model* m, const float* x, const flo
                     (long long)batch, (long long)m->cached_batch);
     hipStream_t s = (hipStream_t)stream;
     const bool scalar = (flags & MDT_SIGMA_SCALAR) != 0;
-    const int64_t modw = (int64_t)m->Ld * 6 * m->D;
+    const int64_t modw = cond_width(m);
     const int64_t sst = scalar ? 0 : 1;  // stride of sigma / of the modulation rows across samples
     MDT_TRY(run_modulation(m, sigma, 1, scalar ? 1 : (int)batch, s));
     LAUNCH(mdt_launch_action_embed(x, (flags & MDT_RAW_INPUT) ? nullptr : sigma, sst, m->cfg.sigma_data, m->Wa, m->ba,
                                    m->y, (int)(batch * m->Ta), m->A, m->D, m->Ta, s));
-    MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, m->mod, scalar ? 0 : modw, s));
+    MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, cond_row(m, 0), scalar ? 0 : modw, s));
     mdt_head_args h = head_args(m, m->y, batch, x, sigma, sst, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
     LAUNCH(mdt_launch_head(h, s));
     return MDT_OK;
@@ -742,7 +801,7 @@ extern "C" mdt_status mdt_forward(mdt_model* m, const float* tokens, const float
     if (!m) return fail(MDT_ERR_INVALID_ARG, "mdt_forward: null handle");
     // MDTTransformer.forward -> enc_only_forward always embeds the goal with goal_emb (mdt_transformer.py:215)
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
-    MDT_TRY(mdt_encode(m, tokens, tokens2, goal, modality, honour, batch, ctx_out, stream));
+    MDT_TRY(mdt_encode(m, tokens, tokens2, goal, modality, honour, sigma, batch, ctx_out, stream));
     return mdt_denoise_cached(m, x, sigma, batch, 0, out, stream);
 }
 
@@ -753,7 +812,9 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
     if (n_steps < 1 || n_steps > MAX_STEPS) return fail(MDT_ERR_INVALID_ARG, "n_steps must be 1..%d", MAX_STEPS);
     hipStream_t s = (hipStream_t)stream;
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
-    MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, ctx_out, s));
+    const bool per_step_ctx = m->cond == COND_TOKEN;  // sigma is a context token: the encoder cannot be hoisted
+    if (!per_step_ctx) MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, nullptr, 0, ctx_out, s));
+    else { MDT_TRY(check_loaded(m)); MDT_TRY(mdt_reserve(m, batch)); }
     // per-step scalars, fp32 like the reference's 0-dim tensor math (gc_sampling.py:946-950):
     //   t = -ln(sigma); ratio = exp(-t_next)/exp(-t); coef = -expm1(-(t_next - t))
     float* sh = m->steps_host.data();
@@ -766,10 +827,9 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
         sh[4 * i + 3] = sigmas[i];
     }
     HIP_TRY(hipMemcpyAsync(m->steps, sh, (size_t)n_steps * 4 * sizeof(float), hipMemcpyHostToDevice, s));
-    const int64_t modw = (int64_t)m->Ld * 6 * m->D;
-    MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));  // one row of adaLN vectors per step
+    MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));  // one row of conditioning vectors per step
     // ---- cut the batch into sample-aligned slices (multiples of 16 samples = 5 row tiles) on separate streams ----
-    int ways = m->ways;
+    int ways = per_step_ctx ? 1 : m->ways;  // the encoder works on whole-batch buffers
     while (ways > 1 && batch / ways < 32) --ways;
     int64_t b0[MAX_WAYS + 1];
     b0[0] = 0;
@@ -796,10 +856,13 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
     }
     for (int i = 0; i < n_steps; ++i) {
         const bool last = i == n_steps - 1;
+        if (per_step_ctx)  // the reference leaves the LAST step's context in latent_encoder_emb
+            MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, m->steps + 4 * i + 3, 0,
+                               last ? ctx_out : nullptr, s));
         for (int w = 0; w < ways; ++w) {
             const int64_t nb = b0[w + 1] - b0[w];
             const View V = decoder_view(m, b0[w]);
-            MDT_TRY(run_decoder_blocks(m, V, nb, m->mod + (int64_t)i * modw, 0, st[w]));
+            MDT_TRY(run_decoder_blocks(m, V, nb, cond_row(m, i), 0, st[w]));
             const float* xin = (i == 0 ? x_T : m->xbuf) + b0[w] * xs;
             float* xout = (last ? out : m->xbuf) + b0[w] * xs;
             mdt_head_args h = head_args(m, V.y, nb, xin, m->steps + 4 * i + 3, 0, xout, MDT_HEAD_DDIM);
@@ -822,7 +885,7 @@ extern "C" mdt_status mdt_loss_fwd(mdt_model* m, const float* tokens, const floa
         return fail(MDT_ERR_INVALID_ARG, "mdt_loss_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
-    MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, ctx_out, s));
+    MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, sigma, 1, ctx_out, s));
     const int per = m->Ta * m->A;
     const int64_t n = batch * per;
     LAUNCH(mdt_launch_noise_input(action, noise, sigma, m->noised, n, per, s));
@@ -841,9 +904,10 @@ extern "C" double mdt_flops_per_chunk(const mdt_model* m, int32_t n_steps) {
                  m->Le * (Te * 2.0 * (4 * D * D + 8 * D * D) + attn(Te, Te));
     double kv = m->Ld * Te * 2.0 * 2 * D * D;
     double sig = 2.0 * (D * 2 * D + 2 * D * D);
-    double blk = 2.0 * D * 6 * D + Ta * 2.0 * (4 * D * D) + Ta * 2.0 * (2 * D * D) + Ta * 2.0 * 8 * D * D +
-                 attn(Ta, Ta) + attn(Ta, Te);
+    double blk = (m->cond == COND_ADALN ? 2.0 * D * 6 * D : 0.0) + Ta * 2.0 * (4 * D * D) + Ta * 2.0 * (2 * D * D) +
+                 Ta * 2.0 * 8 * D * D + attn(Ta, Ta) + attn(Ta, Te);
     double step = sig + 2.0 * Ta * A * D * 2 + m->Ld * blk;
+    if (m->cond == COND_TOKEN) return n_steps * (enc + kv + step);  // the sigma token re-runs the encoder every step
     return enc + kv + n_steps * step;
 }
 

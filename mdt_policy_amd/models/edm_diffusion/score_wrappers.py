@@ -89,6 +89,9 @@ class GCDenoiser(nn.Module):
         ``self(state, x, goal, sigma)`` inside the block -- what the Python samplers in gc_sampling use."""
         im = self.inner_model
         eng = self._engine()
+        if eng.sigma_in_context:  # use_ada_conditioning=False: sigma is a context token, nothing can be hoisted
+            yield None
+            return
         g = im._goals(goal, False)
         ctx = eng.encode(state, g, honour_modality=im._arch == "mdtv")
         im.latent_encoder_emb = ctx

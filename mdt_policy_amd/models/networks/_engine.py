@@ -44,7 +44,8 @@ class HipEngine:
         self.expected = {self.lib.mdt_param_name(handle, i).decode(): self.lib.mdt_param_numel(handle, i)
                          for i in range(n)}
         self._uploaded: Dict[str, tuple] = {}
-        self.Te = 1 + (cfg.n_obs_token if cfg.arch == 0 else 2)
+        self.sigma_in_context = not cfg.use_ada_conditioning  # sigma embedding is the first context token
+        self.Te = int(self.sigma_in_context) + 1 + (cfg.n_obs_token if cfg.arch == 0 else 2)
         self.Ta, self.A, self.D = cfg.action_seq_len, cfg.action_dim, cfg.embed_dim
 
     def __del__(self):
@@ -118,13 +119,20 @@ class HipEngine:
         return _lib.MODALITY["lang"] if state.get("modality", None) == "lang" else _lib.MODALITY["vis"]
 
     # ------------------------------------------------------------------------------------------
-    def encode(self, state: dict, goal: torch.Tensor, honour_modality: bool) -> torch.Tensor:
+    def encode(self, state: dict, goal: torch.Tensor, honour_modality: bool,
+               sigma: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``sigma`` is only read by use_ada_conditioning=False models (it is their first context token)."""
         self.sync_params()
         tok, tok2, B = self._tokens(state)
         g = self._goal(goal, B)
+        s = None
+        if self.sigma_in_context:
+            if sigma is None:
+                raise ValueError("use_ada_conditioning=False: the encoder needs sigma (its first context token)")
+            s = self._in(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma, (B,))
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         _lib.check(self.lib.mdt_encode(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
-                                       int(honour_modality), B, _ptr(ctx), self._stream()))
+                                       int(honour_modality), _ptr(s), B, _ptr(ctx), self._stream()))
         return ctx
 
     def denoise_cached(self, x: torch.Tensor, sigma: torch.Tensor, flags: int = 0) -> torch.Tensor:
@@ -242,14 +250,14 @@ class HipScoreNetwork(nn.Module):
         """Raw score network F(states, actions, goals, sigma) (reference mdtv_transformer.py:208-211)."""
         self._guard_mode()
         eng = self.hip_engine()
-        ctx = eng.encode(states, self._goals(goals, uncond), honour_modality=self._arch == "mdtv")
+        ctx = eng.encode(states, self._goals(goals, uncond), honour_modality=self._arch == "mdtv", sigma=sigma)
         self.latent_encoder_emb = ctx
         return eng.denoise_cached(actions, sigma, _lib.RAW_OUTPUT | _lib.RAW_INPUT)
 
     def forward_enc_only(self, states, actions=None, goals=None, sigma=None, uncond: Optional[bool] = False):
         """Context tokens (reference mdtv_transformer.py:213-222 / mdt_transformer.py:257-281)."""
         self._guard_mode()
-        ctx = self.hip_engine().encode(states, self._goals(goals, uncond), honour_modality=True)
+        ctx = self.hip_engine().encode(states, self._goals(goals, uncond), honour_modality=True, sigma=sigma)
         if self._arch == "mdtv":  # MDTTransformer.forward_enc_only does not cache (mdt_transformer.py:257-281)
             self.latent_encoder_emb = ctx
         return ctx

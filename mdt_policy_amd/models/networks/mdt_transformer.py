@@ -14,7 +14,7 @@ import torch.nn as nn
 from ... import _lib
 from ._engine import HipScoreNetwork
 from .mdtv_transformer import _goal_embedder, _SinusoidalSlot
-from .transformers.transformer_blocks import TransformerEncoder, TransformerFiLMDecoder
+from .transformers.transformer_blocks import TransformerEncoder, TransformerDecoder, TransformerFiLMDecoder
 
 
 class MDTTransformer(HipScoreNetwork):
@@ -53,8 +53,6 @@ class MDTTransformer(HipScoreNetwork):
     ):
         super().__init__()
         self._init_common()
-        if not use_ada_conditioning:
-            raise NotImplementedError("use_ada_conditioning=False is not implemented by the HIP path (SURVEY.md 8(f) 3)")
         if not goal_conditioned:
             raise NotImplementedError("goal_conditioned=False is not implemented by the HIP path")
         if not linear_output:
@@ -89,12 +87,18 @@ class MDTTransformer(HipScoreNetwork):
                                           resid_pdrop=resid_pdrop, n_layers=n_enc_layers, block_size=block_size,
                                           bias=bias, use_rot_embed=use_rot_embed, rotary_xpos=rotary_xpos,
                                           mlp_pdrop=mlp_pdrop)
-        self.decoder = TransformerFiLMDecoder(embed_dim=embed_dim, n_heads=n_heads, attn_pdrop=attn_pdrop,
-                                              resid_pdrop=resid_pdrop, n_layers=n_dec_layers,
-                                              film_cond_dim=embed_dim, block_size=block_size, bias=bias,
-                                              use_rot_embed=use_rot_embed, rotary_xpos=rotary_xpos,
-                                              mlp_pdrop=mlp_pdrop, use_cross_attention=True,
-                                              use_noise_encoder=use_noise_encoder)
+        if use_ada_conditioning:
+            self.decoder = TransformerFiLMDecoder(embed_dim=embed_dim, n_heads=n_heads, attn_pdrop=attn_pdrop,
+                                                  resid_pdrop=resid_pdrop, n_layers=n_dec_layers,
+                                                  film_cond_dim=embed_dim, block_size=block_size, bias=bias,
+                                                  use_rot_embed=use_rot_embed, rotary_xpos=rotary_xpos,
+                                                  mlp_pdrop=mlp_pdrop, use_cross_attention=True,
+                                                  use_noise_encoder=use_noise_encoder)
+        else:  # sigma enters as the first encoder token instead (concatenate_inputs)
+            self.decoder = TransformerDecoder(embed_dim=embed_dim, n_heads=n_heads, attn_pdrop=attn_pdrop,
+                                              resid_pdrop=resid_pdrop, n_layers=n_dec_layers, block_size=block_size,
+                                              bias=bias, use_rot_embed=use_rot_embed, rotary_xpos=rotary_xpos,
+                                              mlp_pdrop=mlp_pdrop, use_cross_attention=True)
         self.block_size = block_size
         self.goal_seq_len = goal_seq_len
         self.obs_seq_len = obs_seq_len

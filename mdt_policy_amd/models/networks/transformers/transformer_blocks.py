@@ -1,7 +1,8 @@
 """Parameter containers with the reference's module tree (names AND registration order).
 
 Reference: mdt/models/networks/transformers/transformer_blocks.py (LayerNorm :29, Attention :66, MLP :161,
-Block :183, AdaLNZero :245, ConditionedBlock :266, TransformerEncoder :344, TransformerFiLMDecoder :509).
+Block :183, AdaLNZero :245, ConditionedBlock :266, NoiseBlock :311, TransformerEncoder :344, TransformerDecoder :460,
+TransformerFiLMDecoder :509).
 Checkpoints address parameters by state_dict key and the evaluation harness maps EMA weights POSITIONALLY onto
 ``named_parameters()`` (mdt/evaluation/utils.py:98), so both are part of the drop-in boundary.  These classes
 own parameters only: the arithmetic of the whole tree runs in libmdt_hip.so (gfx950 kernels), driven by the
@@ -95,6 +96,10 @@ class ConditionedBlock(Block):
         self.adaLN_zero = AdaLNZero(film_cond_dim)
 
 
+class NoiseBlock(Block):
+    """Same parameters as Block; the sigma embedding is added to the normalised input of both attentions."""
+
+
 class TransformerEncoder(_ParamOnly):
     def __init__(self, embed_dim, n_heads, attn_pdrop, resid_pdrop, n_layers, block_size, bias=False,
                  use_rot_embed=False, rotary_xpos=False, mlp_pdrop=0):
@@ -110,11 +115,32 @@ class TransformerFiLMDecoder(_ParamOnly):
                  use_rot_embed=False, rotary_xpos=False, mlp_pdrop=0, use_cross_attention=True,
                  use_noise_encoder=False, kwargs=None):
         super().__init__()
+        if not use_cross_attention:
+            raise NotImplementedError("the HIP decoder always cross-attends to the context")
         if use_noise_encoder:
-            raise NotImplementedError("use_noise_encoder=True (NoiseBlock) is not implemented by the HIP path")
+            self.blocks = nn.Sequential(*[
+                NoiseBlock(embed_dim, n_heads, attn_pdrop, resid_pdrop, mlp_pdrop, block_size, causal=True,
+                           use_cross_attention=use_cross_attention, use_rot_embed=use_rot_embed,
+                           rotary_xpos=rotary_xpos, bias=bias) for _ in range(n_layers)])
+        else:
+            self.blocks = nn.Sequential(*[
+                ConditionedBlock(embed_dim, n_heads, attn_pdrop, resid_pdrop, mlp_pdrop, block_size, causal=True,
+                                 use_cross_attention=use_cross_attention, use_rot_embed=use_rot_embed,
+                                 rotary_xpos=rotary_xpos, bias=bias, film_cond_dim=film_cond_dim)
+                for _ in range(n_layers)])
+        self.ln = LayerNorm(embed_dim, bias)
+
+
+class TransformerDecoder(_ParamOnly):
+    """Plain cross-attending decoder of the use_ada_conditioning=False variant."""
+
+    def __init__(self, embed_dim, n_heads, attn_pdrop, resid_pdrop, n_layers, block_size, bias=False,
+                 use_rot_embed=False, rotary_xpos=False, mlp_pdrop=0, use_cross_attention=True):
+        super().__init__()
+        if not use_cross_attention:
+            raise NotImplementedError("the HIP decoder always cross-attends to the context")
         self.blocks = nn.Sequential(*[
-            ConditionedBlock(embed_dim, n_heads, attn_pdrop, resid_pdrop, mlp_pdrop, block_size, causal=True,
-                             use_cross_attention=use_cross_attention, use_rot_embed=use_rot_embed,
-                             rotary_xpos=rotary_xpos, bias=bias, film_cond_dim=film_cond_dim)
-            for _ in range(n_layers)])
+            Block(embed_dim, n_heads, attn_pdrop, resid_pdrop, mlp_pdrop, block_size, causal=True,
+                  use_cross_attention=use_cross_attention, use_rot_embed=use_rot_embed, rotary_xpos=rotary_xpos,
+                  bias=bias) for _ in range(n_layers)])
         self.ln = LayerNorm(embed_dim, bias)

@@ -164,6 +164,23 @@ def conditioned_block(P: Params, pre: str, x: Tensor, c: Tensor, ctx: Tensor, n_
     return x
 
 
+def noise_block(P: Params, pre: str, x: Tensor, c: Tensor, ctx: Tensor, n_heads: int, use_rot: bool) -> Tensor:
+    """NoiseBlock.forward (transformer_blocks.py:335-341): the sigma embedding is ADDED to the normalised input of
+    the self- and cross-attention; the MLP branch is unconditioned; no gates."""
+    x = x + attention(P, pre + ".attn", _ln(P, pre + ".ln_1", x) + c, None, n_heads, True, use_rot)
+    x = x + attention(P, pre + ".cross_att", _ln(P, pre + ".ln3", x) + c, ctx, n_heads, True, use_rot)
+    x = x + mlp(P, pre + ".mlp", _ln(P, pre + ".ln_2", x))
+    return x
+
+
+def plain_decoder_block(P: Params, pre: str, x: Tensor, ctx: Tensor, n_heads: int, use_rot: bool) -> Tensor:
+    """Block.forward with cross attention, causal (TransformerDecoder, transformer_blocks.py:209-214,460-506)."""
+    x = x + attention(P, pre + ".attn", _ln(P, pre + ".ln_1", x), None, n_heads, True, use_rot)
+    x = x + attention(P, pre + ".cross_att", _ln(P, pre + ".ln3", x), ctx, n_heads, True, use_rot)
+    x = x + mlp(P, pre + ".mlp", _ln(P, pre + ".ln_2", x))
+    return x
+
+
 # ----------------------------------------------------------------------------------------------
 # score networks        mdt/models/networks/mdtv_transformer.py, mdt/models/networks/mdt_transformer.py
 # ----------------------------------------------------------------------------------------------
@@ -189,11 +206,12 @@ def _prep_goal(cfg: dict, goal: Tensor, states_len: int) -> Tensor:
 
 
 def encode(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv", entry: str = "forward",
-           trace: Optional[dict] = None) -> Tensor:
+           trace: Optional[dict] = None, sigma: Optional[Tensor] = None) -> Tensor:
     """MDT-V: forward_enc_only (mdtv_transformer.py:213-222).  MDT: enc_only_forward (mdt_transformer.py:211-229,
     always goal_emb) when entry == 'forward', forward_enc_only (:257-281, honours modality) otherwise.
     adaLN variants only (use_ada_conditioning=True): the encoder sees neither sigma nor the actions."""
-    assert cfg.get("use_ada_conditioning", False), "oracle covers the adaLN (default) variant"
+    ada = cfg.get("use_ada_conditioning", False)
+    assert ada or sigma is not None, "without adaLN conditioning the encoder needs sigma (its first token)"
     modality = state.get("modality", "vis")
     H, rot = cfg["n_heads"], cfg.get("use_rot_embed", False)
     if arch == "mdtv":
@@ -213,6 +231,8 @@ def encode(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv", 
             g = g + pos[:, : cfg["goal_seq_len"], :]
             s = s + pos[:, cfg["goal_seq_len"]: cfg["goal_seq_len"] + 1, :]
         h = torch.cat([g, s], dim=1)
+    if not ada:  # concatenate_inputs: the sigma embedding is the FIRST encoder token (mdtv_transformer.py:296-297)
+        h = torch.cat([sigma_embedding(P, cfg, sigma), h], dim=1)
     if trace is not None:
         trace["goal_embed"], trace["state_embed"] = g, s
     for l in range(cfg["n_enc_layers"]):
@@ -246,7 +266,13 @@ def decode(P: Params, cfg: dict, ctx: Tensor, x_in: Tensor, sigma: Tensor, trace
     if trace is not None:
         trace["sigma_emb"], trace["action_emb"] = c, y
     for l in range(cfg["n_dec_layers"]):
-        y = conditioned_block(P, f"inner_model.decoder.blocks.{l}", y, c, ctx, H, rot, trace)
+        pre = f"inner_model.decoder.blocks.{l}"
+        if not cfg.get("use_ada_conditioning", False):
+            y = plain_decoder_block(P, pre, y, ctx, H, rot)
+        elif cfg.get("use_noise_encoder", False):
+            y = noise_block(P, pre, y, c, ctx, H, rot)
+        else:
+            y = conditioned_block(P, pre, y, c, ctx, H, rot, trace)
     y = _ln(P, "inner_model.decoder.ln", y)
     if cfg.get("linear_output", True):
         out = _lin(P, "inner_model.action_pred", y)
@@ -273,7 +299,7 @@ def denoise(P: Params, cfg: dict, state: dict, x: Tensor, goal: Tensor, sigma: T
     """GCDenoiser.forward (score_wrappers.py:65-80); pass ``ctx`` to reuse a hoisted encoder output."""
     c_skip, c_out, c_in = [s[:, None, None] for s in get_scalings(sigma, sigma_data)]
     if ctx is None:
-        ctx = encode(P, cfg, state, goal, arch, "forward", trace)
+        ctx = encode(P, cfg, state, goal, arch, "forward", trace, sigma=sigma)
     out = decode(P, cfg, ctx, x * c_in, sigma, trace) * c_out + x * c_skip
     if trace is not None:
         trace["denoised"] = out
@@ -285,27 +311,36 @@ def loss(P: Params, cfg: dict, state: dict, action: Tensor, goal: Tensor, noise:
     """GCDenoiser.loss (score_wrappers.py:45-63), eval mode (no dropout / goal masking)."""
     c_skip, c_out, c_in = [s[:, None, None] for s in get_scalings(sigma, sigma_data)]
     noised = action + noise * sigma[:, None, None]
-    ctx = encode(P, cfg, state, goal, arch, "forward")
+    ctx = encode(P, cfg, state, goal, arch, "forward", sigma=sigma)
     model_output = decode(P, cfg, ctx, noised * c_in, sigma)
     target = (action - c_skip * noised) / c_out
     return (model_output - target).pow(2).flatten(1).mean(), model_output
 
 
-def forward_context_only(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv") -> Tensor:
+def forward_context_only(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv",
+                         sigma: Optional[Tensor] = None) -> Tensor:
     """GCDenoiser.forward_context_only (score_wrappers.py:82-97) -> inner_model.forward_enc_only."""
-    return encode(P, cfg, state, goal, arch, "forward_enc_only")
+    return encode(P, cfg, state, goal, arch, "forward_enc_only", sigma=sigma)
 
 
 # ----------------------------------------------------------------------------------------------
 # samplers                                         mdt/models/edm_diffusion/gc_sampling.py
 # ----------------------------------------------------------------------------------------------
 @torch.no_grad()
+def _hoisted(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str, hoist: bool) -> Optional[Tensor]:
+    """The encoder output is step independent only when sigma conditions the decoder (use_ada_conditioning);
+    otherwise sigma is the first context token and every model call re-runs the encoder, as the reference does."""
+    if hoist and cfg.get("use_ada_conditioning", False):
+        return encode(P, cfg, state, goal, arch)
+    return None
+
+
 def sample_ddim(P: Params, cfg: dict, state: dict, x: Tensor, goal: Tensor, sigmas: Tensor, sigma_data: float = 0.5,
                 arch: str = "mdtv", hoist: bool = False, per_step: Optional[List[Tensor]] = None) -> Tensor:
     """sample_ddim (gc_sampling.py:922-951).  hoist=False re-runs the encoder every step exactly as the
     reference does; hoist=True evaluates it once (sigma-independent with adaLN conditioning)."""
     s_in = x.new_ones([x.shape[0]])
-    ctx = encode(P, cfg, state, goal, arch) if hoist else None
+    ctx = _hoisted(P, cfg, state, goal, arch, hoist)
     for i in range(len(sigmas) - 1):
         den = denoise(P, cfg, state, x, goal, sigmas[i] * s_in, sigma_data, arch, ctx)
         if per_step is not None:
@@ -321,7 +356,7 @@ def sample_euler(P: Params, cfg: dict, state: dict, x: Tensor, goal: Tensor, sig
                  arch: str = "mdtv", hoist: bool = True) -> Tensor:
     """sample_euler with s_churn = 0 (gc_sampling.py:164-209): d = (x - den)/sigma; x += d * (s_next - s)."""
     s_in = x.new_ones([x.shape[0]])
-    ctx = encode(P, cfg, state, goal, arch) if hoist else None
+    ctx = _hoisted(P, cfg, state, goal, arch, hoist)
     for i in range(len(sigmas) - 1):
         den = denoise(P, cfg, state, x, goal, sigmas[i] * s_in, sigma_data, arch, ctx)
         d = (x - den) / sigmas[i]
@@ -335,7 +370,7 @@ def sample_heun(P: Params, cfg: dict, state: dict, x: Tensor, goal: Tensor, sigm
     """sample_heun with s_churn = 0 (gc_sampling.py:256-312): Euler predictor + trapezoidal corrector,
     plain Euler on the last step (sigma_next == 0)."""
     s_in = x.new_ones([x.shape[0]])
-    ctx = encode(P, cfg, state, goal, arch) if hoist else None
+    ctx = _hoisted(P, cfg, state, goal, arch, hoist)
     for i in range(len(sigmas) - 1):
         den = denoise(P, cfg, state, x, goal, sigmas[i] * s_in, sigma_data, arch, ctx)
         d = (x - den) / sigmas[i]
@@ -355,7 +390,7 @@ def sample_dpmpp_2m(P: Params, cfg: dict, state: dict, x: Tensor, goal: Tensor, 
                     sigma_data: float = 0.5, arch: str = "mdtv", hoist: bool = True) -> Tensor:
     """sample_dpmpp_2m (gc_sampling.py:699-734): DPM-Solver++(2M) multistep."""
     s_in = x.new_ones([x.shape[0]])
-    ctx = encode(P, cfg, state, goal, arch) if hoist else None
+    ctx = _hoisted(P, cfg, state, goal, arch, hoist)
     old = None
     for i in range(len(sigmas) - 1):
         den = denoise(P, cfg, state, x, goal, sigmas[i] * s_in, sigma_data, arch, ctx)

@@ -278,6 +278,10 @@ G8_VARIANTS = {
     "plain_goal": ("mdtv", dict(use_mlp_goal=False, use_modality_encoder=False)),
     "two_tokens": ("mdtv", dict(n_obs_token=2, action_seq_len=7, action_dim=5, n_heads=4)),
     "mdt_bias_nopos": ("mdt", dict(bias=True, use_abs_pos_emb=False, n_heads=4)),
+    # conditioning variants of the decoder
+    "no_ada": ("mdtv", dict(use_ada_conditioning=False)),
+    "noise_block": ("mdtv", dict(use_noise_encoder=True)),
+    "mdt_no_ada": ("mdt", dict(use_ada_conditioning=False)),
 }
 
 

@@ -251,7 +251,10 @@ def test_collapsed_and_explicit_cross_attention_paths_agree(monkeypatch):
     assert not torch.equal(outs["1"], outs["0"])  # different arithmetic: the two paths really are distinct
 
 
-@pytest.mark.parametrize("name", ["bias", "plain_goal", "two_tokens", "mdt_bias_nopos"])
+G8 = ["bias", "plain_goal", "two_tokens", "mdt_bias_nopos", "no_ada", "noise_block", "mdt_no_ada"]
+
+
+@pytest.mark.parametrize("name", G8)
 def test_g8_constructor_variants(name):
     meta, fx = load_fixture(f"g8_{name}.npz")
     from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
@@ -270,6 +273,43 @@ def test_g8_constructor_variants(name):
     assert_close(torch.stack(steps), fx["denoised_steps"], what="denoised")
     assert_close(out.cpu(), fx["actions"], what="actions (fused loop)")
     assert_close(out2.cpu(), fx["actions"], what="actions (python loop)")
+
+
+@pytest.mark.parametrize("name", ["no_ada", "noise_block", "mdt_no_ada"])
+def test_conditioning_variants_entry_points_against_the_oracle(name):
+    """use_ada_conditioning=False (sigma token in the context, plain decoder) and use_noise_encoder=True (NoiseBlock):
+    forward with one sigma per sample, the split encoder/decoder calls, the loss, and another sampler, against the
+    oracle (itself pinned on these variants by the g8 fixtures)."""
+    meta, _ = load_fixture(f"g8_{name}.npz")
+    model = build(meta)
+    cfg, P, arch = cfg_of(meta), params_of(meta), meta["arch"]
+    state, goal, noise = inputs_of(meta)
+    gstate, ggoal, gnoise = gpu_inputs(meta)
+    B = noise.shape[0]
+    sigma = torch.tensor([0.07, 1.3, 40.0])[:B]
+    im = model.inner_model
+    with torch.no_grad():
+        out = model(gstate, gnoise, ggoal, sigma.cuda())
+        assert_close(out.cpu(), O.denoise(P, cfg, state, noise, goal, sigma, arch=arch), what="forward")
+        assert_close(im.latent_encoder_emb.cpu(), O.encode(P, cfg, state, goal, arch, sigma=sigma), what="ctx")
+        ctx = model.forward_context_only(gstate, gnoise, ggoal, sigma.cuda())
+        assert_close(ctx.cpu(), O.forward_context_only(P, cfg, state, goal, arch, sigma=sigma), what="ctx only")
+        if arch == "mdtv":  # MDT's forward_enc_only does not cache its context (mdt_transformer.py:257-281)
+            raw = im.forward_dec_only(ctx, gnoise, sigma.cuda())
+            assert_close(raw.cpu(), O.decode(P, cfg, O.encode(P, cfg, state, goal, arch, "forward_enc_only", sigma=sigma),
+                                             noise, sigma), what="dec only")
+        act = noise * 0.3
+        eps = torch.randn(noise.shape, generator=torch.Generator().manual_seed(5))
+        loss, _ = model.loss(gstate, act.cuda(), ggoal, eps.cuda(), sigma.cuda())
+        ref_loss, _ = O.loss(P, cfg, state, act, goal, eps, sigma, arch=arch)
+        assert_close(loss.cpu(), ref_loss, what="loss")
+        gs = sampling()
+        sig = gs.get_sigmas_karras(4, 0.01, 80.0)
+        got = gs.sample_heun(model, gstate, gnoise * 80.0, ggoal, sig)
+        assert_close(got.cpu(), O.sample_heun(P, cfg, state, noise * 80.0, goal, sig, arch=arch), what="heun")
+        B5 = gs.sample_ddim(model, gstate, gnoise * 80.0, ggoal, gs.get_sigmas_exponential(5, 0.001, 80.0))
+        ref5 = O.sample_ddim(P, cfg, state, noise * 80.0, goal, O.get_sigmas_exponential(5, 0.001, 80.0), arch=arch)
+        assert_close(B5.cpu(), ref5, what="ddim 5 steps")
 
 
 @pytest.mark.parametrize("name,kw,key", [
