@@ -66,6 +66,12 @@ class HeadArgs(C.Structure):
         ("ba", C.c_void_p)]
 
 
+class ResamplerConfig(C.Structure):
+    """mirrors mdt_resampler_config (include/mdt_resampler.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "dim_head", "heads", "num_latents", "num_time_embeds",
+                                          "ff_mult", "activation")]
+
+
 ARCH = {"mdtv": 0, "mdt": 1}
 MODALITY = {"vis": 0, "lang": 1}
 ACT = {"none": 0, "gelu": 1, "mish": 2, "silu": 3}
@@ -100,6 +106,15 @@ SYMBOLS = [
     ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_head", _I32, [C.POINTER(HeadArgs), _VP]),
     ("mdt_op_action_embed", _I32, [_VP, _VP, _I64, _F, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _VP]),
+    # include/mdt_resampler.h
+    ("mdt_resampler_create", _I32, [C.POINTER(ResamplerConfig), C.POINTER(_VP)]),
+    ("mdt_resampler_destroy", _I32, [_VP]),
+    ("mdt_resampler_param_count", _I64, [_VP]),
+    ("mdt_resampler_param_name", C.c_char_p, [_VP, _I64]),
+    ("mdt_resampler_param_numel", _I64, [_VP, _I64]),
+    ("mdt_resampler_load_param", _I32, [_VP, C.c_char_p, _VP, _I64, _VP]),
+    ("mdt_resampler_forward", _I32, [_VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    ("mdt_resampler_flops", C.c_double, [_VP, _I32, _I32]),
 ]
 
 _lock = threading.Lock()

@@ -1,10 +1,62 @@
-// mdt_internal.h -- launcher prototypes shared by mdt_kernels.hip (device code) and mdt_model.hip (host logic).
+// mdt_internal.h -- launcher prototypes shared by mdt_kernels.hip (device code) and the host logic
+// (mdt_model.hip: denoiser handle; mdt_resampler.hip: Perceiver resampler handle), plus the host helpers both use.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "mdt_hip.h"
 #include "mdt_hip_ops.h"
+#include "mdt_resampler.h"
+
+// ---- error plumbing: the message behind mdt_last_error() (thread local, defined in mdt_model.hip) ----
+mdt_status mdt_fail(mdt_status st, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return mdt_fail(MDT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));  \
+    } while (0)
+
+#define MDT_TRY(expr)                      \
+    do {                                   \
+        mdt_status _s = (expr);            \
+        if (_s != MDT_OK) return _s;       \
+    } while (0)
+
+#define LAUNCH(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return mdt_fail(MDT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));       \
+    } while (0)
+
+// ---- a Linear whose weight lives fragment-packed in a handle's arena ----
+struct Lin {
+    float* wp = nullptr;    // fragment-packed (N, K)
+    float* bias = nullptr;  // (N) or nullptr
+    int N = 0, K = 0;
+};
+
+// bump allocator over one hipMalloc'ed block (count pass with base == nullptr, then the real pass)
+struct Bump {
+    float* base = nullptr;
+    size_t off = 0;
+    float* take(size_t n) {
+        float* p = base ? base + off : nullptr;
+        off += (n + 63) & ~(size_t)63;  // 256-byte granules keep every buffer 16-byte aligned
+        return p;
+    }
+};
+
+static inline mdt_gemm_args gemm_args(const float* A, int64_t lda, const Lin& w, float* out, int64_t ldo, int M) {
+    mdt_gemm_args g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.lda = lda; g.Wp = w.wp; g.bias = w.bias; g.out = out; g.ldo = ldo;
+    g.M = M; g.N = w.N; g.K = w.K;
+    g.shift_off = -1; g.scale_off = -1; g.gate_off = -1; g.rows_per_sample = 1;
+    g.gin = 1; g.gout = 1; g.goff = 0;
+    return g;
+}
 
 int mdt_gemm_kchunk(int K, int ln, int cap);
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s);
@@ -25,3 +77,14 @@ hipError_t mdt_launch_transpose(const float* src, float* dst, int R, int Cc, hip
 hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s);
 hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s);
 bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta);
+// ---- Perceiver resampler kernels ----
+// media (B, T, n, D) + time_pos_emb[t] * mask[b][t] -> out (same shape); mask may be nullptr
+hipError_t mdt_launch_add_time_emb(const float* media, const float* tpe, const uint8_t* mask, float* out, int64_t B,
+                                   int T, int n, int D, hipStream_t s);
+// out[b*R + r][:] = src[r][:]
+hipError_t mdt_launch_bcast_rows(const float* src, float* out, int64_t B, int R, int D, hipStream_t s);
+// softmax(q k^T * scale) v for few queries over many keys: q (B*Tq, H*64) ld ldq; k / v rows (B*Tk) ld ldkv
+hipError_t mdt_launch_attention_long(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                     float* out, int64_t ldo, int B, int H, int hd, int Tq, int Tk, float scale,
+                                     hipStream_t s);
+bool mdt_attention_long_supported(int hd, int Tq, int Tk);

@@ -1479,3 +1479,169 @@ hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* pack
                        K / 16);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Perceiver resampler pieces (perceiver_resampler.py)
+// ------------------------------------------------------------------------------------------------
+// x_f + time_pos_emb[t] * mask[b][t]                                    (perceiver_resampler.py:141-148)
+__global__ void k_add_time_emb(const float* __restrict__ media, const float* __restrict__ tpe,
+                               const uint8_t* __restrict__ mask, float* __restrict__ out, int64_t n4, int T, int n,
+                               int d4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t row = i / d4;
+    const int c = (int)(i - row * d4);
+    const int64_t frame = row / n;  // b * T + t
+    const int t = (int)(frame % T);
+    const float mk = mask ? (mask[frame] ? 1.f : 0.f) : 1.f;
+    const f32x4 x = ldg4(media + i * 4), e = ldg4(tpe + ((int64_t)t * d4 + c) * 4);
+    f32x4 o;
+    o.x = x.x + e.x * mk; o.y = x.y + e.y * mk; o.z = x.z + e.z * mk; o.w = x.w + e.w * mk;
+    st4(out + i * 4, o);
+}
+
+// repeat(latents, 'q d -> b q d')                                       (perceiver_resampler.py:154)
+__global__ void k_bcast_rows(const float* __restrict__ src, float* __restrict__ out, int64_t n4, int per4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    st4(out + i * 4, ldg4(src + (i % per4) * 4));
+}
+
+hipError_t mdt_launch_add_time_emb(const float* media, const float* tpe, const uint8_t* mask, float* out, int64_t B,
+                                   int T, int n, int D, hipStream_t s) {
+    const int64_t n4 = B * T * n * (D / 4);
+    hipLaunchKernelGGL(k_add_time_emb, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, media, tpe, mask, out, n4, T,
+                       n, D / 4);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_bcast_rows(const float* src, float* out, int64_t B, int R, int D, hipStream_t s) {
+    const int64_t n4 = B * R * (D / 4);
+    hipLaunchKernelGGL(k_bcast_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, out, n4, R * (D / 4));
+    return hipGetLastError();
+}
+
+// Few queries (the learnt latents, <= 16) over many keys (media tokens + latents, ~400): one workgroup per
+// (sample, head).                                            (PerceiverAttentionLayer.forward, :51-82)
+//   1. thread per key: the key's HD floats in registers, dotted with every (pre-scaled) query held in LDS
+//   2. wave per query: max / exp / sum over the keys (scores stay in LDS)
+//   3. thread (key group g, feature d): P.V over the group's keys for all queries, V read once and coalesced over
+//      d; the G = 256 / HD partial sums meet in LDS.
+// 0.3 % of the resampler's FLOPs (the K/V projections of the media tokens are the other 99 %), VALU.
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long(const float* __restrict__ q, int64_t ldq,
+                                                   const float* __restrict__ k, const float* __restrict__ v,
+                                                   int64_t ldkv, float* __restrict__ out, int64_t ldo, int Tq, int Tk,
+                                                   float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int H4 = HD / 4, G = 256 / HD, QMAX = 16;
+    const int tid = threadIdx.x, b = blockIdx.x, h = blockIdx.y;
+    const int Tkp = (Tk + 3) & ~3;
+    float* qs = lds;                    // [Tq][HD]   scaled queries
+    float* S = qs + Tq * HD;            // [Tq][Tkp]  scores -> unnormalised probabilities
+    float* inv = S + Tq * Tkp;          // [16]       1 / sum
+    float* red = inv + QMAX;            // [G][Tq][HD]
+    for (int i = tid; i < Tq * HD; i += 256) {
+        const int qi = i / HD, d = i - qi * HD;
+        qs[i] = q[((int64_t)b * Tq + qi) * ldq + h * HD + d] * scale;
+    }
+    __syncthreads();
+    const float* kb = k + (int64_t)b * Tk * ldkv + h * HD;
+    const float* vb = v + (int64_t)b * Tk * ldkv + h * HD;
+    for (int f0 = 0; f0 < Tk; f0 += 256) {
+        const int f = min(f0 + tid, Tk - 1);
+        f32x4 kr[H4];
+#pragma unroll
+        for (int c = 0; c < H4; ++c) kr[c] = ldg4(kb + (int64_t)f * ldkv + c * 4);
+        for (int qi = 0; qi < Tq; ++qi) {
+            const f32x4* qv = reinterpret_cast<const f32x4*>(qs + qi * HD);
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < H4; ++c) {
+                const f32x4 t = qv[c];
+                acc = fmaf(t.x, kr[c].x, acc); acc = fmaf(t.y, kr[c].y, acc);
+                acc = fmaf(t.z, kr[c].z, acc); acc = fmaf(t.w, kr[c].w, acc);
+            }
+            if (f0 + tid < Tk) S[qi * Tkp + f] = acc;
+        }
+    }
+    __syncthreads();
+    const int w = tid >> 6, lane = tid & 63;
+    for (int qi = w; qi < Tq; qi += 4) {
+        float* row = S + qi * Tkp;
+        float mx = -INFINITY;
+        for (int f = lane; f < Tk; f += 64) mx = fmaxf(mx, row[f]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int f = lane; f < Tk; f += 64) {
+            const float e = expf(row[f] - mx);
+            row[f] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) inv[qi] = 1.f / sum;
+    }
+    __syncthreads();
+    const int g = tid / HD, d = tid - g * HD;
+    float acc[QMAX];
+#pragma unroll
+    for (int qi = 0; qi < QMAX; ++qi) acc[qi] = 0.f;
+    for (int f0 = g; f0 < Tk; f0 += 4 * G) {
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[u] = vb[(int64_t)min(f0 + u * G, Tk - 1) * ldkv + d];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + u * G;
+            if (f < Tk) {
+#pragma unroll
+                for (int qi = 0; qi < QMAX; ++qi)
+                    if (qi < Tq) acc[qi] = fmaf(S[qi * Tkp + f], vv[u], acc[qi]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < QMAX; ++qi)
+        if (qi < Tq) red[(g * Tq + qi) * HD + d] = acc[qi];
+    __syncthreads();
+    for (int i = tid; i < Tq * HD; i += 256) {
+        const int qi = i / HD, dd = i - qi * HD;
+        float t = 0.f;
+        for (int gg = 0; gg < G; ++gg) t += red[(gg * Tq + qi) * HD + dd];
+        out[((int64_t)b * Tq + qi) * ldo + h * HD + dd] = t * inv[qi];
+    }
+}
+
+static size_t attn_long_lds(int hd, int Tq, int Tk) {
+    return (size_t)(Tq * hd + Tq * ((Tk + 3) & ~3) + 16 + 256 * Tq) * sizeof(float);
+}
+
+bool mdt_attention_long_supported(int hd, int Tq, int Tk) {
+    return (hd == 16 || hd == 32 || hd == 64) && Tq >= 1 && Tq <= 16 && Tk >= 1 && Tk <= 4096 &&
+           attn_long_lds(hd, Tq, Tk) <= 160 * 1024;
+}
+
+template <int HD>
+static hipError_t launch_attn_long_t(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                     float* out, int64_t ldo, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
+    const size_t lds = attn_long_lds(HD, Tq, Tk);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_long<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_attn_long<HD>), dim3(B, H), dim3(256), lds, s, q, ldq, k, v, ldkv, out, ldo, Tq, Tk, scale);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_attention_long(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                     float* out, int64_t ldo, int B, int H, int hd, int Tq, int Tk, float scale,
+                                     hipStream_t s) {
+    if (!mdt_attention_long_supported(hd, Tq, Tk)) return hipErrorInvalidValue;
+    switch (hd) {
+        case 16: return launch_attn_long_t<16>(q, ldq, k, v, ldkv, out, ldo, B, H, Tq, Tk, scale, s);
+        case 32: return launch_attn_long_t<32>(q, ldq, k, v, ldkv, out, ldo, B, H, Tq, Tk, scale, s);
+        default: return launch_attn_long_t<64>(q, ldq, k, v, ldkv, out, ldo, B, H, Tq, Tk, scale, s);
+    }
+}

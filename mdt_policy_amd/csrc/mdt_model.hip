@@ -22,11 +22,11 @@
 #include "mdt_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// error plumbing
+// error plumbing (shared with mdt_resampler.hip through mdt_internal.h)
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static mdt_status fail(mdt_status st, const char* fmt, ...) {
+mdt_status mdt_fail(mdt_status st, const char* fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
@@ -35,18 +35,7 @@ static mdt_status fail(mdt_status st, const char* fmt, ...) {
     g_err = buf;
     return st;
 }
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t _e = (expr);                                                                         \
-        if (_e != hipSuccess) return fail(MDT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));  \
-    } while (0)
-
-#define MDT_TRY(expr)                      \
-    do {                                   \
-        mdt_status _s = (expr);            \
-        if (_s != MDT_OK) return _s;       \
-    } while (0)
+#define fail mdt_fail
 
 extern "C" const char* mdt_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32)"; }
@@ -54,12 +43,6 @@ extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f
 // ------------------------------------------------------------------------------------------------
 // model description
 // ------------------------------------------------------------------------------------------------
-struct Lin {
-    float* wp = nullptr;    // fragment-packed (N, K)
-    float* bias = nullptr;  // (N) or nullptr
-    int N = 0, K = 0;
-};
-
 enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2 };  // TRANSPOSE: (rows, K) -> (K, rows)
 
 struct Slot {
@@ -81,16 +64,6 @@ struct DecBlock : EncBlock {
     Lin xq, xproj;
     float *xq_raw = nullptr;  // cross_att.query.weight, reference layout (collapsed cross-attention fold)
     float *xo_T = nullptr;    // cross_att.c_proj.weight transposed
-};
-
-struct Bump {
-    float* base = nullptr;
-    size_t off = 0;
-    float* take(size_t n) {
-        float* p = base ? base + off : nullptr;
-        off += (n + 63) & ~(size_t)63;  // 256-byte granules keep every buffer 16-byte aligned
-        return p;
-    }
 };
 
 // how sigma conditions the decoder (reference constructor flags use_ada_conditioning / use_noise_encoder)
@@ -522,22 +495,6 @@ extern "C" mdt_status mdt_reserve(mdt_model* m, int64_t max_batch) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-static mdt_gemm_args gemm_args(const float* A, int64_t lda, const Lin& w, float* out, int64_t ldo, int M) {
-    mdt_gemm_args g;
-    memset(&g, 0, sizeof g);
-    g.A = A; g.lda = lda; g.Wp = w.wp; g.bias = w.bias; g.out = out; g.ldo = ldo;
-    g.M = M; g.N = w.N; g.K = w.K;
-    g.shift_off = -1; g.scale_off = -1; g.gate_off = -1; g.rows_per_sample = 1;
-    g.gin = 1; g.gout = 1; g.goff = 0;
-    return g;
-}
-
-#define LAUNCH(expr)                                                                                  \
-    do {                                                                                              \
-        hipError_t _e = (expr);                                                                       \
-        if (_e != hipSuccess) return fail(MDT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));       \
-    } while (0)
-
 static bool misaligned(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
 // one transformer Block on the encoder tokens / the self-attention + MLP halves of a ConditionedBlock

@@ -1,0 +1,143 @@
+"""Perceiver resampler with the reference's constructor, parameter tree and forward signature; the arithmetic
+runs in libmdt_hip.so (``mdt_resampler_*`` of include/mdt_resampler.h, gfx950 kernels).
+
+Reference: mdt/models/networks/transformers/perceiver_resampler.py (PerceiverAttentionLayer :11-82,
+PerceiverResampler :85-162); built by the agent at mdt/models/mdtv_agent.py:90-97 and called in
+``compute_voltron_embeddings`` (:392-404) on the two cameras' Voltron patch tokens,
+``(B, 1, 2*196, 384) -> (B, 3, 384)`` = the ``state_images`` tokens of the denoiser.
+
+Forward only (``torch.no_grad()``): the backward of this module is part of the training path, SURVEY.md 8(f) 1.
+There is no eager fallback: CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from .... import _lib
+from .utils import feed_forward_layer
+
+
+class PerceiverAttentionLayer(nn.Module):
+    """Parameters of one latent cross-attention layer (reference perceiver_resampler.py:14-30)."""
+
+    def __init__(self, dim: int, dim_head: int = 64, heads: int = 8):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        inner_dim = dim_head * heads
+        self.norm_media = nn.LayerNorm(dim)
+        self.norm_latents = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(dim, inner_dim, bias=False)
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+
+    def forward(self, features, latents):  # pragma: no cover - guard
+        raise RuntimeError("PerceiverAttentionLayer is a parameter container; call the owning PerceiverResampler")
+
+
+class PerceiverResampler(nn.Module):
+    def __init__(self, dim: int, depth: int, dim_head: int = 64, heads: int = 8, num_latents: int = 64,
+                 num_time_embeds: int = 4, ff_mult: int = 4, activation: str = "gelu", trainable: bool = True):
+        super().__init__()
+        self.dim = dim
+        self.num_queries = num_latents
+        self._cfg = dict(dim=dim, depth=depth, dim_head=dim_head, heads=heads, num_latents=num_latents,
+                         num_time_embeds=num_time_embeds, ff_mult=int(ff_mult), activation=0)
+        if int(ff_mult) != ff_mult:
+            raise NotImplementedError("ff_mult must be an integer")
+        self.latents = nn.Parameter(torch.randn(num_latents, dim))
+        self.time_pos_emb = nn.Parameter(torch.randn(num_time_embeds, 1, dim))
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([PerceiverAttentionLayer(dim=dim, dim_head=dim_head, heads=heads),
+                                              feed_forward_layer(dim=dim, mult=ff_mult, activation=activation)]))
+        self.norm = nn.LayerNorm(dim)
+        self._update_trainable_state(trainable)
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_device = None
+        self._uploaded: Dict[str, tuple] = {}
+
+    def _update_trainable_state(self, trainable: bool = True):
+        for param in self.parameters():
+            param.requires_grad = trainable
+
+    # -- library handle --------------------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):  # .to()/.cuda(): parameters are re-created, drop the stale handle
+        out = super()._apply(fn, *a, **kw)
+        self._drop_handle()
+        return out
+
+    def _drop_handle(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().mdt_resampler_destroy(h)
+            except Exception:
+                pass
+        self._handle, self._handle_device, self._uploaded = None, None, {}
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    def _engine(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("the Perceiver resampler runs only on a ROCm GPU (hand-written gfx950 kernels); move "
+                               "the module and its input with .to('cuda') -- there is no CPU execution path")
+        lib = _lib.load()
+        if self._handle is None or self._handle_device != device:
+            self._drop_handle()
+            cfg = _lib.ResamplerConfig(**self._cfg)
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.mdt_resampler_create(C.byref(cfg), C.byref(h)))
+            self._handle, self._handle_device = h, device
+        stream = torch.cuda.current_stream(device).cuda_stream
+        for name, p in self.named_parameters():
+            tag = (p.data_ptr(), p._version)
+            if self._uploaded.get(name) == tag:
+                continue
+            if p.device != device or p.dtype != torch.float32:
+                raise RuntimeError(f"parameter {name} must be float32 on {device}, got {p.dtype} on {p.device}")
+            src = p.detach().contiguous()
+            _lib.check(lib.mdt_resampler_load_param(self._handle, name.encode(), src.data_ptr(), src.numel(), stream))
+            self._uploaded[name] = tag
+        return lib, stream
+
+    # -- reference API -----------------------------------------------------------------------------
+    def forward(self, x_f: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x_f (batch, n_frames, n_features, dim), mask (batch, n_frames) bool -> (batch, num_latents, dim)
+        (reference perceiver_resampler.py:124-162)."""
+        assert x_f.ndim == 4
+        batch_size, max_length, n_features, dim = x_f.shape
+        assert dim == self.dim
+        if torch.is_grad_enabled() and (x_f.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("autograd through the HIP resampler is not implemented yet (SURVEY.md 8(f) "
+                                      "item 1); wrap the call in torch.no_grad()")
+        lib, stream = self._engine(x_f.device)
+        x = x_f.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        if not x.is_contiguous() or x.data_ptr() % 16:
+            x = x.contiguous().clone()
+        m = None
+        if mask is not None:
+            m = mask.to(device=x.device, dtype=torch.bool).reshape(batch_size, max_length).contiguous().view(torch.uint8)
+        out = torch.empty((batch_size, self.num_queries, dim), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mdt_resampler_forward(self._handle, x.data_ptr(), None if m is None else m.data_ptr(),
+                                             batch_size, max_length, n_features, out.data_ptr(), stream))
+        return out
+
+    def flops(self, n_frames: int, n_features: int) -> float:
+        """Algorithmic FLOPs of one forward per sample (needs a live handle, i.e. a previous forward)."""
+        if self._handle is None:
+            raise RuntimeError("call forward() once first")
+        return float(_lib.load().mdt_resampler_flops(self._handle, int(n_frames), int(n_features)))

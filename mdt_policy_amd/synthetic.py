@@ -41,6 +41,8 @@ def param_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, profile: str 
     leaf = name.rsplit(".", 1)[-1]
     if name.endswith("rotary_pos_emb.freqs"):
         raise ValueError("rotary freqs are a deterministic buffer, not synthetic")
+    if leaf in ("latents", "time_pos_emb"):  # Perceiver resampler: torch.randn initialised (perceiver_resampler.py:105-106)
+        return normal(name, shape, seed, std=1.0)
     if len(shape) == 3:  # pos_emb (1, T, d)
         return normal(name, shape, seed, std=0.02 if profile == "init" else 0.1)
     if len(shape) == 2:  # Linear weight (out, in)

@@ -49,6 +49,9 @@ def install_stubs():
     stub("omegaconf", DictConfig=dict, OmegaConf=object)
     stub("torchsde")
     stub("torchdiffeq", odeint=None)
+    # einops_exts.rearrange_many(tensors, pattern, **kw) = map(rearrange) (used by the Perceiver resampler only)
+    import einops
+    stub("einops_exts", rearrange_many=lambda ts, pattern, **kw: tuple(einops.rearrange(t, pattern, **kw) for t in ts))
     sys.path.insert(0, REF)
 
 
@@ -296,6 +299,36 @@ def g8():
         save(f"g8_{name}.npz", meta, **res)
 
 
+G9_PERCEIVER = {
+    # name: (constructor kwargs, (B, T, n), masked)
+    "default": (dict(dim=384, depth=6, dim_head=64, heads=8, num_latents=3, num_time_embeds=1), (2, 1, 392), False),
+    "tiny_masked": (dict(dim=64, depth=2, dim_head=16, heads=4, num_latents=5, num_time_embeds=4), (3, 3, 7), True),
+    "many_latents": (dict(dim=128, depth=1, dim_head=32, heads=2, num_latents=16, num_time_embeds=2, ff_mult=2),
+                     (2, 2, 150), False),
+}
+
+
+def g9():
+    """Perceiver resampler (perceiver_resampler.py) on synthetic media tokens."""
+    from mdt.models.networks.transformers.perceiver_resampler import PerceiverResampler
+
+    for name, (kw, (B, T, n), masked) in G9_PERCEIVER.items():
+        m = PerceiverResampler(**kw).eval()
+        sd = m.state_dict()
+        new = synthetic.fill_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], 91, "rich")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()}, strict=True)
+        x = torch.from_numpy(synthetic.normal("media", (B, T, n, kw["dim"]), 92))
+        mask = None
+        if masked:
+            mask = torch.tensor([[True, True, False], [True, False, True], [True, True, True]])[:B, :T]
+        with torch.no_grad():
+            out = m(x, mask)
+        meta = dict(kwargs=kw, B=B, T=T, n=n, masked=masked, weight_seed=91, input_seed=92, profile="rich",
+                    mask=None if mask is None else mask.int().tolist(),
+                    state_dict=[[k, list(v.shape)] for k, v in sd.items()])
+        save(f"g9_perceiver_{name}.npz", meta, out=out.numpy())
+
+
 def manifest():
     """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
     out = {}
@@ -318,7 +351,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "manifest"]
     for w in which:
         print(w)
         globals()[w]()

@@ -75,3 +75,14 @@ def assert_close(got, want, rtol=RTOL, atol=ATOL, what=""):
     bad = err > tol
     assert not bad.any(), (f"{what}: {bad.sum()}/{bad.size} outside rtol={rtol} atol={atol}; "
                            f"max abs err {err.max():.3e} (|want| max {np.abs(want).max():.3e})")
+
+
+def perceiver_case(name):
+    """(meta, fixture arrays, params, media tokens, mask) of a g9 Perceiver-resampler fixture."""
+    meta, fx = load_fixture(f"g9_perceiver_{name}.npz")
+    shapes = [(k, tuple(s)) for k, s in meta["state_dict"]]
+    P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, meta["weight_seed"], meta["profile"]).items()}
+    x = torch.from_numpy(synthetic.normal("media", (meta["B"], meta["T"], meta["n"], meta["kwargs"]["dim"]),
+                                          meta["input_seed"]))
+    mask = None if meta["mask"] is None else torch.tensor(meta["mask"], dtype=torch.bool)
+    return meta, fx, P, x, mask

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for hdr in ("mdt_hip.h", "mdt_hip_ops.h"):
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
         src = open(os.path.join(ROOT, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(mdt_[a-z_0-9]+)\s*\(", src))
