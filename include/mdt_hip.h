@@ -160,6 +160,13 @@ mdt_status mdt_loss_fwd(mdt_model *m, const float *tokens, const float *tokens2,
  * full score matrices, encoder + cross K/V once, n_steps decoder evaluations). */
 double mdt_flops_per_chunk(const mdt_model *m, int32_t n_steps);
 
+/* Host helper (no GPU work): pyhash.fnv1_32 as the reference's harness uses it to derive deterministic
+ * validation window sizes and environment seeds (mdt/datasets/base_dataset.py:20,37; mdt/evaluation/utils.py:17,305).
+ * FNV-1, 32 bit: for each byte  h = h * 0x01000193; h ^= byte  (pyhash-0.9.3/src/fnv/hash_32.c:91-113), started from
+ * `seed` -- pyhash passes its seed (default 0) as the initial value (src/FNV1.h:36-39, src/Hash.h:113,167), NOT the
+ * standard offset basis 0x811c9dc5.  Chaining: pass the previous result as `seed`. */
+uint32_t mdt_fnv1_32(const void *buf, uint64_t len, uint32_t seed);
+
 #ifdef __cplusplus
 }
 #endif

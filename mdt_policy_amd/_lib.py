@@ -96,6 +96,7 @@ SYMBOLS = [
     ("mdt_sample_ddim", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, C.POINTER(C.c_float), _I32, _I64, _VP, _VP, _VP]),
     ("mdt_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     ("mdt_flops_per_chunk", C.c_double, [_VP, _I32]),
+    ("mdt_fnv1_32", C.c_uint32, [C.c_char_p, C.c_uint64, C.c_uint32]),
     ("mdt_op_packed_numel", _I64, [_I64, _I64]),
     ("mdt_op_pack_weight", _I32, [_VP, _I64, _I64, _VP, _I64, _I64, _VP]),
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),

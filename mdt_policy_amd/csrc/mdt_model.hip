@@ -38,6 +38,16 @@ mdt_status mdt_fail(mdt_status st, const char* fmt, ...) {
 #define fail mdt_fail
 
 extern "C" const char* mdt_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t mdt_fnv1_32(const void* buf, uint64_t len, uint32_t seed) {
+    const unsigned char* p = static_cast<const unsigned char*>(buf);
+    uint32_t h = seed;
+    for (uint64_t i = 0; i < len; ++i) {
+        h *= 0x01000193u;
+        h ^= p[i];
+    }
+    return h;
+}
+
 extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32)"; }
 
 // ------------------------------------------------------------------------------------------------

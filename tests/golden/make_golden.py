@@ -329,6 +329,24 @@ def g9():
         save(f"g9_perceiver_{name}.npz", meta, out=out.numpy())
 
 
+def g10():
+    """String hashes of the harness (pyhash.fnv1_32 call sites) from the REFERENCE's fnv_32_buf, built by
+    oracle/Makefile from pyhash-0.9.3/src/fnv/hash_32.c into oracle/_ref/.  str -> UTF-16 code units, as pyhash's
+    Hash.h:241-268 feeds them."""
+    from oracle import fnv_oracle as FO
+
+    assert FO.reference_available(), "run `make -C oracle` first"
+    strings = [str(i) for i in list(range(0, 40)) + [99, 100, 12345, 987654321]]
+    strings += [str({"led": 0, "lightbulb": 1, "slider": "left", "drawer": "open"}.values()), "", "window", "\u00e9t\u00e9",
+                "\u6f22\u5b57", "a" * 300]
+    vec = [{"s": s, "seed": seed, "h": FO.reference_fnv_32_buf(FO.str_bytes(s), seed)}
+           for s in strings for seed in (0, 1, 0x811C9DC5)]
+    with open(os.path.join(HERE, "g10_fnv.json"), "w") as f:
+        json.dump({"source": "fnv_32_buf of pyhash-0.9.3/src/fnv/hash_32.c (oracle/_ref/libfnv_ref.so), UTF-16 input",
+                   "vectors": vec}, f, indent=0)
+    print(f"  wrote g10_fnv.json: {len(vec)} vectors")
+
+
 def manifest():
     """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
     out = {}
@@ -351,7 +369,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "manifest"]
     for w in which:
         print(w)
         globals()[w]()
