@@ -66,6 +66,35 @@ class HeadArgs(C.Structure):
         ("ba", C.c_void_p)]
 
 
+class LnTrainArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("mod", C.c_void_p), ("mod_stride", C.c_int64),
+                ("shift_off", C.c_int32), ("scale_off", C.c_int32), ("rows_per_sample", C.c_int32),
+                ("out", C.c_void_p), ("stats", C.c_void_p), ("M", C.c_int32), ("D", C.c_int32)]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("stats", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("mod", C.c_void_p),
+                ("mod_stride", C.c_int64), ("shift_off", C.c_int32), ("scale_off", C.c_int32),
+                ("dh", C.c_void_p), ("ld_dh", C.c_int64), ("dx", C.c_void_p), ("accumulate", C.c_int32),
+                ("d_mod", C.c_void_p), ("d_mod_stride", C.c_int64), ("pw", C.c_void_p), ("pb", C.c_void_p),
+                ("B", C.c_int32), ("rows_per_sample", C.c_int32), ("D", C.c_int32)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("ldq", C.c_int64), ("k", C.c_void_p), ("v", C.c_void_p), ("ldkv", C.c_int64),
+                ("d_out", C.c_void_p), ("ld_do", C.c_int64), ("dq", C.c_void_p), ("ld_dq", C.c_int64),
+                ("dk", C.c_void_p), ("dv", C.c_void_p), ("ld_dkv", C.c_int64), ("accumulate_kv", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("hd", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32),
+                ("causal", C.c_int32)]
+
+
+class LinearBwdArgs(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("dY", C.c_void_p), ("ldy", C.c_int64), ("Wt", C.c_void_p),
+                ("dW", C.c_void_p), ("dbias", C.c_void_p), ("dX", C.c_void_p), ("ldxo", C.c_int64),
+                ("accumulate_dw", C.c_int32), ("accumulate_dx", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("scratch", C.c_void_p)]
+
+
 class ResamplerConfig(C.Structure):
     """mirrors mdt_resampler_config (include/mdt_resampler.h)"""
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "dim_head", "heads", "num_latents", "num_time_embeds",
@@ -107,6 +136,24 @@ SYMBOLS = [
     ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_head", _I32, [C.POINTER(HeadArgs), _VP]),
     ("mdt_op_action_embed", _I32, [_VP, _VP, _I64, _F, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _VP]),
+    # include/mdt_hip_train.h
+    ("mdt_train_prepare", _I32, [_VP]),
+    ("mdt_grad_numel", _I64, [_VP]),
+    ("mdt_grad_offset", _I64, [_VP, _I64]),
+    ("mdt_train_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, C.POINTER(_I32), _VP]),
+    ("mdt_train_loss_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("mdt_train_encode_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _I64, _VP, C.POINTER(_I32), _VP]),
+    ("mdt_train_encode_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("mdt_tape_release", _I32, [_VP, _I32]),
+    ("mdt_op_pack_weight_t", _I32, [_VP, _I64, _I64, _I64, _VP, _I64, _I64, _VP]),
+    ("mdt_op_ln_fwd_train", _I32, [C.POINTER(LnTrainArgs), _VP]),
+    ("mdt_op_ln_bwd", _I32, [C.POINTER(LnBwdArgs), _VP]),
+    ("mdt_op_attn_bwd", _I32, [C.POINTER(AttnBwdArgs), _VP]),
+    ("mdt_op_act_fwd", _I32, [_VP, _VP, _I64, _I32, _VP]),
+    ("mdt_op_act_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP]),
+    ("mdt_op_gate_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP, _VP, _I64, _I32, _I32, _VP]),
+    ("mdt_op_colsum", _I32, [_VP, _I64, _I64, _I64, _VP, _I32, _VP]),
+    ("mdt_op_linear_bwd", _I32, [C.POINTER(LinearBwdArgs), _VP]),
     # include/mdt_resampler.h
     ("mdt_resampler_create", _I32, [C.POINTER(ResamplerConfig), C.POINTER(_VP)]),
     ("mdt_resampler_destroy", _I32, [_VP]),

@@ -8,6 +8,7 @@
 #include "mdt_hip.h"
 #include "mdt_hip_ops.h"
 #include "mdt_resampler.h"
+#include "mdt_hip_train.h"
 
 // ---- error plumbing: the message behind mdt_last_error() (thread local, defined in mdt_model.hip) ----
 mdt_status mdt_fail(mdt_status st, const char* fmt, ...);
@@ -35,6 +36,7 @@ struct Lin {
     float* wp = nullptr;    // fragment-packed (N, K)
     float* bias = nullptr;  // (N) or nullptr
     int N = 0, K = 0;
+    float* wt = nullptr;    // training only: fragment-packed image of W^T (N' = K, K' = N), for dX = dY W
 };
 
 // bump allocator over one hipMalloc'ed block (count pass with base == nullptr, then the real pass)
@@ -88,3 +90,30 @@ hipError_t mdt_launch_attention_long(const float* q, int64_t ldq, const float* k
                                      float* out, int64_t ldo, int B, int H, int hd, int Tq, int Tk, float scale,
                                      hipStream_t s);
 bool mdt_attention_long_supported(int hd, int Tq, int Tk);
+// ---- training-path kernels (mdt_train_kernels.hip) ----
+hipError_t mdt_launch_pack_weight_t(const float* src, int rows, int cols, int64_t ld, float* packed, int k_off, int K16,
+                                    hipStream_t s);
+hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, hipStream_t s);
+hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);
+hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s);
+hipError_t mdt_launch_act_fwd(const float* u, float* out, int64_t n, int act, hipStream_t s);
+hipError_t mdt_launch_act_bwd(const float* u, const float* dy, float* du, int64_t n, int act, hipStream_t s);
+hipError_t mdt_launch_gate_residual(const float* x, const float* av, const float* gate, int64_t gstride, int rps, float* out,
+                                    int M, int D, hipStream_t s);
+hipError_t mdt_launch_gate_bwd(const float* dx, const float* av, const float* gate, int64_t gstride, int rps, float* da,
+                               float* dgate, int64_t dgstride, int B, int D, hipStream_t s);
+hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s);
+hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s);
+hipError_t mdt_launch_loss_grad(const float* F, const float* act, const float* noised, const float* sigma, float sd,
+                                int64_t n, int per_sample, const float* gscale, float* dF, hipStream_t s);
+hipError_t mdt_launch_narrow_dx(const float* G, const float* W, float* out, int M, int A, int D, hipStream_t s);
+hipError_t mdt_launch_narrow_dw(const float* G, const float* Y, int64_t ldy, float* partial, int n_slices, int M, int A,
+                                int D, int transposed, hipStream_t s);
+hipError_t mdt_launch_scaled_input(const float* x, const float* sigma, float sd, int64_t n, int per_sample, float* out,
+                                   hipStream_t s);
+hipError_t mdt_launch_gather_rows(const float* src, float* dst, int M, int D, int gin, int gout, int goff, hipStream_t s);
+hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream_t s);
+// backward of a Linear through the forward GEMM kernel (mdt_train.hip); see mdt_linear_bwd_args
+mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s);
+struct mdt_model;
+void mdt_train_free(mdt_model* m);  // releases what mdt_train_prepare() and the tapes allocated (mdt_train.hip)

@@ -22,49 +22,7 @@
 
 #include "mdt_internal.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define WAVE 64
-
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
-}
-
-// exact-erf GELU (nn.GELU default).  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding
-// level): one rcp, one exp and a degree-5 Horner chain instead of libm erff's ~40 instructions -- the c_fc
-// epilogue applies it to 32 values per lane and was a quarter of that kernel's time with erff.
-__device__ __forceinline__ float act_gelu(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float q = p * t * __expf(-z * z);          // erfc(z), z >= 0
-    const float cdf = x >= 0.f ? 1.0f - 0.5f * q : 0.5f * q;  // Phi(x) without cancellation on the negative side
-    return x * cdf;
-}
-__device__ __forceinline__ float act_mish(float x) {
-    float sp = x > 20.0f ? x : log1pf(expf(x));  // torch softplus threshold 20
-    return x * tanhf(sp);
-}
-__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + expf(-x)); }
-
-__device__ __forceinline__ f32x4 apply_act(f32x4 v, int act) {
-    if (act == MDT_ACT_GELU) {
-        v.x = act_gelu(v.x); v.y = act_gelu(v.y); v.z = act_gelu(v.z); v.w = act_gelu(v.w);
-    } else if (act == MDT_ACT_MISH) {
-        v.x = act_mish(v.x); v.y = act_mish(v.y); v.z = act_mish(v.z); v.w = act_mish(v.w);
-    } else if (act == MDT_ACT_SILU) {
-        v.x = act_silu(v.x); v.y = act_silu(v.y); v.z = act_silu(v.z); v.w = act_silu(v.w);
-    }
-    return v;
-}
+#include "mdt_device.h"
 
 // XCD-aware block id: the dispatcher places block b on XCD b % 8 (speed-only assumption); give every XCD a
 // contiguous range of logical tiles so the row tiles it touches stay in its private L2.  Bijective for any n.

@@ -50,73 +50,7 @@ extern "C" uint32_t mdt_fnv1_32(const void* buf, uint64_t len, uint32_t seed) {
 
 extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32)"; }
 
-// ------------------------------------------------------------------------------------------------
-// model description
-// ------------------------------------------------------------------------------------------------
-enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2 };  // TRANSPOSE: (rows, K) -> (K, rows)
-
-struct Slot {
-    std::string name;
-    int64_t numel = 0;
-    int kind = SLOT_RAW;
-    float* dst = nullptr;  // packed image base (SLOT_PACK) or raw destination (SLOT_RAW)
-    int rows = 0, K = 0, n_off = 0;
-    bool loaded = false;
-};
-
-struct EncBlock {
-    float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
-    Lin qkv, proj, fc, proj2;
-};
-
-struct DecBlock : EncBlock {
-    float *ln3_w = nullptr, *ln3_b = nullptr;
-    Lin xq, xproj;
-    float *xq_raw = nullptr;  // cross_att.query.weight, reference layout (collapsed cross-attention fold)
-    float *xo_T = nullptr;    // cross_att.c_proj.weight transposed
-};
-
-// how sigma conditions the decoder (reference constructor flags use_ada_conditioning / use_noise_encoder)
-enum CondMode {
-    COND_ADALN = 0,  // ConditionedBlock + AdaLNZero           (transformer_blocks.py:264-309) -- the shipped configs
-    COND_NOISE = 1,  // NoiseBlock: ln(x) + c before both attentions (transformer_blocks.py:312-341)
-    COND_TOKEN = 2,  // plain Block decoder; sigma embedding is the FIRST encoder token (mdtv_transformer.py:296-297)
-};
-
-struct mdt_model {
-    mdt_config cfg;
-    int D, H, hd, Te, Ta, A, Le, Ld, G, O, n_tok;
-    int cond = COND_ADALN;
-    int sig_tok = 0;  // 1 when the context starts with the sigma token (COND_TOKEN): Te = sig_tok + 1 + n_tok
-    // parameters
-    float* arena = nullptr;
-    size_t arena_floats = 0;
-    std::vector<Slot> slots;   // one per parameter the path reads (enumerated by mdt_param_*)
-    std::vector<Slot> extra;   // additional images of an already listed parameter (same name)
-    Lin tok, incam, goal0, goal2, lang0, lang2, sig1, sig3, kv_all, mod_all;
-    std::vector<EncBlock> enc;
-    std::vector<DecBlock> dec;
-    float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
-    float *Wa = nullptr, *ba = nullptr, *Wp = nullptr, *bp = nullptr, *pos_emb = nullptr;
-    float *freqs = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;  // constant tables
-    float* staging = nullptr;  // host->device parameter staging
-    size_t staging_floats = 0;
-    // workspace
-    float* ws = nullptr;
-    int64_t cap = 0;
-    float *h_enc, *qkv, *att, *hid, *ctx, *kvx, *y, *qx, *sig_e, *sig_t, *sig_c, *mod, *xbuf, *noised, *Fbuf, *steps;
-    float* cmod = nullptr;  // COND_NOISE: rows of [c | ones(D)], read as (shift, scale) by the LayerNorm prologue
-    int64_t cached_batch = 0;  // batch of the context currently cached by mdt_encode (0 = none)
-    std::vector<float> steps_host;
-    // sampler pipelining: the batch is cut into `ways` sample-aligned slices whose launch chains run on separate
-    // HIP streams, so one slice's prologue / epilogue / launch gaps overlap another slice's MFMA main loops
-    int ways = 1;
-    // collapsed cross-attention (k_xattn_fold / k_xattn_apply): folded projections per sample and decoder block
-    bool xfold = false;
-    float *xU = nullptr, *xW = nullptr, *xc = nullptr;  // [Ld][cap][H*Te][D], same, [Ld][cap][H*Te]
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-};
+#include "mdt_model_types.h"
 
 static const int MAX_WAYS = 4;
 
@@ -166,6 +100,12 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
     };
     auto lin_part = [&](Lin& l, const std::string& prefix, int rows, int n_off, bool bias) {
         add_slot(prefix + ".weight", (int64_t)rows * l.K, SLOT_PACK, l.wp, rows, l.K, n_off);
+        if (fill_slots) {
+            m->slots.back().lin = &l;
+            LinPart p;
+            p.lin = &l; p.w_slot = (int)m->slots.size() - 1; p.b_slot = bias ? p.w_slot + 1 : -1; p.rows = rows; p.n_off = n_off;
+            m->parts.push_back(p);
+        }
         if (bias) add_slot(prefix + ".bias", rows, SLOT_RAW, l.bias ? l.bias + n_off : nullptr, 0, 0, 0);
     };
     auto raw = [&](float*& p, const std::string& name, int64_t n) {
@@ -382,6 +322,7 @@ extern "C" mdt_status mdt_destroy(mdt_model* m) {
         if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    mdt_train_free(m);
     (void)hipFree(m->arena);
     (void)hipFree(m->staging);
     (void)hipFree(m->ws);
@@ -436,6 +377,8 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
         }
         if (t->kind == SLOT_TRANSPOSE) HIP_TRY(mdt_launch_transpose(dev_src, t->dst, t->rows, t->K, s));
         else HIP_TRY(mdt_launch_pack_weight(dev_src, t->rows, t->K, t->dst, t->n_off, s));
+        if (t->kind == SLOT_PACK && t->lin && t->lin->wt)  // training: image of W^T for dX = dY W
+            HIP_TRY(mdt_launch_pack_weight_t(dev_src, t->rows, t->K, t->K, t->lin->wt, t->n_off, t->lin->N / 16, s));
     }
     slot->loaded = true;
     return MDT_OK;

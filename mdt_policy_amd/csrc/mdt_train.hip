@@ -1,0 +1,638 @@
+// mdt_train.hip -- TRAINING path of the denoiser handle (include/mdt_hip_train.h, "model level"): the forward of
+// GCDenoiser.loss with every activation its backward needs kept on a tape, and the backward that turns a tape into
+// the gradient of every parameter (reference state_dict layout) and of the encoder inputs.
+//
+// Reference: torch.autograd through score_wrappers.py:45-63 (loss), mdtv_transformer.py:208-236 /
+// mdt_transformer.py:207-242 (encoder + decoder), transformer_blocks.py:209-214 (Block), :291-309
+// (ConditionedBlock); driven by MDTVAgent.training_step -> diffusion_loss (mdtv_agent.py:222-262,:508-521).
+//
+// Structure: the forward runs the SAME kernels as inference, un-fused where the backward needs the intermediate
+// (LayerNorm output, pre-GELU, the un-gated branch outputs); every dense contraction of the backward runs on the
+// forward's fp32-MFMA GEMM (mdt_linear_bwd, mdt_train_ops.hip).  Eval-mode arithmetic: dropout probabilities are
+// not part of this ABI yet (the facade refuses train-mode dropout > 0).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "mdt_model_types.h"
+
+#define fail mdt_fail
+
+namespace {
+
+struct BlockTape {  // one transformer block; rows M = B*T
+    float *x_in, *st1, *h1, *qkv, *att, *a1, *x1;          // self-attention half (a1: decoder only, un-gated branch)
+    float *st3, *h3, *q, *att2, *x2;                        // cross-attention half (decoder only)
+    float *st2, *h2, *u, *hid, *mo, *x3;                    // MLP half (mo: decoder only)
+};
+
+struct Tape {
+    bool in_use = false;
+    bool has_decoder = false;
+    int64_t B = 0, cap = 0;
+    int lang = 0;  // 1: the goal went through lang_emb
+    float* buf = nullptr;
+    // inputs
+    float *tokens, *tokens2, *goal, *action, *noised, *sigma;
+    // encoder
+    float *g_pre, *g_h;
+    std::vector<BlockTape> enc;
+    float *x_enc_out, *st_f, *ctx, *kvx;
+    // sigma path
+    float *sig_e, *sig_tpre, *sig_t, *sig_cpre, *sig_s, *mod;
+    // decoder
+    float *xin, *y0;
+    std::vector<BlockTape> dec;
+    float *st_h, *lnout, *F;
+};
+
+}  // namespace
+
+struct mdt_train_state {
+    float* wt_arena = nullptr;
+    std::vector<Tape> tapes;
+    std::vector<int64_t> grad_off;  // per slot
+    int64_t grad_numel = 0;
+    // backward scratch (one backward at a time per handle)
+    float* scratch = nullptr;
+    int64_t scratch_cap = 0;  // batch capacity
+    float *dx, *dxe, *t_d, *t_d2, *t_3d, *t_4d, *d_mod, *d_kvx, *pw, *pb, *narrow, *lin_scratch, *dF, *small;
+};
+
+static const int NARROW_SLICES = 32;
+
+// ------------------------------------------------------------------------------------------------
+// setup
+// ------------------------------------------------------------------------------------------------
+extern "C" mdt_status mdt_train_prepare(mdt_model* m) {
+    if (!m) return fail(MDT_ERR_INVALID_ARG, "mdt_train_prepare: null handle");
+    if (m->train) return MDT_OK;
+    if (m->cond != COND_ADALN)
+        return fail(MDT_ERR_UNSUPPORTED, "training: only the adaLN decoder (use_ada_conditioning=True, "
+                                         "use_noise_encoder=False) is implemented");
+    if (m->cfg.use_rot_embed) return fail(MDT_ERR_UNSUPPORTED, "training: use_rot_embed=True is not implemented");
+    mdt_train_state* t = new mdt_train_state();
+    std::vector<Lin*> lins;
+    for (const LinPart& p : m->parts)
+        if (std::find(lins.begin(), lins.end(), p.lin) == lins.end()) lins.push_back(p.lin);
+    Bump count;
+    for (Lin* l : lins) count.take((size_t)l->N * l->K);
+    hipError_t e = hipMalloc((void**)&t->wt_arena, count.off * sizeof(float));
+    if (e != hipSuccess) { delete t; return fail(MDT_ERR_HIP, "hipMalloc(transposed weights) failed: %s", hipGetErrorString(e)); }
+    (void)hipMemset(t->wt_arena, 0, count.off * sizeof(float));
+    Bump real;
+    real.base = t->wt_arena;
+    for (Lin* l : lins) l->wt = real.take((size_t)l->N * l->K);
+    int64_t off = 0;
+    for (const Slot& s : m->slots) { t->grad_off.push_back(off); off += s.numel; }
+    t->grad_numel = off;
+    for (Slot& s : m->slots) s.loaded = false;  // every weight needs its transposed image: upload again
+    m->cached_batch = 0;
+    m->train = t;
+    return MDT_OK;
+}
+
+void mdt_train_free(mdt_model* m) {
+    if (!m || !m->train) return;
+    mdt_train_state* t = m->train;
+    for (Tape& tp : t->tapes) (void)hipFree(tp.buf);
+    (void)hipFree(t->scratch);
+    (void)hipFree(t->wt_arena);
+    for (const LinPart& p : m->parts) p.lin->wt = nullptr;
+    delete t;
+    m->train = nullptr;
+}
+
+extern "C" int64_t mdt_grad_numel(const mdt_model* m) {
+    if (!m) return 0;
+    if (m->train) return m->train->grad_numel;
+    int64_t n = 0;
+    for (const Slot& s : m->slots) n += s.numel;
+    return n;
+}
+
+extern "C" int64_t mdt_grad_offset(const mdt_model* m, int64_t i) {
+    if (!m || i < 0 || i >= (int64_t)m->slots.size()) return -1;
+    int64_t off = 0;
+    for (int64_t k = 0; k < i; ++k) off += m->slots[k].numel;
+    return off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tapes
+// ------------------------------------------------------------------------------------------------
+static void carve_block(const mdt_model* m, Bump& b, BlockTape& t, int64_t M, bool dec) {
+    const int D = m->D;
+    t.x_in = b.take(M * D); t.st1 = b.take(M * 2); t.h1 = b.take(M * D); t.qkv = b.take(M * 3 * D); t.att = b.take(M * D);
+    t.a1 = dec ? b.take(M * D) : nullptr;
+    t.x1 = b.take(M * D);
+    if (dec) {
+        t.st3 = b.take(M * 2); t.h3 = b.take(M * D); t.q = b.take(M * D); t.att2 = b.take(M * D); t.x2 = b.take(M * D);
+    } else {
+        t.st3 = t.h3 = t.q = t.att2 = nullptr;
+        t.x2 = t.x1;
+    }
+    t.st2 = b.take(M * 2); t.h2 = b.take(M * D); t.u = b.take(M * 4 * D); t.hid = b.take(M * 4 * D);
+    t.mo = dec ? b.take(M * D) : nullptr;
+    t.x3 = b.take(M * D);
+}
+
+static void carve_tape(const mdt_model* m, Bump& b, Tape& t, int64_t B) {
+    const int D = m->D;
+    const int64_t Me = B * m->Te, Ma = B * m->Ta;
+    t.tokens = b.take(B * (m->cfg.arch == MDT_ARCH_MDTV ? m->n_tok : 1) * m->O);
+    t.tokens2 = b.take(m->cfg.arch == MDT_ARCH_MDT ? B * m->O : 0);
+    t.goal = b.take(B * m->G);
+    t.action = b.take(Ma * m->A); t.noised = b.take(Ma * m->A); t.sigma = b.take(B);
+    t.g_pre = b.take(B * 2 * D); t.g_h = b.take(B * 2 * D);
+    t.enc.resize(m->Le);
+    for (int l = 0; l < m->Le; ++l) carve_block(m, b, t.enc[l], Me, false);
+    t.x_enc_out = b.take(Me * D);  // input of the first block / output chain starts here when Le == 0
+    t.st_f = b.take(Me * 2); t.ctx = b.take(Me * D); t.kvx = b.take(Me * m->Ld * 2 * D);
+    t.sig_e = b.take(B * D); t.sig_tpre = b.take(B * 2 * D); t.sig_t = b.take(B * 2 * D); t.sig_cpre = b.take(B * D);
+    t.sig_s = b.take(B * D); t.mod = b.take(B * m->Ld * 6 * D);
+    t.xin = b.take(Ma * m->A); t.y0 = b.take(Ma * D);
+    t.dec.resize(m->Ld);
+    for (int l = 0; l < m->Ld; ++l) carve_block(m, b, t.dec[l], Ma, true);
+    t.st_h = b.take(Ma * 2); t.lnout = b.take(Ma * D); t.F = b.take(Ma * m->A);
+}
+
+static mdt_status acquire_tape(mdt_model* m, int64_t B, mdt_tape_id* id) {
+    mdt_train_state* ts = m->train;
+    int pick = -1;
+    for (size_t i = 0; i < ts->tapes.size(); ++i)
+        if (!ts->tapes[i].in_use && ts->tapes[i].cap >= B) { pick = (int)i; break; }
+    if (pick < 0)
+        for (size_t i = 0; i < ts->tapes.size(); ++i)
+            if (!ts->tapes[i].in_use) { pick = (int)i; break; }
+    if (pick < 0) {
+        if (ts->tapes.size() >= 16) return fail(MDT_ERR_STATE, "more than 16 tapes alive: release tapes after their backward");
+        ts->tapes.emplace_back();
+        pick = (int)ts->tapes.size() - 1;
+    }
+    Tape& t = ts->tapes[pick];
+    if (t.cap < B) {
+        if (t.buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(t.buf)); t.buf = nullptr; t.cap = 0; }
+        Bump count;
+        carve_tape(m, count, t, B);
+        HIP_TRY(hipMalloc((void**)&t.buf, count.off * sizeof(float)));
+        t.cap = B;
+    }
+    Bump real;
+    real.base = t.buf;
+    carve_tape(m, real, t, t.cap);
+    t.in_use = true;
+    t.B = B;
+    t.has_decoder = false;
+    *id = pick;
+    return MDT_OK;
+}
+
+static mdt_status get_tape(mdt_model* m, mdt_tape_id id, Tape** out) {
+    if (!m || !m->train) return fail(MDT_ERR_STATE, "training was not prepared (mdt_train_prepare)");
+    if (id < 0 || id >= (int)m->train->tapes.size() || !m->train->tapes[id].in_use)
+        return fail(MDT_ERR_INVALID_ARG, "invalid or released tape %d", id);
+    *out = &m->train->tapes[id];
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_tape_release(mdt_model* m, mdt_tape_id id) {
+    Tape* t;
+    MDT_TRY(get_tape(m, id, &t));
+    t->in_use = false;
+    return MDT_OK;
+}
+
+static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int64_t B) {
+    const int D = m->D;
+    const int64_t Me = B * m->Te, Ma = B * m->Ta, Mx = std::max(Me, Ma), Mp = (Mx + 15) & ~(int64_t)15;
+    const int64_t Bp = (B + 15) & ~(int64_t)15;
+    ts->dx = b.take(Ma * D); ts->dxe = b.take(Me * D);
+    ts->t_d = b.take(Mx * D); ts->t_d2 = b.take(Mx * D); ts->t_3d = b.take(Mx * 3 * D); ts->t_4d = b.take(Mx * 4 * D);
+    ts->d_mod = b.take(B * m->Ld * 6 * D); ts->d_kvx = b.take(Me * m->Ld * 2 * D);
+    ts->pw = b.take(B * D); ts->pb = b.take(B * D);
+    ts->narrow = b.take((size_t)NARROW_SLICES * 16 * D);
+    // Linear backward scratch: (N + K) * Mp for the widest layers on Mx rows, and for the per-sample layers on B rows
+    const int64_t widest = std::max<int64_t>((int64_t)5 * D * Mp,
+                                             std::max<int64_t>(((int64_t)m->Ld * 6 * D + D) * Bp,
+                                                               std::max<int64_t>(((int64_t)m->Ld * 2 * D + D) * ((Me + 15) & ~15),
+                                                                                 (int64_t)(2 * D + std::max(m->G, m->O) + D) * Mp)));
+    ts->lin_scratch = b.take(widest);
+    ts->dF = b.take(Ma * m->A);
+    ts->small = b.take(std::max<int64_t>(B * 2 * D, Mx * (int64_t)std::max(m->O, m->G)));
+}
+
+static mdt_status reserve_scratch(mdt_model* m, int64_t B) {
+    mdt_train_state* ts = m->train;
+    if (B > ts->scratch_cap) {
+        if (ts->scratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ts->scratch)); ts->scratch = nullptr; }
+        Bump count;
+        carve_scratch(m, count, ts, B);
+        HIP_TRY(hipMalloc((void**)&ts->scratch, count.off * sizeof(float)));
+        ts->scratch_cap = B;
+    }
+    Bump real;
+    real.base = ts->scratch;
+    carve_scratch(m, real, ts, ts->scratch_cap);
+    return MDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+static mdt_ln_train_args ln_args(const float* x, const float* w, const float* b, float* out, float* stats, int M, int D) {
+    mdt_ln_train_args a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.w = w; a.b = b; a.out = out; a.stats = stats; a.M = M; a.D = D; a.rows_per_sample = 1;
+    a.shift_off = a.scale_off = -1;
+    return a;
+}
+
+// one block forward; mod == nullptr: plain Block (encoder), else ConditionedBlock rows of `mod` (stride modw)
+static mdt_status block_fwd(mdt_model* m, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T, bool causal,
+                            const float* mod, int64_t modw, const float* kv, hipStream_t s) {
+    const int D = m->D, M = (int)(B * T);
+    mdt_ln_train_args l1 = ln_args(t.x_in, e.ln1_w, e.ln1_b, t.h1, t.st1, M, D);
+    if (mod) { l1.mod = mod; l1.mod_stride = modw; l1.shift_off = 0; l1.scale_off = D; l1.rows_per_sample = T; }
+    LAUNCH(mdt_launch_ln_fwd_train(l1, s));
+    LAUNCH(mdt_launch_gemm(gemm_args(t.h1, D, e.qkv, t.qkv, 3 * D, M), s));
+    mdt_attn_args a;
+    memset(&a, 0, sizeof a);
+    a.q = t.qkv; a.ldq = 3 * D; a.k = t.qkv + D; a.v = t.qkv + 2 * D; a.ldkv = 3 * D;
+    a.out = t.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T; a.causal = causal;
+    LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
+    if (d) {
+        LAUNCH(mdt_launch_gemm(gemm_args(t.att, D, e.proj, t.a1, D, M), s));
+        LAUNCH(mdt_launch_gate_residual(t.x_in, t.a1, mod + 2 * D, modw, T, t.x1, M, D, s));
+        mdt_ln_train_args l3 = ln_args(t.x1, d->ln3_w, d->ln3_b, t.h3, t.st3, M, D);
+        LAUNCH(mdt_launch_ln_fwd_train(l3, s));
+        LAUNCH(mdt_launch_gemm(gemm_args(t.h3, D, d->xq, t.q, D, M), s));
+        mdt_attn_args x;
+        memset(&x, 0, sizeof x);
+        x.q = t.q; x.ldq = D; x.k = kv; x.v = kv + D; x.ldkv = (int64_t)m->Ld * 2 * D;
+        x.out = t.att2; x.ldo = D; x.B = (int)B; x.H = m->H; x.hd = m->hd; x.Tq = T; x.Tk = m->Te; x.causal = 1;
+        LAUNCH(mdt_launch_attention(x, m->rope_cos, m->rope_sin, s));
+        HIP_TRY(hipMemcpyAsync(t.x2, t.x1, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        mdt_gemm_args p = gemm_args(t.att2, D, d->xproj, t.x2, D, M);
+        p.residual = 1;
+        LAUNCH(mdt_launch_gemm(p, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(t.x1, t.x_in, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        mdt_gemm_args p = gemm_args(t.att, D, e.proj, t.x1, D, M);
+        p.residual = 1;
+        LAUNCH(mdt_launch_gemm(p, s));
+    }
+    mdt_ln_train_args l2 = ln_args(t.x2, e.ln2_w, e.ln2_b, t.h2, t.st2, M, D);
+    if (mod) { l2.mod = mod; l2.mod_stride = modw; l2.shift_off = 3 * D; l2.scale_off = 4 * D; l2.rows_per_sample = T; }
+    LAUNCH(mdt_launch_ln_fwd_train(l2, s));
+    LAUNCH(mdt_launch_gemm(gemm_args(t.h2, D, e.fc, t.u, 4 * D, M), s));
+    LAUNCH(mdt_launch_act_fwd(t.u, t.hid, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
+    if (d) {
+        LAUNCH(mdt_launch_gemm(gemm_args(t.hid, 4 * D, e.proj2, t.mo, D, M), s));
+        LAUNCH(mdt_launch_gate_residual(t.x2, t.mo, mod + 5 * D, modw, T, t.x3, M, D, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(t.x3, t.x2, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        mdt_gemm_args p = gemm_args(t.hid, 4 * D, e.proj2, t.x3, D, M);
+        p.residual = 1;
+        LAUNCH(mdt_launch_gemm(p, s));
+    }
+    return MDT_OK;
+}
+
+static float* enc_first_input(const mdt_model* m, Tape& t) { return m->Le > 0 ? t.enc[0].x_in : t.x_enc_out; }
+static float* enc_last_output(const mdt_model* m, Tape& t) { return m->Le > 0 ? t.enc[m->Le - 1].x3 : t.x_enc_out; }
+
+static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const float* tokens2, const float* goal, int modality,
+                          int honour, float* ctx_out, hipStream_t s) {
+    const mdt_config& c = m->cfg;
+    const int D = m->D, Te = m->Te;
+    const int64_t B = t.B;
+    const int ntok_rows = c.arch == MDT_ARCH_MDTV ? m->n_tok : 1;
+    HIP_TRY(hipMemcpyAsync(t.tokens, tokens, (size_t)B * ntok_rows * m->O * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (c.arch == MDT_ARCH_MDT)
+        HIP_TRY(hipMemcpyAsync(t.tokens2, tokens2, (size_t)B * m->O * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t.goal, goal, (size_t)B * m->G * sizeof(float), hipMemcpyDeviceToDevice, s));
+    t.lang = honour && c.use_modality_encoder && modality == MDT_MODALITY_LANG;
+    const Lin& g0 = t.lang ? m->lang0 : m->goal0;
+    const Lin& g2 = t.lang ? m->lang2 : m->goal2;
+    const float* pos0 = (c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb) ? m->pos_emb : nullptr;
+    const float* pos1 = pos0 ? m->pos_emb + (int64_t)c.goal_seq_len * D : nullptr;
+    float* x0 = enc_first_input(m, t);
+    {
+        const float* gin = t.goal;
+        int64_t ld = m->G;
+        if (c.use_mlp_goal) {
+            LAUNCH(mdt_launch_gemm(gemm_args(t.goal, m->G, g0, t.g_pre, 2 * D, (int)B), s));
+            LAUNCH(mdt_launch_act_fwd(t.g_pre, t.g_h, B * 2 * D, MDT_ACT_GELU, s));
+            gin = t.g_h; ld = 2 * D;
+        }
+        mdt_gemm_args a = gemm_args(gin, ld, g2, x0, D, (int)B);
+        a.gin = 1; a.gout = Te; a.goff = 0; a.rowvec = pos0;
+        LAUNCH(mdt_launch_gemm(a, s));
+    }
+    if (c.arch == MDT_ARCH_MDTV) {
+        mdt_gemm_args a = gemm_args(t.tokens, m->O, m->tok, x0, D, (int)(B * m->n_tok));
+        a.gin = m->n_tok; a.gout = Te; a.goff = 1;
+        LAUNCH(mdt_launch_gemm(a, s));
+    } else {
+        mdt_gemm_args a = gemm_args(t.tokens, m->O, m->tok, x0, D, (int)B);
+        a.gin = 1; a.gout = Te; a.goff = 1; a.rowvec = pos1;
+        LAUNCH(mdt_launch_gemm(a, s));
+        mdt_gemm_args b2 = gemm_args(t.tokens2, m->O, m->incam, x0, D, (int)B);
+        b2.gin = 1; b2.gout = Te; b2.goff = 2; b2.rowvec = pos1;
+        LAUNCH(mdt_launch_gemm(b2, s));
+    }
+    for (int l = 0; l < m->Le; ++l) {
+        if (l > 0) t.enc[l].x_in = t.enc[l - 1].x3;  // chain: a block's input is its predecessor's output buffer
+        MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, 0, nullptr, s));
+    }
+    mdt_ln_train_args lf = ln_args(enc_last_output(m, t), m->enc_ln_w, m->enc_ln_b, t.ctx, t.st_f, (int)(B * Te), D);
+    LAUNCH(mdt_launch_ln_fwd_train(lf, s));
+    if (ctx_out) HIP_TRY(hipMemcpyAsync(ctx_out, t.ctx, (size_t)B * Te * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return MDT_OK;
+}
+
+static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const float* noise, const float* sigma, float* loss_out,
+                          float* model_output, hipStream_t s) {
+    const int D = m->D, Ta = m->Ta, A = m->A;
+    const int64_t B = t.B, Ma = B * Ta;
+    const int64_t modw = (int64_t)m->Ld * 6 * D;
+    HIP_TRY(hipMemcpyAsync(t.action, action, (size_t)Ma * A * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t.sigma, sigma, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // cross-attention K|V of all decoder blocks
+    LAUNCH(mdt_launch_gemm(gemm_args(t.ctx, D, m->kv_all, t.kvx, (int64_t)m->Ld * 2 * D, (int)(B * m->Te)), s));
+    // sigma embedding -> adaLN modulation rows
+    LAUNCH(mdt_launch_sigma_emb(t.sigma, 1, m->freqs, t.sig_e, (int)B, D, s));
+    LAUNCH(mdt_launch_gemm(gemm_args(t.sig_e, D, m->sig1, t.sig_tpre, 2 * D, (int)B), s));
+    LAUNCH(mdt_launch_act_fwd(t.sig_tpre, t.sig_t, B * 2 * D, MDT_ACT_MISH, s));
+    LAUNCH(mdt_launch_gemm(gemm_args(t.sig_t, 2 * D, m->sig3, t.sig_cpre, D, (int)B), s));
+    LAUNCH(mdt_launch_act_fwd(t.sig_cpre, t.sig_s, B * D, MDT_ACT_SILU, s));
+    LAUNCH(mdt_launch_gemm(gemm_args(t.sig_s, D, m->mod_all, t.mod, modw, (int)B), s));
+    // noised actions, preconditioned input, action embedding
+    const int per = Ta * A;
+    LAUNCH(mdt_launch_noise_input(t.action, noise, t.sigma, t.noised, Ma * A, per, s));
+    LAUNCH(mdt_launch_scaled_input(t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, t.xin, s));
+    LAUNCH(mdt_launch_action_embed(t.xin, nullptr, 0, m->cfg.sigma_data, m->Wa, m->ba, t.y0, (int)Ma, A, D, Ta, s));
+    for (int l = 0; l < m->Ld; ++l) {
+        t.dec[l].x_in = l == 0 ? t.y0 : t.dec[l - 1].x3;
+        MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, t.mod + (int64_t)l * 6 * D, modw,
+                          t.kvx + (int64_t)l * 2 * D, s));
+    }
+    float* xl = t.dec[m->Ld - 1].x3;
+    mdt_ln_train_args lh = ln_args(xl, m->dec_ln_w, m->dec_ln_b, t.lnout, t.st_h, (int)Ma, D);
+    LAUNCH(mdt_launch_ln_fwd_train(lh, s));
+    mdt_head_args h;
+    memset(&h, 0, sizeof h);
+    h.y = xl; h.ln_w = m->dec_ln_w; h.ln_b = m->dec_ln_b; h.Wp = m->Wp; h.bp = m->bp;
+    h.x = t.noised; h.sigma = t.sigma; h.sigma_stride = 1; h.out = t.F;
+    h.M = (int)Ma; h.D = D; h.A = A; h.rows_per_sample = Ta; h.mode = MDT_HEAD_RAW; h.sigma_data = m->cfg.sigma_data;
+    LAUNCH(mdt_launch_head(h, s));
+    if (model_output) HIP_TRY(hipMemcpyAsync(model_output, t.F, (size_t)Ma * A * sizeof(float), hipMemcpyDeviceToDevice, s));
+    LAUNCH(mdt_launch_loss_reduce(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, loss_out, s));
+    t.has_decoder = true;
+    return MDT_OK;
+}
+
+static mdt_status check_ready(mdt_model* m) {
+    if (!m) return fail(MDT_ERR_INVALID_ARG, "null handle");
+    if (!m->train) return fail(MDT_ERR_STATE, "training was not prepared: call mdt_train_prepare() and upload the parameters");
+    for (const Slot& sl : m->slots)
+        if (!sl.loaded) return fail(MDT_ERR_NOT_LOADED, "parameter '%s' was not loaded after mdt_train_prepare()", sl.name.c_str());
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_train_encode_fwd(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                           int32_t modality, int32_t honour_modality, int64_t batch, float* ctx_out,
+                                           mdt_tape_id* tape, void* stream) {
+    MDT_TRY(check_ready(m));
+    if (!tokens || !goal || !tape || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_train_encode_fwd: bad argument");
+    if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
+    MDT_TRY(acquire_tape(m, batch, tape));
+    mdt_status st = enc_fwd(m, m->train->tapes[*tape], tokens, tokens2, goal, modality, honour_modality, ctx_out,
+                            (hipStream_t)stream);
+    if (st != MDT_OK) m->train->tapes[*tape].in_use = false;
+    return st;
+}
+
+extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                         int32_t modality, const float* action, const float* noise, const float* sigma,
+                                         int64_t batch, float* loss_out, float* model_output, float* ctx_out,
+                                         mdt_tape_id* tape, void* stream) {
+    MDT_TRY(check_ready(m));
+    if (!tokens || !goal || !action || !noise || !sigma || !loss_out || !tape || batch < 1)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_train_loss_fwd: bad argument");
+    if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
+    hipStream_t s = (hipStream_t)stream;
+    MDT_TRY(acquire_tape(m, batch, tape));
+    Tape& t = m->train->tapes[*tape];
+    const int honour = m->cfg.arch == MDT_ARCH_MDTV;  // MDTTransformer.forward always uses goal_emb (mdt_transformer.py:215)
+    mdt_status st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, ctx_out, s);
+    if (st == MDT_OK) st = dec_fwd(m, t, action, noise, sigma, loss_out, model_output, s);
+    if (st != MDT_OK) t.in_use = false;
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// gradient slots of a (possibly stacked) Linear: every reference Linear inside `l`
+static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float* X, int64_t ldx, const float* dY, int64_t ldy,
+                          int M, float* dX, int64_t ldxo, int acc_dx, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    for (const LinPart& p : m->parts) {
+        if (p.lin != &l) continue;
+        mdt_linear_bwd_args a;
+        memset(&a, 0, sizeof a);
+        a.X = X; a.ldx = ldx; a.dY = dY + p.n_off; a.ldy = ldy;
+        a.dW = grads + ts->grad_off[p.w_slot];
+        a.dbias = p.b_slot >= 0 ? grads + ts->grad_off[p.b_slot] : nullptr;
+        a.accumulate_dw = 1;
+        a.M = M; a.N = p.rows; a.K = l.K; a.scratch = ts->lin_scratch;
+        MDT_TRY(mdt_linear_bwd(a, s));
+    }
+    if (dX) {
+        mdt_linear_bwd_args a;
+        memset(&a, 0, sizeof a);
+        a.X = X; a.ldx = ldx; a.dY = dY; a.ldy = ldy; a.Wt = l.wt; a.dX = dX; a.ldxo = ldxo; a.accumulate_dx = acc_dx;
+        a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
+        MDT_TRY(mdt_linear_bwd(a, s));
+    }
+    return MDT_OK;
+}
+
+static int slot_of(const mdt_model* m, const float* dst) {
+    for (size_t i = 0; i < m->slots.size(); ++i)
+        if (m->slots[i].dst == dst) return (int)i;
+    return -1;
+}
+
+static float* grad_of(mdt_model* m, float* grads, const float* param) {
+    const int i = param ? slot_of(m, param) : -1;
+    return i < 0 ? nullptr : grads + m->train->grad_off[i];
+}
+
+// LayerNorm backward + reduction of the per-sample weight/bias partials into the gradient slots
+static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float* stats, const float* w, const float* b,
+                         const float* mod, int64_t modw, int shift_off, int scale_off, const float* dh, float* dx, int acc,
+                         float* d_mod, int64_t B, int T, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    mdt_ln_bwd_args a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.stats = stats; a.w = w; a.b = b; a.mod = mod; a.mod_stride = modw; a.shift_off = shift_off; a.scale_off = scale_off;
+    a.dh = dh; a.ld_dh = m->D; a.dx = dx; a.accumulate = acc; a.d_mod = d_mod; a.d_mod_stride = modw;
+    a.pw = ts->pw; a.pb = b ? ts->pb : nullptr; a.B = (int)B; a.rows_per_sample = T; a.D = m->D;
+    LAUNCH(mdt_launch_ln_bwd(a, s));
+    LAUNCH(mdt_launch_colsum(ts->pw, m->D, (int)B, m->D, grad_of(m, grads, w), 1, s));
+    if (b) LAUNCH(mdt_launch_colsum(ts->pb, m->D, (int)B, m->D, grad_of(m, grads, b), 1, s));
+    return MDT_OK;
+}
+
+// dx: gradient wrt the block's output on entry, wrt its input on return (in place)
+static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T,
+                            bool causal, const float* mod, float* d_mod, int64_t modw, const float* kv, float* d_kv,
+                            float* dx, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const int D = m->D, M = (int)(B * T);
+    // ---- MLP half: x3 = x2 + g2 * c_proj(gelu(c_fc(h2)))
+    const float* d_mo = dx;
+    if (d) {
+        LAUNCH(mdt_launch_gate_bwd(dx, t.mo, mod + 5 * D, modw, T, ts->t_d, d_mod + 5 * D, modw, (int)B, D, s));
+        d_mo = ts->t_d;
+    }
+    MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, d_mo, D, M, ts->t_4d, 4 * D, 0, s));
+    LAUNCH(mdt_launch_act_bwd(t.u, ts->t_4d, ts->t_4d, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
+    MDT_TRY(lin_bwd(m, grads, e.fc, t.h2, D, ts->t_4d, 4 * D, M, ts->t_d2, D, 0, s));
+    MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, mod ? 3 * D : -1, mod ? 4 * D : -1, ts->t_d2, dx, 1,
+                   d_mod, B, T, s));
+    if (d) {
+        // ---- cross-attention half: x2 = x1 + c_proj(attn(q(ln3(x1)), K, V))
+        MDT_TRY(lin_bwd(m, grads, d->xproj, t.att2, D, dx, D, M, ts->t_d, D, 0, s));
+        mdt_attn_bwd_args x;
+        memset(&x, 0, sizeof x);
+        x.q = t.q; x.ldq = D; x.k = kv; x.v = kv + D; x.ldkv = (int64_t)m->Ld * 2 * D;
+        x.d_out = ts->t_d; x.ld_do = D; x.dq = ts->t_d2; x.ld_dq = D;
+        x.dk = d_kv; x.dv = d_kv + D; x.ld_dkv = (int64_t)m->Ld * 2 * D; x.accumulate_kv = 0;
+        x.B = (int)B; x.H = m->H; x.hd = m->hd; x.Tq = T; x.Tk = m->Te; x.causal = 1;
+        LAUNCH(mdt_launch_attn_bwd(x, s));
+        MDT_TRY(lin_bwd(m, grads, d->xq, t.h3, D, ts->t_d2, D, M, ts->t_d, D, 0, s));
+        MDT_TRY(ln_bwd(m, grads, t.x1, t.st3, d->ln3_w, d->ln3_b, nullptr, 0, -1, -1, ts->t_d, dx, 1, nullptr, B, T, s));
+    }
+    // ---- self-attention half: x1 = x_in + g1 * c_proj(attn(qkv(h1)))
+    const float* d_a = dx;
+    if (d) {
+        LAUNCH(mdt_launch_gate_bwd(dx, t.a1, mod + 2 * D, modw, T, ts->t_d, d_mod + 2 * D, modw, (int)B, D, s));
+        d_a = ts->t_d;
+    }
+    MDT_TRY(lin_bwd(m, grads, e.proj, t.att, D, d_a, D, M, ts->t_d2, D, 0, s));
+    mdt_attn_bwd_args a;
+    memset(&a, 0, sizeof a);
+    a.q = t.qkv; a.ldq = 3 * D; a.k = t.qkv + D; a.v = t.qkv + 2 * D; a.ldkv = 3 * D;
+    a.d_out = ts->t_d2; a.ld_do = D; a.dq = ts->t_3d; a.ld_dq = 3 * D;
+    a.dk = ts->t_3d + D; a.dv = ts->t_3d + 2 * D; a.ld_dkv = 3 * D; a.accumulate_kv = 0;
+    a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T; a.causal = causal;
+    LAUNCH(mdt_launch_attn_bwd(a, s));
+    MDT_TRY(lin_bwd(m, grads, e.qkv, t.h1, D, ts->t_3d, 3 * D, M, ts->t_d, D, 0, s));
+    MDT_TRY(ln_bwd(m, grads, t.x_in, t.st1, e.ln1_w, e.ln1_b, mod, modw, mod ? 0 : -1, mod ? D : -1, ts->t_d, dx, 1, d_mod, B,
+                   T, s));
+    return MDT_OK;
+}
+
+// encoder backward: dxe holds d(ctx) on entry
+static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, float* d_tokens2, float* d_goal,
+                          hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const mdt_config& c = m->cfg;
+    const int D = m->D, Te = m->Te;
+    const int64_t B = t.B, Me = B * Te;
+    // final LayerNorm: ctx = ln(x_L)
+    HIP_TRY(hipMemcpyAsync(ts->t_d, ts->dxe, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MDT_TRY(ln_bwd(m, grads, enc_last_output(m, t), t.st_f, m->enc_ln_w, m->enc_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dxe, 0,
+                   nullptr, B, Te, s));
+    for (int l = m->Le - 1; l >= 0; --l)
+        MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, nullptr, 0, nullptr, nullptr, ts->dxe, s));
+    // token embeddings: the forward scattered their rows into the context
+    const Lin& g0 = t.lang ? m->lang0 : m->goal0;
+    const Lin& g2 = t.lang ? m->lang2 : m->goal2;
+    float* dg = ts->t_d;  // (B, D)
+    LAUNCH(mdt_launch_gather_rows(ts->dxe, dg, (int)B, D, 1, Te, 0, s));
+    const bool pos = c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb;
+    float* g_pos = pos ? grad_of(m, grads, m->pos_emb) : nullptr;
+    if (pos) LAUNCH(mdt_launch_colsum(dg, D, (int)B, D, g_pos, 1, s));
+    if (c.use_mlp_goal) {
+        MDT_TRY(lin_bwd(m, grads, g2, t.g_h, 2 * D, dg, D, (int)B, ts->small, 2 * D, 0, s));
+        LAUNCH(mdt_launch_act_bwd(t.g_pre, ts->small, ts->small, B * 2 * D, MDT_ACT_GELU, s));
+        MDT_TRY(lin_bwd(m, grads, g0, t.goal, m->G, ts->small, 2 * D, (int)B, d_goal, m->G, 0, s));
+    } else {
+        MDT_TRY(lin_bwd(m, grads, g2, t.goal, m->G, dg, D, (int)B, d_goal, m->G, 0, s));
+    }
+    if (c.arch == MDT_ARCH_MDTV) {
+        float* dt = ts->t_d2;  // (B*n_tok, D)
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, dt, (int)(B * m->n_tok), D, m->n_tok, Te, 1, s));
+        MDT_TRY(lin_bwd(m, grads, m->tok, t.tokens, m->O, dt, D, (int)(B * m->n_tok), d_tokens, m->O, 0, s));
+    } else {
+        float* d1 = ts->t_d2;
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, 1, s));
+        if (pos) LAUNCH(mdt_launch_colsum(d1, D, (int)B, D, g_pos + (int64_t)c.goal_seq_len * D, 1, s));
+        MDT_TRY(lin_bwd(m, grads, m->tok, t.tokens, m->O, d1, D, (int)B, d_tokens, m->O, 0, s));
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, 2, s));
+        if (pos) LAUNCH(mdt_launch_colsum(d1, D, (int)B, D, g_pos + (int64_t)c.goal_seq_len * D, 1, s));
+        MDT_TRY(lin_bwd(m, grads, m->incam, t.tokens2, m->O, d1, D, (int)B, d_tokens2, m->O, 0, s));
+    }
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const float* g_ctx, float* grads, float* d_tokens,
+                                           float* d_tokens2, float* d_goal, void* stream) {
+    Tape* t;
+    MDT_TRY(get_tape(m, tape, &t));
+    if (!g_ctx || !grads) return fail(MDT_ERR_INVALID_ARG, "mdt_train_encode_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    MDT_TRY(reserve_scratch(m, t->B));
+    HIP_TRY(hipMemcpyAsync(m->train->dxe, g_ctx, (size_t)t->B * m->Te * m->D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return enc_bwd(m, *t, grads, d_tokens, d_tokens2, d_goal, s);
+}
+
+extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const float* g_loss, const float* g_ctx, float* grads,
+                                         float* d_tokens, float* d_tokens2, float* d_goal, void* stream) {
+    Tape* tp;
+    MDT_TRY(get_tape(m, tape, &tp));
+    Tape& t = *tp;
+    if (!grads) return fail(MDT_ERR_INVALID_ARG, "mdt_train_loss_bwd: null gradient buffer");
+    if (!t.has_decoder) return fail(MDT_ERR_STATE, "tape %d holds an encoder-only forward: use mdt_train_encode_bwd", tape);
+    hipStream_t s = (hipStream_t)stream;
+    mdt_train_state* ts = m->train;
+    MDT_TRY(reserve_scratch(m, t.B));
+    const int D = m->D, Ta = m->Ta, A = m->A;
+    const int64_t B = t.B, Ma = B * Ta, Me = B * m->Te;
+    const int64_t modw = (int64_t)m->Ld * 6 * D;
+    // ---- loss and action head: F = action_pred(ln(x_L))
+    LAUNCH(mdt_launch_loss_grad(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, Ta * A, g_loss, ts->dF, s));
+    LAUNCH(mdt_launch_colsum(ts->dF, A, (int)Ma, A, grad_of(m, grads, m->bp), 1, s));
+    LAUNCH(mdt_launch_narrow_dw(ts->dF, t.lnout, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 0, s));
+    LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wp), 1, s));
+    LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_d, (int)Ma, A, D, s));
+    MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
+                   B, Ta, s));
+    // ---- decoder blocks
+    for (int l = m->Ld - 1; l >= 0; --l)
+        MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, t.mod + (int64_t)l * 6 * D,
+                          ts->d_mod + (int64_t)l * 6 * D, modw, t.kvx + (int64_t)l * 2 * D, ts->d_kvx + (int64_t)l * 2 * D, ts->dx,
+                          s));
+    // ---- action embedding: y0 = action_emb(xin); no gradient flows to the noisy actions
+    LAUNCH(mdt_launch_colsum(ts->dx, D, (int)Ma, D, grad_of(m, grads, m->ba), 1, s));
+    LAUNCH(mdt_launch_narrow_dw(t.xin, ts->dx, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 1, s));
+    LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wa), 1, s));
+    // ---- sigma path: mod = modulation(silu(c)), c = sigma_emb(sigma)
+    MDT_TRY(lin_bwd(m, grads, m->mod_all, t.sig_s, D, ts->d_mod, modw, (int)B, ts->small, D, 0, s));
+    LAUNCH(mdt_launch_act_bwd(t.sig_cpre, ts->small, ts->small, B * D, MDT_ACT_SILU, s));
+    MDT_TRY(lin_bwd(m, grads, m->sig3, t.sig_t, 2 * D, ts->small, D, (int)B, ts->t_d2, 2 * D, 0, s));
+    LAUNCH(mdt_launch_act_bwd(t.sig_tpre, ts->t_d2, ts->t_d2, B * 2 * D, MDT_ACT_MISH, s));
+    MDT_TRY(lin_bwd(m, grads, m->sig1, t.sig_e, D, ts->t_d2, 2 * D, (int)B, nullptr, 0, 0, s));
+    // ---- context: K|V projections of all blocks, plus whatever other losses hung onto latent_encoder_emb
+    if (g_ctx) HIP_TRY(hipMemcpyAsync(ts->dxe, g_ctx, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MDT_TRY(lin_bwd(m, grads, m->kv_all, t.ctx, D, ts->d_kvx, (int64_t)m->Ld * 2 * D, (int)Me, ts->dxe, D, g_ctx ? 1 : 0, s));
+    return enc_bwd(m, t, grads, d_tokens, d_tokens2, d_goal, s);
+}

@@ -1,0 +1,489 @@
+// mdt_train_kernels.hip -- gfx950 kernels of the TRAINING path (GCDenoiser.loss forward with saved activations,
+// and its backward): the row-local / per-sample pieces.  Every dense contraction of the backward (dX = dY W,
+// dW = dY^T X) runs on the same fp32-MFMA GEMM as the forward (mdt_kernels.hip: k_gemm) -- dX with a transposed
+// packed image of the weight, dW with the transposed gradient as the row operand and the transposed activation
+// packed as the "weight" (k_pack_weight_t) -- so this file holds no GEMM.
+//
+// Reference semantics: autograd through mdt/models/networks/transformers/transformer_blocks.py (LayerNorm :29-38,
+// Attention :119-158, MLP :161-180, ConditionedBlock :291-309) and mdt/models/edm_diffusion/score_wrappers.py:45-63.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdt_internal.h"
+
+#include "mdt_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// packing the TRANSPOSE of a row-major (rows, cols) matrix part into a fragment-packed (N' = cols, K' = K16*16)
+// image at k-offset k_off:  src[r][c] -> logical (n' = c, k' = k_off + r).
+//   * weights:      W (N, K) part at row offset n_off -> image of W^T (N' = K, K' = N_total), k_off = n_off
+//   * activations:  X (M, K)                           -> image of X^T (N' = K, K' = M padded to 16)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_weight_t(const float* __restrict__ src, int rows, int cols, int64_t lds_, float* __restrict__ packed,
+                                int k_off, int K16) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)rows * cols) return;
+    const int r = (int)(idx / cols), c = (int)(idx % cols);
+    const int n = c, k = k_off + r;
+    const int nt = n >> 4, ni = n & 15, kc = k >> 4, h = (k & 15) >> 2, j = k & 3;
+    packed[(((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4 + j] = src[(int64_t)r * lds_ + c];
+}
+
+hipError_t mdt_launch_pack_weight_t(const float* src, int rows, int cols, int64_t ld, float* packed, int k_off, int K16,
+                                    hipStream_t s) {
+    const int64_t n = (int64_t)rows * cols;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_weight_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, ld, packed,
+                       k_off, K16);
+    return hipGetLastError();
+}
+
+// dst (C, ldd) = src (R, C; lds)^T, through a 32x33 LDS tile so both sides are coalesced
+__global__ __launch_bounds__(256) void k_transpose_ld(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                      int64_t ldd, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < Cc) ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < Cc && r < R) dst[(int64_t)c * ldd + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_ld, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, Cc);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (+ adaLN modulate) forward that keeps the row statistics        (transformer_blocks.py:37-38,:262)
+//   h = shift + (xhat * w + b) * scale ;  stats[row] = (mean, rstd)
+// one wave per row; lane owns columns lane, lane+64, ...  (D <= 512)
+// ------------------------------------------------------------------------------------------------
+#define LN_MAXC 8
+
+__global__ __launch_bounds__(256) void k_ln_fwd_train(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, const float* __restrict__ mod,
+                                                      int64_t mod_stride, int shift_off, int scale_off, int rps,
+                                                      float* __restrict__ out, float* __restrict__ stats, int M, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * D;
+    float v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mean : 0.f;
+        q = fmaf(d, d, q);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+    const float* mr = mod ? mod + (int64_t)(row / rps) * mod_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            float n = (v[i] - mean) * rstd * w[c] + (b ? b[c] : 0.f);
+            if (mr) n = fmaf(n, mr[scale_off + c], mr[shift_off + c]);
+            out[(int64_t)row * D + c] = n;
+        }
+    }
+    if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s) {
+    if (a.D > 64 * LN_MAXC || a.D < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ln_fwd_train, dim3((a.M + 3) / 4), dim3(256), 0, s, a.x, a.w, a.b, a.mod, a.mod_stride,
+                       a.shift_off, a.scale_off, a.rows_per_sample > 0 ? a.rows_per_sample : 1, a.out, a.stats, a.M, a.D);
+    return hipGetLastError();
+}
+
+// LayerNorm (+ modulate) backward.  One workgroup per sample (rows_per_sample rows, a wave per row in turn):
+//   dn   = dh * scale                     (scale = 1 without modulation)
+//   dxh  = dn * w
+//   dx  (+)= rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
+//   per sample:  d_shift = sum_rows dh ;  d_scale = sum_rows dh * n ;  pw = sum_rows dn * xhat ;  pb = sum_rows dn
+// pw / pb are per-sample partials of the weight / bias gradient (summed over samples by k_colsum afterwards).
+__global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
+    extern __shared__ float red[];  // [4 waves][4 kinds][D]
+    const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D = a.D, rps = a.rows_per_sample;
+    const float* mr = a.mod ? a.mod + (int64_t)b * a.mod_stride : nullptr;
+    float wgt[LN_MAXC], bia[LN_MAXC], sc[LN_MAXC];
+    float a_sh[LN_MAXC], a_sc[LN_MAXC], a_w[LN_MAXC], a_b[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        wgt[i] = c < D ? a.w[c] : 0.f;
+        bia[i] = (c < D && a.b) ? a.b[c] : 0.f;
+        sc[i] = c < D ? (mr ? mr[a.scale_off + c] : 1.f) : 0.f;
+        a_sh[i] = a_sc[i] = a_w[i] = a_b[i] = 0.f;
+    }
+    for (int r = wv; r < rps; r += 4) {
+        const int64_t row = (int64_t)b * rps + r;
+        const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
+        float xh[LN_MAXC], dxh[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const float xv = c < D ? a.x[row * D + c] : 0.f;
+            const float dh = c < D ? a.dh[row * a.ld_dh + c] : 0.f;
+            xh[i] = c < D ? (xv - mean) * rstd : 0.f;
+            const float n = fmaf(xh[i], wgt[i], bia[i]);
+            const float dn = dh * sc[i];
+            a_sh[i] += dh;
+            a_sc[i] = fmaf(dh, n, a_sc[i]);
+            a_w[i] = fmaf(dn, xh[i], a_w[i]);
+            a_b[i] += dn;
+            dxh[i] = dn * wgt[i];
+            s1 += dxh[i];
+            s2 = fmaf(dxh[i], xh[i], s2);
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float g = rstd * (dxh[i] - c1 - xh[i] * c2);
+                float* p = a.dx + row * D + c;
+                *p = a.accumulate ? *p + g : g;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            red[(wv * 4 + 0) * D + c] = a_sh[i];
+            red[(wv * 4 + 1) * D + c] = a_sc[i];
+            red[(wv * 4 + 2) * D + c] = a_w[i];
+            red[(wv * 4 + 3) * D + c] = a_b[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = red[(0 * 4 + k) * D + c] + red[(1 * 4 + k) * D + c] + red[(2 * 4 + k) * D + c] +
+                                           red[(3 * 4 + k) * D + c];
+        if (a.d_mod) {  // accumulate: one row of d_mod collects the gradients of several consumers
+            if (a.shift_off >= 0) a.d_mod[(int64_t)b * a.d_mod_stride + a.shift_off + c] = t[0];
+            if (a.scale_off >= 0) a.d_mod[(int64_t)b * a.d_mod_stride + a.scale_off + c] = t[1];
+        }
+        a.pw[(int64_t)b * D + c] = t[2];
+        if (a.pb) a.pb[(int64_t)b * D + c] = t[3];
+    }
+}
+
+hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s) {
+    if (a.D > 64 * LN_MAXC || a.D < 1 || a.rows_per_sample < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ln_bwd, dim3(a.B), dim3(256), (size_t)16 * a.D * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise activation forward / backward on a pre-activation buffer      (nn.GELU :171, nn.Mish, nn.SiLU :251)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_act_fwd(const float* __restrict__ u, float* __restrict__ out, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = apply_act1(u[i], act);
+}
+__global__ void k_act_bwd(const float* __restrict__ u, const float* dy, float* du, int64_t n, int act) {  // du may alias dy
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) du[i] = dy[i] * apply_act_grad1(u[i], act);
+}
+hipError_t mdt_launch_act_fwd(const float* u, float* out, int64_t n, int act, hipStream_t s) {
+    hipLaunchKernelGGL(k_act_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, out, n, act);
+    return hipGetLastError();
+}
+hipError_t mdt_launch_act_bwd(const float* u, const float* dy, float* du, int64_t n, int act, hipStream_t s) {
+    hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, dy, du, n, act);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// gated residual   x_out = x + gate[sample] * a                              (transformer_blocks.py:296-307)
+// forward, and backward:  d_a = gate * d_x ;  d_gate[sample] = sum_rows d_x * a   (one workgroup per sample)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gate_residual(const float* __restrict__ x, const float* __restrict__ av, const float* __restrict__ gate,
+                                int64_t gstride, int rps, float* __restrict__ out, int64_t n, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t row = i / D;
+    const int c = (int)(i - row * D);
+    const float g = gate ? gate[(row / rps) * gstride + c] : 1.f;
+    out[i] = fmaf(g, av[i], x[i]);
+}
+hipError_t mdt_launch_gate_residual(const float* x, const float* av, const float* gate, int64_t gstride, int rps, float* out,
+                                    int M, int D, hipStream_t s) {
+    const int64_t n = (int64_t)M * D;
+    hipLaunchKernelGGL(k_gate_residual, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, av, gate, gstride,
+                       rps > 0 ? rps : 1, out, n, D);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_gate_bwd(const float* __restrict__ dx, const float* __restrict__ av,
+                                                  const float* __restrict__ gate, int64_t gstride, int rps,
+                                                  float* __restrict__ da, float* __restrict__ dgate, int64_t dgstride,
+                                                  int D) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float g = gate[(int64_t)b * gstride + c];
+        float acc = 0.f;
+        for (int r = 0; r < rps; ++r) {
+            const int64_t i = ((int64_t)b * rps + r) * D + c;
+            const float d = dx[i];
+            acc = fmaf(d, av[i], acc);
+            da[i] = g * d;
+        }
+        dgate[(int64_t)b * dgstride + c] = acc;
+    }
+}
+hipError_t mdt_launch_gate_bwd(const float* dx, const float* av, const float* gate, int64_t gstride, int rps, float* da,
+                               float* dgate, int64_t dgstride, int B, int D, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dx, av, gate, gstride, rps, da, dgate, dgstride, D);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums  out[n] (+)= sum_m X[m][n]   (bias gradients; reduction of per-sample partials)
+// grid.x = column groups of 64, 4 row groups per workgroup meet in LDS; deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t ldx, int M, int N,
+                                                float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    if (c < N) {
+        int m = rg;
+        for (; m + 12 < M; m += 16) {
+            acc0 += X[(int64_t)m * ldx + c];
+            acc1 += X[(int64_t)(m + 4) * ldx + c];
+            acc2 += X[(int64_t)(m + 8) * ldx + c];
+            acc3 += X[(int64_t)(m + 12) * ldx + c];
+        }
+        for (; m < M; m += 4) acc0 += X[(int64_t)m * ldx + c];
+    }
+    part[rg][cl] = (acc0 + acc1) + (acc2 + acc3);
+    __syncthreads();
+    if (rg == 0 && c < N) {
+        const float t = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, s, X, ldx, M, N, out, accumulate);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention backward for the small sequences of this model (Tq, Tk <= 16): one wave per (sample, head).
+//   P recomputed from q, k (same masking as k_attn);  dV = P^T dO ;  dP = dO V^T ;
+//   dS = P * (dP - rowsum(dP * P)) * scale ;  dQ = dS K ;  dK = dS^T Q        (F.scaled_dot_product_attention :142)
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scale) {
+    __shared__ float qs[16][HD + 1], ks[16][HD + 1], vs[16][HD + 1], os[16][HD + 1];
+    __shared__ float P[16][17], dS[16][17];
+    const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int Tq = a.Tq, Tk = a.Tk;
+    for (int i = lane; i < Tq * HD; i += 64) {
+        const int r = i / HD, d = i - r * HD;
+        qs[r][d] = a.q[((int64_t)b * Tq + r) * a.ldq + h * HD + d];
+        os[r][d] = a.d_out[((int64_t)b * Tq + r) * a.ld_do + h * HD + d];
+    }
+    for (int i = lane; i < Tk * HD; i += 64) {
+        const int r = i / HD, d = i - r * HD;
+        ks[r][d] = a.k[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
+        vs[r][d] = a.v[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
+    }
+    __syncthreads();
+    if (lane < Tq) {
+        const int i = lane;
+        float sc[16], dp[16];
+        float mx = -INFINITY;
+        for (int j = 0; j < Tk; ++j) {
+            float s = 0.f, t = 0.f;
+            for (int d = 0; d < HD; ++d) {
+                s = fmaf(qs[i][d], ks[j][d], s);
+                t = fmaf(os[i][d], vs[j][d], t);
+            }
+            const bool vis = !a.causal || j <= i;
+            sc[j] = vis ? s * scale : -INFINITY;
+            dp[j] = t;
+            mx = fmaxf(mx, sc[j]);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < Tk; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+        const float inv = 1.f / sum;
+        float delta = 0.f;
+        for (int j = 0; j < Tk; ++j) { sc[j] *= inv; delta = fmaf(sc[j], dp[j], delta); }
+        for (int j = 0; j < Tk; ++j) {
+            P[i][j] = sc[j];
+            dS[i][j] = sc[j] * (dp[j] - delta) * scale;
+        }
+    }
+    __syncthreads();
+    // dQ[i][d] = sum_j dS[i][j] K[j][d]
+    for (int e = lane; e < Tq * HD; e += 64) {
+        const int i = e / HD, d = e - i * HD;
+        float acc = 0.f;
+        for (int j = 0; j < Tk; ++j) acc = fmaf(dS[i][j], ks[j][d], acc);
+        a.dq[((int64_t)b * Tq + i) * a.ld_dq + h * HD + d] = acc;
+    }
+    // dK[j][d] = sum_i dS[i][j] Q[i][d] ;  dV[j][d] = sum_i P[i][j] dO[i][d]
+    for (int e = lane; e < Tk * HD; e += 64) {
+        const int j = e / HD, d = e - j * HD;
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < Tq; ++i) {
+            ak = fmaf(dS[i][j], qs[i][d], ak);
+            av = fmaf(P[i][j], os[i][d], av);
+        }
+        float* pk = a.dk + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
+        float* pv = a.dv + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
+        *pk = a.accumulate_kv ? *pk + ak : ak;
+        *pv = a.accumulate_kv ? *pv + av : av;
+    }
+}
+
+hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s) {
+    if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
+    const float scale = 1.0f / sqrtf((float)a.hd);
+    const dim3 grid(a.B, a.H);
+    switch (a.hd) {
+        case 16: hipLaunchKernelGGL((k_attn_bwd<16>), grid, dim3(64), 0, s, a, scale); break;
+        case 32: hipLaunchKernelGGL((k_attn_bwd<32>), grid, dim3(64), 0, s, a, scale); break;
+        case 48: hipLaunchKernelGGL((k_attn_bwd<48>), grid, dim3(64), 0, s, a, scale); break;
+        case 64: hipLaunchKernelGGL((k_attn_bwd<64>), grid, dim3(64), 0, s, a, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss gradient and the narrow (A <= 16 wide) linears around the action tokens
+// ------------------------------------------------------------------------------------------------
+// dF = gscale * 2 (F - target) / n ,  target = (action - c_skip * noised) / c_out     (score_wrappers.py:59-63)
+__global__ void k_loss_grad(const float* __restrict__ F, const float* __restrict__ act, const float* __restrict__ noised,
+                            const float* __restrict__ sigma, float sd, int64_t n, int per_sample,
+                            const float* __restrict__ gscale, float* __restrict__ dF) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sg = sigma[i / per_sample];
+    const float den2 = sg * sg + sd * sd;
+    const float c_skip = sd * sd / den2, c_out = sg * sd / sqrtf(den2);
+    const float tgt = (act[i] - c_skip * noised[i]) / c_out;
+    dF[i] = (gscale ? *gscale : 1.f) * 2.f * (F[i] - tgt) / (float)n;
+}
+hipError_t mdt_launch_loss_grad(const float* F, const float* act, const float* noised, const float* sigma, float sd,
+                                int64_t n, int per_sample, const float* gscale, float* dF, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, F, act, noised, sigma, sd, n,
+                       per_sample, gscale, dF);
+    return hipGetLastError();
+}
+
+// out[m][d] = sum_a G[m][a] * W[a][d]            (d(ln_out) = dF @ action_pred.weight, W is (A, D))
+__global__ void k_narrow_dx(const float* __restrict__ G, const float* __restrict__ W, float* __restrict__ out, int64_t n,
+                            int A, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t m = i / D;
+    const int d = (int)(i - m * D);
+    float acc = 0.f;
+    for (int a = 0; a < A; ++a) acc = fmaf(G[m * A + a], W[a * D + d], acc);
+    out[i] = acc;
+}
+hipError_t mdt_launch_narrow_dx(const float* G, const float* W, float* out, int M, int A, int D, hipStream_t s) {
+    const int64_t n = (int64_t)M * D;
+    hipLaunchKernelGGL(k_narrow_dx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, W, out, n, A, D);
+    return hipGetLastError();
+}
+
+// partial[y][a][d] = sum_{m in slice y} G[m][a] * Y[m][d]   (A <= 16); summed over y by k_colsum.
+//   transposed = 0: rows of the result are a (action_pred.weight (A, D));  1: result stored (D, A) (action_emb.weight)
+__global__ __launch_bounds__(256) void k_narrow_dw(const float* __restrict__ G, const float* __restrict__ Y, int64_t ldy,
+                                                   float* __restrict__ partial, int M, int A, int D, int transposed) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int ny = gridDim.y, y = blockIdx.y;
+    const int m0 = (int)((int64_t)M * y / ny), m1 = (int)((int64_t)M * (y + 1) / ny);
+    float acc[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) acc[a] = 0.f;
+    if (d < D) {
+        for (int m = m0; m < m1; ++m) {
+            const float yv = Y[(int64_t)m * ldy + d];
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                if (a < A) acc[a] = fmaf(G[(int64_t)m * A + a], yv, acc[a]);
+        }
+        float* p = partial + (int64_t)y * A * D;
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            if (a < A) p[transposed ? d * A + a : a * D + d] = acc[a];
+    }
+}
+hipError_t mdt_launch_narrow_dw(const float* G, const float* Y, int64_t ldy, float* partial, int n_slices, int M, int A,
+                                int D, int transposed, hipStream_t s) {
+    if (A < 1 || A > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_narrow_dw, dim3((D + 255) / 256, n_slices), dim3(256), 0, s, G, Y, ldy, partial, M, A, D,
+                       transposed);
+    return hipGetLastError();
+}
+
+// d_y[m][d] = c_in[sample] ... is not needed (no gradient flows to the noisy actions); the action embedding only
+// needs its weight / bias gradient: xin[m][a] = noised[m][a] * c_in(sigma[sample]) recomputed here.
+__global__ void k_scaled_input(const float* __restrict__ x, const float* __restrict__ sigma, float sd, int64_t n,
+                               int per_sample, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sg = sigma[i / per_sample];
+    out[i] = x[i] / sqrtf(sg * sg + sd * sd);
+}
+hipError_t mdt_launch_scaled_input(const float* x, const float* sigma, float sd, int64_t n, int per_sample, float* out,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(k_scaled_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, sigma, sd, n, per_sample, out);
+    return hipGetLastError();
+}
+
+// gather / scatter-add of row groups: dst[(m / gin) * gin + m % gin] = src[(m / gin) * gout + m % gin + goff]
+// (the inverse of the GEMM epilogue's output row remap: picks the goal / state rows out of the context gradient)
+__global__ void k_gather_rows(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int D, int gin, int gout,
+                              int goff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t m = i / D;
+    const int c = (int)(i - m * D);
+    dst[i] = src[((m / gin) * gout + m % gin + goff) * D + c];
+}
+hipError_t mdt_launch_gather_rows(const float* src, float* dst, int M, int D, int gin, int gout, int goff, hipStream_t s) {
+    const int64_t n = (int64_t)M * D;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n, D, gin, gout, goff);
+    return hipGetLastError();
+}
+
+// y (+)= x elementwise
+__global__ void k_axpy1(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_axpy1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}

@@ -52,10 +52,31 @@ class GCDenoiser(nn.Module):
         c_in = 1 / (sigma ** 2 + sd ** 2) ** 0.5
         return c_skip, c_out, c_in
 
-    def _engine(self):
+    def _engine(self, allow_grad: bool = False):
         self.inner_model._sigma_data = float(self.sigma_data)
-        self.inner_model._guard_mode()
+        self.inner_model._guard_mode(allow_grad)
         return self.inner_model.hip_engine(float(self.sigma_data))
+
+    def _wants_grad(self, *tensors) -> bool:
+        return torch.is_grad_enabled() and (any(p.requires_grad for p in self.inner_model.parameters()) or
+                                            any(torch.is_tensor(t) and t.requires_grad for t in tensors))
+
+    def _train_inputs(self, eng, state, goal):
+        """Encoder inputs as the contiguous fp32 tensors the C ABI takes, still attached to the autograd graph."""
+        im = self.inner_model
+        prep = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0) \
+            else t.float().contiguous().clone()
+        if im._arch == "mdtv":
+            tok, tok2 = prep(state["state_images"]), None
+            B = tok.shape[0]
+        else:
+            tok, tok2 = prep(state["static"]), prep(state["gripper"])
+            B = tok.shape[0]
+        eng._tokens(state)  # shape validation
+        g = prep(im._goals(goal, False))
+        eng._goal(g, B)
+        named = [(n, p) for n, p in im.named_parameters()]
+        return tok, tok2, g, B, [n for n, _ in named], [p for _, p in named]
 
     def forward(self, state, action, goal, sigma, **kwargs):
         """D(x; sigma) = F(x*c_in, sigma)*c_out + x*c_skip (reference score_wrappers.py:65-80)."""
@@ -71,13 +92,35 @@ class GCDenoiser(nn.Module):
     def loss(self, state, action, goal, noise, sigma, **kwargs):
         """Denoising score-matching loss, forward value (reference score_wrappers.py:45-63)."""
         im = self.inner_model
+        if self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
+            # training step: HIP forward with a tape + HIP backward behind torch.autograd
+            from ._autograd import HipDiffusionLoss
+            eng = self._engine(allow_grad=True)
+            tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal)
+            a, nz = eng._in(action, (B, eng.Ta, eng.A)), eng._in(noise, (B, eng.Ta, eng.A))
+            loss, model_output, ctx = HipDiffusionLoss.apply(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)), names,
+                                                             *params)
+            im.latent_encoder_emb = ctx
+            return loss, model_output
         loss, model_output, ctx = self._engine().loss_fwd(state, action, im._goals(goal, False), noise, sigma)
         im.latent_encoder_emb = ctx
         return loss, model_output
 
     def forward_context_only(self, state, action, goal, sigma, **kwargs):
         """Encoder tokens only (reference score_wrappers.py:82-97 -> inner_model.forward_enc_only)."""
-        return self.inner_model.forward_enc_only(state, action, goal, sigma, **kwargs)
+        im = self.inner_model
+        if not kwargs.get("uncond", False) and \
+                self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
+            from ._autograd import HipContextOnly
+            eng = self._engine(allow_grad=True)
+            if eng.sigma_in_context:
+                raise NotImplementedError("training with use_ada_conditioning=False is not implemented")
+            tok, tok2, g, _, names, params = self._train_inputs(eng, state, goal)
+            ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, names, *params)
+            if im._arch == "mdtv":
+                im.latent_encoder_emb = ctx
+            return ctx
+        return im.forward_enc_only(state, action, goal, sigma, **kwargs)
 
     def get_params(self):
         return self.inner_model.parameters()

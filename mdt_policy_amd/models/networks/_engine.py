@@ -188,6 +188,89 @@ class HipEngine:
     def reserve(self, max_batch: int) -> None:
         _lib.check(self.lib.mdt_reserve(self.handle, int(max_batch)))
 
+    # -- training path (include/mdt_hip_train.h) ----------------------------------------------------
+    def train_prepare(self) -> None:
+        """Allocate the transposed weight images and learn the gradient layout (idempotent)."""
+        if getattr(self, "_grad_layout", None) is not None:
+            return
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mdt_train_prepare(self.handle))
+        self._uploaded.clear()  # every parameter is re-uploaded so that its transposed image exists
+        n = self.lib.mdt_param_count(self.handle)
+        self._grad_layout = {self.lib.mdt_param_name(self.handle, i).decode():
+                             (int(self.lib.mdt_grad_offset(self.handle, i)), int(self.lib.mdt_param_numel(self.handle, i)))
+                             for i in range(n)}
+        self._grad_numel = int(self.lib.mdt_grad_numel(self.handle))
+
+    def train_loss_fwd(self, state: dict, tok, tok2, goal, action, noise, sigma):
+        self.train_prepare()
+        self.sync_params()
+        B = tok.shape[0]
+        loss = torch.empty((), device=self.device, dtype=torch.float32)
+        mo = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
+        ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        tape = C.c_int32(-1)
+        _lib.check(self.lib.mdt_train_loss_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
+                                               _ptr(action), _ptr(noise), _ptr(sigma), B, _ptr(loss), _ptr(mo), _ptr(ctx),
+                                               C.byref(tape), self._stream()))
+        return loss, mo, ctx, int(tape.value)
+
+    def train_encode_fwd(self, state: dict, tok, tok2, goal, honour_modality: bool):
+        self.train_prepare()
+        self.sync_params()
+        B = tok.shape[0]
+        ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        tape = C.c_int32(-1)
+        _lib.check(self.lib.mdt_train_encode_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
+                                                 int(honour_modality), B, _ptr(ctx), C.byref(tape), self._stream()))
+        return ctx, int(tape.value)
+
+    def _input_grads(self, tok, tok2, goal, needs):
+        d_tok = torch.empty_like(tok) if needs[0] else None
+        d_tok2 = torch.empty_like(tok2) if (needs[1] and tok2 is not None) else None
+        d_goal = torch.empty_like(goal) if needs[2] else None
+        return d_tok, d_tok2, d_goal
+
+    def train_loss_bwd(self, tape: int, g_loss, g_ctx, tok, tok2, goal, needs):
+        grads = torch.zeros(self._grad_numel, device=self.device, dtype=torch.float32)
+        d_tok, d_tok2, d_goal = self._input_grads(tok, tok2, goal, needs)
+        gl = None if g_loss is None else self._in(g_loss, ())
+        gc = None if g_ctx is None else self._in(g_ctx)
+        _lib.check(self.lib.mdt_train_loss_bwd(self.handle, tape, _ptr(gl), _ptr(gc), _ptr(grads), _ptr(d_tok),
+                                               _ptr(d_tok2), _ptr(d_goal), self._stream()))
+        return grads, d_tok, d_tok2, d_goal
+
+    def train_encode_bwd(self, tape: int, g_ctx, tok, tok2, goal, needs):
+        grads = torch.zeros(self._grad_numel, device=self.device, dtype=torch.float32)
+        d_tok, d_tok2, d_goal = self._input_grads(tok, tok2, goal, needs)
+        gc = self._in(g_ctx)
+        _lib.check(self.lib.mdt_train_encode_bwd(self.handle, tape, _ptr(gc), _ptr(grads), _ptr(d_tok), _ptr(d_tok2),
+                                                 _ptr(d_goal), self._stream()))
+        return grads, d_tok, d_tok2, d_goal
+
+    def tape_release(self, tape: int) -> None:
+        _lib.check(self.lib.mdt_tape_release(self.handle, tape))
+
+    def unused_goal_embedder(self, state: dict, honour_modality: bool) -> Optional[str]:
+        """Name prefix of the goal embedder this forward did NOT go through (None without a modality encoder)."""
+        if not self.cfg.use_modality_encoder:
+            return None
+        lang = honour_modality and self._modality(state) == _lib.MODALITY["lang"]
+        return "goal_emb." if lang else "lang_emb."
+
+    def param_grads(self, grads: torch.Tensor, params, unused: Optional[str] = None):
+        """Views of the flat gradient buffer, one per (name, parameter) of the module; None where this forward did
+        not read the parameter (proprio_emb, the other modality's goal embedder), as autograd leaves it in the
+        reference -- optimizers skip such parameters instead of decaying them."""
+        out = []
+        for name, p in params:
+            ent = self._grad_layout.get("inner_model." + name)
+            if ent is None or not p.requires_grad or (unused and name.startswith(unused)):
+                out.append(None)
+            else:
+                out.append(grads[ent[0]:ent[0] + ent[1]].view(p.shape))
+        return out
+
     def flops_per_chunk(self, n_steps: int) -> float:
         return float(self.lib.mdt_flops_per_chunk(self.handle, int(n_steps)))
 
@@ -224,12 +307,12 @@ class HipScoreNetwork(nn.Module):
         self._engines = {}
         return out
 
-    def _guard_mode(self):
+    def _guard_mode(self, allow_grad: bool = False):
         if self.training and any(float(p) > 0 for p in self._pdrops):
             raise NotImplementedError(
                 "train() mode with dropout > 0: the HIP path implements the eval-mode forward only "
                 "(training backward + dropout are SURVEY.md 8(f) item 1, not built yet); call .eval()")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if not allow_grad and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # forward values are exact, but no autograd graph is recorded
             raise NotImplementedError(
                 "autograd through the HIP denoiser is not implemented yet (SURVEY.md 8(f) item 1); wrap the call "

@@ -223,8 +223,9 @@ def encode(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv", 
     else:
         goal = _prep_goal(cfg, goal, 1 if entry == "forward" else state["static"].shape[1])
         g = _goal_embed(P, cfg, goal, modality, entry != "forward")
-        st = _lin(P, "inner_model.tok_emb", state["static"].float())
-        gr = _lin(P, "inner_model.incam_embed", state["gripper"].float())
+        wdt = P["inner_model.tok_emb.weight"].dtype  # the reference casts with .float(); fp64 only for gradient checks
+        st = _lin(P, "inner_model.tok_emb", state["static"].to(wdt))
+        gr = _lin(P, "inner_model.incam_embed", state["gripper"].to(wdt))
         s = torch.stack((st, gr), dim=2).reshape(st.shape[0], 2, -1)  # mdt_transformer.py:300-307
         if cfg.get("use_abs_pos_emb", True):  # apply_position_embeddings (:309-315), t = 1
             pos = P["inner_model.pos_emb"]

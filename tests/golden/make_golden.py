@@ -211,6 +211,49 @@ def g4():
     save("g4_loss.npz", meta, loss=np.array(loss.item(), np.float32), model_output=mo.numpy(), sigma=li["sigma"])
 
 
+G11_CASES = {
+    # name: (arch, config factory name, overrides, B)
+    "mdtv_tiny": ("mdtv", "mdtv_tiny", {}, 6),
+    "mdt_tiny": ("mdt", "mdt_tiny", {}, 5),
+    "mdtv_bias_plain_goal": ("mdtv", "mdtv_tiny", dict(bias=True, use_mlp_goal=False, use_modality_encoder=False), 4),
+    "mdtv_default": ("mdtv", "mdtv_default", {}, 8),
+}
+
+
+def g11():
+    """Training step of the reference: loss.backward() through GCDenoiser.loss in eval mode (no dropout) plus an
+    extra scalar hung on latent_encoder_emb (the way the MGF / CLA auxiliary losses use it).  Stored per parameter:
+    the gradient's l2 norm, sum and its first 6 entries; in full: the gradients of the encoder inputs."""
+    for name, (arch, factory, ov, B) in G11_CASES.items():
+        cfg = getattr(configs, factory)(**ov)
+        model = build_reference(cfg, arch, seed=111, profile="rich")
+        inp = synthetic.sampler_inputs(B, cfg, 112, arch)
+        li = synthetic.loss_inputs(B, cfg, 113)
+        state = make_state(inp, arch, "lang")
+        leaves = {k: v.requires_grad_() for k, v in state.items() if torch.is_tensor(v)}
+        goal = torch.from_numpy(inp["goal"]).requires_grad_()
+        loss, _ = model.loss(state, torch.from_numpy(li["actions"]), goal, torch.from_numpy(li["noise_train"]),
+                             torch.from_numpy(li["sigma"]))
+        ctx = model.inner_model.latent_encoder_emb
+        wctx = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), 114))
+        total = loss + 0.1 * (ctx * wctx).sum() / ctx.numel()
+        total.backward()
+        arrays, summ = {}, {}
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                summ[k] = None
+                continue
+            g = p.grad.detach().double()
+            summ[k] = [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
+        for k, v in leaves.items():
+            arrays["d_" + k] = v.grad.numpy()
+        arrays["d_goal"] = goal.grad.numpy()
+        meta = dict(config=factory, overrides=ov, arch=arch, B=B, modality="lang", weight_seed=111, profile="rich",
+                    input_seed=112, loss_seed=113, ctx_seed=114, grads=summ,
+                    state_dict=[[k, list(v.shape)] for k, v in model.state_dict().items()])
+        save(f"g11_grads_{name}.npz", meta, loss=np.array(loss.item(), np.float32), **arrays)
+
+
 def g5():
     from mdt.models.edm_diffusion import gc_sampling as gs
 
@@ -369,7 +412,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "manifest"]
     for w in which:
         print(w)
         globals()[w]()

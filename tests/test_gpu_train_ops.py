@@ -1,0 +1,178 @@
+"""Kernel-level parity of the TRAINING path (pytest -m gpu): every backward piece, called through the C ABI of
+include/mdt_hip_train.h, against torch.autograd (float64 on the CPU) of the same op."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import assert_close
+from tests.test_gpu_ops import dev, expected_pack, stream
+
+pytestmark = pytest.mark.gpu
+
+G_TOL = dict(rtol=1e-3, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mdt_policy_amd import _lib
+    return _lib
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def test_pack_weight_t_layout(lib):
+    W = rnd(48, 32, seed=1)                         # (rows, cols) -> image of W^T (N' = 32, K' = 64) at k offset 16
+    P = torch.zeros(32 * 64, device="cuda")
+    lib.check(lib.load().mdt_op_pack_weight_t(dev(W).data_ptr(), 48, 32, 32, P.data_ptr(), 16, 64, stream()))
+    full = torch.zeros(32, 64)
+    full[:, 16:64] = W.T
+    np.testing.assert_array_equal(P.cpu().numpy(), expected_pack(full))
+
+
+@pytest.mark.parametrize("D,rps,B,mod,bias", [(384, 10, 5, True, False), (384, 4, 3, False, True), (128, 10, 2, True, True),
+                                             (512, 3, 2, True, False), (64, 1, 7, False, False)])
+def test_layernorm_train_forward_and_backward(lib, D, rps, B, mod, bias):
+    M = B * rps
+    x, w, b = rnd(M, D, seed=2), 1 + 0.1 * rnd(D, seed=3), (0.1 * rnd(D, seed=4) if bias else None)
+    modt = rnd(B, 6 * D, seed=5) if mod else None
+    sh, sc = 3 * D, 4 * D
+    dh = rnd(M, D, seed=6)
+    dx0 = rnd(M, D, seed=7)
+    # reference (float64 autograd)
+    x64 = x.double().requires_grad_()
+    w64 = w.double().requires_grad_()
+    b64 = b.double().requires_grad_() if bias else None
+    m64 = modt.double().requires_grad_() if mod else None
+    n = F.layer_norm(x64, (D,), w64, b64, 1e-5)
+    if mod:
+        rows = torch.arange(M) // rps
+        h = m64[rows, sh:sh + D] + n * m64[rows, sc:sc + D]
+    else:
+        h = n
+    h.backward(dh.double())
+    # HIP forward
+    L = lib.load()
+    xd, wd, bd = dev(x), dev(w), (dev(b) if bias else None)
+    md = dev(modt) if mod else None
+    out = torch.empty(M, D, device="cuda")
+    stats = torch.empty(M, 2, device="cuda")
+    a = lib.LnTrainArgs(x=xd.data_ptr(), w=wd.data_ptr(), b=bd.data_ptr() if bias else None,
+                        mod=md.data_ptr() if mod else None, mod_stride=6 * D, shift_off=sh, scale_off=sc,
+                        rows_per_sample=rps, out=out.data_ptr(), stats=stats.data_ptr(), M=M, D=D)
+    lib.check(L.mdt_op_ln_fwd_train(C.byref(a), stream()))
+    assert_close(out.cpu(), h.detach(), what="ln forward")
+    # HIP backward (accumulating into an existing dx, as the residual path does)
+    dhd, dx = dev(dh), dev(dx0).clone()
+    dmod = torch.zeros(B, 6 * D, device="cuda")
+    pw, pb = torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda")
+    g = lib.LnBwdArgs(x=xd.data_ptr(), stats=stats.data_ptr(), w=wd.data_ptr(), b=bd.data_ptr() if bias else None,
+                      mod=md.data_ptr() if mod else None, mod_stride=6 * D, shift_off=sh if mod else -1,
+                      scale_off=sc if mod else -1, dh=dhd.data_ptr(), ld_dh=D, dx=dx.data_ptr(), accumulate=1,
+                      d_mod=dmod.data_ptr() if mod else None, d_mod_stride=6 * D, pw=pw.data_ptr(), pb=pb.data_ptr(),
+                      B=B, rows_per_sample=rps, D=D)
+    lib.check(L.mdt_op_ln_bwd(C.byref(g), stream()))
+    assert_close(dx.cpu() - dx0, x64.grad, what="dx", **G_TOL)
+    dw = torch.zeros(D, device="cuda")
+    lib.check(L.mdt_op_colsum(pw.data_ptr(), D, B, D, dw.data_ptr(), 0, stream()))
+    assert_close(dw.cpu(), w64.grad, what="dw", **G_TOL)
+    if bias:
+        assert_close(pb.sum(0).cpu(), b64.grad, what="db", **G_TOL)
+    if mod:
+        assert_close(dmod.cpu(), m64.grad, what="d_mod", **G_TOL)
+
+
+@pytest.mark.parametrize("hd,H,Tq,Tk,causal", [(48, 8, 10, 10, 1), (48, 8, 10, 4, 1), (48, 8, 4, 4, 0), (16, 8, 10, 5, 1),
+                                              (64, 2, 16, 16, 1), (32, 4, 7, 3, 0)])
+def test_attention_backward(lib, hd, H, Tq, Tk, causal):
+    B, Dm = 3, H * hd
+    qkv = rnd(B * Tq, 3 * Dm, seed=11)            # self-attention layout when Tq == Tk; otherwise separate kv
+    kv = rnd(B * Tk, 2 * Dm, seed=12)
+    do = rnd(B * Tq, Dm, seed=13)
+    q = qkv[:, :Dm].double().requires_grad_()
+    k = kv[:, :Dm].double().requires_grad_()
+    v = kv[:, Dm:].double().requires_grad_()
+    split = lambda t, T: t.view(B, T, H, hd).transpose(1, 2)
+    att = split(q, Tq) @ split(k, Tk).transpose(-1, -2) / hd ** 0.5
+    if causal:
+        att = att.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool).tril(), float("-inf"))
+    y = (att.softmax(-1) @ split(v, Tk)).transpose(1, 2).reshape(B * Tq, Dm)
+    y.backward(do.double())
+    qd, kvd, dod = dev(qkv), dev(kv), dev(do)
+    dq = torch.zeros(B * Tq, 3 * Dm, device="cuda")
+    dkv0 = rnd(B * Tk, 2 * Dm, seed=14)
+    dkv = dev(dkv0).clone()
+    a = lib.AttnBwdArgs(q=qd.data_ptr(), ldq=3 * Dm, k=kvd.data_ptr(), v=kvd.data_ptr() + 4 * Dm, ldkv=2 * Dm,
+                        d_out=dod.data_ptr(), ld_do=Dm, dq=dq.data_ptr(), ld_dq=3 * Dm, dk=dkv.data_ptr(),
+                        dv=dkv.data_ptr() + 4 * Dm, ld_dkv=2 * Dm, accumulate_kv=1, B=B, H=H, hd=hd, Tq=Tq, Tk=Tk,
+                        causal=causal)
+    lib.check(lib.load().mdt_op_attn_bwd(C.byref(a), stream()))
+    assert_close(dq[:, :Dm].cpu(), q.grad, what="dq", **G_TOL)
+    assert_close(dkv[:, :Dm].cpu() - dkv0[:, :Dm], k.grad, what="dk", **G_TOL)
+    assert_close(dkv[:, Dm:].cpu() - dkv0[:, Dm:], v.grad, what="dv", **G_TOL)
+
+
+@pytest.mark.parametrize("act,fn", [(1, F.gelu), (2, F.mish), (3, F.silu)])
+def test_activation_forward_backward(lib, act, fn):
+    u = torch.cat([rnd(5000, seed=21) * 3, torch.tensor([-30.0, -8.0, -1e-3, 0.0, 1e-3, 8.0, 25.0, 30.0])])
+    dy = rnd(u.numel(), seed=22)
+    u64 = u.double().requires_grad_()
+    y = fn(u64)
+    y.backward(dy.double())
+    ud, dyd = dev(u), dev(dy)
+    out, du = torch.empty_like(ud), torch.empty_like(ud)
+    L = lib.load()
+    lib.check(L.mdt_op_act_fwd(ud.data_ptr(), out.data_ptr(), u.numel(), act, stream()))
+    lib.check(L.mdt_op_act_bwd(ud.data_ptr(), dyd.data_ptr(), du.data_ptr(), u.numel(), act, stream()))
+    assert_close(out.cpu(), y.detach(), rtol=1e-4, atol=2e-6, what="act")
+    assert_close(du.cpu(), u64.grad, rtol=1e-4, atol=5e-6, what="act grad")
+
+
+def test_gate_backward_and_colsum(lib):
+    B, rps, D = 6, 10, 384
+    dx, a, mod = rnd(B * rps, D, seed=31), rnd(B * rps, D, seed=32), rnd(B, 6 * D, seed=33)
+    dxd, ad, md = dev(dx), dev(a), dev(mod)
+    da = torch.empty(B * rps, D, device="cuda")
+    dmod = torch.zeros(B, 6 * D, device="cuda")
+    L = lib.load()
+    lib.check(L.mdt_op_gate_bwd(dxd.data_ptr(), ad.data_ptr(), md.data_ptr() + 4 * 2 * D, 6 * D, rps, da.data_ptr(),
+                                dmod.data_ptr() + 4 * 2 * D, 6 * D, B, D, stream()))
+    gate = mod[:, 2 * D:3 * D]
+    assert_close(da.cpu(), dx * gate.repeat_interleave(rps, 0), what="d_a", **G_TOL)
+    assert_close(dmod[:, 2 * D:3 * D].cpu(), (dx * a).view(B, rps, D).sum(1).double(), what="d_gate", **G_TOL)
+    assert dmod[:, :2 * D].abs().max() == 0 and dmod[:, 3 * D:].abs().max() == 0
+    for M, N in [(2560, 1536), (37, 7), (1, 100), (130, 64)]:
+        X = rnd(M, N + 3, seed=M)
+        out0 = rnd(N, seed=N)
+        out = dev(out0).clone()
+        lib.check(L.mdt_op_colsum(dev(X).data_ptr(), N + 3, M, N, out.data_ptr(), 1, stream()))
+        assert_close(out.cpu() - out0, X[:, :N].double().sum(0), rtol=1e-4, atol=1e-4, what=f"colsum {M}x{N}")
+
+
+@pytest.mark.parametrize("M,N,K", [(2560, 1536, 384), (1280, 384, 1536), (1024, 1152, 384), (250, 384, 384), (37, 768, 512),
+                                   (3, 64, 128), (128, 9216, 384)])
+def test_linear_backward_through_the_forward_gemm(lib, M, N, K):
+    X, W, dY = rnd(M, K, seed=41), rnd(N, K, seed=42) / K ** 0.5, rnd(M, N, seed=43)
+    L = lib.load()
+    Xd, dYd = dev(X), dev(dY)
+    Wt = torch.zeros(N * K, device="cuda")
+    lib.check(L.mdt_op_pack_weight_t(dev(W).data_ptr(), N, K, K, Wt.data_ptr(), 0, N, stream()))
+    Mp = (M + 15) // 16 * 16
+    scratch = torch.empty((N + K) * Mp, device="cuda")
+    dW0, dX0 = rnd(N, K, seed=44), rnd(M, K, seed=45)
+    dW, dX = dev(dW0).clone(), dev(dX0).clone()
+    db = torch.zeros(N, device="cuda")
+    a = lib.LinearBwdArgs(X=Xd.data_ptr(), ldx=K, dY=dYd.data_ptr(), ldy=N, Wt=Wt.data_ptr(), dW=dW.data_ptr(),
+                          dbias=db.data_ptr(), dX=dX.data_ptr(), ldxo=K, accumulate_dw=1, accumulate_dx=1, M=M, N=N, K=K,
+                          scratch=scratch.data_ptr())
+    lib.check(L.mdt_op_linear_bwd(C.byref(a), stream()))
+    ref_dW = dY.double().T @ X.double()
+    ref_dX = dY.double() @ W.double()
+    tol = dict(rtol=1e-3, atol=1e-4 * max(1.0, (M / 64) ** 0.5))
+    assert_close(dW.cpu() - dW0, ref_dW, what="dW", **tol)
+    assert_close(dX.cpu() - dX0, ref_dX, what="dX", rtol=1e-3, atol=1e-4)
+    assert_close(db.cpu(), dY.double().sum(0), what="dbias", rtol=1e-3, atol=1e-4 * max(1.0, (M / 64) ** 0.5))

@@ -1,0 +1,162 @@
+"""Training path: gradients of GCDenoiser.loss (+ a scalar hung on latent_encoder_emb).
+CPU: autograd through the oracle vs the golden gradient summaries of the REFERENCE's own loss.backward()
+(tests/golden/g11_grads_*.npz).  GPU: the HIP forward/backward behind torch.autograd vs both."""
+import numpy as np
+import pytest
+import torch
+
+from mdt_policy_amd import synthetic
+from oracle import mdt_oracle as O
+from tests.helpers import assert_close, cfg_of, inputs_of, load_fixture, params_of
+
+CASES = ["mdtv_tiny", "mdt_tiny", "mdtv_bias_plain_goal", "mdtv_default"]
+
+
+def case(name):
+    meta, fx = load_fixture(f"g11_grads_{name}.npz")
+    cfg = cfg_of(meta)
+    state, goal, _ = inputs_of(meta)
+    li = {k: torch.from_numpy(v) for k, v in synthetic.loss_inputs(meta["B"], cfg, meta["loss_seed"]).items()}
+    return meta, fx, cfg, state, goal, li
+
+
+def summary(g):
+    g = g.detach().double().cpu()
+    return [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
+
+
+def check_summaries(got, want, what, rtol=2e-3):
+    """got / want: {name: [norm, sum, first 6]}; compared relative to the gradient's own scale."""
+    assert set(k for k, v in want.items() if v is not None) == set(got), what
+    for k, w in want.items():
+        if w is None:
+            continue
+        g = np.array(got[k]); w = np.array(w)
+        # floor: gradients that are mathematically zero (key biases: softmax is shift invariant) are fp32 noise
+        tol = rtol * abs(w[0]) + 1e-6
+        assert abs(g[0] - w[0]) <= tol, f"{what} {k}: norm {g[0]} vs {w[0]}"
+        assert np.all(np.abs(g[1:] - w[1:]) <= tol), f"{what} {k}: {g[1:]} vs {w[1:]}"
+
+
+def oracle_total(P, cfg, meta, state, goal, li, dtype):
+    """loss + 0.1 * <ctx, w> / numel, as the fixture was generated."""
+    st = {k: (v.to(dtype) if torch.is_tensor(v) else v) for k, v in state.items()}
+    loss, _ = O.loss(P, cfg, st, li["actions"].to(dtype), goal, li["noise_train"].to(dtype), li["sigma"].to(dtype),
+                     arch=meta["arch"])
+    entry = "forward"
+    ctx = O.encode(P, cfg, st, goal, meta["arch"], entry)
+    wctx = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), meta["ctx_seed"])).to(dtype)
+    return loss, loss + 0.1 * (ctx * wctx).sum() / ctx.numel()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_autograd_matches_the_reference_gradients(name):
+    meta, fx, cfg, state, goal, li = case(name)
+    P = {k: v.double().requires_grad_(v.dtype.is_floating_point) for k, v in params_of(meta).items()}
+    state = {k: (v.double().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+    goal = goal.double().requires_grad_()
+    loss, total = oracle_total(P, cfg, meta, state, goal, li, torch.float64)
+    total.backward()
+    assert abs(loss.item() - float(np.asarray(fx["loss"]).reshape(-1)[0])) <= 1e-4 * abs(float(np.asarray(fx["loss"]).reshape(-1)[0]))
+    got = {k[len("inner_model."):]: summary(v.grad) for k, v in P.items() if v.grad is not None}
+    want = {k[len("inner_model."):]: v for k, v in meta["grads"].items()}
+    # the oracle holds lang_emb as an alias of goal_emb when there is no modality encoder: fold its gradient in
+    check_summaries({k: v for k, v in got.items() if k in want and want[k] is not None}, want, name)
+    for k, v in state.items():
+        if torch.is_tensor(v):
+            assert_close(v.grad, fx["d_" + k], rtol=2e-3, atol=1e-7, what="d_" + k)
+    assert_close(goal.grad, fx["d_goal"], rtol=2e-3, atol=1e-7, what="d_goal")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_gradients_match_reference_and_oracle(name):
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, state, goal, li = case(name)
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()  # eval(): dropout off (the fixture's reference run was in eval mode too)
+    gstate = {k: (v.cuda().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+    ggoal = goal.cuda().requires_grad_()
+    loss, mo = model.loss(gstate, li["actions"].cuda(), ggoal, li["noise_train"].cuda(), li["sigma"].cuda())
+    ctx = model.inner_model.latent_encoder_emb
+    wctx = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), meta["ctx_seed"])).cuda()
+    total = loss + 0.1 * (ctx * wctx).sum() / ctx.numel()
+    total.backward()
+    assert abs(loss.item() - float(np.asarray(fx["loss"]).reshape(-1)[0])) <= 1e-3 * abs(float(np.asarray(fx["loss"]).reshape(-1)[0]))
+    got = {k: summary(p.grad) for k, p in model.inner_model.named_parameters() if p.grad is not None}
+    want = {k[len("inner_model."):]: v for k, v in meta["grads"].items()}
+    check_summaries(got, want, name + " vs reference")
+    for k, v in gstate.items():
+        if torch.is_tensor(v):
+            assert_close(v.grad.cpu(), fx["d_" + k], rtol=2e-3, atol=1e-6, what="d_" + k)
+    assert_close(ggoal.grad.cpu(), fx["d_goal"], rtol=2e-3, atol=1e-6, what="d_goal")
+    # full tensors against float64 autograd through the oracle
+    P = {k: v.double().requires_grad_(v.dtype.is_floating_point) for k, v in params_of(meta).items()}
+    st64 = {k: (v.double() if torch.is_tensor(v) else v) for k, v in state.items()}
+    _, tot64 = oracle_total(P, cfg, meta, st64, goal.double(), li, torch.float64)
+    tot64.backward()
+    for k, p in model.inner_model.named_parameters():
+        ref = P["inner_model." + k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        scale = float(ref.abs().max())
+        assert_close(p.grad.cpu(), ref, rtol=2e-3, atol=2e-3 * scale + 1e-7, what=k)  # floor: key-bias gradients are exactly 0 in theory
+
+
+@pytest.mark.gpu
+def test_hip_training_steps_follow_the_oracle():
+    """Five AdamW steps on the facade (HIP forward/backward, torch optimizer) against the same five steps on the
+    oracle with torch autograd: losses and a few weights stay together."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, state, goal, li = case("mdtv_tiny")
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in params_of(meta).items()}
+    used = [k for k in P if "proprio_emb" not in k and "rotary" not in k and k != "inner_model.pos_emb"]
+    opt_h = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05)
+    opt_o = torch.optim.AdamW([P[k] for k in used], lr=1e-3, weight_decay=0.05)
+    gstate = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    for step in range(5):
+        opt_h.zero_grad(); opt_o.zero_grad()
+        lh, _ = model.loss(gstate, li["actions"].cuda(), goal.cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
+        lh.backward(); opt_h.step()
+        lo, _ = O.loss(P, cfg, state, li["actions"], goal, li["noise_train"], li["sigma"], arch="mdtv")
+        lo.backward(); opt_o.step()
+        assert abs(lh.item() - lo.item()) <= 2e-3 * abs(lo.item()), (step, lh.item(), lo.item())
+    sd = model.state_dict()
+    for k in ("inner_model.decoder.blocks.1.mlp.c_fc.weight", "inner_model.encoder.blocks.0.attn.query.weight",
+              "inner_model.sigma_emb.1.weight", "inner_model.action_pred.weight"):
+        assert_close(sd[k].cpu(), P[k].detach(), rtol=1e-3, atol=1e-4, what=k)
+    assert lh.item() < float(np.asarray(fx["loss"]).reshape(-1)[0])  # it learns
+
+
+@pytest.mark.gpu
+def test_hip_context_only_backward_and_tape_rules():
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, state, goal, li = case("mdtv_tiny")
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    gstate = {k: (v.cuda().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+    # two forwards alive at once (the reference's training step: loss + forward_context_only, then ONE backward)
+    loss, _ = model.loss(gstate, li["actions"].cuda(), goal.cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
+    ctx = model.forward_context_only(gstate, li["actions"].cuda(), goal.cuda(), li["sigma"].cuda())
+    w = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), 7)).cuda()
+    (loss + (ctx * w).mean()).backward()
+    P = {k: v.double().requires_grad_(v.dtype.is_floating_point) for k, v in params_of(meta).items()}
+    st64 = {k: (v.double().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+    l64, _ = O.loss(P, cfg, st64, li["actions"].double(), goal.double(), li["noise_train"].double(), li["sigma"].double())
+    c64 = O.forward_context_only(P, cfg, st64, goal.double())
+    (l64 + (c64 * w.cpu().double()).mean()).backward()
+    for k in ("tok_emb.weight", "encoder.blocks.0.mlp.c_proj.weight", "lang_emb.2.bias", "decoder.blocks.0.cross_att.key.weight"):
+        ref = P["inner_model." + k].grad
+        got = dict(model.inner_model.named_parameters())[k].grad
+        assert_close(got.cpu(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()), what=k)
+    assert_close(gstate["state_images"].grad.cpu(), st64["state_images"].grad, rtol=2e-3, atol=1e-6, what="d_tokens")
+    # under no_grad nothing is taped and the plain forward path answers
+    with torch.no_grad():
+        l2, _ = model.loss(gstate, li["actions"].cuda(), goal.cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
+    assert abs(l2.item() - loss.item()) < 1e-4 * abs(loss.item())
