@@ -85,7 +85,26 @@ class AttnBwdArgs(C.Structure):
                 ("d_out", C.c_void_p), ("ld_do", C.c_int64), ("dq", C.c_void_p), ("ld_dq", C.c_int64),
                 ("dk", C.c_void_p), ("dv", C.c_void_p), ("ld_dkv", C.c_int64), ("accumulate_kv", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("hd", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32),
-                ("causal", C.c_int32)]
+                ("causal", C.c_int32), ("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class AttnTrainArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("ldq", C.c_int64), ("k", C.c_void_p), ("v", C.c_void_p), ("ldkv", C.c_int64),
+                ("out", C.c_void_p), ("ldo", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("hd", C.c_int32),
+                ("Tq", C.c_int32), ("Tk", C.c_int32), ("causal", C.c_int32), ("p", C.c_float), ("site", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class MergeArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("a", C.c_void_p), ("gate", C.c_void_p), ("gate_stride", C.c_int64),
+                ("out", C.c_void_p), ("dgate", C.c_void_p), ("dgate_stride", C.c_int64), ("B", C.c_int32),
+                ("rows_per_sample", C.c_int32), ("D", C.c_int32), ("p", C.c_float), ("site", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class Dropout(C.Structure):
+    """mirrors mdt_dropout (include/mdt_hip_train.h)"""
+    _fields_ = [("attn_p", C.c_float), ("resid_p", C.c_float), ("mlp_p", C.c_float), ("seed", C.c_uint64)]
 
 
 class LinearBwdArgs(C.Structure):
@@ -140,9 +159,10 @@ SYMBOLS = [
     ("mdt_train_prepare", _I32, [_VP]),
     ("mdt_grad_numel", _I64, [_VP]),
     ("mdt_grad_offset", _I64, [_VP, _I64]),
-    ("mdt_train_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, C.POINTER(_I32), _VP]),
+    ("mdt_train_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, C.POINTER(Dropout), _VP, _VP, _VP,
+                                  C.POINTER(_I32), _VP]),
     ("mdt_train_loss_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    ("mdt_train_encode_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _I64, _VP, C.POINTER(_I32), _VP]),
+    ("mdt_train_encode_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(Dropout), _VP, C.POINTER(_I32), _VP]),
     ("mdt_train_encode_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("mdt_tape_release", _I32, [_VP, _I32]),
     ("mdt_op_pack_weight_t", _I32, [_VP, _I64, _I64, _I64, _VP, _I64, _I64, _VP]),
@@ -151,7 +171,9 @@ SYMBOLS = [
     ("mdt_op_attn_bwd", _I32, [C.POINTER(AttnBwdArgs), _VP]),
     ("mdt_op_act_fwd", _I32, [_VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_act_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP]),
-    ("mdt_op_gate_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP, _VP, _I64, _I32, _I32, _VP]),
+    ("mdt_op_attn_fwd_train", _I32, [C.POINTER(AttnTrainArgs), _VP]),
+    ("mdt_op_merge_fwd", _I32, [C.POINTER(MergeArgs), _VP]),
+    ("mdt_op_merge_bwd", _I32, [C.POINTER(MergeArgs), _VP]),
     ("mdt_op_colsum", _I32, [_VP, _I64, _I64, _I64, _VP, _I32, _VP]),
     ("mdt_op_linear_bwd", _I32, [C.POINTER(LinearBwdArgs), _VP]),
     # include/mdt_resampler.h

@@ -83,3 +83,27 @@ __device__ __forceinline__ float apply_act_grad1(float v, int act) {
            : act == MDT_ACT_SILU ? act_silu_grad(v)
                                  : 1.0f;
 }
+
+// ------------------------------------------------------------------------------------------------
+// counter-based dropout masks (training): Philox4x32-10 keyed by the call's 64-bit seed, counter =
+// (element index, site id).  The backward regenerates the mask from the same (seed, site, index), so no mask is
+// ever stored.  keep(element) <=> uniform >= p; kept values are scaled by 1 / (1 - p) (nn.Dropout / SDPA dropout_p).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint32_t site, uint64_t idx) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = site, c3 = 0x9e3779b9u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+// multiplier of element idx: 0 (dropped) or 1 / (1 - p); p == 0 or seed == 0 -> 1
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t site, uint64_t idx, float p) {
+    if (p <= 0.f || seed == 0) return 1.f;
+    const float u = (float)(philox_u32(seed, site, idx) >> 8) * (1.0f / 16777216.0f);  // [0, 1) on a 24-bit grid
+    return u >= p ? 1.0f / (1.0f - p) : 0.f;
+}

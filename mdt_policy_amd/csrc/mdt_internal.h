@@ -98,10 +98,9 @@ hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);
 hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s);
 hipError_t mdt_launch_act_fwd(const float* u, float* out, int64_t n, int act, hipStream_t s);
 hipError_t mdt_launch_act_bwd(const float* u, const float* dy, float* du, int64_t n, int act, hipStream_t s);
-hipError_t mdt_launch_gate_residual(const float* x, const float* av, const float* gate, int64_t gstride, int rps, float* out,
-                                    int M, int D, hipStream_t s);
-hipError_t mdt_launch_gate_bwd(const float* dx, const float* av, const float* gate, int64_t gstride, int rps, float* da,
-                               float* dgate, int64_t dgstride, int B, int D, hipStream_t s);
+hipError_t mdt_launch_merge_fwd(const mdt_merge_args& a, hipStream_t s);
+hipError_t mdt_launch_merge_bwd(const mdt_merge_args& a, hipStream_t s);
+hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s);
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s);
 hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s);
 hipError_t mdt_launch_loss_grad(const float* F, const float* act, const float* noised, const float* sigma, float sd,

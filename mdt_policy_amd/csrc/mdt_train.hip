@@ -8,8 +8,8 @@
 //
 // Structure: the forward runs the SAME kernels as inference, un-fused where the backward needs the intermediate
 // (LayerNorm output, pre-GELU, the un-gated branch outputs); every dense contraction of the backward runs on the
-// forward's fp32-MFMA GEMM (mdt_linear_bwd, mdt_train_ops.hip).  Eval-mode arithmetic: dropout probabilities are
-// not part of this ABI yet (the facade refuses train-mode dropout > 0).
+// forward's fp32-MFMA GEMM (mdt_linear_bwd, mdt_train_ops.hip).  Dropout (attention probabilities, attention /
+// MLP branch outputs) uses counter-based masks (mdt_device.h: dropout_scale) that the backward regenerates.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -24,9 +24,9 @@
 namespace {
 
 struct BlockTape {  // one transformer block; rows M = B*T
-    float *x_in, *st1, *h1, *qkv, *att, *a1, *x1;          // self-attention half (a1: decoder only, un-gated branch)
-    float *st3, *h3, *q, *att2, *x2;                        // cross-attention half (decoder only)
-    float *st2, *h2, *u, *hid, *mo, *x3;                    // MLP half (mo: decoder only)
+    float *x_in, *st1, *h1, *qkv, *att, *a1, *x1;          // self-attention half (a1: branch output before gate/dropout)
+    float *st3, *h3, *q, *att2, *a2, *x2;                   // cross-attention half (decoder only)
+    float *st2, *h2, *u, *hid, *mo, *x3;                    // MLP half (mo: branch output before gate/dropout)
 };
 
 struct Tape {
@@ -34,6 +34,7 @@ struct Tape {
     bool has_decoder = false;
     int64_t B = 0, cap = 0;
     int lang = 0;  // 1: the goal went through lang_emb
+    mdt_dropout drop = {0.f, 0.f, 0.f, 0};
     float* buf = nullptr;
     // inputs
     float *tokens, *tokens2, *goal, *action, *noised, *sigma;
@@ -127,16 +128,17 @@ extern "C" int64_t mdt_grad_offset(const mdt_model* m, int64_t i) {
 static void carve_block(const mdt_model* m, Bump& b, BlockTape& t, int64_t M, bool dec) {
     const int D = m->D;
     t.x_in = b.take(M * D); t.st1 = b.take(M * 2); t.h1 = b.take(M * D); t.qkv = b.take(M * 3 * D); t.att = b.take(M * D);
-    t.a1 = dec ? b.take(M * D) : nullptr;
+    t.a1 = b.take(M * D);
     t.x1 = b.take(M * D);
     if (dec) {
-        t.st3 = b.take(M * 2); t.h3 = b.take(M * D); t.q = b.take(M * D); t.att2 = b.take(M * D); t.x2 = b.take(M * D);
+        t.st3 = b.take(M * 2); t.h3 = b.take(M * D); t.q = b.take(M * D); t.att2 = b.take(M * D); t.a2 = b.take(M * D);
+        t.x2 = b.take(M * D);
     } else {
-        t.st3 = t.h3 = t.q = t.att2 = nullptr;
+        t.st3 = t.h3 = t.q = t.att2 = t.a2 = nullptr;
         t.x2 = t.x1;
     }
     t.st2 = b.take(M * 2); t.h2 = b.take(M * D); t.u = b.take(M * 4 * D); t.hid = b.take(M * 4 * D);
-    t.mo = dec ? b.take(M * D) : nullptr;
+    t.mo = b.take(M * D);
     t.x3 = b.take(M * D);
 }
 
@@ -251,54 +253,69 @@ static mdt_ln_train_args ln_args(const float* x, const float* w, const float* b,
     return a;
 }
 
-// one block forward; mod == nullptr: plain Block (encoder), else ConditionedBlock rows of `mod` (stride modw)
+// dropout sites: one id per (block, place); the element index inside a site is the place's own flat index
+enum { SITE_ATTN = 0, SITE_RESID = 1, SITE_MLP = 2, SITE_XATTN = 3, SITE_XRESID = 4 };
+static uint32_t site_id(int block, int place) { return (uint32_t)(block * 8 + place + 1); }
+
+static mdt_merge_args merge_args(const float* x, const float* a, const float* gate, int64_t gstride, float* out, int64_t B,
+                                 int T, int D, float p, uint32_t site, uint64_t seed) {
+    mdt_merge_args g;
+    memset(&g, 0, sizeof g);
+    g.x = x; g.a = a; g.gate = gate; g.gate_stride = gstride; g.out = out; g.B = (int)B; g.rows_per_sample = T; g.D = D;
+    g.p = p; g.site = site; g.seed = seed;
+    return g;
+}
+
+static mdt_status attn_fwd(mdt_model* m, const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out,
+                           int64_t B, int Tq, int Tk, bool causal, const mdt_dropout& dr, uint32_t site, hipStream_t s) {
+    if (dr.seed != 0 && dr.attn_p > 0.f) {
+        mdt_attn_train_args a;
+        memset(&a, 0, sizeof a);
+        a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.out = out; a.ldo = m->D;
+        a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
+        a.p = dr.attn_p; a.site = site; a.seed = dr.seed;
+        LAUNCH(mdt_launch_attn_fwd_train(a, s));
+        return MDT_OK;
+    }
+    mdt_attn_args a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.out = out; a.ldo = m->D;
+    a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
+    LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
+    return MDT_OK;
+}
+
+// one block forward; mod == nullptr: plain Block (encoder), else ConditionedBlock rows of `mod` (stride modw).
+// `blk` numbers the block for the dropout sites (encoder blocks first, then decoder blocks).
 static mdt_status block_fwd(mdt_model* m, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T, bool causal,
-                            const float* mod, int64_t modw, const float* kv, hipStream_t s) {
+                            const float* mod, int64_t modw, const float* kv, const mdt_dropout& dr, int blk, hipStream_t s) {
     const int D = m->D, M = (int)(B * T);
     mdt_ln_train_args l1 = ln_args(t.x_in, e.ln1_w, e.ln1_b, t.h1, t.st1, M, D);
     if (mod) { l1.mod = mod; l1.mod_stride = modw; l1.shift_off = 0; l1.scale_off = D; l1.rows_per_sample = T; }
     LAUNCH(mdt_launch_ln_fwd_train(l1, s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.h1, D, e.qkv, t.qkv, 3 * D, M), s));
-    mdt_attn_args a;
-    memset(&a, 0, sizeof a);
-    a.q = t.qkv; a.ldq = 3 * D; a.k = t.qkv + D; a.v = t.qkv + 2 * D; a.ldkv = 3 * D;
-    a.out = t.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T; a.causal = causal;
-    LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
+    MDT_TRY(attn_fwd(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, t.att, B, T, T, causal, dr, site_id(blk, SITE_ATTN), s));
+    LAUNCH(mdt_launch_gemm(gemm_args(t.att, D, e.proj, t.a1, D, M), s));
+    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x_in, t.a1, mod ? mod + 2 * D : nullptr, modw, t.x1, B, T, D, dr.resid_p,
+                                           site_id(blk, SITE_RESID), dr.seed), s));
     if (d) {
-        LAUNCH(mdt_launch_gemm(gemm_args(t.att, D, e.proj, t.a1, D, M), s));
-        LAUNCH(mdt_launch_gate_residual(t.x_in, t.a1, mod + 2 * D, modw, T, t.x1, M, D, s));
         mdt_ln_train_args l3 = ln_args(t.x1, d->ln3_w, d->ln3_b, t.h3, t.st3, M, D);
         LAUNCH(mdt_launch_ln_fwd_train(l3, s));
         LAUNCH(mdt_launch_gemm(gemm_args(t.h3, D, d->xq, t.q, D, M), s));
-        mdt_attn_args x;
-        memset(&x, 0, sizeof x);
-        x.q = t.q; x.ldq = D; x.k = kv; x.v = kv + D; x.ldkv = (int64_t)m->Ld * 2 * D;
-        x.out = t.att2; x.ldo = D; x.B = (int)B; x.H = m->H; x.hd = m->hd; x.Tq = T; x.Tk = m->Te; x.causal = 1;
-        LAUNCH(mdt_launch_attention(x, m->rope_cos, m->rope_sin, s));
-        HIP_TRY(hipMemcpyAsync(t.x2, t.x1, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-        mdt_gemm_args p = gemm_args(t.att2, D, d->xproj, t.x2, D, M);
-        p.residual = 1;
-        LAUNCH(mdt_launch_gemm(p, s));
-    } else {
-        HIP_TRY(hipMemcpyAsync(t.x1, t.x_in, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-        mdt_gemm_args p = gemm_args(t.att, D, e.proj, t.x1, D, M);
-        p.residual = 1;
-        LAUNCH(mdt_launch_gemm(p, s));
+        // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
+        MDT_TRY(attn_fwd(m, t.q, D, kv, kv + D, (int64_t)m->Ld * 2 * D, t.att2, B, T, m->Te, true, dr, site_id(blk, SITE_XATTN), s));
+        LAUNCH(mdt_launch_gemm(gemm_args(t.att2, D, d->xproj, t.a2, D, M), s));
+        LAUNCH(mdt_launch_merge_fwd(merge_args(t.x1, t.a2, nullptr, 0, t.x2, B, T, D, dr.resid_p, site_id(blk, SITE_XRESID),
+                                               dr.seed), s));
     }
     mdt_ln_train_args l2 = ln_args(t.x2, e.ln2_w, e.ln2_b, t.h2, t.st2, M, D);
     if (mod) { l2.mod = mod; l2.mod_stride = modw; l2.shift_off = 3 * D; l2.scale_off = 4 * D; l2.rows_per_sample = T; }
     LAUNCH(mdt_launch_ln_fwd_train(l2, s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.h2, D, e.fc, t.u, 4 * D, M), s));
     LAUNCH(mdt_launch_act_fwd(t.u, t.hid, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
-    if (d) {
-        LAUNCH(mdt_launch_gemm(gemm_args(t.hid, 4 * D, e.proj2, t.mo, D, M), s));
-        LAUNCH(mdt_launch_gate_residual(t.x2, t.mo, mod + 5 * D, modw, T, t.x3, M, D, s));
-    } else {
-        HIP_TRY(hipMemcpyAsync(t.x3, t.x2, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-        mdt_gemm_args p = gemm_args(t.hid, 4 * D, e.proj2, t.x3, D, M);
-        p.residual = 1;
-        LAUNCH(mdt_launch_gemm(p, s));
-    }
+    LAUNCH(mdt_launch_gemm(gemm_args(t.hid, 4 * D, e.proj2, t.mo, D, M), s));
+    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x2, t.mo, mod ? mod + 5 * D : nullptr, modw, t.x3, B, T, D, dr.mlp_p,
+                                           site_id(blk, SITE_MLP), dr.seed), s));
     return MDT_OK;
 }
 
@@ -347,7 +364,7 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
     }
     for (int l = 0; l < m->Le; ++l) {
         if (l > 0) t.enc[l].x_in = t.enc[l - 1].x3;  // chain: a block's input is its predecessor's output buffer
-        MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, 0, nullptr, s));
+        MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, 0, nullptr, t.drop, l, s));
     }
     mdt_ln_train_args lf = ln_args(enc_last_output(m, t), m->enc_ln_w, m->enc_ln_b, t.ctx, t.st_f, (int)(B * Te), D);
     LAUNCH(mdt_launch_ln_fwd_train(lf, s));
@@ -379,7 +396,7 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     for (int l = 0; l < m->Ld; ++l) {
         t.dec[l].x_in = l == 0 ? t.y0 : t.dec[l - 1].x3;
         MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, t.mod + (int64_t)l * 6 * D, modw,
-                          t.kvx + (int64_t)l * 2 * D, s));
+                          t.kvx + (int64_t)l * 2 * D, t.drop, m->Le + l, s));
     }
     float* xl = t.dec[m->Ld - 1].x3;
     mdt_ln_train_args lh = ln_args(xl, m->dec_ln_w, m->dec_ln_b, t.lnout, t.st_h, (int)Ma, D);
@@ -396,6 +413,19 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     return MDT_OK;
 }
 
+static mdt_status check_dropout(const mdt_dropout* d) {
+    if (!d) return MDT_OK;
+    for (float p : {d->attn_p, d->resid_p, d->mlp_p})
+        if (!(p >= 0.f && p < 1.f)) return fail(MDT_ERR_INVALID_ARG, "dropout probabilities must be in [0, 1)");
+    return MDT_OK;
+}
+
+static mdt_dropout effective_dropout(const mdt_dropout* d) {
+    mdt_dropout z = {0.f, 0.f, 0.f, 0};
+    if (!d || d->seed == 0 || (d->attn_p <= 0.f && d->resid_p <= 0.f && d->mlp_p <= 0.f)) return z;
+    return *d;
+}
+
 static mdt_status check_ready(mdt_model* m) {
     if (!m) return fail(MDT_ERR_INVALID_ARG, "null handle");
     if (!m->train) return fail(MDT_ERR_STATE, "training was not prepared: call mdt_train_prepare() and upload the parameters");
@@ -405,12 +435,14 @@ static mdt_status check_ready(mdt_model* m) {
 }
 
 extern "C" mdt_status mdt_train_encode_fwd(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
-                                           int32_t modality, int32_t honour_modality, int64_t batch, float* ctx_out,
-                                           mdt_tape_id* tape, void* stream) {
+                                           int32_t modality, int32_t honour_modality, int64_t batch, const mdt_dropout* drop,
+                                           float* ctx_out, mdt_tape_id* tape, void* stream) {
     MDT_TRY(check_ready(m));
     if (!tokens || !goal || !tape || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_train_encode_fwd: bad argument");
     if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
+    MDT_TRY(check_dropout(drop));
     MDT_TRY(acquire_tape(m, batch, tape));
+    m->train->tapes[*tape].drop = effective_dropout(drop);
     mdt_status st = enc_fwd(m, m->train->tapes[*tape], tokens, tokens2, goal, modality, honour_modality, ctx_out,
                             (hipStream_t)stream);
     if (st != MDT_OK) m->train->tapes[*tape].in_use = false;
@@ -419,15 +451,17 @@ extern "C" mdt_status mdt_train_encode_fwd(mdt_model* m, const float* tokens, co
 
 extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
                                          int32_t modality, const float* action, const float* noise, const float* sigma,
-                                         int64_t batch, float* loss_out, float* model_output, float* ctx_out,
-                                         mdt_tape_id* tape, void* stream) {
+                                         int64_t batch, const mdt_dropout* drop, float* loss_out, float* model_output,
+                                         float* ctx_out, mdt_tape_id* tape, void* stream) {
     MDT_TRY(check_ready(m));
     if (!tokens || !goal || !action || !noise || !sigma || !loss_out || !tape || batch < 1)
         return fail(MDT_ERR_INVALID_ARG, "mdt_train_loss_fwd: bad argument");
     if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
     hipStream_t s = (hipStream_t)stream;
+    MDT_TRY(check_dropout(drop));
     MDT_TRY(acquire_tape(m, batch, tape));
     Tape& t = m->train->tapes[*tape];
+    t.drop = effective_dropout(drop);
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;  // MDTTransformer.forward always uses goal_emb (mdt_transformer.py:215)
     mdt_status st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, ctx_out, s);
     if (st == MDT_OK) st = dec_fwd(m, t, action, noise, sigma, loss_out, model_output, s);
@@ -490,50 +524,58 @@ static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float
     return MDT_OK;
 }
 
+static mdt_attn_bwd_args attn_bwd_args(mdt_model* m, const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                       const float* d_out, float* dq, int64_t ld_dq, float* dk, float* dv, int64_t ld_dkv,
+                                       int64_t B, int Tq, int Tk, bool causal, const mdt_dropout& dr, uint32_t site) {
+    mdt_attn_bwd_args a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.d_out = d_out; a.ld_do = m->D;
+    a.dq = dq; a.ld_dq = ld_dq; a.dk = dk; a.dv = dv; a.ld_dkv = ld_dkv; a.accumulate_kv = 0;
+    a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
+    a.p = dr.seed ? dr.attn_p : 0.f; a.site = site; a.seed = dr.seed;
+    return a;
+}
+
 // dx: gradient wrt the block's output on entry, wrt its input on return (in place)
 static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T,
                             bool causal, const float* mod, float* d_mod, int64_t modw, const float* kv, float* d_kv,
-                            float* dx, hipStream_t s) {
+                            float* dx, const mdt_dropout& dr, int blk, hipStream_t s) {
     mdt_train_state* ts = m->train;
     const int D = m->D, M = (int)(B * T);
-    // ---- MLP half: x3 = x2 + g2 * c_proj(gelu(c_fc(h2)))
-    const float* d_mo = dx;
-    if (d) {
-        LAUNCH(mdt_launch_gate_bwd(dx, t.mo, mod + 5 * D, modw, T, ts->t_d, d_mod + 5 * D, modw, (int)B, D, s));
-        d_mo = ts->t_d;
+    // ---- MLP half: x3 = x2 + g2 * drop(c_proj(gelu(c_fc(h2))))
+    {
+        mdt_merge_args g = merge_args(dx, t.mo, mod ? mod + 5 * D : nullptr, modw, ts->t_d, B, T, D, dr.mlp_p,
+                                      site_id(blk, SITE_MLP), dr.seed);
+        if (mod) { g.dgate = d_mod + 5 * D; g.dgate_stride = modw; }
+        LAUNCH(mdt_launch_merge_bwd(g, s));
     }
-    MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, d_mo, D, M, ts->t_4d, 4 * D, 0, s));
+    MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, ts->t_d, D, M, ts->t_4d, 4 * D, 0, s));
     LAUNCH(mdt_launch_act_bwd(t.u, ts->t_4d, ts->t_4d, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
     MDT_TRY(lin_bwd(m, grads, e.fc, t.h2, D, ts->t_4d, 4 * D, M, ts->t_d2, D, 0, s));
     MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, mod ? 3 * D : -1, mod ? 4 * D : -1, ts->t_d2, dx, 1,
                    d_mod, B, T, s));
     if (d) {
-        // ---- cross-attention half: x2 = x1 + c_proj(attn(q(ln3(x1)), K, V))
-        MDT_TRY(lin_bwd(m, grads, d->xproj, t.att2, D, dx, D, M, ts->t_d, D, 0, s));
-        mdt_attn_bwd_args x;
-        memset(&x, 0, sizeof x);
-        x.q = t.q; x.ldq = D; x.k = kv; x.v = kv + D; x.ldkv = (int64_t)m->Ld * 2 * D;
-        x.d_out = ts->t_d; x.ld_do = D; x.dq = ts->t_d2; x.ld_dq = D;
-        x.dk = d_kv; x.dv = d_kv + D; x.ld_dkv = (int64_t)m->Ld * 2 * D; x.accumulate_kv = 0;
-        x.B = (int)B; x.H = m->H; x.hd = m->hd; x.Tq = T; x.Tk = m->Te; x.causal = 1;
-        LAUNCH(mdt_launch_attn_bwd(x, s));
+        // ---- cross-attention half: x2 = x1 + drop(c_proj(attn(q(ln3(x1)), K, V)))
+        LAUNCH(mdt_launch_merge_bwd(merge_args(dx, t.a2, nullptr, 0, ts->t_d2, B, T, D, dr.resid_p, site_id(blk, SITE_XRESID),
+                                               dr.seed), s));
+        MDT_TRY(lin_bwd(m, grads, d->xproj, t.att2, D, ts->t_d2, D, M, ts->t_d, D, 0, s));
+        LAUNCH(mdt_launch_attn_bwd(attn_bwd_args(m, t.q, D, kv, kv + D, (int64_t)m->Ld * 2 * D, ts->t_d, ts->t_d2, D, d_kv,
+                                                 d_kv + D, (int64_t)m->Ld * 2 * D, B, T, m->Te, true, dr,
+                                                 site_id(blk, SITE_XATTN)), s));
         MDT_TRY(lin_bwd(m, grads, d->xq, t.h3, D, ts->t_d2, D, M, ts->t_d, D, 0, s));
         MDT_TRY(ln_bwd(m, grads, t.x1, t.st3, d->ln3_w, d->ln3_b, nullptr, 0, -1, -1, ts->t_d, dx, 1, nullptr, B, T, s));
     }
-    // ---- self-attention half: x1 = x_in + g1 * c_proj(attn(qkv(h1)))
-    const float* d_a = dx;
-    if (d) {
-        LAUNCH(mdt_launch_gate_bwd(dx, t.a1, mod + 2 * D, modw, T, ts->t_d, d_mod + 2 * D, modw, (int)B, D, s));
-        d_a = ts->t_d;
+    // ---- self-attention half: x1 = x_in + g1 * drop(c_proj(attn(qkv(h1))))
+    {
+        mdt_merge_args g = merge_args(dx, t.a1, mod ? mod + 2 * D : nullptr, modw, ts->t_d, B, T, D, dr.resid_p,
+                                      site_id(blk, SITE_RESID), dr.seed);
+        if (mod) { g.dgate = d_mod + 2 * D; g.dgate_stride = modw; }
+        LAUNCH(mdt_launch_merge_bwd(g, s));
     }
-    MDT_TRY(lin_bwd(m, grads, e.proj, t.att, D, d_a, D, M, ts->t_d2, D, 0, s));
-    mdt_attn_bwd_args a;
-    memset(&a, 0, sizeof a);
-    a.q = t.qkv; a.ldq = 3 * D; a.k = t.qkv + D; a.v = t.qkv + 2 * D; a.ldkv = 3 * D;
-    a.d_out = ts->t_d2; a.ld_do = D; a.dq = ts->t_3d; a.ld_dq = 3 * D;
-    a.dk = ts->t_3d + D; a.dv = ts->t_3d + 2 * D; a.ld_dkv = 3 * D; a.accumulate_kv = 0;
-    a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T; a.causal = causal;
-    LAUNCH(mdt_launch_attn_bwd(a, s));
+    MDT_TRY(lin_bwd(m, grads, e.proj, t.att, D, ts->t_d, D, M, ts->t_d2, D, 0, s));
+    LAUNCH(mdt_launch_attn_bwd(attn_bwd_args(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, ts->t_d2, ts->t_3d, 3 * D,
+                                             ts->t_3d + D, ts->t_3d + 2 * D, 3 * D, B, T, T, causal, dr, site_id(blk, SITE_ATTN)),
+                               s));
     MDT_TRY(lin_bwd(m, grads, e.qkv, t.h1, D, ts->t_3d, 3 * D, M, ts->t_d, D, 0, s));
     MDT_TRY(ln_bwd(m, grads, t.x_in, t.st1, e.ln1_w, e.ln1_b, mod, modw, mod ? 0 : -1, mod ? D : -1, ts->t_d, dx, 1, d_mod, B,
                    T, s));
@@ -552,7 +594,8 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
     MDT_TRY(ln_bwd(m, grads, enc_last_output(m, t), t.st_f, m->enc_ln_w, m->enc_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dxe, 0,
                    nullptr, B, Te, s));
     for (int l = m->Le - 1; l >= 0; --l)
-        MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, nullptr, 0, nullptr, nullptr, ts->dxe, s));
+        MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, nullptr, 0, nullptr, nullptr, ts->dxe,
+                          t.drop, l, s));
     // token embeddings: the forward scattered their rows into the context
     const Lin& g0 = t.lang ? m->lang0 : m->goal0;
     const Lin& g2 = t.lang ? m->lang2 : m->goal2;
@@ -620,7 +663,7 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     for (int l = m->Ld - 1; l >= 0; --l)
         MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, t.mod + (int64_t)l * 6 * D,
                           ts->d_mod + (int64_t)l * 6 * D, modw, t.kvx + (int64_t)l * 2 * D, ts->d_kvx + (int64_t)l * 2 * D, ts->dx,
-                          s));
+                          t.drop, m->Le + l, s));
     // ---- action embedding: y0 = action_emb(xin); no gradient flows to the noisy actions
     LAUNCH(mdt_launch_colsum(ts->dx, D, (int)Ma, D, grad_of(m, grads, m->ba), 1, s));
     LAUNCH(mdt_launch_narrow_dw(t.xin, ts->dx, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 1, s));

@@ -218,46 +218,41 @@ hipError_t mdt_launch_act_bwd(const float* u, const float* dy, float* du, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
-// gated residual   x_out = x + gate[sample] * a                              (transformer_blocks.py:296-307)
-// forward, and backward:  d_a = gate * d_x ;  d_gate[sample] = sum_rows d_x * a   (one workgroup per sample)
+// branch merge   x_out = x + gate[sample] * dropout(a)                      (transformer_blocks.py:156,176,296-307)
+// forward, and backward:  d_a = mask/(1-p) * gate * d_x ;  d_gate[sample] = sum_rows d_x * dropout(a)
+// (one workgroup per sample; gate / d_gate optional; the mask is regenerated from (seed, site, row*D + column))
 // ------------------------------------------------------------------------------------------------
-__global__ void k_gate_residual(const float* __restrict__ x, const float* __restrict__ av, const float* __restrict__ gate,
-                                int64_t gstride, int rps, float* __restrict__ out, int64_t n, int D) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t row = i / D;
-    const int c = (int)(i - row * D);
-    const float g = gate ? gate[(row / rps) * gstride + c] : 1.f;
-    out[i] = fmaf(g, av[i], x[i]);
-}
-hipError_t mdt_launch_gate_residual(const float* x, const float* av, const float* gate, int64_t gstride, int rps, float* out,
-                                    int M, int D, hipStream_t s) {
-    const int64_t n = (int64_t)M * D;
-    hipLaunchKernelGGL(k_gate_residual, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, av, gate, gstride,
-                       rps > 0 ? rps : 1, out, n, D);
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void k_gate_bwd(const float* __restrict__ dx, const float* __restrict__ av,
-                                                  const float* __restrict__ gate, int64_t gstride, int rps,
-                                                  float* __restrict__ da, float* __restrict__ dgate, int64_t dgstride,
-                                                  int D) {
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void k_merge_fwd(mdt_merge_args a) {
+    const int b = blockIdx.x, D = a.D, rps = a.rows_per_sample;
     for (int c = threadIdx.x; c < D; c += 256) {
-        const float g = gate[(int64_t)b * gstride + c];
+        const float g = a.gate ? a.gate[(int64_t)b * a.gate_stride + c] : 1.f;
+        for (int r = 0; r < rps; ++r) {
+            const int64_t i = ((int64_t)b * rps + r) * D + c;
+            const float av = a.a[i] * dropout_scale(a.seed, a.site, (uint64_t)i, a.p);
+            a.out[i] = fmaf(g, av, a.x[i]);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_merge_bwd(mdt_merge_args a) {
+    const int b = blockIdx.x, D = a.D, rps = a.rows_per_sample;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float g = a.gate ? a.gate[(int64_t)b * a.gate_stride + c] : 1.f;
         float acc = 0.f;
         for (int r = 0; r < rps; ++r) {
             const int64_t i = ((int64_t)b * rps + r) * D + c;
-            const float d = dx[i];
-            acc = fmaf(d, av[i], acc);
-            da[i] = g * d;
+            const float d = a.x[i], ds = dropout_scale(a.seed, a.site, (uint64_t)i, a.p);
+            acc = fmaf(d, a.a[i] * ds, acc);
+            a.out[i] = g * d * ds;
         }
-        dgate[(int64_t)b * dgstride + c] = acc;
+        if (a.dgate) a.dgate[(int64_t)b * a.dgate_stride + c] = acc;
     }
 }
-hipError_t mdt_launch_gate_bwd(const float* dx, const float* av, const float* gate, int64_t gstride, int rps, float* da,
-                               float* dgate, int64_t dgstride, int B, int D, hipStream_t s) {
-    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dx, av, gate, gstride, rps, da, dgate, dgstride, D);
+hipError_t mdt_launch_merge_fwd(const mdt_merge_args& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_fwd, dim3(a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t mdt_launch_merge_bwd(const mdt_merge_args& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_bwd, dim3(a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -298,6 +293,62 @@ hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* o
 //   P recomputed from q, k (same masking as k_attn);  dV = P^T dO ;  dP = dO V^T ;
 //   dS = P * (dP - rowsum(dP * P)) * scale ;  dQ = dS K ;  dK = dS^T Q        (F.scaled_dot_product_attention :142)
 // ------------------------------------------------------------------------------------------------
+// training forward with dropout on the probabilities: out = (mask/(1-p) * softmax(q k^T / sqrt(hd))) v
+template <int HD>
+__global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, float scale) {
+    __shared__ float qs[16][HD + 1], ks[16][HD + 1], vs[16][HD + 1];
+    __shared__ float P[16][17];
+    const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int Tq = a.Tq, Tk = a.Tk;
+    for (int i = lane; i < Tq * HD; i += 64) {
+        const int r = i / HD, d = i - r * HD;
+        qs[r][d] = a.q[((int64_t)b * Tq + r) * a.ldq + h * HD + d];
+    }
+    for (int i = lane; i < Tk * HD; i += 64) {
+        const int r = i / HD, d = i - r * HD;
+        ks[r][d] = a.k[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
+        vs[r][d] = a.v[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
+    }
+    __syncthreads();
+    if (lane < Tq) {
+        const int i = lane;
+        float sc[16];
+        float mx = -INFINITY;
+        for (int j = 0; j < Tk; ++j) {
+            float s = 0.f;
+            for (int d = 0; d < HD; ++d) s = fmaf(qs[i][d], ks[j][d], s);
+            sc[j] = (!a.causal || j <= i) ? s * scale : -INFINITY;
+            mx = fmaxf(mx, sc[j]);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < Tk; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+        const float inv = 1.f / sum;
+        const uint64_t base = (((uint64_t)b * a.H + h) * Tq + i) * Tk;
+        for (int j = 0; j < Tk; ++j) P[i][j] = sc[j] * inv * dropout_scale(a.seed, a.site, base + j, a.p);
+    }
+    __syncthreads();
+    for (int e = lane; e < Tq * HD; e += 64) {
+        const int i = e / HD, d = e - i * HD;
+        float acc = 0.f;
+        for (int j = 0; j < Tk; ++j) acc = fmaf(P[i][j], vs[j][d], acc);
+        a.out[((int64_t)b * Tq + i) * a.ldo + h * HD + d] = acc;
+    }
+}
+
+hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s) {
+    if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
+    const float scale = 1.0f / sqrtf((float)a.hd);
+    const dim3 grid(a.B, a.H);
+    switch (a.hd) {
+        case 16: hipLaunchKernelGGL((k_attn_fwd_train<16>), grid, dim3(64), 0, s, a, scale); break;
+        case 32: hipLaunchKernelGGL((k_attn_fwd_train<32>), grid, dim3(64), 0, s, a, scale); break;
+        case 48: hipLaunchKernelGGL((k_attn_fwd_train<48>), grid, dim3(64), 0, s, a, scale); break;
+        case 64: hipLaunchKernelGGL((k_attn_fwd_train<64>), grid, dim3(64), 0, s, a, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scale) {
     __shared__ float qs[16][HD + 1], ks[16][HD + 1], vs[16][HD + 1], os[16][HD + 1];
@@ -333,12 +384,17 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
         float sum = 0.f;
         for (int j = 0; j < Tk; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
         const float inv = 1.f / sum;
+        // with dropout: out = (m * P) V, m = mask/(1-p)  =>  dP = m * (dO V^T), dV uses m * P
+        const uint64_t base = (((uint64_t)b * a.H + h) * Tq + i) * Tk;
         float delta = 0.f;
-        for (int j = 0; j < Tk; ++j) { sc[j] *= inv; delta = fmaf(sc[j], dp[j], delta); }
         for (int j = 0; j < Tk; ++j) {
-            P[i][j] = sc[j];
-            dS[i][j] = sc[j] * (dp[j] - delta) * scale;
+            const float mk = dropout_scale(a.seed, a.site, base + j, a.p);
+            sc[j] *= inv;
+            dp[j] *= mk;
+            delta = fmaf(sc[j], dp[j], delta);
+            P[i][j] = sc[j] * mk;  // what multiplied V in the forward
         }
+        for (int j = 0; j < Tk; ++j) dS[i][j] = sc[j] * (dp[j] - delta) * scale;
     }
     __syncthreads();
     // dQ[i][d] = sum_j dS[i][j] K[j][d]

@@ -90,13 +90,23 @@ extern "C" mdt_status mdt_op_act_bwd(const float* u, const float* dy, float* du,
     return MDT_OK;
 }
 
-extern "C" mdt_status mdt_op_gate_bwd(const float* dx, const float* a, const float* gate, int64_t gate_stride,
-                                      int32_t rows_per_sample, float* da, float* dgate, int64_t dgate_stride, int32_t B,
-                                      int32_t D, void* stream) {
-    if (!dx || !a || !gate || !da || !dgate || B < 1 || rows_per_sample < 1)
-        return fail(MDT_ERR_INVALID_ARG, "mdt_op_gate_bwd: bad argument");
-    LAUNCH(mdt_launch_gate_bwd(dx, a, gate, gate_stride, rows_per_sample, da, dgate, dgate_stride, B, D,
-                               (hipStream_t)stream));
+extern "C" mdt_status mdt_op_merge_fwd(const mdt_merge_args* a, void* stream) {
+    if (!a || !a->x || !a->a || !a->out || a->B < 1 || a->rows_per_sample < 1)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_merge_fwd: bad argument");
+    LAUNCH(mdt_launch_merge_fwd(*a, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_merge_bwd(const mdt_merge_args* a, void* stream) {
+    if (!a || !a->x || !a->a || !a->out || a->B < 1 || a->rows_per_sample < 1)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_merge_bwd: bad argument");
+    LAUNCH(mdt_launch_merge_bwd(*a, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_attn_fwd_train(const mdt_attn_train_args* a, void* stream) {
+    if (!a || !a->q || !a->k || !a->v || !a->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_fwd_train: null argument");
+    LAUNCH(mdt_launch_attn_fwd_train(*a, (hipStream_t)stream));
     return MDT_OK;
 }
 

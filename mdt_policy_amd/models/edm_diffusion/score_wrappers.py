@@ -98,8 +98,8 @@ class GCDenoiser(nn.Module):
             eng = self._engine(allow_grad=True)
             tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal)
             a, nz = eng._in(action, (B, eng.Ta, eng.A)), eng._in(noise, (B, eng.Ta, eng.A))
-            loss, model_output, ctx = HipDiffusionLoss.apply(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)), names,
-                                                             *params)
+            loss, model_output, ctx = HipDiffusionLoss.apply(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)),
+                                                             im.train_dropout(), names, *params)
             im.latent_encoder_emb = ctx
             return loss, model_output
         loss, model_output, ctx = self._engine().loss_fwd(state, action, im._goals(goal, False), noise, sigma)
@@ -116,7 +116,7 @@ class GCDenoiser(nn.Module):
             if eng.sigma_in_context:
                 raise NotImplementedError("training with use_ada_conditioning=False is not implemented")
             tok, tok2, g, _, names, params = self._train_inputs(eng, state, goal)
-            ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, names, *params)
+            ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, im.train_dropout(), names, *params)
             if im._arch == "mdtv":
                 im.latent_encoder_emb = ctx
             return ctx

@@ -202,7 +202,7 @@ class HipEngine:
                              for i in range(n)}
         self._grad_numel = int(self.lib.mdt_grad_numel(self.handle))
 
-    def train_loss_fwd(self, state: dict, tok, tok2, goal, action, noise, sigma):
+    def train_loss_fwd(self, state: dict, tok, tok2, goal, action, noise, sigma, drop=None):
         self.train_prepare()
         self.sync_params()
         B = tok.shape[0]
@@ -211,18 +211,20 @@ class HipEngine:
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         tape = C.c_int32(-1)
         _lib.check(self.lib.mdt_train_loss_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
-                                               _ptr(action), _ptr(noise), _ptr(sigma), B, _ptr(loss), _ptr(mo), _ptr(ctx),
+                                               _ptr(action), _ptr(noise), _ptr(sigma), B,
+                                               None if drop is None else C.byref(drop), _ptr(loss), _ptr(mo), _ptr(ctx),
                                                C.byref(tape), self._stream()))
         return loss, mo, ctx, int(tape.value)
 
-    def train_encode_fwd(self, state: dict, tok, tok2, goal, honour_modality: bool):
+    def train_encode_fwd(self, state: dict, tok, tok2, goal, honour_modality: bool, drop=None):
         self.train_prepare()
         self.sync_params()
         B = tok.shape[0]
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         tape = C.c_int32(-1)
         _lib.check(self.lib.mdt_train_encode_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
-                                                 int(honour_modality), B, _ptr(ctx), C.byref(tape), self._stream()))
+                                                 int(honour_modality), B, None if drop is None else C.byref(drop),
+                                                 _ptr(ctx), C.byref(tape), self._stream()))
         return ctx, int(tape.value)
 
     def _input_grads(self, tok, tok2, goal, needs):
@@ -307,11 +309,24 @@ class HipScoreNetwork(nn.Module):
         self._engines = {}
         return out
 
+    def train_dropout(self):
+        """mdt_dropout of one train-mode forward (fresh seed from torch's CPU generator, so torch.manual_seed makes
+        runs repeatable), or None in eval mode / without dropout."""
+        embed_p, attn_p, resid_p, mlp_p, goal_p = (float(p) for p in self._pdrops)
+        if not self.training or max(attn_p, resid_p, mlp_p) <= 0:
+            return None
+        seed = int(torch.randint(1, 2 ** 62, (1,)).item())
+        return _lib.Dropout(attn_p=attn_p, resid_p=resid_p, mlp_p=mlp_p, seed=seed)
+
     def _guard_mode(self, allow_grad: bool = False):
-        if self.training and any(float(p) > 0 for p in self._pdrops):
+        embed_p, attn_p, resid_p, mlp_p, goal_p = (float(p) for p in self._pdrops)
+        if self.training and (embed_p > 0 or goal_p > 0):
+            raise NotImplementedError("train() mode with embed_pdrob / goal_drop > 0 is not implemented by the HIP path "
+                                      "(both are 0 in the shipped configurations)")
+        if self.training and max(attn_p, resid_p, mlp_p) > 0 and not (allow_grad and torch.is_grad_enabled()):
             raise NotImplementedError(
-                "train() mode with dropout > 0: the HIP path implements the eval-mode forward only "
-                "(training backward + dropout are SURVEY.md 8(f) item 1, not built yet); call .eval()")
+                "train() mode with dropout > 0 outside a training step: only GCDenoiser.loss / forward_context_only "
+                "under autograd apply dropout on the HIP path; call .eval() for inference")
         if not allow_grad and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # forward values are exact, but no autograd graph is recorded
             raise NotImplementedError(

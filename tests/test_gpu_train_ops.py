@@ -132,25 +132,119 @@ def test_activation_forward_backward(lib, act, fn):
     assert_close(du.cpu(), u64.grad, rtol=1e-4, atol=5e-6, what="act grad")
 
 
-def test_gate_backward_and_colsum(lib):
+def merge(lib, fn, x, a, gate, out, dgate, B, rps, D, p=0.0, site=0, seed=0, gate_col=0, ld=0):
+    g = lib.MergeArgs(x=x.data_ptr(), a=a.data_ptr(), gate=(gate.data_ptr() + 4 * gate_col) if gate is not None else None,
+                      gate_stride=ld, out=out.data_ptr(), dgate=(dgate.data_ptr() + 4 * gate_col) if dgate is not None else None,
+                      dgate_stride=ld, B=B, rows_per_sample=rps, D=D, p=p, site=site, seed=seed)
+    lib.check(getattr(lib.load(), fn)(C.byref(g), stream()))
+
+
+def test_merge_gate_backward_and_colsum(lib):
     B, rps, D = 6, 10, 384
-    dx, a, mod = rnd(B * rps, D, seed=31), rnd(B * rps, D, seed=32), rnd(B, 6 * D, seed=33)
-    dxd, ad, md = dev(dx), dev(a), dev(mod)
+    x, a, mod = rnd(B * rps, D, seed=31), rnd(B * rps, D, seed=32), rnd(B, 6 * D, seed=33)
+    xd, ad, md = dev(x), dev(a), dev(mod)
+    out = torch.empty(B * rps, D, device="cuda")
+    merge(lib, "mdt_op_merge_fwd", xd, ad, md, out, None, B, rps, D, gate_col=2 * D, ld=6 * D)
+    gate = mod[:, 2 * D:3 * D].repeat_interleave(rps, 0)
+    assert_close(out.cpu(), x + gate * a, what="x + g a")
+    merge(lib, "mdt_op_merge_fwd", xd, ad, None, out, None, B, rps, D)
+    assert_close(out.cpu(), x + a, what="x + a")
+    dx = rnd(B * rps, D, seed=34)
     da = torch.empty(B * rps, D, device="cuda")
     dmod = torch.zeros(B, 6 * D, device="cuda")
-    L = lib.load()
-    lib.check(L.mdt_op_gate_bwd(dxd.data_ptr(), ad.data_ptr(), md.data_ptr() + 4 * 2 * D, 6 * D, rps, da.data_ptr(),
-                                dmod.data_ptr() + 4 * 2 * D, 6 * D, B, D, stream()))
-    gate = mod[:, 2 * D:3 * D]
-    assert_close(da.cpu(), dx * gate.repeat_interleave(rps, 0), what="d_a", **G_TOL)
+    merge(lib, "mdt_op_merge_bwd", dev(dx), ad, md, da, dmod, B, rps, D, gate_col=2 * D, ld=6 * D)
+    assert_close(da.cpu(), dx * gate, what="d_a", **G_TOL)
     assert_close(dmod[:, 2 * D:3 * D].cpu(), (dx * a).view(B, rps, D).sum(1).double(), what="d_gate", **G_TOL)
     assert dmod[:, :2 * D].abs().max() == 0 and dmod[:, 3 * D:].abs().max() == 0
+    L = lib.load()
     for M, N in [(2560, 1536), (37, 7), (1, 100), (130, 64)]:
         X = rnd(M, N + 3, seed=M)
         out0 = rnd(N, seed=N)
-        out = dev(out0).clone()
-        lib.check(L.mdt_op_colsum(dev(X).data_ptr(), N + 3, M, N, out.data_ptr(), 1, stream()))
-        assert_close(out.cpu() - out0, X[:, :N].double().sum(0), rtol=1e-4, atol=1e-4, what=f"colsum {M}x{N}")
+        o = dev(out0).clone()
+        lib.check(L.mdt_op_colsum(dev(X).data_ptr(), N + 3, M, N, o.data_ptr(), 1, stream()))
+        assert_close(o.cpu() - out0, X[:, :N].double().sum(0), rtol=1e-4, atol=1e-4, what=f"colsum {M}x{N}")
+
+
+def test_merge_dropout_mask_statistics_and_backward(lib):
+    B, rps, D, p, seed = 64, 10, 384, 0.1, 123456789
+    zeros, ones = torch.zeros(B * rps, D, device="cuda"), torch.ones(B * rps, D, device="cuda")
+    m1, m1b, m2, m3 = (torch.empty(B * rps, D, device="cuda") for _ in range(4))
+    merge(lib, "mdt_op_merge_fwd", zeros, ones, None, m1, None, B, rps, D, p=p, site=5, seed=seed)
+    merge(lib, "mdt_op_merge_fwd", zeros, ones, None, m1b, None, B, rps, D, p=p, site=5, seed=seed)
+    merge(lib, "mdt_op_merge_fwd", zeros, ones, None, m2, None, B, rps, D, p=p, site=6, seed=seed)
+    merge(lib, "mdt_op_merge_fwd", zeros, ones, None, m3, None, B, rps, D, p=p, site=5, seed=seed + 1)
+    assert torch.equal(m1, m1b)                                   # counter based: reproducible
+    vals = torch.unique(m1).cpu()
+    assert_close(vals, torch.tensor([0.0, 1 / (1 - p)]), rtol=1e-6, atol=0, what="mask values")
+    n = m1.numel()
+    keep = (m1 > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5      # binomial, 5 sigma
+    for other in (m2, m3):                                         # other site / other seed: independent masks
+        agree = ((m1 > 0) == (other > 0)).float().mean().item()
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 0.01
+    # columns / rows are not correlated in an obvious way
+    assert abs((m1 > 0).float().mean(0).std().item() - (p * (1 - p) / (B * rps)) ** 0.5) < 0.01
+    # forward / backward with that mask against autograd
+    x, a, mod, dx = rnd(B * rps, D, seed=35), rnd(B * rps, D, seed=36), rnd(B, 6 * D, seed=37), rnd(B * rps, D, seed=38)
+    out, da, dmod = torch.empty_like(m1), torch.empty_like(m1), torch.zeros(B, 6 * D, device="cuda")
+    merge(lib, "mdt_op_merge_fwd", dev(x), dev(a), dev(mod), out, None, B, rps, D, p=p, site=5, seed=seed, gate_col=5 * D, ld=6 * D)
+    merge(lib, "mdt_op_merge_bwd", dev(dx), dev(a), dev(mod), da, dmod, B, rps, D, p=p, site=5, seed=seed, gate_col=5 * D, ld=6 * D)
+    mask = m1.cpu().double()
+    a64, g64 = a.double().requires_grad_(), mod[:, 5 * D:].double().requires_grad_()
+    y = x.double() + g64.repeat_interleave(rps, 0) * (a64 * mask)
+    y.backward(dx.double())
+    assert_close(out.cpu(), y.detach(), what="merge with dropout")
+    assert_close(da.cpu(), a64.grad, what="d_a with dropout", **G_TOL)
+    assert_close(dmod[:, 5 * D:].cpu(), g64.grad, what="d_gate with dropout", **G_TOL)
+
+
+@pytest.mark.parametrize("hd,H,Tq,Tk,causal", [(48, 8, 10, 10, 1), (48, 8, 10, 4, 1), (16, 4, 4, 4, 0)])
+def test_attention_dropout_forward_and_backward(lib, hd, H, Tq, Tk, causal):
+    B, Dm, p, seed, site = 5, H * hd, 0.3, 987654321, 11
+    L = lib.load()
+    q, kv, do = rnd(B * Tq, Dm, seed=51), rnd(B * Tk, 2 * Dm, seed=52), rnd(B * Tq, Dm, seed=53)
+    qd, dod = dev(q), dev(do)
+
+    def fwd(kvt, pp):
+        out = torch.empty(B * Tq, Dm, device="cuda")
+        a = lib.AttnTrainArgs(q=qd.data_ptr(), ldq=Dm, k=kvt.data_ptr(), v=kvt.data_ptr() + 4 * Dm, ldkv=2 * Dm,
+                              out=out.data_ptr(), ldo=Dm, B=B, H=H, hd=hd, Tq=Tq, Tk=Tk, causal=causal, p=pp, site=site,
+                              seed=seed)
+        lib.check(L.mdt_op_attn_fwd_train(C.byref(a), stream()))
+        return out.cpu()
+
+    # probe the probabilities with one-hot values: out[i, h*hd + j] = P_used[i, j]   (Tk <= hd)
+    probe = kv.clone()
+    probe[:, Dm:] = torch.eye(Tk, hd).repeat(B, H)
+    pick = lambda o: o.view(B, Tq, H, hd)[..., :Tk].permute(0, 2, 1, 3)        # (B, H, Tq, Tk)
+    P0, Pd = pick(fwd(dev(probe), 0.0)), pick(fwd(dev(probe), p))
+    visible = P0 > 0
+    mask = torch.where(visible, Pd / P0.clamp_min(1e-30), torch.zeros_like(P0))
+    vals = torch.unique(mask[visible].round(decimals=4))
+    assert_close(vals, torch.tensor([0.0, round(1 / (1 - p), 4)]), rtol=1e-3, atol=1e-4, what="mask values")
+    keep = (mask[visible] > 0).float().mean().item()
+    nvis = int(visible.sum())
+    assert abs(keep - (1 - p)) < 5 * (p * (1 - p) / nvis) ** 0.5
+    # forward / backward with random values against autograd using that mask
+    split = lambda t, T: t.view(B, T, H, hd).transpose(1, 2)
+    q64 = q.double().requires_grad_()
+    k64, v64 = kv[:, :Dm].double().requires_grad_(), kv[:, Dm:].double().requires_grad_()
+    att = split(q64, Tq) @ split(k64, Tk).transpose(-1, -2) / hd ** 0.5
+    if causal:
+        att = att.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool).tril(), float("-inf"))
+    y = ((att.softmax(-1) * mask.double()) @ split(v64, Tk)).transpose(1, 2).reshape(B * Tq, Dm)
+    y.backward(do.double())
+    assert_close(fwd(dev(kv), p), y.detach(), what="attention with dropout")
+    kvd = dev(kv)
+    dq, dkv = torch.zeros(B * Tq, Dm, device="cuda"), torch.zeros(B * Tk, 2 * Dm, device="cuda")
+    g = lib.AttnBwdArgs(q=qd.data_ptr(), ldq=Dm, k=kvd.data_ptr(), v=kvd.data_ptr() + 4 * Dm, ldkv=2 * Dm,
+                        d_out=dod.data_ptr(), ld_do=Dm, dq=dq.data_ptr(), ld_dq=Dm, dk=dkv.data_ptr(),
+                        dv=dkv.data_ptr() + 4 * Dm, ld_dkv=2 * Dm, accumulate_kv=0, B=B, H=H, hd=hd, Tq=Tq, Tk=Tk,
+                        causal=causal, p=p, site=site, seed=seed)
+    lib.check(L.mdt_op_attn_bwd(C.byref(g), stream()))
+    assert_close(dq.cpu(), q64.grad, what="dq", **G_TOL)
+    assert_close(dkv[:, :Dm].cpu(), k64.grad, what="dk", **G_TOL)
+    assert_close(dkv[:, Dm:].cpu(), v64.grad, what="dv", **G_TOL)
 
 
 @pytest.mark.parametrize("M,N,K", [(2560, 1536, 384), (1280, 384, 1536), (1024, 1152, 384), (250, 384, 384), (37, 768, 512),
