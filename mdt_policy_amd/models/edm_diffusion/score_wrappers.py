@@ -61,8 +61,11 @@ class GCDenoiser(nn.Module):
         return torch.is_grad_enabled() and (any(p.requires_grad for p in self.inner_model.parameters()) or
                                             any(torch.is_tensor(t) and t.requires_grad for t in tensors))
 
-    def _train_inputs(self, eng, state, goal):
-        """Encoder inputs as the contiguous fp32 tensors the C ABI takes, still attached to the autograd graph."""
+    def _train_inputs(self, eng, state, goal, honour_modality: bool):
+        """Encoder inputs as the contiguous fp32 tensors the C ABI takes, still attached to the autograd graph, and
+        the parameters THIS forward reads: the others (proprio_emb, MDT-V's pos_emb, the other modality's goal
+        embedder) stay out of the graph, so their .grad stays None and DistributedDataParallel's
+        find_unused_parameters sees them exactly as it does on the reference modules."""
         im = self.inner_model
         prep = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0) \
             else t.float().contiguous().clone()
@@ -75,7 +78,10 @@ class GCDenoiser(nn.Module):
         eng._tokens(state)  # shape validation
         g = prep(im._goals(goal, False))
         eng._goal(g, B)
-        named = [(n, p) for n, p in im.named_parameters()]
+        eng.train_prepare()
+        unused = eng.unused_goal_embedder(state, honour_modality)
+        named = [(n, p) for n, p in im.named_parameters()
+                 if ("inner_model." + n) in eng._grad_layout and not (unused and n.startswith(unused))]
         return tok, tok2, g, B, [n for n, _ in named], [p for _, p in named]
 
     def forward(self, state, action, goal, sigma, **kwargs):
@@ -96,7 +102,7 @@ class GCDenoiser(nn.Module):
             # training step: HIP forward with a tape + HIP backward behind torch.autograd
             from ._autograd import HipDiffusionLoss
             eng = self._engine(allow_grad=True)
-            tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal)
+            tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal, im._arch == "mdtv")
             a, nz = eng._in(action, (B, eng.Ta, eng.A)), eng._in(noise, (B, eng.Ta, eng.A))
             loss, model_output, ctx = HipDiffusionLoss.apply(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)),
                                                              im.train_dropout(), names, *params)
@@ -115,7 +121,7 @@ class GCDenoiser(nn.Module):
             eng = self._engine(allow_grad=True)
             if eng.sigma_in_context:
                 raise NotImplementedError("training with use_ada_conditioning=False is not implemented")
-            tok, tok2, g, _, names, params = self._train_inputs(eng, state, goal)
+            tok, tok2, g, _, names, params = self._train_inputs(eng, state, goal, True)
             ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, im.train_dropout(), names, *params)
             if im._arch == "mdtv":
                 im.latent_encoder_emb = ctx

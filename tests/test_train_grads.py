@@ -216,3 +216,72 @@ def test_hip_train_mode_dropout_is_seeded_consistent_and_differentiated_correctl
     # tapes of forwards that never ran a backward were handed back (60+ forwards above, 16 tapes at most)
     with torch.no_grad(), pytest.raises(NotImplementedError, match="dropout"):
         model.loss(gstate, *args)
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the box's one GPU: RCCL cannot
+    try:
+        from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+        meta, fx, cfg, state, goal, li = case("mdtv_tiny")
+        model = GCDenoiser(cfg, 0.5)
+        model.load_state_dict(params_of(meta))
+        model = model.cuda().eval()
+        B = meta["B"]
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        ddp = DDP(_LossModule(model), find_unused_parameters=True)
+        st = {k: (v[lo:hi].cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+        for _ in range(2):  # a second iteration: the reducer must have seen every bucket of the first one complete
+            ddp.zero_grad()
+            loss = ddp(st, li["actions"][lo:hi].cuda(), goal[lo:hi].cuda(), li["noise_train"][lo:hi].cuda(),
+                       li["sigma"][lo:hi].cuda())
+            loss.backward()
+        g = {k: p.grad.cpu().numpy() for k, p in model.inner_model.named_parameters() if p.grad is not None}
+        q.put((rank, g if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+class _LossModule(torch.nn.Module):
+    """What a LightningModule's training_step does with the denoiser: returns the diffusion loss."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, state, action, goal, noise, sigma):
+        return self.model.loss(state, action, goal, noise, sigma)[0]
+
+
+@pytest.mark.gpu
+def test_hip_gradients_under_distributed_data_parallel():
+    """DistributedDataParallel around the facade (2 processes, each half of the batch): the all-reduced gradients
+    equal the single-process full-batch gradients.  gloo here because both ranks sit on the box's single GPU; on a
+    node with one GPU per rank the same code runs over backend='nccl' (RCCL)."""
+    import torch.multiprocessing as mp
+    from tests.test_sharding_gloo import _free_port
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    meta, fx, cfg, state, goal, li = case("mdtv_tiny")
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    st = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    loss, _ = model.loss(st, li["actions"].cuda(), goal.cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
+    loss.backward()
+    full = {k: p.grad.cpu() for k, p in model.inner_model.named_parameters() if p.grad is not None}
+    assert set(full) == set(got[0])
+    for k, ref in full.items():
+        assert_close(got[0][k], ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-7, what=k)
