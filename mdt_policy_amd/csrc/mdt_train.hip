@@ -87,8 +87,23 @@ extern "C" mdt_status mdt_train_prepare(mdt_model* m) {
     Bump real;
     real.base = t->wt_arena;
     for (Lin* l : lins) l->wt = real.take((size_t)l->N * l->K);
+    // Gradient layout: the parts of a stacked Linear (q|k|v, the K|V of all decoder blocks, all adaLN projections)
+    // are contiguous in packed-row order -- weights (N, K), then biases (N) -- so ONE dW GEMM / ONE column sum
+    // serves the whole stack; every other parameter follows in slot order.  Offsets are multiples of 4 floats.
+    t->grad_off.assign(m->slots.size(), -1);
     int64_t off = 0;
-    for (const Slot& s : m->slots) { t->grad_off.push_back(off); off += s.numel; }
+    for (size_t i = 0; i < m->slots.size(); ++i) {
+        if (t->grad_off[i] >= 0) continue;
+        const Lin* l = m->slots[i].kind == SLOT_PACK ? m->slots[i].lin : nullptr;
+        if (!l) { t->grad_off[i] = off; off += (m->slots[i].numel + 3) & ~(int64_t)3; continue; }
+        const int64_t wbase = off, bbase = off + (int64_t)l->N * l->K;
+        for (const LinPart& p : m->parts) {
+            if (p.lin != l) continue;
+            t->grad_off[p.w_slot] = wbase + (int64_t)p.n_off * l->K;
+            if (p.b_slot >= 0) t->grad_off[p.b_slot] = bbase + p.n_off;
+        }
+        off = bbase + (l->bias ? l->N : 0);
+    }
     t->grad_numel = off;
     for (Slot& s : m->slots) s.loaded = false;  // every weight needs its transposed image: upload again
     m->cached_batch = 0;
@@ -107,19 +122,11 @@ void mdt_train_free(mdt_model* m) {
     m->train = nullptr;
 }
 
-extern "C" int64_t mdt_grad_numel(const mdt_model* m) {
-    if (!m) return 0;
-    if (m->train) return m->train->grad_numel;
-    int64_t n = 0;
-    for (const Slot& s : m->slots) n += s.numel;
-    return n;
-}
+extern "C" int64_t mdt_grad_numel(const mdt_model* m) { return (m && m->train) ? m->train->grad_numel : -1; }
 
 extern "C" int64_t mdt_grad_offset(const mdt_model* m, int64_t i) {
-    if (!m || i < 0 || i >= (int64_t)m->slots.size()) return -1;
-    int64_t off = 0;
-    for (int64_t k = 0; k < i; ++k) off += m->slots[k].numel;
-    return off;
+    if (!m || !m->train || i < 0 || i >= (int64_t)m->slots.size()) return -1;
+    return m->train->grad_off[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,6 +229,7 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
                                              std::max<int64_t>(((int64_t)m->Ld * 6 * D + D) * Bp,
                                                                std::max<int64_t>(((int64_t)m->Ld * 2 * D + D) * ((Me + 15) & ~15),
                                                                                  (int64_t)(2 * D + std::max(m->G, m->O) + D) * Mp)));
+    // (N + K) * Mp of every Linear: MLP 5D (Mp rows); qkv 4D; adaLN stack (Ld*6D + D) on B rows; K|V stack on Me rows
     ts->lin_scratch = b.take(widest);
     ts->dF = b.take(Ma * m->A);
     ts->small = b.take(std::max<int64_t>(B * 2 * D, Mx * (int64_t)std::max(m->O, m->G)));
@@ -476,25 +484,19 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
 static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float* X, int64_t ldx, const float* dY, int64_t ldy,
                           int M, float* dX, int64_t ldxo, int acc_dx, hipStream_t s) {
     mdt_train_state* ts = m->train;
-    for (const LinPart& p : m->parts) {
-        if (p.lin != &l) continue;
-        mdt_linear_bwd_args a;
-        memset(&a, 0, sizeof a);
-        a.X = X; a.ldx = ldx; a.dY = dY + p.n_off; a.ldy = ldy;
-        a.dW = grads + ts->grad_off[p.w_slot];
-        a.dbias = p.b_slot >= 0 ? grads + ts->grad_off[p.b_slot] : nullptr;
-        a.accumulate_dw = 1;
-        a.M = M; a.N = p.rows; a.K = l.K; a.scratch = ts->lin_scratch;
-        MDT_TRY(mdt_linear_bwd(a, s));
-    }
-    if (dX) {
-        mdt_linear_bwd_args a;
-        memset(&a, 0, sizeof a);
-        a.X = X; a.ldx = ldx; a.dY = dY; a.ldy = ldy; a.Wt = l.wt; a.dX = dX; a.ldxo = ldxo; a.accumulate_dx = acc_dx;
-        a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
-        MDT_TRY(mdt_linear_bwd(a, s));
-    }
-    return MDT_OK;
+    const LinPart* first = nullptr;  // the part at row 0: the stack's gradient region starts at its slot
+    for (const LinPart& p : m->parts)
+        if (p.lin == &l && p.n_off == 0) { first = &p; break; }
+    if (!first) return fail(MDT_ERR_STATE, "lin_bwd: Linear without a registered parameter");
+    mdt_linear_bwd_args a;
+    memset(&a, 0, sizeof a);
+    a.X = X; a.ldx = ldx; a.dY = dY; a.ldy = ldy;
+    a.dW = grads + ts->grad_off[first->w_slot];
+    a.dbias = first->b_slot >= 0 ? grads + ts->grad_off[first->b_slot] : nullptr;
+    a.accumulate_dw = 1;
+    a.Wt = l.wt; a.dX = dX; a.ldxo = ldxo; a.accumulate_dx = acc_dx;
+    a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
+    return mdt_linear_bwd(a, s);
 }
 
 static int slot_of(const mdt_model* m, const float* dst) {

@@ -19,7 +19,7 @@ li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(B, cfg, 2)
 state = {"state_images": inp["state_images"], "modality": "lang"}
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
 n_params = sum(p.numel() for p in model.parameters())
-for mode in ("eval", "train"):
+for mode in os.environ.get("MDT_TRAIN_BENCH_MODES", "eval,train").split(","):
     model.train(mode == "train")
 
     def step():
