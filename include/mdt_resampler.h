@@ -57,6 +57,20 @@ mdt_status mdt_resampler_load_param(mdt_resampler *r, const char *name, const fl
 mdt_status mdt_resampler_forward(mdt_resampler *r, const float *x_f, const uint8_t *mask, int64_t batch,
                                  int32_t n_frames, int32_t n_tokens, float *out, void *stream);
 
+/* ---- training (PerceiverResampler is a trainable module of the agent, mdtv_agent.py:90-97) ----
+ * mdt_resampler_train_prepare: allocates the transposed weight images; parameters must be uploaded again after it.
+ * Gradients come back in one flat buffer: parameter i at [mdt_resampler_grad_offset(i), + numel), reference layout.
+ * mdt_resampler_forward_train keeps a tape (several may be alive: the agent resamples once per modality batch before
+ * its single backward); mdt_resampler_backward ACCUMULATES into `grads` and optionally returns d(x_f). */
+mdt_status mdt_resampler_train_prepare(mdt_resampler *r);
+int64_t mdt_resampler_grad_numel(const mdt_resampler *r);
+int64_t mdt_resampler_grad_offset(const mdt_resampler *r, int64_t i);
+mdt_status mdt_resampler_forward_train(mdt_resampler *r, const float *x_f, const uint8_t *mask, int64_t batch,
+                                       int32_t n_frames, int32_t n_tokens, float *out, int32_t *tape, void *stream);
+mdt_status mdt_resampler_backward(mdt_resampler *r, int32_t tape, const float *g_out, float *grads, float *d_x_f,
+                                  void *stream);
+mdt_status mdt_resampler_tape_release(mdt_resampler *r, int32_t tape);
+
 /* Algorithmic FLOPs of one forward() per sample (2 per multiply-add). */
 double mdt_resampler_flops(const mdt_resampler *r, int32_t n_frames, int32_t n_tokens);
 

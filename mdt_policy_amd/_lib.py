@@ -184,6 +184,12 @@ SYMBOLS = [
     ("mdt_resampler_param_numel", _I64, [_VP, _I64]),
     ("mdt_resampler_load_param", _I32, [_VP, C.c_char_p, _VP, _I64, _VP]),
     ("mdt_resampler_forward", _I32, [_VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
+    ("mdt_resampler_train_prepare", _I32, [_VP]),
+    ("mdt_resampler_grad_numel", _I64, [_VP]),
+    ("mdt_resampler_grad_offset", _I64, [_VP, _I64]),
+    ("mdt_resampler_forward_train", _I32, [_VP, _VP, _VP, _I64, _I32, _I32, _VP, C.POINTER(_I32), _VP]),
+    ("mdt_resampler_backward", _I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    ("mdt_resampler_tape_release", _I32, [_VP, _I32]),
     ("mdt_resampler_flops", C.c_double, [_VP, _I32, _I32]),
 ]
 

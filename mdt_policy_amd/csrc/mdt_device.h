@@ -9,6 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define WAVE 64
 
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
+
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------

@@ -114,5 +114,11 @@ hipError_t mdt_launch_gather_rows(const float* src, float* dst, int M, int D, in
 hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream_t s);
 // backward of a Linear through the forward GEMM kernel (mdt_train.hip); see mdt_linear_bwd_args
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s);
+hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                         const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
+                                         int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s);
+bool mdt_attention_long_bwd_supported(int hd, int Tq, int Tk);
+hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, int64_t B, int T, int n, int D,
+                                    int accumulate, hipStream_t s);
 struct mdt_model;
 void mdt_train_free(mdt_model* m);  // releases what mdt_train_prepare() and the tapes allocated (mdt_train.hip)

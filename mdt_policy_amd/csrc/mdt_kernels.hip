@@ -56,7 +56,6 @@ __global__ void k_pack_weight(const float* __restrict__ w, int n_rows, int K, fl
 // step) | LayerNorm + modulate with a per-sample row (GCDenoiser.forward / loss with per-sample sigma)
 enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_LN_MOD_BCAST = 2, PRO_LN_MOD_ROWS = 3 };
 
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
 // output store of the GEMM epilogues.  -DMDT_ST_WT (tuning build) makes it a write-through (sc0 sc1) store so that the
 // tile does not stay dirty in L2 until the end-of-kernel write-back.
 __device__ __forceinline__ void st4(float* p, f32x4 v) {

@@ -543,3 +543,174 @@ hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream
     hipLaunchKernelGGL(k_axpy1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Perceiver resampler: backward of k_attn_long (few queries, ~400 keys), one workgroup per (sample, head).
+//   s[q][f] = (scale q[q]) . k[f] ;  P = softmax_f(s) ;  o[q] = sum_f P[q][f] v[f]
+//   dP[q][f] = dO[q] . v[f] ;  dS = P * (dP - sum_f P dP)
+//   dq[q] = scale * sum_f dS[q][f] k[f] ;  dk[f] = sum_q dS[q][f] (scale q[q]) ;  dv[f] = sum_q P[q][f] dO[q]
+// Pass 1 (thread per key): scores -> P in LDS.  Pass 2 (thread per key): dP -> LDS, then dS in place.
+// Pass 3 (thread per key): dk / dv rows.  Pass 4 (thread = key group x feature): dq through an LDS reduction.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_bwd(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                       const float* __restrict__ v, int64_t ldkv,
+                                                       const float* __restrict__ d_out, int64_t ld_do,
+                                                       float* __restrict__ dq, int64_t ld_dq, float* __restrict__ dk,
+                                                       float* __restrict__ dv, int64_t ld_dkv, int Tq, int Tk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int H4 = HD / 4, G = 256 / HD, QMAX = 16;
+    const int tid = threadIdx.x, b = blockIdx.x, h = blockIdx.y;
+    const int Tkp = (Tk + 3) & ~3;
+    float* qs = lds;                  // [Tq][HD] scaled queries
+    float* os = qs + Tq * HD;         // [Tq][HD] dO
+    float* P = os + Tq * HD;          // [Tq][Tkp]
+    float* dS = P + Tq * Tkp;         // [Tq][Tkp]  dP, then dS
+    float* aux = dS + Tq * Tkp;       // [16] delta per query
+    float* red = aux + QMAX;          // [G][Tq][HD]
+    for (int i = tid; i < Tq * HD; i += 256) {
+        const int qi = i / HD, d = i - qi * HD;
+        qs[i] = q[((int64_t)b * Tq + qi) * ldq + h * HD + d] * scale;
+        os[i] = d_out[((int64_t)b * Tq + qi) * ld_do + h * HD + d];
+    }
+    __syncthreads();
+    const float* kb = k + (int64_t)b * Tk * ldkv + h * HD;
+    const float* vb = v + (int64_t)b * Tk * ldkv + h * HD;
+    // pass 1 + 2a: scores and dP per key
+    for (int f0 = 0; f0 < Tk; f0 += 256) {
+        const int f = min(f0 + tid, Tk - 1);
+        f32x4 kr[H4], vr[H4];
+#pragma unroll
+        for (int c = 0; c < H4; ++c) { kr[c] = ldg4(kb + (int64_t)f * ldkv + c * 4); vr[c] = ldg4(vb + (int64_t)f * ldkv + c * 4); }
+        for (int qi = 0; qi < Tq; ++qi) {
+            const f32x4* qv = reinterpret_cast<const f32x4*>(qs + qi * HD);
+            const f32x4* ov = reinterpret_cast<const f32x4*>(os + qi * HD);
+            float s = 0.f, t = 0.f;
+#pragma unroll
+            for (int c = 0; c < H4; ++c) {
+                const f32x4 a = qv[c], o = ov[c];
+                s = fmaf(a.x, kr[c].x, s); s = fmaf(a.y, kr[c].y, s); s = fmaf(a.z, kr[c].z, s); s = fmaf(a.w, kr[c].w, s);
+                t = fmaf(o.x, vr[c].x, t); t = fmaf(o.y, vr[c].y, t); t = fmaf(o.z, vr[c].z, t); t = fmaf(o.w, vr[c].w, t);
+            }
+            if (f0 + tid < Tk) { P[qi * Tkp + f] = s; dS[qi * Tkp + f] = t; }
+        }
+    }
+    __syncthreads();
+    // softmax per query, delta = sum_f P dP, then dS = P (dP - delta)
+    const int w = tid >> 6, lane = tid & 63;
+    for (int qi = w; qi < Tq; qi += 4) {
+        float* pr = P + qi * Tkp;
+        float* dr = dS + qi * Tkp;
+        float mx = -INFINITY;
+        for (int f = lane; f < Tk; f += 64) mx = fmaxf(mx, pr[f]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int f = lane; f < Tk; f += 64) { const float e = expf(pr[f] - mx); pr[f] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        float dl = 0.f;
+        for (int f = lane; f < Tk; f += 64) { const float p = pr[f] * inv; pr[f] = p; dl = fmaf(p, dr[f], dl); }
+        dl = wave_sum(dl);
+        for (int f = lane; f < Tk; f += 64) dr[f] = pr[f] * (dr[f] - dl);
+    }
+    __syncthreads();
+    // pass 3: dk[f] = sum_q dS[q][f] qs[q] ; dv[f] = sum_q P[q][f] dO[q]   (thread per key, rows written as float4)
+    for (int f = tid; f < Tk; f += 256) {
+        f32x4 ak[H4], av[H4];
+#pragma unroll
+        for (int c = 0; c < H4; ++c) { ak[c] = f32x4{0.f, 0.f, 0.f, 0.f}; av[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int qi = 0; qi < Tq; ++qi) {
+            const float ds = dS[qi * Tkp + f], p = P[qi * Tkp + f];
+            const f32x4* qv = reinterpret_cast<const f32x4*>(qs + qi * HD);
+            const f32x4* ov = reinterpret_cast<const f32x4*>(os + qi * HD);
+#pragma unroll
+            for (int c = 0; c < H4; ++c) {
+                const f32x4 a = qv[c], o = ov[c];
+                ak[c].x = fmaf(ds, a.x, ak[c].x); ak[c].y = fmaf(ds, a.y, ak[c].y);
+                ak[c].z = fmaf(ds, a.z, ak[c].z); ak[c].w = fmaf(ds, a.w, ak[c].w);
+                av[c].x = fmaf(p, o.x, av[c].x); av[c].y = fmaf(p, o.y, av[c].y);
+                av[c].z = fmaf(p, o.z, av[c].z); av[c].w = fmaf(p, o.w, av[c].w);
+            }
+        }
+        float* pk = dk + ((int64_t)b * Tk + f) * ld_dkv + h * HD;
+        float* pv = dv + ((int64_t)b * Tk + f) * ld_dkv + h * HD;
+#pragma unroll
+        for (int c = 0; c < H4; ++c) { *(f32x4*)(pk + c * 4) = ak[c]; *(f32x4*)(pv + c * 4) = av[c]; }
+    }
+    // pass 4: dq[q][d] = scale * sum_f dS[q][f] k[f][d]
+    const int g = tid / HD, d = tid - g * HD;
+    float acc[QMAX];
+#pragma unroll
+    for (int qi = 0; qi < QMAX; ++qi) acc[qi] = 0.f;
+    for (int f = g; f < Tk; f += G) {
+        const float kv_ = kb[(int64_t)f * ldkv + d];
+#pragma unroll
+        for (int qi = 0; qi < QMAX; ++qi)
+            if (qi < Tq) acc[qi] = fmaf(dS[qi * Tkp + f], kv_, acc[qi]);
+    }
+#pragma unroll
+    for (int qi = 0; qi < QMAX; ++qi)
+        if (qi < Tq) red[(g * Tq + qi) * HD + d] = acc[qi];
+    __syncthreads();
+    for (int i = tid; i < Tq * HD; i += 256) {
+        const int qi = i / HD, dd = i - qi * HD;
+        float t = 0.f;
+        for (int gg = 0; gg < G; ++gg) t += red[(gg * Tq + qi) * HD + dd];
+        dq[((int64_t)b * Tq + qi) * ld_dq + h * HD + dd] = t * scale;
+    }
+}
+
+static size_t attn_long_bwd_lds(int hd, int Tq, int Tk) {
+    return (size_t)(2 * Tq * hd + 2 * Tq * ((Tk + 3) & ~3) + 16 + 256 * Tq) * sizeof(float);
+}
+
+bool mdt_attention_long_bwd_supported(int hd, int Tq, int Tk) {
+    return (hd == 16 || hd == 32 || hd == 64) && Tq >= 1 && Tq <= 16 && Tk >= 1 && Tk <= 4096 &&
+           attn_long_bwd_lds(hd, Tq, Tk) <= 160 * 1024;
+}
+
+template <int HD>
+static hipError_t launch_attn_long_bwd_t(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                         const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
+                                         int64_t ld_dkv, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
+    const size_t lds = attn_long_bwd_lds(HD, Tq, Tk);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_long_bwd<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_attn_long_bwd<HD>), dim3(B, H), dim3(256), lds, s, q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk,
+                       dv, ld_dkv, Tq, Tk, scale);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                         const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
+                                         int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s) {
+    if (!mdt_attention_long_bwd_supported(hd, Tq, Tk)) return hipErrorInvalidValue;
+    switch (hd) {
+        case 16: return launch_attn_long_bwd_t<16>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s);
+        case 32: return launch_attn_long_bwd_t<32>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s);
+        default: return launch_attn_long_bwd_t<64>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s);
+    }
+}
+
+// time_pos_emb gradient: out[t][d] = sum_{b, n} mask[b][t] * dxf[b][t][n][d]      (grid: T x D/256, loop b, n)
+__global__ void k_time_emb_grad(const float* __restrict__ dxf, const uint8_t* __restrict__ mask, float* __restrict__ out,
+                                int64_t B, int T, int n, int D, int accumulate) {
+    const int t = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    float acc = 0.f;
+    for (int64_t b = 0; b < B; ++b) {
+        if (mask && !mask[b * T + t]) continue;
+        const float* base = dxf + ((b * T + t) * (int64_t)n) * D + d;
+        for (int i = 0; i < n; ++i) acc += base[(int64_t)i * D];
+    }
+    float* p = out + (int64_t)t * D + d;
+    *p = accumulate ? *p + acc : acc;
+}
+hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, int64_t B, int T, int n, int D,
+                                    int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_time_emb_grad, dim3((D + 255) / 256, T), dim3(256), 0, s, dxf, mask, out, B, T, n, D, accumulate);
+    return hipGetLastError();
+}

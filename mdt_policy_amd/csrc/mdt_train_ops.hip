@@ -18,20 +18,26 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
     if (a.dbias) LAUNCH(mdt_launch_colsum(a.dY, a.ldy, a.M, a.N, a.dbias, a.accumulate_dw, s));
     if (a.dW) {
         if (a.N % 16) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: N must be a multiple of 16 for dW");
-        const int Mp = (a.M + 15) & ~15;
-        float* dYt = a.scratch;                          // (N, Mp)
-        float* Xt = a.scratch + (size_t)a.N * Mp;        // packed (N' = K, K' = Mp)
-        if (Mp != a.M) {
-            HIP_TRY(hipMemsetAsync(dYt, 0, (size_t)a.N * Mp * sizeof(float), s));
-            HIP_TRY(hipMemsetAsync(Xt, 0, (size_t)a.K * Mp * sizeof(float), s));
+        // the reduction runs over the rows; very tall inputs (Perceiver media tokens) go through in slices that
+        // keep the GEMM's K' within its limit, each accumulating into dW
+        const int SLICE = 32768;
+        for (int m0 = 0; m0 < a.M; m0 += SLICE) {
+            const int Ms = std::min(SLICE, a.M - m0);
+            const int Mp = (Ms + 15) & ~15;
+            float* dYt = a.scratch;                          // (N, Mp)
+            float* Xt = a.scratch + (size_t)a.N * Mp;        // packed (N' = K, K' = Mp)
+            if (Mp != Ms) {
+                HIP_TRY(hipMemsetAsync(dYt, 0, (size_t)a.N * Mp * sizeof(float), s));
+                HIP_TRY(hipMemsetAsync(Xt, 0, (size_t)a.K * Mp * sizeof(float), s));
+            }
+            LAUNCH(mdt_launch_transpose_ld(a.dY + (int64_t)m0 * a.ldy, a.ldy, dYt, Mp, Ms, a.N, s));
+            LAUNCH(mdt_launch_pack_weight_t(a.X + (int64_t)m0 * a.ldx, Ms, a.K, a.ldx, Xt, 0, Mp / 16, s));
+            Lin w;
+            w.wp = Xt; w.bias = nullptr; w.N = a.K; w.K = Mp;
+            mdt_gemm_args g = gemm_args(dYt, Mp, w, a.dW, a.K, a.N);
+            g.residual = (a.accumulate_dw || m0 > 0) ? 1 : 0;
+            LAUNCH(mdt_launch_gemm(g, s));
         }
-        LAUNCH(mdt_launch_transpose_ld(a.dY, a.ldy, dYt, Mp, a.M, a.N, s));
-        LAUNCH(mdt_launch_pack_weight_t(a.X, a.M, a.K, a.ldx, Xt, 0, Mp / 16, s));
-        Lin w;
-        w.wp = Xt; w.bias = nullptr; w.N = a.K; w.K = Mp;
-        mdt_gemm_args g = gemm_args(dYt, Mp, w, a.dW, a.K, a.N);
-        g.residual = a.accumulate_dw;
-        LAUNCH(mdt_launch_gemm(g, s));
     }
     if (a.dX) {
         if (!a.Wt || (a.N % 16)) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: dX needs the packed W^T and N % 16 == 0");

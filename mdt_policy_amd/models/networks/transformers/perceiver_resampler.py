@@ -6,7 +6,8 @@ PerceiverResampler :85-162); built by the agent at mdt/models/mdtv_agent.py:90-9
 ``compute_voltron_embeddings`` (:392-404) on the two cameras' Voltron patch tokens,
 ``(B, 1, 2*196, 384) -> (B, 3, 384)`` = the ``state_images`` tokens of the denoiser.
 
-Forward only (``torch.no_grad()``): the backward of this module is part of the training path, SURVEY.md 8(f) 1.
+Differentiable: under autograd the forward keeps a tape in the library handle and the backward (HIP) returns the
+gradient of every parameter and of the media tokens, so the module trains inside the agent like the reference's.
 There is no eager fallback: CPU tensors or a missing library raise.
 """
 from __future__ import annotations
@@ -19,6 +20,57 @@ from torch import nn
 
 from .... import _lib
 from .utils import feed_forward_layer
+
+
+class _ResamplerTape:
+    def __init__(self, mod, tape_id):
+        self.mod, self.id = mod, tape_id
+
+    def release(self):
+        if self.id is not None and self.mod._handle is not None:
+            try:
+                _lib.load().mdt_resampler_tape_release(self.mod._handle, self.id)
+            except Exception:
+                pass
+        self.id = None
+
+    __del__ = release
+
+
+class _ResamplerFn(torch.autograd.Function):
+    """PerceiverResampler.forward under autograd: HIP forward with a tape, HIP backward."""
+
+    @staticmethod
+    def forward(ctx, mod, x, mask_u8, names, *params):
+        lib, stream = mod._engine(x.device, train=True)
+        B, T, n, dim = x.shape
+        out = torch.empty((B, mod.num_queries, dim), device=x.device, dtype=torch.float32)
+        tape = C.c_int32(-1)
+        _lib.check(lib.mdt_resampler_forward_train(mod._handle, x.data_ptr(), None if mask_u8 is None else mask_u8.data_ptr(),
+                                                   B, T, n, out.data_ptr(), C.byref(tape), stream))
+        ctx.mod, ctx.tape = mod, _ResamplerTape(mod, int(tape.value))
+        ctx.named = list(zip(names, params))
+        ctx.x_shape, ctx.need_x = x.shape, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        mod = ctx.mod
+        if ctx.tape.id is None:
+            raise RuntimeError("the HIP resampler tape of this forward was already consumed (no retain_graph support)")
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(g_out.device).cuda_stream
+        g = g_out.detach().float().contiguous()
+        grads = torch.zeros(mod._grad_numel, device=g.device, dtype=torch.float32)
+        d_x = torch.empty(ctx.x_shape, device=g.device, dtype=torch.float32) if ctx.need_x else None
+        _lib.check(lib.mdt_resampler_backward(mod._handle, ctx.tape.id, g.data_ptr(), grads.data_ptr(),
+                                              None if d_x is None else d_x.data_ptr(), stream))
+        ctx.tape.release()
+        out = []
+        for name, p in ctx.named:
+            off, n = mod._grad_layout[name]
+            out.append(grads[off:off + n].view(p.shape) if p.requires_grad else None)
+        return (None, d_x, None, None, *out)
 
 
 class PerceiverAttentionLayer(nn.Module):
@@ -81,6 +133,7 @@ class PerceiverResampler(nn.Module):
             except Exception:
                 pass
         self._handle, self._handle_device, self._uploaded = None, None, {}
+        self._grad_layout = None
 
     def __del__(self):
         try:
@@ -88,7 +141,7 @@ class PerceiverResampler(nn.Module):
         except Exception:
             pass
 
-    def _engine(self, device: torch.device):
+    def _engine(self, device: torch.device, train: bool = False):
         if device.type != "cuda":
             raise RuntimeError("the Perceiver resampler runs only on a ROCm GPU (hand-written gfx950 kernels); move "
                                "the module and its input with .to('cuda') -- there is no CPU execution path")
@@ -100,6 +153,14 @@ class PerceiverResampler(nn.Module):
             with torch.cuda.device(device):
                 _lib.check(lib.mdt_resampler_create(C.byref(cfg), C.byref(h)))
             self._handle, self._handle_device = h, device
+        if train and getattr(self, "_grad_layout", None) is None:
+            _lib.check(lib.mdt_resampler_train_prepare(self._handle))
+            self._uploaded = {}  # every weight is uploaded again so that its transposed image exists
+            n = lib.mdt_resampler_param_count(self._handle)
+            self._grad_layout = {lib.mdt_resampler_param_name(self._handle, i).decode():
+                                 (int(lib.mdt_resampler_grad_offset(self._handle, i)),
+                                  int(lib.mdt_resampler_param_numel(self._handle, i))) for i in range(n)}
+            self._grad_numel = int(lib.mdt_resampler_grad_numel(self._handle))
         stream = torch.cuda.current_stream(device).cuda_stream
         for name, p in self.named_parameters():
             tag = (p.data_ptr(), p._version)
@@ -119,18 +180,22 @@ class PerceiverResampler(nn.Module):
         assert x_f.ndim == 4
         batch_size, max_length, n_features, dim = x_f.shape
         assert dim == self.dim
+        m = None
+        if mask is not None:
+            m = mask.to(device=x_f.device, dtype=torch.bool).reshape(batch_size, max_length).contiguous().view(torch.uint8)
         if torch.is_grad_enabled() and (x_f.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("autograd through the HIP resampler is not implemented yet (SURVEY.md 8(f) "
-                                      "item 1); wrap the call in torch.no_grad()")
+            if x_f.device.type != "cuda":
+                self._engine(x_f.device)  # raises the no-CPU-path error
+            x = x_f if (x_f.dtype == torch.float32 and x_f.is_contiguous() and x_f.data_ptr() % 16 == 0) \
+                else x_f.float().contiguous().clone()
+            named = list(self.named_parameters())
+            return _ResamplerFn.apply(self, x, m, [k for k, _ in named], *[p for _, p in named])
         lib, stream = self._engine(x_f.device)
         x = x_f.detach()
         if x.dtype != torch.float32:
             x = x.float()
         if not x.is_contiguous() or x.data_ptr() % 16:
             x = x.contiguous().clone()
-        m = None
-        if mask is not None:
-            m = mask.to(device=x.device, dtype=torch.bool).reshape(batch_size, max_length).contiguous().view(torch.uint8)
         out = torch.empty((batch_size, self.num_queries, dim), device=x.device, dtype=torch.float32)
         _lib.check(lib.mdt_resampler_forward(self._handle, x.data_ptr(), None if m is None else m.data_ptr(),
                                              batch_size, max_length, n_features, out.data_ptr(), stream))

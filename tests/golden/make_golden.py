@@ -364,12 +364,21 @@ def g9():
         mask = None
         if masked:
             mask = torch.tensor([[True, True, False], [True, False, True], [True, True, True]])[:B, :T]
-        with torch.no_grad():
-            out = m(x, mask)
+        x.requires_grad_()
+        out = m(x, mask)
+        # training: gradients of every parameter and of the media tokens for a fixed random cotangent
+        cot = torch.from_numpy(synthetic.normal("cotangent", tuple(out.shape), 93))
+        (out * cot).sum().backward()
+        grads = {}
+        for k, p in m.named_parameters():
+            g = p.grad.detach().double()
+            grads[k] = [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
+        dx = x.grad.detach()
         meta = dict(kwargs=kw, B=B, T=T, n=n, masked=masked, weight_seed=91, input_seed=92, profile="rich",
-                    mask=None if mask is None else mask.int().tolist(),
+                    mask=None if mask is None else mask.int().tolist(), cot_seed=93, grads=grads,
+                    d_x_summary=[float(dx.double().norm()), float(dx.double().sum())],
                     state_dict=[[k, list(v.shape)] for k, v in sd.items()])
-        save(f"g9_perceiver_{name}.npz", meta, out=out.numpy())
+        save(f"g9_perceiver_{name}.npz", meta, out=out.detach().numpy(), d_x_head=dx[:, :, :4, :].numpy())
 
 
 def g10():
