@@ -114,6 +114,12 @@ class LinearBwdArgs(C.Structure):
                 ("K", C.c_int32), ("scratch", C.c_void_p)]
 
 
+class OptTensor(C.Structure):
+    """mirrors mdt_opt_tensor (include/mdt_hip_train.h)"""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
+                ("numel", C.c_int64)]
+
+
 class ResamplerConfig(C.Structure):
     """mirrors mdt_resampler_config (include/mdt_resampler.h)"""
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "dim_head", "heads", "num_latents", "num_time_embeds",
@@ -176,6 +182,8 @@ SYMBOLS = [
     ("mdt_op_merge_bwd", _I32, [C.POINTER(MergeArgs), _VP]),
     ("mdt_op_colsum", _I32, [_VP, _I64, _I64, _I64, _VP, _I32, _VP]),
     ("mdt_op_linear_bwd", _I32, [C.POINTER(LinearBwdArgs), _VP]),
+    ("mdt_op_multi_adamw", _I32, [C.POINTER(OptTensor), _I32, _F, _F, _F, _F, _F, _I64, _VP]),
+    ("mdt_op_multi_ema", _I32, [C.POINTER(OptTensor), _I32, _F, _VP]),
     # include/mdt_resampler.h
     ("mdt_resampler_create", _I32, [C.POINTER(ResamplerConfig), C.POINTER(_VP)]),
     ("mdt_resampler_destroy", _I32, [_VP]),

@@ -120,5 +120,9 @@ hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const floa
 bool mdt_attention_long_bwd_supported(int hd, int Tq, int Tk);
 hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, int64_t B, int T, int n, int D,
                                     int accumulate, hipStream_t s);
+hipError_t mdt_launch_multi_adamw(const mdt_opt_tensor* tab, const int2* blocks, int n_blocks, float lr, float beta1,
+                                  float beta2, float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s);
+hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks, int n_blocks, float a, float b,
+                                  hipStream_t s);
 struct mdt_model;
 void mdt_train_free(mdt_model* m);  // releases what mdt_train_prepare() and the tapes allocated (mdt_train.hip)

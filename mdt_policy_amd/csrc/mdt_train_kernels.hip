@@ -714,3 +714,50 @@ hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float
     hipLaunchKernelGGL(k_time_emb_grad, dim3((D + 255) / 256, T), dim3(256), 0, s, dxf, mask, out, B, T, n, D, accumulate);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// multi-tensor optimizer kernels: ONE launch updates a whole list of tensors (torch.optim.AdamW semantics;
+// the EMA callback's amp_C.multi_tensor_axpby, mdt/callbacks/ema.py:108-115, which exists only on NVIDIA/apex).
+// blocks[i] = (tensor index, first element); a workgroup walks OPT_CHUNK elements of one tensor.
+// ------------------------------------------------------------------------------------------------
+#define OPT_CHUNK 4096
+
+__global__ __launch_bounds__(256) void k_multi_adamw(const mdt_opt_tensor* __restrict__ tab, const int2* __restrict__ blocks,
+                                                     float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                     float bc2_sqrt) {
+    const int2 blk = blocks[blockIdx.x];
+    const mdt_opt_tensor t = tab[blk.x];
+    const int64_t end = min((int64_t)blk.y + OPT_CHUNK, t.numel);
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blk.y + threadIdx.x; i < end; i += 256) {
+        const float g = t.g[i];
+        float p = t.p[i] * (1.0f - lr * wd);                 // decoupled weight decay
+        const float m = fmaf(beta1, t.m[i], (1.0f - beta1) * g);
+        const float v = fmaf(beta2, t.v[i], (1.0f - beta2) * g * g);
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        p -= step_size * (m / denom);
+        t.m[i] = m; t.v[i] = v; t.p[i] = p;
+    }
+}
+
+// ema = a * ema + b * w     (a = decay, b = 1 - decay)
+__global__ __launch_bounds__(256) void k_multi_axpby(const mdt_opt_tensor* __restrict__ tab, const int2* __restrict__ blocks,
+                                                     float a, float b) {
+    const int2 blk = blocks[blockIdx.x];
+    const mdt_opt_tensor t = tab[blk.x];
+    const int64_t end = min((int64_t)blk.y + OPT_CHUNK, t.numel);
+    for (int64_t i = (int64_t)blk.y + threadIdx.x; i < end; i += 256) t.ema[i] = fmaf(a, t.ema[i], b * t.p[i]);
+}
+
+hipError_t mdt_launch_multi_adamw(const mdt_opt_tensor* tab, const int2* blocks, int n_blocks, float lr, float beta1,
+                                  float beta2, float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_multi_adamw, dim3(n_blocks), dim3(256), 0, s, tab, blocks, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+    return hipGetLastError();
+}
+hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks, int n_blocks, float a, float b,
+                                  hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_multi_axpby, dim3(n_blocks), dim3(256), 0, s, tab, blocks, a, b);
+    return hipGetLastError();
+}

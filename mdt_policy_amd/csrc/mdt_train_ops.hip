@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <vector>
 
 #include "mdt_internal.h"
 
@@ -120,5 +123,74 @@ extern "C" mdt_status mdt_op_colsum(const float* X, int64_t ldx, int64_t M, int6
                                     void* stream) {
     if (!X || !out || M < 1 || N < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_op_colsum: bad argument");
     LAUNCH(mdt_launch_colsum(X, ldx, (int)M, (int)N, out, accumulate, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-tensor optimizer updates: the (tensor, chunk) table is rebuilt on the host per call (a few KB) and
+// uploaded stream-ordered into a per-process device buffer
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct OptTable {
+    std::mutex mu;
+    void* dev = nullptr;
+    size_t cap = 0;
+    std::vector<char> host;
+};
+OptTable g_opt;
+}  // namespace
+
+static mdt_status upload_opt_table(const mdt_opt_tensor* tensors, int n, const mdt_opt_tensor** d_tab, const int2** d_blocks,
+                                   int* n_blocks, hipStream_t s) {
+    const int CH = 4096;  // OPT_CHUNK of the kernels
+    std::vector<int2> blocks;
+    for (int i = 0; i < n; ++i) {
+        if (tensors[i].numel < 0 || tensors[i].numel > ((int64_t)1 << 31) - CH)
+            return fail(MDT_ERR_INVALID_ARG, "multi-tensor update: tensor %d has an unsupported size", i);
+        for (int64_t off = 0; off < tensors[i].numel; off += CH) blocks.push_back(make_int2(i, (int)off));
+    }
+    const size_t tab_bytes = ((size_t)n * sizeof(mdt_opt_tensor) + 255) & ~(size_t)255;
+    const size_t total = tab_bytes + blocks.size() * sizeof(int2);
+    if (total > g_opt.cap) {
+        if (g_opt.dev) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g_opt.dev)); g_opt.dev = nullptr; g_opt.cap = 0; }
+        HIP_TRY(hipMalloc(&g_opt.dev, total * 2));
+        g_opt.cap = total * 2;
+    }
+    // the staging copy must stay valid until the async copy ran: synchronise before reusing it
+    HIP_TRY(hipStreamSynchronize(s));
+    g_opt.host.resize(total);
+    memcpy(g_opt.host.data(), tensors, (size_t)n * sizeof(mdt_opt_tensor));
+    memcpy(g_opt.host.data() + tab_bytes, blocks.data(), blocks.size() * sizeof(int2));
+    HIP_TRY(hipMemcpyAsync(g_opt.dev, g_opt.host.data(), total, hipMemcpyHostToDevice, s));
+    *d_tab = (const mdt_opt_tensor*)g_opt.dev;
+    *d_blocks = (const int2*)((const char*)g_opt.dev + tab_bytes);
+    *n_blocks = (int)blocks.size();
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_multi_adamw(const mdt_opt_tensor* tensors, int32_t n, float lr, float beta1, float beta2,
+                                         float eps, float weight_decay, int64_t step, void* stream) {
+    if (!tensors || n < 0 || step < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_adamw: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!tensors[i].p || !tensors[i].g || !tensors[i].m || !tensors[i].v)
+            return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_adamw: tensor %d lacks p / g / m / v", i);
+    std::lock_guard<std::mutex> lock(g_opt.mu);
+    hipStream_t s = (hipStream_t)stream;
+    const mdt_opt_tensor* tab; const int2* blocks; int nb;
+    MDT_TRY(upload_opt_table(tensors, n, &tab, &blocks, &nb, s));
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    LAUNCH(mdt_launch_multi_adamw(tab, blocks, nb, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)std::sqrt(bc2), s));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_multi_ema(const mdt_opt_tensor* tensors, int32_t n, float decay, void* stream) {
+    if (!tensors || n < 0 || !(decay >= 0.f && decay <= 1.f)) return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_ema: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!tensors[i].p || !tensors[i].ema) return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_ema: tensor %d lacks p / ema", i);
+    std::lock_guard<std::mutex> lock(g_opt.mu);
+    hipStream_t s = (hipStream_t)stream;
+    const mdt_opt_tensor* tab; const int2* blocks; int nb;
+    MDT_TRY(upload_opt_table(tensors, n, &tab, &blocks, &nb, s));
+    LAUNCH(mdt_launch_multi_axpby(tab, blocks, nb, decay, 1.0f - decay, s));
     return MDT_OK;
 }
