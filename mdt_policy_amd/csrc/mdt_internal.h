@@ -93,7 +93,10 @@ bool mdt_attention_long_supported(int hd, int Tq, int Tk);
 // ---- training-path kernels (mdt_train_kernels.hip) ----
 hipError_t mdt_launch_pack_weight_t(const float* src, int rows, int cols, int64_t ld, float* packed, int k_off, int K16,
                                     hipStream_t s);
-hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, hipStream_t s);
+hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, float* part,
+                                   hipStream_t s);
+hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
+                              int accumulate, hipStream_t s);
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);
 hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s);
 hipError_t mdt_launch_act_fwd(const float* u, float* out, int64_t n, int act, hipStream_t s);

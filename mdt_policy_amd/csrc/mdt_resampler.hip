@@ -362,7 +362,8 @@ static void carve_rscratch(mdt_resampler* r, Bump& b, int64_t rows, int64_t B) {
     r->g_dq = b.take(lr * I); r->g_datt = b.take(lr * I); r->g_dlat = b.take(lr * D); r->g_ff = b.take(lr * r->ff);
     r->g_td = b.take(lr * D); r->g_pw = b.take(B * D); r->g_pb = b.take(B * D);
     const int64_t mp = (std::min<int64_t>(std::max(rows, lr), 32768) + 15) & ~(int64_t)15;
-    r->g_lin = b.take((size_t)(std::max(2 * I, r->ff) + std::max(std::max(D, I), r->ff)) * mp);
+    r->g_lin = b.take((size_t)(std::max(2 * I, r->ff) + std::max(std::max(D, I), r->ff)) * mp +
+                      (size_t)std::max(2 * I, r->ff) * (mp / 32 + 2));
 }
 
 static mdt_status rscratch(mdt_resampler* r, int64_t rows, int64_t B) {
@@ -487,8 +488,8 @@ static mdt_status r_ln_bwd(mdt_resampler* r, float* grads, const float* x, const
     a.x = x; a.stats = stats; a.w = w; a.b = b; a.shift_off = a.scale_off = -1; a.dh = dh; a.ld_dh = r->D; a.dx = dx;
     a.accumulate = acc; a.pw = r->g_pw; a.pb = r->g_pb; a.B = (int)B; a.rows_per_sample = rps; a.D = r->D;
     LAUNCH(mdt_launch_ln_bwd(a, s));
-    LAUNCH(mdt_launch_colsum(r->g_pw, r->D, (int)B, r->D, grads + r->grad_off[rslot_of(r, w)], 1, s));
-    LAUNCH(mdt_launch_colsum(r->g_pb, r->D, (int)B, r->D, grads + r->grad_off[rslot_of(r, b)], 1, s));
+    LAUNCH(mdt_launch_colsum2(r->g_pw, r->g_pb, r->D, (int)B, r->D, grads + r->grad_off[rslot_of(r, w)],
+                              grads + r->grad_off[rslot_of(r, b)], 1, s));
     return MDT_OK;
 }
 

@@ -230,7 +230,7 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
                                                                std::max<int64_t>(((int64_t)m->Ld * 2 * D + D) * ((Me + 15) & ~15),
                                                                                  (int64_t)(2 * D + std::max(m->G, m->O) + D) * Mp)));
     // (N + K) * Mp of every Linear: MLP 5D (Mp rows); qkv 4D; adaLN stack (Ld*6D + D) on B rows; K|V stack on Me rows
-    ts->lin_scratch = b.take(widest);
+    ts->lin_scratch = b.take(widest + (int64_t)std::max(m->Ld * 6 * D, 4 * D) * (Mp / 32 + 2));  // + bias partials
     ts->dF = b.take(Ma * m->A);
     ts->small = b.take(std::max<int64_t>(B * 2 * D, Mx * (int64_t)std::max(m->O, m->G)));
 }
@@ -521,8 +521,8 @@ static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float
     a.dh = dh; a.ld_dh = m->D; a.dx = dx; a.accumulate = acc; a.d_mod = d_mod; a.d_mod_stride = modw;
     a.pw = ts->pw; a.pb = b ? ts->pb : nullptr; a.B = (int)B; a.rows_per_sample = T; a.D = m->D;
     LAUNCH(mdt_launch_ln_bwd(a, s));
-    LAUNCH(mdt_launch_colsum(ts->pw, m->D, (int)B, m->D, grad_of(m, grads, w), 1, s));
-    if (b) LAUNCH(mdt_launch_colsum(ts->pb, m->D, (int)B, m->D, grad_of(m, grads, b), 1, s));
+    if (b) LAUNCH(mdt_launch_colsum2(ts->pw, ts->pb, m->D, (int)B, m->D, grad_of(m, grads, w), grad_of(m, grads, b), 1, s));
+    else LAUNCH(mdt_launch_colsum(ts->pw, m->D, (int)B, m->D, grad_of(m, grads, w), 1, s));
     return MDT_OK;
 }
 

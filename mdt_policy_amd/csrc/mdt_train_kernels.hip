@@ -38,9 +38,11 @@ hipError_t mdt_launch_pack_weight_t(const float* src, int rows, int cols, int64_
     return hipGetLastError();
 }
 
-// dst (C, ldd) = src (R, C; lds)^T, through a 32x33 LDS tile so both sides are coalesced
+// dst (C, ldd) = src (R, C; lds)^T, through a 32x33 LDS tile so both sides are coalesced.  Optionally also emits
+// per-row-block column sums  part[blockIdx.y][c] = sum of the block's 32 rows of column c  (the bias gradient is
+// then a column sum over R/32 partial rows instead of R rows).
 __global__ __launch_bounds__(256) void k_transpose_ld(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
-                                                      int64_t ldd, int R, int Cc) {
+                                                      int64_t ldd, int R, int Cc, float* __restrict__ part) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -55,10 +57,17 @@ __global__ __launch_bounds__(256) void k_transpose_ld(const float* __restrict__ 
         const int c = c0 + ty + 8 * i, r = r0 + tx;
         if (c < Cc && r < R) dst[(int64_t)c * ldd + r] = tile[tx][ty + 8 * i];
     }
+    if (part && threadIdx.x < 32 && c0 + tx < Cc) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc += tile[r][tx];
+        part[(int64_t)blockIdx.y * Cc + c0 + tx] = acc;
+    }
 }
 
-hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_ld, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, Cc);
+hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, float* part,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_ld, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, Cc, part);
     return hipGetLastError();
 }
 
@@ -283,6 +292,30 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int
         out[c] = accumulate ? out[c] + t : t;
     }
 }
+// two independent column sums of equal shape in one launch (LayerNorm weight / bias partials)
+__global__ __launch_bounds__(256) void k_colsum2(const float* __restrict__ X0, const float* __restrict__ X1, int64_t ldx, int M,
+                                                 int N, float* __restrict__ out0, float* __restrict__ out1, int accumulate) {
+    __shared__ float part[4][64];
+    const float* X = blockIdx.y ? X1 : X0;
+    float* out = blockIdx.y ? out1 : out0;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    if (c < N)
+        for (int m = rg; m < M; m += 4) acc += X[(int64_t)m * ldx + c];
+    part[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < N) {
+        const float t = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
+                              int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_colsum2, dim3((N + 63) / 64, 2), dim3(256), 0, s, X0, X1, ldx, M, N, out0, out1, accumulate);
+    return hipGetLastError();
+}
+
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, s, X, ldx, M, N, out, accumulate);
     return hipGetLastError();

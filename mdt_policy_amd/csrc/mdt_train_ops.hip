@@ -18,7 +18,9 @@
 // Mp = M rounded up to 16; the pad columns / k-slices are zero, so they add nothing.
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || a.K < 1 || (a.K % 16)) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: bad shape");
-    if (a.dbias) LAUNCH(mdt_launch_colsum(a.dY, a.ldy, a.M, a.N, a.dbias, a.accumulate_dw, s));
+    // the bias gradient rides on the transpose the dW path needs anyway (per-32-row column partials)
+    const bool bias_from_partials = a.dbias && a.dW && !(a.N % 16);
+    if (a.dbias && !bias_from_partials) LAUNCH(mdt_launch_colsum(a.dY, a.ldy, a.M, a.N, a.dbias, a.accumulate_dw, s));
     if (a.dW) {
         if (a.N % 16) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: N must be a multiple of 16 for dW");
         // the reduction runs over the rows; very tall inputs (Perceiver media tokens) go through in slices that
@@ -29,11 +31,15 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
             const int Mp = (Ms + 15) & ~15;
             float* dYt = a.scratch;                          // (N, Mp)
             float* Xt = a.scratch + (size_t)a.N * Mp;        // packed (N' = K, K' = Mp)
+            // column partials live in the tail of the packed-X region's slack: (Mp/32 + 1) x N floats behind it
+            float* part = bias_from_partials ? Xt + (size_t)a.K * Mp : nullptr;
             if (Mp != Ms) {
                 HIP_TRY(hipMemsetAsync(dYt, 0, (size_t)a.N * Mp * sizeof(float), s));
                 HIP_TRY(hipMemsetAsync(Xt, 0, (size_t)a.K * Mp * sizeof(float), s));
             }
-            LAUNCH(mdt_launch_transpose_ld(a.dY + (int64_t)m0 * a.ldy, a.ldy, dYt, Mp, Ms, a.N, s));
+            LAUNCH(mdt_launch_transpose_ld(a.dY + (int64_t)m0 * a.ldy, a.ldy, dYt, Mp, Ms, a.N, part, s));
+            if (part)
+                LAUNCH(mdt_launch_colsum(part, a.N, (Ms + 31) / 32, a.N, a.dbias, (a.accumulate_dw || m0 > 0) ? 1 : 0, s));
             LAUNCH(mdt_launch_pack_weight_t(a.X + (int64_t)m0 * a.ldx, Ms, a.K, a.ldx, Xt, 0, Mp / 16, s));
             Lin w;
             w.wp = Xt; w.bias = nullptr; w.N = a.K; w.K = Mp;
