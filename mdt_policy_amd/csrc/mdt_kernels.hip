@@ -591,6 +591,109 @@ static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t 
 
 // activation chunk length: whole K when it fits (always for the LayerNorm prologue), else the largest divisor of K
 // that is a multiple of 16 and <= cap (cap 768 = 97 KiB of LDS for the one-workgroup-per-CU wide tiles, else 384)
+// ------------------------------------------------------------------------------------------------
+// k_gemm_smallm: the same fused GEMM for FEW rows (rollout batches: B = 1 is M = 10 decoder / 4 encoder rows).
+// There the tiled kernel above has N/64 = 6 workgroups, each walking the whole K behind a 6 KB load window:
+// 11-17 us of pure latency.  Here the parallelism comes from the reduction instead: one workgroup per 16 columns
+// (and per 16 rows), its 8 waves split K between them (interleaved k16 steps), every wave keeps 4 weight
+// fragments + 4 activation fragments in flight, partial 16x16 tiles meet in LDS and wave 0 runs the epilogue.
+// Activations come straight from global memory in MFMA-fragment order (lane: row l%16, 4 consecutive k), with
+// LayerNorm / modulate applied in registers from per-row statistics the workgroup computes first.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_gemm_smallm(mdt_gemm_args a, const float* __restrict__ zeros) {
+    __shared__ float s_mean[16], s_rstd[16];
+    __shared__ __attribute__((aligned(16))) float red[8][64][4];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tile = blockIdx.x, m0 = blockIdx.y * 16;
+    const int K16 = a.K >> 4;
+    if (a.ln) {  // row statistics: 32 threads per row, whole row in registers (K <= 512)
+        const int r = tid >> 5, l32 = tid & 31;
+        const int64_t m = min(m0 + r, a.M - 1);
+        const int n4 = a.K >> 2;
+        f32x4 v[4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = l32 + 32 * i;
+            v[i] = c4 < n4 ? ldg4(a.A + m * a.lda + 4 * c4) : zero4;
+            sum += hsum4(v[i]);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)a.K;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = l32 + 32 * i;
+            if (c4 < n4) sq += hsq4(v[i] - mean);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        if (l32 == 0) { s_mean[r] = mean; s_rstd[r] = 1.0f / sqrtf(sq / (float)a.K + 1e-5f); }
+        __syncthreads();
+    }
+    const int mrow = m0 + (lane & 15);
+    const int64_t mc = min(mrow, a.M - 1);
+    const bool mok = mrow < a.M;
+    const int kq = 4 * (lane >> 4);
+    const float* xrow = a.A + mc * a.lda + kq;
+    const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
+    const bool modded = a.ln && a.mod != nullptr && a.shift_off >= 0;
+    const float* mrw = modded ? a.mod + (a.mod_stride == 0 ? 0 : (mc / a.rows_per_sample) * a.mod_stride) : zeros;
+    const float mean = a.ln ? s_mean[lane & 15] : 0.f, rstd = a.ln ? s_rstd[lane & 15] : 1.f;
+    f32x4 acc = zero4;
+    for (int ks0 = wave; ks0 < K16; ks0 += 32) {  // 4 of this wave's k16 steps per round, all loads issued first
+        f32x4 wf[4], xv[4], lw[4], lb[4], sh[4], sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = min(ks0 + 8 * u, K16 - 1);
+            wf[u] = ldg4(wbase + ks * 256);
+            xv[u] = ldg4(xrow + ks * 16);
+            if (a.ln) {
+                lw[u] = ldg4(a.ln_w + ks * 16 + kq);
+                lb[u] = a.ln_b ? ldg4(a.ln_b + ks * 16 + kq) : zero4;
+                if (modded) { sh[u] = ldg4(mrw + a.shift_off + ks * 16 + kq); sc[u] = ldg4(mrw + a.scale_off + ks * 16 + kq); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ks0 + 8 * u < K16) {
+                f32x4 x = xv[u];
+                if (a.ln) {
+                    x = (x - mean) * rstd * lw[u] + lb[u];
+                    if (modded) x = sh[u] + x * sc[u];
+                }
+                x = sel4(mok, x, zero4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][e], x[e], acc, 0, 0, 0);
+            }
+        }
+    }
+    *(f32x4*)&red[wave][lane][0] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 v = *(const f32x4*)&red[0][lane][0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)&red[w][lane][0];
+    // ---- epilogue (as k_gemm): lane holds out[mrow][ncol .. ncol+3]
+    const int ncol = n_tile * 16 + kq;
+    const float* biasp = a.bias != nullptr ? a.bias : zeros;
+    const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+    v = apply_act(v + ldg4(biasp + ncol) + ldg4(rvp + ncol), a.act);
+    const int64_t orow = a.gin == 1 ? mc * a.gout + a.goff : (mc / a.gin) * a.gout + (mc % a.gin) + a.goff;
+    float* op = a.out + orow * a.ldo + ncol;
+    if (a.residual) {
+        f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (a.gate_off >= 0)
+            g = ldg4(a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (mc / a.rows_per_sample) * a.mod_stride) + ncol);
+        v = ldg4(op) + g * v;
+    }
+    if (mok) st4(op, v);
+}
+
+static int g_mdt_smallm_max = -1;  // rows up to which k_gemm_smallm is used (env MDT_HIP_SMALLM_MAX, default below)
+
 int mdt_gemm_kchunk(int K, int ln, int cap) {
     if (ln || K <= 512) return K;
     for (int c = cap; c >= 16; c -= 16)
@@ -614,6 +717,14 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
     hipError_t ze = ensure_zeros();
     if (ze != hipSuccess) return ze;
+    if (g_mdt_smallm_max < 0) {
+        const char* e = getenv("MDT_HIP_SMALLM_MAX");
+        g_mdt_smallm_max = e ? atoi(e) : 192;  // measured crossover with the tiled kernel: M ~ 240 (tools/latency.py)
+    }
+    if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512)) {
+        hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4), dim3(512), 0, s, a, g_zeros);
+        return hipGetLastError();
+    }
     // Geometry selection (rows are in tiles of 32).  The decoder at B = 256 has 80 row tiles for 256 CUs:
     //   wide  (8 waves, 32 x 512 / 32 x 384): N >= 1024 -> 240 workgroups, each activation tile re-read 3x
     //   mid   (8 waves, 32 x 128)           : N  < 1024 -> 240 workgroups for N = 384

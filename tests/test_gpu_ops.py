@@ -96,7 +96,8 @@ def test_gemm_plain_bias(lib, M, N, K):
 @pytest.mark.parametrize("M,N,K,ln", [(2560, 1152, 384, True), (2560, 384, 1536, False), (100, 528, 128, True),
                                       (77, 1536, 384, True), (33, 384, 768, False), (64, 1024, 80, False)])
 def test_gemm_every_geometry(lib, geo, M, N, K, ln):
-    """All workgroup geometries give the same (bit-identical) result: the k order of every dot product is fixed."""
+    """All TILED workgroup geometries give the same (bit-identical) result: the k order of every dot product is fixed.
+    The heuristic (geometry 0) may pick the split-K small-M kernel instead: equal to rounding."""
     g = torch.Generator().manual_seed(geo * 0 + M + N + K)
     A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
     lw = torch.randn(K, generator=g) * 0.2 + 1
@@ -105,13 +106,70 @@ def test_gemm_every_geometry(lib, geo, M, N, K, ln):
     want = (y0.double() + x @ W.double().T + b.double()).float()
     try:
         lib.load().mdt_op_set_gemm_geometry(0)
+        heur = run_gemm(lib, A, W, bias=b, ln_w=lw if ln else None, residual_into=y0)
+        lib.load().mdt_op_set_gemm_geometry(1)
         ref = run_gemm(lib, A, W, bias=b, ln_w=lw if ln else None, residual_into=y0)
         lib.load().mdt_op_set_gemm_geometry(geo)
         got = run_gemm(lib, A, W, bias=b, ln_w=lw if ln else None, residual_into=y0)
     finally:
         lib.load().mdt_op_set_gemm_geometry(0)
     assert_close(got, want, rtol=1e-4, atol=1e-4, what=f"geometry {geo}")
-    assert torch.equal(got, ref), "geometries disagree bitwise"
+    assert torch.equal(got, ref), "tiled geometries disagree bitwise"
+    assert_close(heur, ref, rtol=1e-5, atol=1e-5, what="heuristic choice vs tiled")
+
+
+@pytest.mark.parametrize("M", [1, 10, 16, 17, 40, 160, 192, 193])
+@pytest.mark.parametrize("case", ["plain", "ln_mod_rows", "ln_bias_bcast", "gated_residual_k1536", "remap_gelu"])
+def test_gemm_small_m_kernel_matches_reference_and_tiled(lib, M, case):
+    """Rollout-sized batches (M <= 192 rows) run on k_gemm_smallm (K split over a workgroup's 8 waves); every fused
+    feature against float64 and against the tiled kernel forced through the geometry hook (M = 193: tiled anyway)."""
+    g = torch.Generator().manual_seed(M * 31 + len(case))
+    D, T = 384, 1
+    kw, N, K = {}, 384, 384
+    if case == "plain":
+        N, K = 1152, 768
+        A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+        want = A.double() @ W.double().T + b.double()
+        kw = dict(bias=b)
+    elif case in ("ln_mod_rows", "ln_bias_bcast"):
+        N = 1536
+        A, W, b = torch.randn(M, D, generator=g) * 2 + 0.3, torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g)
+        lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+        rows = case == "ln_mod_rows"
+        T = 10 if (rows and M % 10 == 0) else 1
+        nb = M // T
+        mod = torch.randn(nb if rows else 1, 6 * D, generator=g)
+        x = F.layer_norm(A.double(), (D,), lw.double(), None if rows else lb.double(), 1e-5)
+        mr = mod.double().repeat_interleave(T, 0) if rows else mod.double()
+        x = mr[:, 3 * D:4 * D] + x * mr[:, 4 * D:5 * D]
+        want = x @ W.double().T + b.double()
+        kw = dict(bias=b, ln_w=lw, ln_b=None if rows else lb, mod=mod if rows else mod[0].clone(),
+                  mod_stride=6 * D if rows else 0, shift_off=3 * D, scale_off=4 * D, rps=T)
+    elif case == "gated_residual_k1536":
+        K = 1536
+        T = 10 if M % 10 == 0 else 1
+        A, W = torch.randn(M, K, generator=g), torch.randn(D, K, generator=g) / math.sqrt(K)
+        y0, mod = torch.randn(M, D, generator=g), torch.randn(M // T, 6 * D, generator=g)
+        want = y0.double() + (A.double() @ W.double().T) * mod[:, 5 * D:].double().repeat_interleave(T, 0)
+        kw = dict(residual_into=y0, mod=mod, mod_stride=6 * D, rps=T, gate_off=5 * D)
+    else:  # rows scattered into a wider buffer, positional row vector, GELU
+        N, K = 128, 512
+        A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+        pos = torch.randn(N, generator=g)
+        want = F.gelu(A.double() @ W.double().T + pos.double())
+        kw = dict(gin=1, gout=3, goff=2, rowvec=pos, out_rows=M * 3, act="gelu")
+    outs = {}
+    try:
+        for geo in (0, 1):
+            lib.load().mdt_op_set_gemm_geometry(geo)
+            o = run_gemm(lib, A, W, **kw)
+            outs[geo] = o.reshape(M, 3, N)[:, 2] if case == "remap_gelu" else o
+            if case == "remap_gelu":
+                assert torch.isnan(o.reshape(M, 3, N)[:, :2]).all()
+    finally:
+        lib.load().mdt_op_set_gemm_geometry(0)
+    assert_close(outs[0], want.float(), rtol=2e-4, atol=2e-4, what=f"{case} M={M}")
+    assert_close(outs[0], outs[1], rtol=1e-5, atol=2e-5, what=f"{case} M={M}: small-M vs tiled")
 
 
 def test_gemm_is_transpose_sensitive(lib):

@@ -178,7 +178,8 @@ def test_against_oracle_random_batch_sizes():
 
 def test_full_size_properties():
     """Size-independent properties at B=256: determinism and batch independence (a sample's actions do not
-    depend on what else is in the batch -- bit-exact, the k-order of every dot product is fixed)."""
+    depend on what else is in the batch).  Bit-exact between batches served by the same GEMM kernel (the k-order of
+    every dot product is fixed); across the small-M / tiled kernel switch (M = 192 rows) equal to rounding."""
     meta, _ = load_fixture("g3_b256_lang.npz")
     model = build(meta)
     state, goal, noise = gpu_inputs(meta)
@@ -187,10 +188,13 @@ def test_full_size_properties():
         a = sampling().sample_ddim(model, state, noise * 80.0, goal, sig)
         b = sampling().sample_ddim(model, state, noise * 80.0, goal, sig)
         assert torch.equal(a, b), "non-deterministic"
-        sub = slice(100, 117)
-        st = {"state_images": state["state_images"][sub].contiguous(), "modality": state["modality"]}
-        c = sampling().sample_ddim(model, st, noise[sub] * 80.0, goal[sub], sig)
-    assert torch.equal(a[sub], c), "batch dependence"
+        for sub, exact in ((slice(20, 220), True), (slice(100, 117), False)):
+            st = {"state_images": state["state_images"][sub].contiguous(), "modality": state["modality"]}
+            c = sampling().sample_ddim(model, st, noise[sub] * 80.0, goal[sub], sig)
+            if exact:
+                assert torch.equal(a[sub], c), "batch dependence"
+            else:
+                assert_close(c.cpu(), a[sub].cpu(), rtol=1e-5, atol=2e-6, what="batch dependence (small-M kernel)")
     assert torch.isfinite(a).all()
 
 
