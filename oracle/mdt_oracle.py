@@ -99,7 +99,7 @@ def rotary_tables(n_pos: int, dtype, rot_dim: int = 32, theta: float = 10000.0):
 def apply_rotary(t: Tensor, rot_dim: int) -> Tensor:
     """position_embeddings.py:56-70,138-142: rotate the first rot_dim features of (B,H,T,hd) in
     interleaved pairs by the token's own position 0..T-1."""
-    cos, sin = rotary_tables(t.shape[-2], t.dtype, rot_dim)
+    cos, sin = (v.to(t.device) for v in rotary_tables(t.shape[-2], t.dtype, rot_dim))
     tr, rest = t[..., :rot_dim], t[..., rot_dim:]
     x1, x2 = tr[..., 0::2], tr[..., 1::2]
     half = torch.stack((-x2, x1), dim=-1).flatten(-2)
@@ -123,7 +123,7 @@ def attention(P: Params, pre: str, x: Tensor, ctx: Optional[Tensor], n_heads: in
     att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hd))
     if causal:
         Tk = k.shape[-2]
-        keep = torch.ones(T, Tk, dtype=torch.bool).tril()
+        keep = torch.ones(T, Tk, dtype=torch.bool, device=att.device).tril()
         att = att.masked_fill(~keep, float("-inf"))
     y = att.softmax(dim=-1) @ v
     y = y.transpose(1, 2).reshape(B, T, C)
@@ -251,7 +251,7 @@ def sigma_embedding(P: Params, cfg: dict, sigma: Tensor) -> Tensor:
     d = cfg["embed_dim"]
     half = d // 2
     s = (sigma.log() / 4)[:, None]
-    f = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(sigma.dtype)
+    f = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(sigma)  # dtype and device of sigma
     e = s * f[None, :]
     e = torch.cat((e.sin(), e.cos()), dim=-1)
     c = _lin(P, "inner_model.sigma_emb.3", F.mish(_lin(P, "inner_model.sigma_emb.1", e)))
