@@ -61,6 +61,22 @@ def get_sigmas_ve(n, sigma_min=0.02, sigma_max=100, device='cpu'):
     return append_zero(torch.sqrt(t))
 
 
+def get_iddpm_sigmas(n, sigma_min=0.02, sigma_max=100, M=1000, j_0=0, C_1=0.001, C_2=0.008, device='cpu'):
+    """Improved-DDPM schedule (reference gc_sampling.py:71-81): u_{j-1} from the cosine alpha-bar recursion, the
+    levels inside [sigma_min, sigma_max] sub-sampled at n evenly spaced (rounded) indices.  As in the reference the
+    alpha-bar ratios are float32 (Python float x integer tensor promotes to the default dtype) and only the
+    recursion itself runs in float64 -- the ratios near j = M sit within rounding of 1, so this matters at 1e-4."""
+    j = torch.arange(0, M + 1, device=device)
+    abar = (0.5 * np.pi * j / M / (C_2 + 1)).sin() ** 2              # float32
+    ratio = (abar[:-1] / abar[1:]).clip(min=C_1)                     # ratio[j-1] = abar(j-1) / abar(j)
+    u = torch.zeros(M + 1, dtype=torch.float64, device=device)
+    for jj in range(M, j_0, -1):
+        u[jj - 1] = ((u[jj] ** 2 + 1) / ratio[jj - 1] - 1).sqrt()
+    kept = u[torch.logical_and(u >= sigma_min, u <= sigma_max)]
+    idx = ((len(kept) - 1) / (n - 1) * torch.arange(n, dtype=torch.float64, device=device)).round().to(torch.int64)
+    return append_zero(kept[idx]).to(torch.float32)
+
+
 def get_sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3, device='cpu'):
     t = torch.linspace(1, eps_s, n, device=device)
     return append_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1))
@@ -396,6 +412,256 @@ def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, e
                 denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action, model), **extra_args)
                 action = _f(_sigma(t_next) / _sigma(t)) * action - _f((-h).expm1()) * denoised_2
             action = action + noise_sampler(sig[i], sig[i + 1]) * s_noise * _f(sigma_up)
+            if scaler is not None:
+                action = scaler.clip_output(action)
+    return action
+
+
+# ------------------------------------------------------------------------------------------------
+# DPM-Solver (fixed-step "fast" and adaptive) and DPM-Solver++ SDE      (reference gc_sampling.py:495-690,737-790,834-870)
+# ------------------------------------------------------------------------------------------------
+class BrownianTreeNoiseSampler:
+    """Noise sampler backed by torchsde.BrownianTree (reference gc_sampling.py:112-160), the default of
+    ``sample_dpmpp_sde``.  torchsde is an optional dependency, exactly as in the reference: without it, pass your own
+    ``noise_sampler(sigma, sigma_next)``."""
+
+    def __init__(self, x, sigma_min, sigma_max, seed=None, transform=lambda x: x):
+        try:
+            import torchsde
+        except ImportError as e:  # pragma: no cover - environment dependent
+            raise ImportError("BrownianTreeNoiseSampler needs torchsde (as the reference does); pass noise_sampler=... "
+                              "to sample_dpmpp_sde instead") from e
+        self.transform = transform
+        t0, t1 = self.transform(torch.as_tensor(sigma_min)), self.transform(torch.as_tensor(sigma_max))
+        self.sign = 1 if t0 < t1 else -1
+        lo, hi = (t0, t1) if t0 < t1 else (t1, t0)
+        seeds = [torch.randint(0, 2 ** 63 - 1, []).item()] if seed is None else ([seed] if isinstance(seed, int) else list(seed))
+        self.batched = not (seed is None or isinstance(seed, int))
+        w0 = torch.zeros_like(x[0] if self.batched else x)
+        self.trees = [torchsde.BrownianTree(lo, w0, hi, entropy=sd) for sd in seeds]
+
+    def __call__(self, sigma, sigma_next):
+        t0, t1 = self.transform(torch.as_tensor(sigma)), self.transform(torch.as_tensor(sigma_next))
+        sign = 1 if t0 < t1 else -1
+        lo, hi = (t0, t1) if t0 < t1 else (t1, t0)
+        w = torch.stack([tree(lo, hi) for tree in self.trees]) * (self.sign * sign)
+        return (w if self.batched else w[0]) / (t1 - t0).abs().sqrt()
+
+
+class PIDStepSizeController:
+    """PID step-size controller of the adaptive DPM-Solver (reference gc_sampling.py:495-521)."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h = h
+        self.b1 = (pcoeff + icoeff + dcoeff) / order
+        self.b2 = -(pcoeff + 2 * dcoeff) / order
+        self.b3 = dcoeff / order
+        self.accept_safety, self.eps, self.errs = accept_safety, eps, []
+
+    def propose_step(self, error):
+        inv = 1 / (float(error) + self.eps)
+        if not self.errs:
+            self.errs = [inv, inv, inv]
+        self.errs[0] = inv
+        factor = self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3
+        factor = 1 + math.atan(factor - 1)  # limiter
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs[2], self.errs[1] = self.errs[1], self.errs[0]
+        self.h *= factor
+        return accept
+
+
+class DPMSolver:
+    """DPM-Solver-1/2/3 steps in t = -ln(sigma) (reference gc_sampling.py:524-670, arXiv:2206.00927).  Time values are
+    0-dim host tensors; the model is evaluated at sigma = exp(-t) shared by the whole batch."""
+
+    def __init__(self, model, extra_args=None, eps_callback=None, info_callback=None):
+        self.model = model
+        self.extra_args = {} if extra_args is None else extra_args
+        self.eps_callback, self.info_callback = eps_callback, info_callback
+
+    t = staticmethod(_t)
+    sigma = staticmethod(_sigma)
+
+    def eps(self, cache, key, state, action, goal, t):
+        if key in cache:
+            return cache[key], cache
+        sig = _sigma(t)
+        e = (action - self.model(state, action, goal, _sig_in(sig, action, self.model), **self.extra_args)) / _f(sig)
+        if self.eps_callback is not None:
+            self.eps_callback()
+        return e, {key: e, **cache}
+
+    def dpm_solver_1_step(self, state, action, goal, t, t_next, eps_cache=None):
+        cache = {} if eps_cache is None else eps_cache
+        h = t_next - t
+        e, cache = self.eps(cache, 'eps', state, action, goal, t)
+        return action - _f(_sigma(t_next) * h.expm1()) * e, cache
+
+    def dpm_solver_2_step(self, state, action, goal, t, t_next, r1=1 / 2, eps_cache=None):
+        cache = {} if eps_cache is None else eps_cache
+        h = t_next - t
+        e, cache = self.eps(cache, 'eps', state, action, goal, t)
+        s1 = t + r1 * h
+        u1 = action - _f(_sigma(s1) * (r1 * h).expm1()) * e
+        e1, cache = self.eps(cache, 'eps_r1', state, u1, goal, s1)
+        out = action - _f(_sigma(t_next) * h.expm1()) * e - _f(_sigma(t_next) / (2 * r1) * h.expm1()) * (e1 - e)
+        return out, cache
+
+    def dpm_solver_3_step(self, state, action, goal, t, t_next, r1=1 / 3, r2=2 / 3, eps_cache=None):
+        cache = {} if eps_cache is None else eps_cache
+        h = t_next - t
+        e, cache = self.eps(cache, 'eps', state, action, goal, t)
+        s1, s2 = t + r1 * h, t + r2 * h
+        u1 = action - _f(_sigma(s1) * (r1 * h).expm1()) * e
+        e1, cache = self.eps(cache, 'eps_r1', state, u1, goal, s1)
+        u2 = action - _f(_sigma(s2) * (r2 * h).expm1()) * e \
+            - _f(_sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1)) * (e1 - e)
+        e2, cache = self.eps(cache, 'eps_r2', state, u2, goal, s2)
+        out = action - _f(_sigma(t_next) * h.expm1()) * e - _f(_sigma(t_next) / r2 * (h.expm1() / h - 1)) * (e2 - e)
+        return out, cache
+
+    def dpm_solver_fast(self, state, action, goal, t_start, t_end, nfe, eta=0., s_noise=1., noise_sampler=None):
+        # (the reference builds its default noise sampler from an undefined name, gc_sampling.py:600, so it only
+        #  runs with an explicit one; here the default is the action-shaped Gaussian sampler it meant)
+        noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+        if not t_end > t_start and eta:
+            raise ValueError('eta must be 0 for reverse sampling')
+        m = math.floor(nfe / 3) + 1
+        ts = torch.linspace(_f(t_start), _f(t_end), m + 1)
+        orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
+        with _hoist(self.model, state, goal):
+            for i, order in enumerate(orders):
+                cache = {}
+                t, t_next = ts[i], ts[i + 1]
+                if eta:
+                    sd, su = get_ancestral_step(_sigma(t), _sigma(t_next), eta)
+                    t_next_ = torch.minimum(torch.as_tensor(t_end), _t(sd))
+                    su = (_sigma(t_next) ** 2 - _sigma(t_next_) ** 2) ** 0.5
+                else:
+                    t_next_, su = t_next, 0.
+                e, cache = self.eps(cache, 'eps', state, action, goal, t)
+                if self.info_callback is not None:
+                    self.info_callback({'x': action, 'i': i, 't': ts[i], 't_up': t, 'denoised': action - _f(_sigma(t)) * e})
+                step = (self.dpm_solver_1_step, self.dpm_solver_2_step, self.dpm_solver_3_step)[order - 1]
+                action, cache = step(state, action, goal, t, t_next_, eps_cache=cache)
+                if _f(su) != 0:
+                    action = action + _f(su) * s_noise * noise_sampler(_sigma(t), _sigma(t_next))
+        return action
+
+    def dpm_solver_adaptive(self, state, action, goal, t_start, t_end, order=3, rtol=0.05, atol=0.0078, h_init=0.05,
+                            pcoeff=0., icoeff=1., dcoeff=0., accept_safety=0.81, eta=0., s_noise=1., noise_sampler=None):
+        # (the reference reads `noise_sampler` before assigning it, gc_sampling.py:633: its adaptive solver cannot run)
+        noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+        if order not in {2, 3}:
+            raise ValueError('order should be 2 or 3')
+        t_start, t_end = torch.as_tensor(t_start, dtype=torch.float32), torch.as_tensor(t_end, dtype=torch.float32)
+        forward = bool(t_end > t_start)
+        if not forward and eta:
+            raise ValueError('eta must be 0 for reverse sampling')
+        h_init = abs(h_init) * (1 if forward else -1)
+        s = t_start
+        action_prev = action
+        pid = PIDStepSizeController(h_init, pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
+        info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
+        with _hoist(self.model, state, goal):
+            while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+                cache = {}
+                t = torch.minimum(t_end, s + pid.h) if forward else torch.maximum(t_end, s + pid.h)
+                if eta:
+                    sd, su = get_ancestral_step(_sigma(s), _sigma(t), eta)
+                    t_ = torch.minimum(t_end, _t(sd))
+                    su = (_sigma(t) ** 2 - _sigma(t_) ** 2) ** 0.5
+                else:
+                    t_, su = t, 0.
+                e, cache = self.eps(cache, 'eps', state, action, goal, s)
+                denoised = action - _f(_sigma(s)) * e
+                if order == 2:
+                    low, cache = self.dpm_solver_1_step(state, action, goal, s, t_, eps_cache=cache)
+                    high, cache = self.dpm_solver_2_step(state, action, goal, s, t_, eps_cache=cache)
+                else:
+                    low, cache = self.dpm_solver_2_step(state, action, goal, s, t_, r1=1 / 3, eps_cache=cache)
+                    high, cache = self.dpm_solver_3_step(state, action, goal, s, t_, eps_cache=cache)
+                delta = torch.clamp(rtol * torch.maximum(low.abs(), action_prev.abs()), min=atol)
+                error = torch.linalg.norm((low - high) / delta) / action.numel() ** 0.5
+                if pid.propose_step(error):
+                    action_prev = low
+                    action = high if _f(su) == 0 else high + _f(su) * s_noise * noise_sampler(_sigma(s), _sigma(t))
+                    s = t
+                    info['n_accept'] += 1
+                else:
+                    info['n_reject'] += 1
+                info['nfe'] += order
+                info['steps'] += 1
+                if self.info_callback is not None:
+                    self.info_callback({'x': action, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised,
+                                        'error': error, 'h': pid.h, **info})
+        return action, info
+
+
+@torch.no_grad()
+def sample_dpm_fast(model, state, action, goal, sigma_min, sigma_max, n, scaler=None, extra_args=None, callback=None,
+                    disable=None, eta=0., s_noise=1., noise_sampler=None):
+    """DPM-Solver-Fast, fixed step size, n model evaluations (reference gc_sampling.py:673-697)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    solver = DPMSolver(model, extra_args)
+    if callback is not None:
+        solver.info_callback = lambda info: callback({'sigma': _sigma(info['t']), 'sigma_hat': _sigma(info['t_up']), **info})
+    return solver.dpm_solver_fast(state, action, goal, _t(torch.tensor(float(sigma_max))), _t(torch.tensor(float(sigma_min))),
+                                  n, eta, s_noise, noise_sampler)
+
+
+@torch.no_grad()
+def sample_dpm_adaptive(model, state, action, goal, sigma_min, sigma_max, extra_args=None, callback=None, disable=None,
+                        order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0., icoeff=1., dcoeff=0., accept_safety=0.81,
+                        eta=0., s_noise=1., return_info=False, noise_sampler=None):
+    """DPM-Solver-12 / -23 with adaptive step size (reference gc_sampling.py:834-870)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    solver = DPMSolver(model, extra_args)
+    if callback is not None:
+        solver.info_callback = lambda info: callback({'sigma': _sigma(info['t']), 'sigma_hat': _sigma(info['t_up']), **info})
+    action, info = solver.dpm_solver_adaptive(state, action, goal, _t(torch.tensor(float(sigma_max))),
+                                              _t(torch.tensor(float(sigma_min))), order, rtol, atol, h_init, pcoeff, icoeff,
+                                              dcoeff, accept_safety, eta, s_noise, noise_sampler)
+    return (action, info) if return_info else action
+
+
+@torch.no_grad()
+def sample_dpmpp_sde(model, state, action, goal, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1.,
+                     scaler=None, noise_sampler=None, r=1 / 2):
+    """DPM-Solver++ (stochastic) (reference gc_sampling.py:737-790): a midpoint evaluation at s = t + r h, ancestral
+    noise at both sub-steps from ``noise_sampler(sigma, sigma_next)`` (default: a torchsde Brownian tree)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host(sigmas)
+    if noise_sampler is None:
+        noise_sampler = BrownianTreeNoiseSampler(action, sig[sig > 0].min(), sig.max())
+    fac = 1 / (2 * r)
+    with _hoist(model, state, goal):
+        for i in range(len(sig) - 1):
+            denoised = model(state, action, goal, _sig_in(sig[i], action, model), **extra_args)
+            if callback is not None:
+                callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+            if sig[i + 1] == 0:
+                action = action + to_d(action, sig[i], denoised) * _f(sig[i + 1] - sig[i])  # Euler
+                continue
+            t, t_next = _t(sig[i]), _t(sig[i + 1])
+            h = t_next - t
+            s = t + h * r
+            sd, su = get_ancestral_step(_sigma(t), _sigma(s), eta)
+            s_ = _t(sd)
+            x_2 = _f(_sigma(s_) / _sigma(t)) * action - _f((t - s_).expm1()) * denoised
+            if _f(su) != 0:
+                x_2 = x_2 + noise_sampler(_sigma(t), _sigma(s)) * (s_noise * _f(su))
+            denoised_2 = model(state, x_2, goal, _sig_in(_sigma(s), action, model), **extra_args)
+            sd, su = get_ancestral_step(_sigma(t), _sigma(t_next), eta)
+            t_next_ = _t(sd)
+            denoised_d = (1 - fac) * denoised + fac * denoised_2
+            action = _f(_sigma(t_next_) / _sigma(t)) * action - _f((t - t_next_).expm1()) * denoised_d
+            if _f(su) != 0:
+                action = action + noise_sampler(_sigma(t), _sigma(t_next)) * (s_noise * _f(su))
             if scaler is not None:
                 action = scaler.clip_output(action)
     return action

@@ -316,6 +316,25 @@ def g7():
     torch.manual_seed(1234)
     out["euler_churn_seed1234"] = gs.sample_euler(model, state, x0.clone(), goal, sigmas, disable=True, s_churn=4.).numpy()
     save("g7b_samplers.npz", meta, **out)
+    # DPM-Solver-fast / DPM-Solver++ SDE.  sample_dpm_fast only runs in the reference with an explicit noise sampler
+    # (its default reads an undefined name, gc_sampling.py:600), sample_dpmpp_sde's default needs torchsde: both get a
+    # deterministic stand-in sampler returning a fixed N(0,1) tensor.  sample_dpm_adaptive cannot run in the
+    # reference at all (gc_sampling.py:633 reads noise_sampler before assignment): no golden for it.
+    out = {}
+    fixed = torch.from_numpy(synthetic.normal("sde_noise", tuple(x0.shape), 73))
+    ns = lambda s0, s1: fixed
+    solver = gs.DPMSolver(model)
+    for nfe in (9, 10, 11):
+        out[f"dpm_fast_nfe{nfe}"] = solver.dpm_solver_fast(state, x0.clone(), goal, solver.t(torch.tensor(80.0)),
+                                                           solver.t(torch.tensor(0.001)), nfe, 0., 1., ns).detach().numpy()
+    with torch.no_grad():
+        out["dpmpp_sde_eta0"] = gs.sample_dpmpp_sde(model, state, x0.clone(), goal, sigmas, disable=True, eta=0.,
+                                                    noise_sampler=ns).numpy()
+        out["dpmpp_sde_eta1_fixednoise"] = gs.sample_dpmpp_sde(model, state, x0.clone(), goal, sigmas, disable=True, eta=1.,
+                                                               noise_sampler=ns).numpy()
+    out["iddpm_10"] = gs.get_iddpm_sigmas(10, 0.001, 80.0).numpy()
+    out["iddpm_20_default"] = gs.get_iddpm_sigmas(20).numpy()
+    save("g7c_samplers.npz", dict(meta, noise_seed=73), **out)
 
 
 G8_VARIANTS = {

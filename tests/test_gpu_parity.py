@@ -331,6 +331,35 @@ def test_g7b_remaining_samplers(name, kw, key):
     assert_close(out.cpu(), fx[key], what=key)
 
 
+def test_g7c_dpm_solver_fast_sde_and_adaptive():
+    """DPM-Solver-fast and DPM-Solver++ SDE with the HIP denoiser step against the reference's outputs; the adaptive
+    solver (no reference output exists: the reference's cannot run) against the same solver driven by the oracle."""
+    from mdt_policy_amd import synthetic
+    meta, fx = load_fixture("g7c_samplers.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    x0 = noise * 80.0
+    fixed = torch.from_numpy(synthetic.normal("sde_noise", tuple(x0.shape), meta["noise_seed"])).cuda()
+    ns = lambda s0, s1: fixed
+    with torch.no_grad():
+        for nfe in (9, 10, 11):
+            out = gs.sample_dpm_fast(model, state, x0.clone(), goal, 0.001, 80.0, nfe, noise_sampler=ns)
+            assert_close(out.cpu(), fx[f"dpm_fast_nfe{nfe}"], what=f"dpm_fast nfe={nfe}")
+        sig = gs.get_sigmas_exponential(10, 0.001, 80.0)
+        for eta, key in ((0., "dpmpp_sde_eta0"), (1., "dpmpp_sde_eta1_fixednoise")):
+            out = gs.sample_dpmpp_sde(model, state, x0.clone(), goal, sig, eta=eta, noise_sampler=ns)
+            assert_close(out.cpu(), fx[key], what=key)
+        got, info = gs.sample_dpm_adaptive(model, state, x0.clone(), goal, 0.01, 80.0, return_info=True)
+    cfg, P = cfg_of(meta), params_of(meta)
+    cstate, cgoal, cnoise = inputs_of(meta)
+    ctx = O.encode(P, cfg, cstate, cgoal)
+    want, winfo = gs.sample_dpm_adaptive(lambda s, x, g, sg: O.denoise(P, cfg, s, x, g, sg, ctx=ctx), cstate, cnoise * 80.0,
+                                         cgoal, 0.01, 80.0, return_info=True)
+    assert info["nfe"] == winfo["nfe"] and info["n_accept"] == winfo["n_accept"]
+    assert_close(got.cpu(), want, rtol=2e-3, atol=5e-4, what="dpm_adaptive (HIP step vs oracle step)")
+
+
 def test_c4_total_batch_2048_matches_the_b256_golden_slice():
     """BASELINE config C4's total request (B = 2048) on one GPU: the first 256 chunks are the G3 inputs, the rest
     fresh seeds; their actions must equal the B=256 reference golden (batch independence at the maximum size)."""
