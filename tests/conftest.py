@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs small matrices: more than a handful of intra-op threads only adds synchronisation cost
+    # (on a 256-thread host the oracle tests ran 10x slower with the default thread count)
+    try:
+        import torch
+        torch.set_num_threads(min(8, torch.get_num_threads()))
+    except Exception:  # pragma: no cover
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
