@@ -64,10 +64,11 @@ mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);
 
 /* Tuning / test hook: force the workgroup geometry of every following GEMM launch in this process.
  * 0 = heuristic (default): for M <= 192 rows (rollout-sized batches) the split-K small-M kernel -- one workgroup per
- * 16 columns, K divided between its 8 waves -- otherwise one of the tiled geometries;
- * 1 = 4 waves 32x64; 2 = 8 waves 32x128; 3 = 8 waves 32x384; 4 = 8 waves 32x512; 5 = 4 waves 32x128.
+ * 16 columns, K divided between its 8 waves -- for M <= 1400 the half-height tiled geometry 6, otherwise the widest
+ * tiled geometry that still fills the chip;
+ * 1 = 4 waves 32x64; 2 = 8 waves 32x128; 3 = 8 waves 32x384; 4 = 8 waves 32x512; 5 = 4 waves 32x128; 6 = 4 waves 16x64.
  * The tiled geometries compute bit-identical results (same k order per output element); the small-M kernel agrees
- * to rounding.  MDT_HIP_SMALLM_MAX (environment) moves the row threshold (0 disables the small-M kernel). */
+ * to rounding.  MDT_HIP_SMALLM_MAX / MDT_HIP_MID_MAX (environment) move the two row thresholds (0 disables). */
 void mdt_op_set_gemm_geometry(int32_t geometry);
 
 typedef struct {

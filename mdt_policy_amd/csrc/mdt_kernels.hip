@@ -692,6 +692,7 @@ __global__ __launch_bounds__(512) void k_gemm_smallm(mdt_gemm_args a, const floa
     if (mok) st4(op, v);
 }
 
+static int g_mdt_mid_max = 1400;    // rows up to which the 16 x 64 tiled geometry is used (env MDT_HIP_MID_MAX)
 static int g_mdt_smallm_max = -1;  // rows up to which k_gemm_smallm is used (env MDT_HIP_SMALLM_MAX, default below)
 
 int mdt_gemm_kchunk(int K, int ln, int cap) {
@@ -710,7 +711,7 @@ static hipError_t launch_gemm_pro(const mdt_gemm_args& a, int kchunk, hipStream_
     return launch_gemm_t<MTILES, NTW, NWAVES, PRO_LN>(a, kchunk, s);
 }
 
-int g_mdt_gemm_force = 0;  // tuning hook: 0 = heuristic, else 1..5 selects a geometry below
+int g_mdt_gemm_force = 0;  // tuning hook: 0 = heuristic, else 1..6 selects a geometry below
 static const bool g_mdt_gemm_nopipe = getenv("MDT_HIP_NOPIPE") != nullptr;  // A/B switch for k_gemm_pipe
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
@@ -720,6 +721,8 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (g_mdt_smallm_max < 0) {
         const char* e = getenv("MDT_HIP_SMALLM_MAX");
         g_mdt_smallm_max = e ? atoi(e) : 192;  // measured crossover with the tiled kernel: M ~ 240 (tools/latency.py)
+        const char* f = getenv("MDT_HIP_MID_MAX");
+        if (f) g_mdt_mid_max = atoi(f);
     }
     if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512)) {
         hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4), dim3(512), 0, s, a, g_zeros);
@@ -748,6 +751,9 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
             if (cnt > most) { most = cnt; geo = g; }
         }
     }
+    // mid-size row counts (batches of ~20..140 chunks, and the training path's 384..1536-row dW products): half-height
+    // tiles double the workgroup count; measured 4-17 % faster per sampler call up to M ~ 1400, slower beyond 2000
+    if (a.M <= g_mdt_mid_max) geo = 6;
     if (g_mdt_gemm_force) geo = g_mdt_gemm_force;
     switch (geo) {
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
@@ -760,6 +766,7 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
             return launch_gemm_pro<2, 1, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 3: return launch_gemm_pro<2, 3, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 4: return launch_gemm_pro<2, 4, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
+        case 6: return launch_gemm_pro<1, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 16 x 64
         default: return launch_gemm_pro<2, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
     }
 }

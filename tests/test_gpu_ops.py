@@ -92,7 +92,7 @@ def test_gemm_plain_bias(lib, M, N, K):
     assert_close(got, want, rtol=1e-4, atol=1e-4, what=f"gemm {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("geo", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("geo", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K,ln", [(2560, 1152, 384, True), (2560, 384, 1536, False), (100, 528, 128, True),
                                       (77, 1536, 384, True), (33, 384, 768, False), (64, 1024, 80, False)])
 def test_gemm_every_geometry(lib, geo, M, N, K, ln):
