@@ -77,7 +77,7 @@ class LnBwdArgs(C.Structure):
                 ("mod_stride", C.c_int64), ("shift_off", C.c_int32), ("scale_off", C.c_int32),
                 ("dh", C.c_void_p), ("ld_dh", C.c_int64), ("dx", C.c_void_p), ("accumulate", C.c_int32),
                 ("d_mod", C.c_void_p), ("d_mod_stride", C.c_int64), ("pw", C.c_void_p), ("pb", C.c_void_p),
-                ("B", C.c_int32), ("rows_per_sample", C.c_int32), ("D", C.c_int32)]
+                ("B", C.c_int32), ("rows_per_sample", C.c_int32), ("D", C.c_int32), ("row_chunks", C.c_int32)]
 
 
 class AttnBwdArgs(C.Structure):

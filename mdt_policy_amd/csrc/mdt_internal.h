@@ -121,8 +121,8 @@ hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const floa
                                          const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
                                          int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s);
 bool mdt_attention_long_bwd_supported(int hd, int Tq, int Tk);
-hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, int64_t B, int T, int n, int D,
-                                    int accumulate, hipStream_t s);
+hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, float* partial, int64_t B, int T, int n,
+                                    int D, int accumulate, hipStream_t s);  // partial: B*T*D floats of scratch
 hipError_t mdt_launch_multi_adamw(const mdt_opt_tensor* tab, const int2* blocks, int n_blocks, float lr, float beta1,
                                   float beta2, float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s);
 hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks, int n_blocks, float a, float b,

@@ -354,13 +354,15 @@ static mdt_ln_train_args rln(const float* x, const float* w, const float* b, flo
     return a;
 }
 
+static const int LN_CHUNKS = 8;  // row chunks per sample of the LayerNorm backward over the media tokens
+
 static void carve_rscratch(mdt_resampler* r, Bump& b, int64_t rows, int64_t B) {
     const int D = r->D, I = r->inner, Q = r->Q;
     const int64_t lr = B * Q;
     r->g_dx = b.take(lr * D); r->g_dxf = b.take(rows * D); r->g_nm = b.take(rows * D); r->g_dnm = b.take(rows * D);
     r->g_dkv = b.take((rows + lr) * 2 * I); r->g_dkvm = b.take(rows * 2 * I); r->g_dkvl = b.take(lr * 2 * I);
     r->g_dq = b.take(lr * I); r->g_datt = b.take(lr * I); r->g_dlat = b.take(lr * D); r->g_ff = b.take(lr * r->ff);
-    r->g_td = b.take(lr * D); r->g_pw = b.take(B * D); r->g_pb = b.take(B * D);
+    r->g_td = b.take(lr * D); r->g_pw = b.take(B * LN_CHUNKS * D); r->g_pb = b.take(B * LN_CHUNKS * D);
     const int64_t mp = (std::min<int64_t>(std::max(rows, lr), 32768) + 15) & ~(int64_t)15;
     r->g_lin = b.take((size_t)(std::max(2 * I, r->ff) + std::max(std::max(D, I), r->ff)) * mp +
                       (size_t)std::max(2 * I, r->ff) * (mp / 32 + 2));
@@ -487,8 +489,9 @@ static mdt_status r_ln_bwd(mdt_resampler* r, float* grads, const float* x, const
     memset(&a, 0, sizeof a);
     a.x = x; a.stats = stats; a.w = w; a.b = b; a.shift_off = a.scale_off = -1; a.dh = dh; a.ld_dh = r->D; a.dx = dx;
     a.accumulate = acc; a.pw = r->g_pw; a.pb = r->g_pb; a.B = (int)B; a.rows_per_sample = rps; a.D = r->D;
+    a.row_chunks = std::max(1, std::min(LN_CHUNKS, rps / 32));  // the ~400 media rows of a sample: 8 workgroups
     LAUNCH(mdt_launch_ln_bwd(a, s));
-    LAUNCH(mdt_launch_colsum2(r->g_pw, r->g_pb, r->D, (int)B, r->D, grads + r->grad_off[rslot_of(r, w)],
+    LAUNCH(mdt_launch_colsum2(r->g_pw, r->g_pb, r->D, (int)B * a.row_chunks, r->D, grads + r->grad_off[rslot_of(r, w)],
                               grads + r->grad_off[rslot_of(r, b)], 1, s));
     return MDT_OK;
 }
@@ -532,8 +535,8 @@ extern "C" mdt_status mdt_resampler_backward(mdt_resampler* r, int32_t tape, con
     }
     // latents were repeated over the batch; the time embedding was added (masked) to every token of its frame
     LAUNCH(mdt_launch_colsum(r->g_dx, (int64_t)Q * D, (int)B, Q * D, grads + r->grad_off[rslot_of(r, r->latents)], 1, s));
-    LAUNCH(mdt_launch_time_emb_grad(r->g_dxf, t.has_mask ? t.mask : nullptr, grads + r->grad_off[rslot_of(r, r->tpe)], B, t.T,
-                                    t.n, D, 1, s));
+    LAUNCH(mdt_launch_time_emb_grad(r->g_dxf, t.has_mask ? t.mask : nullptr, grads + r->grad_off[rslot_of(r, r->tpe)],
+                                    r->g_dnm /* free by now: B*T*D <= rows*D floats */, B, t.T, t.n, D, 1, s));
     if (d_x_f) HIP_TRY(hipMemcpyAsync(d_x_f, r->g_dxf, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     return MDT_OK;
 }

@@ -128,10 +128,14 @@ hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s) {
 //   dx  (+)= rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
 //   per sample:  d_shift = sum_rows dh ;  d_scale = sum_rows dh * n ;  pw = sum_rows dn * xhat ;  pb = sum_rows dn
 // pw / pb are per-sample partials of the weight / bias gradient (summed over samples by k_colsum afterwards).
+// Samples with many rows (the Perceiver's ~400 media tokens) are cut into gridDim.y row chunks, each with its own
+// partial row (pw / pb hold B * gridDim.y rows then); modulation gradients need the whole sample in one workgroup.
 __global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
     extern __shared__ float red[];  // [4 waves][4 kinds][D]
     const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int D = a.D, rps = a.rows_per_sample;
+    const int per = (rps + gridDim.y - 1) / gridDim.y, r_lo = blockIdx.y * per, r_hi = min(rps, r_lo + per);
+    const int prow = b * gridDim.y + blockIdx.y;  // row of the pw / pb partials
     const float* mr = a.mod ? a.mod + (int64_t)b * a.mod_stride : nullptr;
     float wgt[LN_MAXC], bia[LN_MAXC], sc[LN_MAXC];
     float a_sh[LN_MAXC], a_sc[LN_MAXC], a_w[LN_MAXC], a_b[LN_MAXC];
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
         sc[i] = c < D ? (mr ? mr[a.scale_off + c] : 1.f) : 0.f;
         a_sh[i] = a_sc[i] = a_w[i] = a_b[i] = 0.f;
     }
-    for (int r = wv; r < rps; r += 4) {
+    for (int r = r_lo + wv; r < r_hi; r += 4) {
         const int64_t row = (int64_t)b * rps + r;
         const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
         float xh[LN_MAXC], dxh[LN_MAXC];
@@ -195,14 +199,16 @@ __global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
             if (a.shift_off >= 0) a.d_mod[(int64_t)b * a.d_mod_stride + a.shift_off + c] = t[0];
             if (a.scale_off >= 0) a.d_mod[(int64_t)b * a.d_mod_stride + a.scale_off + c] = t[1];
         }
-        a.pw[(int64_t)b * D + c] = t[2];
-        if (a.pb) a.pb[(int64_t)b * D + c] = t[3];
+        a.pw[(int64_t)prow * D + c] = t[2];
+        if (a.pb) a.pb[(int64_t)prow * D + c] = t[3];
     }
 }
 
 hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s) {
     if (a.D > 64 * LN_MAXC || a.D < 1 || a.rows_per_sample < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_ln_bwd, dim3(a.B), dim3(256), (size_t)16 * a.D * sizeof(float), s, a);
+    const int chunks = a.row_chunks > 1 ? a.row_chunks : 1;
+    if (chunks > 1 && (a.d_mod || chunks > a.rows_per_sample)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ln_bwd, dim3(a.B, chunks), dim3(256), (size_t)16 * a.D * sizeof(float), s, a);
     return hipGetLastError();
 }
 
@@ -728,24 +734,30 @@ hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const floa
     }
 }
 
-// time_pos_emb gradient: out[t][d] = sum_{b, n} mask[b][t] * dxf[b][t][n][d]      (grid: T x D/256, loop b, n)
-__global__ void k_time_emb_grad(const float* __restrict__ dxf, const uint8_t* __restrict__ mask, float* __restrict__ out,
-                                int64_t B, int T, int n, int D, int accumulate) {
-    const int t = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= D) return;
+// time_pos_emb gradient: out[t][d] = sum_{b, n} mask[b][t] * dxf[b][t][n][d], in two deterministic stages:
+//   partial[b*T + t][d] = mask * sum_n dxf[b][t][n][d]   (one workgroup per frame and 64 columns, 4 row groups)
+//   out[t][d] (+)= sum_b partial[b*T + t][d]              (k_colsum over the B rows of frame t, stride T*D)
+__global__ __launch_bounds__(256) void k_frame_sums(const float* __restrict__ dxf, const uint8_t* __restrict__ mask,
+                                                    float* __restrict__ partial, int n, int D) {
+    __shared__ float part[4][64];
+    const int64_t frame = blockIdx.y;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    for (int64_t b = 0; b < B; ++b) {
-        if (mask && !mask[b * T + t]) continue;
-        const float* base = dxf + ((b * T + t) * (int64_t)n) * D + d;
-        for (int i = 0; i < n; ++i) acc += base[(int64_t)i * D];
+    if (c < D && (!mask || mask[frame])) {
+        const float* base = dxf + frame * (int64_t)n * D + c;
+        for (int i = rg; i < n; i += 4) acc += base[(int64_t)i * D];
     }
-    float* p = out + (int64_t)t * D + d;
-    *p = accumulate ? *p + acc : acc;
+    part[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < D) partial[frame * D + c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
-hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, int64_t B, int T, int n, int D,
-                                    int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(k_time_emb_grad, dim3((D + 255) / 256, T), dim3(256), 0, s, dxf, mask, out, B, T, n, D, accumulate);
-    return hipGetLastError();
+hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, float* partial, int64_t B, int T, int n,
+                                    int D, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_frame_sums, dim3((D + 63) / 64, (unsigned)(B * T)), dim3(256), 0, s, dxf, mask, partial, n, D);
+    hipError_t e = hipGetLastError();
+    for (int t = 0; t < T && e == hipSuccess; ++t)
+        e = mdt_launch_colsum(partial + (int64_t)t * D, (int64_t)T * D, (int)B, D, out + (int64_t)t * D, accumulate, s);
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -75,3 +75,30 @@ def step_hip():
 te, th = timed(step_eager, 10), timed(step_hip, 20)
 print(f"training B={B}: torch eager {te * 1e3:8.2f} ms/step ({B / te:8.0f} samples/s)   HIP {th * 1e3:7.2f} ms/step "
       f"({B / th:8.0f} samples/s)   x{te / th:.1f}")
+
+# ---- Perceiver resampler, forward + backward at the training batch
+from mdt_policy_amd.models.networks.transformers.perceiver_resampler import PerceiverResampler
+from oracle import perceiver_oracle as PO
+
+res = PerceiverResampler(dim=384, depth=6, dim_head=64, heads=8, num_latents=3, num_time_embeds=1).to(dev)
+Pp = {k: v.detach().clone().requires_grad_() for k, v in res.state_dict().items()}
+xm = torch.randn(128, 1, 392, 384, device=dev)
+cot = torch.randn(128, 3, 384, device=dev)
+
+
+def perc_eager():
+    for v in Pp.values():
+        v.grad = None
+    (PO.perceiver_resampler(Pp, xm, 8) * cot).sum().backward()
+
+
+def perc_hip():
+    res.zero_grad(set_to_none=True)
+    (res(xm) * cot).sum().backward()
+
+
+te, th = timed(perc_eager, 5), timed(perc_hip, 5)
+print(f"perceiver fwd+bwd B=128: torch eager {te * 1e3:8.2f} ms   HIP {th * 1e3:7.2f} ms   x{te / th:.1f}")
+with torch.no_grad():
+    te, th = timed(lambda: PO.perceiver_resampler(Pp, xm, 8), 5), timed(lambda: res(xm), 10)
+print(f"perceiver fwd     B=128: torch eager {te * 1e3:8.2f} ms   HIP {th * 1e3:7.2f} ms   x{te / th:.1f}")
