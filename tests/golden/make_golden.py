@@ -254,6 +254,33 @@ def g11():
         save(f"g11_grads_{name}.npz", meta, loss=np.array(loss.item(), np.float32), **arrays)
 
 
+def g13():
+    """Dropout statistics of the REFERENCE in train() mode (attn 0.3 / resid 0.1 / mlp 0.05): the random streams of
+    two implementations cannot coincide, their distributions must.  400 seeded forward passes of GCDenoiser.loss on
+    fixed weights / inputs: mean and std of the loss, mean and variance (over seeds) of the model output."""
+    cfg, arch, B, n = configs.mdtv_tiny(), "mdtv", 6, 400
+    model = build_reference(cfg, arch, seed=131, profile="rich").train()
+    inp = synthetic.sampler_inputs(B, cfg, 132, arch)
+    li = synthetic.loss_inputs(B, cfg, 133)
+    state = make_state(inp, arch, "lang")
+    args = (torch.from_numpy(li["actions"]), torch.from_numpy(inp["goal"]), torch.from_numpy(li["noise_train"]),
+            torch.from_numpy(li["sigma"]))
+    losses, outs = [], []
+    with torch.no_grad():
+        for i in range(n):
+            torch.manual_seed(1000 + i)
+            loss, mo = model.loss(state, *args)
+            losses.append(loss.item()); outs.append(mo)
+        model.eval()
+        loss_eval, mo_eval = model.loss(state, *args)
+    outs = torch.stack(outs).double()
+    meta = dict(config="mdtv_tiny", arch=arch, B=B, n=n, modality="lang", weight_seed=131, profile="rich", input_seed=132,
+                loss_seed=133, loss_mean=float(np.mean(losses)), loss_std=float(np.std(losses, ddof=1)),
+                loss_eval=float(loss_eval), out_var_mean=float(outs.var(0, unbiased=True).mean()),
+                out_abs_dev_from_eval=float((outs.mean(0) - mo_eval.double()).abs().mean()))
+    save("g13_dropout_stats.npz", meta, out_mean=outs.mean(0).float().numpy(), out_var=outs.var(0, unbiased=True).float().numpy())
+
+
 def g5():
     from mdt.models.edm_diffusion import gc_sampling as gs
 
@@ -440,7 +467,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "manifest"]
     for w in which:
         print(w)
         globals()[w]()

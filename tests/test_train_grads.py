@@ -285,3 +285,54 @@ def test_hip_gradients_under_distributed_data_parallel():
     assert set(full) == set(got[0])
     for k, ref in full.items():
         assert_close(got[0][k], ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-7, what=k)
+
+
+def _dropout_stats(overrides):
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx = load_fixture("g13_dropout_stats.npz")
+    cfg = dict(cfg_of(meta), **overrides)
+    state, goal, _ = inputs_of(meta)
+    li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(meta["B"], cfg, meta["loss_seed"]).items()}
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().train()
+    gstate = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    n = meta["n"]
+    losses, outs = [], []
+    for i in range(n):
+        torch.manual_seed(5000 + i)
+        loss, mo = model.loss(gstate, li["actions"], goal.cuda(), li["noise_train"], li["sigma"])
+        losses.append(loss.item()); outs.append(mo.detach())
+        del loss
+    outs = torch.stack(outs).double().cpu()
+    return meta, fx, n, float(np.mean(losses)), float(np.std(losses, ddof=1)), outs.mean(0).numpy(), outs.var(0, unbiased=True).numpy()
+
+
+def _check_dropout_stats(meta, fx, n, lm, ls, mean, var):
+    se = (meta["loss_std"] ** 2 / n + ls ** 2 / n) ** 0.5
+    assert abs(lm - meta["loss_mean"]) <= 4 * se, (lm, meta["loss_mean"], se)
+    assert 0.8 <= ls / meta["loss_std"] <= 1.25, (ls, meta["loss_std"])
+    assert abs(float(var.mean()) / meta["out_var_mean"] - 1) < 0.1, (float(var.mean()), meta["out_var_mean"])
+    # element-wise: means within 5 standard errors (+ a small floor), variances within what the chi-square allows
+    se_el = np.sqrt((fx["out_var"] + var) / n)
+    assert np.all(np.abs(mean - fx["out_mean"]) <= 5 * se_el + 1e-3)
+    ratio = (var + 1e-6) / (fx["out_var"] + 1e-6)
+    assert np.all((ratio > 0.6) & (ratio < 1.6)), (ratio.min(), ratio.max())
+
+
+@pytest.mark.gpu
+def test_hip_dropout_statistics_match_the_reference():
+    """The dropout streams of two implementations cannot coincide, their distributions must: 400 seeded train-mode
+    forward passes on fixed weights and inputs against the same statistics of the REFERENCE (g13): mean / spread of the
+    loss, and mean / variance over seeds of the model output."""
+    meta, fx, n, lm, ls, mean, var = _dropout_stats({})
+    _check_dropout_stats(meta, fx, n, lm, ls, mean, var)
+    assert abs(lm - meta["loss_eval"]) > 2 * (meta["loss_std"] ** 2 / n + ls ** 2 / n) ** 0.5   # not the eval-mode loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overrides", [dict(attn_pdrop=0.0), dict(resid_pdrop=0.0), dict(mlp_pdrop=0.3)])
+def test_hip_dropout_statistics_detect_a_wrong_site(overrides):
+    """Negative control: the same check rejects a model whose dropout differs at one site."""
+    with pytest.raises(AssertionError):
+        _check_dropout_stats(*_dropout_stats(overrides))
