@@ -58,6 +58,11 @@ typedef struct {
     int32_t gate_off;      /* offset of the gate vector inside the mod row, or -1                     */
     int32_t gin, gout, goff;   /* output row = (m / gin) * gout + m % gin + goff  (1,1,0 = identity)  */
     const float *rowvec;   /* NULL or (N) vector added to every row after bias (positional embedding) */
+    /* batched launch: `batch` independent products in one launch, member z reading A + z*bs_a, Wp + z*bs_w and
+     * writing out + z*bs_out (floats); 0 or 1 = a single product.  Used for the split-K partial products of the
+     * training path's weight gradients.                                                              */
+    int32_t batch;
+    int64_t bs_a, bs_w, bs_out;
 } mdt_gemm_args;
 
 mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);

@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
         ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("mod", C.c_void_p), ("mod_stride", C.c_int64),
         ("shift_off", C.c_int32), ("scale_off", C.c_int32), ("rows_per_sample", C.c_int32), ("act", C.c_int32),
         ("residual", C.c_int32), ("gate_off", C.c_int32), ("gin", C.c_int32), ("gout", C.c_int32),
-        ("goff", C.c_int32), ("rowvec", C.c_void_p)]
+        ("goff", C.c_int32), ("rowvec", C.c_void_p), ("batch", C.c_int32), ("bs_a", C.c_int64), ("bs_w", C.c_int64),
+        ("bs_out", C.c_int64)]
 
 
 class AttnArgs(C.Structure):
@@ -182,6 +183,7 @@ SYMBOLS = [
     ("mdt_op_merge_bwd", _I32, [C.POINTER(MergeArgs), _VP]),
     ("mdt_op_colsum", _I32, [_VP, _I64, _I64, _I64, _VP, _I32, _VP]),
     ("mdt_op_linear_bwd", _I32, [C.POINTER(LinearBwdArgs), _VP]),
+    ("mdt_op_linear_bwd_scratch", _I64, [_I64, _I64, _I64]),
     ("mdt_op_multi_adamw", _I32, [C.POINTER(OptTensor), _I32, _F, _F, _F, _F, _F, _I64, _VP]),
     ("mdt_op_multi_ema", _I32, [C.POINTER(OptTensor), _I32, _F, _VP]),
     # include/mdt_resampler.h

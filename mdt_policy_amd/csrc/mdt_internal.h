@@ -92,9 +92,11 @@ hipError_t mdt_launch_attention_long(const float* q, int64_t ldq, const float* k
 bool mdt_attention_long_supported(int hd, int Tq, int Tk);
 // ---- training-path kernels (mdt_train_kernels.hip) ----
 hipError_t mdt_launch_pack_weight_t(const float* src, int rows, int cols, int64_t ld, float* packed, int k_off, int K16,
-                                    hipStream_t s);
+                                    hipStream_t s, int slice_len = 0);
 hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, float* part,
-                                   hipStream_t s);
+                                   hipStream_t s, int slice_len = 0);
+// floats of scratch mdt_linear_bwd needs for an (M, N, K) layer
+int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K);
 hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
                               int accumulate, hipStream_t s);
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);

@@ -275,6 +275,9 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     constexpr int R = NTW == 1 ? 6 : (NTW == 2 ? 4 : 3);
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.z) {  // batched launch (split-K partial products): every operand advances by its batch stride
+        a.A += (int64_t)blockIdx.z * a.bs_a; a.Wp += (int64_t)blockIdx.z * a.bs_w; a.out += (int64_t)blockIdx.z * a.bs_out;
+    }
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int by = logical / grid_n, bx = logical - by * grid_n;
     const int m0 = by * MT;
@@ -409,6 +412,9 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave >= NWAVES;
+    if (blockIdx.z) {  // batched launch (split-K partial products): every operand advances by its batch stride
+        a.A += (int64_t)blockIdx.z * a.bs_a; a.Wp += (int64_t)blockIdx.z * a.bs_w; a.out += (int64_t)blockIdx.z * a.bs_out;
+    }
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int by = logical / grid_n, bx = logical - by * grid_n;
     const int m0 = by * MT;
@@ -561,8 +567,8 @@ static hipError_t launch_gemm_r(const mdt_gemm_args& a, int kchunk, hipStream_t 
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_gemm<MTILES, NTW, NWAVES, PRO, RES>), dim3(gn * gm), dim3(64 * NWAVES), lds, s, a, kchunk, gn,
-                       g_zeros);
+    hipLaunchKernelGGL((k_gemm<MTILES, NTW, NWAVES, PRO, RES>), dim3(gn * gm, 1, a.batch > 1 ? a.batch : 1), dim3(64 * NWAVES),
+                       lds, s, a, kchunk, gn, g_zeros);
     return hipGetLastError();
 }
 
@@ -578,8 +584,8 @@ static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStre
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_gemm_pipe<MTILES, NTW, NWAVES, LW, RES>), dim3(gn * gm), dim3(64 * (NWAVES + LW)), lds, s, a,
-                       kchunk, gn, g_zeros);
+    hipLaunchKernelGGL((k_gemm_pipe<MTILES, NTW, NWAVES, LW, RES>), dim3(gn * gm, 1, a.batch > 1 ? a.batch : 1),
+                       dim3(64 * (NWAVES + LW)), lds, s, a, kchunk, gn, g_zeros);
     return hipGetLastError();
 }
 
@@ -605,6 +611,9 @@ __global__ __launch_bounds__(512) void k_gemm_smallm(mdt_gemm_args a, const floa
     __shared__ __attribute__((aligned(16))) float red[8][64][4];
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.z) {
+        a.A += (int64_t)blockIdx.z * a.bs_a; a.Wp += (int64_t)blockIdx.z * a.bs_w; a.out += (int64_t)blockIdx.z * a.bs_out;
+    }
     const int n_tile = blockIdx.x, m0 = blockIdx.y * 16;
     const int K16 = a.K >> 4;
     if (a.ln) {  // row statistics: 32 threads per row, whole row in registers (K <= 512)
@@ -725,7 +734,7 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         if (f) g_mdt_mid_max = atoi(f);
     }
     if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512)) {
-        hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4), dim3(512), 0, s, a, g_zeros);
+        hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4, a.batch > 1 ? a.batch : 1), dim3(512), 0, s, a, g_zeros);
         return hipGetLastError();
     }
     // Geometry selection (rows are in tiles of 32).  The decoder at B = 256 has 80 row tiles for 256 CUs:
@@ -733,27 +742,29 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     //   mid   (8 waves, 32 x 128)           : N  < 1024 -> 240 workgroups for N = 384
     //   small (4 waves, 32 x 64)            : few row tiles (small batches): more, smaller workgroups
     const int gm = (a.M + 31) / 32;
-    // widest geometry that still yields >= 200 workgroups (~1 per CU), preferring one whose column tile divides N;
-    // otherwise the one with the most workgroups
+    // Pick the geometry with the best (wave fill) x (tile efficiency): workgroups run in waves of ~256 (one per CU), so
+    // a count just above a multiple of 256 wastes most of its last wave (M = 10240, N = 384 on 32x384 tiles: 320
+    // workgroups = 1.25 waves); wide tiles amortise the per-workgroup prologue / epilogue better than narrow ones.
     const int tile_n[5] = {0, 64, 128, 384, 512};
-    int geo = 1, best = -1;
+    const float eff[5] = {0.f, 0.85f, 0.92f, 1.0f, 1.0f};
+    int geo = 1;
+    float best = -1.f;
     for (int g = 4; g >= 1; --g) {
-        const int cnt = gm * ((a.N + tile_n[g] - 1) / tile_n[g]);
-        if (cnt >= 200) {
-            int score = 4 * g + (a.N % tile_n[g] == 0 ? 100 : 0);
-            if (score > best) { best = score; geo = g; }
-        }
-    }
-    if (best < 0) {
-        int most = -1;
-        for (int g = 1; g <= 4; ++g) {
-            const int cnt = gm * ((a.N + tile_n[g] - 1) / tile_n[g]);
-            if (cnt > most) { most = cnt; geo = g; }
-        }
+        const int cols = (a.N + tile_n[g] - 1) / tile_n[g];
+        const int cnt = gm * cols;
+        const float fill = (float)cnt / (float)(((cnt + 255) / 256) * 256);
+        const float used = (float)a.N / (float)(cols * tile_n[g]);   // columns of the last tile that are real work
+        const float score = fill * eff[g] * used;
+        if (score > best) { best = score; geo = g; }
     }
     // mid-size row counts (batches of ~20..140 chunks, and the training path's 384..1536-row dW products): half-height
     // tiles double the workgroup count; measured 4-17 % faster per sampler call up to M ~ 1400, slower beyond 2000
     if (a.M <= g_mdt_mid_max) geo = 6;
+    if (a.batch > 1) {  // split-K partial products (deep reductions): geometry chosen for those, env override for A/B runs
+        static int bgeo = -1;
+        if (bgeo < 0) { const char* e = getenv("MDT_HIP_BATCH_GEO"); bgeo = e ? atoi(e) : 5; }
+        geo = bgeo;
+    }
     if (g_mdt_gemm_force) geo = g_mdt_gemm_force;
     switch (geo) {
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);

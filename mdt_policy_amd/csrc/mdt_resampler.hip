@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "mdt_internal.h"
@@ -363,9 +364,11 @@ static void carve_rscratch(mdt_resampler* r, Bump& b, int64_t rows, int64_t B) {
     r->g_dkv = b.take((rows + lr) * 2 * I); r->g_dkvm = b.take(rows * 2 * I); r->g_dkvl = b.take(lr * 2 * I);
     r->g_dq = b.take(lr * I); r->g_datt = b.take(lr * I); r->g_dlat = b.take(lr * D); r->g_ff = b.take(lr * r->ff);
     r->g_td = b.take(lr * D); r->g_pw = b.take(B * LN_CHUNKS * D); r->g_pb = b.take(B * LN_CHUNKS * D);
-    const int64_t mp = (std::min<int64_t>(std::max(rows, lr), 32768) + 15) & ~(int64_t)15;
-    r->g_lin = b.take((size_t)(std::max(2 * I, r->ff) + std::max(std::max(D, I), r->ff)) * mp +
-                      (size_t)std::max(2 * I, r->ff) * (mp / 32 + 2));
+    int64_t need = mdt_linear_bwd_scratch(rows, 2 * I, D);
+    for (auto nk : {std::pair<int, int>(2 * I, D), std::pair<int, int>(I, D), std::pair<int, int>(D, I), std::pair<int, int>(r->ff, D),
+                    std::pair<int, int>(D, r->ff)})
+        need = std::max(need, mdt_linear_bwd_scratch(lr, nk.first, nk.second));
+    r->g_lin = b.take(need);
 }
 
 static mdt_status rscratch(mdt_resampler* r, int64_t rows, int64_t B) {

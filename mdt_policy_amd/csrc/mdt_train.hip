@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "mdt_model_types.h"
@@ -217,20 +218,24 @@ extern "C" mdt_status mdt_tape_release(mdt_model* m, mdt_tape_id id) {
 
 static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int64_t B) {
     const int D = m->D;
-    const int64_t Me = B * m->Te, Ma = B * m->Ta, Mx = std::max(Me, Ma), Mp = (Mx + 15) & ~(int64_t)15;
-    const int64_t Bp = (B + 15) & ~(int64_t)15;
+    const int64_t Me = B * m->Te, Ma = B * m->Ta, Mx = std::max(Me, Ma);
     ts->dx = b.take(Ma * D); ts->dxe = b.take(Me * D);
     ts->t_d = b.take(Mx * D); ts->t_d2 = b.take(Mx * D); ts->t_3d = b.take(Mx * 3 * D); ts->t_4d = b.take(Mx * 4 * D);
     ts->d_mod = b.take(B * m->Ld * 6 * D); ts->d_kvx = b.take(Me * m->Ld * 2 * D);
     ts->pw = b.take(B * D); ts->pb = b.take(B * D);
     ts->narrow = b.take((size_t)NARROW_SLICES * 16 * D);
-    // Linear backward scratch: (N + K) * Mp for the widest layers on Mx rows, and for the per-sample layers on B rows
-    const int64_t widest = std::max<int64_t>((int64_t)5 * D * Mp,
-                                             std::max<int64_t>(((int64_t)m->Ld * 6 * D + D) * Bp,
-                                                               std::max<int64_t>(((int64_t)m->Ld * 2 * D + D) * ((Me + 15) & ~15),
-                                                                                 (int64_t)(2 * D + std::max(m->G, m->O) + D) * Mp)));
-    // (N + K) * Mp of every Linear: MLP 5D (Mp rows); qkv 4D; adaLN stack (Ld*6D + D) on B rows; K|V stack on Me rows
-    ts->lin_scratch = b.take(widest + (int64_t)std::max(m->Ld * 6 * D, 4 * D) * (Mp / 32 + 2));  // + bias partials
+    // Linear backward scratch: the largest need over every (rows, N, K) this model's backward runs
+    int64_t need = 0;
+    for (int64_t rows : {Ma, Me}) {
+        for (auto nk : {std::pair<int, int>(4 * D, D), std::pair<int, int>(D, 4 * D), std::pair<int, int>(3 * D, D),
+                        std::pair<int, int>(D, D), std::pair<int, int>(m->Ld * 2 * D, D)})
+            need = std::max(need, mdt_linear_bwd_scratch(rows, nk.first, nk.second));
+    }
+    for (auto nk : {std::pair<int, int>(m->Ld * 6 * D, D), std::pair<int, int>(D, 2 * D), std::pair<int, int>(2 * D, D),
+                    std::pair<int, int>(2 * D, m->G), std::pair<int, int>(D, m->G), std::pair<int, int>(D, m->O)})
+        need = std::max(need, mdt_linear_bwd_scratch(B, nk.first, nk.second));
+    need = std::max(need, mdt_linear_bwd_scratch(B * m->n_tok, D, m->O));
+    ts->lin_scratch = b.take(need);
     ts->dF = b.take(Ma * m->A);
     ts->small = b.take(std::max<int64_t>(B * 2 * D, Mx * (int64_t)std::max(m->O, m->G)));
 }

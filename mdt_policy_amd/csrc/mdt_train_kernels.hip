@@ -19,30 +19,41 @@
 //   * weights:      W (N, K) part at row offset n_off -> image of W^T (N' = K, K' = N_total), k_off = n_off
 //   * activations:  X (M, K)                           -> image of X^T (N' = K, K' = M padded to 16)
 // ------------------------------------------------------------------------------------------------
+// slice_len > 0: the rows are cut into slices of slice_len (a multiple of 16); slice s becomes its own packed image
+// (N' = cols, K' = slice_len) at packed + s * cols * slice_len (the per-slice operands of a split-K product).
 __global__ void k_pack_weight_t(const float* __restrict__ src, int rows, int cols, int64_t lds_, float* __restrict__ packed,
-                                int k_off, int K16) {
+                                int k_off, int K16, int slice_len) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)rows * cols) return;
     const int r = (int)(idx / cols), c = (int)(idx % cols);
-    const int n = c, k = k_off + r;
+    int k = k_off + r;
+    int64_t base = 0;
+    if (slice_len > 0) {
+        const int sl = k / slice_len;
+        k -= sl * slice_len;
+        base = (int64_t)sl * cols * slice_len;
+    }
+    const int n = c;
     const int nt = n >> 4, ni = n & 15, kc = k >> 4, h = (k & 15) >> 2, j = k & 3;
-    packed[(((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4 + j] = src[(int64_t)r * lds_ + c];
+    packed[base + (((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4 + j] = src[(int64_t)r * lds_ + c];
 }
 
 hipError_t mdt_launch_pack_weight_t(const float* src, int rows, int cols, int64_t ld, float* packed, int k_off, int K16,
-                                    hipStream_t s) {
+                                    hipStream_t s, int slice_len) {
     const int64_t n = (int64_t)rows * cols;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_pack_weight_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, ld, packed,
-                       k_off, K16);
+                       k_off, K16, slice_len);
     return hipGetLastError();
 }
 
 // dst (C, ldd) = src (R, C; lds)^T, through a 32x33 LDS tile so both sides are coalesced.  Optionally also emits
 // per-row-block column sums  part[blockIdx.y][c] = sum of the block's 32 rows of column c  (the bias gradient is
 // then a column sum over R/32 partial rows instead of R rows).
+// slice_len > 0 (a multiple of 32): the R rows are cut into slices; slice s lands as its own (C, slice_len) matrix at
+// dst + s * C * slice_len (ldd is ignored then).
 __global__ __launch_bounds__(256) void k_transpose_ld(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
-                                                      int64_t ldd, int R, int Cc, float* __restrict__ part) {
+                                                      int64_t ldd, int R, int Cc, float* __restrict__ part, int slice_len) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -55,7 +66,14 @@ __global__ __launch_bounds__(256) void k_transpose_ld(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < Cc && r < R) dst[(int64_t)c * ldd + r] = tile[tx][ty + 8 * i];
+        if (c < Cc && r < R) {
+            if (slice_len > 0) {
+                const int sl = r / slice_len;
+                dst[((int64_t)sl * Cc + c) * slice_len + (r - sl * slice_len)] = tile[tx][ty + 8 * i];
+            } else {
+                dst[(int64_t)c * ldd + r] = tile[tx][ty + 8 * i];
+            }
+        }
     }
     if (part && threadIdx.x < 32 && c0 + tx < Cc) {
         float acc = 0.f;
@@ -66,8 +84,9 @@ __global__ __launch_bounds__(256) void k_transpose_ld(const float* __restrict__ 
 }
 
 hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, int64_t ldd, int R, int Cc, float* part,
-                                   hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_ld, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, Cc, part);
+                                   hipStream_t s, int slice_len) {
+    hipLaunchKernelGGL(k_transpose_ld, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, Cc, part,
+                       slice_len);
     return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -16,6 +17,28 @@
 //              "weight" X^T packed as an (N' = K, K' = Mp) image: out'(N x K) = dY^T . (X^T)^T
 //   dX[m][k] = sum_n dY[m][n] W[n][k]  -> GEMM with row operand dY and the packed image of W^T (N' = K, K' = N)
 // Mp = M rounded up to 16; the pad columns / k-slices are zero, so they add nothing.
+// Split of the row reduction of dW = dY^T X into S parallel slices of L rows (multiples of 32), so that the product
+// fills the chip with WIDE tiles however small N x K is: slice s multiplies its own (N, L) piece of dY^T with its own
+// packed (K, L) piece of X^T in ONE batched launch (grid.z = S), and the S partial (N, K) products are summed in a
+// fixed order by a column sum -- deterministic, unlike atomics.  Only worth it for deep reductions.
+static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
+    const int64_t tiles = ((N + 31) / 32) * ((K + 127) / 128);   // 32 x 128 tiles of one product
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>((400 + tiles - 1) / tiles, M / 1024));  // slices >= 1024 deep
+    s = std::min<int64_t>(s, 32);
+    if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
+    int64_t l = ((M + s - 1) / s + 31) / 32 * 32;                // equal slices: at most 31 pad rows each
+    while (l > 16384) { ++s; l = ((M + s - 1) / s + 31) / 32 * 32; }  // keeps the GEMM's K' well inside its limit
+    *S = (int)((M + l - 1) / l);
+    *L = (int)l;
+}
+
+int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K) {
+    int S, L;
+    split_rows(M, N, K, &S, &L);
+    const int64_t Mp = (int64_t)S * L;
+    return (N + K) * Mp + (int64_t)S * N * K + N * (Mp / 32 + 2);
+}
+
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || a.K < 1 || (a.K % 16)) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: bad shape");
     // the bias gradient rides on the transpose the dW path needs anyway (per-32-row column partials)
@@ -23,30 +46,30 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
     if (a.dbias && !bias_from_partials) LAUNCH(mdt_launch_colsum(a.dY, a.ldy, a.M, a.N, a.dbias, a.accumulate_dw, s));
     if (a.dW) {
         if (a.N % 16) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: N must be a multiple of 16 for dW");
-        // the reduction runs over the rows; very tall inputs (Perceiver media tokens) go through in slices that
-        // keep the GEMM's K' within its limit, each accumulating into dW
-        const int SLICE = 32768;
-        for (int m0 = 0; m0 < a.M; m0 += SLICE) {
-            const int Ms = std::min(SLICE, a.M - m0);
-            const int Mp = (Ms + 15) & ~15;
-            float* dYt = a.scratch;                          // (N, Mp)
-            float* Xt = a.scratch + (size_t)a.N * Mp;        // packed (N' = K, K' = Mp)
-            // column partials live in the tail of the packed-X region's slack: (Mp/32 + 1) x N floats behind it
-            float* part = bias_from_partials ? Xt + (size_t)a.K * Mp : nullptr;
-            if (Mp != Ms) {
-                HIP_TRY(hipMemsetAsync(dYt, 0, (size_t)a.N * Mp * sizeof(float), s));
-                HIP_TRY(hipMemsetAsync(Xt, 0, (size_t)a.K * Mp * sizeof(float), s));
-            }
-            LAUNCH(mdt_launch_transpose_ld(a.dY + (int64_t)m0 * a.ldy, a.ldy, dYt, Mp, Ms, a.N, part, s));
-            if (part)
-                LAUNCH(mdt_launch_colsum(part, a.N, (Ms + 31) / 32, a.N, a.dbias, (a.accumulate_dw || m0 > 0) ? 1 : 0, s));
-            LAUNCH(mdt_launch_pack_weight_t(a.X + (int64_t)m0 * a.ldx, Ms, a.K, a.ldx, Xt, 0, Mp / 16, s));
-            Lin w;
-            w.wp = Xt; w.bias = nullptr; w.N = a.K; w.K = Mp;
-            mdt_gemm_args g = gemm_args(dYt, Mp, w, a.dW, a.K, a.N);
-            g.residual = (a.accumulate_dw || m0 > 0) ? 1 : 0;
-            LAUNCH(mdt_launch_gemm(g, s));
+        int S, L;
+        split_rows(a.M, a.N, a.K, &S, &L);
+        const int64_t Mp = (int64_t)S * L;
+        float* dYt = a.scratch;                                  // [S][N][L]
+        float* Xt = dYt + (int64_t)a.N * Mp;                     // [S] packed (N' = K, K' = L)
+        float* parts = Xt + (int64_t)a.K * Mp;                   // [S][N][K] partial products (S > 1)
+        float* bpart = parts + (int64_t)S * a.N * a.K;           // (ceil(M/32), N) column partials of dY
+        if (Mp != a.M) {  // zero pad rows of the last slice
+            HIP_TRY(hipMemsetAsync(dYt + (int64_t)(S - 1) * a.N * L, 0, (size_t)a.N * L * sizeof(float), s));
+            HIP_TRY(hipMemsetAsync(Xt + (int64_t)(S - 1) * a.K * L, 0, (size_t)a.K * L * sizeof(float), s));
         }
+        LAUNCH(mdt_launch_transpose_ld(a.dY, a.ldy, dYt, L, a.M, a.N, bias_from_partials ? bpart : nullptr, s, L));
+        if (bias_from_partials) LAUNCH(mdt_launch_colsum(bpart, a.N, (a.M + 31) / 32, a.N, a.dbias, a.accumulate_dw, s));
+        LAUNCH(mdt_launch_pack_weight_t(a.X, a.M, a.K, a.ldx, Xt, 0, L / 16, s, L));
+        Lin w;
+        w.wp = Xt; w.bias = nullptr; w.N = a.K; w.K = L;
+        mdt_gemm_args g = gemm_args(dYt, L, w, S > 1 ? parts : a.dW, a.K, a.N);
+        if (S > 1) {
+            g.batch = S; g.bs_a = (int64_t)a.N * L; g.bs_w = (int64_t)a.K * L; g.bs_out = (int64_t)a.N * a.K;
+        } else {
+            g.residual = a.accumulate_dw;
+        }
+        LAUNCH(mdt_launch_gemm(g, s));
+        if (S > 1) LAUNCH(mdt_launch_colsum(parts, (int64_t)a.N * a.K, S, a.N * a.K, a.dW, a.accumulate_dw, s));
     }
     if (a.dX) {
         if (!a.Wt || (a.N % 16)) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: dX needs the packed W^T and N % 16 == 0");
@@ -58,6 +81,8 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
     }
     return MDT_OK;
 }
+
+extern "C" int64_t mdt_op_linear_bwd_scratch(int64_t M, int64_t N, int64_t K) { return mdt_linear_bwd_scratch(M, N, K); }
 
 extern "C" mdt_status mdt_op_linear_bwd(const mdt_linear_bwd_args* a, void* stream) {
     if (!a || !a->X || !a->dY || !a->scratch) return fail(MDT_ERR_INVALID_ARG, "mdt_op_linear_bwd: null argument");

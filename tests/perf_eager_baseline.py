@@ -48,7 +48,8 @@ for B in (256, 1):
     print(f"sampling B={B:3d}: torch eager {t_eager * 1e3:8.2f} ms ({B / t_eager:9.0f} chunks/s)   "
           f"HIP {t_hip * 1e3:7.2f} ms ({B / t_hip:9.0f} chunks/s)   x{t_eager / t_hip:.1f}", flush=True)
 
-B = 128
+TRAIN_B = [int(v) for v in os.environ.get("MDT_EAGER_TRAIN_B", "128").split(",")]
+B = TRAIN_B[0]
 inp = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
 li = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
 st = {"state_images": inp["state_images"], "modality": "lang"}

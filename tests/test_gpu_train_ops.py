@@ -258,7 +258,7 @@ def test_linear_backward_through_the_forward_gemm(lib, M, N, K):
     Wt = torch.zeros(N * K, device="cuda")
     lib.check(L.mdt_op_pack_weight_t(dev(W).data_ptr(), N, K, K, Wt.data_ptr(), 0, N, stream()))
     Mp = (M + 15) // 16 * 16
-    scratch = torch.empty((N + K) * Mp + N * (Mp // 32 + 1), device="cuda")
+    scratch = torch.empty(L.mdt_op_linear_bwd_scratch(M, N, K), device="cuda")
     dW0, dX0 = rnd(N, K, seed=44), rnd(M, K, seed=45)
     dW, dX = dev(dW0).clone(), dev(dX0).clone()
     db = torch.zeros(N, device="cuda")
