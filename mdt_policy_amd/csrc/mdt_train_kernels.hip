@@ -292,13 +292,21 @@ hipError_t mdt_launch_merge_bwd(const mdt_merge_args& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 // column sums  out[n] (+)= sum_m X[m][n]   (bias gradients; reduction of per-sample partials)
-// grid.x = column groups of 64, 4 row groups per workgroup meet in LDS; deterministic.
+// grid.x = column groups of 64, 4 row groups per workgroup meet in LDS; deterministic.  Tall inputs with few columns
+// (the action head's (B*Ta, 7) gradient, LayerNorm partials of a large batch) would run on a handful of workgroups:
+// they go through gridDim.y row slices into a small scratch and a second pass over the slices.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t ldx, int M, int N,
                                                 float* __restrict__ out, int accumulate) {
     __shared__ float part[4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    if (gridDim.y > 1) {  // row slice blockIdx.y -> row blockIdx.y of the (gridDim.y, N) scratch `out`
+        const int per = (M + gridDim.y - 1) / gridDim.y, lo = blockIdx.y * per;
+        X += (int64_t)lo * ldx;
+        M = max(0, min(per, M - lo));
+        out += (int64_t)blockIdx.y * N;
+    }
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     if (c < N) {
         int m = rg;
@@ -341,7 +349,20 @@ hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int
     return hipGetLastError();
 }
 
+static float* g_colsum_scratch = nullptr;  // 64 row slices x 4096 columns (1 MiB), shared: stream-ordered use only
+static const int CS_SLICES = 64, CS_MAXN = 4096;
+
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
+    if (M >= 2048 && N <= CS_MAXN) {
+        if (!g_colsum_scratch) {
+            hipError_t e = hipMalloc((void**)&g_colsum_scratch, (size_t)CS_SLICES * CS_MAXN * sizeof(float));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, CS_SLICES), dim3(256), 0, s, X, ldx, M, N, g_colsum_scratch, 0);
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, s, g_colsum_scratch, (int64_t)N, CS_SLICES, N, out,
+                           accumulate);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, s, X, ldx, M, N, out, accumulate);
     return hipGetLastError();
 }

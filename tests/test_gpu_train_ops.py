@@ -159,7 +159,7 @@ def test_merge_gate_backward_and_colsum(lib):
     assert_close(dmod[:, 2 * D:3 * D].cpu(), (dx * a).view(B, rps, D).sum(1).double(), what="d_gate", **G_TOL)
     assert dmod[:, :2 * D].abs().max() == 0 and dmod[:, 3 * D:].abs().max() == 0
     L = lib.load()
-    for M, N in [(2560, 1536), (37, 7), (1, 100), (130, 64)]:
+    for M, N in [(2560, 1536), (37, 7), (1, 100), (130, 64), (10240, 7), (2048, 384), (5000, 4096), (2049, 4100)]:
         X = rnd(M, N + 3, seed=M)
         out0 = rnd(N, seed=N)
         o = dev(out0).clone()
