@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "mdt_internal.h"
 
 #include "mdt_device.h"
@@ -349,18 +352,28 @@ hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int
     return hipGetLastError();
 }
 
-static float* g_colsum_scratch = nullptr;  // 64 row slices x 4096 columns (1 MiB), shared: stream-ordered use only
+// 64 row slices x 4096 columns (1 MiB) of scratch PER STREAM: uses on one stream are ordered, two streams (two
+// handles training side by side) must not share it
 static const int CS_SLICES = 64, CS_MAXN = 4096;
+static std::mutex g_cs_mu;
+static std::unordered_map<hipStream_t, float*> g_cs_scratch;
+
+static float* colsum_scratch(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_cs_mu);
+    auto it = g_cs_scratch.find(s);
+    if (it != g_cs_scratch.end()) return it->second;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, (size_t)CS_SLICES * CS_MAXN * sizeof(float)) != hipSuccess) return nullptr;
+    g_cs_scratch[s] = p;
+    return p;
+}
 
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
     if (M >= 2048 && N <= CS_MAXN) {
-        if (!g_colsum_scratch) {
-            hipError_t e = hipMalloc((void**)&g_colsum_scratch, (size_t)CS_SLICES * CS_MAXN * sizeof(float));
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, CS_SLICES), dim3(256), 0, s, X, ldx, M, N, g_colsum_scratch, 0);
-        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, s, g_colsum_scratch, (int64_t)N, CS_SLICES, N, out,
-                           accumulate);
+        float* scratch = colsum_scratch(s);
+        if (!scratch) return hipErrorOutOfMemory;
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, CS_SLICES), dim3(256), 0, s, X, ldx, M, N, scratch, 0);
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, s, scratch, (int64_t)N, CS_SLICES, N, out, accumulate);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, s, X, ldx, M, N, out, accumulate);
