@@ -93,6 +93,57 @@ def time_dominant_kernel(device, M):
             "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
 
 
+def other_configs(device):
+    """Diagnostic numbers for BASELINE.json's other single-GPU configurations (not the metric): the MDT-V training step
+    at B = 1024 (configs[2]: diffusion loss forward + backward + AdamW, train() mode with the shipped dropout rates) and
+    the rollout batch B = 1 (10 DDIM steps)."""
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    from mdt_policy_amd.optim import FusedAdamW
+    out = {}
+    cfg = configs.mdtv_default()
+    torch.manual_seed(0)
+    model = GCDenoiser(cfg, 0.5).to(device)
+
+    def timed(fn, warm, n):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / n
+
+    B = 1024
+    inp = {k: torch.from_numpy(v).to(device) for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
+    li = {k: torch.from_numpy(v).to(device) for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
+    state = {"state_images": inp["state_images"], "modality": "lang"}
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+    model.train()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model.loss(state, li["actions"], inp["goal"], li["noise_train"], li["sigma"])
+        loss.backward()
+        opt.step()
+
+    dt = timed(step, 3, 10)
+    out["train_step_mdtv_B1024"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1),
+                                    "what": "GCDenoiser.loss forward + HIP backward + FusedAdamW, train() mode, dropout "
+                                            "0.3/0.1/0.05, fp32, synthetic CALVIN-shaped batch (no masked-token aux head)"}
+    del opt
+    model.eval()
+    one = {k: v[:1].contiguous() for k, v in inp.items()}
+    st1 = {"state_images": one["state_images"], "modality": "lang"}
+    sig = gs.get_sigmas_exponential(10, 0.001, 80.0)
+    with torch.no_grad():
+        dt = timed(lambda: gs.sample_ddim(model, st1, one["noise"] * 80.0, one["goal"], sig), 5, 50)
+    out["rollout_B1_10steps"] = {"ms_per_chunk": round(dt * 1e3, 3)}
+    return out
+
+
 def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -242,6 +293,11 @@ def main():
         except Exception as e:  # diagnostic leg only; never hides the main number
             res["roofline"]["dominant_kernel"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
+            try:  # diagnostic legs only; never hide the main number
+                res["other_configs"] = other_configs(device)
+                log("other configurations timed")
+            except Exception as e:
+                res["other_configs"] = {"error": str(e)}
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             res["cpu_baseline"] = cpu_baseline(cfg, P, B, args.denoise_steps, args.cpu_seconds, threads)
         print(json.dumps(res), flush=True)
