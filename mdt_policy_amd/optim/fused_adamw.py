@@ -60,5 +60,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 # the library wrote the parameters behind autograd's back: bump their version counters (no kernel) so
                 # that the HIP engines see the change and re-upload the weights before the next forward
                 ps = [p for p, _, _ in items]
-                torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
+                try:
+                    torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
+                except (AttributeError, TypeError):  # other torch builds: an in-place no-op bumps it the public way
+                    torch._foreach_add_(ps, 0.0)
         return loss
