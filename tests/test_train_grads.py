@@ -336,3 +336,34 @@ def test_hip_dropout_statistics_detect_a_wrong_site(overrides):
     """Negative control: the same check rejects a model whose dropout differs at one site."""
     with pytest.raises(AssertionError):
         _check_dropout_stats(*_dropout_stats(overrides))
+
+
+@pytest.mark.gpu
+def test_hip_training_under_lightning_style_amp():
+    """The reference trains with precision 16 (conf/config.yaml:46): autocast + GradScaler around the step.  The HIP
+    path stays fp32 inside; half-precision inputs are cast on the way in (differentiably) and the scaled loss
+    gradient flows through the backward, so the unscaled gradients equal the plain fp32 ones."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, state, goal, li = case("mdtv_tiny")
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    args = (li["actions"].cuda(), goal.cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
+    gstate = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    loss, _ = model.loss(gstate, *args)
+    loss.backward()
+    ref = {k: p.grad.clone() for k, p in model.inner_model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    tokens16 = gstate["state_images"].half().requires_grad_()           # e.g. an upstream module that ran in fp16
+    with torch.autocast("cuda", dtype=torch.float16):
+        l16, _ = model.loss(dict(gstate, state_images=tokens16), *args)
+    assert l16.dtype == torch.float32 and abs(l16.item() - loss.item()) <= 2e-3 * abs(loss.item())
+    scaler.scale(l16).backward()
+    assert tokens16.grad is not None and tokens16.grad.dtype == torch.float16
+    scaler.unscale_(opt)
+    for k, p in model.inner_model.named_parameters():
+        if k in ref:
+            assert_close(p.grad.cpu(), ref[k].cpu(), rtol=5e-3, atol=5e-3 * float(ref[k].abs().max()) + 1e-7, what=k)
+    scaler.step(opt); scaler.update()
