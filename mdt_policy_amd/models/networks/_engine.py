@@ -304,6 +304,11 @@ class HipScoreNetwork(nn.Module):
             self._engines = {key: eng}  # one live handle: a moved / re-scaled model drops the old arena
         return eng
 
+    def __getstate__(self):  # copy.deepcopy / pickle (EMA copies, checkpoints of whole modules): never the library handle
+        d = self.__dict__.copy()
+        d["_engines"] = {}
+        return d
+
     def _apply(self, fn, *a, **kw):  # .to()/.cuda()/.float(): parameters are re-created, drop stale handles
         out = super()._apply(fn, *a, **kw)
         self._engines = {}

@@ -120,6 +120,11 @@ class PerceiverResampler(nn.Module):
             param.requires_grad = trainable
 
     # -- library handle --------------------------------------------------------------------------
+    def __getstate__(self):  # copy.deepcopy / pickle: never the library handle
+        d = self.__dict__.copy()
+        d["_handle"], d["_handle_device"], d["_uploaded"], d["_grad_layout"] = None, None, {}, None
+        return d
+
     def _apply(self, fn, *a, **kw):  # .to()/.cuda(): parameters are re-created, drop the stale handle
         out = super()._apply(fn, *a, **kw)
         self._drop_handle()

@@ -198,6 +198,26 @@ def test_full_size_properties():
     assert torch.isfinite(a).all()
 
 
+def test_deepcopy_and_pickle_of_a_live_model():
+    """EMA helpers and checkpointing code deep-copy / pickle whole modules: a module with a live library handle must
+    copy as parameters only and build its own handle on first use."""
+    import copy
+    import pickle
+    meta, fx = load_fixture("g1_tiny_mdtv.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sig = sampling().get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    with torch.no_grad():
+        a = sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, sig)
+        twin = copy.deepcopy(model)
+        again = pickle.loads(pickle.dumps(model))
+        assert twin.inner_model._engines == {} and again.inner_model._engines == {}
+        b = sampling().sample_ddim(twin, state, noise * meta["sigma_max"], goal, sig)
+        c = sampling().sample_ddim(again, state, noise * meta["sigma_max"], goal, sig)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert twin.inner_model.hip_engine() is not model.inner_model.hip_engine()
+
+
 def test_parameter_updates_reach_the_kernels():
     meta, _ = load_fixture("g2_stages_mdtv.npz")
     from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
