@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "mdt_internal.h"
 
 #include "mdt_device.h"
@@ -545,14 +547,32 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
     }
 }
 
-static float* g_zeros = nullptr;  // 256 KiB of zeros: stands in for absent bias / rowvec / LayerNorm-bias vectors
+// 256 KiB of zeros per device: stands in for absent bias / rowvec / LayerNorm-bias vectors.  ensure_zeros() points
+// g_zeros at the CURRENT device's buffer (a process normally drives one GPU; a second one gets its own buffer).
 static const int ZEROS_FLOATS = 65536;
+static const int MAX_DEVICES = 32;
+static float* g_zeros_dev[MAX_DEVICES] = {nullptr};
+static thread_local float* g_zeros = nullptr;
 
 static hipError_t ensure_zeros() {
-    if (g_zeros != nullptr) return hipSuccess;
-    hipError_t e = hipMalloc((void**)&g_zeros, ZEROS_FLOATS * sizeof(float));
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    return hipMemset(g_zeros, 0, ZEROS_FLOATS * sizeof(float));
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (g_zeros_dev[dev] == nullptr) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (g_zeros_dev[dev] == nullptr) {
+            float* p = nullptr;
+            e = hipMalloc((void**)&p, ZEROS_FLOATS * sizeof(float));
+            if (e != hipSuccess) return e;
+            e = hipMemset(p, 0, ZEROS_FLOATS * sizeof(float));
+            if (e != hipSuccess) return e;
+            g_zeros_dev[dev] = p;
+        }
+    }
+    g_zeros = g_zeros_dev[dev];
+    return hipSuccess;
 }
 
 template <int MTILES, int NTW, int NWAVES, int PRO, bool RES>

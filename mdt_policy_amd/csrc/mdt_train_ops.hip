@@ -162,17 +162,17 @@ extern "C" mdt_status mdt_op_colsum(const float* X, int64_t ldx, int64_t M, int6
 // uploaded stream-ordered into a per-process device buffer
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct OptTable {
+struct OptTable {  // one per device: the table lives in that device's memory
     std::mutex mu;
     void* dev = nullptr;
     size_t cap = 0;
     std::vector<char> host;
 };
-OptTable g_opt;
+OptTable g_opt_dev[32];
 }  // namespace
 
-static mdt_status upload_opt_table(const mdt_opt_tensor* tensors, int n, const mdt_opt_tensor** d_tab, const int2** d_blocks,
-                                   int* n_blocks, hipStream_t s) {
+static mdt_status upload_opt_table(OptTable& g_opt, const mdt_opt_tensor* tensors, int n, const mdt_opt_tensor** d_tab,
+                                   const int2** d_blocks, int* n_blocks, hipStream_t s) {
     const int CH = 4096;  // OPT_CHUNK of the kernels
     std::vector<int2> blocks;
     for (int i = 0; i < n; ++i) {
@@ -205,10 +205,14 @@ extern "C" mdt_status mdt_op_multi_adamw(const mdt_opt_tensor* tensors, int32_t 
     for (int i = 0; i < n; ++i)
         if (!tensors[i].p || !tensors[i].g || !tensors[i].m || !tensors[i].v)
             return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_adamw: tensor %d lacks p / g / m / v", i);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32) return fail(MDT_ERR_INVALID_ARG, "device index %d out of range", dev);
+    OptTable& g_opt = g_opt_dev[dev];
     std::lock_guard<std::mutex> lock(g_opt.mu);
     hipStream_t s = (hipStream_t)stream;
     const mdt_opt_tensor* tab; const int2* blocks; int nb;
-    MDT_TRY(upload_opt_table(tensors, n, &tab, &blocks, &nb, s));
+    MDT_TRY(upload_opt_table(g_opt, tensors, n, &tab, &blocks, &nb, s));
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
     LAUNCH(mdt_launch_multi_adamw(tab, blocks, nb, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)std::sqrt(bc2), s));
     return MDT_OK;
@@ -218,10 +222,14 @@ extern "C" mdt_status mdt_op_multi_ema(const mdt_opt_tensor* tensors, int32_t n,
     if (!tensors || n < 0 || !(decay >= 0.f && decay <= 1.f)) return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_ema: bad argument");
     for (int i = 0; i < n; ++i)
         if (!tensors[i].p || !tensors[i].ema) return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_ema: tensor %d lacks p / ema", i);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32) return fail(MDT_ERR_INVALID_ARG, "device index %d out of range", dev);
+    OptTable& g_opt = g_opt_dev[dev];
     std::lock_guard<std::mutex> lock(g_opt.mu);
     hipStream_t s = (hipStream_t)stream;
     const mdt_opt_tensor* tab; const int2* blocks; int nb;
-    MDT_TRY(upload_opt_table(tensors, n, &tab, &blocks, &nb, s));
+    MDT_TRY(upload_opt_table(g_opt, tensors, n, &tab, &blocks, &nb, s));
     LAUNCH(mdt_launch_multi_axpby(tab, blocks, nb, decay, 1.0f - decay, s));
     return MDT_OK;
 }
