@@ -554,6 +554,12 @@ static const int MAX_DEVICES = 32;
 static float* g_zeros_dev[MAX_DEVICES] = {nullptr};
 static thread_local float* g_zeros = nullptr;
 
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 0;
+    return dev;
+}
+
 static hipError_t ensure_zeros() {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -580,7 +586,8 @@ static hipError_t launch_gemm_r(const mdt_gemm_args& a, int kchunk, hipStream_t 
     const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
     const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
     const size_t lds = (size_t)MT * (kchunk + 4) * sizeof(float);
-    static size_t lds_attr = 0;  // per instantiation
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};  // per instantiation and per device (function attributes are per device)
+    size_t& lds_attr = lds_attr_dev[current_device()];
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm<MTILES, NTW, NWAVES, PRO, RES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -597,7 +604,8 @@ static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStre
     const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
     const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
     const size_t lds = (size_t)2 * MT * (kchunk + 4) * sizeof(float);  // double-buffered activation chunk
-    static size_t lds_attr = 0;
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_pipe<MTILES, NTW, NWAVES, LW, RES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -958,7 +966,8 @@ static hipError_t launch_attn_tt(const mdt_attn_args& a, const float* rc, const 
     const int hs = (a.H % 2 == 0 && a.B >= 64) ? 2 : 1;  // head split: 2 half-size workgroups per sample
     const int Hl = a.H / hs;
     const size_t lds = ((size_t)(a.Tq + 2 * a.Tk) * Hl * HD + (size_t)Hl * a.Tq * 16 * LP) * sizeof(float);
-    static size_t lds_attr = 0;
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn<HD, TKC, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
