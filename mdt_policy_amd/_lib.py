@@ -86,14 +86,15 @@ class AttnBwdArgs(C.Structure):
                 ("d_out", C.c_void_p), ("ld_do", C.c_int64), ("dq", C.c_void_p), ("ld_dq", C.c_int64),
                 ("dk", C.c_void_p), ("dv", C.c_void_p), ("ld_dkv", C.c_int64), ("accumulate_kv", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("hd", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32),
-                ("causal", C.c_int32), ("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64)]
+                ("causal", C.c_int32), ("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64),
+                ("rope", C.c_int32), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
 
 
 class AttnTrainArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("ldq", C.c_int64), ("k", C.c_void_p), ("v", C.c_void_p), ("ldkv", C.c_int64),
                 ("out", C.c_void_p), ("ldo", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("hd", C.c_int32),
                 ("Tq", C.c_int32), ("Tk", C.c_int32), ("causal", C.c_int32), ("p", C.c_float), ("site", C.c_uint32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("rope", C.c_int32), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
 
 
 class MergeArgs(C.Structure):

@@ -75,7 +75,6 @@ extern "C" mdt_status mdt_train_prepare(mdt_model* m) {
     if (m->cond != COND_ADALN)
         return fail(MDT_ERR_UNSUPPORTED, "training: only the adaLN decoder (use_ada_conditioning=True, "
                                          "use_noise_encoder=False) is implemented");
-    if (m->cfg.use_rot_embed) return fail(MDT_ERR_UNSUPPORTED, "training: use_rot_embed=True is not implemented");
     mdt_train_state* t = new mdt_train_state();
     std::vector<Lin*> lins;
     for (const LinPart& p : m->parts)
@@ -287,6 +286,7 @@ static mdt_status attn_fwd(mdt_model* m, const float* q, int64_t ldq, const floa
         a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.out = out; a.ldo = m->D;
         a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
         a.p = dr.attn_p; a.site = site; a.seed = dr.seed;
+        a.rope = m->cfg.use_rot_embed; a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
         LAUNCH(mdt_launch_attn_fwd_train(a, s));
         return MDT_OK;
     }
@@ -294,6 +294,7 @@ static mdt_status attn_fwd(mdt_model* m, const float* q, int64_t ldq, const floa
     memset(&a, 0, sizeof a);
     a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.out = out; a.ldo = m->D;
     a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
+    a.rope = m->cfg.use_rot_embed;
     LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
     return MDT_OK;
 }
@@ -540,6 +541,7 @@ static mdt_attn_bwd_args attn_bwd_args(mdt_model* m, const float* q, int64_t ldq
     a.dq = dq; a.ld_dq = ld_dq; a.dk = dk; a.dv = dv; a.ld_dkv = ld_dkv; a.accumulate_kv = 0;
     a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
     a.p = dr.seed ? dr.attn_p : 0.f; a.site = site; a.seed = dr.seed;
+    a.rope = m->cfg.use_rot_embed; a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
     return a;
 }
 

@@ -385,6 +385,23 @@ hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* o
 //   P recomputed from q, k (same masking as k_attn);  dV = P^T dO ;  dP = dO V^T ;
 //   dS = P * (dP - rowsum(dP * P)) * scale ;  dQ = dS K ;  dK = dS^T Q        (F.scaled_dot_product_attention :142)
 // ------------------------------------------------------------------------------------------------
+// RoPE on rows held in LDS: feature pairs (2i, 2i+1), i < 16, of row r rotate by angle pos(r) * freq_i
+// (position_embeddings.py:56-70,138-142; tables cos/sin[pos][i], 16 x 16).  sign = -1 applies the transpose, which is
+// what carries a gradient with respect to the rotated vector back to the unrotated one.
+template <int HD>
+__device__ __forceinline__ void rope_rows(float (*rows)[HD + 1], int T, const float* __restrict__ rc,
+                                          const float* __restrict__ rs, float sign, int lane) {
+    for (int e = lane; e < T * 16; e += 64) {
+        const int r = e >> 4, i = e & 15;
+        if (2 * i + 1 < HD) {
+            const float c = rc[r * 16 + i], sn = sign * rs[r * 16 + i];
+            const float x1 = rows[r][2 * i], x2 = rows[r][2 * i + 1];
+            rows[r][2 * i] = x1 * c - x2 * sn;
+            rows[r][2 * i + 1] = x2 * c + x1 * sn;
+        }
+    }
+}
+
 // training forward with dropout on the probabilities: out = (mask/(1-p) * softmax(q k^T / sqrt(hd))) v
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, float scale) {
@@ -402,6 +419,11 @@ __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, fl
         vs[r][d] = a.v[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
     }
     __syncthreads();
+    if (a.rope) {
+        rope_rows<HD>(qs, Tq, a.rope_cos, a.rope_sin, 1.f, lane);
+        rope_rows<HD>(ks, Tk, a.rope_cos, a.rope_sin, 1.f, lane);
+        __syncthreads();
+    }
     if (lane < Tq) {
         const int i = lane;
         float sc[16];
@@ -429,6 +451,7 @@ __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, fl
 
 hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s) {
     if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
+    if (a.rope && (a.hd < 32 || !a.rope_cos || !a.rope_sin)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)a.hd);
     const dim3 grid(a.B, a.H);
     switch (a.hd) {
@@ -458,6 +481,11 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
         vs[r][d] = a.v[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
     }
     __syncthreads();
+    if (a.rope) {  // the scores were formed on the rotated q / k
+        rope_rows<HD>(qs, Tq, a.rope_cos, a.rope_sin, 1.f, lane);
+        rope_rows<HD>(ks, Tk, a.rope_cos, a.rope_sin, 1.f, lane);
+        __syncthreads();
+    }
     if (lane < Tq) {
         const int i = lane;
         float sc[16], dp[16];
@@ -489,6 +517,44 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
         for (int j = 0; j < Tk; ++j) dS[i][j] = sc[j] * (dp[j] - delta) * scale;
     }
     __syncthreads();
+    if (a.rope) {
+        // gradients with respect to the ROTATED q / k: computed into the (no longer needed) dO / V tiles, rotated back
+        // by the transpose, then stored.  dV first, while dO is still intact.
+        for (int e = lane; e < Tk * HD; e += 64) {
+            const int j = e / HD, d = e - j * HD;
+            float av = 0.f;
+            for (int i = 0; i < Tq; ++i) av = fmaf(P[i][j], os[i][d], av);
+            float* pv = a.dv + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
+            *pv = a.accumulate_kv ? *pv + av : av;
+        }
+        __syncthreads();
+        for (int e = lane; e < Tq * HD; e += 64) {
+            const int i = e / HD, d = e - i * HD;
+            float acc = 0.f;
+            for (int j = 0; j < Tk; ++j) acc = fmaf(dS[i][j], ks[j][d], acc);
+            os[i][d] = acc;                                   // dQ_rot
+        }
+        for (int e = lane; e < Tk * HD; e += 64) {
+            const int j = e / HD, d = e - j * HD;
+            float ak = 0.f;
+            for (int i = 0; i < Tq; ++i) ak = fmaf(dS[i][j], qs[i][d], ak);
+            vs[j][d] = ak;                                    // dK_rot
+        }
+        __syncthreads();
+        rope_rows<HD>(os, Tq, a.rope_cos, a.rope_sin, -1.f, lane);
+        rope_rows<HD>(vs, Tk, a.rope_cos, a.rope_sin, -1.f, lane);
+        __syncthreads();
+        for (int e = lane; e < Tq * HD; e += 64) {
+            const int i = e / HD, d = e - i * HD;
+            a.dq[((int64_t)b * Tq + i) * a.ld_dq + h * HD + d] = os[i][d];
+        }
+        for (int e = lane; e < Tk * HD; e += 64) {
+            const int j = e / HD, d = e - j * HD;
+            float* pk = a.dk + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
+            *pk = a.accumulate_kv ? *pk + vs[j][d] : vs[j][d];
+        }
+        return;
+    }
     // dQ[i][d] = sum_j dS[i][j] K[j][d]
     for (int e = lane; e < Tq * HD; e += 64) {
         const int i = e / HD, d = e - i * HD;
@@ -513,6 +579,7 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
 
 hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s) {
     if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
+    if (a.rope && (a.hd < 32 || !a.rope_cos || !a.rope_sin)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)a.hd);
     const dim3 grid(a.B, a.H);
     switch (a.hd) {

@@ -217,6 +217,9 @@ G11_CASES = {
     "mdt_tiny": ("mdt", "mdt_tiny", {}, 5),
     "mdtv_bias_plain_goal": ("mdtv", "mdtv_tiny", dict(bias=True, use_mlp_goal=False, use_modality_encoder=False), 4),
     "mdtv_default": ("mdtv", "mdtv_default", {}, 8),
+    # RoPE rotates 32 features: head_dim must be >= 32 (position_embeddings.py:66)
+    "mdtv_rope": ("mdtv", "mdtv_tiny", dict(use_rot_embed=True, n_heads=4), 5),
+    "mdt_rope": ("mdt", "mdt_tiny", dict(use_rot_embed=True, n_heads=2), 4),
 }
 
 

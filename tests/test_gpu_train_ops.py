@@ -88,10 +88,27 @@ def test_layernorm_train_forward_and_backward(lib, D, rps, B, mod, bias):
         assert_close(dmod.cpu(), m64.grad, what="d_mod", **G_TOL)
 
 
-@pytest.mark.parametrize("hd,H,Tq,Tk,causal", [(48, 8, 10, 10, 1), (48, 8, 10, 4, 1), (48, 8, 4, 4, 0), (16, 8, 10, 5, 1),
-                                              (64, 2, 16, 16, 1), (32, 4, 7, 3, 0)])
-def test_attention_backward(lib, hd, H, Tq, Tk, causal):
+def _rope_tables():
+    """(16, 16) cos / sin tables as mdt_create builds them, from the oracle's restatement."""
+    from oracle.mdt_oracle import rotary_tables
+    cos, sin = rotary_tables(16, torch.float64)                # (16, 32), pairs repeated
+    return dev(cos[:, ::2].float().contiguous()), dev(sin[:, ::2].float().contiguous())
+
+
+def _rot(t, rope):
+    if not rope:
+        return t
+    from oracle.mdt_oracle import apply_rotary
+    return apply_rotary(t, 32)
+
+
+@pytest.mark.parametrize("hd,H,Tq,Tk,causal,rope", [(48, 8, 10, 10, 1, 0), (48, 8, 10, 4, 1, 0), (48, 8, 4, 4, 0, 0),
+                                                   (16, 8, 10, 5, 1, 0), (64, 2, 16, 16, 1, 0), (32, 4, 7, 3, 0, 0),
+                                                   (48, 8, 10, 10, 1, 1), (48, 8, 10, 4, 1, 1), (32, 4, 7, 3, 0, 1),
+                                                   (64, 2, 16, 16, 1, 1)])
+def test_attention_backward(lib, hd, H, Tq, Tk, causal, rope):
     B, Dm = 3, H * hd
+    rc, rs = _rope_tables()
     qkv = rnd(B * Tq, 3 * Dm, seed=11)            # self-attention layout when Tq == Tk; otherwise separate kv
     kv = rnd(B * Tk, 2 * Dm, seed=12)
     do = rnd(B * Tq, Dm, seed=13)
@@ -99,7 +116,7 @@ def test_attention_backward(lib, hd, H, Tq, Tk, causal):
     k = kv[:, :Dm].double().requires_grad_()
     v = kv[:, Dm:].double().requires_grad_()
     split = lambda t, T: t.view(B, T, H, hd).transpose(1, 2)
-    att = split(q, Tq) @ split(k, Tk).transpose(-1, -2) / hd ** 0.5
+    att = _rot(split(q, Tq), rope) @ _rot(split(k, Tk), rope).transpose(-1, -2) / hd ** 0.5
     if causal:
         att = att.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool).tril(), float("-inf"))
     y = (att.softmax(-1) @ split(v, Tk)).transpose(1, 2).reshape(B * Tq, Dm)
@@ -111,7 +128,7 @@ def test_attention_backward(lib, hd, H, Tq, Tk, causal):
     a = lib.AttnBwdArgs(q=qd.data_ptr(), ldq=3 * Dm, k=kvd.data_ptr(), v=kvd.data_ptr() + 4 * Dm, ldkv=2 * Dm,
                         d_out=dod.data_ptr(), ld_do=Dm, dq=dq.data_ptr(), ld_dq=3 * Dm, dk=dkv.data_ptr(),
                         dv=dkv.data_ptr() + 4 * Dm, ld_dkv=2 * Dm, accumulate_kv=1, B=B, H=H, hd=hd, Tq=Tq, Tk=Tk,
-                        causal=causal)
+                        causal=causal, rope=rope, rope_cos=rc.data_ptr(), rope_sin=rs.data_ptr())
     lib.check(lib.load().mdt_op_attn_bwd(C.byref(a), stream()))
     assert_close(dq[:, :Dm].cpu(), q.grad, what="dq", **G_TOL)
     assert_close(dkv[:, :Dm].cpu() - dkv0[:, :Dm], k.grad, what="dk", **G_TOL)
@@ -200,10 +217,12 @@ def test_merge_dropout_mask_statistics_and_backward(lib):
     assert_close(dmod[:, 5 * D:].cpu(), g64.grad, what="d_gate with dropout", **G_TOL)
 
 
-@pytest.mark.parametrize("hd,H,Tq,Tk,causal", [(48, 8, 10, 10, 1), (48, 8, 10, 4, 1), (16, 4, 4, 4, 0)])
-def test_attention_dropout_forward_and_backward(lib, hd, H, Tq, Tk, causal):
+@pytest.mark.parametrize("hd,H,Tq,Tk,causal,rope", [(48, 8, 10, 10, 1, 0), (48, 8, 10, 4, 1, 0), (16, 4, 4, 4, 0, 0),
+                                                   (48, 8, 10, 10, 1, 1), (32, 4, 10, 4, 1, 1), (64, 2, 5, 16, 0, 1)])
+def test_attention_dropout_forward_and_backward(lib, hd, H, Tq, Tk, causal, rope):
     B, Dm, p, seed, site = 5, H * hd, 0.3, 987654321, 11
     L = lib.load()
+    rc, rs = _rope_tables()
     q, kv, do = rnd(B * Tq, Dm, seed=51), rnd(B * Tk, 2 * Dm, seed=52), rnd(B * Tq, Dm, seed=53)
     qd, dod = dev(q), dev(do)
 
@@ -211,7 +230,7 @@ def test_attention_dropout_forward_and_backward(lib, hd, H, Tq, Tk, causal):
         out = torch.empty(B * Tq, Dm, device="cuda")
         a = lib.AttnTrainArgs(q=qd.data_ptr(), ldq=Dm, k=kvt.data_ptr(), v=kvt.data_ptr() + 4 * Dm, ldkv=2 * Dm,
                               out=out.data_ptr(), ldo=Dm, B=B, H=H, hd=hd, Tq=Tq, Tk=Tk, causal=causal, p=pp, site=site,
-                              seed=seed)
+                              seed=seed, rope=rope, rope_cos=rc.data_ptr(), rope_sin=rs.data_ptr())
         lib.check(L.mdt_op_attn_fwd_train(C.byref(a), stream()))
         return out.cpu()
 
@@ -231,7 +250,7 @@ def test_attention_dropout_forward_and_backward(lib, hd, H, Tq, Tk, causal):
     split = lambda t, T: t.view(B, T, H, hd).transpose(1, 2)
     q64 = q.double().requires_grad_()
     k64, v64 = kv[:, :Dm].double().requires_grad_(), kv[:, Dm:].double().requires_grad_()
-    att = split(q64, Tq) @ split(k64, Tk).transpose(-1, -2) / hd ** 0.5
+    att = _rot(split(q64, Tq), rope) @ _rot(split(k64, Tk), rope).transpose(-1, -2) / hd ** 0.5
     if causal:
         att = att.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool).tril(), float("-inf"))
     y = ((att.softmax(-1) * mask.double()) @ split(v64, Tk)).transpose(1, 2).reshape(B * Tq, Dm)
@@ -242,7 +261,8 @@ def test_attention_dropout_forward_and_backward(lib, hd, H, Tq, Tk, causal):
     g = lib.AttnBwdArgs(q=qd.data_ptr(), ldq=Dm, k=kvd.data_ptr(), v=kvd.data_ptr() + 4 * Dm, ldkv=2 * Dm,
                         d_out=dod.data_ptr(), ld_do=Dm, dq=dq.data_ptr(), ld_dq=Dm, dk=dkv.data_ptr(),
                         dv=dkv.data_ptr() + 4 * Dm, ld_dkv=2 * Dm, accumulate_kv=0, B=B, H=H, hd=hd, Tq=Tq, Tk=Tk,
-                        causal=causal, p=p, site=site, seed=seed)
+                        causal=causal, p=p, site=site, seed=seed, rope=rope, rope_cos=rc.data_ptr(),
+                        rope_sin=rs.data_ptr())
     lib.check(L.mdt_op_attn_bwd(C.byref(g), stream()))
     assert_close(dq.cpu(), q64.grad, what="dq", **G_TOL)
     assert_close(dkv[:, :Dm].cpu(), k64.grad, what="dk", **G_TOL)

@@ -9,7 +9,7 @@ from mdt_policy_amd import synthetic
 from oracle import mdt_oracle as O
 from tests.helpers import assert_close, cfg_of, inputs_of, load_fixture, params_of
 
-CASES = ["mdtv_tiny", "mdt_tiny", "mdtv_bias_plain_goal", "mdtv_default"]
+CASES = ["mdtv_tiny", "mdt_tiny", "mdtv_bias_plain_goal", "mdtv_default", "mdtv_rope", "mdt_rope"]
 
 
 def case(name):
