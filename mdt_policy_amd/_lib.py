@@ -78,7 +78,8 @@ class LnBwdArgs(C.Structure):
                 ("mod_stride", C.c_int64), ("shift_off", C.c_int32), ("scale_off", C.c_int32),
                 ("dh", C.c_void_p), ("ld_dh", C.c_int64), ("dx", C.c_void_p), ("accumulate", C.c_int32),
                 ("d_mod", C.c_void_p), ("d_mod_stride", C.c_int64), ("pw", C.c_void_p), ("pb", C.c_void_p),
-                ("B", C.c_int32), ("rows_per_sample", C.c_int32), ("D", C.c_int32), ("row_chunks", C.c_int32)]
+                ("B", C.c_int32), ("rows_per_sample", C.c_int32), ("D", C.c_int32), ("row_chunks", C.c_int32),
+                ("accumulate_dmod", C.c_int32)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -170,7 +171,8 @@ SYMBOLS = [
     ("mdt_train_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, C.POINTER(Dropout), _VP, _VP, _VP,
                                   C.POINTER(_I32), _VP]),
     ("mdt_train_loss_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    ("mdt_train_encode_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _I64, C.POINTER(Dropout), _VP, C.POINTER(_I32), _VP]),
+    ("mdt_train_encode_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I64, C.POINTER(Dropout), _VP, C.POINTER(_I32),
+                                    _VP]),
     ("mdt_train_encode_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("mdt_tape_release", _I32, [_VP, _I32]),
     ("mdt_op_pack_weight_t", _I32, [_VP, _I64, _I64, _I64, _VP, _I64, _I64, _VP]),

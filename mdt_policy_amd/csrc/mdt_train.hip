@@ -4,7 +4,9 @@
 //
 // Reference: torch.autograd through score_wrappers.py:45-63 (loss), mdtv_transformer.py:208-236 /
 // mdt_transformer.py:207-242 (encoder + decoder), transformer_blocks.py:209-214 (Block), :291-309
-// (ConditionedBlock); driven by MDTVAgent.training_step -> diffusion_loss (mdtv_agent.py:222-262,:508-521).
+// (ConditionedBlock), :335-341 (NoiseBlock); driven by MDTVAgent.training_step -> diffusion_loss
+// (mdtv_agent.py:222-262,:508-521).  All three conditioning modes train: adaLN-Zero rows, NoiseBlock (the sigma
+// embedding added to the attention inputs), and the sigma token at the head of the encoder context.
 //
 // Structure: the forward runs the SAME kernels as inference, un-fused where the backward needs the intermediate
 // (LayerNorm output, pre-GELU, the un-gated branch outputs); every dense contraction of the backward runs on the
@@ -72,9 +74,6 @@ static const int NARROW_SLICES = 32;
 extern "C" mdt_status mdt_train_prepare(mdt_model* m) {
     if (!m) return fail(MDT_ERR_INVALID_ARG, "mdt_train_prepare: null handle");
     if (m->train) return MDT_OK;
-    if (m->cond != COND_ADALN)
-        return fail(MDT_ERR_UNSUPPORTED, "training: only the adaLN decoder (use_ada_conditioning=True, "
-                                         "use_noise_encoder=False) is implemented");
     mdt_train_state* t = new mdt_train_state();
     std::vector<Lin*> lins;
     for (const LinPart& p : m->parts)
@@ -299,21 +298,39 @@ static mdt_status attn_fwd(mdt_model* m, const float* q, int64_t ldq, const floa
     return MDT_OK;
 }
 
-// one block forward; mod == nullptr: plain Block (encoder), else ConditionedBlock rows of `mod` (stride modw).
-// `blk` numbers the block for the dropout sites (encoder blocks first, then decoder blocks).
+// Where a block's LayerNorms and branch gates find their conditioning in a per-sample row of `mod`:
+//   adaLN-Zero (transformer_blocks.py:291-309): [shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp]
+//   NoiseBlock (:335-341): the row IS c, a shift on ln_1 and ln3; no scales, no gates, the MLP unconditioned
+//   none: plain Block (encoder; decoder of the sigma-token variant)
+struct CondLayout { int sh1, sc1, g1, sh3, sh2, sc2, g2; };
+static CondLayout cond_layout(int cond, int D) {
+    if (cond == COND_ADALN) return {0, D, 2 * D, -1, 3 * D, 4 * D, 5 * D};
+    if (cond == COND_NOISE) return {0, -1, -1, 0, -1, -1, -1};
+    return {-1, -1, -1, -1, -1, -1, -1};
+}
+static void ln_cond(mdt_ln_train_args& l, const float* mod, int64_t modw, int sh, int sc, int T) {
+    if (!mod || (sh < 0 && sc < 0)) return;
+    l.mod = mod; l.mod_stride = modw; l.shift_off = sh; l.scale_off = sc; l.rows_per_sample = T;
+}
+
+// one block forward; mod == nullptr: plain Block, else conditioned by the rows of `mod` (stride modw) as `cond` lays
+// them out.  `blk` numbers the block for the dropout sites (encoder blocks first, then decoder blocks).
 static mdt_status block_fwd(mdt_model* m, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T, bool causal,
-                            const float* mod, int64_t modw, const float* kv, const mdt_dropout& dr, int blk, hipStream_t s) {
+                            int cond, const float* mod, int64_t modw, const float* kv, const mdt_dropout& dr, int blk,
+                            hipStream_t s) {
     const int D = m->D, M = (int)(B * T);
+    const CondLayout c = cond_layout(mod ? cond : COND_TOKEN, D);
     mdt_ln_train_args l1 = ln_args(t.x_in, e.ln1_w, e.ln1_b, t.h1, t.st1, M, D);
-    if (mod) { l1.mod = mod; l1.mod_stride = modw; l1.shift_off = 0; l1.scale_off = D; l1.rows_per_sample = T; }
+    ln_cond(l1, mod, modw, c.sh1, c.sc1, T);
     LAUNCH(mdt_launch_ln_fwd_train(l1, s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.h1, D, e.qkv, t.qkv, 3 * D, M), s));
     MDT_TRY(attn_fwd(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, t.att, B, T, T, causal, dr, site_id(blk, SITE_ATTN), s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.att, D, e.proj, t.a1, D, M), s));
-    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x_in, t.a1, mod ? mod + 2 * D : nullptr, modw, t.x1, B, T, D, dr.resid_p,
+    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x_in, t.a1, c.g1 >= 0 ? mod + c.g1 : nullptr, modw, t.x1, B, T, D, dr.resid_p,
                                            site_id(blk, SITE_RESID), dr.seed), s));
     if (d) {
         mdt_ln_train_args l3 = ln_args(t.x1, d->ln3_w, d->ln3_b, t.h3, t.st3, M, D);
+        ln_cond(l3, mod, modw, c.sh3, -1, T);
         LAUNCH(mdt_launch_ln_fwd_train(l3, s));
         LAUNCH(mdt_launch_gemm(gemm_args(t.h3, D, d->xq, t.q, D, M), s));
         // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
@@ -323,13 +340,28 @@ static mdt_status block_fwd(mdt_model* m, const EncBlock& e, const DecBlock* d, 
                                                dr.seed), s));
     }
     mdt_ln_train_args l2 = ln_args(t.x2, e.ln2_w, e.ln2_b, t.h2, t.st2, M, D);
-    if (mod) { l2.mod = mod; l2.mod_stride = modw; l2.shift_off = 3 * D; l2.scale_off = 4 * D; l2.rows_per_sample = T; }
+    ln_cond(l2, mod, modw, c.sh2, c.sc2, T);
     LAUNCH(mdt_launch_ln_fwd_train(l2, s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.h2, D, e.fc, t.u, 4 * D, M), s));
     LAUNCH(mdt_launch_act_fwd(t.u, t.hid, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.hid, 4 * D, e.proj2, t.mo, D, M), s));
-    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x2, t.mo, mod ? mod + 5 * D : nullptr, modw, t.x3, B, T, D, dr.mlp_p,
+    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x2, t.mo, c.g2 >= 0 ? mod + c.g2 : nullptr, modw, t.x3, B, T, D, dr.mlp_p,
                                            site_id(blk, SITE_MLP), dr.seed), s));
+    return MDT_OK;
+}
+
+// c = sigma_emb(sigma): sinusoidal -> Linear -> Mish -> Linear, kept on the tape (mdtv_transformer.py:169-174,238-244).
+// The last Linear writes row r of its output to row r * gout of `out` (leading dimension D).
+static mdt_status sigma_fwd(mdt_model* m, Tape& t, const float* sigma, float* out, int gout, hipStream_t s) {
+    const int D = m->D;
+    const int64_t B = t.B;
+    HIP_TRY(hipMemcpyAsync(t.sigma, sigma, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    LAUNCH(mdt_launch_sigma_emb(t.sigma, 1, m->freqs, t.sig_e, (int)B, D, s));
+    LAUNCH(mdt_launch_gemm(gemm_args(t.sig_e, D, m->sig1, t.sig_tpre, 2 * D, (int)B), s));
+    LAUNCH(mdt_launch_act_fwd(t.sig_tpre, t.sig_t, B * 2 * D, MDT_ACT_MISH, s));
+    mdt_gemm_args a = gemm_args(t.sig_t, 2 * D, m->sig3, out, D, (int)B);
+    a.gin = 1; a.gout = gout; a.goff = 0;
+    LAUNCH(mdt_launch_gemm(a, s));
     return MDT_OK;
 }
 
@@ -337,10 +369,13 @@ static float* enc_first_input(const mdt_model* m, Tape& t) { return m->Le > 0 ? 
 static float* enc_last_output(const mdt_model* m, Tape& t) { return m->Le > 0 ? t.enc[m->Le - 1].x3 : t.x_enc_out; }
 
 static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const float* tokens2, const float* goal, int modality,
-                          int honour, float* ctx_out, hipStream_t s) {
+                          int honour, const float* sigma, float* ctx_out, hipStream_t s) {
     const mdt_config& c = m->cfg;
     const int D = m->D, Te = m->Te;
+    const int t0 = m->sig_tok;  // context row of the goal token (1 when the sigma token leads the context)
     const int64_t B = t.B;
+    if (t0 && !sigma)
+        return fail(MDT_ERR_INVALID_ARG, "use_ada_conditioning=False puts sigma into the context: sigma is required");
     const int ntok_rows = c.arch == MDT_ARCH_MDTV ? m->n_tok : 1;
     HIP_TRY(hipMemcpyAsync(t.tokens, tokens, (size_t)B * ntok_rows * m->O * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (c.arch == MDT_ARCH_MDT)
@@ -352,6 +387,7 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
     const float* pos0 = (c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb) ? m->pos_emb : nullptr;
     const float* pos1 = pos0 ? m->pos_emb + (int64_t)c.goal_seq_len * D : nullptr;
     float* x0 = enc_first_input(m, t);
+    if (t0) MDT_TRY(sigma_fwd(m, t, sigma, x0, Te, s));  // concatenate_inputs (mdtv_transformer.py:296-297)
     {
         const float* gin = t.goal;
         int64_t ld = m->G;
@@ -361,24 +397,24 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
             gin = t.g_h; ld = 2 * D;
         }
         mdt_gemm_args a = gemm_args(gin, ld, g2, x0, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = 0; a.rowvec = pos0;
+        a.gin = 1; a.gout = Te; a.goff = t0; a.rowvec = pos0;
         LAUNCH(mdt_launch_gemm(a, s));
     }
     if (c.arch == MDT_ARCH_MDTV) {
         mdt_gemm_args a = gemm_args(t.tokens, m->O, m->tok, x0, D, (int)(B * m->n_tok));
-        a.gin = m->n_tok; a.gout = Te; a.goff = 1;
+        a.gin = m->n_tok; a.gout = Te; a.goff = t0 + 1;
         LAUNCH(mdt_launch_gemm(a, s));
     } else {
         mdt_gemm_args a = gemm_args(t.tokens, m->O, m->tok, x0, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = 1; a.rowvec = pos1;
+        a.gin = 1; a.gout = Te; a.goff = t0 + 1; a.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(a, s));
         mdt_gemm_args b2 = gemm_args(t.tokens2, m->O, m->incam, x0, D, (int)B);
-        b2.gin = 1; b2.gout = Te; b2.goff = 2; b2.rowvec = pos1;
+        b2.gin = 1; b2.gout = Te; b2.goff = t0 + 2; b2.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(b2, s));
     }
     for (int l = 0; l < m->Le; ++l) {
         if (l > 0) t.enc[l].x_in = t.enc[l - 1].x3;  // chain: a block's input is its predecessor's output buffer
-        MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, 0, nullptr, t.drop, l, s));
+        MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, 0, nullptr, t.drop, l, s));
     }
     mdt_ln_train_args lf = ln_args(enc_last_output(m, t), m->enc_ln_w, m->enc_ln_b, t.ctx, t.st_f, (int)(B * Te), D);
     LAUNCH(mdt_launch_ln_fwd_train(lf, s));
@@ -390,18 +426,19 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
                           float* model_output, hipStream_t s) {
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta;
-    const int64_t modw = (int64_t)m->Ld * 6 * D;
+    // conditioning rows of the decoder blocks: adaLN-Zero (B, Ld*6D), NoiseBlock (B, D) = c, sigma token: none
+    const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * D : D;
+    const int64_t mod_blk = m->cond == COND_ADALN ? 6 * D : 0;  // a block's offset in the row
     HIP_TRY(hipMemcpyAsync(t.action, action, (size_t)Ma * A * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(t.sigma, sigma, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     // cross-attention K|V of all decoder blocks
     LAUNCH(mdt_launch_gemm(gemm_args(t.ctx, D, m->kv_all, t.kvx, (int64_t)m->Ld * 2 * D, (int)(B * m->Te)), s));
-    // sigma embedding -> adaLN modulation rows
-    LAUNCH(mdt_launch_sigma_emb(t.sigma, 1, m->freqs, t.sig_e, (int)B, D, s));
-    LAUNCH(mdt_launch_gemm(gemm_args(t.sig_e, D, m->sig1, t.sig_tpre, 2 * D, (int)B), s));
-    LAUNCH(mdt_launch_act_fwd(t.sig_tpre, t.sig_t, B * 2 * D, MDT_ACT_MISH, s));
-    LAUNCH(mdt_launch_gemm(gemm_args(t.sig_t, 2 * D, m->sig3, t.sig_cpre, D, (int)B), s));
-    LAUNCH(mdt_launch_act_fwd(t.sig_cpre, t.sig_s, B * D, MDT_ACT_SILU, s));
-    LAUNCH(mdt_launch_gemm(gemm_args(t.sig_s, D, m->mod_all, t.mod, modw, (int)B), s));
+    if (m->cond == COND_ADALN) {  // sigma embedding -> SiLU -> the stacked modulation Linear of every block
+        MDT_TRY(sigma_fwd(m, t, sigma, t.sig_cpre, 1, s));
+        LAUNCH(mdt_launch_act_fwd(t.sig_cpre, t.sig_s, B * D, MDT_ACT_SILU, s));
+        LAUNCH(mdt_launch_gemm(gemm_args(t.sig_s, D, m->mod_all, t.mod, modw, (int)B), s));
+    } else if (m->cond == COND_NOISE) {
+        MDT_TRY(sigma_fwd(m, t, sigma, t.mod, 1, s));
+    }  // COND_TOKEN: enc_fwd already ran the sigma MLP (and filled t.sigma)
     // noised actions, preconditioned input, action embedding
     const int per = Ta * A;
     LAUNCH(mdt_launch_noise_input(t.action, noise, t.sigma, t.noised, Ma * A, per, s));
@@ -409,8 +446,9 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     LAUNCH(mdt_launch_action_embed(t.xin, nullptr, 0, m->cfg.sigma_data, m->Wa, m->ba, t.y0, (int)Ma, A, D, Ta, s));
     for (int l = 0; l < m->Ld; ++l) {
         t.dec[l].x_in = l == 0 ? t.y0 : t.dec[l - 1].x3;
-        MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, t.mod + (int64_t)l * 6 * D, modw,
-                          t.kvx + (int64_t)l * 2 * D, t.drop, m->Le + l, s));
+        MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond,
+                          m->cond == COND_TOKEN ? nullptr : t.mod + l * mod_blk, modw, t.kvx + (int64_t)l * 2 * D, t.drop,
+                          m->Le + l, s));
     }
     float* xl = t.dec[m->Ld - 1].x3;
     mdt_ln_train_args lh = ln_args(xl, m->dec_ln_w, m->dec_ln_b, t.lnout, t.st_h, (int)Ma, D);
@@ -449,15 +487,15 @@ static mdt_status check_ready(mdt_model* m) {
 }
 
 extern "C" mdt_status mdt_train_encode_fwd(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
-                                           int32_t modality, int32_t honour_modality, int64_t batch, const mdt_dropout* drop,
-                                           float* ctx_out, mdt_tape_id* tape, void* stream) {
+                                           int32_t modality, int32_t honour_modality, const float* sigma, int64_t batch,
+                                           const mdt_dropout* drop, float* ctx_out, mdt_tape_id* tape, void* stream) {
     MDT_TRY(check_ready(m));
     if (!tokens || !goal || !tape || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_train_encode_fwd: bad argument");
     if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
     MDT_TRY(check_dropout(drop));
     MDT_TRY(acquire_tape(m, batch, tape));
     m->train->tapes[*tape].drop = effective_dropout(drop);
-    mdt_status st = enc_fwd(m, m->train->tapes[*tape], tokens, tokens2, goal, modality, honour_modality, ctx_out,
+    mdt_status st = enc_fwd(m, m->train->tapes[*tape], tokens, tokens2, goal, modality, honour_modality, sigma, ctx_out,
                             (hipStream_t)stream);
     if (st != MDT_OK) m->train->tapes[*tape].in_use = false;
     return st;
@@ -477,7 +515,7 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
     Tape& t = m->train->tapes[*tape];
     t.drop = effective_dropout(drop);
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;  // MDTTransformer.forward always uses goal_emb (mdt_transformer.py:215)
-    mdt_status st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, ctx_out, s);
+    mdt_status st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, sigma, ctx_out, s);
     if (st == MDT_OK) st = dec_fwd(m, t, action, noise, sigma, loss_out, model_output, s);
     if (st != MDT_OK) t.in_use = false;
     return st;
@@ -519,12 +557,14 @@ static float* grad_of(mdt_model* m, float* grads, const float* param) {
 // LayerNorm backward + reduction of the per-sample weight/bias partials into the gradient slots
 static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float* stats, const float* w, const float* b,
                          const float* mod, int64_t modw, int shift_off, int scale_off, const float* dh, float* dx, int acc,
-                         float* d_mod, int64_t B, int T, hipStream_t s) {
+                         float* d_mod, int64_t B, int T, hipStream_t s, int acc_dmod = 0) {
     mdt_train_state* ts = m->train;
     mdt_ln_bwd_args a;
     memset(&a, 0, sizeof a);
     a.x = x; a.stats = stats; a.w = w; a.b = b; a.mod = mod; a.mod_stride = modw; a.shift_off = shift_off; a.scale_off = scale_off;
     a.dh = dh; a.ld_dh = m->D; a.dx = dx; a.accumulate = acc; a.d_mod = d_mod; a.d_mod_stride = modw;
+    a.accumulate_dmod = acc_dmod;
+    if (shift_off < 0 && scale_off < 0) { a.mod = nullptr; a.d_mod = nullptr; }
     a.pw = ts->pw; a.pb = b ? ts->pb : nullptr; a.B = (int)B; a.rows_per_sample = T; a.D = m->D;
     LAUNCH(mdt_launch_ln_bwd(a, s));
     if (b) LAUNCH(mdt_launch_colsum2(ts->pw, ts->pb, m->D, (int)B, m->D, grad_of(m, grads, w), grad_of(m, grads, b), 1, s));
@@ -546,23 +586,25 @@ static mdt_attn_bwd_args attn_bwd_args(mdt_model* m, const float* q, int64_t ldq
 }
 
 // dx: gradient wrt the block's output on entry, wrt its input on return (in place)
+// d_mod mirrors mod (same stride and offsets); NoiseBlock: every LayerNorm ADDS its d_shift into the one d_c row.
 static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T,
-                            bool causal, const float* mod, float* d_mod, int64_t modw, const float* kv, float* d_kv,
+                            bool causal, int cond, const float* mod, float* d_mod, int64_t modw, const float* kv, float* d_kv,
                             float* dx, const mdt_dropout& dr, int blk, hipStream_t s) {
     mdt_train_state* ts = m->train;
     const int D = m->D, M = (int)(B * T);
+    const CondLayout c = cond_layout(mod ? cond : COND_TOKEN, D);
+    const int acc_dmod = cond == COND_NOISE;
     // ---- MLP half: x3 = x2 + g2 * drop(c_proj(gelu(c_fc(h2))))
     {
-        mdt_merge_args g = merge_args(dx, t.mo, mod ? mod + 5 * D : nullptr, modw, ts->t_d, B, T, D, dr.mlp_p,
+        mdt_merge_args g = merge_args(dx, t.mo, c.g2 >= 0 ? mod + c.g2 : nullptr, modw, ts->t_d, B, T, D, dr.mlp_p,
                                       site_id(blk, SITE_MLP), dr.seed);
-        if (mod) { g.dgate = d_mod + 5 * D; g.dgate_stride = modw; }
+        if (c.g2 >= 0) { g.dgate = d_mod + c.g2; g.dgate_stride = modw; }
         LAUNCH(mdt_launch_merge_bwd(g, s));
     }
     MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, ts->t_d, D, M, ts->t_4d, 4 * D, 0, s));
     LAUNCH(mdt_launch_act_bwd(t.u, ts->t_4d, ts->t_4d, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
     MDT_TRY(lin_bwd(m, grads, e.fc, t.h2, D, ts->t_4d, 4 * D, M, ts->t_d2, D, 0, s));
-    MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, mod ? 3 * D : -1, mod ? 4 * D : -1, ts->t_d2, dx, 1,
-                   d_mod, B, T, s));
+    MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, c.sh2, c.sc2, ts->t_d2, dx, 1, d_mod, B, T, s, acc_dmod));
     if (d) {
         // ---- cross-attention half: x2 = x1 + drop(c_proj(attn(q(ln3(x1)), K, V)))
         LAUNCH(mdt_launch_merge_bwd(merge_args(dx, t.a2, nullptr, 0, ts->t_d2, B, T, D, dr.resid_p, site_id(blk, SITE_XRESID),
@@ -572,13 +614,13 @@ static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const
                                                  d_kv + D, (int64_t)m->Ld * 2 * D, B, T, m->Te, true, dr,
                                                  site_id(blk, SITE_XATTN)), s));
         MDT_TRY(lin_bwd(m, grads, d->xq, t.h3, D, ts->t_d2, D, M, ts->t_d, D, 0, s));
-        MDT_TRY(ln_bwd(m, grads, t.x1, t.st3, d->ln3_w, d->ln3_b, nullptr, 0, -1, -1, ts->t_d, dx, 1, nullptr, B, T, s));
+        MDT_TRY(ln_bwd(m, grads, t.x1, t.st3, d->ln3_w, d->ln3_b, mod, modw, c.sh3, -1, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod));
     }
     // ---- self-attention half: x1 = x_in + g1 * drop(c_proj(attn(qkv(h1))))
     {
-        mdt_merge_args g = merge_args(dx, t.a1, mod ? mod + 2 * D : nullptr, modw, ts->t_d, B, T, D, dr.resid_p,
+        mdt_merge_args g = merge_args(dx, t.a1, c.g1 >= 0 ? mod + c.g1 : nullptr, modw, ts->t_d, B, T, D, dr.resid_p,
                                       site_id(blk, SITE_RESID), dr.seed);
-        if (mod) { g.dgate = d_mod + 2 * D; g.dgate_stride = modw; }
+        if (c.g1 >= 0) { g.dgate = d_mod + c.g1; g.dgate_stride = modw; }
         LAUNCH(mdt_launch_merge_bwd(g, s));
     }
     MDT_TRY(lin_bwd(m, grads, e.proj, t.att, D, ts->t_d, D, M, ts->t_d2, D, 0, s));
@@ -586,8 +628,18 @@ static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const
                                              ts->t_3d + D, ts->t_3d + 2 * D, 3 * D, B, T, T, causal, dr, site_id(blk, SITE_ATTN)),
                                s));
     MDT_TRY(lin_bwd(m, grads, e.qkv, t.h1, D, ts->t_3d, 3 * D, M, ts->t_d, D, 0, s));
-    MDT_TRY(ln_bwd(m, grads, t.x_in, t.st1, e.ln1_w, e.ln1_b, mod, modw, mod ? 0 : -1, mod ? D : -1, ts->t_d, dx, 1, d_mod, B,
-                   T, s));
+    MDT_TRY(ln_bwd(m, grads, t.x_in, t.st1, e.ln1_w, e.ln1_b, mod, modw, c.sh1, c.sc1, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod));
+    return MDT_OK;
+}
+
+// backward of sigma_fwd given d(c) (B, D) in `dc` (consumed); sigma itself takes no gradient
+static mdt_status sigma_bwd(mdt_model* m, Tape& t, float* grads, float* dc, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const int D = m->D;
+    const int64_t B = t.B;
+    MDT_TRY(lin_bwd(m, grads, m->sig3, t.sig_t, 2 * D, dc, D, (int)B, ts->t_d2, 2 * D, 0, s));
+    LAUNCH(mdt_launch_act_bwd(t.sig_tpre, ts->t_d2, ts->t_d2, B * 2 * D, MDT_ACT_MISH, s));
+    MDT_TRY(lin_bwd(m, grads, m->sig1, t.sig_e, D, ts->t_d2, 2 * D, (int)B, nullptr, 0, 0, s));
     return MDT_OK;
 }
 
@@ -603,13 +655,18 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
     MDT_TRY(ln_bwd(m, grads, enc_last_output(m, t), t.st_f, m->enc_ln_w, m->enc_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dxe, 0,
                    nullptr, B, Te, s));
     for (int l = m->Le - 1; l >= 0; --l)
-        MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, nullptr, nullptr, 0, nullptr, nullptr, ts->dxe,
-                          t.drop, l, s));
+        MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, nullptr, 0, nullptr, nullptr,
+                          ts->dxe, t.drop, l, s));
+    const int t0 = m->sig_tok;
+    if (t0) {  // the sigma token is row 0 of every sample's context
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, ts->small, (int)B, D, 1, Te, 0, s));
+        MDT_TRY(sigma_bwd(m, t, grads, ts->small, s));
+    }
     // token embeddings: the forward scattered their rows into the context
     const Lin& g0 = t.lang ? m->lang0 : m->goal0;
     const Lin& g2 = t.lang ? m->lang2 : m->goal2;
     float* dg = ts->t_d;  // (B, D)
-    LAUNCH(mdt_launch_gather_rows(ts->dxe, dg, (int)B, D, 1, Te, 0, s));
+    LAUNCH(mdt_launch_gather_rows(ts->dxe, dg, (int)B, D, 1, Te, t0, s));
     const bool pos = c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb;
     float* g_pos = pos ? grad_of(m, grads, m->pos_emb) : nullptr;
     if (pos) LAUNCH(mdt_launch_colsum(dg, D, (int)B, D, g_pos, 1, s));
@@ -622,14 +679,14 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
     }
     if (c.arch == MDT_ARCH_MDTV) {
         float* dt = ts->t_d2;  // (B*n_tok, D)
-        LAUNCH(mdt_launch_gather_rows(ts->dxe, dt, (int)(B * m->n_tok), D, m->n_tok, Te, 1, s));
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, dt, (int)(B * m->n_tok), D, m->n_tok, Te, t0 + 1, s));
         MDT_TRY(lin_bwd(m, grads, m->tok, t.tokens, m->O, dt, D, (int)(B * m->n_tok), d_tokens, m->O, 0, s));
     } else {
         float* d1 = ts->t_d2;
-        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, 1, s));
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, t0 + 1, s));
         if (pos) LAUNCH(mdt_launch_colsum(d1, D, (int)B, D, g_pos + (int64_t)c.goal_seq_len * D, 1, s));
         MDT_TRY(lin_bwd(m, grads, m->tok, t.tokens, m->O, d1, D, (int)B, d_tokens, m->O, 0, s));
-        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, 2, s));
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, t0 + 2, s));
         if (pos) LAUNCH(mdt_launch_colsum(d1, D, (int)B, D, g_pos + (int64_t)c.goal_seq_len * D, 1, s));
         MDT_TRY(lin_bwd(m, grads, m->incam, t.tokens2, m->O, d1, D, (int)B, d_tokens2, m->O, 0, s));
     }
@@ -659,7 +716,8 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     MDT_TRY(reserve_scratch(m, t.B));
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta, Me = B * m->Te;
-    const int64_t modw = (int64_t)m->Ld * 6 * D;
+    const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * D : D;
+    const int64_t mod_blk = m->cond == COND_ADALN ? 6 * D : 0;
     // ---- loss and action head: F = action_pred(ln(x_L))
     LAUNCH(mdt_launch_loss_grad(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, Ta * A, g_loss, ts->dF, s));
     LAUNCH(mdt_launch_colsum(ts->dF, A, (int)Ma, A, grad_of(m, grads, m->bp), 1, s));
@@ -669,20 +727,25 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
                    B, Ta, s));
     // ---- decoder blocks
+    if (m->cond == COND_NOISE) HIP_TRY(hipMemsetAsync(ts->d_mod, 0, (size_t)B * D * sizeof(float), s));  // d_c accumulates
+    const bool rows = m->cond != COND_TOKEN;
     for (int l = m->Ld - 1; l >= 0; --l)
-        MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, t.mod + (int64_t)l * 6 * D,
-                          ts->d_mod + (int64_t)l * 6 * D, modw, t.kvx + (int64_t)l * 2 * D, ts->d_kvx + (int64_t)l * 2 * D, ts->dx,
-                          t.drop, m->Le + l, s));
+        MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond, rows ? t.mod + l * mod_blk : nullptr,
+                          rows ? ts->d_mod + l * mod_blk : nullptr, modw, t.kvx + (int64_t)l * 2 * D,
+                          ts->d_kvx + (int64_t)l * 2 * D, ts->dx, t.drop, m->Le + l, s));
     // ---- action embedding: y0 = action_emb(xin); no gradient flows to the noisy actions
     LAUNCH(mdt_launch_colsum(ts->dx, D, (int)Ma, D, grad_of(m, grads, m->ba), 1, s));
     LAUNCH(mdt_launch_narrow_dw(t.xin, ts->dx, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 1, s));
     LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wa), 1, s));
-    // ---- sigma path: mod = modulation(silu(c)), c = sigma_emb(sigma)
-    MDT_TRY(lin_bwd(m, grads, m->mod_all, t.sig_s, D, ts->d_mod, modw, (int)B, ts->small, D, 0, s));
-    LAUNCH(mdt_launch_act_bwd(t.sig_cpre, ts->small, ts->small, B * D, MDT_ACT_SILU, s));
-    MDT_TRY(lin_bwd(m, grads, m->sig3, t.sig_t, 2 * D, ts->small, D, (int)B, ts->t_d2, 2 * D, 0, s));
-    LAUNCH(mdt_launch_act_bwd(t.sig_tpre, ts->t_d2, ts->t_d2, B * 2 * D, MDT_ACT_MISH, s));
-    MDT_TRY(lin_bwd(m, grads, m->sig1, t.sig_e, D, ts->t_d2, 2 * D, (int)B, nullptr, 0, 0, s));
+    // ---- sigma path.  adaLN: mod = modulation(silu(c)), c = sigma_emb(sigma); NoiseBlock: the rows are c itself;
+    //      sigma token: its gradient arrives with the context's (enc_bwd)
+    if (m->cond == COND_ADALN) {
+        MDT_TRY(lin_bwd(m, grads, m->mod_all, t.sig_s, D, ts->d_mod, modw, (int)B, ts->small, D, 0, s));
+        LAUNCH(mdt_launch_act_bwd(t.sig_cpre, ts->small, ts->small, B * D, MDT_ACT_SILU, s));
+        MDT_TRY(sigma_bwd(m, t, grads, ts->small, s));
+    } else if (m->cond == COND_NOISE) {
+        MDT_TRY(sigma_bwd(m, t, grads, ts->d_mod, s));
+    }
     // ---- context: K|V projections of all blocks, plus whatever other losses hung onto latent_encoder_emb
     if (g_ctx) HIP_TRY(hipMemcpyAsync(ts->dxe, g_ctx, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     MDT_TRY(lin_bwd(m, grads, m->kv_all, t.ctx, D, ts->d_kvx, (int64_t)m->Ld * 2 * D, (int)Me, ts->dxe, D, g_ctx ? 1 : 0, s));

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_train(const float* __restrict__ 
         const int c = lane + 64 * i;
         if (c < D) {
             float n = (v[i] - mean) * rstd * w[c] + (b ? b[c] : 0.f);
-            if (mr) n = fmaf(n, mr[scale_off + c], mr[shift_off + c]);
+            if (mr) n = fmaf(n, scale_off >= 0 ? mr[scale_off + c] : 1.f, shift_off >= 0 ? mr[shift_off + c] : 0.f);
             out[(int64_t)row * D + c] = n;
         }
     }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
         const int c = lane + 64 * i;
         wgt[i] = c < D ? a.w[c] : 0.f;
         bia[i] = (c < D && a.b) ? a.b[c] : 0.f;
-        sc[i] = c < D ? (mr ? mr[a.scale_off + c] : 1.f) : 0.f;
+        sc[i] = c < D ? ((mr && a.scale_off >= 0) ? mr[a.scale_off + c] : 1.f) : 0.f;
         a_sh[i] = a_sc[i] = a_w[i] = a_b[i] = 0.f;
     }
     for (int r = r_lo + wv; r < r_hi; r += 4) {
@@ -217,9 +217,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = red[(0 * 4 + k) * D + c] + red[(1 * 4 + k) * D + c] + red[(2 * 4 + k) * D + c] +
                                            red[(3 * 4 + k) * D + c];
-        if (a.d_mod) {  // accumulate: one row of d_mod collects the gradients of several consumers
-            if (a.shift_off >= 0) a.d_mod[(int64_t)b * a.d_mod_stride + a.shift_off + c] = t[0];
-            if (a.scale_off >= 0) a.d_mod[(int64_t)b * a.d_mod_stride + a.scale_off + c] = t[1];
+        if (a.d_mod) {
+            // accumulate_dmod: the same conditioning vector feeds several LayerNorms (NoiseBlock adds c at every
+            // attention input), whose launches follow each other on the stream and add into one row
+            float* dm = a.d_mod + (int64_t)b * a.d_mod_stride;
+            if (a.shift_off >= 0) dm[a.shift_off + c] = a.accumulate_dmod ? dm[a.shift_off + c] + t[0] : t[0];
+            if (a.scale_off >= 0) dm[a.scale_off + c] = a.accumulate_dmod ? dm[a.scale_off + c] + t[1] : t[1];
         }
         a.pw[(int64_t)prow * D + c] = t[2];
         if (a.pb) a.pb[(int64_t)prow * D + c] = t[3];

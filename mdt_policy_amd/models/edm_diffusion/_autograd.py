@@ -65,8 +65,8 @@ class HipContextOnly(torch.autograd.Function):
     """context = GCDenoiser.forward_context_only(...), differentiable (CLA / MGF auxiliary losses hang on it)."""
 
     @staticmethod
-    def forward(ctx, eng, state, tok, tok2, goal, honour, drop, names, *params):
-        cx, tape = eng.train_encode_fwd(state, tok, tok2, goal, honour, drop)
+    def forward(ctx, eng, state, tok, tok2, goal, honour, drop, sigma, names, *params):
+        cx, tape = eng.train_encode_fwd(state, tok, tok2, goal, honour, drop, sigma)
         ctx.eng, ctx.tape = eng, _Tape(eng, tape)
         ctx.named = list(zip(names, params))
         ctx.unused = eng.unused_goal_embedder(state, honour)
@@ -82,4 +82,4 @@ class HipContextOnly(torch.autograd.Function):
         tok, tok2, goal = ctx.inputs
         grads, d_tok, d_tok2, d_goal = eng.train_encode_bwd(ctx.tape.id, g_ctx, tok, tok2, goal, ctx.needs)
         ctx.tape.release()
-        return (None, None, d_tok, d_tok2, d_goal, None, None, None, *eng.param_grads(grads, ctx.named, ctx.unused))
+        return (None, None, d_tok, d_tok2, d_goal, None, None, None, None, *eng.param_grads(grads, ctx.named, ctx.unused))

@@ -119,10 +119,9 @@ class GCDenoiser(nn.Module):
                 self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
             from ._autograd import HipContextOnly
             eng = self._engine(allow_grad=True)
-            if eng.sigma_in_context:
-                raise NotImplementedError("training with use_ada_conditioning=False is not implemented")
-            tok, tok2, g, _, names, params = self._train_inputs(eng, state, goal, True)
-            ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, im.train_dropout(), names, *params)
+            tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal, True)
+            sg = eng._in(sigma, (B,)) if eng.sigma_in_context else None  # the sigma token leads the context
+            ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, im.train_dropout(), sg, names, *params)
             if im._arch == "mdtv":
                 im.latent_encoder_emb = ctx
             return ctx

@@ -216,15 +216,18 @@ class HipEngine:
                                                C.byref(tape), self._stream()))
         return loss, mo, ctx, int(tape.value)
 
-    def train_encode_fwd(self, state: dict, tok, tok2, goal, honour_modality: bool, drop=None):
+    def train_encode_fwd(self, state: dict, tok, tok2, goal, honour_modality: bool, drop=None, sigma=None):
         self.train_prepare()
         self.sync_params()
         B = tok.shape[0]
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         tape = C.c_int32(-1)
+        if self.sigma_in_context and sigma is None:
+            raise ValueError("use_ada_conditioning=False: sigma is a context token and must be given")
         _lib.check(self.lib.mdt_train_encode_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
-                                                 int(honour_modality), B, None if drop is None else C.byref(drop),
-                                                 _ptr(ctx), C.byref(tape), self._stream()))
+                                                 int(honour_modality), _ptr(sigma) if self.sigma_in_context else None, B,
+                                                 None if drop is None else C.byref(drop), _ptr(ctx), C.byref(tape),
+                                                 self._stream()))
         return ctx, int(tape.value)
 
     def _input_grads(self, tok, tok2, goal, needs):

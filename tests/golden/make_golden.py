@@ -220,6 +220,10 @@ G11_CASES = {
     # RoPE rotates 32 features: head_dim must be >= 32 (position_embeddings.py:66)
     "mdtv_rope": ("mdtv", "mdtv_tiny", dict(use_rot_embed=True, n_heads=4), 5),
     "mdt_rope": ("mdt", "mdt_tiny", dict(use_rot_embed=True, n_heads=2), 4),
+    # conditioning variants of the decoder (SURVEY.md 8(f) items 1 x 3)
+    "mdtv_noise_block": ("mdtv", "mdtv_tiny", dict(use_noise_encoder=True), 5),
+    "mdtv_no_ada": ("mdtv", "mdtv_tiny", dict(use_ada_conditioning=False), 5),
+    "mdt_no_ada": ("mdt", "mdt_tiny", dict(use_ada_conditioning=False, bias=True), 4),
 }
 
 

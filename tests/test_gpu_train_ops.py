@@ -102,6 +102,39 @@ def _rot(t, rope):
     return apply_rotary(t, 32)
 
 
+def test_layernorm_shift_only_conditioning_accumulates_its_gradient(lib):
+    """NoiseBlock (transformer_blocks.py:335-341): h = ln(x) + c, the same c at several LayerNorms -> d_c adds up."""
+    D, rps, B = 128, 10, 4
+    M = B * rps
+    L = lib.load()
+    c = rnd(B, D, seed=61)
+    c64 = c.double().requires_grad_()
+    cd = dev(c)
+    dc = torch.zeros(B, D, device="cuda")
+    total = 0
+    for i in range(2):
+        x, w, dh = rnd(M, D, seed=62 + i), 1 + 0.1 * rnd(D, seed=64 + i), rnd(M, D, seed=66 + i)
+        x64 = x.double().requires_grad_()
+        h = F.layer_norm(x64, (D,), w.double(), None, 1e-5) + c64.repeat_interleave(rps, 0)
+        total = total + (h * dh.double()).sum()
+        xd, wd, dhd = dev(x), dev(w), dev(dh)
+        out, stats = torch.empty(M, D, device="cuda"), torch.empty(M, 2, device="cuda")
+        a = lib.LnTrainArgs(x=xd.data_ptr(), w=wd.data_ptr(), b=None, mod=cd.data_ptr(), mod_stride=D, shift_off=0,
+                            scale_off=-1, rows_per_sample=rps, out=out.data_ptr(), stats=stats.data_ptr(), M=M, D=D)
+        lib.check(L.mdt_op_ln_fwd_train(C.byref(a), stream()))
+        assert_close(out.cpu(), h.detach(), what="ln + c forward")
+        dx, pw = torch.zeros(M, D, device="cuda"), torch.empty(B, D, device="cuda")
+        g = lib.LnBwdArgs(x=xd.data_ptr(), stats=stats.data_ptr(), w=wd.data_ptr(), b=None, mod=cd.data_ptr(), mod_stride=D,
+                          shift_off=0, scale_off=-1, dh=dhd.data_ptr(), ld_dh=D, dx=dx.data_ptr(), accumulate=0,
+                          d_mod=dc.data_ptr(), d_mod_stride=D, pw=pw.data_ptr(), pb=None, B=B, rows_per_sample=rps, D=D,
+                          row_chunks=0, accumulate_dmod=1)
+        lib.check(L.mdt_op_ln_bwd(C.byref(g), stream()))
+        gx, = torch.autograd.grad((h * dh.double()).sum(), x64, retain_graph=True)
+        assert_close(dx.cpu(), gx, what="dx", **G_TOL)
+    total.backward()
+    assert_close(dc.cpu(), c64.grad, what="d_c over two LayerNorms", **G_TOL)
+
+
 @pytest.mark.parametrize("hd,H,Tq,Tk,causal,rope", [(48, 8, 10, 10, 1, 0), (48, 8, 10, 4, 1, 0), (48, 8, 4, 4, 0, 0),
                                                    (16, 8, 10, 5, 1, 0), (64, 2, 16, 16, 1, 0), (32, 4, 7, 3, 0, 0),
                                                    (48, 8, 10, 10, 1, 1), (48, 8, 10, 4, 1, 1), (32, 4, 7, 3, 0, 1),

@@ -9,7 +9,8 @@ from mdt_policy_amd import synthetic
 from oracle import mdt_oracle as O
 from tests.helpers import assert_close, cfg_of, inputs_of, load_fixture, params_of
 
-CASES = ["mdtv_tiny", "mdt_tiny", "mdtv_bias_plain_goal", "mdtv_default", "mdtv_rope", "mdt_rope"]
+CASES = ["mdtv_tiny", "mdt_tiny", "mdtv_bias_plain_goal", "mdtv_default", "mdtv_rope", "mdt_rope", "mdtv_noise_block",
+         "mdtv_no_ada", "mdt_no_ada"]
 
 
 def case(name):
@@ -44,7 +45,7 @@ def oracle_total(P, cfg, meta, state, goal, li, dtype):
     loss, _ = O.loss(P, cfg, st, li["actions"].to(dtype), goal, li["noise_train"].to(dtype), li["sigma"].to(dtype),
                      arch=meta["arch"])
     entry = "forward"
-    ctx = O.encode(P, cfg, st, goal, meta["arch"], entry)
+    ctx = O.encode(P, cfg, st, goal, meta["arch"], entry, sigma=li["sigma"].to(dtype))
     wctx = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), meta["ctx_seed"])).to(dtype)
     return loss, loss + 0.1 * (ctx * wctx).sum() / ctx.numel()
 
@@ -134,9 +135,10 @@ def test_hip_training_steps_follow_the_oracle():
 
 
 @pytest.mark.gpu
-def test_hip_context_only_backward_and_tape_rules():
+@pytest.mark.parametrize("name", ["mdtv_tiny", "mdtv_no_ada", "mdtv_noise_block"])
+def test_hip_context_only_backward_and_tape_rules(name):
     from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
-    meta, fx, cfg, state, goal, li = case("mdtv_tiny")
+    meta, fx, cfg, state, goal, li = case(name)
     model = GCDenoiser(cfg, 0.5)
     model.load_state_dict(params_of(meta))
     model = model.cuda().eval()
@@ -149,9 +151,10 @@ def test_hip_context_only_backward_and_tape_rules():
     P = {k: v.double().requires_grad_(v.dtype.is_floating_point) for k, v in params_of(meta).items()}
     st64 = {k: (v.double().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
     l64, _ = O.loss(P, cfg, st64, li["actions"].double(), goal.double(), li["noise_train"].double(), li["sigma"].double())
-    c64 = O.forward_context_only(P, cfg, st64, goal.double())
+    c64 = O.forward_context_only(P, cfg, st64, goal.double(), sigma=li["sigma"].double())
     (l64 + (c64 * w.cpu().double()).mean()).backward()
-    for k in ("tok_emb.weight", "encoder.blocks.0.mlp.c_proj.weight", "lang_emb.2.bias", "decoder.blocks.0.cross_att.key.weight"):
+    for k in ("tok_emb.weight", "encoder.blocks.0.mlp.c_proj.weight", "lang_emb.2.bias", "decoder.blocks.0.cross_att.key.weight",
+              "sigma_emb.1.weight", "sigma_emb.3.bias"):
         ref = P["inner_model." + k].grad
         got = dict(model.inner_model.named_parameters())[k].grad
         assert_close(got.cpu(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()), what=k)
