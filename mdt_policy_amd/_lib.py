@@ -107,7 +107,8 @@ class MergeArgs(C.Structure):
 
 class Dropout(C.Structure):
     """mirrors mdt_dropout (include/mdt_hip_train.h)"""
-    _fields_ = [("attn_p", C.c_float), ("resid_p", C.c_float), ("mlp_p", C.c_float), ("seed", C.c_uint64)]
+    _fields_ = [("attn_p", C.c_float), ("resid_p", C.c_float), ("mlp_p", C.c_float), ("embed_p", C.c_float),
+                ("seed", C.c_uint64)]
 
 
 class LinearBwdArgs(C.Structure):

@@ -116,6 +116,8 @@ hipError_t mdt_launch_narrow_dw(const float* G, const float* Y, int64_t ldy, flo
 hipError_t mdt_launch_scaled_input(const float* x, const float* sigma, float sd, int64_t n, int per_sample, float* out,
                                    hipStream_t s);
 hipError_t mdt_launch_gather_rows(const float* src, float* dst, int M, int D, int gin, int gout, int goff, hipStream_t s);
+hipError_t mdt_launch_dropout_rows(float* x, int64_t rows, int D, int rows_per_sample, int row_lo, float p, uint32_t site,
+                                   uint64_t seed, hipStream_t s);
 hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream_t s);
 // backward of a Linear through the forward GEMM kernel (mdt_train.hip); see mdt_linear_bwd_args
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s);

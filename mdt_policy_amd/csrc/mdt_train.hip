@@ -37,7 +37,7 @@ struct Tape {
     bool has_decoder = false;
     int64_t B = 0, cap = 0;
     int lang = 0;  // 1: the goal went through lang_emb
-    mdt_dropout drop = {0.f, 0.f, 0.f, 0};
+    mdt_dropout drop = {0.f, 0.f, 0.f, 0.f, 0};
     float* buf = nullptr;
     // inputs
     float *tokens, *tokens2, *goal, *action, *noised, *sigma;
@@ -266,6 +266,7 @@ static mdt_ln_train_args ln_args(const float* x, const float* w, const float* b,
 
 // dropout sites: one id per (block, place); the element index inside a site is the place's own flat index
 enum { SITE_ATTN = 0, SITE_RESID = 1, SITE_MLP = 2, SITE_XATTN = 3, SITE_XRESID = 4 };
+enum { SITE_EMBED_CTX = 0, SITE_EMBED_ACTION = 1 };  // places of the pseudo block Le + Ld: the embedding dropouts
 static uint32_t site_id(int block, int place) { return (uint32_t)(block * 8 + place + 1); }
 
 static mdt_merge_args merge_args(const float* x, const float* a, const float* gate, int64_t gstride, float* out, int64_t B,
@@ -412,6 +413,9 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
         b2.gin = 1; b2.gout = Te; b2.goff = t0 + 2; b2.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(b2, s));
     }
+    if (c.arch == MDT_ARCH_MDT)  // MDTTransformer drops the embedded goal / state tokens (mdt_transformer.py:220-227)
+        LAUNCH(mdt_launch_dropout_rows(x0, B * Te, D, Te, t0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_CTX),
+                                       t.drop.seed, s));
     for (int l = 0; l < m->Le; ++l) {
         if (l > 0) t.enc[l].x_in = t.enc[l - 1].x3;  // chain: a block's input is its predecessor's output buffer
         MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, 0, nullptr, t.drop, l, s));
@@ -444,6 +448,7 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     LAUNCH(mdt_launch_noise_input(t.action, noise, t.sigma, t.noised, Ma * A, per, s));
     LAUNCH(mdt_launch_scaled_input(t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, t.xin, s));
     LAUNCH(mdt_launch_action_embed(t.xin, nullptr, 0, m->cfg.sigma_data, m->Wa, m->ba, t.y0, (int)Ma, A, D, Ta, s));
+    LAUNCH(mdt_launch_dropout_rows(t.y0, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed, s));
     for (int l = 0; l < m->Ld; ++l) {
         t.dec[l].x_in = l == 0 ? t.y0 : t.dec[l - 1].x3;
         MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond,
@@ -467,14 +472,14 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
 
 static mdt_status check_dropout(const mdt_dropout* d) {
     if (!d) return MDT_OK;
-    for (float p : {d->attn_p, d->resid_p, d->mlp_p})
+    for (float p : {d->attn_p, d->resid_p, d->mlp_p, d->embed_p})
         if (!(p >= 0.f && p < 1.f)) return fail(MDT_ERR_INVALID_ARG, "dropout probabilities must be in [0, 1)");
     return MDT_OK;
 }
 
 static mdt_dropout effective_dropout(const mdt_dropout* d) {
-    mdt_dropout z = {0.f, 0.f, 0.f, 0};
-    if (!d || d->seed == 0 || (d->attn_p <= 0.f && d->resid_p <= 0.f && d->mlp_p <= 0.f)) return z;
+    mdt_dropout z = {0.f, 0.f, 0.f, 0.f, 0};
+    if (!d || d->seed == 0 || (d->attn_p <= 0.f && d->resid_p <= 0.f && d->mlp_p <= 0.f && d->embed_p <= 0.f)) return z;
     return *d;
 }
 
@@ -658,6 +663,9 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
         MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, nullptr, 0, nullptr, nullptr,
                           ts->dxe, t.drop, l, s));
     const int t0 = m->sig_tok;
+    if (c.arch == MDT_ARCH_MDT)
+        LAUNCH(mdt_launch_dropout_rows(ts->dxe, Me, D, Te, t0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_CTX),
+                                       t.drop.seed, s));
     if (t0) {  // the sigma token is row 0 of every sample's context
         LAUNCH(mdt_launch_gather_rows(ts->dxe, ts->small, (int)B, D, 1, Te, 0, s));
         MDT_TRY(sigma_bwd(m, t, grads, ts->small, s));
@@ -733,7 +741,9 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
         MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond, rows ? t.mod + l * mod_blk : nullptr,
                           rows ? ts->d_mod + l * mod_blk : nullptr, modw, t.kvx + (int64_t)l * 2 * D,
                           ts->d_kvx + (int64_t)l * 2 * D, ts->dx, t.drop, m->Le + l, s));
-    // ---- action embedding: y0 = action_emb(xin); no gradient flows to the noisy actions
+    // ---- action embedding: y0 = drop(action_emb(xin)); no gradient flows to the noisy actions
+    LAUNCH(mdt_launch_dropout_rows(ts->dx, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed,
+                                   s));
     LAUNCH(mdt_launch_colsum(ts->dx, D, (int)Ma, D, grad_of(m, grads, m->ba), 1, s));
     LAUNCH(mdt_launch_narrow_dw(t.xin, ts->dx, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 1, s));
     LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wa), 1, s));

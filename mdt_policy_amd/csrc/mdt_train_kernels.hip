@@ -696,6 +696,25 @@ hipError_t mdt_launch_gather_rows(const float* src, float* dst, int M, int D, in
     return hipGetLastError();
 }
 
+// nn.Dropout on embedded tokens, in place (self.drop: mdtv_transformer.py:104,227; mdt_transformer.py:220-227,234):
+// rows whose position inside their sample (row % rows_per_sample) is below row_lo are left alone (the sigma token).
+// The backward applies the same call to the gradient.
+__global__ void k_dropout_rows(float* __restrict__ x, int64_t n, int D, int rows_per_sample, int row_lo, float p,
+                               uint32_t site, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if ((int)((i / D) % rows_per_sample) < row_lo) return;
+    x[i] *= dropout_scale(seed, site, (uint64_t)i, p);
+}
+hipError_t mdt_launch_dropout_rows(float* x, int64_t rows, int D, int rows_per_sample, int row_lo, float p, uint32_t site,
+                                   uint64_t seed, hipStream_t s) {
+    if (p <= 0.f || seed == 0) return hipSuccess;
+    const int64_t n = rows * D;
+    hipLaunchKernelGGL(k_dropout_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, D, rows_per_sample, row_lo, p,
+                       site, seed);
+    return hipGetLastError();
+}
+
 // y (+)= x elementwise
 __global__ void k_axpy1(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

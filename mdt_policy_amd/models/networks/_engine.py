@@ -321,17 +321,14 @@ class HipScoreNetwork(nn.Module):
         """mdt_dropout of one train-mode forward (fresh seed from torch's CPU generator, so torch.manual_seed makes
         runs repeatable), or None in eval mode / without dropout."""
         embed_p, attn_p, resid_p, mlp_p, goal_p = (float(p) for p in self._pdrops)
-        if not self.training or max(attn_p, resid_p, mlp_p) <= 0:
+        if not self.training or max(attn_p, resid_p, mlp_p, embed_p) <= 0:
             return None
         seed = int(torch.randint(1, 2 ** 62, (1,)).item())
-        return _lib.Dropout(attn_p=attn_p, resid_p=resid_p, mlp_p=mlp_p, seed=seed)
+        return _lib.Dropout(attn_p=attn_p, resid_p=resid_p, mlp_p=mlp_p, embed_p=embed_p, seed=seed)
 
     def _guard_mode(self, allow_grad: bool = False):
         embed_p, attn_p, resid_p, mlp_p, goal_p = (float(p) for p in self._pdrops)
-        if self.training and (embed_p > 0 or goal_p > 0):
-            raise NotImplementedError("train() mode with embed_pdrob / goal_drop > 0 is not implemented by the HIP path "
-                                      "(both are 0 in the shipped configurations)")
-        if self.training and max(attn_p, resid_p, mlp_p) > 0 and not (allow_grad and torch.is_grad_enabled()):
+        if self.training and max(attn_p, resid_p, mlp_p, embed_p) > 0 and not (allow_grad and torch.is_grad_enabled()):
             raise NotImplementedError(
                 "train() mode with dropout > 0 outside a training step: only GCDenoiser.loss / forward_context_only "
                 "under autograd apply dropout on the HIP path; call .eval() for inference")
@@ -343,11 +340,17 @@ class HipScoreNetwork(nn.Module):
 
     # -- reference API ---------------------------------------------------------------------------
     def _goals(self, goals: torch.Tensor, uncond: bool) -> torch.Tensor:
-        """preprocess_goals, eval mode (reference mdtv_transformer.py:246-258)."""
+        """preprocess_goals (reference mdtv_transformer.py:246-258) incl. mask_cond (:302-310): in train() mode every
+        goal ELEMENT is zeroed with probability goal_drop -- the reference's own torch.bernoulli draw on the goal's
+        device, so a seeded run masks the same elements."""
         if goals.dim() == 2:
             goals = goals[:, None, :]
         if goals.shape[1] != 1 and self.goal_seq_len == 1:
             goals = goals[:, :1, :]
+        goal_p = float(self._pdrops[4])
+        if self.training and goal_p > 0.0:
+            mask = torch.bernoulli(torch.ones(goals.shape, device=goals.device) * goal_p)
+            goals = goals * (1.0 - mask)
         if uncond:
             goals = torch.zeros_like(goals)
         return goals

@@ -264,8 +264,15 @@ def g11():
 def g13():
     """Dropout statistics of the REFERENCE in train() mode (attn 0.3 / resid 0.1 / mlp 0.05): the random streams of
     two implementations cannot coincide, their distributions must.  400 seeded forward passes of GCDenoiser.loss on
-    fixed weights / inputs: mean and std of the loss, mean and variance (over seeds) of the model output."""
-    cfg, arch, B, n = configs.mdtv_tiny(), "mdtv", 6, 400
+    fixed weights / inputs: mean and std of the loss, mean and variance (over seeds) of the model output.
+    Second fixture: MDT with only embed_pdrob (self.drop on goal / state / action embeddings) and goal_drop (mask_cond)."""
+    _g13("g13_dropout_stats.npz", "mdtv_tiny", {}, "mdtv")
+    _g13("g13_embed_goal_drop_stats.npz", "mdt_tiny",
+         dict(embed_pdrob=0.2, goal_drop=0.15, attn_pdrop=0.0, resid_pdrop=0.0, mlp_pdrop=0.0), "mdt")
+
+
+def _g13(fname, factory, ov, arch):
+    cfg, B, n = getattr(configs, factory)(**ov), 6, 400
     model = build_reference(cfg, arch, seed=131, profile="rich").train()
     inp = synthetic.sampler_inputs(B, cfg, 132, arch)
     li = synthetic.loss_inputs(B, cfg, 133)
@@ -281,11 +288,11 @@ def g13():
         model.eval()
         loss_eval, mo_eval = model.loss(state, *args)
     outs = torch.stack(outs).double()
-    meta = dict(config="mdtv_tiny", arch=arch, B=B, n=n, modality="lang", weight_seed=131, profile="rich", input_seed=132,
+    meta = dict(config=factory, overrides=ov, arch=arch, B=B, n=n, modality="lang", weight_seed=131, profile="rich", input_seed=132,
                 loss_seed=133, loss_mean=float(np.mean(losses)), loss_std=float(np.std(losses, ddof=1)),
                 loss_eval=float(loss_eval), out_var_mean=float(outs.var(0, unbiased=True).mean()),
                 out_abs_dev_from_eval=float((outs.mean(0) - mo_eval.double()).abs().mean()))
-    save("g13_dropout_stats.npz", meta, out_mean=outs.mean(0).float().numpy(), out_var=outs.var(0, unbiased=True).float().numpy())
+    save(fname, meta, out_mean=outs.mean(0).float().numpy(), out_var=outs.var(0, unbiased=True).float().numpy())
 
 
 def g5():

@@ -290,9 +290,9 @@ def test_hip_gradients_under_distributed_data_parallel():
         assert_close(got[0][k], ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-7, what=k)
 
 
-def _dropout_stats(overrides):
+def _dropout_stats(overrides, fixture="g13_dropout_stats.npz"):
     from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
-    meta, fx = load_fixture("g13_dropout_stats.npz")
+    meta, fx = load_fixture(fixture)
     cfg = dict(cfg_of(meta), **overrides)
     state, goal, _ = inputs_of(meta)
     li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(meta["B"], cfg, meta["loss_seed"]).items()}
@@ -339,6 +339,76 @@ def test_hip_dropout_statistics_detect_a_wrong_site(overrides):
     """Negative control: the same check rejects a model whose dropout differs at one site."""
     with pytest.raises(AssertionError):
         _check_dropout_stats(*_dropout_stats(overrides))
+
+
+@pytest.mark.gpu
+def test_hip_embedding_dropout_and_goal_masking_statistics_match_the_reference():
+    """embed_pdrob (self.drop on MDT's embedded goal / state / action tokens) and goal_drop (mask_cond) against 400
+    train-mode passes of the REFERENCE with only those two switched on (g13_embed_goal_drop_stats)."""
+    fixture = "g13_embed_goal_drop_stats.npz"
+    meta, fx, n, lm, ls, mean, var = _dropout_stats({}, fixture)
+    _check_dropout_stats(meta, fx, n, lm, ls, mean, var)
+    for wrong in (dict(embed_pdrob=0.0), dict(goal_drop=0.0), dict(embed_pdrob=0.4)):
+        with pytest.raises(AssertionError):
+            _check_dropout_stats(*_dropout_stats(wrong, fixture))
+
+
+@pytest.mark.gpu
+def test_hip_embedding_dropout_is_differentiated_correctly():
+    """Same seed -> same masks in forward and backward: the directional derivative of the seeded train-mode loss
+    (embed_pdrob only, MDT: context and action embeddings) matches central finite differences."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, state, goal, li = case("mdt_tiny")
+    cfg = dict(cfg, embed_pdrob=0.25, attn_pdrop=0.0, resid_pdrop=0.0, mlp_pdrop=0.0)
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().train()
+    gstate = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    args = (li["actions"].cuda(), goal.cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
+
+    def run(seed):
+        torch.manual_seed(seed)
+        return model.loss(gstate, *args)[0]
+
+    l1, l2, l3 = run(3), run(3), run(4)
+    assert l1.item() == l2.item() and l1.item() != l3.item()
+    l1.backward()
+    names = ["tok_emb.weight", "incam_embed.weight", "goal_emb.2.weight", "action_emb.weight", "encoder.blocks.0.attn.query.weight"]
+    params = dict(model.inner_model.named_parameters())
+    for k in names:
+        p = params[k]
+        g = p.grad.clone()
+        d = torch.from_numpy(synthetic.normal("dir_" + k, tuple(p.shape), 9)).cuda()
+        eps = 2e-2 / float(d.norm()) * max(float(p.detach().norm()), 1.0)
+        with torch.no_grad():
+            p.add_(eps * d)
+        lp = run(3).item()          # train-mode dropout only runs under autograd
+        with torch.no_grad():
+            p.sub_(2 * eps * d)
+        lm = run(3).item()
+        with torch.no_grad():
+            p.add_(eps * d)
+        fd = (lp - lm) / (2 * eps)
+        an = float((g * d).sum())
+        assert abs(fd - an) <= 3e-2 * abs(an) + 2e-4, (k, fd, an)
+
+
+def test_goal_masking_draws_the_reference_bernoulli_stream():
+    """mask_cond (mdtv_transformer.py:302-310): in train() mode goals * (1 - bernoulli(goal_drop)), elementwise."""
+    from mdt_policy_amd import configs
+    from mdt_policy_amd.models.networks.mdtv_transformer import MDTVTransformer
+    cfg = {k: v for k, v in configs.mdtv_tiny(goal_drop=0.3).items() if k != "_target_"}
+    net = MDTVTransformer(**cfg)
+    goal = torch.from_numpy(synthetic.normal("goal", (7, 1, 512), 5))
+    net.train()
+    torch.manual_seed(11)
+    got = net._goals(goal, False)
+    torch.manual_seed(11)
+    want = goal * (1.0 - torch.bernoulli(torch.ones((7, 1, 512)) * 0.3))
+    assert torch.equal(got, want) and 0.2 < float((got == 0).float().mean()) < 0.4
+    net.eval()
+    assert net._goals(goal, False) is goal
+    assert torch.equal(net._goals(goal, True), torch.zeros_like(goal))
 
 
 @pytest.mark.gpu
