@@ -107,6 +107,9 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
     }
 }
 
+#ifndef MDT_RING_ADD
+#define MDT_RING_ADD 0  // tuning builds: deeper weight-fragment rings (tools/gpu_ring_ab.sh)
+#endif
 // one k-step of the MFMA main loop (uses the enclosing kernel's ring / wp / ap / stride / acc / kg / K16): prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
 #define MDT_KSTEP(U, KC)                                                                                  \
     {                                                                                                     \
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     constexpr int MT = MTILES * 16;
     // weight-fragment ring: R-1 k-steps of 1-KiB loads in flight per column tile.  A k-step is only 8 MFMAs
     // (256 pipe cycles) with one column tile per wave, so the narrow variants need the deeper ring to cover L2 latency.
-    constexpr int R = NTW == 1 ? 6 : (NTW == 2 ? 4 : 3);
+    constexpr int R = (NTW == 1 ? 6 : (NTW == 2 ? 4 : 3)) + MDT_RING_ADD;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.z) {  // batched launch (split-K partial products): every operand advances by its batch stride
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
                                                                  const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MT = MTILES * 16;
-    constexpr int R = NTW == 1 ? 6 : (NTW == 2 ? 4 : 3);
+    constexpr int R = (NTW == 1 ? 6 : (NTW == 2 ? 4 : 3)) + MDT_RING_ADD;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave >= NWAVES;

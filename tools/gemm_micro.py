@@ -6,7 +6,7 @@ from mdt_policy_amd import _lib
 lib = _lib.load()
 dev = torch.device("cuda")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-M, D = 2560, 384
+M, D = int(os.environ.get("M", "2560")), 384
 g = torch.Generator().manual_seed(0)
 s = torch.cuda.current_stream().cuda_stream
 def packed(N, K):
