@@ -130,6 +130,11 @@ class ResamplerConfig(C.Structure):
                                           "ff_mult", "activation")]
 
 
+class MapPoolConfig(C.Structure):
+    """mirrors mdt_map_pool_config (include/mdt_map_pool.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("n_latents", "embed_dim", "output_dim", "n_heads", "mlp_hidden")]
+
+
 ARCH = {"mdtv": 0, "mdt": 1}
 MODALITY = {"vis": 0, "lang": 1}
 ACT = {"none": 0, "gelu": 1, "mish": 2, "silu": 3}
@@ -205,6 +210,20 @@ SYMBOLS = [
     ("mdt_resampler_backward", _I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     ("mdt_resampler_tape_release", _I32, [_VP, _I32]),
     ("mdt_resampler_flops", C.c_double, [_VP, _I32, _I32]),
+    # include/mdt_map_pool.h
+    ("mdt_map_pool_create", _I32, [C.POINTER(MapPoolConfig), C.POINTER(_VP)]),
+    ("mdt_map_pool_destroy", _I32, [_VP]),
+    ("mdt_map_pool_param_count", _I64, [_VP]),
+    ("mdt_map_pool_param_name", C.c_char_p, [_VP, _I64]),
+    ("mdt_map_pool_param_numel", _I64, [_VP, _I64]),
+    ("mdt_map_pool_load_param", _I32, [_VP, C.c_char_p, _VP, _I64, _VP]),
+    ("mdt_map_pool_forward", _I32, [_VP, _VP, _I64, _I32, _VP, _VP]),
+    ("mdt_map_pool_train_prepare", _I32, [_VP]),
+    ("mdt_map_pool_grad_numel", _I64, [_VP]),
+    ("mdt_map_pool_grad_offset", _I64, [_VP, _I64]),
+    ("mdt_map_pool_forward_train", _I32, [_VP, _VP, _I64, _I32, _VP, C.POINTER(_I32), _VP]),
+    ("mdt_map_pool_backward", _I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    ("mdt_map_pool_tape_release", _I32, [_VP, _I32]),
 ]
 
 _lock = threading.Lock()

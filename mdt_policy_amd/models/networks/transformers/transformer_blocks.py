@@ -144,3 +144,7 @@ class TransformerDecoder(_ParamOnly):
                   use_cross_attention=use_cross_attention, use_rot_embed=use_rot_embed, rotary_xpos=rotary_xpos,
                   bias=bias) for _ in range(n_layers)])
         self.ln = LayerNorm(embed_dim, bias)
+
+
+# the contrastive head lives next to the blocks in the reference (transformer_blocks.py:42-62, :716-880)
+from .map_pool import (ClipStyleProjection, MAPAttention, MAPBlock, MeanPooling, RMSNorm, SwishGLU)  # noqa: E402,F401

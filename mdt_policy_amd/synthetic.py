@@ -53,7 +53,7 @@ def param_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, profile: str 
         if profile == "init":
             return np.zeros(shape, np.float32)
         return normal(name, shape, seed, std=0.1)
-    if len(shape) == 1 and leaf == "weight":  # LayerNorm gain
+    if len(shape) == 1 and leaf in ("weight", "g"):  # LayerNorm / RMSNorm gain
         if profile == "init":
             return np.ones(shape, np.float32)
         return normal(name, shape, seed, std=0.1, mean=1.0)

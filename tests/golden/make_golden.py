@@ -459,6 +459,88 @@ def g10():
     print(f"  wrote g10_fnv.json: {len(vec)} vectors")
 
 
+G14_CLA = {
+    # name: (ClipStyleProjection kwargs, (B, N tokens))
+    "map_tiny": (dict(clip_style="map", token_dim=128, clip_token_index=1, num_token=4), (5, 4)),
+    "map_default": (dict(clip_style="map", token_dim=384, clip_token_index=1, num_token=4), (6, 4)),
+    "map_state_only": (dict(clip_style="map_state_only", token_dim=128, clip_token_index=1, num_token=4), (4, 4)),
+    "map_five_tokens": (dict(clip_style="map", token_dim=128, clip_token_index=1, num_token=5), (3, 5)),
+    "mean_pooling": (dict(clip_style="mean_pooling", token_dim=128), (4, 4)),
+    "mlp": (dict(clip_style="mlp", token_dim=128, num_token=4), (4, 4)),
+    "single_token": (dict(clip_style="single_token", token_dim=128, clip_token_index=1), (4, 4)),
+}
+
+
+def install_agent_stubs():
+    """mdtv_agent.py imports the training harness (Lightning, wandb, the Voltron encoder) at module level; none of it
+    takes part in clip_auxiliary_loss, which is called UNBOUND below with an object that only carries logit_scale."""
+    from unittest import mock
+
+    class Auto(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return mock.MagicMock()
+
+    def stub(name, **kw):
+        m = Auto(name)
+        m.__dict__.update(kw)
+        m.__path__ = []
+        sys.modules[name] = m
+
+    stub("pytorch_lightning", LightningModule=torch.nn.Module, Callback=object)
+    stub("pytorch_lightning.utilities", rank_zero_info=print, rank_zero_only=lambda f: f)
+    stub("pytorch_lightning.utilities.exceptions", MisconfigurationException=Exception)
+    stub("pytorch_lightning.utilities.types", STEP_OUTPUT=object)
+    stub("wandb")
+    stub("mdt.models.perceptual_encoders.voltron_encoder")
+
+
+def g14():
+    """Contrastive (CLA) head: ClipStyleProjection outputs + gradients for every clip style, and the agent's own
+    clip_auxiliary_loss (values and gradients) in its three modes."""
+    from mdt.models.networks.transformers.transformer_blocks import ClipStyleProjection
+
+    for name, (kw, (B, N)) in G14_CLA.items():
+        m = ClipStyleProjection(**kw)
+        sd = m.state_dict()
+        new = synthetic.fill_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], 141, "rich")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()}, strict=True)
+        x = torch.from_numpy(synthetic.normal("ctx", (B, N, kw["token_dim"]), 142)).requires_grad_()
+        out = m(x)
+        cot = torch.from_numpy(synthetic.normal("cotangent", tuple(out.shape), 143))
+        (out * cot).sum().backward()
+        grads = {}
+        for k, p in m.named_parameters():
+            g = p.grad.detach().double()
+            grads[k] = [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
+        meta = dict(kwargs=kw, B=B, N=N, weight_seed=141, input_seed=142, cot_seed=143, profile="rich", grads=grads,
+                    state_dict=[[k, list(v.shape)] for k, v in sd.items()])
+        save(f"g14_cla_{name}.npz", meta, out=out.detach().numpy(), d_x=x.grad.numpy())
+
+    install_agent_stubs()
+    from mdt.models.mdtv_agent import MDTVAgent
+
+    class Holder:
+        pass
+
+    arrays, meta = {}, dict(input_seed=145, cases=[])
+    for B, D, ls in ((7, 128, float(np.log(1 / 0.07))), (16, 384, 1.3), (1, 64, 0.0)):
+        for mode in ("symmetric", "img_to_text", "text_to_img"):
+            h = Holder()
+            h.logit_scale = torch.tensor(ls, dtype=torch.float32, requires_grad=True)
+            img = torch.from_numpy(synthetic.normal("img", (B, D), 145)).requires_grad_()
+            lang = torch.from_numpy(synthetic.normal("lang", (B, D), 146) + 0.5 * synthetic.normal("img", (B, D), 145)).requires_grad_()
+            loss = MDTVAgent.clip_auxiliary_loss(h, img, lang, mode=mode)
+            loss.backward()
+            key = f"B{B}_D{D}_{mode}"
+            arrays[key + "_loss"] = np.array(loss.item(), np.float32)
+            arrays[key + "_d_img"], arrays[key + "_d_lang"] = img.grad.numpy(), lang.grad.numpy()
+            arrays[key + "_d_scale"] = np.array(h.logit_scale.grad.item(), np.float32)
+            meta["cases"].append(dict(key=key, B=B, D=D, logit_scale=ls, mode=mode))
+    save("g14_cla_infonce.npz", meta, **arrays)
+
+
 def manifest():
     """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
     out = {}
@@ -481,7 +563,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "g14", "manifest"]
     for w in which:
         print(w)
         globals()[w]()
