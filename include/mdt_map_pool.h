@@ -65,6 +65,26 @@ mdt_status mdt_map_pool_backward(mdt_map_pool *p, int32_t tape, const float *g_o
                                  void *stream);
 mdt_status mdt_map_pool_tape_release(mdt_map_pool *p, int32_t tape);
 
+/* ---- loss: InfoNCE between the pooled embeddings ----
+ * MDTVAgent.clip_auxiliary_loss(image_features, lang_features, mode) (mdt/models/mdtv_agent.py:774-799): both sets
+ * L2-normalised, S = exp(logit_scale) * img @ lang^T, cross entropy against the diagonal over the rows
+ * (img_to_text), the columns (text_to_img) or the mean of both (symmetric).  Value and -- when the three gradient
+ * pointers are given -- dL/d(image_features), dL/d(lang_features), dL/d(logit_scale) in the same enqueue. */
+enum { MDT_INFONCE_SYMMETRIC = 0, MDT_INFONCE_IMG_TO_TEXT = 1, MDT_INFONCE_TEXT_TO_IMG = 2 };
+typedef struct {
+    const float *image_features;  /* (batch, dim)                                                   */
+    const float *lang_features;   /* (batch, dim)                                                   */
+    const float *logit_scale;     /* device scalar: the log temperature parameter (mdtv_agent.py:140) */
+    int32_t batch, dim;           /* dim: multiple of 16; batch 1..32768 (the GLOBAL batch after the gather) */
+    int32_t mode;                 /* MDT_INFONCE_*                                                    */
+    float *loss;                  /* device scalar out                                                */
+    float *d_image, *d_lang;      /* (batch, dim) out, or all three NULL                              */
+    float *d_logit_scale;         /* device scalar out                                                */
+    float *scratch;               /* mdt_op_infonce_scratch(batch, dim) floats                        */
+} mdt_infonce_args;
+int64_t mdt_op_infonce_scratch(int64_t batch, int64_t dim);
+mdt_status mdt_op_infonce(const mdt_infonce_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

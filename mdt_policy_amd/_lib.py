@@ -135,6 +135,14 @@ class MapPoolConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_latents", "embed_dim", "output_dim", "n_heads", "mlp_hidden")]
 
 
+class InfoNCEArgs(C.Structure):
+    """mirrors mdt_infonce_args (include/mdt_map_pool.h)"""
+    _fields_ = [("image_features", C.c_void_p), ("lang_features", C.c_void_p), ("logit_scale", C.c_void_p),
+                ("batch", C.c_int32), ("dim", C.c_int32), ("mode", C.c_int32), ("loss", C.c_void_p),
+                ("d_image", C.c_void_p), ("d_lang", C.c_void_p), ("d_logit_scale", C.c_void_p), ("scratch", C.c_void_p)]
+
+
+INFONCE_MODE = {"symmetric": 0, "img_to_text": 1, "text_to_img": 2}
 ARCH = {"mdtv": 0, "mdt": 1}
 MODALITY = {"vis": 0, "lang": 1}
 ACT = {"none": 0, "gelu": 1, "mish": 2, "silu": 3}
@@ -224,6 +232,8 @@ SYMBOLS = [
     ("mdt_map_pool_forward_train", _I32, [_VP, _VP, _I64, _I32, _VP, C.POINTER(_I32), _VP]),
     ("mdt_map_pool_backward", _I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     ("mdt_map_pool_tape_release", _I32, [_VP, _I32]),
+    ("mdt_op_infonce_scratch", _I64, [_I64, _I64]),
+    ("mdt_op_infonce", _I32, [C.POINTER(InfoNCEArgs), _VP]),
 ]
 
 _lock = threading.Lock()

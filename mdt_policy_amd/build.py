@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libmdt_hip.so")
-SOURCES = ["mdt_kernels.hip", "mdt_model.hip", "mdt_resampler.hip", "mdt_map_pool.hip", "mdt_train_kernels.hip", "mdt_train_ops.hip", "mdt_train.hip"]
+SOURCES = ["mdt_kernels.hip", "mdt_model.hip", "mdt_resampler.hip", "mdt_map_pool.hip", "mdt_infonce.hip", "mdt_train_kernels.hip", "mdt_train_ops.hip", "mdt_train.hip"]
 ARCH = "gfx950"
 
 

@@ -7,38 +7,67 @@ clip_auxiliary_loss (:774-799); the same code in MDTAgent.  The pooled embedding
 ``model.forward_context_only`` (vision goal) -- both differentiable HIP forwards, so the loss trains the goal
 embedders, the encoder and the pooling head as in the reference.
 
-The InfoNCE itself is a (global batch)^2 x d product and two cross-entropies over the pooled (B, d) embeddings: host
-PyTorch (rocBLAS), like the reference; with more than one process the embeddings of all ranks are gathered with
-gradients over RCCL first (Lightning's ``all_gather(sync_grads=True)``, mdtv_agent.py:460-466).
+The InfoNCE over the pooled (global batch, d) embeddings is one HIP enqueue (``mdt_op_infonce``: normalisation, the
+B x B product on the fp32-MFMA GEMM, row / column log-sum-exp, loss, and all three gradients); with more than one
+process the embeddings of all ranks are gathered with gradients over RCCL first (Lightning's
+``all_gather(sync_grads=True)``, mdtv_agent.py:460-466).  No CPU path: CPU tensors raise.
 """
 from __future__ import annotations
 
 from typing import Optional
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
+from .. import _lib
 from .edm_diffusion.utils import append_dims
+
+
+class _InfoNCE(torch.autograd.Function):
+    """Loss value and the three gradients come out of ONE enqueue; backward scales them by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, img, lang, logit_scale, mode):
+        lib = _lib.load()
+        B, D = img.shape
+        dev = img.device
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        need = any(ctx.needs_input_grad[:3])
+        d_img = torch.empty_like(img) if need else None
+        d_lang = torch.empty_like(lang) if need else None
+        d_ls = torch.empty((), device=dev, dtype=torch.float32) if need else None
+        scratch = torch.empty(int(lib.mdt_op_infonce_scratch(B, D)), device=dev, dtype=torch.float32)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a = _lib.InfoNCEArgs(image_features=img.data_ptr(), lang_features=lang.data_ptr(), logit_scale=logit_scale.data_ptr(),
+                             batch=B, dim=D, mode=mode, loss=loss.data_ptr(), d_image=ptr(d_img), d_lang=ptr(d_lang),
+                             d_logit_scale=ptr(d_ls), scratch=scratch.data_ptr())
+        _lib.check(lib.mdt_op_infonce(C.byref(a), torch.cuda.current_stream(dev).cuda_stream))
+        ctx.save_for_backward(d_img, d_lang, d_ls)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_img, d_lang, d_ls = ctx.saved_tensors
+        return g * d_img, g * d_lang, g * d_ls, None
 
 
 def clip_auxiliary_loss(image_features: torch.Tensor, lang_features: torch.Tensor, logit_scale: torch.Tensor,
                         mode: str = "symmetric", lang_text=None) -> torch.Tensor:
     """InfoNCE between pooled vision-goal and language-goal contexts (reference mdtv_agent.py:774-799).
     ``logit_scale`` is the agent's log-temperature parameter (``log(1/0.07)`` initially, :140)."""
-    image_features = F.normalize(image_features, dim=-1)
-    lang_features = F.normalize(lang_features, dim=-1)
-    scale = logit_scale.exp()
-    similarity_matrix = scale * image_features @ lang_features.t()
-    labels = torch.arange(similarity_matrix.shape[0], device=image_features.device)
-    if mode == "symmetric":
-        return (F.cross_entropy(similarity_matrix, labels) +
-                F.cross_entropy(scale * lang_features @ image_features.t(), labels)) / 2
-    if mode == "img_to_text":
-        return F.cross_entropy(similarity_matrix, labels)
-    if mode == "text_to_img":
-        return F.cross_entropy(similarity_matrix.t(), labels)
-    raise ValueError("Invalid mode. Expected one of: 'symmetric', 'img_to_text', 'text_to_img'.")
+    if mode not in _lib.INFONCE_MODE:
+        raise ValueError("Invalid mode. Expected one of: 'symmetric', 'img_to_text', 'text_to_img'.")
+    if image_features.device.type != "cuda":
+        raise RuntimeError("clip_auxiliary_loss runs only on a ROCm GPU (hand-written gfx950 kernels): there is no CPU "
+                           "execution path")
+    if image_features.shape != lang_features.shape or image_features.ndim != 2:
+        raise ValueError(f"expected two (batch, dim) tensors, got {tuple(image_features.shape)} and {tuple(lang_features.shape)}")
+    prep = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0) \
+        else t.float().contiguous().clone()
+    ls = logit_scale.to(device=image_features.device, dtype=torch.float32).reshape(())
+    return _InfoNCE.apply(prep(image_features), prep(lang_features), ls, _lib.INFONCE_MODE[mode])
 
 
 class _AllGatherWithGrad(torch.autograd.Function):

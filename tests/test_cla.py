@@ -57,25 +57,33 @@ def _infonce_cases():
         yield c, fx, img, lang
 
 
-@pytest.mark.parametrize("which", ["oracle", "facade"])
-def test_infonce_matches_the_reference_loss_and_gradients(which):
-    from mdt_policy_amd.models.contrastive import clip_auxiliary_loss
-    fn = O.clip_auxiliary_loss if which == "oracle" else clip_auxiliary_loss
+def _check_infonce(fn, device, rtol, tight):
     n = 0
     for c, fx, img, lang in _infonce_cases():
-        img, lang = img.requires_grad_(), lang.requires_grad_()
-        ls = torch.tensor(c["logit_scale"], dtype=torch.float32, requires_grad=True)
+        img, lang = img.to(device).requires_grad_(), lang.to(device).requires_grad_()
+        ls = torch.tensor(c["logit_scale"], dtype=torch.float32, device=device, requires_grad=True)
         loss = fn(img, lang, ls, mode=c["mode"])
-        loss.backward()
+        (3.0 * loss).backward()
         k = c["key"]
-        assert_close(loss.detach().reshape(1), fx[k + "_loss"].reshape(1), rtol=1e-5, atol=1e-6, what=k)
-        assert_close(img.grad, fx[k + "_d_img"], rtol=1e-4, atol=1e-7, what=k + " d_img")
-        assert_close(lang.grad, fx[k + "_d_lang"], rtol=1e-4, atol=1e-7, what=k + " d_lang")
-        assert_close(ls.grad.reshape(1), fx[k + "_d_scale"].reshape(1), rtol=1e-4, atol=1e-6, what=k + " d_scale")
+        assert_close(loss.detach().reshape(1).cpu(), fx[k + "_loss"].reshape(1), rtol=rtol, atol=1e-6 if tight else 1e-4, what=k)
+        for got, name in ((img.grad, "_d_img"), (lang.grad, "_d_lang"), (ls.grad.reshape(1), "_d_scale")):
+            want = 3.0 * fx[k + name].reshape(got.shape)
+            assert_close(got.cpu(), want, rtol=rtol, atol=(1e-7 if tight else 1e-3 * float(np.abs(want).max()) + 1e-7),
+                         what=k + name)
         n += 1
     assert n == 9
     with pytest.raises(ValueError):
         fn(img, lang, ls, mode="both")
+
+
+def test_oracle_infonce_matches_the_reference_loss_and_gradients():
+    _check_infonce(O.clip_auxiliary_loss, "cpu", 1e-4, True)
+
+
+def test_infonce_has_no_cpu_path():
+    from mdt_policy_amd.models.contrastive import clip_auxiliary_loss
+    with pytest.raises(RuntimeError, match="ROCm GPU"):
+        clip_auxiliary_loss(torch.zeros(4, 16), torch.zeros(4, 16), torch.tensor(0.0))
 
 
 def test_facade_state_dict_matches_the_reference_names_and_order():
@@ -98,7 +106,8 @@ def test_map_block_has_no_cpu_path():
 
 def _gather_worker(rank, world, port, q):
     import torch.distributed as dist
-    from mdt_policy_amd.models.contrastive import all_gather_with_grad, clip_auxiliary_loss
+    from mdt_policy_amd.models.contrastive import all_gather_with_grad
+    clip_auxiliary_loss = O.clip_auxiliary_loss  # CPU processes: the loss itself is the oracle's, the gather the facade's
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     B, D = 3, 16
     img = torch.from_numpy(synthetic.normal("img", (world * B, D), 7))[rank * B:(rank + 1) * B].clone().requires_grad_()
@@ -115,7 +124,7 @@ def test_all_gather_with_grad_reproduces_the_global_batch_loss():
     """Two gloo processes, each with half of the batch: the loss equals the single-process loss on the whole batch and
     every rank's gradient is the matching slice of the whole-batch gradient times the number of ranks (each rank
     back-propagates its own copy of the global loss and the gathers sum them -- exactly what DDP then averages)."""
-    from mdt_policy_amd.models.contrastive import clip_auxiliary_loss
+    clip_auxiliary_loss = O.clip_auxiliary_loss
     from tests.test_sharding_gloo import _free_port as free_port
     world, B, D = 2, 3, 16
     ctx = mp.get_context("spawn")
@@ -139,6 +148,35 @@ def test_all_gather_with_grad_reproduces_the_global_batch_loss():
 
 
 # ---------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_hip_infonce_matches_the_reference_loss_and_gradients():
+    from mdt_policy_amd.models.contrastive import clip_auxiliary_loss
+    _check_infonce(clip_auxiliary_loss, "cuda", 1e-3, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,mode", [(1024, 384, "symmetric"), (2048, 384, "symmetric"), (333, 128, "text_to_img"),
+                                      (17, 64, "img_to_text")])
+def test_hip_infonce_large_batches_against_float64(B, D, mode):
+    """The global batch of the reference's training (8 x 128 ... 2048) and ragged sizes, against float64 autograd."""
+    from mdt_policy_amd.models.contrastive import clip_auxiliary_loss
+    img = torch.from_numpy(synthetic.normal("img", (B, D), 21))
+    lang = torch.from_numpy(0.7 * synthetic.normal("img", (B, D), 21) + synthetic.normal("lang", (B, D), 22))
+    i64, l64 = img.double().requires_grad_(), lang.double().requires_grad_()
+    s64 = torch.tensor(float(np.log(1 / 0.07)), dtype=torch.float64, requires_grad=True)
+    ref = O.clip_auxiliary_loss(i64, l64, s64, mode)
+    ref.backward()
+    ig, lg = img.cuda().requires_grad_(), lang.cuda().requires_grad_()
+    sg = torch.tensor(float(np.log(1 / 0.07)), device="cuda", requires_grad=True)
+    loss = clip_auxiliary_loss(ig, lg, sg, mode)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item()) + 1e-6
+    assert abs(sg.grad.item() - s64.grad.item()) <= 1e-3 * abs(s64.grad.item()) + 1e-6
+    assert_close(ig.grad.cpu(), i64.grad, rtol=1e-3, atol=1e-3 * float(i64.grad.abs().max()), what="d_img")
+    assert_close(lg.grad.cpu(), l64.grad, rtol=1e-3, atol=1e-3 * float(l64.grad.abs().max()), what="d_lang")
+    with torch.no_grad():  # value only: no gradient buffers are produced
+        assert abs(clip_auxiliary_loss(ig, lg, sg, mode).item() - loss.item()) <= 1e-6 * abs(loss.item())
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", STYLES)
 def test_hip_projection_matches_reference_and_oracle(name):
