@@ -66,7 +66,7 @@ struct mdt_train_state {
     float *dx, *dxe, *t_d, *t_d2, *t_3d, *t_4d, *d_mod, *d_kvx, *pw, *pb, *narrow, *lin_scratch, *dF, *small;
 };
 
-static const int NARROW_SLICES = 32;
+static const int NARROW_SLICES = 128;  // row slices of the narrow (A x D) weight gradients: 128 x 2 workgroups
 
 // ------------------------------------------------------------------------------------------------
 // setup

@@ -645,7 +645,18 @@ __global__ __launch_bounds__(256) void k_narrow_dw(const float* __restrict__ G, 
 #pragma unroll
     for (int a = 0; a < 16; ++a) acc[a] = 0.f;
     if (d < D) {
-        for (int m = m0; m < m1; ++m) {
+        int m = m0;
+        for (; m + 4 <= m1; m += 4) {  // four rows' loads in flight per trip
+            float yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) yv[u] = Y[(int64_t)(m + u) * ldy + d];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < 16; ++a)
+                    if (a < A) acc[a] = fmaf(G[(int64_t)(m + u) * A + a], yv[u], acc[a]);
+        }
+        for (; m < m1; ++m) {
             const float yv = Y[(int64_t)m * ldy + d];
 #pragma unroll
             for (int a = 0; a < 16; ++a)

@@ -23,7 +23,14 @@
 // fixed order by a column sum -- deterministic, unlike atomics.  Only worth it for deep reductions.
 static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     const int64_t tiles = ((N + 31) / 32) * ((K + 127) / 128);   // 32 x 128 tiles of one product
-    int64_t s = std::max<int64_t>(1, std::min<int64_t>((400 + tiles - 1) / tiles, M / 1024));  // slices >= 1024 deep
+    static int64_t target = -1, min_depth = -1;  // tuning knobs (A/B runs): workgroups aimed for, least slice depth
+    if (target < 0) { const char* e = getenv("MDT_HIP_SPLIT_TARGET"); target = e ? atoll(e) : 1000; }
+    if (min_depth < 0) { const char* e = getenv("MDT_HIP_SPLIT_DEPTH"); min_depth = e ? atoll(e) : 512; }
+    // measured (tools/gpu_splitk_ab.sh, B = 1024 step): aiming for ~1000 workgroups of >= 512-deep slices instead of 400
+    // of >= 1024 is 11 % faster per step (several 4-wave workgroups share a CU); reductions under 4096 rows (B = 128:
+    // 1280 rows) were 2.6 % slower when cut in two, so they keep the 1024-row floor
+    const int64_t depth = M >= 4096 ? min_depth : std::max<int64_t>(min_depth, 1024);
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>((target + tiles - 1) / tiles, M / depth));
     s = std::min<int64_t>(s, 32);
     if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
     int64_t l = ((M + s - 1) / s + 31) / 32 * 32;                // equal slices: at most 31 pad rows each
