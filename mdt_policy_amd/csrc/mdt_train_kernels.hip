@@ -41,10 +41,42 @@ __global__ void k_pack_weight_t(const float* __restrict__ src, int rows, int col
     packed[base + (((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4 + j] = src[(int64_t)r * lds_ + c];
 }
 
+// The same packing with one thread per (4 consecutive source rows, column): the four values are the j = 0..3 floats of
+// one fragment slot, so a wave writes 1 KiB contiguously (the scalar kernel writes 4-byte pieces 16 bytes apart) and
+// reads four coalesced row segments.  Needs k_off % 4 == 0; rows past `rows` inside the last group are written as 0.
+__global__ void k_pack_weight_t4(const float* __restrict__ src, int rows, int cols, int64_t lds_, float* __restrict__ packed,
+                                 int k_off, int K16, int slice_len) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows4 = (rows + 3) >> 2;
+    if (idx >= (int64_t)rows4 * cols) return;
+    const int r4 = (int)(idx / cols), c = (int)(idx % cols);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * r4 + j;
+        v[j] = r < rows ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    int k = k_off + 4 * r4;
+    int64_t base = 0;
+    if (slice_len > 0) {
+        const int sl = k / slice_len;
+        k -= sl * slice_len;
+        base = (int64_t)sl * cols * slice_len;
+    }
+    const int nt = c >> 4, ni = c & 15, kc = k >> 4, h = (k & 15) >> 2;
+    *(f32x4*)(packed + base + (((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4) = v;
+}
+
 hipError_t mdt_launch_pack_weight_t(const float* src, int rows, int cols, int64_t ld, float* packed, int k_off, int K16,
                                     hipStream_t s, int slice_len) {
     const int64_t n = (int64_t)rows * cols;
     if (n == 0) return hipSuccess;
+    if ((k_off & 3) == 0 && (slice_len & 3) == 0) {
+        const int64_t n4 = (int64_t)((rows + 3) >> 2) * cols;
+        hipLaunchKernelGGL(k_pack_weight_t4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, rows, cols, ld, packed,
+                           k_off, K16, slice_len);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_pack_weight_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, ld, packed,
                        k_off, K16, slice_len);
     return hipGetLastError();
@@ -349,8 +381,13 @@ __global__ __launch_bounds__(256) void k_colsum2(const float* __restrict__ X0, c
         out[c] = accumulate ? out[c] + t : t;
     }
 }
+hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s);
 hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
                               int accumulate, hipStream_t s) {
+    if (M >= 512) {  // deep sums: the sliced two-stage reduction, once per operand (63 -> 2 x 9 us at M = 1024, N = 384)
+        hipError_t e = mdt_launch_colsum(X0, ldx, M, N, out0, accumulate, s);
+        return e != hipSuccess ? e : mdt_launch_colsum(X1, ldx, M, N, out1, accumulate, s);
+    }
     hipLaunchKernelGGL(k_colsum2, dim3((N + 63) / 64, 2), dim3(256), 0, s, X0, X1, ldx, M, N, out0, out1, accumulate);
     return hipGetLastError();
 }
@@ -372,7 +409,7 @@ static float* colsum_scratch(hipStream_t s) {
 }
 
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
-    if (M >= 2048 && N <= CS_MAXN) {
+    if (M >= 512 && N <= CS_MAXN) {  // 64 row slices in parallel, then their sum (a single stage runs on N / 64 workgroups)
         float* scratch = colsum_scratch(s);
         if (!scratch) return hipErrorOutOfMemory;
         hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, CS_SLICES), dim3(256), 0, s, X, ldx, M, N, scratch, 0);
