@@ -790,7 +790,9 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     }
     // mid-size row counts (batches of ~20..140 chunks, and the training path's 384..1536-row dW products): half-height
     // tiles double the workgroup count; measured 4-17 % faster per sampler call up to M ~ 1400, slower beyond 2000
-    if (a.M <= g_mdt_mid_max) geo = 6;
+    // ... unless the output is so wide that they would be thousands (the stacked adaLN projection of a training batch:
+    // 1024 x 9216 -> 9216 workgroups that each re-read their weight tile): then the scored choice stands
+    if (a.M <= g_mdt_mid_max && (int64_t)((a.M + 15) / 16) * ((a.N + 63) / 64) <= 4096) geo = 6;
     if (a.batch > 1) {  // split-K partial products (deep reductions): geometry chosen for those, env override for A/B runs
         static int bgeo = -1;
         if (bgeo < 0) { const char* e = getenv("MDT_HIP_BATCH_GEO"); bgeo = e ? atoi(e) : 5; }

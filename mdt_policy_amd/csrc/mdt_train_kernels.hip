@@ -526,19 +526,26 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
         rope_rows<HD>(ks, Tk, a.rope_cos, a.rope_sin, 1.f, lane);
         __syncthreads();
     }
+    // the two HD-deep dot products of every (query, key) pair, one pair per lane (Tq * Tk <= 256 pairs): scores -> P,
+    // dO . V -> dS; the row-wise softmax algebra below then only touches Tk values per query
+    for (int e = lane; e < Tq * Tk; e += 64) {
+        const int i = e / Tk, j = e - i * Tk;
+        float s = 0.f, t = 0.f;
+        for (int d = 0; d < HD; ++d) {
+            s = fmaf(qs[i][d], ks[j][d], s);
+            t = fmaf(os[i][d], vs[j][d], t);
+        }
+        P[i][j] = (!a.causal || j <= i) ? s * scale : -INFINITY;
+        dS[i][j] = t;
+    }
+    __syncthreads();
     if (lane < Tq) {
         const int i = lane;
         float sc[16], dp[16];
         float mx = -INFINITY;
         for (int j = 0; j < Tk; ++j) {
-            float s = 0.f, t = 0.f;
-            for (int d = 0; d < HD; ++d) {
-                s = fmaf(qs[i][d], ks[j][d], s);
-                t = fmaf(os[i][d], vs[j][d], t);
-            }
-            const bool vis = !a.causal || j <= i;
-            sc[j] = vis ? s * scale : -INFINITY;
-            dp[j] = t;
+            sc[j] = P[i][j];
+            dp[j] = dS[i][j];
             mx = fmaxf(mx, sc[j]);
         }
         float sum = 0.f;
