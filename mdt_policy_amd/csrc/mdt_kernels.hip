@@ -788,6 +788,10 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         const float score = fill * eff[g] * used;
         if (score > best) { best = score; geo = g; }
     }
+    // deep K in several LDS chunks (mlp.c_proj and its kin, K = 4d) at large row counts: co-resident 4-wave 32 x 128
+    // workgroups beat the 8-wave loader-wave kernel (tools/gemm_micro.py, N = 384, K = 1536: M = 10240 116 vs 131 us,
+    // M = 5120 60 vs 66 us; at M = 2560 the loader-wave kernel still wins, 37.7 vs 42.5 us)
+    if (geo == 2 && !a.ln && a.K > 512 && a.M >= 4096) geo = 5;
     // mid-size row counts (batches of ~20..140 chunks, and the training path's 384..1536-row dW products): half-height
     // tiles double the workgroup count; measured 4-17 % faster per sampler call up to M ~ 1400, slower beyond 2000
     // ... unless the output is so wide that they would be thousands (the stacked adaLN projection of a training batch:

@@ -30,6 +30,9 @@ shapes = {
  "proj2 gated-res N=384 K=1536": args(hid, 4 * D, packed(D, 4 * D), y, D, D, 4 * D, residual=1, mod=mod.data_ptr(), gate_off=5 * D),
 }
 geos = [int(x) for x in os.environ.get("GEOS", "0").split(",")]
+for a in shapes.values():  # clocks / first-use effects settle before the first timed geometry
+    for _ in range(20): _lib.check(lib.mdt_op_gemm(C.byref(a), s))
+torch.cuda.synchronize()
 for geo in geos:
   lib.mdt_op_set_gemm_geometry(geo)
   print(f"--- geometry {geo}")
