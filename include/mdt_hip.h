@@ -70,7 +70,8 @@ typedef struct {
                                         (mdtv_transformer.py:296-297, transformer_blocks.py:460-506)  */
     int32_t use_noise_encoder;    /* with use_ada_conditioning: NoiseBlock (ln(x)+c) instead of
                                      ConditionedBlock (transformer_blocks.py:312-341, :533-544)      */
-    int32_t linear_output;        /* must be 1                                                      */
+    int32_t linear_output;        /* 1: action_pred = Linear(d, A); 0: Linear(d, h) -> GELU -> Linear(h, A), h = 100
+                                   * (MDTV, mdtv_transformer.py:178-185) / h = d (MDT, mdt_transformer.py:170-177) */
     int32_t bias;                 /* reference 'bias' flag: biases on c_proj / MLP / LayerNorms     */
     float   sigma_data;           /* GCDenoiser.sigma_data                                          */
 } mdt_config;

@@ -107,6 +107,8 @@ typedef struct {
     /* optional fused embedding of the NEXT step's input: y_next = (out * c_in(sigma_next)) Wa^T + ba */
     float *y_next;             /* NULL or (M, D) (may alias y)                                        */
     const float *Wa, *ba;      /* action_emb.weight TRANSPOSED to (A, D) row-major, bias (D)          */
+    int32_t no_ln;             /* 1: y is used as it is (the MLP head's hidden layer), ln_w / ln_b only have to be
+                                * readable for D floats                                                */
 } mdt_head_args;
 
 mdt_status mdt_op_head(const mdt_head_args *args, void *stream);

@@ -64,7 +64,7 @@ class HeadArgs(C.Structure):
         ("x", C.c_void_p), ("sigma", C.c_void_p), ("sigma_stride", C.c_int64), ("out", C.c_void_p),
         ("M", C.c_int32), ("D", C.c_int32), ("A", C.c_int32), ("rows_per_sample", C.c_int32), ("mode", C.c_int32),
         ("step", C.c_void_p), ("sigma_data", C.c_float), ("y_next", C.c_void_p), ("Wa", C.c_void_p),
-        ("ba", C.c_void_p)]
+        ("ba", C.c_void_p), ("no_ln", C.c_int32)]
 
 
 class LnTrainArgs(C.Structure):

@@ -119,6 +119,8 @@ hipError_t mdt_launch_gather_rows(const float* src, float* dst, int M, int D, in
 hipError_t mdt_launch_dropout_rows(float* x, int64_t rows, int D, int rows_per_sample, int row_lo, float p, uint32_t site,
                                    uint64_t seed, hipStream_t s);
 hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream_t s);
+// dst[r][c] += src[r][c] for r < rows, c < cols (leading dimensions lds_ / ldd)
+hipError_t mdt_launch_add_2d(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int cols, hipStream_t s);
 // backward of a Linear through the forward GEMM kernel (mdt_train.hip); see mdt_linear_bwd_args
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s);
 hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,

@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __re
     wave_sum_n<RW>(red);
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        const float mean = red[r] * inv_d;
+        const float mean = a.no_ln ? 0.f : red[r] * inv_d;
         red[r] = 0.f;
 #pragma unroll
         for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p] - mean, zero4); red[r] += hsq4(v[r][p]); }
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __re
     for (int r = 0; r < RW; ++r) {
         const float rstd = 1.0f / sqrtf(red[r] * inv_d + 1e-5f);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) v[r][p] = sel4(cv[p], v[r][p] * rstd * w[p] + bb[p], zero4);
+        for (int p = 0; p < 2; ++p) v[r][p] = sel4(cv[p] && !a.no_ln, v[r][p] * rstd * w[p] + bb[p], v[r][p]);
     }
     // ---- action_pred: RW * AMAX dot products reduced together ----
     float res[RW * AMAX];

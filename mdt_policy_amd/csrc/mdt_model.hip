@@ -205,8 +205,18 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
     m->Wa = b.take((size_t)D * A);  // stored transposed (A, D): lanes read 16 contiguous bytes per action component
     add_slot(P + "action_emb.weight", (int64_t)D * A, SLOT_TRANSPOSE, m->Wa, D, A, 0);
     raw(m->ba, P + "action_emb.bias", D);
-    raw(m->Wp, P + "action_pred.weight", (int64_t)A * D);
-    raw(m->bp, P + "action_pred.bias", A);
+    if (c.linear_output) {
+        raw(m->Wp, P + "action_pred.weight", (int64_t)A * D);
+        raw(m->bp, P + "action_pred.bias", A);
+    } else {  // nn.Sequential(Linear(d, 100), GELU(), Linear(100, A))   (mdtv_transformer.py:181-185)
+        m->HH = c.arch == MDT_ARCH_MDTV ? 100 : D;
+        m->HP = (m->HH + 15) / 16 * 16;
+        lin_begin(m->head0, m->HP, D, true);          // rows HH..HP-1 of the image and of the bias stay zero
+        lin_part(m->head0, P + "action_pred.0", m->HH, 0, true);
+        m->Wp = b.take((size_t)A * m->HP);             // (A, HP): columns HH.. stay zero
+        add_slot(P + "action_pred.2.weight", (int64_t)A * m->HH, SLOT_PAD_COLS, m->Wp, A, m->HH, m->HP);
+        raw(m->bp, P + "action_pred.2.bias", A);
+    }
     // constant tables
     m->freqs = b.take(D / 2);
     m->rope_cos = b.take(16 * 16);
@@ -229,7 +239,6 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     if (!cfg || !out) return fail(MDT_ERR_INVALID_ARG, "mdt_create: null argument");
     const mdt_config& c = *cfg;
     if (c.arch != MDT_ARCH_MDTV && c.arch != MDT_ARCH_MDT) return fail(MDT_ERR_INVALID_ARG, "unknown arch %d", c.arch);
-    if (!c.linear_output) return fail(MDT_ERR_UNSUPPORTED, "linear_output=False (MLP action head) is not implemented");
     if (c.goal_seq_len != 1) return fail(MDT_ERR_UNSUPPORTED, "goal_seq_len must be 1");
     if (c.embed_dim <= 0 || c.embed_dim % 16 || c.embed_dim > 512)
         return fail(MDT_ERR_UNSUPPORTED, "embed_dim %d: need a multiple of 16, <= 512", c.embed_dim);
@@ -362,6 +371,11 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
     for (Slot* t : targets) {
         if (t->kind == SLOT_RAW) {
             HIP_TRY(hipMemcpyAsync(t->dst, src, numel * sizeof(float), hipMemcpyDefault, s));
+            continue;
+        }
+        if (t->kind == SLOT_PAD_COLS) {  // (rows, K) -> (rows, n_off): the pad columns keep the arena's zeros
+            HIP_TRY(hipMemcpy2DAsync(t->dst, (size_t)t->n_off * sizeof(float), src, (size_t)t->K * sizeof(float),
+                                     (size_t)t->K * sizeof(float), (size_t)t->rows, hipMemcpyDefault, s));
             continue;
         }
         if (dev_src == nullptr) {
@@ -676,6 +690,31 @@ static mdt_head_args head_args(mdt_model* m, const float* y, int64_t B, const fl
     return h;
 }
 
+// The action head on the rows of `h.y`.  Linear head: ONE launch (decoder LN, action_pred, EDM combine, DDIM update,
+// next step's embedding).  MLP head (linear_output = 0): decoder LN -> action_pred.0 + GELU on the GEMM ->
+// action_pred.2 and the rest in the head kernel reading the hidden layer as it is; `scratch` holds M * (D + HP)
+// floats (the slice's MLP hidden buffer is free at this point); the next step's embedding is its own launch then.
+static mdt_status run_head(mdt_model* m, mdt_head_args h, float* scratch, const float* sigma_next, hipStream_t s) {
+    if (m->HP == 0) {
+        LAUNCH(mdt_launch_head(h, s));
+        return MDT_OK;
+    }
+    const int D = m->D, HP = m->HP;
+    float* ln = scratch;
+    float* hh = scratch + (int64_t)h.M * D;
+    LAUNCH(mdt_launch_layernorm(h.y, m->dec_ln_w, m->dec_ln_b, ln, h.M, D, s));
+    mdt_gemm_args g = gemm_args(ln, D, m->head0, hh, HP, h.M);
+    g.act = MDT_ACT_GELU;
+    LAUNCH(mdt_launch_gemm(g, s));
+    float* y_next = h.y_next;
+    h.y = hh; h.D = HP; h.no_ln = 1; h.y_next = nullptr;
+    LAUNCH(mdt_launch_head(h, s));
+    if (y_next)
+        LAUNCH(mdt_launch_action_embed(h.out, sigma_next, 0, m->cfg.sigma_data, m->Wa, m->ba, y_next, h.M, m->A, D,
+                                       m->Ta, s));
+    return MDT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI: model level
 // ------------------------------------------------------------------------------------------------
@@ -701,8 +740,7 @@ extern "C" mdt_status mdt_denoise_cached(mdt_model* m, const float* x, const flo
                                    m->y, (int)(batch * m->Ta), m->A, m->D, m->Ta, s));
     MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, cond_row(m, 0), scalar ? 0 : modw, s));
     mdt_head_args h = head_args(m, m->y, batch, x, sigma, sst, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
-    LAUNCH(mdt_launch_head(h, s));
-    return MDT_OK;
+    return run_head(m, h, m->hid, nullptr, s);
 }
 
 extern "C" mdt_status mdt_forward(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
@@ -778,7 +816,7 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
             mdt_head_args h = head_args(m, V.y, nb, xin, m->steps + 4 * i + 3, 0, xout, MDT_HEAD_DDIM);
             h.step = m->steps + 4 * i;
             if (!last) { h.y_next = V.y; h.Wa = m->Wa; h.ba = m->ba; }
-            LAUNCH(mdt_launch_head(h, st[w]));
+            MDT_TRY(run_head(m, h, V.hid, m->steps + 4 * (i + 1) + 3, st[w]));
         }
     }
     for (int w = 1; w < ways; ++w) {
@@ -816,7 +854,8 @@ extern "C" double mdt_flops_per_chunk(const mdt_model* m, int32_t n_steps) {
     double sig = 2.0 * (D * 2 * D + 2 * D * D);
     double blk = (m->cond == COND_ADALN ? 2.0 * D * 6 * D : 0.0) + Ta * 2.0 * (4 * D * D) + Ta * 2.0 * (2 * D * D) +
                  Ta * 2.0 * 8 * D * D + attn(Ta, Ta) + attn(Ta, Te);
-    double step = sig + 2.0 * Ta * A * D * 2 + m->Ld * blk;
+    const double head = m->HP ? 2.0 * Ta * ((double)D * m->HH + (double)m->HH * A) : 2.0 * Ta * A * D;
+    double step = sig + 2.0 * Ta * A * D + head + m->Ld * blk;
     if (m->cond == COND_TOKEN) return n_steps * (enc + kv + step);  // the sigma token re-runs the encoder every step
     return enc + kv + n_steps * step;
 }

@@ -9,7 +9,8 @@
 // ------------------------------------------------------------------------------------------------
 // model description
 // ------------------------------------------------------------------------------------------------
-enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2 };  // TRANSPOSE: (rows, K) -> (K, rows)
+// TRANSPOSE: (rows, K) -> (K, rows);  PAD_COLS: (rows, K) -> (rows, n_off) row-major, columns K.. stay zero
+enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2, SLOT_PAD_COLS = 3 };
 
 struct Slot {
     std::string name;
@@ -62,6 +63,11 @@ struct mdt_model {
     std::vector<LinPart> parts;
     mdt_train_state* train = nullptr;  // non-null after mdt_train_prepare()
     Lin tok, incam, goal0, goal2, lang0, lang2, sig1, sig3, kv_all, mod_all;
+    // MLP action head (linear_output = 0): action_pred.0 = Linear(d, HH) padded to HP = ceil16(HH) rows, action_pred.2
+    // = Linear(HH, A) held as (A, HP) with zero pad columns.  HH = 100 in MDTVTransformer (mdtv_transformer.py:182),
+    // embed_dim in MDTTransformer (mdt_transformer.py:174).  HP = 0 with the plain Linear head.
+    Lin head0;
+    int HH = 0, HP = 0;
     std::vector<EncBlock> enc;
     std::vector<DecBlock> dec;
     float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;

@@ -51,6 +51,7 @@ struct Tape {
     float *xin, *y0;
     std::vector<BlockTape> dec;
     float *st_h, *lnout, *F;
+    float *hpre, *hh;  // MLP action head: hidden layer before / after GELU, (rows, HP)
 };
 
 }  // namespace
@@ -166,6 +167,7 @@ static void carve_tape(const mdt_model* m, Bump& b, Tape& t, int64_t B) {
     t.dec.resize(m->Ld);
     for (int l = 0; l < m->Ld; ++l) carve_block(m, b, t.dec[l], Ma, true);
     t.st_h = b.take(Ma * 2); t.lnout = b.take(Ma * D); t.F = b.take(Ma * m->A);
+    t.hpre = b.take(Ma * m->HP); t.hh = b.take(Ma * m->HP);
 }
 
 static mdt_status acquire_tape(mdt_model* m, int64_t B, mdt_tape_id* id) {
@@ -221,7 +223,7 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
     ts->t_d = b.take(Mx * D); ts->t_d2 = b.take(Mx * D); ts->t_3d = b.take(Mx * 3 * D); ts->t_4d = b.take(Mx * 4 * D);
     ts->d_mod = b.take(B * m->Ld * 6 * D); ts->d_kvx = b.take(Me * m->Ld * 2 * D);
     ts->pw = b.take(B * D); ts->pb = b.take(B * D);
-    ts->narrow = b.take((size_t)NARROW_SLICES * 16 * D);
+    ts->narrow = b.take((size_t)NARROW_SLICES * 16 * std::max(D, m->HP));
     // Linear backward scratch: the largest need over every (rows, N, K) this model's backward runs
     int64_t need = 0;
     for (int64_t rows : {Ma, Me}) {
@@ -233,9 +235,10 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
                     std::pair<int, int>(2 * D, m->G), std::pair<int, int>(D, m->G), std::pair<int, int>(D, m->O)})
         need = std::max(need, mdt_linear_bwd_scratch(B, nk.first, nk.second));
     need = std::max(need, mdt_linear_bwd_scratch(B * m->n_tok, D, m->O));
+    if (m->HP) need = std::max(need, mdt_linear_bwd_scratch(Ma, m->HP, D));
     ts->lin_scratch = b.take(need);
     ts->dF = b.take(Ma * m->A);
-    ts->small = b.take(std::max<int64_t>(B * 2 * D, Mx * (int64_t)std::max(m->O, m->G)));
+    ts->small = b.take(std::max<int64_t>({B * 2 * D, Mx * (int64_t)std::max(m->O, m->G), (int64_t)16 * m->HP}));
 }
 
 static mdt_status reserve_scratch(mdt_model* m, int64_t B) {
@@ -463,6 +466,11 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     h.y = xl; h.ln_w = m->dec_ln_w; h.ln_b = m->dec_ln_b; h.Wp = m->Wp; h.bp = m->bp;
     h.x = t.noised; h.sigma = t.sigma; h.sigma_stride = 1; h.out = t.F;
     h.M = (int)Ma; h.D = D; h.A = A; h.rows_per_sample = Ta; h.mode = MDT_HEAD_RAW; h.sigma_data = m->cfg.sigma_data;
+    if (m->HP) {  // MLP head: action_pred.0 on the normalised rows, GELU, action_pred.2 in the head kernel
+        LAUNCH(mdt_launch_gemm(gemm_args(t.lnout, D, m->head0, t.hpre, m->HP, (int)Ma), s));
+        LAUNCH(mdt_launch_act_fwd(t.hpre, t.hh, Ma * m->HP, MDT_ACT_GELU, s));
+        h.y = t.hh; h.D = m->HP; h.no_ln = 1;
+    }
     LAUNCH(mdt_launch_head(h, s));
     if (model_output) HIP_TRY(hipMemcpyAsync(model_output, t.F, (size_t)Ma * A * sizeof(float), hipMemcpyDeviceToDevice, s));
     LAUNCH(mdt_launch_loss_reduce(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, loss_out, s));
@@ -729,9 +737,21 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     // ---- loss and action head: F = action_pred(ln(x_L))
     LAUNCH(mdt_launch_loss_grad(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, Ta * A, g_loss, ts->dF, s));
     LAUNCH(mdt_launch_colsum(ts->dF, A, (int)Ma, A, grad_of(m, grads, m->bp), 1, s));
-    LAUNCH(mdt_launch_narrow_dw(ts->dF, t.lnout, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 0, s));
-    LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wp), 1, s));
-    LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_d, (int)Ma, A, D, s));
+    if (m->HP) {
+        // F = action_pred.2(gelu(action_pred.0(ln))): the narrow layer on the (rows, HP) hidden rows, whose gradient
+        // lands padded (A, HP) and is added into the (A, HH) slot; then GELU and the d x HP Linear on the GEMM
+        const int HP = m->HP;
+        LAUNCH(mdt_launch_narrow_dw(ts->dF, t.hh, HP, ts->narrow, NARROW_SLICES, (int)Ma, A, HP, 0, s));
+        LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * HP, NARROW_SLICES, A * HP, ts->small, 0, s));
+        LAUNCH(mdt_launch_add_2d(ts->small, HP, grad_of(m, grads, m->Wp), m->HH, A, m->HH, s));
+        LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_4d, (int)Ma, A, HP, s));
+        LAUNCH(mdt_launch_act_bwd(t.hpre, ts->t_4d, ts->t_4d, Ma * HP, MDT_ACT_GELU, s));
+        MDT_TRY(lin_bwd(m, grads, m->head0, t.lnout, D, ts->t_4d, HP, (int)Ma, ts->t_d, D, 0, s));
+    } else {
+        LAUNCH(mdt_launch_narrow_dw(ts->dF, t.lnout, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 0, s));
+        LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wp), 1, s));
+        LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_d, (int)Ma, A, D, s));
+    }
     MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
                    B, Ta, s));
     // ---- decoder blocks

@@ -775,6 +775,16 @@ __global__ void k_axpy1(const float* __restrict__ x, float* __restrict__ y, int6
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += x[i];
 }
+__global__ void k_add_2d(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int rows, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int r = i / cols, c = i - r * cols;
+    dst[(int64_t)r * ldd + c] += src[(int64_t)r * lds_ + c];
+}
+hipError_t mdt_launch_add_2d(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_2d, dim3((rows * cols + 255) / 256), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols);
+    return hipGetLastError();
+}
 hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_axpy1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
     return hipGetLastError();

@@ -68,8 +68,7 @@ class MDTVTransformer(HipScoreNetwork):
         self._init_common()
         if not goal_conditioned:
             raise NotImplementedError("goal_conditioned=False is not implemented by the HIP path")
-        if not linear_output:
-            raise NotImplementedError("linear_output=False is not implemented by the HIP path")
+        self.linear_output = bool(linear_output)
         self.device = device
         self.goal_conditioned = goal_conditioned
         self.obs_dim, self.goal_dim, self.embed_dim = obs_dim, goal_dim, embed_dim
@@ -118,7 +117,10 @@ class MDTVTransformer(HipScoreNetwork):
         self.sigma_emb = nn.Sequential(_SinusoidalSlot(), nn.Linear(embed_dim, embed_dim * 2), nn.Mish(),
                                        nn.Linear(embed_dim * 2, embed_dim))
         self.action_emb = nn.Linear(action_dim, embed_dim)
-        self.action_pred = nn.Linear(embed_dim, action_dim)
+        if linear_output:
+            self.action_pred = nn.Linear(embed_dim, action_dim)
+        else:  # reference mdtv_transformer.py:181-185 (parameter holder: the arithmetic runs in the HIP head)
+            self.action_pred = nn.Sequential(nn.Linear(embed_dim, 100), nn.GELU(), nn.Linear(100, action_dim))
         self.apply(self._init_weights)
 
     def _init_weights(self, module):
@@ -141,4 +143,4 @@ class MDTVTransformer(HipScoreNetwork):
             use_mlp_goal=int(self.use_mlp_goal), use_modality_encoder=int(self.use_modality_encoder),
             use_abs_pos_emb=int(self.use_abs_pos_emb), use_rot_embed=int(self.use_rot_embed),
             use_ada_conditioning=int(self.use_ada_conditioning), use_noise_encoder=int(self.use_noise_encoder),
-            linear_output=1, bias=int(self.bias_flag), sigma_data=float(sigma_data))
+            linear_output=int(self.linear_output), bias=int(self.bias_flag), sigma_data=float(sigma_data))

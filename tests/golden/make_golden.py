@@ -224,6 +224,7 @@ G11_CASES = {
     "mdtv_noise_block": ("mdtv", "mdtv_tiny", dict(use_noise_encoder=True), 5),
     "mdtv_no_ada": ("mdtv", "mdtv_tiny", dict(use_ada_conditioning=False), 5),
     "mdt_no_ada": ("mdt", "mdt_tiny", dict(use_ada_conditioning=False, bias=True), 4),
+    "mdtv_mlp_head": ("mdtv", "mdtv_tiny", dict(linear_output=False), 5),
 }
 
 
@@ -388,6 +389,9 @@ G8_VARIANTS = {
     "no_ada": ("mdtv", dict(use_ada_conditioning=False)),
     "noise_block": ("mdtv", dict(use_noise_encoder=True)),
     "mdt_no_ada": ("mdt", dict(use_ada_conditioning=False)),
+    # the MLP action head (linear_output=False: Linear(d, 100) -> GELU -> Linear(100, A))
+    "mlp_head": ("mdtv", dict(linear_output=False)),
+    "mdt_mlp_head": ("mdt", dict(linear_output=False, bias=True)),
 }
 
 

@@ -59,7 +59,7 @@ def test_create_rejects_unsupported_configurations_before_touching_the_device():
                 goal_dim=512, n_obs_token=3, goal_seq_len=1, action_seq_len=10, use_mlp_goal=1,
                 use_modality_encoder=1, use_abs_pos_emb=1, use_rot_embed=0, use_ada_conditioning=1,
                 use_noise_encoder=0, linear_output=1, bias=0, sigma_data=0.5)
-    for bad, status in ((dict(linear_output=0), 2), (dict(use_ada_conditioning=0, n_obs_token=15), 2), (dict(embed_dim=100), 2),
+    for bad, status in ((dict(use_ada_conditioning=0, n_obs_token=15), 2), (dict(embed_dim=100), 2),
                         (dict(use_rot_embed=1), 1), (dict(arch=5), 1), (dict(sigma_data=0.0), 1),
                         (dict(goal_dim=256), 2), (dict(action_seq_len=17), 2)):
         cfg = _lib.MDTConfig(**dict(base, **bad))
@@ -82,7 +82,7 @@ def test_facade_state_dict_names_shapes_and_order_match_the_reference(key, cfg):
 
 
 @pytest.mark.parametrize("name", ["bias", "plain_goal", "two_tokens", "mdt_bias_nopos", "no_ada", "noise_block",
-                                  "mdt_no_ada"])
+                                  "mdt_no_ada", "mlp_head", "mdt_mlp_head"])
 def test_facade_state_dict_of_the_constructor_variants(name):
     """bias / goal embedder / token-count variants and the two other decoder conditionings (plain TransformerDecoder
     without adaLN_zero for use_ada_conditioning=False, NoiseBlock for use_noise_encoder=True)."""
@@ -112,7 +112,7 @@ def test_facade_refuses_cpu_execution():
     with pytest.raises(NotImplementedError, match="autograd"):
         m(state, torch.zeros(1, 10, 7), torch.zeros(1, 1, 512), torch.ones(1))
     with pytest.raises(NotImplementedError):
-        GCDenoiser(configs.mdtv_tiny(linear_output=False), 0.5)
+        GCDenoiser(configs.mdtv_tiny(goal_conditioned=False), 0.5)
     with pytest.raises(TypeError):
         GCDenoiser(torch.nn.Linear(2, 2), 0.5)
 

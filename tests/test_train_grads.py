@@ -10,7 +10,7 @@ from oracle import mdt_oracle as O
 from tests.helpers import assert_close, cfg_of, inputs_of, load_fixture, params_of
 
 CASES = ["mdtv_tiny", "mdt_tiny", "mdtv_bias_plain_goal", "mdtv_default", "mdtv_rope", "mdt_rope", "mdtv_noise_block",
-         "mdtv_no_ada", "mdt_no_ada"]
+         "mdtv_no_ada", "mdt_no_ada", "mdtv_mlp_head"]
 
 
 def case(name):
