@@ -245,3 +245,17 @@ def test_dpm_solver_adaptive_converges_to_the_ode_solution():
     assert res[(3, 0.005)][1] > res[(3, 0.05)][1], res                           # accuracy is paid in evaluations
     with pytest.raises(ValueError):
         gs.sample_dpm_adaptive(m2, st, x0, goal[:2], 0.0, 80.0)
+
+
+def test_headers_are_plain_c():
+    """include/*.h is the boundary another host language binds: every header must compile as C11 on its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    for hdr in sorted(os.listdir(inc)):
+        r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", "-I", inc,
+                            os.path.join(inc, hdr)], capture_output=True, text=True)
+        assert r.returncode == 0, f"{hdr}: {r.stderr}"
