@@ -74,6 +74,9 @@ typedef struct {
                                    * (MDTV, mdtv_transformer.py:178-185) / h = d (MDT, mdt_transformer.py:170-177) */
     int32_t bias;                 /* reference 'bias' flag: biases on c_proj / MLP / LayerNorms     */
     float   sigma_data;           /* GCDenoiser.sigma_data                                          */
+    int32_t no_goal_conditioning; /* 1: constructor kwarg goal_conditioned=False.  MDTV: the goal token FOLLOWS the
+                                     state tokens (mdtv_transformer.py:284-299); MDT: no goal token at all, which
+                                     the reference can only run with use_ada_conditioning=0 (mdt_transformer.py:326-334) */
 } mdt_config;
 
 /* Human-readable message of the last failing call on this thread ("" if none). */

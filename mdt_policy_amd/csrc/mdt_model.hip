@@ -261,13 +261,20 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     const int cond = !c.use_ada_conditioning ? COND_TOKEN : (c.use_noise_encoder ? COND_NOISE : COND_ADALN);
     const int sig_tok = cond == COND_TOKEN ? 1 : 0;
     if (n_tok < 1 || sig_tok + 1 + n_tok > 16) return fail(MDT_ERR_UNSUPPORTED, "context length must be <= 16 tokens");
+    const bool gc = c.no_goal_conditioning == 0;
+    if (!gc && c.arch == MDT_ARCH_MDT && c.use_ada_conditioning)
+        return fail(MDT_ERR_UNSUPPORTED, "MDTTransformer with goal_conditioned=False needs use_ada_conditioning=False "
+                                         "(the reference concatenates the absent sigma token, mdt_transformer.py:334)");
+    const int has_goal = (gc || c.arch == MDT_ARCH_MDTV) ? 1 : 0;
     if (c.n_enc_layers < 0 || c.n_dec_layers < 1) return fail(MDT_ERR_INVALID_ARG, "bad layer counts");
     if (!(c.sigma_data > 0.f)) return fail(MDT_ERR_INVALID_ARG, "sigma_data must be > 0");
 
     mdt_model* m = new mdt_model();
     m->cfg = c;
     m->cond = cond; m->sig_tok = sig_tok;
-    m->D = c.embed_dim; m->H = c.n_heads; m->hd = hd; m->n_tok = n_tok; m->Te = sig_tok + 1 + n_tok; m->Ta = c.action_seq_len;
+    m->D = c.embed_dim; m->H = c.n_heads; m->hd = hd; m->n_tok = n_tok; m->Te = sig_tok + has_goal + n_tok; m->Ta = c.action_seq_len;
+    m->g_row = !has_goal ? -1 : (gc ? sig_tok : sig_tok + n_tok);
+    m->tok_row = gc ? sig_tok + 1 : sig_tok;
     m->A = c.action_dim; m->Le = c.n_enc_layers; m->Ld = c.n_dec_layers; m->G = c.goal_dim; m->O = c.obs_dim;
 
     Bump count;
@@ -550,8 +557,8 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     const float* pos1 = pos0 ? m->pos_emb + (int64_t)c.goal_seq_len * D : nullptr;
     // sigma token -> row 0 of every sample's context           (concatenate_inputs, mdtv_transformer.py:296-297)
     if (t0) MDT_TRY(run_sigma_mlp(m, sigma, sstride, (int)B, m->h_enc, D, Te, MDT_ACT_NONE, s));
-    // goal token -> next row                                    (process_goal_embeddings, mdtv_transformer.py:268)
-    {
+    // goal token -> its row                                     (process_goal_embeddings, mdtv_transformer.py:268)
+    if (m->g_row >= 0) {
         const float* gin = goal;
         int64_t ld = m->G;
         if (c.use_mlp_goal) {
@@ -561,20 +568,20 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
             gin = m->hid; ld = 2 * D;
         }
         mdt_gemm_args a = gemm_args(gin, ld, g2, m->h_enc, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = t0; a.rowvec = pos0;
+        a.gin = 1; a.gout = Te; a.goff = m->g_row; a.rowvec = pos0;
         LAUNCH(mdt_launch_gemm(a, s));
     }
     // state tokens -> the rows after it                         (process_state_embeddings, :260 / mdt :300)
     if (c.arch == MDT_ARCH_MDTV) {
         mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)(B * m->n_tok));
-        a.gin = m->n_tok; a.gout = Te; a.goff = t0 + 1;
+        a.gin = m->n_tok; a.gout = Te; a.goff = m->tok_row;
         LAUNCH(mdt_launch_gemm(a, s));
     } else {
         mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = t0 + 1; a.rowvec = pos1;
+        a.gin = 1; a.gout = Te; a.goff = m->tok_row; a.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(a, s));
         mdt_gemm_args b2 = gemm_args(tokens2, m->O, m->incam, m->h_enc, D, (int)B);
-        b2.gin = 1; b2.gout = Te; b2.goff = t0 + 2; b2.rowvec = pos1;
+        b2.gin = 1; b2.gout = Te; b2.goff = m->tok_row + 1; b2.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(b2, s));
     }
     for (int l = 0; l < m->Le; ++l) {
@@ -847,8 +854,8 @@ extern "C" double mdt_flops_per_chunk(const mdt_model* m, int32_t n_steps) {
     if (!m) return 0.0;
     const double D = m->D, Te = m->Te, Ta = m->Ta, A = m->A, G = m->G, O = m->O;
     auto attn = [&](double Tq, double Tk) { return 2.0 * (2.0 * Tq * Tk * D); };
-    double goal = m->cfg.use_mlp_goal ? 2.0 * (G * 2 * D + 2 * D * D) : 2.0 * G * D;
-    double enc = goal + 2.0 * (Te - 1) * O * D +
+    double goal = m->g_row < 0 ? 0.0 : (m->cfg.use_mlp_goal ? 2.0 * (G * 2 * D + 2 * D * D) : 2.0 * G * D);
+    double enc = goal + 2.0 * m->n_tok * O * D +
                  m->Le * (Te * 2.0 * (4 * D * D + 8 * D * D) + attn(Te, Te));
     double kv = m->Ld * Te * 2.0 * 2 * D * D;
     double sig = 2.0 * (D * 2 * D + 2 * D * D);

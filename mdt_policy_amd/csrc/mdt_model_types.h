@@ -55,6 +55,9 @@ struct mdt_model {
     int D, H, hd, Te, Ta, A, Le, Ld, G, O, n_tok;
     int cond = COND_ADALN;
     int sig_tok = 0;  // 1 when the context starts with the sigma token (COND_TOKEN): Te = sig_tok + 1 + n_tok
+    // context rows: [sigma token] [goal] state tokens  (goal_conditioned, the default);
+    // goal_conditioned=False: MDTV [sigma] state tokens, goal ; MDT [sigma] state tokens (g_row = -1: no goal token)
+    int g_row = 0, tok_row = 1;
     // parameters
     float* arena = nullptr;
     size_t arena_floats = 0;

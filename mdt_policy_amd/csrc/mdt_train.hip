@@ -369,6 +369,12 @@ static mdt_status sigma_fwd(mdt_model* m, Tape& t, const float* sigma, float* ou
     return MDT_OK;
 }
 
+// first context row the embedding dropout applies to (rows below it are kept), or -1: no dropout on the context
+static int embed_drop_from(const mdt_model* m) {
+    if (m->cfg.arch == MDT_ARCH_MDT) return m->sig_tok;
+    return m->cfg.no_goal_conditioning ? m->g_row : -1;
+}
+
 static float* enc_first_input(const mdt_model* m, Tape& t) { return m->Le > 0 ? t.enc[0].x_in : t.x_enc_out; }
 static float* enc_last_output(const mdt_model* m, Tape& t) { return m->Le > 0 ? t.enc[m->Le - 1].x3 : t.x_enc_out; }
 
@@ -392,7 +398,7 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
     const float* pos1 = pos0 ? m->pos_emb + (int64_t)c.goal_seq_len * D : nullptr;
     float* x0 = enc_first_input(m, t);
     if (t0) MDT_TRY(sigma_fwd(m, t, sigma, x0, Te, s));  // concatenate_inputs (mdtv_transformer.py:296-297)
-    {
+    if (m->g_row >= 0) {
         const float* gin = t.goal;
         int64_t ld = m->G;
         if (c.use_mlp_goal) {
@@ -401,23 +407,26 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
             gin = t.g_h; ld = 2 * D;
         }
         mdt_gemm_args a = gemm_args(gin, ld, g2, x0, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = t0; a.rowvec = pos0;
+        a.gin = 1; a.gout = Te; a.goff = m->g_row; a.rowvec = pos0;
         LAUNCH(mdt_launch_gemm(a, s));
     }
     if (c.arch == MDT_ARCH_MDTV) {
         mdt_gemm_args a = gemm_args(t.tokens, m->O, m->tok, x0, D, (int)(B * m->n_tok));
-        a.gin = m->n_tok; a.gout = Te; a.goff = t0 + 1;
+        a.gin = m->n_tok; a.gout = Te; a.goff = m->tok_row;
         LAUNCH(mdt_launch_gemm(a, s));
     } else {
         mdt_gemm_args a = gemm_args(t.tokens, m->O, m->tok, x0, D, (int)B);
-        a.gin = 1; a.gout = Te; a.goff = t0 + 1; a.rowvec = pos1;
+        a.gin = 1; a.gout = Te; a.goff = m->tok_row; a.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(a, s));
         mdt_gemm_args b2 = gemm_args(t.tokens2, m->O, m->incam, x0, D, (int)B);
-        b2.gin = 1; b2.gout = Te; b2.goff = t0 + 2; b2.rowvec = pos1;
+        b2.gin = 1; b2.gout = Te; b2.goff = m->tok_row + 1; b2.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(b2, s));
     }
-    if (c.arch == MDT_ARCH_MDT)  // MDTTransformer drops the embedded goal / state tokens (mdt_transformer.py:220-227)
-        LAUNCH(mdt_launch_dropout_rows(x0, B * Te, D, Te, t0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_CTX),
+    // embedding dropout (self.drop): MDTTransformer drops every embedded goal / state token (mdt_transformer.py:220-227),
+    // MDTVTransformer only the goal token it appends when goal_conditioned=False (mdtv_transformer.py:293-294)
+    const int drop_lo = embed_drop_from(m);
+    if (drop_lo >= 0)
+        LAUNCH(mdt_launch_dropout_rows(x0, B * Te, D, Te, drop_lo, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_CTX),
                                        t.drop.seed, s));
     for (int l = 0; l < m->Le; ++l) {
         if (l > 0) t.enc[l].x_in = t.enc[l - 1].x3;  // chain: a block's input is its predecessor's output buffer
@@ -671,8 +680,9 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
         MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, nullptr, 0, nullptr, nullptr,
                           ts->dxe, t.drop, l, s));
     const int t0 = m->sig_tok;
-    if (c.arch == MDT_ARCH_MDT)
-        LAUNCH(mdt_launch_dropout_rows(ts->dxe, Me, D, Te, t0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_CTX),
+    const int drop_lo = embed_drop_from(m);
+    if (drop_lo >= 0)
+        LAUNCH(mdt_launch_dropout_rows(ts->dxe, Me, D, Te, drop_lo, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_CTX),
                                        t.drop.seed, s));
     if (t0) {  // the sigma token is row 0 of every sample's context
         LAUNCH(mdt_launch_gather_rows(ts->dxe, ts->small, (int)B, D, 1, Te, 0, s));
@@ -682,11 +692,15 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
     const Lin& g0 = t.lang ? m->lang0 : m->goal0;
     const Lin& g2 = t.lang ? m->lang2 : m->goal2;
     float* dg = ts->t_d;  // (B, D)
-    LAUNCH(mdt_launch_gather_rows(ts->dxe, dg, (int)B, D, 1, Te, t0, s));
+    const bool has_goal = m->g_row >= 0;
+    if (has_goal) LAUNCH(mdt_launch_gather_rows(ts->dxe, dg, (int)B, D, 1, Te, m->g_row, s));
+    else if (d_goal) HIP_TRY(hipMemsetAsync(d_goal, 0, (size_t)B * m->G * sizeof(float), s));
     const bool pos = c.arch == MDT_ARCH_MDT && c.use_abs_pos_emb;
     float* g_pos = pos ? grad_of(m, grads, m->pos_emb) : nullptr;
-    if (pos) LAUNCH(mdt_launch_colsum(dg, D, (int)B, D, g_pos, 1, s));
-    if (c.use_mlp_goal) {
+    if (pos && has_goal) LAUNCH(mdt_launch_colsum(dg, D, (int)B, D, g_pos, 1, s));
+    if (!has_goal) {
+        // goal_conditioned=False in MDTTransformer: the goal never enters the context
+    } else if (c.use_mlp_goal) {
         MDT_TRY(lin_bwd(m, grads, g2, t.g_h, 2 * D, dg, D, (int)B, ts->small, 2 * D, 0, s));
         LAUNCH(mdt_launch_act_bwd(t.g_pre, ts->small, ts->small, B * 2 * D, MDT_ACT_GELU, s));
         MDT_TRY(lin_bwd(m, grads, g0, t.goal, m->G, ts->small, 2 * D, (int)B, d_goal, m->G, 0, s));
@@ -695,14 +709,14 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
     }
     if (c.arch == MDT_ARCH_MDTV) {
         float* dt = ts->t_d2;  // (B*n_tok, D)
-        LAUNCH(mdt_launch_gather_rows(ts->dxe, dt, (int)(B * m->n_tok), D, m->n_tok, Te, t0 + 1, s));
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, dt, (int)(B * m->n_tok), D, m->n_tok, Te, m->tok_row, s));
         MDT_TRY(lin_bwd(m, grads, m->tok, t.tokens, m->O, dt, D, (int)(B * m->n_tok), d_tokens, m->O, 0, s));
     } else {
         float* d1 = ts->t_d2;
-        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, t0 + 1, s));
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, m->tok_row, s));
         if (pos) LAUNCH(mdt_launch_colsum(d1, D, (int)B, D, g_pos + (int64_t)c.goal_seq_len * D, 1, s));
         MDT_TRY(lin_bwd(m, grads, m->tok, t.tokens, m->O, d1, D, (int)B, d_tokens, m->O, 0, s));
-        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, t0 + 2, s));
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, d1, (int)B, D, 1, Te, m->tok_row + 1, s));
         if (pos) LAUNCH(mdt_launch_colsum(d1, D, (int)B, D, g_pos + (int64_t)c.goal_seq_len * D, 1, s));
         MDT_TRY(lin_bwd(m, grads, m->incam, t.tokens2, m->O, d1, D, (int)B, d_tokens2, m->O, 0, s));
     }

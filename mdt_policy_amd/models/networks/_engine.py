@@ -45,7 +45,9 @@ class HipEngine:
                          for i in range(n)}
         self._uploaded: Dict[str, tuple] = {}
         self.sigma_in_context = not cfg.use_ada_conditioning  # sigma embedding is the first context token
-        self.Te = int(self.sigma_in_context) + 1 + (cfg.n_obs_token if cfg.arch == 0 else 2)
+        # goal_conditioned=False: MDTV keeps the goal token (behind the state tokens), MDT has none
+        self.has_goal_token = not (cfg.no_goal_conditioning and cfg.arch == 1)
+        self.Te = int(self.sigma_in_context) + int(self.has_goal_token) + (cfg.n_obs_token if cfg.arch == 0 else 2)
         self.Ta, self.A, self.D = cfg.action_seq_len, cfg.action_dim, cfg.embed_dim
 
     def __del__(self):
@@ -257,7 +259,9 @@ class HipEngine:
         _lib.check(self.lib.mdt_tape_release(self.handle, tape))
 
     def unused_goal_embedder(self, state: dict, honour_modality: bool) -> Optional[str]:
-        """Name prefix of the goal embedder this forward did NOT go through (None without a modality encoder)."""
+        """Name prefix(es) of the goal embedder(s) this forward did NOT go through (None: all were used)."""
+        if not self.has_goal_token:
+            return ("goal_emb.", "lang_emb.")
         if not self.cfg.use_modality_encoder:
             return None
         lang = honour_modality and self._modality(state) == _lib.MODALITY["lang"]

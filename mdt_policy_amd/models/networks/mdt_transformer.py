@@ -53,8 +53,9 @@ class MDTTransformer(HipScoreNetwork):
     ):
         super().__init__()
         self._init_common()
-        if not goal_conditioned:
-            raise NotImplementedError("goal_conditioned=False is not implemented by the HIP path")
+        if not goal_conditioned and use_ada_conditioning:
+            # the reference builds but cannot run this: concatenate_inputs cats the absent sigma token (:334)
+            raise NotImplementedError("MDTTransformer with goal_conditioned=False needs use_ada_conditioning=False")
         self.linear_output = bool(linear_output)
         self.device = device
         self.goal_conditioned = goal_conditioned
@@ -143,4 +144,5 @@ class MDTTransformer(HipScoreNetwork):
             use_mlp_goal=int(self.use_mlp_goal), use_modality_encoder=int(self.use_modality_encoder),
             use_abs_pos_emb=int(self.use_abs_pos_emb), use_rot_embed=int(self.use_rot_embed),
             use_ada_conditioning=int(self.use_ada_conditioning), use_noise_encoder=int(self.use_noise_encoder),
-            linear_output=int(self.linear_output), bias=int(self.bias_flag), sigma_data=float(sigma_data))
+            linear_output=int(self.linear_output), bias=int(self.bias_flag), sigma_data=float(sigma_data),
+            no_goal_conditioning=int(not self.goal_conditioned))

@@ -219,7 +219,8 @@ def encode(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv", 
         goal = _prep_goal(cfg, goal, tokens.shape[1])
         g = _goal_embed(P, cfg, goal, modality, True)
         s = _lin(P, "inner_model.tok_emb", tokens)
-        h = torch.cat([g, s], dim=1)  # concatenate_inputs (:284-299), goal_conditioned, no proprio
+        # concatenate_inputs (:284-299), no proprio: [goal, state] when goal_conditioned, else [state, drop(goal)]
+        h = torch.cat([g, s], dim=1) if cfg.get("goal_conditioned", True) else torch.cat([s, g], dim=1)
     else:
         goal = _prep_goal(cfg, goal, 1 if entry == "forward" else state["static"].shape[1])
         g = _goal_embed(P, cfg, goal, modality, entry != "forward")
@@ -231,7 +232,8 @@ def encode(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv", 
             pos = P["inner_model.pos_emb"]
             g = g + pos[:, : cfg["goal_seq_len"], :]
             s = s + pos[:, cfg["goal_seq_len"]: cfg["goal_seq_len"] + 1, :]
-        h = torch.cat([g, s], dim=1)
+        # concatenate_inputs (mdt_transformer.py:326-334): without goal conditioning the goal never enters
+        h = torch.cat([g, s], dim=1) if cfg.get("goal_conditioned", True) else s
     if not ada:  # concatenate_inputs: the sigma embedding is the FIRST encoder token (mdtv_transformer.py:296-297)
         h = torch.cat([sigma_embedding(P, cfg, sigma), h], dim=1)
     if trace is not None:

@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
     if (!f) { perror("blob"); return 1; }
     int32_t nf = 0, fields[32];
     mdt_config cfg;
+    memset(&cfg, 0, sizeof cfg); /* fields behind sigma_data (no_goal_conditioning) keep their defaults */
     if (rd(f, &nf, 4) || nf != 19 || rd(f, fields, 4 * nf) || rd(f, &cfg.sigma_data, 4)) return 1;
     memcpy(&cfg, fields, 4 * nf); /* the 19 int32 fields lead the struct in declaration order */
     mdt_model* m = NULL;

@@ -225,6 +225,8 @@ G11_CASES = {
     "mdtv_no_ada": ("mdtv", "mdtv_tiny", dict(use_ada_conditioning=False), 5),
     "mdt_no_ada": ("mdt", "mdt_tiny", dict(use_ada_conditioning=False, bias=True), 4),
     "mdtv_mlp_head": ("mdtv", "mdtv_tiny", dict(linear_output=False), 5),
+    "mdtv_no_goal_cond": ("mdtv", "mdtv_tiny", dict(goal_conditioned=False, use_noise_encoder=True), 5),
+    "mdt_no_goal_cond": ("mdt", "mdt_tiny", dict(goal_conditioned=False, use_ada_conditioning=False), 4),
 }
 
 
@@ -255,7 +257,8 @@ def g11():
             summ[k] = [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
         for k, v in leaves.items():
             arrays["d_" + k] = v.grad.numpy()
-        arrays["d_goal"] = goal.grad.numpy()
+        # MDTTransformer with goal_conditioned=False never reads the goal: autograd leaves its gradient None
+        arrays["d_goal"] = goal.grad.numpy() if goal.grad is not None else np.zeros_like(inp["goal"])
         meta = dict(config=factory, overrides=ov, arch=arch, B=B, modality="lang", weight_seed=111, profile="rich",
                     input_seed=112, loss_seed=113, ctx_seed=114, grads=summ,
                     state_dict=[[k, list(v.shape)] for k, v in model.state_dict().items()])
@@ -390,6 +393,10 @@ G8_VARIANTS = {
     "noise_block": ("mdtv", dict(use_noise_encoder=True)),
     "mdt_no_ada": ("mdt", dict(use_ada_conditioning=False)),
     # the MLP action head (linear_output=False: Linear(d, 100) -> GELU -> Linear(100, A))
+    # goal_conditioned=False: MDT-V appends the goal token behind the state tokens, MDT (only runnable without adaLN
+    # conditioning) has no goal token
+    "no_goal_cond": ("mdtv", dict(goal_conditioned=False)),
+    "mdt_no_goal_cond": ("mdt", dict(goal_conditioned=False, use_ada_conditioning=False)),
     "mlp_head": ("mdtv", dict(linear_output=False)),
     "mdt_mlp_head": ("mdt", dict(linear_output=False, bias=True)),
 }

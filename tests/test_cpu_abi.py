@@ -82,7 +82,7 @@ def test_facade_state_dict_names_shapes_and_order_match_the_reference(key, cfg):
 
 
 @pytest.mark.parametrize("name", ["bias", "plain_goal", "two_tokens", "mdt_bias_nopos", "no_ada", "noise_block",
-                                  "mdt_no_ada", "mlp_head", "mdt_mlp_head"])
+                                  "mdt_no_ada", "mlp_head", "mdt_mlp_head", "no_goal_cond", "mdt_no_goal_cond"])
 def test_facade_state_dict_of_the_constructor_variants(name):
     """bias / goal embedder / token-count variants and the two other decoder conditionings (plain TransformerDecoder
     without adaLN_zero for use_ada_conditioning=False, NoiseBlock for use_noise_encoder=True)."""
@@ -111,8 +111,8 @@ def test_facade_refuses_cpu_execution():
         m(state, torch.zeros(1, 10, 7), torch.zeros(1, 1, 512), torch.ones(1))
     with pytest.raises(NotImplementedError, match="autograd"):
         m(state, torch.zeros(1, 10, 7), torch.zeros(1, 1, 512), torch.ones(1))
-    with pytest.raises(NotImplementedError):
-        GCDenoiser(configs.mdtv_tiny(goal_conditioned=False), 0.5)
+    with pytest.raises(NotImplementedError):  # the reference builds this one but cannot run it
+        GCDenoiser(configs.mdt_tiny(goal_conditioned=False, use_ada_conditioning=True), 0.5)
     with pytest.raises(TypeError):
         GCDenoiser(torch.nn.Linear(2, 2), 0.5)
 

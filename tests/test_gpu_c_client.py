@@ -36,7 +36,8 @@ def test_c_host_program_matches_the_python_facade(fixture, tmp_path):
     sig = gs.get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
     x_T = noise * meta["sigma_max"]
     blob = tmp_path / "blob.bin"
-    names = [n for n, _ in _lib.MDTConfig._fields_ if n != "sigma_data"]
+    allf = [n for n, _ in _lib.MDTConfig._fields_]
+    names = allf[:allf.index("sigma_data")]  # the int32 fields that lead the struct
     with open(blob, "wb") as f:
         f.write(struct.pack("<i", len(names)))
         f.write(struct.pack(f"<{len(names)}i", *[getattr(cfg, n) for n in names]))

@@ -275,7 +275,8 @@ def test_collapsed_and_explicit_cross_attention_paths_agree(monkeypatch):
     assert not torch.equal(outs["1"], outs["0"])  # different arithmetic: the two paths really are distinct
 
 
-G8 = ["bias", "plain_goal", "two_tokens", "mdt_bias_nopos", "no_ada", "noise_block", "mdt_no_ada", "mlp_head", "mdt_mlp_head"]
+G8 = ["bias", "plain_goal", "two_tokens", "mdt_bias_nopos", "no_ada", "noise_block", "mdt_no_ada", "mlp_head", "mdt_mlp_head",
+      "no_goal_cond", "mdt_no_goal_cond"]
 
 
 @pytest.mark.parametrize("name", G8)
@@ -299,7 +300,8 @@ def test_g8_constructor_variants(name):
     assert_close(out2.cpu(), fx["actions"], what="actions (python loop)")
 
 
-@pytest.mark.parametrize("name", ["no_ada", "noise_block", "mdt_no_ada", "mlp_head", "mdt_mlp_head"])
+@pytest.mark.parametrize("name", ["no_ada", "noise_block", "mdt_no_ada", "mlp_head", "mdt_mlp_head", "no_goal_cond",
+                                  "mdt_no_goal_cond"])
 def test_conditioning_variants_entry_points_against_the_oracle(name):
     """use_ada_conditioning=False (sigma token in the context, plain decoder) and use_noise_encoder=True (NoiseBlock):
     forward with one sigma per sample, the split encoder/decoder calls, the loss, and another sampler, against the
