@@ -100,6 +100,11 @@ class HipEngine:
         return t
 
     def _tokens(self, state: dict):
+        if "state_obs" in state:
+            # the reference would embed it with proprio_emb and append one more context token
+            # (mdtv_transformer.py:260-266); no caller of the reference passes it
+            raise NotImplementedError("a proprioceptive 'state_obs' entry in the state dict is not implemented by the HIP "
+                                      "path (the reference's agents never pass one)")
         if self.cfg.arch == 0:
             tok = self._in(state["state_images"])
             if tok.dim() != 3 or tok.shape[1] != self.cfg.n_obs_token or tok.shape[2] != self.cfg.obs_dim:
