@@ -981,6 +981,32 @@ __global__ __launch_bounds__(256) void k_multi_adamw(const mdt_opt_tensor* __res
     const mdt_opt_tensor t = tab[blk.x];
     const int64_t end = min((int64_t)blk.y + OPT_CHUNK, t.numel);
     const float step_size = lr / bc1;
+    // whole chunks of 16-byte aligned tensors: 4 float4 per thread and array, every load issued before the first store
+    if (end - blk.y == OPT_CHUNK && ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0)) {
+        f32x4 *p4 = (f32x4*)(t.p + blk.y), *m4 = (f32x4*)(t.m + blk.y), *v4 = (f32x4*)(t.v + blk.y);
+        const f32x4* g4 = (const f32x4*)(t.g + blk.y);
+        f32x4 pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            pv[k] = p4[i]; gv[k] = g4[i]; mv[k] = m4[i]; vv[k] = v4[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = gv[k][e];
+                float p = pv[k][e] * (1.0f - lr * wd);
+                const float m = fmaf(beta1, mv[k][e], (1.0f - beta1) * g);
+                const float v = fmaf(beta2, vv[k][e], (1.0f - beta2) * g * g);
+                p -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+                pv[k][e] = p; mv[k][e] = m; vv[k][e] = v;
+            }
+            p4[i] = pv[k]; m4[i] = mv[k]; v4[i] = vv[k];
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blk.y + threadIdx.x; i < end; i += 256) {
         const float g = t.g[i];
         float p = t.p[i] * (1.0f - lr * wd);                 // decoupled weight decay
@@ -998,6 +1024,20 @@ __global__ __launch_bounds__(256) void k_multi_axpby(const mdt_opt_tensor* __res
     const int2 blk = blocks[blockIdx.x];
     const mdt_opt_tensor t = tab[blk.x];
     const int64_t end = min((int64_t)blk.y + OPT_CHUNK, t.numel);
+    if (end - blk.y == OPT_CHUNK && ((((uintptr_t)t.p | (uintptr_t)t.ema) & 15) == 0)) {
+        f32x4* e4 = (f32x4*)(t.ema + blk.y);
+        const f32x4* p4 = (const f32x4*)(t.p + blk.y);
+        f32x4 ev[4], pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ev[k] = e4[threadIdx.x + 256 * k]; pv[k] = p4[threadIdx.x + 256 * k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ev[k][e] = fmaf(a, ev[k][e], b * pv[k][e]);
+            e4[threadIdx.x + 256 * k] = ev[k];
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blk.y + threadIdx.x; i < end; i += 256) t.ema[i] = fmaf(a, t.ema[i], b * t.p[i]);
 }
 

@@ -19,6 +19,13 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        # host-side caches (not part of state_dict): the step count as a Python int and the addresses of the moment
+        # buffers, so that a step makes two tensor calls per parameter instead of seven
+        self._nsteps, self._mv = {}, {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._nsteps, self._mv = {}, {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -28,7 +35,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         for group in self.param_groups:
-            by_step = {}
+            by_step, steps = {}, []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -43,14 +50,23 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                n = self._nsteps.get(p)
+                mv = self._mv.get(p)
+                if n is None or mv is None or mv[0] is not st["exp_avg"] or mv[1] is not st["exp_avg_sq"]:
+                    n = int(st["step"].item())
+                    self._mv[p] = (st["exp_avg"], st["exp_avg_sq"], st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                   p.numel())
+                self._nsteps[p] = n + 1
+                steps.append(st["step"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_step.setdefault(int(st["step"].item()), []).append((p, g, st))
+                by_step.setdefault(n + 1, []).append((p, g))
+            if steps:
+                torch._foreach_add_(steps, 1.0)  # the state_dict's per-parameter counters, one call for all of them
             for step, items in by_step.items():  # parameters that joined later carry their own step count
                 tab = (_lib.OptTensor * len(items))()
-                for i, (p, g, st) in enumerate(items):
-                    tab[i] = _lib.OptTensor(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(),
-                                            v=st["exp_avg_sq"].data_ptr(), ema=None, numel=p.numel())
+                for i, (p, g) in enumerate(items):
+                    _, _, m_ptr, v_ptr, numel = self._mv[p]
+                    tab[i] = _lib.OptTensor(p=p.data_ptr(), g=g.data_ptr(), m=m_ptr, v=v_ptr, ema=None, numel=numel)
                 dev = items[0][0].device
                 with torch.cuda.device(dev):
                     _lib.check(lib.mdt_op_multi_adamw(tab, len(items), float(group["lr"]), float(group["betas"][0]),
@@ -59,7 +75,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                                       torch.cuda.current_stream(dev).cuda_stream))
                 # the library wrote the parameters behind autograd's back: bump their version counters (no kernel) so
                 # that the HIP engines see the change and re-upload the weights before the next forward
-                ps = [p for p, _, _ in items]
+                ps = [p for p, _ in items]
                 try:
                     torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
                 except (AttributeError, TypeError):  # other torch builds: an in-place no-op bumps it the public way
