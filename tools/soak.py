@@ -40,15 +40,24 @@ B = 128
 inp = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
 li = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
 st = {"state_images": inp["state_images"], "modality": "lang"}
-opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+from mdt_policy_amd.models.contrastive import compute_contrastive_loss
+from mdt_policy_amd.models.networks.transformers.transformer_blocks import ClipStyleProjection
+from mdt_policy_amd.optim import FusedAdamW
+
+clip = ClipStyleProjection("map", 384, 1, 4).to(dev)
+logit_scale = torch.nn.Parameter(torch.tensor(2.659, device=dev))
+opt = FusedAdamW(list(model.parameters()) + list(clip.parameters()) + [logit_scale], lr=1e-5)
 model.train()
 
 
 def step():
+    """The agent's training step: diffusion loss (language goal) + contrastive loss against the vision-goal context
+    (HIP denoiser forward / backward, HIP MAPBlock, HIP InfoNCE), FusedAdamW."""
     opt.zero_grad(set_to_none=True)
     loss, _ = model.loss(st, li["actions"], inp["goal"], li["noise_train"], li["sigma"])
-    ctx = model.forward_context_only(st, li["actions"], inp["goal"], li["sigma"])
-    (loss + 1e-3 * ctx.mean()).backward()
+    cont = compute_contrastive_loss(model, clip, logit_scale, dict(st, modality="vis"), inp["goal"], li["actions"],
+                                    li["sigma"], li["noise_train"])
+    (loss + cont).backward()
     opt.step()
 
 
