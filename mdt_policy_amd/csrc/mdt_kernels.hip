@@ -33,6 +33,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+#ifdef MDT_NO_SAMPLE_REMAP  // A/B build: per-sample kernels keep sample b on XCD b % 8
+#define MDT_SAMPLE_REMAP(bid, n) (bid)
+#else
+#define MDT_SAMPLE_REMAP(bid, n) xcd_remap(bid, n)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
@@ -836,7 +842,9 @@ __global__ __launch_bounds__(256) void k_attn(mdt_attn_args a, const float* __re
     MDT_TS(0)
     MDT_TS_HWID()
     constexpr int ROT = 32;  // rotary dims (position_embeddings.py / transformer_blocks.py:108)
-    const int tid = threadIdx.x, b = blockIdx.x;
+    // sample -> XCD as the GEMMs map row tiles -> XCD (xcd_remap): the q/k/v rows this workgroup reads were written
+    // by GEMM tiles of the same XCD and the rows it writes are read there again (speed only)
+    const int tid = threadIdx.x, b = MDT_SAMPLE_REMAP(blockIdx.x, gridDim.x);
     // gridDim.y workgroups share a sample, each taking H / gridDim.y heads (a contiguous column range of q/k/v)
     const int Hl = a.H / gridDim.y;              // heads of this workgroup
     const int coff = blockIdx.y * Hl * HD;       // first column
@@ -1390,7 +1398,7 @@ __global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const fl
     MDT_TS_HWID()
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x, D = a.D, Ta = a.Ta, Te = a.Te;
+    const int b = MDT_SAMPLE_REMAP(blockIdx.x, gridDim.x), D = a.D, Ta = a.Ta, Te = a.Te;
     const int n4 = D >> 2, NS = D >> 5;                  // float4 per row, 32-feature segments per row
     float* xn = lds;                                     // [Ta][D] normalised rows
     float* part = xn + Ta * D;                           // [Ta][NP][NS] partial dots
