@@ -113,6 +113,14 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
     }
 }
 
+// The enclosing kernel says with KSTEP_PRIO whether a k-step's MFMA block runs at raised issue priority: it pays where
+// loader waves share the SIMDs with the MFMA waves (k_gemm_pipe: mlp.c_proj 37.6 -> 36.1 us) and costs 1-3 % where
+// every wave does both (k_gemm).  -DMDT_NO_KSTEP_PRIO switches it off for A/B runs.
+#ifdef MDT_NO_KSTEP_PRIO
+#define MDT_PRIO(x)
+#else
+#define MDT_PRIO(x) if constexpr (KSTEP_PRIO) __builtin_amdgcn_s_setprio(x);
+#endif
 #ifndef MDT_RING_ADD
 #define MDT_RING_ADD 0  // tuning builds: deeper weight-fragment rings (tools/gpu_ring_ab.sh)
 #endif
@@ -125,12 +133,14 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
         f32x4 avn[MTILES]; /* activation fragments of the NEXT k-step: their LDS latency hides under the MFMAs */ \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
             *(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16);                           \
+        MDT_PRIO(1)                                                                                       \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
             _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                          \
                 _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                               \
                     __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0);  \
             }                                                                                             \
         }                                                                                                 \
+        MDT_PRIO(0)                                                                                       \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
     }
 
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     MDT_TS(0)
     MDT_TS_HWID()
     constexpr int MT = MTILES * 16;
+    constexpr bool KSTEP_PRIO = false;
     // weight-fragment ring: R-1 k-steps of 1-KiB loads in flight per column tile.  A k-step is only 8 MFMAs
     // (256 pipe cycles) with one column tile per wave, so the narrow variants need the deeper ring to cover L2 latency.
     constexpr int R = (NTW == 1 ? 6 : (NTW == 2 ? 4 : 3)) + MDT_RING_ADD;
@@ -419,6 +430,7 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
                                                                  const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MT = MTILES * 16;
+    constexpr bool KSTEP_PRIO = true;
     constexpr int R = (NTW == 1 ? 6 : (NTW == 2 ? 4 : 3)) + MDT_RING_ADD;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
