@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
                                                                  const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MT = MTILES * 16;
-    constexpr bool KSTEP_PRIO = true;
+    constexpr bool KSTEP_PRIO = true;  // (a priority raised once for the waves' whole life measured 1.5 % slower)
     constexpr int R = (NTW == 1 ? 6 : (NTW == 2 ? 4 : 3)) + MDT_RING_ADD;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
