@@ -125,7 +125,8 @@ hipError_t mdt_launch_add_2d(const float* src, int64_t lds_, float* dst, int64_t
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s);
 hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                                          const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
-                                         int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s);
+                                         int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s,
+                                         float* dkl = nullptr, int F = 0);  // F > 0: keys < F -> dk / dv (B*F rows), the rest -> dkl
 bool mdt_attention_long_bwd_supported(int hd, int Tq, int Tk);
 hipError_t mdt_launch_time_emb_grad(const float* dxf, const uint8_t* mask, float* out, float* partial, int64_t B, int T, int n,
                                     int D, int accumulate, hipStream_t s);  // partial: B*T*D floats of scratch

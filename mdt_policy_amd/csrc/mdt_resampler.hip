@@ -361,7 +361,7 @@ static void carve_rscratch(mdt_resampler* r, Bump& b, int64_t rows, int64_t B) {
     const int D = r->D, I = r->inner, Q = r->Q;
     const int64_t lr = B * Q;
     r->g_dx = b.take(lr * D); r->g_dxf = b.take(rows * D); r->g_nm = b.take(rows * D); r->g_dnm = b.take(rows * D);
-    r->g_dkv = b.take((rows + lr) * 2 * I); r->g_dkvm = b.take(rows * 2 * I); r->g_dkvl = b.take(lr * 2 * I);
+    r->g_dkv = nullptr; r->g_dkvm = b.take(rows * 2 * I); r->g_dkvl = b.take(lr * 2 * I);
     r->g_dq = b.take(lr * I); r->g_datt = b.take(lr * I); r->g_dlat = b.take(lr * D); r->g_ff = b.take(lr * r->ff);
     r->g_td = b.take(lr * D); r->g_pw = b.take(B * LN_CHUNKS * D); r->g_pb = b.take(B * LN_CHUNKS * D);
     int64_t need = mdt_linear_bwd_scratch(rows, 2 * I, D);
@@ -524,13 +524,11 @@ extern "C" mdt_status mdt_resampler_backward(mdt_resampler* r, int32_t tape, con
         MDT_TRY(r_ln_bwd(r, grads, P.x_mid, P.st_f, L.ff_w, L.ff_b, r->g_td, r->g_dx, 1, B, Q, s));
         // attention: x_mid = x_in + to_out(attn(to_q(ln_l(x_in)), to_k|to_v(cat(ln_m(x_f), ln_l(x_in)))))
         MDT_TRY(r_lin_bwd(r, grads, L.o, P.att, I, r->g_dx, D, lr, r->g_datt, I, 0, s));
-        LAUNCH(mdt_launch_attention_long_bwd(P.q, I, P.kv, P.kv + I, 2 * I, r->g_datt, I, r->g_dq, I, r->g_dkv, r->g_dkv + I,
-                                             2 * I, (int)B, r->H, r->hd, Q, Tk, scale, s));
+        // dK|dV of the media rows and of the latent rows leave the kernel in their own dense buffers
+        LAUNCH(mdt_launch_attention_long_bwd(P.q, I, P.kv, P.kv + I, 2 * I, r->g_datt, I, r->g_dq, I, r->g_dkvm, r->g_dkvm + I,
+                                             2 * I, (int)B, r->H, r->hd, Q, Tk, scale, s, r->g_dkvl, F));
         MDT_TRY(r_lin_bwd(r, grads, L.q, P.lat_n, D, r->g_dq, I, lr, r->g_dlat, D, 0, s));
-        // K|V rows: the latents' behind the media tokens' in every sample
-        LAUNCH(mdt_launch_gather_rows(r->g_dkv, r->g_dkvl, (int)lr, 2 * I, Q, Tk, F, s));
         MDT_TRY(r_lin_bwd(r, grads, L.kv, P.lat_n, D, r->g_dkvl, 2 * I, lr, r->g_dlat, D, 1, s));
-        LAUNCH(mdt_launch_gather_rows(r->g_dkv, r->g_dkvm, (int)rows, 2 * I, F, Tk, 0, s));
         LAUNCH(mdt_launch_ln_fwd_train(rln(t.xf, L.nm_w, L.nm_b, r->g_nm, nullptr, rows, D), s));  // recomputed, not kept
         MDT_TRY(r_lin_bwd(r, grads, L.kv, r->g_nm, D, r->g_dkvm, 2 * I, rows, r->g_dnm, D, 0, s));
         MDT_TRY(r_ln_bwd(r, grads, t.xf, P.st_m, L.nm_w, L.nm_b, r->g_dnm, r->g_dxf, 1, B, F, s));

@@ -803,7 +803,8 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd(const float* __restrict__
                                                        const float* __restrict__ v, int64_t ldkv,
                                                        const float* __restrict__ d_out, int64_t ld_do,
                                                        float* __restrict__ dq, int64_t ld_dq, float* __restrict__ dk,
-                                                       float* __restrict__ dv, int64_t ld_dkv, int Tq, int Tk, float scale) {
+                                                       float* __restrict__ dv, int64_t ld_dkv, int Tq, int Tk, float scale,
+                                                       float* __restrict__ dkl, int F) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int H4 = HD / 4, G = 256 / HD, QMAX = 16;
     const int tid = threadIdx.x, b = blockIdx.x, h = blockIdx.y;
@@ -879,8 +880,11 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd(const float* __restrict__
                 av[c].z = fmaf(p, o.z, av[c].z); av[c].w = fmaf(p, o.w, av[c].w);
             }
         }
-        float* pk = dk + ((int64_t)b * Tk + f) * ld_dkv + h * HD;
-        float* pv = dv + ((int64_t)b * Tk + f) * ld_dkv + h * HD;
+        // F > 0: the first F keys of a sample (media tokens) and the rest (latents) land in two dense buffers, (B*F, ld)
+        // at dk / dv and (B*(Tk-F), ld) at dkl (V at the same offset behind K) -- what the two K|V GEMMs' backwards read
+        float* pk = F > 0 ? (f < F ? dk + ((int64_t)b * F + f) * ld_dkv : dkl + ((int64_t)b * (Tk - F) + (f - F)) * ld_dkv) + h * HD
+                          : dk + ((int64_t)b * Tk + f) * ld_dkv + h * HD;
+        float* pv = pk + (dv - dk);
 #pragma unroll
         for (int c = 0; c < H4; ++c) { *(f32x4*)(pk + c * 4) = ak[c]; *(f32x4*)(pv + c * 4) = av[c]; }
     }
@@ -919,25 +923,28 @@ bool mdt_attention_long_bwd_supported(int hd, int Tq, int Tk) {
 template <int HD>
 static hipError_t launch_attn_long_bwd_t(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                                          const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
-                                         int64_t ld_dkv, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
+                                         int64_t ld_dkv, int B, int H, int Tq, int Tk, float scale, hipStream_t s, float* dkl,
+                                         int F) {
     const size_t lds = attn_long_bwd_lds(HD, Tq, Tk);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_long_bwd<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_attn_long_bwd<HD>), dim3(B, H), dim3(256), lds, s, q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk,
-                       dv, ld_dkv, Tq, Tk, scale);
+                       dv, ld_dkv, Tq, Tk, scale, dkl, F);
     return hipGetLastError();
 }
 
 hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                                          const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
-                                         int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s) {
+                                         int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s,
+                                         float* dkl, int F) {
+    if (F < 0 || F >= Tk || (F > 0 && !dkl)) return hipErrorInvalidValue;
     if (!mdt_attention_long_bwd_supported(hd, Tq, Tk)) return hipErrorInvalidValue;
     switch (hd) {
-        case 16: return launch_attn_long_bwd_t<16>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s);
-        case 32: return launch_attn_long_bwd_t<32>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s);
-        default: return launch_attn_long_bwd_t<64>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s);
+        case 16: return launch_attn_long_bwd_t<16>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s, dkl, F);
+        case 32: return launch_attn_long_bwd_t<32>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s, dkl, F);
+        default: return launch_attn_long_bwd_t<64>(q, ldq, k, v, ldkv, d_out, ld_do, dq, ld_dq, dk, dv, ld_dkv, B, H, Tq, Tk, scale, s, dkl, F);
     }
 }
 
