@@ -841,6 +841,7 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         case 3: return launch_gemm_pro<2, 3, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 4: return launch_gemm_pro<2, 4, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 6: return launch_gemm_pro<1, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 16 x 64
+        case 7: return launch_gemm_pro<4, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 64 x 128 (deep-K products)
         default: return launch_gemm_pro<2, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
     }
 }
