@@ -18,4 +18,4 @@ STATS=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$STATS" ] && head -25 "$STATS"
 # keep only the summaries (traces are large)
 find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
-if [ "$3" = "cpu" ]; then echo "== cpu threads =="; timeout 300 python tools/cpu_threads_probe.py 256 2>&1 | tee $OUT/cpu_threads.txt; fi
+if [ "$3" = "cpu" ]; then echo "== cpu threads =="; timeout 300 python tests/perf_cpu_threads.py 256 2>&1 | tee $OUT/cpu_threads.txt; fi
