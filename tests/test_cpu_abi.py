@@ -259,3 +259,15 @@ def test_headers_are_plain_c():
         r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", "-I", inc,
                             os.path.join(inc, hdr)], capture_output=True, text=True)
         assert r.returncode == 0, f"{hdr}: {r.stderr}"
+
+
+def test_integration_doc_stub_matches_the_config_struct():
+    """INTEGRATION.md shows the ctypes stub another host would write: its field list must follow include/mdt_hip.h
+    (= _lib.MDTConfig), or the example corrupts the trailing fields."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class MDTConfig(C.Structure)"):doc.index("lib.mdt_last_error.restype")]
+    names = re.findall(r'"([a-z_0-9]+)"', block)
+    assert names == [n for n, _ in _lib.MDTConfig._fields_]
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdt_hip.h")).read(), flags=re.S)
+    struct = hdr[hdr.index("typedef struct {"):hdr.index("} mdt_config;")]
+    assert re.findall(r"(?:int32_t|float)\s+([a-z_0-9]+);", struct) == names
