@@ -271,3 +271,79 @@ def test_integration_doc_stub_matches_the_config_struct():
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdt_hip.h")).read(), flags=re.S)
     struct = hdr[hdr.index("typedef struct {"):hdr.index("} mdt_config;")]
     assert re.findall(r"(?:int32_t|float)\s+([a-z_0-9]+);", struct) == names
+
+
+_STRUCTS = {"mdt_config": "MDTConfig", "mdt_gemm_args": "GemmArgs", "mdt_attn_args": "AttnArgs", "mdt_head_args": "HeadArgs",
+            "mdt_xfold_args": "XFoldArgs", "mdt_xapply_args": "XApplyArgs", "mdt_dropout": "Dropout",
+            "mdt_ln_train_args": "LnTrainArgs", "mdt_ln_bwd_args": "LnBwdArgs", "mdt_attn_train_args": "AttnTrainArgs",
+            "mdt_attn_bwd_args": "AttnBwdArgs", "mdt_merge_args": "MergeArgs", "mdt_linear_bwd_args": "LinearBwdArgs",
+            "mdt_opt_tensor": "OptTensor", "mdt_map_pool_config": "MapPoolConfig", "mdt_infonce_args": "InfoNCEArgs",
+            "mdt_resampler_config": "ResamplerConfig"}
+_CTYPE = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float}
+
+
+def _header_structs():
+    """{struct name: [(field, ctypes type)]} parsed from include/*.h (POD structs: scalars and pointers only)."""
+    out = {}
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", hdr)).read(), flags=re.S)
+        for body, name in re.findall(r"typedef struct \{(.*?)\}\s*(mdt_[a-z_]+);", src, flags=re.S):
+            fields = []
+            for decl in body.split(";"):
+                decl = " ".join(decl.split())
+                if not decl:
+                    continue
+                m = re.match(r"(?:const )?(\w+)\s*(.*)", decl)
+                base, rest = m.group(1), m.group(2)
+                for item in rest.split(","):
+                    item = item.strip()
+                    ptr = item.startswith("*")
+                    fields.append((item.lstrip("* "), C.c_void_p if ptr else _CTYPE[base]))
+            out[name] = fields
+    return out
+
+
+def test_ctypes_structs_mirror_the_headers_field_by_field():
+    """Every POD struct of include/*.h against its ctypes mirror in _lib.py: names, order and types (a field appended to
+    a header but not to its mirror silently shifts or truncates the arguments)."""
+    hs = _header_structs()
+    assert set(hs) == set(_STRUCTS), set(hs) ^ set(_STRUCTS)
+    for cname, pyname in _STRUCTS.items():
+        got = [(n, t) for n, t in getattr(_lib, pyname)._fields_]
+        assert [n for n, _ in got] == [n for n, _ in hs[cname]], cname
+        for (n, t), (_, want) in zip(got, hs[cname]):
+            assert C.sizeof(t) == C.sizeof(want), f"{cname}.{n}"
+            assert (t is C.c_float) == (want is C.c_float), f"{cname}.{n}"
+
+
+def _kind(ctype):
+    if ctype in (C.c_int32, C.c_uint32): return "i32"
+    if ctype in (C.c_int64, C.c_uint64): return "i64"
+    if ctype is C.c_float: return "f32"
+    if ctype is C.c_double: return "f64"
+    return "ptr"  # c_void_p, c_char_p, POINTER(...)
+
+
+def test_ctypes_prototypes_mirror_the_headers():
+    """Argument count and kind (pointer / 32-bit / 64-bit integer / float / double) of every function the headers
+    declare against the ctypes table."""
+    protos = {}
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", hdr)).read(), flags=re.S)
+        src = re.sub(r"typedef struct \{.*?\}\s*mdt_[a-z_]+;", "", src, flags=re.S)
+        for name, args in re.findall(r"\b(mdt_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", src):
+            kinds = []
+            for a in [x.strip() for x in args.split(",")]:
+                if a in ("void", ""):
+                    continue
+                if "*" in a:
+                    kinds.append("ptr")
+                else:
+                    t = a.replace("const ", "").split()[0]
+                    kinds.append({"int32_t": "i32", "uint32_t": "i32", "int64_t": "i64", "uint64_t": "i64", "float": "f32",
+                                  "double": "f64", "mdt_tape_id": "i32"}[t])  # typedef int32_t mdt_tape_id
+            protos[name] = kinds
+    table = {n: [_kind(t) for t in argt] for n, _, argt in _lib.SYMBOLS}
+    assert set(protos) == set(table)
+    for n, kinds in protos.items():
+        assert table[n] == kinds, (n, table[n], kinds)
