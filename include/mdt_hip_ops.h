@@ -88,6 +88,14 @@ typedef struct {
 
 mdt_status mdt_op_attention(const mdt_attn_args *args, void *stream);
 
+/* One sample's self-attention fused into its output projection (the rollout batch B = 1, where every launch is
+ * latency): out (+)= gate * (softmax(q k^T / sqrt(hd)) v @ W^T + bias) for the T <= 16 rows of qkv (T, 3*K), q | k | v
+ * column blocks of K = 8 * hd each.  `proj` describes the projection as for mdt_op_gemm (A is ignored, M = T; bias /
+ * residual / gate as there; no LayerNorm prologue, activation or row remap).  8 heads, hd in {16,32,48,64}, no RoPE.
+ * Replaces Attention.forward's SDPA + c_proj (transformer_blocks.py:142-157) for one sample. */
+mdt_status mdt_op_attn_proj(const mdt_gemm_args *proj, const float *qkv, int64_t ldq, int32_t hd, int32_t T, int32_t causal,
+                            void *stream);
+
 mdt_status mdt_op_layernorm(const float *in, const float *w, const float *b, float *out, int64_t M, int32_t D,
                             void *stream);
 

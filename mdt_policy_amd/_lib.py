@@ -173,6 +173,7 @@ SYMBOLS = [
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
     ("mdt_op_set_gemm_geometry", None, [_I32]),
     ("mdt_op_attention", _I32, [C.POINTER(AttnArgs), _VP]),
+    ("mdt_op_attn_proj", _I32, [C.POINTER(GemmArgs), _VP, _I64, _I32, _I32, _I32, _VP]),
     ("mdt_op_xattn_fold", _I32, [C.POINTER(XFoldArgs), _VP]),
     ("mdt_op_xattn_apply", _I32, [C.POINTER(XApplyArgs), _VP]),
     ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),

@@ -63,6 +63,10 @@ static inline mdt_gemm_args gemm_args(const float* A, int64_t lda, const Lin& w,
 int mdt_gemm_kchunk(int K, int ln, int cap);
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s);
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin, hipStream_t s);
+// one sample's self-attention fused into its output projection p (rollout batch 1); see mdt_kernels.hip
+bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope);
+hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int H, int hd, int T, int causal,
+                                hipStream_t s);
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
                                 hipStream_t s);
 hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,

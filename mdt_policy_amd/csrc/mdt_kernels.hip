@@ -576,6 +576,99 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_attn_proj_smallm: ONE sample's self-attention fused into its output projection (rollout batch B = 1).
+//   out (+)= gate * (attn(q, k, v) @ Wp^T + bias)            rows T <= 16, 8 heads
+// The split-K small-M GEMM gives wave w the k-range of head w (8 waves = 8 heads, head_dim = K / 8), so each wave first
+// computes ITS head's attention output for the T rows (q / k / v of the head staged in the wave's own LDS region, scores
+// and softmax by the wave alone, no workgroup barrier) and then feeds it to the MFMAs as the activation fragment.  Every
+// workgroup (16 output columns) repeats the T x T attention -- 19 kFLOP per head -- in exchange for one launch and one
+// round trip of the attention output per block.  The weight fragments are requested before the attention starts.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(512) void k_attn_proj_smallm(mdt_gemm_args a, const float* __restrict__ qkv, int64_t ldq, int T,
+                                                         int causal, float scale, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ __attribute__((aligned(16))) float red[8][64][4];
+    constexpr int ST = HD + 4, H4 = HD / 4, KS = HD / 16;  // padded row stride, float4 per row, k16 steps per head
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    const int n_tile = blockIdx.x, K16 = a.K >> 4, D = a.K;
+    // weight fragments of this head's k-range (in flight while the attention runs)
+    const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
+    f32x4 wf[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) wf[u] = ldg4(wbase + (h * KS + u) * 256);
+    float* qs = lds + h * (3 * 16 * ST + 16 * 17);  // [16][ST] q, later the attention output
+    float* ks = qs + 16 * ST;
+    float* vs = ks + 16 * ST;
+    float* P = vs + 16 * ST;                         // [16][17]
+    for (int i = lane; i < T * H4; i += 64) {
+        const int t = i / H4, c = i - t * H4;
+        const float* row = qkv + (int64_t)t * ldq + h * HD + 4 * c;
+        *(f32x4*)(qs + t * ST + 4 * c) = ldg4(row);
+        *(f32x4*)(ks + t * ST + 4 * c) = ldg4(row + D);
+        *(f32x4*)(vs + t * ST + 4 * c) = ldg4(row + 2 * D);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < T * T; e += 64) {
+        const int i = e / T, j = e - i * T;
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < H4; ++c) {
+            const f32x4 qv = *(const f32x4*)(qs + i * ST + 4 * c), kv = *(const f32x4*)(ks + j * ST + 4 * c);
+            sacc = fmaf(qv.x, kv.x, sacc); sacc = fmaf(qv.y, kv.y, sacc); sacc = fmaf(qv.z, kv.z, sacc); sacc = fmaf(qv.w, kv.w, sacc);
+        }
+        P[i * 17 + j] = (!causal || j <= i) ? sacc * scale : -INFINITY;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < T) {
+        float* row = P + lane * 17;
+        float mx = row[0];
+        for (int j = 1; j < T; ++j) mx = fmaxf(mx, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { row[j] = expf(row[j] - mx); sum += row[j]; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < T; ++j) row[j] *= inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 16 * H4; i += 64) {  // rows T..15 of the activation tile are zero
+        const int t = i / H4, c = i - t * H4;
+        f32x4 o = zero4;
+        if (t < T)
+            for (int j = 0; j < T; ++j) o += P[t * 17 + j] * *(const f32x4*)(vs + j * ST + 4 * c);
+        *(f32x4*)(qs + t * ST + 4 * c) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- this head's slice of the projection: lane holds row lane % 16, k = 16 u + 4 (lane / 16) .. + 3 ----
+    const int mrow = lane & 15, kq = 4 * (lane >> 4);
+    f32x4 acc = zero4;
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+        const f32x4 x = *(const f32x4*)(qs + mrow * ST + 16 * u + kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][e], x[e], acc, 0, 0, 0);
+    }
+    *(f32x4*)&red[h][lane][0] = acc;
+    __syncthreads();
+    if (h != 0) return;
+    f32x4 v = *(const f32x4*)&red[0][lane][0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)&red[w][lane][0];
+    const bool mok = mrow < T;
+    const int64_t mc = min(mrow, T - 1);
+    const int ncol = n_tile * 16 + kq;
+    const float* biasp = a.bias != nullptr ? a.bias : zeros;
+    v = v + ldg4(biasp + ncol);
+    float* op = a.out + mc * a.ldo + ncol;
+    if (a.residual) {
+        f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (a.gate_off >= 0) g = ldg4(a.mod + a.gate_off + ncol);  // one sample: row 0 of the conditioning rows
+        v = ldg4(op) + g * v;
+    }
+    if (mok) st4(op, v);
+}
+
 // 256 KiB of zeros per device: stands in for absent bias / rowvec / LayerNorm-bias vectors.  ensure_zeros() points
 // g_zeros at the CURRENT device's buffer (a process normally drives one GPU; a second one gets its own buffer).
 static const int ZEROS_FLOATS = 65536;
@@ -779,6 +872,49 @@ static hipError_t launch_gemm_pro(const mdt_gemm_args& a, int kchunk, hipStream_
 
 int g_mdt_gemm_force = 0;  // tuning hook: 0 = heuristic, else 1..6 selects a geometry below
 static const bool g_mdt_gemm_nopipe = getenv("MDT_HIP_NOPIPE") != nullptr;  // A/B switch for k_gemm_pipe
+
+// Self-attention of ONE sample fused into its output projection (k_attn_proj_smallm).  `p` is the projection's GEMM
+// (A ignored: the attention output never reaches memory; M = the sample's T rows); q / k / v are the three column
+// blocks of the (T, 3 K) qkv rows.  Supported: 8 heads of 16 / 32 / 48 / 64, T <= 16, no RoPE, plain output rows.
+static bool attn_proj_disabled() {  // MDT_HIP_NO_ATTN_PROJ=1: the separate attention + projection launches (A/B runs)
+    static int off = -1;
+    if (off < 0) off = getenv("MDT_HIP_NO_ATTN_PROJ") != nullptr;
+    return off != 0;
+}
+
+bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope) {
+    return H == 8 && (hd == 16 || hd == 32 || hd == 48 || hd == 64) && p.K == H * hd && T >= 1 && T <= 16 && p.M == T && !rope &&
+           !(p.N & 15) && p.gin == 1 && p.gout == 1 && p.goff == 0 && !p.ln && p.act == MDT_ACT_NONE && p.rowvec == nullptr &&
+           p.batch <= 1 && !attn_proj_disabled();
+}
+
+template <int HD>
+static hipError_t launch_attn_proj_t(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int T, int causal, hipStream_t s) {
+    const size_t lds = (size_t)8 * (3 * 16 * (HD + 4) + 16 * 17) * sizeof(float);
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
+    if (lds > 48 * 1024 && lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_proj_smallm<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_attn_proj_smallm<HD>), dim3(p.N >> 4), dim3(512), lds, s, p, qkv, ldq, T, causal,
+                       1.0f / sqrtf((float)HD), g_zeros);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int H, int hd, int T, int causal,
+                                hipStream_t s) {
+    if (!mdt_attn_proj_supported(p, H, hd, T, 0)) return hipErrorInvalidValue;
+    hipError_t ze = ensure_zeros();
+    if (ze != hipSuccess) return ze;
+    switch (hd) {
+        case 16: return launch_attn_proj_t<16>(p, qkv, ldq, T, causal, s);
+        case 32: return launch_attn_proj_t<32>(p, qkv, ldq, T, causal, s);
+        case 48: return launch_attn_proj_t<48>(p, qkv, ldq, T, causal, s);
+        default: return launch_attn_proj_t<64>(p, qkv, ldq, T, causal, s);
+    }
+}
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;

@@ -489,15 +489,20 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
     g.rows_per_sample = T;
     if (mr.mod && mr.shift >= 0) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = mr.shift; g.scale_off = mr.scale; }
     LAUNCH(mdt_launch_gemm(g, s));
+    mdt_gemm_args p = gemm_args(V.att, D, e.proj, x, D, M);
+    p.residual = 1; p.rows_per_sample = T;
+    if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
+    if (B == 1 && mdt_attn_proj_supported(p, m->H, m->hd, T, m->cfg.use_rot_embed)) {
+        // rollout batch: attention and projection in one launch (the attention output never leaves the workgroup)
+        LAUNCH(mdt_launch_attn_proj(p, V.qkv, 3 * D, m->H, m->hd, T, causal, s));
+        return MDT_OK;
+    }
     mdt_attn_args a;
     memset(&a, 0, sizeof a);
     a.q = V.qkv; a.ldq = 3 * D; a.k = V.qkv + D; a.v = V.qkv + 2 * D; a.ldkv = 3 * D;
     a.out = V.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = T; a.Tk = T;
     a.causal = causal; a.rope = m->cfg.use_rot_embed;
     LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
-    mdt_gemm_args p = gemm_args(V.att, D, e.proj, x, D, M);
-    p.residual = 1; p.rows_per_sample = T;
-    if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
     LAUNCH(mdt_launch_gemm(p, s));
     return MDT_OK;
 }
@@ -932,6 +937,15 @@ extern "C" mdt_status mdt_op_xattn_apply(const mdt_xapply_args* a, void* stream)
     if (!mdt_xattn_apply_supported(a->D, a->H, a->Te, a->Ta))
         return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_apply: unsupported (D, H, Te, Ta) = (%d, %d, %d, %d)", a->D, a->H, a->Te, a->Ta);
     LAUNCH(mdt_launch_xattn_apply(*a, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_attn_proj(const mdt_gemm_args* proj, const float* qkv, int64_t ldq, int32_t hd, int32_t T,
+                                       int32_t causal, void* stream) {
+    if (!proj || !qkv || !proj->Wp || !proj->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_proj: null argument");
+    if (!mdt_attn_proj_supported(*proj, 8, hd, T, 0))
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_proj: needs 8 heads of 16/32/48/64 (K = 8 * hd), T = M <= 16, a plain projection");
+    LAUNCH(mdt_launch_attn_proj(*proj, qkv, ldq, 8, hd, T, causal, (hipStream_t)stream));
     return MDT_OK;
 }
 

@@ -290,6 +290,31 @@ def test_attention(lib, H, hd, Tq, Tk, causal, B):
     assert_close(run_attn(lib, q, k, v, H, causal), ref_attn(q, k, v, H, causal), rtol=1e-4, atol=1e-5, what="attention")
 
 
+@pytest.mark.parametrize("hd,T,causal,gated", [(48, 10, True, True), (48, 4, False, False), (16, 10, True, True), (32, 16, True, False),
+                                               (64, 10, False, True), (64, 16, True, True), (48, 1, True, False)])
+def test_attention_fused_into_projection_for_one_sample(lib, hd, T, causal, gated):
+    """mdt_op_attn_proj (rollout batch 1): out += gate * (attention(q, k, v) @ W^T + b) against float64."""
+    g = torch.Generator().manual_seed(hd + T)
+    H, D, N = 8, 8 * hd, 8 * hd
+    qkv = torch.randn(T, 3 * D, generator=g)
+    W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g) * 0.1
+    gate, y0 = torch.randn(6 * N, generator=g), torch.randn(T, N, generator=g)
+    att = ref_attn(qkv[None, :, :D], qkv[None, :, D:2 * D], qkv[None, :, 2 * D:], H, causal)[0].double()
+    upd = att @ W.double().T + b.double()
+    want = y0.double() + (gate[2 * N:3 * N].double() * upd if gated else upd)
+    qd, Pd, bd, gd, out = dev(qkv), pack(lib, W), dev(b), dev(gate), dev(y0).clone()
+    a = lib.GemmArgs()
+    a.A, a.lda, a.Wp, a.bias, a.out, a.ldo, a.M, a.N, a.K = None, D, Pd.data_ptr(), bd.data_ptr(), out.data_ptr(), N, T, N, D
+    a.shift_off = a.scale_off = -1
+    a.gate_off = 2 * N if gated else -1
+    a.mod = gd.data_ptr() if gated else None
+    a.residual, a.rows_per_sample, a.gin, a.gout = 1, T, 1, 1
+    lib.check(lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()))
+    assert_close(out.cpu(), want.float(), rtol=1e-4, atol=2e-5, what="attention + projection")
+    a.M = T + 1  # not one sample's rows
+    assert lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()) == 2
+
+
 def test_attention_matches_sdpa_is_causal_for_rectangular_scores(lib):
     """The reference calls F.scaled_dot_product_attention(is_causal=True) on 10x4 scores."""
     g = torch.Generator().manual_seed(77)

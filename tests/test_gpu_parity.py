@@ -259,6 +259,30 @@ def test_fails_loudly_instead_of_falling_back():
                      torch.ones(1, device="cuda"))
 
 
+def test_rollout_batch_one_matches_the_oracle_at_the_default_size():
+    """B = 1 (the reference's rollout batch) takes the small-batch kernels, incl. the self-attention fused into its output
+    projection (8 heads of 48): the fused sampler loop against the oracle's sample_ddim."""
+    from mdt_policy_amd import configs
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    from mdt_policy_amd import synthetic
+    cfg = configs.mdtv_default()
+    model = GCDenoiser(cfg, 0.5)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 5, "rich").items()}
+    model.load_state_dict(P, strict=False)
+    model = model.cuda().eval()
+    inp = {k: torch.from_numpy(v) for k, v in synthetic.sampler_inputs(1, cfg, 6).items()}
+    state = {"state_images": inp["state_images"], "modality": "lang"}
+    sig = gs.get_sigmas_exponential(5, 0.001, 80.0)
+    x_T = inp["noise"] * 80.0
+    want = O.sample_ddim(P, cfg, state, x_T, inp["goal"], sig)
+    with torch.no_grad():
+        got = gs.sample_ddim(model, {"state_images": inp["state_images"].cuda(), "modality": "lang"}, x_T.cuda(),
+                             inp["goal"].cuda(), sig)
+    assert_close(got.cpu(), want, what="B = 1 actions")
+
+
 def test_collapsed_and_explicit_cross_attention_paths_agree(monkeypatch):
     """MDT_HIP_XFOLD=0 keeps the q-GEMM / attention / c_proj-GEMM sequence; both must match the reference golden."""
     from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
