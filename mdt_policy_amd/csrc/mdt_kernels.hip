@@ -577,7 +577,8 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_attn_proj_smallm: ONE sample's self-attention fused into its output projection (rollout batch B = 1).
+// k_attn_proj_smallm: a sample's self-attention fused into its output projection (rollout batches: B = 1 and a few more;
+// one workgroup per 16 output columns and sample).
 //   out (+)= gate * (attn(q, k, v) @ Wp^T + bias)            rows T <= 16, 8 heads
 // The split-K small-M GEMM gives wave w the k-range of head w (8 waves = 8 heads, head_dim = K / 8), so each wave first
 // computes ITS head's attention output for the T rows (q / k / v of the head staged in the wave's own LDS region, scores
@@ -594,6 +595,8 @@ __global__ __launch_bounds__(512) void k_attn_proj_smallm(mdt_gemm_args a, const
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
     const int n_tile = blockIdx.x, K16 = a.K >> 4, D = a.K;
+    const int b = blockIdx.y;  // sample: rows [b * T, b * T + T) of qkv and of the output
+    qkv += (int64_t)b * T * ldq;
     // weight fragments of this head's k-range (in flight while the attention runs)
     const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
     f32x4 wf[KS];
@@ -660,10 +663,10 @@ __global__ __launch_bounds__(512) void k_attn_proj_smallm(mdt_gemm_args a, const
     const int ncol = n_tile * 16 + kq;
     const float* biasp = a.bias != nullptr ? a.bias : zeros;
     v = v + ldg4(biasp + ncol);
-    float* op = a.out + mc * a.ldo + ncol;
+    float* op = a.out + ((int64_t)b * T + mc) * a.ldo + ncol;
     if (a.residual) {
         f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
-        if (a.gate_off >= 0) g = ldg4(a.mod + a.gate_off + ncol);  // one sample: row 0 of the conditioning rows
+        if (a.gate_off >= 0) g = ldg4(a.mod + a.gate_off + (int64_t)b * a.mod_stride + ncol);  // the sample's conditioning row
         v = ldg4(op) + g * v;
     }
     if (mok) st4(op, v);
@@ -883,7 +886,8 @@ static bool attn_proj_disabled() {  // MDT_HIP_NO_ATTN_PROJ=1: the separate atte
 }
 
 bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope) {
-    return H == 8 && (hd == 16 || hd == 32 || hd == 48 || hd == 64) && p.K == H * hd && T >= 1 && T <= 16 && p.M == T && !rope &&
+    return H == 8 && (hd == 16 || hd == 32 || hd == 48 || hd == 64) && p.K == H * hd && T >= 1 && T <= 16 && p.M >= T &&
+           p.M % T == 0 && p.M / T <= 64 && (p.rows_per_sample == T || p.M == T) && !rope &&
            !(p.N & 15) && p.gin == 1 && p.gout == 1 && p.goff == 0 && !p.ln && p.act == MDT_ACT_NONE && p.rowvec == nullptr &&
            p.batch <= 1 && !attn_proj_disabled();
 }
@@ -898,7 +902,7 @@ static hipError_t launch_attn_proj_t(const mdt_gemm_args& p, const float* qkv, i
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_attn_proj_smallm<HD>), dim3(p.N >> 4), dim3(512), lds, s, p, qkv, ldq, T, causal,
+    hipLaunchKernelGGL((k_attn_proj_smallm<HD>), dim3(p.N >> 4, p.M / T), dim3(512), lds, s, p, qkv, ldq, T, causal,
                        1.0f / sqrtf((float)HD), g_zeros);
     return hipGetLastError();
 }

@@ -480,6 +480,13 @@ struct ModRef {
     ModRef(const float* m_, int64_t st, int sh, int sc, int g) : mod(m_), stride(st), shift(sh), scale(sc), gate(g) {}
 };
 
+// largest batch whose self-attention runs fused into the projection (MDT_HIP_ATTN_PROJ_MAX overrides; measured crossover)
+static int64_t g_attn_proj_max_batch() {
+    static int64_t v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_PROJ_MAX"); v = e ? atoll(e) : 8; }  // B = 2 / 4 / 8: 1.87 -> 1.71, 2.02 -> 1.85, 2.24 -> 2.07 ms; B = 16: 2.76 -> 2.83 (slower)
+    return v;
+}
+
 static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, bool causal,
                                 ModRef mr, hipStream_t s) {
     float* x = V.y;
@@ -492,7 +499,7 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
     mdt_gemm_args p = gemm_args(V.att, D, e.proj, x, D, M);
     p.residual = 1; p.rows_per_sample = T;
     if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
-    if (B == 1 && mdt_attn_proj_supported(p, m->H, m->hd, T, m->cfg.use_rot_embed)) {
+    if (B <= g_attn_proj_max_batch() && mdt_attn_proj_supported(p, m->H, m->hd, T, m->cfg.use_rot_embed)) {
         // rollout batch: attention and projection in one launch (the attention output never leaves the workgroup)
         LAUNCH(mdt_launch_attn_proj(p, V.qkv, 3 * D, m->H, m->hd, T, causal, s));
         return MDT_OK;
@@ -944,7 +951,8 @@ extern "C" mdt_status mdt_op_attn_proj(const mdt_gemm_args* proj, const float* q
                                        int32_t causal, void* stream) {
     if (!proj || !qkv || !proj->Wp || !proj->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_proj: null argument");
     if (!mdt_attn_proj_supported(*proj, 8, hd, T, 0))
-        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_proj: needs 8 heads of 16/32/48/64 (K = 8 * hd), T = M <= 16, a plain projection");
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_proj: needs 8 heads of 16/32/48/64 (K = 8 * hd), T <= 16 rows per sample "
+                                         "(M = samples * T, at most 64 samples), a plain projection");
     LAUNCH(mdt_launch_attn_proj(*proj, qkv, ldq, 8, hd, T, causal, (hipStream_t)stream));
     return MDT_OK;
 }

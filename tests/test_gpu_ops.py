@@ -290,28 +290,32 @@ def test_attention(lib, H, hd, Tq, Tk, causal, B):
     assert_close(run_attn(lib, q, k, v, H, causal), ref_attn(q, k, v, H, causal), rtol=1e-4, atol=1e-5, what="attention")
 
 
-@pytest.mark.parametrize("hd,T,causal,gated", [(48, 10, True, True), (48, 4, False, False), (16, 10, True, True), (32, 16, True, False),
-                                               (64, 10, False, True), (64, 16, True, True), (48, 1, True, False)])
-def test_attention_fused_into_projection_for_one_sample(lib, hd, T, causal, gated):
-    """mdt_op_attn_proj (rollout batch 1): out += gate * (attention(q, k, v) @ W^T + b) against float64."""
-    g = torch.Generator().manual_seed(hd + T)
+@pytest.mark.parametrize("hd,T,causal,gated,B", [(48, 10, True, True, 1), (48, 4, False, False, 1), (16, 10, True, True, 1),
+                                                 (32, 16, True, False, 1), (64, 10, False, True, 1), (64, 16, True, True, 2),
+                                                 (48, 1, True, False, 1), (48, 10, True, True, 5), (16, 4, False, True, 16)])
+def test_attention_fused_into_projection_per_sample(lib, hd, T, causal, gated, B):
+    """mdt_op_attn_proj (rollout batches): out += gate_b * (attention(q, k, v) @ W^T + b) per sample, against float64."""
+    g = torch.Generator().manual_seed(hd + T + B)
     H, D, N = 8, 8 * hd, 8 * hd
-    qkv = torch.randn(T, 3 * D, generator=g)
+    qkv = torch.randn(B * T, 3 * D, generator=g)
     W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g) * 0.1
-    gate, y0 = torch.randn(6 * N, generator=g), torch.randn(T, N, generator=g)
-    att = ref_attn(qkv[None, :, :D], qkv[None, :, D:2 * D], qkv[None, :, 2 * D:], H, causal)[0].double()
+    gate, y0 = torch.randn(B, 6 * N, generator=g), torch.randn(B * T, N, generator=g)
+    q3 = qkv.view(B, T, 3 * D)
+    att = ref_attn(q3[..., :D], q3[..., D:2 * D], q3[..., 2 * D:], H, causal).double().reshape(B * T, D)
     upd = att @ W.double().T + b.double()
-    want = y0.double() + (gate[2 * N:3 * N].double() * upd if gated else upd)
+    if gated:
+        upd = gate[:, 2 * N:3 * N].double().repeat_interleave(T, 0) * upd
+    want = y0.double() + upd
     qd, Pd, bd, gd, out = dev(qkv), pack(lib, W), dev(b), dev(gate), dev(y0).clone()
     a = lib.GemmArgs()
-    a.A, a.lda, a.Wp, a.bias, a.out, a.ldo, a.M, a.N, a.K = None, D, Pd.data_ptr(), bd.data_ptr(), out.data_ptr(), N, T, N, D
+    a.A, a.lda, a.Wp, a.bias, a.out, a.ldo, a.M, a.N, a.K = None, D, Pd.data_ptr(), bd.data_ptr(), out.data_ptr(), N, B * T, N, D
     a.shift_off = a.scale_off = -1
     a.gate_off = 2 * N if gated else -1
-    a.mod = gd.data_ptr() if gated else None
+    a.mod, a.mod_stride = (gd.data_ptr(), 6 * N) if gated else (None, 0)
     a.residual, a.rows_per_sample, a.gin, a.gout = 1, T, 1, 1
     lib.check(lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()))
     assert_close(out.cpu(), want.float(), rtol=1e-4, atol=2e-5, what="attention + projection")
-    a.M = T + 1  # not one sample's rows
+    a.M = 65 * T  # more samples than the fused kernel takes
     assert lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()) == 2
 
 
