@@ -16,7 +16,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, Optional
 
-import einops
 import torch
 from torch import nn
 
@@ -209,6 +208,8 @@ class MAPBlock(nn.Module):
 
 
 class MeanPooling(nn.Module):
+    """Mean over the tokens (reference transformer_blocks.py:873-880)."""
+
     def __init__(self, token_dim):
         super().__init__()
         self.token_dim = token_dim
@@ -217,31 +218,40 @@ class MeanPooling(nn.Module):
         return x.mean(dim=1).view(-1, self.token_dim)
 
 
+# clip_style -> (pooling kind, drop the goal token first)
+_CLIP_STYLES = {
+    "map": ("map", False), "map_state_only": ("map", True),
+    "mean_pooling": ("mean", False), "mean_pool_state_only": ("mean", True),
+    "mlp": ("mlp", False), "single_token": ("token", False), "multihead": ("keep", False),
+}
+
+
 class ClipStyleProjection(nn.Module):
-    """reference transformer_blocks.py:833-870"""
+    """Pools the (B, tokens, d) context into the embedding the contrastive loss compares (reference
+    transformer_blocks.py:833-870: same constructor, same ``latent_proj`` sub-module per style, same outputs)."""
 
     def __init__(self, clip_style, token_dim=384, clip_token_index=0, num_token=4):
         super().__init__()
+        if clip_style not in _CLIP_STYLES:
+            raise ValueError("Invalid clip_style. Expected 'map', 'mean_pooling', or 'single_token' or 'multihead'.")
         self.clip_style = clip_style
         self.clip_token_index = clip_token_index
-        if clip_style == 'map' or clip_style == 'map_state_only':
+        kind, self._state_only = _CLIP_STYLES[clip_style]
+        self._kind = kind
+        if kind == "map":
             self.latent_proj = MAPBlock(1, token_dim, 8, output_dim=token_dim)
-        elif clip_style == 'mean_pooling' or clip_style == 'mean_pool_state_only':
+        elif kind == "mean":
             self.latent_proj = MeanPooling(token_dim)
-        elif clip_style == 'mlp':
+        elif kind == "mlp":
             self.latent_proj = nn.Sequential(nn.Linear(num_token * token_dim, token_dim), nn.LayerNorm(token_dim), nn.Tanh())
-        elif clip_style == 'single_token':
+        else:  # one token / all tokens: nothing to learn
             self.latent_proj = nn.Identity()
-        elif clip_style == 'multihead':
-            self.latent_proj = nn.Identity()
-        else:
-            raise ValueError("Invalid clip_style. Expected 'map', 'mean_pooling', or 'single_token' or 'multihead'.")
 
     def forward(self, x):
-        if self.clip_style == 'single_token':
+        if self._kind == "token":
             x = x[:, self.clip_token_index, :]
-        elif self.clip_style == 'map_state_only' or self.clip_style == 'mean_pool_state_only':
+        elif self._state_only:
             x = x[:, 1:]
-        elif self.clip_style == 'mlp':
-            x = einops.rearrange(x, 'b t d -> b (t d)')
+        elif self._kind == "mlp":
+            x = x.flatten(1)
         return self.latent_proj(x)
