@@ -20,37 +20,14 @@ from .transformers.transformer_blocks import TransformerEncoder, TransformerDeco
 class MDTTransformer(HipScoreNetwork):
     _arch = "mdt"
 
-    def __init__(
-        self,
-        obs_dim: int,
-        goal_dim: int,
-        device: str,
-        goal_conditioned: bool,
-        action_dim: int,
-        embed_dim: int,
-        embed_pdrob: float,
-        attn_pdrop: float,
-        resid_pdrop: float,
-        mlp_pdrop: float,
-        n_dec_layers: int,
-        n_enc_layers: int,
-        n_heads: int,
-        goal_seq_len: int,
-        obs_seq_len: int,
-        action_seq_len: int,
-        proprio_dim: Optional[int] = None,
-        goal_drop: float = 0.1,
-        bias=False,
-        use_abs_pos_emb: bool = True,
-        use_rot_embed: bool = False,
-        rotary_xpos: bool = False,
-        linear_output: bool = True,
-        use_ada_conditioning: bool = False,
-        use_noise_encoder: bool = False,
-        latent_is_decoder: bool = False,
-        use_modality_encoder: bool = False,
-        use_mlp_goal: bool = False,
-    ):
+    def __init__(self, obs_dim: int, goal_dim: int, device: str, goal_conditioned: bool, action_dim: int,
+                 embed_dim: int, embed_pdrob: float, attn_pdrop: float, resid_pdrop: float, mlp_pdrop: float,
+                 n_dec_layers: int, n_enc_layers: int, n_heads: int, goal_seq_len: int, obs_seq_len: int,
+                 action_seq_len: int, proprio_dim: Optional[int] = None, goal_drop: float = 0.1, bias=False,
+                 use_abs_pos_emb: bool = True, use_rot_embed: bool = False, rotary_xpos: bool = False,
+                 linear_output: bool = True, use_ada_conditioning: bool = False,
+                 use_noise_encoder: bool = False, latent_is_decoder: bool = False,
+                 use_modality_encoder: bool = False, use_mlp_goal: bool = False):
         super().__init__()
         self._init_common()
         if not goal_conditioned and use_ada_conditioning:
