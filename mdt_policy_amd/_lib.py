@@ -165,6 +165,10 @@ SYMBOLS = [
     ("mdt_denoise_cached", _I32, [_VP, _VP, _VP, _I64, _I32, _VP, _VP]),
     ("mdt_forward", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _I64, _VP, _VP, _VP]),
     ("mdt_sample_ddim", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, C.POINTER(C.c_float), _I32, _I64, _VP, _VP, _VP]),
+    ("mdt_sample_ddim_dev", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _I32, _I64, _VP, _VP, _VP]),
+    ("mdt_persist_status", _I32, [_VP]),
+    ("mdt_persist_launches", _I64, [_VP]),
+    ("mdt_op_set_persist", None, [_I32]),
     ("mdt_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     ("mdt_flops_per_chunk", C.c_double, [_VP, _I32]),
     ("mdt_fnv1_32", C.c_uint32, [C.c_char_p, C.c_uint64, C.c_uint32]),

@@ -61,6 +61,8 @@ static inline mdt_gemm_args gemm_args(const float* A, int64_t lda, const Lin& w,
 }
 
 int mdt_gemm_kchunk(int K, int ln, int cap);
+// the current device's buffer of zeros (stands in for absent bias / LayerNorm-bias vectors); nullptr on failure
+const float* mdt_zeros();
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s);
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin, hipStream_t s);
 // one sample's self-attention fused into its output projection p (rollout batch 1); see mdt_kernels.hip
@@ -71,6 +73,7 @@ hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b,
                                 hipStream_t s);
 hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,
                                 hipStream_t s);
+hipError_t mdt_launch_ddim_steps(const float* sigmas_dev, int n, float* steps, hipStream_t s);
 hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t sstride, float sd, const float* Wa,
                                    const float* ba, float* y, int M, int A, int D, int rps, hipStream_t s);
 hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s);

@@ -51,6 +51,7 @@ extern "C" uint32_t mdt_fnv1_32(const void* buf, uint64_t len, uint32_t seed) {
 extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32)"; }
 
 #include "mdt_model_types.h"
+#include "mdt_persist.h"
 
 static const int MAX_WAYS = 4;
 
@@ -339,6 +340,7 @@ extern "C" mdt_status mdt_destroy(mdt_model* m) {
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     mdt_train_free(m);
+    mdt_persist_free(m);
     (void)hipFree(m->arena);
     (void)hipFree(m->staging);
     (void)hipFree(m->ws);
@@ -772,10 +774,11 @@ extern "C" mdt_status mdt_forward(mdt_model* m, const float* tokens, const float
     return mdt_denoise_cached(m, x, sigma, batch, 0, out, stream);
 }
 
-extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
-                                      int32_t modality, const float* x_T, const float* sigmas, int32_t n_steps,
-                                      int64_t batch, float* out, float* ctx_out, void* stream) {
-    if (!m || !x_T || !sigmas || !out || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_sample_ddim: bad argument");
+// sigmas_host or sigmas_dev (exactly one non-null): the n_steps + 1 noise levels
+static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                   int32_t modality, const float* x_T, const float* sigmas, const float* sigmas_dev,
+                                   int32_t n_steps, int64_t batch, float* out, float* ctx_out, void* stream) {
+    if (!m || !x_T || (!sigmas && !sigmas_dev) || !out || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_sample_ddim: bad argument");
     if (n_steps < 1 || n_steps > MAX_STEPS) return fail(MDT_ERR_INVALID_ARG, "n_steps must be 1..%d", MAX_STEPS);
     hipStream_t s = (hipStream_t)stream;
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
@@ -784,16 +787,20 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
     else { MDT_TRY(check_loaded(m)); MDT_TRY(mdt_reserve(m, batch)); }
     // per-step scalars, fp32 like the reference's 0-dim tensor math (gc_sampling.py:946-950):
     //   t = -ln(sigma); ratio = exp(-t_next)/exp(-t); coef = -expm1(-(t_next - t))
-    float* sh = m->steps_host.data();
-    for (int i = 0; i < n_steps; ++i) {
-        const float t = -logf(sigmas[i]), tn = -logf(sigmas[i + 1]);
-        const float h = tn - t;
-        sh[4 * i + 0] = expf(-tn) / expf(-t);
-        sh[4 * i + 1] = -expm1f(-h);
-        sh[4 * i + 2] = sigmas[i + 1];
-        sh[4 * i + 3] = sigmas[i];
+    if (sigmas_dev) {  // the schedule lives on the device (mdtv_agent.py:660-667): no copy, no synchronisation
+        LAUNCH(mdt_launch_ddim_steps(sigmas_dev, n_steps, m->steps, s));
+    } else {
+        float* sh = m->steps_host.data();
+        for (int i = 0; i < n_steps; ++i) {
+            const float t = -logf(sigmas[i]), tn = -logf(sigmas[i + 1]);
+            const float h = tn - t;
+            sh[4 * i + 0] = expf(-tn) / expf(-t);
+            sh[4 * i + 1] = -expm1f(-h);
+            sh[4 * i + 2] = sigmas[i + 1];
+            sh[4 * i + 3] = sigmas[i];
+        }
+        HIP_TRY(hipMemcpyAsync(m->steps, sh, (size_t)n_steps * 4 * sizeof(float), hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(hipMemcpyAsync(m->steps, sh, (size_t)n_steps * 4 * sizeof(float), hipMemcpyHostToDevice, s));
     MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));  // one row of conditioning vectors per step
     // ---- cut the batch into sample-aligned slices (multiples of 16 samples = 5 row tiles) on separate streams ----
     int ways = per_step_ctx ? 1 : m->ways;  // the encoder works on whole-batch buffers
@@ -821,6 +828,8 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
         LAUNCH(mdt_launch_action_embed(x_T + b0[w] * xs, m->steps + 3, 0, m->cfg.sigma_data, m->Wa, m->ba, V.y,
                                        (int)(nb * m->Ta), m->A, m->D, m->Ta, st[w]));
     }
+    if (!per_step_ctx && ways == 1 && mdt_persist_supported(m, batch))  // the whole step loop as ONE launch (mdt_persist.hip)
+        return mdt_persist_sample(m, batch, n_steps, x_T, out, s);
     for (int i = 0; i < n_steps; ++i) {
         const bool last = i == n_steps - 1;
         if (per_step_ctx)  // the reference leaves the LAST step's context in latent_encoder_emb
@@ -843,6 +852,20 @@ extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const f
         HIP_TRY(hipStreamWaitEvent(s, m->ev_join[w - 1], 0));
     }
     return MDT_OK;
+}
+
+extern "C" mdt_status mdt_sample_ddim(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                      int32_t modality, const float* x_T, const float* sigmas, int32_t n_steps,
+                                      int64_t batch, float* out, float* ctx_out, void* stream) {
+    if (!sigmas) return fail(MDT_ERR_INVALID_ARG, "mdt_sample_ddim: null sigmas");
+    return sample_ddim_impl(m, tokens, tokens2, goal, modality, x_T, sigmas, nullptr, n_steps, batch, out, ctx_out, stream);
+}
+
+extern "C" mdt_status mdt_sample_ddim_dev(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                          int32_t modality, const float* x_T, const float* sigmas_dev, int32_t n_steps,
+                                          int64_t batch, float* out, float* ctx_out, void* stream) {
+    if (!sigmas_dev) return fail(MDT_ERR_INVALID_ARG, "mdt_sample_ddim_dev: null sigmas");
+    return sample_ddim_impl(m, tokens, tokens2, goal, modality, x_T, nullptr, sigmas_dev, n_steps, batch, out, ctx_out, stream);
 }
 
 extern "C" mdt_status mdt_loss_fwd(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,

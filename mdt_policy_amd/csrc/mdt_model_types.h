@@ -92,6 +92,7 @@ struct mdt_model {
     bool xfold = false;
     float *xU = nullptr, *xW = nullptr, *xc = nullptr;  // [Ld][cap][H*Te][D], same, [Ld][cap][H*Te]
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    void* persist = nullptr;  // mdt_persist_state (mdt_persist.hip): the persistent decoder kernel's buffers
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 

@@ -1,0 +1,1077 @@
+// mdt_tiles.h -- the per-workgroup TILE BODIES of the decoder's kernels, shared by
+//   * mdt_kernels.hip : one launch per operation (grid = tiles), and
+//   * mdt_persist.hip : the persistent decoder kernel (one launch per sampler call; every XCD owns a slice of the
+//                       batch and walks the phase list, its workgroups meeting at a fence-free per-XCD barrier).
+// A body is written once; the template flag COH selects how ACTIVATIONS (anything another workgroup of the same launch
+// may have written) are read:
+//   COH = false : plain global loads (between launches the kernel boundary makes everything visible)
+//   COH = true  : `buffer_load_dwordx4 ... sc1` -- bypasses the reading CU's vector L1, which is never refreshed by
+//                 another CU's stores; served by the XCD's L2, where the producer's plain stores live once its
+//                 `s_waitcnt vmcnt(0)` has retired (MI355X_MICROARCH.md "inter-workgroup visibility";
+//                 tools/micro/persist_probe.hip: 0 stale words in 1500 phases x 32 peers x 16 KiB under uneven load).
+// Weights, LayerNorm vectors and the modulation table are written before the launch and always read with plain loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdt_internal.h"
+#include "mdt_device.h"
+
+// XCD-aware block id: the dispatcher places block b on XCD b % 8 (speed-only assumption); give every XCD a
+// contiguous range of logical tiles so the row tiles it touches stay in its private L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// the per-sample folded cross-attention matrices (98 KB per sample and block) are read once per launch by one workgroup,
+// but again at each of the 10 steps: plain loads (measured: non-temporal loads, -DMDT_NT_STREAM, cost 1.5 % at B = 256)
+#ifdef MDT_NT_STREAM
+#define MDT_LD_STREAM(p) __builtin_nontemporal_load((const f32x4*)(p))
+#else
+#define MDT_LD_STREAM(p) ldg4(p)
+#endif
+
+#ifdef MDT_NO_SAMPLE_REMAP  // A/B build: per-sample kernels keep sample b on XCD b % 8
+#define MDT_SAMPLE_REMAP(bid, n) (bid)
+#else
+#define MDT_SAMPLE_REMAP(bid, n) xcd_remap(bid, n)
+#endif
+
+// ---- activation loader ----
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <bool COH>
+struct ActLd;
+template <>
+struct ActLd<false> {
+    const float* base;
+    __device__ __forceinline__ explicit ActLd(const float* p) : base(p) {}
+    __device__ __forceinline__ f32x4 ld4(int64_t off) const { return ldg4(base + off); }
+    __device__ __forceinline__ float ld1(int64_t off) const { return base[off]; }
+};
+template <>
+struct ActLd<true> {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ explicit ActLd(const float* p)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0xffffffffu, 0x00020000)) {}
+    // 16 bytes at float offset `off`; off * 4 must stay below 4 GiB (checked by the host before it picks the
+    // persistent kernel)
+    __device__ __forceinline__ f32x4 ld4(int64_t off) const {
+        const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(off << 2), 0, 16 /* sc1 */);
+        return __builtin_bit_cast(f32x4, r);
+    }
+    __device__ __forceinline__ float ld1(int64_t off) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)(off << 2), 0, 16));
+    }
+};
+
+// prologue kinds: plain copy | LayerNorm | LayerNorm + modulate with ONE broadcast row (sampler: one sigma per
+// step) | LayerNorm + modulate with a per-sample row (GCDenoiser.forward / loss with per-sample sigma)
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_LN_MOD_BCAST = 2, PRO_LN_MOD_ROWS = 3 };
+
+// output store of the GEMM epilogues.  -DMDT_ST_WT (tuning build) makes it a write-through (sc0 sc1) store so that the
+// tile does not stay dirty in L2 until the end-of-kernel write-back.
+__device__ __forceinline__ void st4(float* p, f32x4 v) {
+#ifdef MDT_ST_WT
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    *(f32x4*)p = v;
+#endif
+}
+__device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a : b; }
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float hsq4(f32x4 v) { return (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+
+#if defined(MDT_DEBUG_TIMING) && defined(MDT_TILES_TIMING_OWNER)
+// tuning-only build (-DMDT_DEBUG_TIMING): thread 0 of every workgroup records shader-clock stamps of its phases
+__device__ unsigned long long* g_dbg_ts = nullptr;
+#define MDT_TS(i)                                                                         \
+    if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
+        g_dbg_ts[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();            \
+    }
+#define MDT_TS_HWID()                                                                     \
+    if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
+        unsigned hw, xcc;                                                                 \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                  \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                \
+        g_dbg_ts[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;      \
+    }
+#else
+#define MDT_TS(i)
+#define MDT_TS_HWID()
+#endif
+
+// batched wave reduction: N independent sums advance through the 6 butterfly steps together, so the ~100-cycle
+// ds_bpermute latency of a step is paid once per step instead of once per value
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float t[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], off, WAVE);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += t[i];
+    }
+}
+
+// The enclosing kernel says with KSTEP_PRIO whether a k-step's MFMA block runs at raised issue priority: it pays where
+// loader waves share the SIMDs with the MFMA waves (k_gemm_pipe: mlp.c_proj 37.6 -> 36.1 us) and costs 1-3 % where
+// every wave does both (k_gemm).  -DMDT_NO_KSTEP_PRIO switches it off for A/B runs.
+#ifdef MDT_NO_KSTEP_PRIO
+#define MDT_PRIO(x)
+#else
+#define MDT_PRIO(x) if constexpr (KSTEP_PRIO) __builtin_amdgcn_s_setprio(x);
+#endif
+#ifndef MDT_RING_ADD
+#define MDT_RING_ADD 0  // tuning builds: deeper weight-fragment rings (tools/gpu_ring_ab.sh)
+#endif
+// one k-step of the MFMA main loop (uses the enclosing kernel's ring / wp / ap / stride / acc / kg / K16): prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
+#define MDT_KSTEP(U, KC)                                                                                  \
+    {                                                                                                     \
+        const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                      \
+            ldg4(wp[j] + kpf * 256);                                                                      \
+        f32x4 avn[MTILES]; /* activation fragments of the NEXT k-step: their LDS latency hides under the MFMAs */ \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
+            *(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16);                           \
+        MDT_PRIO(1)                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                          \
+                _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                               \
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0);  \
+            }                                                                                             \
+        }                                                                                                 \
+        MDT_PRIO(0)                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
+    }
+
+// Geometry: NWAVES waves (4 or 8); tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns), full K.  Wave w owns NTW
+// column tiles and ALL row tiles of the workgroup tile, so a weight fragment is fetched once per workgroup and
+// reused from registers across the row tiles.  Wide tiles (8 waves x NTW 3..4) keep the number of workgroups that
+// re-read / re-normalise the same activation rows at N / (128*NTW) instead of N / 64.
+// Activation tile -> LDS (shared by the GEMM kernels): plain copy of the (MT x klen) chunk at column k0, or LayerNorm
+// (+ adaLN modulate) of whole rows (k0 = 0, klen = K <= 512).  All global loads of the phase are in flight together.
+template <int MTILES, int NWAVES, int PRO, bool COH>
+__device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* lds, int stride, int m0, int k0, int klen,
+                                                const float* __restrict__ zeros, int tid, int lane, int wave) {
+    constexpr int MT = MTILES * 16;
+    constexpr int NT = 64 * NWAVES;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int n4 = klen >> 2;
+    const ActLd<COH> LA(a.A);
+    if constexpr (PRO != PRO_PLAIN) {
+        // ---- LayerNorm (+ adaLN modulate) prologue: each wave owns a slab of RPW consecutive rows, whole
+        //      rows live in registers (K <= 512 -> two float4 per lane); single chunk by construction ----
+        constexpr int RPW = MT / NWAVES;
+        const int r0 = wave * RPW;
+        int cc[2];
+        bool cv[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            cv[p] = lane + 64 * p < n4;
+            cc[p] = 4 * min(lane + 64 * p, n4 - 1);
+        }
+        f32x4 v[RPW][2], w[2], bb[2];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t m = min(m0 + r0 + r, a.M - 1);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) v[r][p] = LA.ld4(m * a.lda + cc[p]);
+        }
+        const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            w[p] = ldg4(a.ln_w + cc[p]);
+            bb[p] = ldg4(lnb + cc[p]);
+        }
+        // modulation vectors, fetched up front.  BCAST: one row for the whole batch.  ROWS: a slab of RPW
+        // consecutive rows touches at most 2 samples when rows_per_sample >= RPW -> two candidates.
+        constexpr int NC = PRO == PRO_LN_MOD_ROWS ? 2 : 1;
+        f32x4 sh[NC][2], sc[NC][2];
+        int s_lo = 0;
+        bool slow_mod = false;
+        if constexpr (PRO == PRO_LN_MOD_BCAST) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                sh[0][p] = ldg4(a.mod + a.shift_off + cc[p]);
+                sc[0][p] = ldg4(a.mod + a.scale_off + cc[p]);
+            }
+        }
+        if constexpr (PRO == PRO_LN_MOD_ROWS) {
+            s_lo = min(m0 + r0, a.M - 1) / a.rows_per_sample;
+            const int s_hi = min(m0 + r0 + RPW - 1, a.M - 1) / a.rows_per_sample;
+            slow_mod = s_hi > s_lo + 1;
+            const float* mlo = a.mod + (int64_t)s_lo * a.mod_stride;
+            const float* mhi = a.mod + (int64_t)min(s_lo + 1, s_hi) * a.mod_stride;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                sh[0][p] = ldg4(mlo + a.shift_off + cc[p]);
+                sc[0][p] = ldg4(mlo + a.scale_off + cc[p]);
+                sh[NC - 1][p] = ldg4(mhi + a.shift_off + cc[p]);
+                sc[NC - 1][p] = ldg4(mhi + a.scale_off + cc[p]);
+            }
+        }
+        const float inv_k = 1.0f / (float)klen;
+        float red[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            red[r] = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                v[r][p] = sel4(cv[p], v[r][p], zero4);
+                red[r] += hsum4(v[r][p]);
+            }
+        }
+        wave_sum_n<RPW>(red);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float mean = red[r] * inv_k;
+            red[r] = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                v[r][p] = sel4(cv[p], v[r][p] - mean, zero4);
+                red[r] += hsq4(v[r][p]);
+            }
+        }
+        wave_sum_n<RPW>(red);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int m = m0 + r0 + r;
+            const float rstd = 1.0f / sqrtf(red[r] * inv_k + 1e-5f);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f32x4 y = v[r][p] * rstd * w[p] + bb[p];
+                if constexpr (PRO == PRO_LN_MOD_BCAST) y = sh[0][p] + y * sc[0][p];
+                if constexpr (PRO == PRO_LN_MOD_ROWS) {
+                    const int smp = min(m, a.M - 1) / a.rows_per_sample;
+                    f32x4 shv = sel4(smp == s_lo, sh[0][p], sh[NC - 1][p]);
+                    f32x4 scv = sel4(smp == s_lo, sc[0][p], sc[NC - 1][p]);
+                    if (slow_mod) {  // rows_per_sample < RPW: rare generic path, one round trip per row
+                        const float* mr = a.mod + (int64_t)smp * a.mod_stride;
+                        shv = ldg4(mr + a.shift_off + cc[p]);
+                        scv = ldg4(mr + a.scale_off + cc[p]);
+                    }
+                    y = shv + y * scv;
+                }
+                y = sel4(m < a.M, y, zero4);
+                if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
+            }
+        }
+    } else {
+        // ---- plain staging of the (MT x klen) activation chunk: 32 lanes sweep a row in 512-byte pieces,
+        //      NT/32 rows at a time; all loads of the chunk are in flight together (no divisions) ----
+        constexpr int RG = NT / 32;      // rows covered per sweep
+        constexpr int U = MT / RG;       // sweeps
+        const int rg = tid >> 5, l32 = tid & 31;
+        const int nv = (n4 + 31) >> 5;   // 512-byte pieces per row (<= 6 for kchunk <= 768)
+        for (int v0 = 0; v0 < nv; v0 += 3) {
+            f32x4 st[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = min(m0 + rg + RG * u, a.M - 1);
+#pragma unroll
+                for (int v = 0; v < 3; ++v)
+                    st[u][v] = LA.ld4(m * a.lda + k0 + 4 * min(l32 + 32 * (v0 + v), n4 - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = rg + RG * u;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int c4 = l32 + 32 * (v0 + v);
+                    if (c4 < n4) *(f32x4*)(lds + row * stride + 4 * c4) = sel4(m0 + row < a.M, st[u][v], zero4);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused GEMM tile:  out = epilogue( prologue(A) @ W^T ) for row tile `by` and column tile `bx`
+//   64 * NWAVES threads; tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns); full K.
+//   wave w owns NTW column tiles and ALL row tiles of the workgroup tile.
+//   Memory-level parallelism rule for every phase: all global loads of a phase are issued back to back from
+//   clamped (always valid) addresses, consumed afterwards; validity is applied by selects / masked stores.  A
+//   branch around a load makes hipcc wait vmcnt(0) right behind it -- one full L2 round trip per load.
+// No thread leaves early (the persistent kernel follows the tile with a barrier).
+// ------------------------------------------------------------------------------------------------
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES, bool COH>
+__device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, int by, int bx, float* lds,
+                                          const float* __restrict__ zeros, int tid) {
+    MDT_TS(0)
+    MDT_TS_HWID()
+    constexpr int MT = MTILES * 16;
+    constexpr bool KSTEP_PRIO = false;
+    // weight-fragment ring: R-1 k-steps of 1-KiB loads in flight per column tile.  A k-step is only 8 MFMAs
+    // (256 pipe cycles) with one column tile per wave, so the narrow variants need the deeper ring to cover L2 latency.
+    constexpr int R = (NTW == 1 ? 6 : (NTW == 2 ? 4 : 3)) + MDT_RING_ADD;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m0 = by * MT;
+    const int N16 = a.N >> 4, K16 = a.K >> 4;
+    const int nt0 = (bx * NWAVES + wave) * NTW;
+    const bool active = nt0 < N16;  // wave has at least one real column tile
+    const int stride = kchunk + 4;  // floats; 16-byte aligned rows, breaks the power-of-two bank stride
+    const ActLd<COH> LO(a.out);
+
+    // ---- weight stream: one continuous k16 index over the whole K, independent of the LDS chunking ----
+    const float* wp[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = min(nt0 + j, N16 - 1);  // clamp: a partial last wave re-reads a valid tile
+        wp[j] = a.Wp + (int64_t)nt * K16 * 256 + lane * 4;
+    }
+    f32x4 ring[R][NTW];
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
+
+    f32x4 acc[MTILES][NTW];
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
+
+    // ---- epilogue operands (bias / gate / residual) are requested NOW, in the same latency window as the
+    //      activation tile: vmcnt retires loads in order, so a load issued later would stall the weight ring ----
+    const int nq = 4 * (lane >> 4);
+    const bool gated = RES && a.gate_off >= 0;
+    int ncol[NTW];
+    constexpr int NRES = RES ? NTW : 1;  // residual GEMMs (out += gate * value) also prefetch gate and old value
+    f32x4 bias_v[NTW], gate_v[MTILES][NRES], res_v[MTILES][NRES];
+    int64_t ooff[MTILES];
+    {
+        const float* biasp = a.bias != nullptr ? a.bias : zeros;
+        const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
+            bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            const int m = min(m0 + i * 16 + (lane & 15), a.M - 1);
+            const int64_t orow =
+                a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
+            ooff[i] = orow * a.ldo;
+            if constexpr (RES) {
+                const float* gp = zeros;
+                if (gated)
+                    gp = a.mod + a.gate_off +
+                         (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    gate_v[i][j] = ldg4(gp + ncol[j]);
+                    res_v[i][j] = LO.ld4(ooff[i] + ncol[j]);
+                }
+            }
+        }
+    }
+
+    int kg = 0;  // global k16 index of the weight stream
+    for (int k0 = 0; k0 < a.K; k0 += kchunk) {
+        const int klen = min(kchunk, a.K - k0);
+        if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
+        gemm_stage_tile<MTILES, NWAVES, PRO, COH>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave);
+        MDT_TS(1)
+        __syncthreads();
+        MDT_TS(2)
+
+        if (active) {
+            const int nk = klen >> 4;
+            const float* ap = lds + (lane & 15) * stride + 4 * (lane >> 4);
+            f32x4 av[MTILES];
+#pragma unroll
+            for (int i = 0; i < MTILES; ++i) av[i] = *(const f32x4*)(ap + i * 16 * stride);
+            int kc = 0;
+            for (; kc + R <= nk; kc += R) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
+            }
+            if (kc < nk) {  // tail: nk % R steps, then rotate the ring so that slot 0 is the next k-step again
+                const int rem = nk - kc;
+#pragma unroll
+                for (int u = 0; u < R - 1; ++u)
+                    if (u < rem) MDT_KSTEP(u, kc + u)
+                for (int r = 0; r < rem; ++r) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const f32x4 first = ring[0][j];
+#pragma unroll
+                        for (int u = 0; u + 1 < R; ++u) ring[u][j] = ring[u + 1][j];
+                        ring[R - 1][j] = first;
+                    }
+                }
+            }
+            kg += nk;
+        }
+    }
+
+    // ---- epilogue: lane holds out[m0 + i*16 + lane%16][n .. n+3], n = tile*16 + 4*(lane/16) ----
+    MDT_TS(3)
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            const bool mok = m0 + i * 16 + (lane & 15) < a.M;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
+                if constexpr (RES) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
+                if (mok && nt0 + j < N16) st4(a.out + ooff[i] + ncol[j], v);
+            }
+        }
+    }
+    MDT_TS(4)
+}
+
+// ------------------------------------------------------------------------------------------------
+// small-M GEMM tile: 16 rows (m0 ..) x 16 columns (n_tile), K split over the workgroup's 8 waves (interleaved k16
+// steps), every wave keeps 4 weight fragments + 4 activation fragments in flight, partial 16x16 tiles meet in LDS
+// and wave 0 runs the epilogue.  Activations come straight from global memory in MFMA-fragment order (lane: row l%16,
+// 4 consecutive k), LayerNorm / modulate applied in registers from per-row statistics the workgroup computes first.
+// 512 threads.  s_stat: 32 floats, red: 8*64*4 floats of LDS.
+// ------------------------------------------------------------------------------------------------
+template <bool COH>
+__device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_tile, int m0, float* s_stat, float* red,
+                                                 const float* __restrict__ zeros, int tid) {
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, wave = tid >> 6;
+    const int K16 = a.K >> 4;
+    const ActLd<COH> LA(a.A), LO(a.out);
+    float* s_mean = s_stat;
+    float* s_rstd = s_stat + 16;
+    if (a.ln) {  // row statistics: 32 threads per row, whole row in registers (K <= 512)
+        const int r = tid >> 5, l32 = tid & 31;
+        const int64_t m = min(m0 + r, a.M - 1);
+        const int n4 = a.K >> 2;
+        f32x4 v[4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = l32 + 32 * i;
+            v[i] = LA.ld4(m * a.lda + 4 * min(c4, n4 - 1));
+            v[i] = sel4(c4 < n4, v[i], zero4);
+            sum += hsum4(v[i]);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)a.K;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = l32 + 32 * i;
+            if (c4 < n4) sq += hsq4(v[i] - mean);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        if (l32 == 0) { s_mean[r] = mean; s_rstd[r] = 1.0f / sqrtf(sq / (float)a.K + 1e-5f); }
+        __syncthreads();
+    }
+    const int mrow = m0 + (lane & 15);
+    const int64_t mc = min(mrow, a.M - 1);
+    const bool mok = mrow < a.M;
+    const int kq = 4 * (lane >> 4);
+    const int64_t xoff = mc * a.lda + kq;
+    const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
+    const bool modded = a.ln && a.mod != nullptr && a.shift_off >= 0;
+    const float* mrw = modded ? a.mod + (a.mod_stride == 0 ? 0 : (mc / a.rows_per_sample) * a.mod_stride) : zeros;
+    const float mean = a.ln ? s_mean[lane & 15] : 0.f, rstd = a.ln ? s_rstd[lane & 15] : 1.f;
+    f32x4 acc = zero4;
+    for (int ks0 = wave; ks0 < K16; ks0 += 32) {  // 4 of this wave's k16 steps per round, all loads issued first
+        f32x4 wf[4], xv[4], lw[4], lb[4], sh[4], sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = min(ks0 + 8 * u, K16 - 1);
+            wf[u] = ldg4(wbase + ks * 256);
+            xv[u] = LA.ld4(xoff + ks * 16);
+            if (a.ln) {
+                lw[u] = ldg4(a.ln_w + ks * 16 + kq);
+                lb[u] = a.ln_b ? ldg4(a.ln_b + ks * 16 + kq) : zero4;
+                if (modded) { sh[u] = ldg4(mrw + a.shift_off + ks * 16 + kq); sc[u] = ldg4(mrw + a.scale_off + ks * 16 + kq); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ks0 + 8 * u < K16) {
+                f32x4 x = xv[u];
+                if (a.ln) {
+                    x = (x - mean) * rstd * lw[u] + lb[u];
+                    if (modded) x = sh[u] + x * sc[u];
+                }
+                x = sel4(mok, x, zero4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][e], x[e], acc, 0, 0, 0);
+            }
+        }
+    }
+    *(f32x4*)(red + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 v = *(const f32x4*)(red + lane * 4);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)(red + (w * 64 + lane) * 4);
+        // ---- epilogue (as gemm_tile): lane holds out[mrow][ncol .. ncol+3]
+        const int ncol = n_tile * 16 + kq;
+        const float* biasp = a.bias != nullptr ? a.bias : zeros;
+        const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+        v = apply_act(v + ldg4(biasp + ncol) + ldg4(rvp + ncol), a.act);
+        const int64_t orow = a.gin == 1 ? mc * a.gout + a.goff : (mc / a.gin) * a.gout + (mc % a.gin) + a.goff;
+        const int64_t oo = orow * a.ldo + ncol;
+        if (a.residual) {
+            f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (a.gate_off >= 0)
+                g = ldg4(a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (mc / a.rows_per_sample) * a.mod_stride) + ncol);
+            v = LO.ld4(oo) + g * v;
+        }
+        if (mok) st4(a.out + oo, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attn_proj tile: sample b's self-attention fused into 16 columns (n_tile) of its output projection.
+//   out (+)= gate * (attn(q, k, v) @ Wp^T + bias)            rows T <= 16, 8 heads
+// The split-K small-M GEMM gives wave w the k-range of head w (8 waves = 8 heads, head_dim = K / 8), so each wave first
+// computes ITS head's attention output for the T rows (q / k / v of the head staged in the wave's own LDS region, scores
+// and softmax by the wave alone, no workgroup barrier) and then feeds it to the MFMAs as the activation fragment.  Every
+// workgroup (16 output columns) repeats the T x T attention -- 19 kFLOP per head -- in exchange for one launch and one
+// round trip of the attention output per block.  The weight fragments are requested before the attention starts.
+// lds: 8 * (3*16*(HD+4) + 16*17) floats; red: 8*64*4 floats.  512 threads.
+// ------------------------------------------------------------------------------------------------
+template <int HD, bool COH>
+__device__ __forceinline__ void attn_proj_tile(const mdt_gemm_args& a, const float* __restrict__ qkv_base, int64_t ldq, int T,
+                                               int causal, float scale, int n_tile, int b, float* lds, float* red,
+                                               const float* __restrict__ zeros, int tid) {
+    constexpr int ST = HD + 4, H4 = HD / 4, KS = HD / 16;  // padded row stride, float4 per row, k16 steps per head
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, h = tid >> 6;
+    const int K16 = a.K >> 4, D = a.K;
+    const ActLd<COH> LQ(qkv_base), LO(a.out);
+    const int64_t qoff = (int64_t)b * T * ldq;  // rows [b * T, b * T + T) of qkv and of the output
+    // weight fragments of this head's k-range (in flight while the attention runs)
+    const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
+    f32x4 wf[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) wf[u] = ldg4(wbase + (h * KS + u) * 256);
+    float* qs = lds + h * (3 * 16 * ST + 16 * 17);  // [16][ST] q, later the attention output
+    float* ks = qs + 16 * ST;
+    float* vs = ks + 16 * ST;
+    float* P = vs + 16 * ST;                         // [16][17]
+    for (int i = lane; i < T * H4; i += 64) {
+        const int t = i / H4, c = i - t * H4;
+        const int64_t row = qoff + (int64_t)t * ldq + h * HD + 4 * c;
+        *(f32x4*)(qs + t * ST + 4 * c) = LQ.ld4(row);
+        *(f32x4*)(ks + t * ST + 4 * c) = LQ.ld4(row + D);
+        *(f32x4*)(vs + t * ST + 4 * c) = LQ.ld4(row + 2 * D);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < T * T; e += 64) {
+        const int i = e / T, j = e - i * T;
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < H4; ++c) {
+            const f32x4 qv = *(const f32x4*)(qs + i * ST + 4 * c), kv = *(const f32x4*)(ks + j * ST + 4 * c);
+            sacc = fmaf(qv.x, kv.x, sacc); sacc = fmaf(qv.y, kv.y, sacc); sacc = fmaf(qv.z, kv.z, sacc); sacc = fmaf(qv.w, kv.w, sacc);
+        }
+        P[i * 17 + j] = (!causal || j <= i) ? sacc * scale : -INFINITY;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < T) {
+        float* row = P + lane * 17;
+        float mx = row[0];
+        for (int j = 1; j < T; ++j) mx = fmaxf(mx, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { row[j] = expf(row[j] - mx); sum += row[j]; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < T; ++j) row[j] *= inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 16 * H4; i += 64) {  // rows T..15 of the activation tile are zero
+        const int t = i / H4, c = i - t * H4;
+        f32x4 o = zero4;
+        if (t < T)
+            for (int j = 0; j < T; ++j) o += P[t * 17 + j] * *(const f32x4*)(vs + j * ST + 4 * c);
+        *(f32x4*)(qs + t * ST + 4 * c) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- this head's slice of the projection: lane holds row lane % 16, k = 16 u + 4 (lane / 16) .. + 3 ----
+    const int mrow = lane & 15, kq = 4 * (lane >> 4);
+    f32x4 acc = zero4;
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+        const f32x4 x = *(const f32x4*)(qs + mrow * ST + 16 * u + kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][e], x[e], acc, 0, 0, 0);
+    }
+    *(f32x4*)(red + (h * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (h == 0) {
+        f32x4 v = *(const f32x4*)(red + lane * 4);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)(red + (w * 64 + lane) * 4);
+        const bool mok = mrow < T;
+        const int64_t mc = min(mrow, T - 1);
+        const int ncol = n_tile * 16 + kq;
+        const float* biasp = a.bias != nullptr ? a.bias : zeros;
+        v = v + ldg4(biasp + ncol);
+        const int64_t oo = ((int64_t)b * T + mc) * a.ldo + ncol;
+        if (a.residual) {
+            f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (a.gate_off >= 0) g = ldg4(a.mod + a.gate_off + (int64_t)b * a.mod_stride + ncol);  // the sample's conditioning row
+            v = LO.ld4(oo) + g * v;
+        }
+        if (mok) st4(a.out + oo, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small attention tile: sample b, head group hg of nhg (Hl = H / nhg heads, a contiguous column range of q/k/v).  The
+// rows (all Hl heads) are staged in LDS with batched 16-byte loads, then thread (head, query row) runs
+// softmax(q k^T) v out of LDS with the scores in registers.  10x10 / 10x4 / 4x4 score matrices are 0.1 % of the FLOPs,
+// so this stays on the VALU.  256 threads (tid 0..255); `lds` is this group's own region; `sync` is the barrier the 256
+// threads share with whoever else runs the same code (a workgroup barrier).
+// TKC: compile-time bound on the number of keys (4 / 10 / 16, the smallest >= Tk), ROPE: rotary embedding on q/k.
+// With both fixed the score / softmax / PV loops are straight-line code over clamped rows with select masks, so the
+// compiler can batch the LDS reads instead of waiting on each one behind a branch.
+// ------------------------------------------------------------------------------------------------
+template <int HD, int TKC, bool ROPE, bool COH>
+__device__ __forceinline__ void attn_tile(const mdt_attn_args& a, const float* __restrict__ rope_cos,
+                                          const float* __restrict__ rope_sin, float scale, int b, int hg, int nhg, float* lds,
+                                          int tid) {
+    MDT_TS(0)
+    MDT_TS_HWID()
+    constexpr int ROT = 32;  // rotary dims (position_embeddings.py / transformer_blocks.py:108)
+    const int Hl = a.H / nhg;              // heads of this group
+    const int coff = hg * Hl * HD;         // first column
+    const int D = Hl * HD, d4 = D >> 2;    // row length staged in LDS
+    // q / k / v live in one allocation (the handle's workspace): one loader at the lowest of the three pointers
+    const float* lo = a.q < a.k ? a.q : a.k;
+    lo = lo < a.v ? lo : a.v;
+    const ActLd<COH> LQ(lo);
+    const int64_t oq = a.q - lo, ok = a.k - lo, ov = a.v - lo;
+    float* qs = lds;                  // [Tq][D]
+    float* ks = qs + a.Tq * D;        // [Tk][D]
+    float* vs = ks + a.Tk * D;        // [Tk][D]
+    const int nq = a.Tq * d4, nkv = a.Tk * d4, total = nq + 2 * nkv;
+    constexpr int BATCH = 12;
+    for (int base = 0; base < total; base += 256 * BATCH) {
+        f32x4 t[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = min(base + u * 256 + tid, total - 1);
+            int64_t src;
+            if (idx < nq) {
+                const int r = idx / d4;
+                src = oq + (int64_t)(b * a.Tq + r) * a.ldq + coff + 4 * (idx - r * d4);
+            } else if (idx < nq + nkv) {
+                const int i2 = idx - nq, r = i2 / d4;
+                src = ok + (int64_t)(b * a.Tk + r) * a.ldkv + coff + 4 * (i2 - r * d4);
+            } else {
+                const int i2 = idx - nq - nkv, r = i2 / d4;
+                src = ov + (int64_t)(b * a.Tk + r) * a.ldkv + coff + 4 * (i2 - r * d4);
+            }
+            t[u] = LQ.ld4(src);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < total) *(f32x4*)(lds + 4 * idx) = t[u];  // q | k | v are laid out back to back
+        }
+    }
+    MDT_TS(1)
+    __syncthreads();
+    MDT_TS(2)
+    // ---- compute: LP lanes share one (head, query row); each owns a DS-wide slice of the head dimension ----
+    constexpr int LP = HD == 48 ? 3 : (HD >= 32 ? 2 : 1);
+    constexpr int DS = HD / LP;  // 16 or 32 dims per lane
+    float* part = vs + a.Tk * D;  // [pairs][16 keys][LP] partial scores
+    const int npairs = Hl * a.Tq;
+    const int pr = min(tid % npairs, npairs - 1), ps = min(tid / npairs, LP - 1);  // pair, slice (clamped: idle lanes recompute)
+    const bool live = tid < npairs * LP;
+    const int t = pr % a.Tq, h = pr / a.Tq;
+    const int nk = a.causal ? min(a.Tk, t + 1) : a.Tk;
+    const int d0 = h * HD + ps * DS;
+    float q[DS];
+#pragma unroll
+    for (int d = 0; d < DS; d += 4) {
+        const f32x4 x = *(const f32x4*)(qs + t * D + d0 + d);
+        q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+    }
+    if constexpr (ROPE) {
+#pragma unroll
+        for (int i = 0; i < DS / 2; ++i) {
+            const int gi = (ps * DS) / 2 + i;  // rotary pair index inside the head
+            if (gi < ROT / 2) {
+                const float c = rope_cos[t * 16 + gi], sn = rope_sin[t * 16 + gi];
+                const float x1 = q[2 * i], x2 = q[2 * i + 1];
+                q[2 * i] = x1 * c - x2 * sn;
+                q[2 * i + 1] = x2 * c + x1 * sn;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) {
+        const int jc = min(j, a.Tk - 1);
+        const float* kp = ks + jc * D + d0;
+        float kr[DS];
+#pragma unroll
+        for (int d = 0; d < DS; d += 4) {
+            const f32x4 x = *(const f32x4*)(kp + d);
+            kr[d] = x.x; kr[d + 1] = x.y; kr[d + 2] = x.z; kr[d + 3] = x.w;
+        }
+        if constexpr (ROPE) {
+#pragma unroll
+            for (int i = 0; i < DS / 2; ++i) {
+                const int gi = (ps * DS) / 2 + i;
+                if (gi < ROT / 2) {
+                    const float c = rope_cos[jc * 16 + gi], sn = rope_sin[jc * 16 + gi];
+                    const float x1 = kr[2 * i], x2 = kr[2 * i + 1];
+                    kr[2 * i] = x1 * c - x2 * sn;
+                    kr[2 * i + 1] = x2 * c + x1 * sn;
+                }
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < DS; ++d) dot = fmaf(q[d], kr[d], dot);
+        if (live) part[(pr * 16 + j) * LP + ps] = dot;
+    }
+    MDT_TS(3)
+    __syncthreads();
+    float sc[TKC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) {
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < LP; ++u) dot += part[(pr * 16 + j) * LP + u];  // fixed order: deterministic
+        sc[j] = j < nk ? dot * scale : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) {
+        sc[j] = expf(sc[j] - mx);  // exp(-inf) = 0 for masked keys; key 0 is always visible so mx is finite
+        sum += sc[j];
+    }
+    const float inv = 1.0f / sum;
+    float o[DS];
+#pragma unroll
+    for (int d = 0; d < DS; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) {
+        const float p = sc[j] * inv;
+        const float* vp = vs + min(j, a.Tk - 1) * D + d0;
+#pragma unroll
+        for (int d = 0; d < DS; d += 4) {
+            const f32x4 x = *(const f32x4*)(vp + d);
+            o[d] = fmaf(p, x.x, o[d]); o[d + 1] = fmaf(p, x.y, o[d + 1]);
+            o[d + 2] = fmaf(p, x.z, o[d + 2]); o[d + 3] = fmaf(p, x.w, o[d + 3]);
+        }
+    }
+    if (live) {
+        float* op = a.out + (int64_t)(b * a.Tq + t) * a.ldo + coff + d0;
+#pragma unroll
+        for (int d = 0; d < DS; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
+    }
+    MDT_TS(4)
+}
+
+__device__ __forceinline__ float edm_c_in(float sigma, float sd) { return 1.0f / sqrtf(sigma * sigma + sd * sd); }
+
+// ------------------------------------------------------------------------------------------------
+// action head rows: decoder LN -> action_pred -> EDM combine -> (DDIM update) -> (next step's embedding) for rows
+// base, base + 1 (one wave per RW = 2 rows so that the action_pred / action_emb weight fragments it fetches are used
+// twice); AMAX (8 or 16) bounds the action dimension at compile time so no load sits behind a branch.
+// The caller guarantees base < a.M (wave-uniform).
+// ------------------------------------------------------------------------------------------------
+template <int AMAX, bool COH>
+__device__ __forceinline__ void head_rows(const mdt_head_args& a, int base, int lane, const float* __restrict__ zeros) {
+    constexpr int RW = 2;
+    const int n4 = a.D >> 2;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const ActLd<COH> LY(a.y), LX(a.x);
+    int cc[2];
+    bool cv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        cv[p] = lane + 64 * p < n4;
+        cc[p] = 4 * min(lane + 64 * p, n4 - 1);
+    }
+    int64_t row[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) row[r] = min(base + r, a.M - 1);
+    // ---- every global operand is requested up front (clamped addresses, no load behind a branch) ----
+    f32x4 v[RW][2], w[2], bb[2], wp[AMAX][2];
+    float xin[RW][AMAX], bpv[AMAX], sigma[RW];
+    const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) v[r][p] = LY.ld4(row[r] * a.D + cc[p]);
+        w[p] = ldg4(a.ln_w + cc[p]);
+        bb[p] = ldg4(lnb + cc[p]);
+    }
+#pragma unroll
+    for (int c = 0; c < AMAX; ++c) {
+        const int ce = min(c, a.A - 1);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wp[c][p] = ldg4(a.Wp + (int64_t)ce * a.D + cc[p]);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) xin[r][c] = LX.ld1(row[r] * a.A + ce);
+        bpv[c] = a.bp[ce];
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) sigma[r] = a.sigma[(row[r] / a.rows_per_sample) * a.sigma_stride];
+    // operands of the fused next-step embedding travel in the same latency window (Wa is the (A, D) image)
+    const float* Wa = a.y_next != nullptr ? a.Wa : a.Wp;
+    const float* bap = a.y_next != nullptr ? a.ba : zeros;
+    f32x4 wa[AMAX][2], ba4[2];
+#pragma unroll
+    for (int c = 0; c < AMAX; ++c)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wa[c][p] = ldg4(Wa + (int64_t)min(c, a.A - 1) * a.D + cc[p]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ba4[p] = ldg4(bap + cc[p]);
+    float ratio = 0.f, coef = 0.f, sig_next = 1.f;
+    if (a.mode == MDT_HEAD_DDIM) {
+        ratio = a.step[0];
+        coef = a.step[1];
+        sig_next = a.step[2];
+    }
+    // ---- LayerNorm of the rows ----
+    const float inv_d = 1.0f / (float)a.D;
+    float red[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        red[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p], zero4); red[r] += hsum4(v[r][p]); }
+    }
+    wave_sum_n<RW>(red);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float mean = a.no_ln ? 0.f : red[r] * inv_d;
+        red[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p] - mean, zero4); red[r] += hsq4(v[r][p]); }
+    }
+    wave_sum_n<RW>(red);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float rstd = 1.0f / sqrtf(red[r] * inv_d + 1e-5f);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) v[r][p] = sel4(cv[p] && !a.no_ln, v[r][p] * rstd * w[p] + bb[p], v[r][p]);
+    }
+    // ---- action_pred: RW * AMAX dot products reduced together ----
+    float res[RW * AMAX];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                s += (v[r][p].x * wp[c][p].x + v[r][p].y * wp[c][p].y) + (v[r][p].z * wp[c][p].z + v[r][p].w * wp[c][p].w);
+            res[r * AMAX + c] = s;
+        }
+    wave_sum_n<RW * AMAX>(res);
+    const float sd = a.sigma_data;
+    const float cin_next = edm_c_in(sig_next, sd);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float den2 = sigma[r] * sigma[r] + sd * sd;
+        const float c_skip = sd * sd / den2;
+        const float c_out = sigma[r] * sd / sqrtf(den2);
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c) {
+            const float F = res[r * AMAX + c] + bpv[c];
+            float o = F;
+            if (a.mode != MDT_HEAD_RAW) {
+                const float den = F * c_out + xin[r][c] * c_skip;
+                o = a.mode == MDT_HEAD_DDIM ? ratio * xin[r][c] + coef * den : den;
+            }
+            res[r * AMAX + c] = o;
+        }
+    }
+    // all lanes hold all results (xor-butterfly sums); lanes 0..A-1 store one each
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c)
+            if (c < a.A && lane == c && base + r < a.M) a.out[row[r] * a.A + c] = res[r * AMAX + c];
+    if (a.y_next != nullptr) {
+        f32x4 acc[RW][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r][p] = ba4[p];
+#pragma unroll
+        for (int c = 0; c < AMAX; ++c)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float xv = c < a.A ? res[r * AMAX + c] * cin_next : 0.f;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) acc[r][p] += xv * wa[c][p];
+            }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (cv[p] && base + r < a.M) *(f32x4*)(a.y_next + row[r] * a.D + cc[p]) = acc[r][p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// collapsed cross-attention of sample b (see k_xattn_fold / k_xattn_apply in mdt_kernels.hip).  Threads 0..383 work
+// (wider workgroups idle their other threads but must call: the body holds workgroup barriers).  Work split:
+//   dots : thread = (pair p = (h, j), segment of 32 features): P * D/32 <= 384 items, U segment in 8 VGPR quads
+//   comb : thread = (float4 column c4, row group tg): D/4 * ntg <= 384 items, all P Wf quads of the column in VGPRs
+// Every global operand (U, Wf, y rows, LayerNorm vectors) is requested before the first dependent instruction.
+// lds: Ta*D + Ta*NP*(D/32) + Ta*NP floats.
+// ------------------------------------------------------------------------------------------------
+template <int NP, bool COH>
+__device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, float* lds, const float* __restrict__ zeros, int tid) {
+    constexpr int NT = 384, RMAX = 4;
+    MDT_TS(0)
+    MDT_TS_HWID()
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, wave = tid >> 6;
+    const int D = a.D, Ta = a.Ta, Te = a.Te;
+    const int n4 = D >> 2, NS = D >> 5;                  // float4 per row, 32-feature segments per row
+    float* xn = lds;                                     // [Ta][D] normalised rows
+    float* part = xn + Ta * D;                           // [Ta][NP][NS] partial dots
+    float* prob = part + Ta * NP * NS;                   // [Ta][NP] probabilities
+    const float* Ub = a.U + (int64_t)b * NP * D;
+    const float* Wb = a.Wf + (int64_t)b * NP * D;
+    const ActLd<COH> LY(a.y);
+    const int64_t yoff = (int64_t)b * Ta * D;
+    float* yb = a.y + yoff;
+
+    // Loads are requested in the order they are consumed (vmcnt retires in order): the sample's rows and the ln3
+    // vectors first, then the U segment, then the Wf column and the old rows for the residual.
+    // ---- LayerNorm (ln3: weight + bias) of the sample's rows: wave w < 6 takes rows w, w+6, ... ----
+    int cc[2];
+    bool cv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        cv[p] = lane + 64 * p < n4;
+        cc[p] = 4 * min(lane + 64 * p, n4 - 1);
+    }
+    constexpr int RW = 3;  // rows per wave (Ta <= 16 < 6 * 3)
+    const int lw6 = min(wave, 5);
+    f32x4 v[RW][2], lw[2], lb[2];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) v[r][p] = LY.ld4(yoff + (int64_t)min(lw6 + 6 * r, Ta - 1) * D + cc[p]);
+    const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { lw[p] = ldg4(a.ln_w + cc[p]); lb[p] = ldg4(lnb + cc[p]); }
+    // ---- dots operand: 8 float4 of U[p], INTERLEAVED over the row (float4 index dsg + NS*i): consecutive lanes read
+    //      consecutive 16-byte pieces both from global memory and, for the normalised rows, from LDS ----
+    const int dp = min(tid / NS, NP - 1), dsg = tid % NS;
+    const bool dlive = tid < NP * NS;
+    f32x4 u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = MDT_LD_STREAM(Ub + (int64_t)dp * D + 4 * (dsg + NS * i));
+    // ---- comb operands: Wf[p][c4] for all p, old y rows of the thread's row group ----
+    const int ntg = NT / n4;                             // row groups (4 for d = 384, 3 for d = 512)
+    const int rpt = (Ta + ntg - 1) / ntg;                // rows per group (<= RMAX, checked by the launcher)
+    const int c4 = tid % n4, tg = tid / n4;
+    const bool clive = tg < ntg;
+    f32x4 wf[NP], yold[RMAX];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) wf[p] = MDT_LD_STREAM(Wb + (int64_t)p * D + 4 * c4);
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) yold[r] = LY.ld4(yoff + (int64_t)min(tg * rpt + r, Ta - 1) * D + 4 * c4);
+    const f32x4 bo = ldg4((a.bo != nullptr ? a.bo : zeros) + 4 * c4);
+    const float inv_d = 1.0f / (float)D;
+    float red[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        red[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p], zero4); red[r] += hsum4(v[r][p]); }
+    }
+    wave_sum_n<RW>(red);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float mean = red[r] * inv_d;
+        red[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p] - mean, zero4); red[r] += hsq4(v[r][p]); }
+    }
+    wave_sum_n<RW>(red);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int t = wave + 6 * r;
+        const float rstd = 1.0f / sqrtf(red[r] * inv_d + 1e-5f);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (cv[p] && t < Ta && wave < 6) *(f32x4*)(xn + t * D + cc[p]) = v[r][p] * rstd * lw[p] + lb[p];
+    }
+    MDT_TS(1)
+    __syncthreads();
+    MDT_TS(2)
+    // ---- partial dots: part[t][p][seg] = xn[t][seg*32..] . U[p][seg*32..] ----
+    if (dlive) {
+        for (int t = 0; t < Ta; ++t) {
+            const float* xr = xn + t * D + 4 * dsg;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 x = *(const f32x4*)(xr + 4 * NS * i);
+                acc = fmaf(x.x, u[i].x, acc); acc = fmaf(x.y, u[i].y, acc);
+                acc = fmaf(x.z, u[i].z, acc); acc = fmaf(x.w, u[i].w, acc);
+            }
+            part[(t * NP + dp) * NS + dsg] = acc;
+        }
+    }
+    MDT_TS(3)
+    __syncthreads();
+    // ---- masked softmax per (row, head) over the Te context tokens: key j visible iff j <= t (top-left causal) ----
+    if (tid < Ta * a.H) {
+        const int t = tid / a.H, h = tid % a.H;
+        const int nk = min(Te, t + 1);
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = -INFINITY;
+            if (j < nk) {
+                const int p = h * Te + j;
+                float acc = a.c[(int64_t)b * NP + p];
+                for (int sgi = 0; sgi < NS; ++sgi) acc += part[(t * NP + p) * NS + sgi];  // fixed order
+                sc[j] = acc;
+                mx = fmaxf(mx, acc);
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = j < nk ? expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < Te) prob[t * NP + h * Te + j] = sc[j] * inv;
+    }
+    __syncthreads();
+    // ---- combine + residual: y[t][c4] += bo + sum_p prob[t][p] * Wf[p][c4] ----
+    if (clive) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int t = tg * rpt + r;
+            if (r < rpt && t < Ta) {
+                f32x4 acc = bo;
+#pragma unroll
+                for (int p = 0; p < NP; p += 4) {
+                    const f32x4 pr = *(const f32x4*)(prob + t * NP + p);  // broadcast read of 4 probabilities
+                    acc += pr.x * wf[p] + pr.y * wf[p + 1] + pr.z * wf[p + 2] + pr.w * wf[p + 3];
+                }
+                *(f32x4*)(yb + (int64_t)t * D + 4 * c4) = yold[r] + acc;
+            }
+        }
+    }
+    MDT_TS(4)
+}

@@ -167,17 +167,34 @@ class HipEngine:
         return out, ctx
 
     def sample_ddim(self, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas):
+        """Fused sampler call.  ``sigmas`` may live on the host (gc_sampling's default) or on the model's device --
+        the agent builds its schedule there (mdtv_agent.py:660-667); a device schedule is consumed in place
+        (mdt_sample_ddim_dev): no copy to the host, no synchronisation."""
         self.sync_params()
         tok, tok2, B = self._tokens(state)
         g, x_ = self._goal(goal, B), self._in(x_T, (B, self.Ta, self.A))
-        sig = [float(v) for v in (sigmas.detach().cpu().tolist() if torch.is_tensor(sigmas) else sigmas)]
-        n = len(sig) - 1
-        arr = (C.c_float * len(sig))(*sig)
         out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        if torch.is_tensor(sigmas) and sigmas.device.type == "cuda":
+            sig = self._in(sigmas.reshape(-1))
+            n = sig.numel() - 1
+            self._keep = sig  # the kernel that reads it is only enqueued: keep the (possibly converted) tensor alive
+            _lib.check(self.lib.mdt_sample_ddim_dev(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
+                                                    _ptr(x_), _ptr(sig), n, B, _ptr(out), _ptr(ctx), self._stream()))
+            return out, ctx
+        sig = [float(v) for v in (sigmas.detach().tolist() if torch.is_tensor(sigmas) else sigmas)]
+        n = len(sig) - 1
+        arr = (C.c_float * len(sig))(*sig)
         _lib.check(self.lib.mdt_sample_ddim(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
                                             _ptr(x_), arr, n, B, _ptr(out), _ptr(ctx), self._stream()))
         return out, ctx
+
+    def persist_status(self) -> int:
+        """Error word of the persistent decoder kernel (0 = fine); meaningful after the stream was synchronised."""
+        return int(self.lib.mdt_persist_status(self.handle))
+
+    def persist_launches(self) -> int:
+        return int(self.lib.mdt_persist_launches(self.handle))
 
     def loss_fwd(self, state: dict, action: torch.Tensor, goal: torch.Tensor, noise: torch.Tensor, sigma: torch.Tensor):
         self.sync_params()

@@ -1,0 +1,136 @@
+"""The persistent decoder kernel (mdt_persist.hip: the whole DDIM step loop as ONE launch, per-XCD sample ownership,
+fence-free XCD-local barriers) against the launch sequence it replaces and against the reference's goldens.
+
+Both paths run the same tile bodies (mdt_tiles.h) on the same tiles in the same k order, so their outputs must be
+BIT-IDENTICAL; a stale read of another workgroup's activations inside the persistent kernel would show up as a
+difference (and, in the soak, as a call that differs from the first one)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, load_fixture
+from tests.test_gpu_parity import build, gpu_inputs, sampling
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from mdt_policy_amd import _lib as L
+    return L.load()
+
+
+@pytest.fixture(autouse=True)
+def _restore_switch():
+    yield
+    _lib().mdt_op_set_persist(-1)
+
+
+def _engine(model):
+    return model.inner_model.hip_engine()
+
+
+def _sample(model, state, x_T, goal, sig, persist):
+    _lib().mdt_op_set_persist(1 if persist else 0)
+    eng = _engine(model)
+    n0 = eng.persist_launches()
+    with torch.no_grad():
+        out = sampling().sample_ddim(model, state, x_T, goal, sig)
+    torch.cuda.synchronize()
+    assert eng.persist_status() == 0
+    used = eng.persist_launches() - n0
+    assert used == (1 if persist else 0), f"persistent launches: {used}"
+    return out
+
+
+def test_unsupported_configuration_keeps_the_launch_sequence():
+    """MDT (two state tokens + goal: Te = 3, H * Te = 24 with 8 heads of 64) at B = 8 has no instantiated variant of the
+    SMALL kernel's attention (its 8 waves are 8 heads; fine) -- whatever the library decides, the call must succeed and
+    match the reference; the switch must never make a call fail."""
+    meta, fx = load_fixture("g3_b8_mdt.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    _lib().mdt_op_set_persist(1)
+    with torch.no_grad():
+        out = sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, torch.from_numpy(fx["sigmas"]))
+    torch.cuda.synchronize()
+    assert _engine(model).persist_status() == 0
+    assert_close(out.cpu(), fx["actions"], what="MDT default B=8")
+
+
+@pytest.mark.parametrize("fixture,what", [("g3_b256_lang.npz", "MDT-V default B=256"), ("g3_b256_init.npz", "init weights B=256"),
+                                          ("g1_tiny_mdtv.npz", "MDT-V tiny B=1"), ("g1_tiny_mdt.npz", "MDT tiny B=1")])
+def test_persistent_matches_reference_and_launch_path(fixture, what):
+    meta, fx = load_fixture(fixture)
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sig = torch.from_numpy(fx["sigmas"])
+    x_T = noise * meta["sigma_max"]
+    a = _sample(model, state, x_T, goal, sig, persist=True)
+    b = _sample(model, state, x_T, goal, sig, persist=False)
+    assert_close(a.cpu(), fx["actions"], what=f"{what}: persistent kernel vs reference")
+    assert torch.equal(a, b), f"{what}: persistent kernel differs from the launch sequence, max |d| = {(a - b).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 8, 128, 136, 200, 250, 256, 300, 512])
+def test_persistent_bit_identical_for_ragged_batches(B):
+    """XCD x owns samples [x S, x S + S): the last XCDs hold fewer (or no) samples when B is not a multiple of 8."""
+    meta, fx = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    from tests.helpers import inputs_of
+    state, goal, noise = inputs_of(meta, batch=B)
+    state = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    goal, noise = goal.cuda(), noise.cuda()
+    sig = torch.from_numpy(fx["sigmas"])
+    a = _sample(model, state, noise * 80.0, goal, sig, persist=True)
+    b = _sample(model, state, noise * 80.0, goal, sig, persist=False)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), f"B={B}: max |d| = {(a - b).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("fixture,n", [("g3_b256_lang.npz", 300), ("g1_tiny_mdtv.npz", 1000)])
+def test_persistent_soak_is_bit_stable(fixture, n):
+    """Stale-read detector: n back-to-back calls (no synchronisation in between) must all equal the first."""
+    meta, fx = load_fixture(fixture)
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sig = torch.from_numpy(fx["sigmas"])
+    x_T = noise * meta["sigma_max"]
+    _lib().mdt_op_set_persist(1)
+    gs = sampling()
+    with torch.no_grad():
+        first = gs.sample_ddim(model, state, x_T, goal, sig).clone()
+        bad = torch.zeros((), device="cuda", dtype=torch.int64)
+        for _ in range(n):
+            out = gs.sample_ddim(model, state, x_T, goal, sig)
+            bad += (out != first).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert _engine(model).persist_status() == 0
+    assert int(bad.item()) == 0, f"{int(bad.item())} of {n} calls differ from the first"
+    assert_close(first.cpu(), fx["actions"], what="soak result vs reference")
+
+
+@pytest.mark.parametrize("fixture", ["g3_b256_lang.npz", "g1_tiny_mdtv.npz", "g3_b8_smin1.npz"])
+@pytest.mark.parametrize("persist", [True, False])
+def test_device_sigmas_as_the_agent_passes_them(fixture, persist):
+    """MDTVAgent.get_noise_schedule builds the schedule ON the device (mdtv_agent.py:660-667): it is consumed in place
+    (mdt_sample_ddim_dev), no copy to the host; same actions as with a host schedule."""
+    meta, fx = load_fixture(fixture)
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    sig = gs.get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"]) if "sigmas" not in fx else torch.from_numpy(fx["sigmas"])
+    x_T = noise * meta["sigma_max"]
+    _lib().mdt_op_set_persist(1 if persist else 0)
+    with torch.no_grad():
+        host = gs.sample_ddim(model, state, x_T, goal, sig)
+        dev = gs.sample_ddim(model, state, x_T, goal, sig.cuda())
+    torch.cuda.synchronize()
+    assert_close(dev.cpu(), fx["actions"], what="device schedule vs reference")
+    assert_close(dev.cpu(), host.cpu(), rtol=1e-5, atol=1e-6, what="device vs host schedule")
+
+
+def test_status_word_reports_nothing_on_a_healthy_run():
+    meta, fx = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    eng = _engine(model)
+    assert eng.persist_status() == 0
