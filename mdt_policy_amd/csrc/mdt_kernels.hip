@@ -438,6 +438,14 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         geo = bgeo;
     }
     if (g_mdt_gemm_force) geo = g_mdt_gemm_force;
+    {   // tuning hooks (A/B runs): geometry of the wide (N >= 1024) / narrow products of large batches
+        static int gw = -1, gn = -1;
+        if (gw < 0) { const char* e = getenv("MDT_HIP_GEO_WIDE"); gw = e ? atoi(e) : 0; const char* f = getenv("MDT_HIP_GEO_NARROW"); gn = f ? atoi(f) : 0; }
+        if (a.M > g_mdt_mid_max && a.batch <= 1 && !g_mdt_gemm_force) {
+            if (a.N >= 1024 && gw) geo = gw;
+            if (a.N < 1024 && gn) geo = gn;
+        }
+    }
     switch (geo) {
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
         case 2:
@@ -451,6 +459,8 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         case 4: return launch_gemm_pro<2, 4, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 6: return launch_gemm_pro<1, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 16 x 64
         case 7: return launch_gemm_pro<4, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 64 x 128 (deep-K products)
+        case 8: return launch_gemm_pro<2, 4, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 32 x 256: two workgroups per CU
+        case 9: return launch_gemm_pro<2, 3, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 32 x 192
         default: return launch_gemm_pro<2, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
     }
 }

@@ -22,6 +22,11 @@ import torch.nn as nn
 from ... import _lib
 
 
+import os
+
+_RESYNC_EVERY = int(os.environ.get("MDT_HIP_PARAM_RESYNC", "0") or 0)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -62,9 +67,20 @@ class HipEngine:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def invalidate(self) -> None:
+        """Forget what was uploaded: the next call re-uploads (and re-packs) every parameter.  For in-place weight
+        updates the version counter does not see -- ``p.data.mul_()/copy_()``, apex / DeepSpeed multi-tensor kernels, any
+        raw-pointer write other than this package's FusedAdamW / multi_tensor_ema (which bump the counter)."""
+        self._uploaded.clear()
+
     def sync_params(self) -> None:
-        """Upload every parameter whose storage or version changed since the last upload."""
+        """Upload every parameter whose storage or version changed since the last upload.  MDT_HIP_PARAM_RESYNC=N
+        (debug safety net) additionally re-uploads everything every N-th call."""
         stream = self._stream()
+        if _RESYNC_EVERY > 0:
+            self._calls = getattr(self, "_calls", 0) + 1
+            if self._calls % _RESYNC_EVERY == 0:
+                self._uploaded.clear()
         seen = 0
         for name, p in self.module.named_parameters():
             key = "inner_model." + name
@@ -337,6 +353,21 @@ class HipScoreNetwork(nn.Module):
         d = self.__dict__.copy()
         d["_engines"] = {}
         return d
+
+    def mark_dirty(self) -> None:
+        """Public escape hatch of the weight cache (see HipEngine.invalidate): call after writing parameters through
+        ``.data`` or a foreign fused optimizer."""
+        for eng in getattr(self, "_engines", {}).values():
+            eng.invalidate()
+
+    def train(self, mode: bool = True):  # mode switches are rare and a natural point to re-validate the arena
+        out = super().train(mode)
+        self.mark_dirty()
+        return out
+
+    def _load_from_state_dict(self, *a, **kw):
+        super()._load_from_state_dict(*a, **kw)
+        self.mark_dirty()
 
     def _apply(self, fn, *a, **kw):  # .to()/.cuda()/.float(): parameters are re-created, drop stale handles
         out = super()._apply(fn, *a, **kw)

@@ -151,6 +151,16 @@ class MAPBlock(nn.Module):
         except Exception:
             pass
 
+    def mark_dirty(self) -> None:
+        """Forget what was uploaded (weights written through ``.data`` / a foreign fused optimizer are not seen by the
+        version counter): the next call re-uploads every parameter."""
+        self._uploaded = {}
+
+    def train(self, mode: bool = True):
+        out = super().train(mode)
+        self._uploaded = {}
+        return out
+
     def _engine(self, device: torch.device, train: bool = False):
         if device.type != "cuda":
             raise RuntimeError("MAPBlock runs only on a ROCm GPU (hand-written gfx950 kernels); move the module and its "

@@ -423,3 +423,29 @@ def test_c4_total_batch_2048_matches_the_b256_golden_slice():
                                      torch.from_numpy(fx["sigmas"]))
     assert out.shape == (2048, 10, 7) and torch.isfinite(out).all()
     assert_close(out[:256].cpu(), fx["actions"], what="first 256 of 2048")
+
+
+def test_mark_dirty_picks_up_writes_the_version_counter_misses():
+    """`p.data.mul_()` does not bump `p._version` (p.data carries its own counter): the packed arena would go stale
+    silently.  `mark_dirty()` (and every train()/eval() switch, load_state_dict) forces the re-upload."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx = load_fixture("g1_tiny_mdtv.npz")
+    model = GCDenoiser(cfg_of(meta), sigma_data=0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    state, goal, noise = gpu_inputs(meta)
+    sig = sampling().get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    with torch.no_grad():
+        a = sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, sig).clone()
+        w = model.inner_model.action_pred.weight
+        v0 = w._version
+        w.data.mul_(0.5)
+        assert w._version == v0  # the hazard: nothing the cache could have noticed
+        model.inner_model.mark_dirty()
+        b = sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, sig).clone()
+        w.data.mul_(2.0)
+        model.eval()  # a mode switch re-validates too
+        c = sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, sig)
+    assert_close(a.cpu(), fx["actions"], what="before")
+    assert (a - b).abs().max().item() > 1e-3, "halved action_pred.weight must change the actions"
+    assert torch.equal(a, c)

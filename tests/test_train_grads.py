@@ -109,6 +109,65 @@ def test_hip_gradients_match_reference_and_oracle(name):
 
 
 @pytest.mark.gpu
+def test_hip_gradients_at_the_c3_batch_b1024():
+    """BASELINE configs[2] at its own size: ONE MDT-V default training step at B = 1024 (M = 10 240 action rows) takes
+    code the B <= 8 fixtures never reach -- the batched split-K dW products (~1000 workgroups of >= 512-row slices), the
+    64-slice column sums and the co-resident 4-wave tiles of M >= 4096.  Every parameter gradient and the input
+    gradients against float64 autograd through the oracle on the same seeded batch (eval mode: dropout off)."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, _, _, _ = case("mdtv_default")
+    B = 1024
+    state, goal, _ = inputs_of(meta, batch=B)
+    li = {k: torch.from_numpy(v) for k, v in synthetic.loss_inputs(B, cfg, meta["loss_seed"]).items()}
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    gstate = {k: (v.cuda().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+    ggoal = goal.cuda().requires_grad_()
+    loss, mo = model.loss(gstate, li["actions"].cuda(), ggoal, li["noise_train"].cuda(), li["sigma"].cuda())
+    ctx = model.inner_model.latent_encoder_emb
+    wctx = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), meta["ctx_seed"])).cuda()
+    (loss + 0.1 * (ctx * wctx).sum() / ctx.numel()).backward()
+    torch.cuda.synchronize()
+    # float64 autograd through the oracle (the checker) -- on the GPU's fp64 units when the oracle's ops run there,
+    # else on the host
+    def oracle_grads(dev):
+        P = {k: v.double().to(dev).requires_grad_(v.dtype.is_floating_point) for k, v in params_of(meta).items()}
+        st = {k: (v.double().to(dev).requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+        g64 = goal.double().to(dev).requires_grad_()
+        l64 = {k: v.to(dev) for k, v in li.items()}
+        lo, tot = oracle_total_dev(P, cfg, meta, st, g64, l64, dev)
+        tot.backward()
+        return P, st, g64, lo
+    def oracle_total_dev(P, cfg, meta, st, g, l, dev):
+        lo, _ = O.loss(P, cfg, st, l["actions"].double(), g, l["noise_train"].double(), l["sigma"].double(), arch=meta["arch"])
+        c = O.encode(P, cfg, st, g, meta["arch"], "forward", sigma=l["sigma"].double())
+        w = torch.from_numpy(synthetic.normal("ctx_weight", tuple(c.shape), meta["ctx_seed"])).double().to(dev)
+        return lo, lo + 0.1 * (c * w).sum() / c.numel()
+    try:
+        P, st64, g64, lo = oracle_grads("cuda")
+    except Exception:  # an oracle op without a device kernel: run the checker on the host
+        torch.set_num_threads(min(32, torch.get_num_threads() * 4))
+        P, st64, g64, lo = oracle_grads("cpu")
+    assert abs(loss.item() - lo.item()) <= 1e-3 * abs(lo.item())
+    n = 0
+    for k, p in model.inner_model.named_parameters():
+        ref = P["inner_model." + k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        scale = float(ref.abs().max())
+        assert_close(p.grad.cpu(), ref.cpu(), rtol=2e-3, atol=2e-3 * scale + 1e-7, what=f"B=1024 {k}")
+        n += 1
+    assert n > 100
+    for k, v in gstate.items():
+        if torch.is_tensor(v):
+            ref = st64[k].grad.cpu()
+            assert_close(v.grad.cpu(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()) + 1e-9, what=f"B=1024 d_{k}")
+    assert_close(ggoal.grad.cpu(), g64.grad.cpu(), rtol=2e-3, atol=2e-3 * float(g64.grad.abs().max()) + 1e-9, what="B=1024 d_goal")
+
+
+@pytest.mark.gpu
 def test_hip_training_steps_follow_the_oracle():
     """Five AdamW steps on the facade (HIP forward/backward, torch optimizer) against the same five steps on the
     oracle with torch autograd: losses and a few weights stay together."""

@@ -1,8 +1,9 @@
 #!/bin/bash
-# B=1 latency: wall time vs sum of kernel durations (is the chain launch- or GPU-bound?)
-OUT=$PWD/gpurun_out/${1:-latprof}; mkdir -p $OUT; export TMPDIR=/tmp
-python tools/latency.py 1 2>&1 | tail -1 | tee $OUT/latency.txt
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o lat -- python $OLDPWD/tools/latency.py 1 > $OUT/prof_run.txt 2> $OUT/prof.err ); echo "rocprof exit $?"
-DB=$(find $OUT/prof -name "*.db" | head -1)
-[ -n "$DB" ] && python tools/prof_summary.py $DB > $OUT/lat_kernel_stats.txt && head -24 $OUT/lat_kernel_stats.txt
-find $OUT/prof -type f -size +20M -delete
+# kernel-trace of the rollout batch (B = 1): per-kernel durations and the gaps between dependent launches
+out=gpurun_out/$1; B=${2:-1}; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d $R/$out/prof -o lat -- python $R/tools/latency.py $B > $R/$out/prof_run.txt 2> $R/$out/prof.err
+db=$(find $R/$out/prof -name "*.db" | head -1)
+python $R/tools/prof_summary.py $db > $R/$out/lat_kernel_stats.txt
+python $R/tools/prof_gaps.py $db 250 > $R/$out/lat_gaps.txt
+cat $R/$out/prof_run.txt $R/$out/lat_gaps.txt
