@@ -141,9 +141,37 @@ def other_configs(device):
                                                  "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                                                  "flops_per_sample": round(3.0 * fwd)},
                                     "what": "GCDenoiser.loss forward + HIP backward + FusedAdamW, train() mode, dropout "
-                                            "0.3/0.1/0.05, fp32, synthetic CALVIN-shaped batch (diffusion loss only: the "
-                                            "masked-token head is timed by tools/mae_bench.py)"}
+                                            "0.3/0.1/0.05, fp32, synthetic CALVIN-shaped batch (diffusion loss only; the full "
+                                            "configs[2] step is train_step_c3_mdtv_B1024)"}
     del opt
+    # BASELINE configs[2] in full: diffusion loss + the masked-token auxiliary (masked generative foresight head on
+    # latent_encoder_emb, mdtv_agent.py:258-269, masked_beta = 1) in ONE optimizer step over both modules
+    try:
+        from mdt_policy_amd.models.img_generation.masked_transformer_decoder import MaskedTransformerImgDecoder
+        from tools.mae_bench import mae_flops
+        gen = MaskedTransformerImgDecoder(resolution=112, patch_size=16, decoder_depth=6, decoder_embed_dim=192, decoder_n_heads=8,
+                                          context_dim=384, mask_ratio=0.75).to(device)
+        imgs = torch.randn(B, 2, 3, 112, 112, device=device)
+        opt2 = FusedAdamW(list(model.parameters()) + list(gen.parameters()), lr=1e-4, weight_decay=0.05)
+
+        def step_c3():
+            opt2.zero_grad(set_to_none=True)
+            loss, _ = model.loss(state, li["actions"], inp["goal"], li["noise_train"], li["sigma"])
+            rec, mask, restore, _ = gen(model.inner_model.latent_encoder_emb, imgs)
+            (loss + gen.compute_loss(imgs, rec, mask, restore)).backward()
+            opt2.step()
+
+        dt3 = timed(step_c3, 2, 5)
+        tf3 = (3.0 * fwd * B + mae_flops(B)) / dt3 / 1e12
+        out["train_step_c3_mdtv_B1024"] = {"ms_per_step": round(dt3 * 1e3, 3), "samples_per_s": round(B / dt3, 1),
+                                           "roofline": {"bound": "mfma", "achieved": round(tf3, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                                                        "unit": "TFLOP/s", "frac": round(tf3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                                        "flops_per_sample": round(3.0 * fwd + mae_flops(1))},
+                                           "what": "BASELINE configs[2]: diffusion loss + masked-token aux (MaskedTransformerImgDecoder, 6 "
+                                                   "blocks d=192, 112x112 frames, mask 0.75) forward + HIP backward + FusedAdamW, fp32"}
+        del opt2, gen, imgs
+    except Exception as e:  # diagnostic leg
+        out["train_step_c3_mdtv_B1024"] = {"error": repr(e)}
     model.eval()
     sig = gs.get_sigmas_exponential(10, 0.001, 80.0).to(device)  # ON the device, as MDTVAgent.get_noise_schedule builds it
     # weight-streaming regime: a call reads the decoder's weights once per step and the encoder's once

@@ -1,0 +1,50 @@
+/*
+ * mdt_mae.h -- kernel-level ops behind the masked generative foresight (MGF) head, the reference's
+ * MaskedTransformerImgDecoder (mdt/models/img_generation/masked_transformer_decoder.py:68-262; built by the agent at
+ * mdt/models/mdtv_agent.py:99 and called on `latent_encoder_emb` at :411-421; shipped configuration
+ * conf/model/img_gen/masked_transformer.yaml: 6 blocks, d = 192, 8 heads of 24, 2 x 49 patch tokens + 4 context tokens).
+ *
+ * Its transformer blocks are `voltron.models.util.transformer.Block(do_rms_norm, do_swish_glu, do_layer_scale)` -- an
+ * un-vendored dependency (requirements.txt:20, no pinned version): restated from the published Voltron
+ * code, PARITY UNPINNED for the block internals; the reference's own part (masking, token assembly, loss) is pinned by
+ * tests/golden/g15_mae_*.npz.
+ *
+ * The host mirror (mdt_policy_amd/models/img_generation/masked_transformer_decoder.py) runs every Linear on the fp32-MFMA
+ * GEMM (mdt_op_gemm forward, mdt_op_linear_bwd backward) and the row / token kernels below; gathers, residual adds and
+ * the loss are PyTorch-ROCm glue.  fp32, row-major, device pointers 16-byte aligned.
+ */
+#ifndef MDT_MAE_H
+#define MDT_MAE_H
+
+#include <stdint.h>
+#include "mdt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* voltron RMSNorm (the reference carries the same class at transformer_blocks.py:43-51):
+ *   y = x / max(||x||_2 * D^-1/2, eps) * g          rows M, D <= 512 */
+mdt_status mdt_op_rms_fwd(const float *x, const float *g, float *out, int64_t M, int32_t D, float eps, void *stream);
+/* dx (+)= backward of the above; dg (D) (+)= sum over rows.  scratch: mdt_op_rms_bwd_scratch(M, D) floats. */
+int64_t mdt_op_rms_bwd_scratch(int64_t M, int32_t D);
+mdt_status mdt_op_rms_bwd(const float *x, const float *g, const float *dy, float *dx, int32_t accumulate_dx, float *dg,
+                          int32_t accumulate_dg, int64_t M, int32_t D, float eps, float *scratch, void *stream);
+
+/* voltron SwishGLU (transformer_blocks.py:55-62): u = [projected | gate] (M, 2 H) -> projected * silu(gate) (M, H) */
+mdt_status mdt_op_swiglu_fwd(const float *u, float *out, int64_t M, int32_t H, void *stream);
+mdt_status mdt_op_swiglu_bwd(const float *u, const float *d_out, float *du, int64_t M, int32_t H, void *stream);
+
+/* Unmasked multi-head self-attention over T <= 128 tokens (voltron Attention.forward):
+ *   qkv (B*T, 3*H*hd) = q | k | v column blocks (row stride ld_qkv), head h at columns h*hd;
+ *   out (B*T, H*hd) = softmax(q k^T * scale) v.   hd a multiple of 4, <= 64.  One workgroup per (sample, head). */
+mdt_status mdt_op_attn_mid_fwd(const float *qkv, int64_t ld_qkv, float *out, int64_t ld_out, int64_t B, int32_t H,
+                               int32_t hd, int32_t T, float scale, void *stream);
+/* d_qkv (B*T, 3*H*hd; same layout, overwritten) from d_out; the probabilities are recomputed from qkv. */
+mdt_status mdt_op_attn_mid_bwd(const float *qkv, int64_t ld_qkv, const float *d_out, int64_t ld_do, float *d_qkv,
+                               int64_t ld_dqkv, int64_t B, int32_t H, int32_t hd, int32_t T, float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

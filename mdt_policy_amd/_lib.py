@@ -237,6 +237,14 @@ SYMBOLS = [
     ("mdt_map_pool_forward_train", _I32, [_VP, _VP, _I64, _I32, _VP, C.POINTER(_I32), _VP]),
     ("mdt_map_pool_backward", _I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     ("mdt_map_pool_tape_release", _I32, [_VP, _I32]),
+    # include/mdt_mae.h
+    ("mdt_op_rms_fwd", _I32, [_VP, _VP, _VP, _I64, _I32, _F, _VP]),
+    ("mdt_op_rms_bwd_scratch", _I64, [_I64, _I32]),
+    ("mdt_op_rms_bwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _I32, _I64, _I32, _F, _VP, _VP]),
+    ("mdt_op_swiglu_fwd", _I32, [_VP, _VP, _I64, _I32, _VP]),
+    ("mdt_op_swiglu_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP]),
+    ("mdt_op_attn_mid_fwd", _I32, [_VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),
+    ("mdt_op_attn_mid_bwd", _I32, [_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),
     ("mdt_op_infonce_scratch", _I64, [_I64, _I64]),
     ("mdt_op_infonce", _I32, [C.POINTER(InfoNCEArgs), _VP]),
 ]

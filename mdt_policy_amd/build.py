@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libmdt_hip.so")
-SOURCES = ["mdt_kernels.hip", "mdt_persist.hip", "mdt_model.hip", "mdt_resampler.hip", "mdt_map_pool.hip", "mdt_infonce.hip", "mdt_train_kernels.hip", "mdt_train_ops.hip", "mdt_train.hip"]
+SOURCES = ["mdt_kernels.hip", "mdt_persist.hip", "mdt_model.hip", "mdt_resampler.hip", "mdt_map_pool.hip", "mdt_mae.hip", "mdt_infonce.hip", "mdt_train_kernels.hip", "mdt_train_ops.hip", "mdt_train.hip"]
 ARCH = "gfx950"
 
 
@@ -30,7 +30,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_persist.h"]]
-    deps += [os.path.join(INCLUDE, f) for f in ("mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h")]
+    deps += [os.path.join(INCLUDE, f) for f in ("mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -9,6 +9,7 @@
 #include "mdt_hip_ops.h"
 #include "mdt_resampler.h"
 #include "mdt_hip_train.h"
+#include "mdt_mae.h"
 
 // ---- error plumbing: the message behind mdt_last_error() (thread local, defined in mdt_model.hip) ----
 mdt_status mdt_fail(mdt_status st, const char* fmt, ...);
@@ -141,5 +142,11 @@ hipError_t mdt_launch_multi_adamw(const mdt_opt_tensor* tab, const int2* blocks,
                                   float beta2, float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s);
 hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks, int n_blocks, float a, float b,
                                   hipStream_t s);
+// RMSNorm / SwishGLU row kernels (mdt_map_pool.hip), shared with the masked-image decoder's ops (mdt_mae.hip)
+hipError_t mdt_launch_rms_fwd(const float* x, const float* g, float* out, int64_t M, int D, float eps, hipStream_t s);
+hipError_t mdt_launch_rms_bwd(const float* x, const float* g, const float* dy, float* dx, int accumulate, float* pg, int64_t M,
+                              int D, float eps, hipStream_t s);
+hipError_t mdt_launch_swiglu_fwd(const float* u, float* out, int64_t M, int Hm, hipStream_t s);
+hipError_t mdt_launch_swiglu_bwd(const float* u, const float* d_out, float* du, int64_t M, int Hm, hipStream_t s);
 struct mdt_model;
 void mdt_train_free(mdt_model* m);  // releases what mdt_train_prepare() and the tapes allocated (mdt_train.hip)

@@ -207,6 +207,30 @@ __global__ void k_swiglu_bwd(const float* __restrict__ u, const float* __restric
     du[m * 2 * Hm + Hm + c] = d * p * act_silu_grad(gt);
 }
 
+// launchers shared with the masked-image decoder's op-level ABI (mdt_mae.hip)
+hipError_t mdt_launch_rms_fwd(const float* x, const float* g, float* out, int64_t M, int D, float eps, hipStream_t s) {
+    if (D > 64 * RMS_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_rms_fwd, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, g, out, (int)M, D, eps);
+    return hipGetLastError();
+}
+// pg: ceil(M / 4) x D floats of scratch (per-workgroup partials of dg; reduce with mdt_launch_colsum)
+hipError_t mdt_launch_rms_bwd(const float* x, const float* g, const float* dy, float* dx, int accumulate, float* pg, int64_t M,
+                              int D, float eps, hipStream_t s) {
+    if (D > 64 * RMS_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_rms_bwd, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, g, dy, dx, accumulate, pg, (int)M, D, eps);
+    return hipGetLastError();
+}
+hipError_t mdt_launch_swiglu_fwd(const float* u, float* out, int64_t M, int Hm, hipStream_t s) {
+    const int64_t n = M * Hm;
+    hipLaunchKernelGGL(k_swiglu_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, out, n, Hm);
+    return hipGetLastError();
+}
+hipError_t mdt_launch_swiglu_bwd(const float* u, const float* d_out, float* du, int64_t M, int Hm, hipStream_t s) {
+    const int64_t n = M * Hm;
+    hipLaunchKernelGGL(k_swiglu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, d_out, du, n, Hm);
+    return hipGetLastError();
+}
+
 namespace {
 
 const float RMS_EPS = 1e-8f;

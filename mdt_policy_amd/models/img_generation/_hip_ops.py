@@ -1,0 +1,190 @@
+"""HIP-backed autograd functions of the masked-image decoder: every Linear on the fp32-MFMA GEMM (mdt_op_gemm forward,
+mdt_op_linear_bwd backward), RMSNorm / SwishGLU row kernels and the mid-length self-attention (include/mdt_mae.h).
+No eager fallback: CPU tensors or a missing library raise."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from ... import _lib
+
+RMS_EPS = 1e-8
+
+
+def _stream(t: torch.Tensor) -> int:
+    if t.device.type != "cuda":
+        raise RuntimeError("the masked-image decoder runs only on a ROCm GPU (hand-written gfx950 kernels); there is no "
+                           "CPU execution path in mdt_policy_amd")
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+class PackedWeights:
+    """Fragment-packed images of an nn.Linear-shaped weight (N, K): the forward operand and the image of W^T for
+    dX = dY W, refreshed when the parameter's storage or version counter changes (``invalidate()`` forces it)."""
+
+    def __init__(self):
+        self._cache: Dict[int, tuple] = {}
+
+    def invalidate(self) -> None:
+        self._cache.clear()
+
+    def get(self, w2d: torch.Tensor, key_param: torch.Tensor, need_t: bool):
+        tag = (key_param.data_ptr(), key_param._version, need_t)
+        ent = self._cache.get(id(key_param))
+        if ent is not None and ent[0][:2] == tag[:2] and (ent[0][2] or not need_t):
+            return ent[1], ent[2]
+        lib = _lib.load()
+        N, K = w2d.shape
+        if N % 16 or K % 16:
+            raise ValueError(f"Linear ({N}, {K}): both dimensions must be multiples of 16 for the packed MFMA operand")
+        src = _c(w2d)
+        s = _stream(src)
+        wp = torch.empty(N * K, device=src.device, dtype=torch.float32)
+        _lib.check(lib.mdt_op_pack_weight(src.data_ptr(), N, K, wp.data_ptr(), 0, N, s))
+        wt = None
+        if need_t:
+            wt = torch.zeros(N * K, device=src.device, dtype=torch.float32)
+            _lib.check(lib.mdt_op_pack_weight_t(src.data_ptr(), N, K, K, wt.data_ptr(), 0, N, s))
+        self._cache[id(key_param)] = (tag, wp, wt)
+        return wp, wt
+
+
+class HipLinear(torch.autograd.Function):
+    """y = x W^T + b on the fused MFMA GEMM; x (..., K) -> (..., N).  ``w2d`` is the (N, K) view of ``weight`` (a Conv2d
+    patch embedding is a Linear over flattened patches)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packs: PackedWeights):
+        lib = _lib.load()
+        w2d = weight.reshape(weight.shape[0], -1)
+        N, K = w2d.shape
+        x2 = _c(x).reshape(-1, K)
+        M = x2.shape[0]
+        need_t = x.requires_grad
+        wp, wt = packs.get(w2d, weight, need_t)
+        out = torch.empty((M, N), device=x2.device, dtype=torch.float32)
+        a = _lib.GemmArgs()
+        a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = x2.data_ptr(), K, wp.data_ptr(), out.data_ptr(), N, M, N, K
+        a.bias = None if bias is None else _c(bias).data_ptr()
+        a.shift_off, a.scale_off, a.gate_off, a.rows_per_sample, a.gin, a.gout, a.goff = -1, -1, -1, 1, 1, 1, 0
+        _lib.check(lib.mdt_op_gemm(C.byref(a), _stream(x2)))
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.packs, ctx.xshape = packs, x.shape
+        return out.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x2, weight, bias = ctx.saved_tensors
+        w2d = weight.reshape(weight.shape[0], -1)
+        N, K = w2d.shape
+        M = x2.shape[0]
+        dY = _c(g).reshape(M, N)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        wt = ctx.packs.get(w2d, weight, True)[1] if need_x else None
+        dW = torch.empty((N, K), device=dY.device, dtype=torch.float32) if need_w else None
+        db = torch.empty((N,), device=dY.device, dtype=torch.float32) if need_b else None
+        dX = torch.empty((M, K), device=dY.device, dtype=torch.float32) if need_x else None
+        scratch = torch.empty(max(1, lib.mdt_op_linear_bwd_scratch(M, N, K)), device=dY.device, dtype=torch.float32)
+        a = _lib.LinearBwdArgs(X=x2.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None if wt is None else wt.data_ptr(),
+                               dW=None if dW is None else dW.data_ptr(), dbias=None if db is None else db.data_ptr(),
+                               dX=None if dX is None else dX.data_ptr(), ldxo=K, accumulate_dw=0, accumulate_dx=0, M=M, N=N, K=K,
+                               scratch=scratch.data_ptr())
+        _lib.check(lib.mdt_op_linear_bwd(C.byref(a), _stream(dY)))
+        return (None if dX is None else dX.reshape(ctx.xshape), None if dW is None else dW.reshape(weight.shape), db, None)
+
+
+class HipRMSNorm(torch.autograd.Function):
+    """voltron RMSNorm: x / max(||x|| D^-1/2, eps) * g over the last dimension."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        lib = _lib.load()
+        D = x.shape[-1]
+        x2 = _c(x).reshape(-1, D)
+        gg = _c(g)
+        out = torch.empty_like(x2)
+        _lib.check(lib.mdt_op_rms_fwd(x2.data_ptr(), gg.data_ptr(), out.data_ptr(), x2.shape[0], D, RMS_EPS, _stream(x2)))
+        ctx.save_for_backward(x2, gg)
+        ctx.xshape = x.shape
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, g = ctx.saved_tensors
+        M, D = x2.shape
+        d = _c(dy).reshape(M, D)
+        dx = torch.empty_like(x2)
+        dg = torch.empty_like(g)
+        scratch = torch.empty(lib.mdt_op_rms_bwd_scratch(M, D), device=d.device, dtype=torch.float32)
+        _lib.check(lib.mdt_op_rms_bwd(x2.data_ptr(), g.data_ptr(), d.data_ptr(), dx.data_ptr(), 0, dg.data_ptr(), 0, M, D, RMS_EPS,
+                                      scratch.data_ptr(), _stream(d)))
+        return dx.reshape(ctx.xshape), dg
+
+
+class HipSwishGLU(torch.autograd.Function):
+    """u = [projected | gate] (..., 2H) -> projected * silu(gate)."""
+
+    @staticmethod
+    def forward(ctx, u):
+        lib = _lib.load()
+        H2 = u.shape[-1]
+        u2 = _c(u).reshape(-1, H2)
+        out = torch.empty((u2.shape[0], H2 // 2), device=u2.device, dtype=torch.float32)
+        _lib.check(lib.mdt_op_swiglu_fwd(u2.data_ptr(), out.data_ptr(), u2.shape[0], H2 // 2, _stream(u2)))
+        ctx.save_for_backward(u2)
+        ctx.ushape = u.shape
+        return out.reshape(*u.shape[:-1], H2 // 2)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        (u2,) = ctx.saved_tensors
+        M, H2 = u2.shape
+        d = _c(d_out).reshape(M, H2 // 2)
+        du = torch.empty_like(u2)
+        _lib.check(lib.mdt_op_swiglu_bwd(u2.data_ptr(), d.data_ptr(), du.data_ptr(), M, H2 // 2, _stream(d)))
+        return du.reshape(ctx.ushape)
+
+
+class HipSelfAttention(torch.autograd.Function):
+    """qkv (B, T, 3 D) = q | k | v -> softmax(q k^T * scale) v (B, T, D), H heads, unmasked, T <= 128."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads: int, scale: float):
+        lib = _lib.load()
+        B, T, D3 = qkv.shape
+        D = D3 // 3
+        q = _c(qkv)
+        out = torch.empty((B, T, D), device=q.device, dtype=torch.float32)
+        _lib.check(lib.mdt_op_attn_mid_fwd(q.data_ptr(), D3, out.data_ptr(), D, B, n_heads, D // n_heads, T, float(scale), _stream(q)))
+        ctx.save_for_backward(q)
+        ctx.cfg = (n_heads, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        (q,) = ctx.saved_tensors
+        n_heads, scale = ctx.cfg
+        B, T, D3 = q.shape
+        D = D3 // 3
+        d = _c(d_out)
+        dq = torch.empty_like(q)
+        _lib.check(lib.mdt_op_attn_mid_bwd(q.data_ptr(), D3, d.data_ptr(), D, dq.data_ptr(), D3, B, n_heads, D // n_heads, T, scale,
+                                           _stream(d)))
+        return dq, None, None

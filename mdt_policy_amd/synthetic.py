@@ -43,6 +43,15 @@ def param_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, profile: str 
         raise ValueError("rotary freqs are a deterministic buffer, not synthetic")
     if leaf in ("latents", "time_pos_emb"):  # Perceiver resampler: torch.randn initialised (perceiver_resampler.py:105-106)
         return normal(name, shape, seed, std=1.0)
+    if len(shape) == 4 and leaf == "weight":  # Conv2d patch embedding (out, c, ph, pw): a Linear over c*ph*pw inputs
+        fan_in = int(np.prod(shape[1:]))
+        return normal(name, shape, seed, std=0.02 if profile == "init" else 1.0 / np.sqrt(fan_in))
+    if len(shape) == 4:  # ctx_dec_pe (1, 2, 1, d)
+        return normal(name, shape, seed, std=0.02 if profile == "init" else 0.1)
+    if len(shape) == 1 and leaf == "gamma":  # LayerScale
+        if profile == "init":
+            return np.full(shape, 0.1, np.float32)
+        return normal(name, shape, seed, std=0.05, mean=0.3)
     if len(shape) == 3:  # pos_emb (1, T, d)
         return normal(name, shape, seed, std=0.02 if profile == "init" else 0.1)
     if len(shape) == 2:  # Linear weight (out, in)

@@ -552,6 +552,85 @@ def g14():
     save("g14_cla_infonce.npz", meta, **arrays)
 
 
+G15_MAE = {
+    # the shipped head (conf/model/img_gen/masked_transformer.yaml with gen_img_res = 112) and a small one
+    "default": (dict(resolution=112, patch_size=16, decoder_depth=6, decoder_embed_dim=192, decoder_n_heads=8, context_dim=384,
+                     mlp_ratio=4, in_channels=3, norm_pixel_loss=True, num_images=2, mask_ratio=0.75, symmetric_mask=True,
+                     img_gen_frame_diff=3), 3, 4),
+    "tiny": (dict(resolution=64, patch_size=16, decoder_depth=2, decoder_embed_dim=64, decoder_n_heads=4, context_dim=128,
+                  mlp_ratio=4, in_channels=3, norm_pixel_loss=True, num_images=2, mask_ratio=0.5, symmetric_mask=True,
+                  img_gen_frame_diff=3), 5, 4),
+}
+
+
+def install_voltron_stand_in():
+    """The decoder imports its transformer blocks from voltron-robotics, which is NOT vendored with the reference and not
+    installed here (requirements.txt:20, unpinned).  For this golden run the missing classes are stood in for by the
+    parameter tree of the published Voltron Block / RMSNorm evaluated with oracle/mae_oracle.py's restatement: what
+    g15 pins is therefore the REFERENCE'S OWN code around the blocks (projection, patch embedding, masking, token assembly,
+    position embeddings, loss); the block internals stay parity-unpinned."""
+    from mdt_policy_amd.models.img_generation import masked_transformer_decoder as F
+    from oracle import mae_oracle as O
+
+    class Block(F.Block):
+        def forward(self, x, mask=None):
+            return O.block(dict(self.named_parameters()), "", x, self.n_heads)
+
+    class RMSNorm(F.RMSNorm):
+        def forward(self, x):
+            return O.rms_norm(x, self.g)
+
+    def stub(name, **kw):
+        m = types.ModuleType(name)
+        m.__dict__.update(kw)
+        m.__path__ = []
+        sys.modules[name] = m
+
+    stub("voltron")
+    stub("voltron.models")
+    stub("voltron.models.util")
+    stub("voltron.models.util.transformer", Block=Block, RMSNorm=RMSNorm, PatchEmbed=None, get_2D_position_embeddings=None)
+    # import-time only (visualisation helpers of the same file)
+    if "torchvision" not in sys.modules:
+        stub("torchvision")
+        stub("torchvision.transforms")
+        stub("torchvision.transforms.functional", normalize=None, to_tensor=None, to_pil_image=None)
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        stub("PIL", Image=None)
+
+
+def g15():
+    """Masked generative foresight head: the reference's MaskedTransformerImgDecoder.forward + compute_loss (+ gradients)
+    around stood-in Voltron blocks (see install_voltron_stand_in)."""
+    install_voltron_stand_in()
+    from mdt.models.img_generation.masked_transformer_decoder import MaskedTransformerImgDecoder
+
+    for name, (kw, B, Tc) in G15_MAE.items():
+        m = MaskedTransformerImgDecoder(**kw)
+        sd = m.state_dict()
+        new = synthetic.fill_state_dict([(k, tuple(v.shape)) for k, v in sd.items() if k != "decoder_pe"], 151, "rich")
+        m.load_state_dict({**{k: torch.from_numpy(v) for k, v in new.items()}, "decoder_pe": sd["decoder_pe"]}, strict=True)
+        ctx = torch.from_numpy(synthetic.normal("ctx", (B, Tc, kw["context_dim"]), 152)).requires_grad_()
+        img = torch.from_numpy(synthetic.normal("img", (B, 2, 3, kw["resolution"], kw["resolution"]), 153))
+        torch.manual_seed(154)
+        rec, mask, restore, visible = m(ctx, img)
+        loss = m.compute_loss(img, rec, mask, restore)
+        loss.backward()
+        grads = {}
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach().double()
+            grads[k] = [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
+        meta = dict(kwargs=kw, B=B, Tc=Tc, weight_seed=151, ctx_seed=152, img_seed=153, profile="rich", grads=grads,
+                    state_dict=[[k, list(v.shape)] for k, v in sd.items()], named_parameters=[k for k, _ in m.named_parameters()])
+        save(f"g15_mae_{name}.npz", meta, rec=rec.detach().numpy(), mask=mask.numpy(), restore=restore.numpy(),
+             visible=visible.detach().numpy(), loss=np.array(loss.item(), np.float32), d_ctx=ctx.grad.numpy(),
+             decoder_pe=sd["decoder_pe"].numpy())
+
+
 def manifest():
     """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
     out = {}
@@ -574,7 +653,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "g14", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "g14", "g15", "manifest"]
     for w in which:
         print(w)
         globals()[w]()

@@ -1,0 +1,210 @@
+"""Masked generative foresight head (reference
+mdt/models/img_generation/masked_transformer_decoder.py).  CPU: the oracle against the golden outputs AND gradients of the
+reference's own forward / compute_loss (tests/golden/g15_mae_*.npz; the Voltron blocks inside are stood in for by the
+oracle's restatement -- block internals parity-unpinned, see oracle/mae_oracle.py), the facade's parameter tree.
+GPU: the HIP ops against float64 PyTorch, the facade against the goldens and against float64 autograd through the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mdt_policy_amd import synthetic
+from oracle import mae_oracle as O
+from tests.helpers import assert_close, load_fixture
+
+CASES = ["default", "tiny"]
+
+
+def case(name):
+    meta, fx = load_fixture(f"g15_mae_{name}.npz")
+    kw = meta["kwargs"]
+    shapes = [(k, tuple(s)) for k, s in meta["state_dict"] if k != "decoder_pe"]
+    P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, meta["weight_seed"], meta["profile"]).items()}
+    P["decoder_pe"] = torch.from_numpy(fx["decoder_pe"])
+    ctx = torch.from_numpy(synthetic.normal("ctx", (meta["B"], meta["Tc"], kw["context_dim"]), meta["ctx_seed"]))
+    img = torch.from_numpy(synthetic.normal("img", (meta["B"], 2, 3, kw["resolution"], kw["resolution"]), meta["img_seed"]))
+    shuffle = torch.argsort(torch.from_numpy(fx["restore"]), dim=1)
+    return meta, fx, kw, P, ctx, img, shuffle
+
+
+def summary(g):
+    g = g.detach().double().cpu()
+    return [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
+
+
+def check_summaries(got, want, what, rtol=2e-3):
+    assert set(want) == set(got), (what, set(want) ^ set(got))
+    for k, w in want.items():
+        g, w = np.array(got[k]), np.array(w)
+        tol = rtol * abs(w[0]) + 1e-6
+        assert abs(g[0] - w[0]) <= tol, f"{what} {k}: norm {g[0]} vs {w[0]}"
+        assert np.all(np.abs(g[1:] - w[1:]) <= tol), f"{what} {k}: {g[1:]} vs {w[1:]}"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_the_reference_forward_loss_and_gradients(name):
+    meta, fx, kw, P, ctx, img, shuffle = case(name)
+    np.testing.assert_allclose(O.position_table(kw["decoder_embed_dim"], kw["resolution"] // kw["patch_size"]), fx["decoder_pe"][0], atol=1e-6)
+    P64 = {k: v.double().requires_grad_(k != "decoder_pe") for k, v in P.items()}
+    c64 = ctx.double().requires_grad_()
+    rec, mask, restore, vis = O.forward(P64, kw, c64, img.double(), shuffle)
+    loss = O.compute_loss(kw, img.double(), rec, mask)
+    loss.backward()
+    assert_close(rec.detach(), fx["rec"], what="reconstructions")
+    assert np.array_equal(mask.numpy(), fx["mask"]) and np.array_equal(restore.numpy(), fx["restore"])
+    assert_close(vis.detach(), fx["visible"], what="visible patches")
+    assert abs(loss.item() - float(fx["loss"].reshape(-1)[0])) <= 1e-5 * abs(loss.item())
+    assert_close(c64.grad, fx["d_ctx"], rtol=2e-3, atol=1e-8, what="d_context")
+    check_summaries({k: summary(v.grad) for k, v in P64.items() if v.grad is not None}, meta["grads"], name)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_facade_parameter_tree_matches_the_reference(name):
+    from mdt_policy_amd.models.img_generation.masked_transformer_decoder import MaskedTransformerImgDecoder
+    meta, fx, kw, P, *_ = case(name)
+    m = MaskedTransformerImgDecoder(**kw)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == meta["state_dict"]
+    assert [k for k, _ in m.named_parameters()] == meta["named_parameters"]
+    assert_close(m.decoder_pe.detach(), fx["decoder_pe"], atol=1e-6, what="decoder_pe (2-D sine-cosine table)")
+    assert not m.decoder_pe.requires_grad
+    assert torch.allclose(m.decoder_blocks[0].layer_scale_attn.gamma, torch.full((kw["decoder_embed_dim"],), 0.1))
+    with pytest.raises(RuntimeError, match="ROCm GPU"):
+        m(torch.zeros(1, 4, kw["context_dim"]), torch.zeros(1, 2, 3, kw["resolution"], kw["resolution"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+def _lib():
+    from mdt_policy_amd import _lib as L
+    return L, L.load()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,hd,T", [(3, 8, 24, 102), (2, 4, 16, 36), (1, 2, 64, 64), (2, 2, 32, 100), (2, 3, 32, 17), (5, 8, 48, 7), (2, 2, 24, 1)])
+def test_attention_mid_forward_and_backward(B, H, hd, T):
+    L, lib = _lib()
+    D = H * hd
+    qkv = torch.from_numpy(synthetic.normal("qkv", (B, T, 3 * D), 161))
+    do = torch.from_numpy(synthetic.normal("do", (B, T, D), 162))
+    q64 = qkv.double().requires_grad_()
+    q, k, v = (t.reshape(B, T, H, hd).transpose(1, 2) for t in q64.split(D, dim=-1))
+    ref = ((q @ k.transpose(-1, -2) * hd ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(B, T, D)
+    ref.backward(do.double())
+    qd, dod = qkv.cuda(), do.cuda()
+    out = torch.empty(B, T, D, device="cuda")
+    L.check(lib.mdt_op_attn_mid_fwd(qd.data_ptr(), 3 * D, out.data_ptr(), D, B, H, hd, T, hd ** -0.5, _s()))
+    assert_close(out.cpu(), ref.detach(), what="attention output")
+    dq = torch.full((B, T, 3 * D), float("nan"), device="cuda")
+    L.check(lib.mdt_op_attn_mid_bwd(qd.data_ptr(), 3 * D, dod.data_ptr(), D, dq.data_ptr(), 3 * D, B, H, hd, T, hd ** -0.5, _s()))
+    assert_close(dq.cpu(), q64.grad, rtol=1e-3, atol=1e-4, what="d_qkv")
+
+
+@pytest.mark.gpu
+def test_attention_mid_rejects_what_it_cannot_run():
+    L, lib = _lib()
+    x = torch.zeros(1, 129, 3 * 48, device="cuda")
+    o = torch.zeros(1, 129, 48, device="cuda")
+    assert lib.mdt_op_attn_mid_fwd(x.data_ptr(), 144, o.data_ptr(), 48, 1, 2, 24, 129, 1.0, _s()) != 0   # T > 128
+    assert lib.mdt_op_attn_mid_fwd(x.data_ptr(), 144, o.data_ptr(), 48, 1, 4, 12, 64, 1.0, _s()) != 0    # head dim 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,D", [(306, 192), (7, 64), (1030, 384)])
+def test_rmsnorm_and_swiglu_ops(M, D):
+    L, lib = _lib()
+    x = torch.from_numpy(synthetic.normal("x", (M, D), 163))
+    g = torch.from_numpy(synthetic.normal("g", (D,), 164, std=0.1, mean=1.0))
+    dy = torch.from_numpy(synthetic.normal("dy", (M, D), 165))
+    x64, g64 = x.double().requires_grad_(), g.double().requires_grad_()
+    ref = O.rms_norm(x64, g64)
+    ref.backward(dy.double())
+    xd, gd, dyd = x.cuda(), g.cuda(), dy.cuda()
+    out, dx, dg = torch.empty_like(xd), torch.empty_like(xd), torch.empty_like(gd)
+    L.check(lib.mdt_op_rms_fwd(xd.data_ptr(), gd.data_ptr(), out.data_ptr(), M, D, 1e-8, _s()))
+    scratch = torch.empty(lib.mdt_op_rms_bwd_scratch(M, D), device="cuda")
+    L.check(lib.mdt_op_rms_bwd(xd.data_ptr(), gd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), 0, dg.data_ptr(), 0, M, D, 1e-8,
+                               scratch.data_ptr(), _s()))
+    assert_close(out.cpu(), ref.detach(), what="rmsnorm")
+    assert_close(dx.cpu(), x64.grad, what="rmsnorm dx")
+    assert_close(dg.cpu(), g64.grad, rtol=1e-3, atol=1e-4 * max(1.0, (M / 64) ** 0.5), what="rmsnorm dg")
+    H = D // 2
+    u64 = x.double().requires_grad_()
+    a, b = u64.tensor_split(2, dim=-1)
+    r2 = a * torch.nn.functional.silu(b)
+    d2 = dy[:, :H]
+    r2.backward(d2.double())
+    o2, du = torch.empty(M, H, device="cuda"), torch.empty_like(xd)
+    L.check(lib.mdt_op_swiglu_fwd(xd.data_ptr(), o2.data_ptr(), M, H, _s()))
+    L.check(lib.mdt_op_swiglu_bwd(xd.data_ptr(), d2.contiguous().cuda().data_ptr(), du.data_ptr(), M, H, _s()))
+    assert_close(o2.cpu(), r2.detach(), what="swiglu")
+    assert_close(du.cpu(), u64.grad, what="swiglu du")
+
+
+def _facade(kw, P):
+    from mdt_policy_amd.models.img_generation.masked_transformer_decoder import MaskedTransformerImgDecoder
+    m = MaskedTransformerImgDecoder(**kw)
+    m.load_state_dict(P, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_head_matches_reference_goldens_and_float64_autograd(name):
+    meta, fx, kw, P, ctx, img, shuffle = case(name)
+    m = _facade(kw, P)
+    c = ctx.cuda().requires_grad_()
+    noise = torch.from_numpy(fx["restore"]).float().cuda()  # argsort(noise) == the fixture's shuffle
+    rec, mask, restore, vis = m(c, img.cuda(), noise=noise)
+    loss = m.compute_loss(img.cuda(), rec, mask, restore)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert_close(rec.detach().cpu(), fx["rec"], what="reconstructions vs reference")
+    assert np.array_equal(mask.cpu().numpy(), fx["mask"]) and np.array_equal(restore.cpu().numpy(), fx["restore"])
+    assert_close(vis.detach().cpu(), fx["visible"], what="visible patches vs reference")
+    ref_loss = float(fx["loss"].reshape(-1)[0])
+    assert abs(loss.item() - ref_loss) <= 1e-3 * abs(ref_loss)
+    assert_close(c.grad.cpu(), fx["d_ctx"], rtol=2e-3, atol=2e-3 * float(np.abs(fx["d_ctx"]).max()), what="d_context vs reference")
+    check_summaries({k: summary(p.grad) for k, p in m.named_parameters() if p.grad is not None}, meta["grads"], name + " vs reference")
+    # full tensors against float64 autograd through the oracle
+    P64 = {k: v.double().requires_grad_(k != "decoder_pe") for k, v in P.items()}
+    r64, m64, _, _ = O.forward(P64, kw, ctx.double(), img.double(), shuffle)
+    O.compute_loss(kw, img.double(), r64, m64).backward()
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = P64[k].grad
+        assert_close(p.grad.cpu(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()) + 1e-9, what=k)
+
+
+@pytest.mark.gpu
+def test_hip_head_training_batch_against_the_oracle_on_gpu_fp64():
+    """A training-sized batch (B = 96: 9 792 decoder rows, the GEMMs' large-M geometries and split-K dW products) against
+    float64 autograd through the oracle."""
+    meta, fx, kw, P, _, _, _ = case("default")
+    B = 96
+    ctx = torch.from_numpy(synthetic.normal("ctx", (B, 4, kw["context_dim"]), 171))
+    img = torch.from_numpy(synthetic.normal("img", (B, 2, 3, kw["resolution"], kw["resolution"]), 172))
+    noise = torch.from_numpy(synthetic.uniform("mask_noise", (B, 49), 173))
+    m = _facade(kw, P)
+    c = ctx.cuda().requires_grad_()
+    rec, mask, restore, _ = m(c, img.cuda(), noise=noise.cuda())
+    loss = m.compute_loss(img.cuda(), rec, mask, restore)
+    loss.backward()
+    shuffle = torch.argsort(noise, dim=1)
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    P64 = {k: v.double().requires_grad_(k != "decoder_pe") for k, v in P.items()}
+    c64 = ctx.double().requires_grad_()
+    r64, m64, _, _ = O.forward(P64, kw, c64, img.double(), shuffle)
+    l64 = O.compute_loss(kw, img.double(), r64, m64)
+    l64.backward()
+    assert abs(loss.item() - l64.item()) <= 1e-3 * abs(l64.item())
+    assert_close(rec.detach().cpu(), r64.detach(), what="B=96 reconstructions")
+    assert_close(c.grad.cpu(), c64.grad, rtol=2e-3, atol=2e-3 * float(c64.grad.abs().max()), what="B=96 d_context")
+    for k, p in m.named_parameters():
+        if p.requires_grad:
+            ref = P64[k].grad
+            assert_close(p.grad.cpu(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()) + 1e-9, what=f"B=96 {k}")
