@@ -399,7 +399,9 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         const char* f = getenv("MDT_HIP_MID_MAX");
         if (f) g_mdt_mid_max = atoi(f);
     }
-    if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512)) {
+    // (not for the batched split-K products of the weight gradients: few output rows there come with a DEEP reduction --
+    // N = 192 layers of the masked-image decoder: 595 us as 16-column split-K tiles vs ~300 us tiled)
+    if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096) {
         hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4, a.batch > 1 ? a.batch : 1), dim3(512), 0, s, a, g_zeros);
         return hipGetLastError();
     }
