@@ -448,184 +448,170 @@ class BrownianTreeNoiseSampler:
         return (w if self.batched else w[0]) / (t1 - t0).abs().sqrt()
 
 
-class PIDStepSizeController:
-    """PID step-size controller of the adaptive DPM-Solver (reference gc_sampling.py:495-521)."""
-
-    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
-        self.h = h
-        self.b1 = (pcoeff + icoeff + dcoeff) / order
-        self.b2 = -(pcoeff + 2 * dcoeff) / order
-        self.b3 = dcoeff / order
-        self.accept_safety, self.eps, self.errs = accept_safety, eps, []
-
-    def propose_step(self, error):
-        inv = 1 / (float(error) + self.eps)
-        if not self.errs:
-            self.errs = [inv, inv, inv]
-        self.errs[0] = inv
-        factor = self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3
-        factor = 1 + math.atan(factor - 1)  # limiter
-        accept = factor >= self.accept_safety
-        if accept:
-            self.errs[2], self.errs[1] = self.errs[1], self.errs[0]
-        self.h *= factor
-        return accept
+# ------------------------------------------------------------------------------------------------
+# DPM-Solver (arXiv:2206.00927) behind sample_dpm_fast / sample_dpm_adaptive (reference gc_sampling.py:495-697,
+# 834-870).  One exponential-integrator routine covers the three orders: with lambda = t = -ln(sigma), h the step and
+# r_1 < r_2 the interior nodes of the order,
+#     x(t+h) = x - sigma(t+h) * [ expm1(h) * eps_0  +  c_k * (eps_k - eps_0) ]
+# where eps_k is the noise prediction at node k (evaluated on the lower-order estimate at that node), and
+#     order 1: no correction;   order 2: c_1 = expm1(h) / (2 r_1);   order 3: c_2 = (expm1(h)/h - 1) / r_2.
+# ------------------------------------------------------------------------------------------------
+_DPM_NODES = {1: (), 2: (1 / 2,), 3: (1 / 3, 2 / 3)}
 
 
-class DPMSolver:
-    """DPM-Solver-1/2/3 steps in t = -ln(sigma) (reference gc_sampling.py:524-670, arXiv:2206.00927).  Time values are
-    0-dim host tensors; the model is evaluated at sigma = exp(-t) shared by the whole batch."""
+class _EpsEvaluator:
+    """eps(x, t) = (x - D(x; sigma(t))) / sigma(t) of a denoiser, counting its evaluations."""
 
-    def __init__(self, model, extra_args=None, eps_callback=None, info_callback=None):
-        self.model = model
-        self.extra_args = {} if extra_args is None else extra_args
-        self.eps_callback, self.info_callback = eps_callback, info_callback
+    def __init__(self, model, state, goal, extra_args):
+        self.model, self.state, self.goal, self.kw = model, state, goal, (extra_args or {})
+        self.evals = 0
 
-    t = staticmethod(_t)
-    sigma = staticmethod(_sigma)
-
-    def eps(self, cache, key, state, action, goal, t):
-        if key in cache:
-            return cache[key], cache
+    def __call__(self, x, t):
         sig = _sigma(t)
-        e = (action - self.model(state, action, goal, _sig_in(sig, action, self.model), **self.extra_args)) / _f(sig)
-        if self.eps_callback is not None:
-            self.eps_callback()
-        return e, {key: e, **cache}
+        self.evals += 1
+        return (x - self.model(self.state, x, self.goal, _sig_in(sig, x, self.model), **self.kw)) / _f(sig)
 
-    def dpm_solver_1_step(self, state, action, goal, t, t_next, eps_cache=None):
-        cache = {} if eps_cache is None else eps_cache
-        h = t_next - t
-        e, cache = self.eps(cache, 'eps', state, action, goal, t)
-        return action - _f(_sigma(t_next) * h.expm1()) * e, cache
 
-    def dpm_solver_2_step(self, state, action, goal, t, t_next, r1=1 / 2, eps_cache=None):
-        cache = {} if eps_cache is None else eps_cache
-        h = t_next - t
-        e, cache = self.eps(cache, 'eps', state, action, goal, t)
-        s1 = t + r1 * h
-        u1 = action - _f(_sigma(s1) * (r1 * h).expm1()) * e
-        e1, cache = self.eps(cache, 'eps_r1', state, u1, goal, s1)
-        out = action - _f(_sigma(t_next) * h.expm1()) * e - _f(_sigma(t_next) / (2 * r1) * h.expm1()) * (e1 - e)
-        return out, cache
+def _dpm_stages(eps, x, t, t_next, nodes, eps0):
+    """Noise predictions at the left end and at the interior `nodes` of [t, t_next] (each on the estimate the lower
+    stages give there): the list [eps_0, eps_1, ...]."""
+    h = t_next - t
+    out = [eps0]
+    for k, r in enumerate(nodes):
+        s = t + r * h
+        u = x - _f(_sigma(s) * (r * h).expm1()) * eps0
+        if k == 1:  # second interior node: first-node correction scaled to this node
+            r1 = nodes[0]
+            u = u - _f(_sigma(s) * (r / r1) * ((r * h).expm1() / (r * h) - 1)) * (out[1] - eps0)
+        out.append(eps(u, s))
+    return out
 
-    def dpm_solver_3_step(self, state, action, goal, t, t_next, r1=1 / 3, r2=2 / 3, eps_cache=None):
-        cache = {} if eps_cache is None else eps_cache
-        h = t_next - t
-        e, cache = self.eps(cache, 'eps', state, action, goal, t)
-        s1, s2 = t + r1 * h, t + r2 * h
-        u1 = action - _f(_sigma(s1) * (r1 * h).expm1()) * e
-        e1, cache = self.eps(cache, 'eps_r1', state, u1, goal, s1)
-        u2 = action - _f(_sigma(s2) * (r2 * h).expm1()) * e \
-            - _f(_sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1)) * (e1 - e)
-        e2, cache = self.eps(cache, 'eps_r2', state, u2, goal, s2)
-        out = action - _f(_sigma(t_next) * h.expm1()) * e - _f(_sigma(t_next) / r2 * (h.expm1() / h - 1)) * (e2 - e)
-        return out, cache
 
-    def dpm_solver_fast(self, state, action, goal, t_start, t_end, nfe, eta=0., s_noise=1., noise_sampler=None):
-        # (the reference builds its default noise sampler from an undefined name, gc_sampling.py:600, so it only
-        #  runs with an explicit one; here the default is the action-shaped Gaussian sampler it meant)
-        noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
-        if not t_end > t_start and eta:
-            raise ValueError('eta must be 0 for reverse sampling')
-        m = math.floor(nfe / 3) + 1
-        ts = torch.linspace(_f(t_start), _f(t_end), m + 1)
-        orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
-        with _hoist(self.model, state, goal):
-            for i, order in enumerate(orders):
-                cache = {}
-                t, t_next = ts[i], ts[i + 1]
-                if eta:
-                    sd, su = get_ancestral_step(_sigma(t), _sigma(t_next), eta)
-                    t_next_ = torch.minimum(torch.as_tensor(t_end), _t(sd))
-                    su = (_sigma(t_next) ** 2 - _sigma(t_next_) ** 2) ** 0.5
-                else:
-                    t_next_, su = t_next, 0.
-                e, cache = self.eps(cache, 'eps', state, action, goal, t)
-                if self.info_callback is not None:
-                    self.info_callback({'x': action, 'i': i, 't': ts[i], 't_up': t, 'denoised': action - _f(_sigma(t)) * e})
-                step = (self.dpm_solver_1_step, self.dpm_solver_2_step, self.dpm_solver_3_step)[order - 1]
-                action, cache = step(state, action, goal, t, t_next_, eps_cache=cache)
-                if _f(su) != 0:
-                    action = action + _f(su) * s_noise * noise_sampler(_sigma(t), _sigma(t_next))
-        return action
+def _dpm_combine(x, t, t_next, nodes, stages):
+    """The order-(len(nodes)+1) update from the stage values of _dpm_stages."""
+    h = t_next - t
+    sn = _sigma(t_next)
+    new = x - _f(sn * h.expm1()) * stages[0]
+    if len(nodes) == 1:
+        new = new - _f(sn / (2 * nodes[0]) * h.expm1()) * (stages[1] - stages[0])
+    elif len(nodes) == 2:
+        new = new - _f(sn / nodes[1] * (h.expm1() / h - 1)) * (stages[2] - stages[0])
+    return new
 
-    def dpm_solver_adaptive(self, state, action, goal, t_start, t_end, order=3, rtol=0.05, atol=0.0078, h_init=0.05,
-                            pcoeff=0., icoeff=1., dcoeff=0., accept_safety=0.81, eta=0., s_noise=1., noise_sampler=None):
-        # (the reference reads `noise_sampler` before assigning it, gc_sampling.py:633: its adaptive solver cannot run)
-        noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
-        if order not in {2, 3}:
-            raise ValueError('order should be 2 or 3')
-        t_start, t_end = torch.as_tensor(t_start, dtype=torch.float32), torch.as_tensor(t_end, dtype=torch.float32)
-        forward = bool(t_end > t_start)
-        if not forward and eta:
-            raise ValueError('eta must be 0 for reverse sampling')
-        h_init = abs(h_init) * (1 if forward else -1)
-        s = t_start
-        action_prev = action
-        pid = PIDStepSizeController(h_init, pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
-        info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
-        with _hoist(self.model, state, goal):
-            while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
-                cache = {}
-                t = torch.minimum(t_end, s + pid.h) if forward else torch.maximum(t_end, s + pid.h)
-                if eta:
-                    sd, su = get_ancestral_step(_sigma(s), _sigma(t), eta)
-                    t_ = torch.minimum(t_end, _t(sd))
-                    su = (_sigma(t) ** 2 - _sigma(t_) ** 2) ** 0.5
-                else:
-                    t_, su = t, 0.
-                e, cache = self.eps(cache, 'eps', state, action, goal, s)
-                denoised = action - _f(_sigma(s)) * e
-                if order == 2:
-                    low, cache = self.dpm_solver_1_step(state, action, goal, s, t_, eps_cache=cache)
-                    high, cache = self.dpm_solver_2_step(state, action, goal, s, t_, eps_cache=cache)
-                else:
-                    low, cache = self.dpm_solver_2_step(state, action, goal, s, t_, r1=1 / 3, eps_cache=cache)
-                    high, cache = self.dpm_solver_3_step(state, action, goal, s, t_, eps_cache=cache)
-                delta = torch.clamp(rtol * torch.maximum(low.abs(), action_prev.abs()), min=atol)
-                error = torch.linalg.norm((low - high) / delta) / action.numel() ** 0.5
-                if pid.propose_step(error):
-                    action_prev = low
-                    action = high if _f(su) == 0 else high + _f(su) * s_noise * noise_sampler(_sigma(s), _sigma(t))
-                    s = t
-                    info['n_accept'] += 1
-                else:
-                    info['n_reject'] += 1
-                info['nfe'] += order
-                info['steps'] += 1
-                if self.info_callback is not None:
-                    self.info_callback({'x': action, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised,
-                                        'error': error, 'h': pid.h, **info})
-        return action, info
+
+def _ancestral_split(t, t_next, t_end, eta):
+    """Deterministic end point and the noise level re-injected after it (eta > 0), in t = -ln(sigma)."""
+    if not eta:
+        return t_next, 0.
+    sd, _ = get_ancestral_step(_sigma(t), _sigma(t_next), eta)
+    t_det = torch.minimum(torch.as_tensor(t_end), _t(sd))
+    return t_det, (_sigma(t_next) ** 2 - _sigma(t_det) ** 2) ** 0.5
+
+
+class _StepControl:
+    """Proportional-integral-derivative step-size control on the inverse error history (Soederlind's digital-filter
+    form, as torchdiffeq / k-diffusion use it), evaluated in the log domain, with the arctan limiter."""
+
+    def __init__(self, h, kp, ki, kd, order, safety, eps=1e-8):
+        self.h = h
+        self.weights = ((kp + ki + kd) / order, -(kp + 2 * kd) / order, kd / order)
+        self.safety, self.eps = safety, eps
+        self.history = None  # log inverse errors: [current, previous, the one before]
+
+    def update(self, error):
+        """Feed the scaled error of the step just tried; returns whether it is accepted and rescales ``h``."""
+        cur = -math.log(float(error) + self.eps)
+        self.history = [cur, cur, cur] if self.history is None else [cur] + self.history[1:]
+        factor = math.exp(sum(w * e for w, e in zip(self.weights, self.history)))
+        factor = 1 + math.atan(factor - 1)
+        ok = factor >= self.safety
+        if ok:
+            self.history = [cur, cur, self.history[1]]  # shift: the accepted error becomes "previous"
+        self.h *= factor
+        return ok
+
+
+def _check_sigma_range(sigma_min, sigma_max):
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
 
 
 @torch.no_grad()
 def sample_dpm_fast(model, state, action, goal, sigma_min, sigma_max, n, scaler=None, extra_args=None, callback=None,
                     disable=None, eta=0., s_noise=1., noise_sampler=None):
-    """DPM-Solver-Fast, fixed step size, n model evaluations (reference gc_sampling.py:673-697)."""
-    if sigma_min <= 0 or sigma_max <= 0:
-        raise ValueError('sigma_min and sigma_max must not be 0')
-    solver = DPMSolver(model, extra_args)
-    if callback is not None:
-        solver.info_callback = lambda info: callback({'sigma': _sigma(info['t']), 'sigma_hat': _sigma(info['t_up']), **info})
-    return solver.dpm_solver_fast(state, action, goal, _t(torch.tensor(float(sigma_max))), _t(torch.tensor(float(sigma_min))),
-                                  n, eta, s_noise, noise_sampler)
+    """DPM-Solver-Fast, fixed step size, n model evaluations (reference gc_sampling.py:673-697 / 592-624): m =
+    floor(n/3)+1 uniform steps in t, third order except for the tail (.., 2, 1 when 3 | n, else .., n mod 3).
+    (The reference builds its default noise sampler from an undefined name, :600, so it only runs with an explicit one;
+    the default here is the action-shaped Gaussian sampler it meant.)"""
+    _check_sigma_range(sigma_min, sigma_max)
+    t_start, t_end = _t(torch.tensor(float(sigma_max))), _t(torch.tensor(float(sigma_min)))
+    if eta and not t_end > t_start:
+        raise ValueError('eta must be 0 for reverse sampling')
+    noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    m = n // 3 + 1
+    grid = torch.linspace(_f(t_start), _f(t_end), m + 1)
+    orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]
+    with _hoist(model, state, goal):
+        eps = _EpsEvaluator(model, state, goal, extra_args)
+        for i, order in enumerate(orders):
+            t, t_next = grid[i], grid[i + 1]
+            t_det, s_up = _ancestral_split(t, t_next, t_end, eta)
+            e0 = eps(action, t)
+            if callback is not None:
+                callback({'x': action, 'i': i, 't': t, 't_up': t, 'denoised': action - _f(_sigma(t)) * e0,
+                          'sigma': _sigma(t), 'sigma_hat': _sigma(t)})
+            nodes = _DPM_NODES[order]
+            action = _dpm_combine(action, t, t_det, nodes, _dpm_stages(eps, action, t, t_det, nodes, e0))
+            if _f(s_up) != 0:
+                action = action + _f(s_up) * s_noise * noise_sampler(_sigma(t), _sigma(t_next))
+    return action
 
 
 @torch.no_grad()
 def sample_dpm_adaptive(model, state, action, goal, sigma_min, sigma_max, extra_args=None, callback=None, disable=None,
                         order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0., icoeff=1., dcoeff=0., accept_safety=0.81,
                         eta=0., s_noise=1., return_info=False, noise_sampler=None):
-    """DPM-Solver-12 / -23 with adaptive step size (reference gc_sampling.py:834-870)."""
-    if sigma_min <= 0 or sigma_max <= 0:
-        raise ValueError('sigma_min and sigma_max must not be 0')
-    solver = DPMSolver(model, extra_args)
-    if callback is not None:
-        solver.info_callback = lambda info: callback({'sigma': _sigma(info['t']), 'sigma_hat': _sigma(info['t_up']), **info})
-    action, info = solver.dpm_solver_adaptive(state, action, goal, _t(torch.tensor(float(sigma_max))),
-                                              _t(torch.tensor(float(sigma_min))), order, rtol, atol, h_init, pcoeff, icoeff,
-                                              dcoeff, accept_safety, eta, s_noise, noise_sampler)
+    """DPM-Solver-12 / -23 with adaptive step size (reference gc_sampling.py:834-870 / 626-670): the embedded pair
+    (order-1, order) shares its stage evaluations -- the order-2 estimate of the 23 pair uses r_1 = 1/3, the first node
+    of the order-3 step -- and the scaled difference of the two drives the step-size control.
+    (The reference reads `noise_sampler` before assigning it, :633: its adaptive solver cannot run.  Parity unpinned.)"""
+    _check_sigma_range(sigma_min, sigma_max)
+    if order not in (2, 3):
+        raise ValueError('order should be 2 or 3')
+    t_start = _t(torch.tensor(float(sigma_max))).to(torch.float32)
+    t_end = _t(torch.tensor(float(sigma_min))).to(torch.float32)
+    forward = bool(t_end > t_start)
+    if eta and not forward:
+        raise ValueError('eta must be 0 for reverse sampling')
+    noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    ctl = _StepControl(abs(h_init) if forward else -abs(h_init), pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
+    info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
+    nodes_hi = _DPM_NODES[order]
+    nodes_lo = nodes_hi[:-1]  # order 2: () ; order 3: (1/3,) -- the same first node, so the pair shares eps_1
+    s, prev = t_start, action
+    with _hoist(model, state, goal):
+        eps = _EpsEvaluator(model, state, goal, extra_args)
+        while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+            t = torch.minimum(t_end, s + ctl.h) if forward else torch.maximum(t_end, s + ctl.h)
+            t_det, s_up = _ancestral_split(s, t, t_end, eta)
+            stages = _dpm_stages(eps, action, s, t_det, nodes_hi, eps(action, s))
+            low = _dpm_combine(action, s, t_det, nodes_lo, stages)
+            high = _dpm_combine(action, s, t_det, nodes_hi, stages)
+            denoised = action - _f(_sigma(s)) * stages[0]
+            tol = torch.clamp(rtol * torch.maximum(low.abs(), prev.abs()), min=atol)
+            error = torch.linalg.norm((low - high) / tol) / action.numel() ** 0.5
+            if ctl.update(error):
+                prev = low
+                action = high if _f(s_up) == 0 else high + _f(s_up) * s_noise * noise_sampler(_sigma(s), _sigma(t))
+                s = t
+                info['n_accept'] += 1
+            else:
+                info['n_reject'] += 1
+            info['steps'] += 1
+            info['nfe'] = eps.evals
+            if callback is not None:
+                callback({'x': action, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised, 'error': error,
+                          'h': ctl.h, 'sigma': _sigma(s), 'sigma_hat': _sigma(s), **info})
     return (action, info) if return_info else action
 
 
