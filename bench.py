@@ -272,11 +272,11 @@ def cpu_baseline(cfg, P, batch, n_denoise, budget_s, threads, only=None):
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{nt},{int(hoist)},{per}", "--batch", str(batch),
                "--denoise-steps", str(n_denoise)]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=2.5 * per + 45, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=2.0 * per + 20, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
             legs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
         except (subprocess.TimeoutExpired, IndexError, ValueError) as e:
             legs.append({"threads": nt, "mode": "hoisted" if hoist else "as_written", "value": None,
-                         "note": f"did not finish within {2.5 * per + 45:.0f} s ({type(e).__name__})"})
+                         "note": f"did not finish within {2.0 * per + 20:.0f} s ({type(e).__name__})"})
         log(f"cpu baseline leg {legs[-1]}")
     head = legs[0]
     return {"value": head["value"], "unit": "action-chunks/s", "cores": head["threads"], "kind": "port",
