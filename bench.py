@@ -413,13 +413,13 @@ def main():
             log("dominant kernel timed")
             # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc pass of the same kernel and shape (profiles/)
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_kernel_pmc.json")
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_kernel_pmc.json")
             if B == 256 and os.path.exists(pmc):
                 with open(pmc) as f:
                     j = json.load(f)
                 res["roofline"]["traffic"] = j["hbm_side_bytes_per_launch"]
                 res["roofline"]["traffic_scope"] = ("bytes per launch of the dominant kernel (TCC_EA0 read x128 B + write "
-                                                    "x64 B, rocprofv3 --pmc pass committed as profiles/r01_dominant_kernel_pmc.json); "
+                                                    "x64 B, rocprofv3 --pmc pass committed as profiles/r02_dominant_kernel_pmc.json); "
                                                     f"algorithmic {j['algorithmic_bytes_per_launch']} B")
         except Exception as e:  # diagnostic leg only; never hides the main number
             res["roofline"]["dominant_kernel"] = {"error": str(e)}
