@@ -166,7 +166,8 @@ extern "C" mdt_status mdt_op_colsum(const float* X, int64_t ldx, int64_t M, int6
 
 // ------------------------------------------------------------------------------------------------
 // multi-tensor optimizer updates: the (tensor, chunk) table of a call lives in device memory.  A training loop passes the
-// same pointers step after step, so the tables are cached by content (4 slots per device, pinned staging): a repeated
+// same pointers step after step, so the tables are cached by content (16 slots per device, least recently used replaced -- the reference's
+// configure_optimizers builds 6-7 parameter groups plus the EMA list --, pinned staging): a repeated
 // table costs nothing, a new one is one asynchronous copy -- the call never waits for the stream (a stream
 // synchronisation here cost 1.5 ms per B = 1024 step: the host lost its run-ahead over the backward's launches).
 // ------------------------------------------------------------------------------------------------
@@ -180,11 +181,12 @@ struct OptSlot {
     std::vector<char> key;    // the caller's table bytes this slot holds
     size_t tab_bytes = 0;
     int n_blocks = 0;
+    uint64_t last_use = 0;
 };
 struct OptTable {  // one per device: the tables live in that device's memory
     std::mutex mu;
-    OptSlot slots[4];
-    int next = 0;
+    OptSlot slots[16];
+    uint64_t clock = 0;
 };
 OptTable g_opt_dev[32];
 }  // namespace
@@ -199,6 +201,7 @@ static mdt_status upload_opt_table(OptTable& g_opt, const mdt_opt_tensor* tensor
             *d_blocks = (const int2*)((const char*)sl.dev + sl.tab_bytes);
             *n_blocks = sl.n_blocks;
             *used = &sl;
+            sl.last_use = ++g_opt.clock;
             return MDT_OK;
         }
     std::vector<int2> blocks;
@@ -209,8 +212,11 @@ static mdt_status upload_opt_table(OptTable& g_opt, const mdt_opt_tensor* tensor
     }
     const size_t tab_bytes = (key_bytes + 255) & ~(size_t)255;
     const size_t total = tab_bytes + blocks.size() * sizeof(int2);
-    OptSlot& sl = g_opt.slots[g_opt.next];
-    g_opt.next = (g_opt.next + 1) % 4;
+    OptSlot* lru = &g_opt.slots[0];
+    for (OptSlot& c : g_opt.slots)
+        if (c.last_use < lru->last_use) lru = &c;
+    OptSlot& sl = *lru;
+    sl.last_use = ++g_opt.clock;
     if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (sl.busy) HIP_TRY(hipEventSynchronize(sl.ev));  // the last kernel that read this slot (long done in practice)
     if (total > sl.cap) {

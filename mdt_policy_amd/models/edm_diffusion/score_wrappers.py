@@ -89,8 +89,10 @@ class GCDenoiser(nn.Module):
         im = self.inner_model
         eng = self._engine()
         goal = im._goals(goal, bool(kwargs.get("uncond", False)))
-        if self._ctx_key is not None and self._ctx_key == (id(state), id(goal), action.shape[0]):
+        if self._ctx_key is not None and self._ctx_key == (id(state), id(goal), action.shape[0], eng.ctx_generation):
             return eng.denoise_cached(action, sigma, 0)  # inside cached_context(): encoder hoisted
+        # (any other call that re-encoded on this handle since -- an uncond / other-state evaluation inside the block --
+        #  bumped eng.ctx_generation: the key no longer matches and this call runs the full forward)
         out, ctx = eng.forward(state, action, goal, sigma)
         im.latent_encoder_emb = ctx
         return out
@@ -146,7 +148,7 @@ class GCDenoiser(nn.Module):
         B = ctx.shape[0]
         prev = self._ctx_key
         # _goals() returns its argument unchanged for the usual (B,1,G) goal, so id(goal) identifies it
-        self._ctx_key = (id(state), id(g), B) if g is goal else None
+        self._ctx_key = (id(state), id(g), B, eng.ctx_generation) if g is goal else None
         try:
             yield ctx
         finally:

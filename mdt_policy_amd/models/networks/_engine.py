@@ -49,6 +49,7 @@ class HipEngine:
         self.expected = {self.lib.mdt_param_name(handle, i).decode(): self.lib.mdt_param_numel(handle, i)
                          for i in range(n)}
         self._uploaded: Dict[str, tuple] = {}
+        self.ctx_generation = 0  # bumped by every call that rewrites the handle's cached context (encoder output, K|V, folds)
         self.sigma_in_context = not cfg.use_ada_conditioning  # sigma embedding is the first context token
         # goal_conditioned=False: MDTV keeps the goal token (behind the state tokens), MDT has none
         self.has_goal_token = not (cfg.no_goal_conditioning and cfg.arch == 1)
@@ -154,6 +155,7 @@ class HipEngine:
                 raise ValueError("use_ada_conditioning=False: the encoder needs sigma (its first context token)")
             s = self._in(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma, (B,))
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        self.ctx_generation += 1
         _lib.check(self.lib.mdt_encode(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
                                        int(honour_modality), _ptr(s), B, _ptr(ctx), self._stream()))
         return ctx
@@ -178,6 +180,7 @@ class HipEngine:
         g, x_, s = self._goal(goal, B), self._in(x, (B, self.Ta, self.A)), self._in(sigma, (B,))
         out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        self.ctx_generation += 1
         _lib.check(self.lib.mdt_forward(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(x_),
                                         _ptr(s), B, _ptr(out), _ptr(ctx), self._stream()))
         return out, ctx
@@ -195,12 +198,14 @@ class HipEngine:
             sig = self._in(sigmas.reshape(-1))
             n = sig.numel() - 1
             self._keep = sig  # the kernel that reads it is only enqueued: keep the (possibly converted) tensor alive
+            self.ctx_generation += 1
             _lib.check(self.lib.mdt_sample_ddim_dev(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
                                                     _ptr(x_), _ptr(sig), n, B, _ptr(out), _ptr(ctx), self._stream()))
             return out, ctx
         sig = [float(v) for v in (sigmas.detach().tolist() if torch.is_tensor(sigmas) else sigmas)]
         n = len(sig) - 1
         arr = (C.c_float * len(sig))(*sig)
+        self.ctx_generation += 1
         _lib.check(self.lib.mdt_sample_ddim(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
                                             _ptr(x_), arr, n, B, _ptr(out), _ptr(ctx), self._stream()))
         return out, ctx
@@ -221,6 +226,7 @@ class HipEngine:
         loss = torch.empty((), device=self.device, dtype=torch.float32)
         mo = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
+        self.ctx_generation += 1
         _lib.check(self.lib.mdt_loss_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(a),
                                          _ptr(nz), _ptr(s), B, _ptr(loss), _ptr(mo), _ptr(ctx), self._stream()))
         return loss, mo, ctx
@@ -250,6 +256,7 @@ class HipEngine:
         mo = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         tape = C.c_int32(-1)
+        self.ctx_generation += 1
         _lib.check(self.lib.mdt_train_loss_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
                                                _ptr(action), _ptr(noise), _ptr(sigma), B,
                                                None if drop is None else C.byref(drop), _ptr(loss), _ptr(mo), _ptr(ctx),
@@ -264,6 +271,7 @@ class HipEngine:
         tape = C.c_int32(-1)
         if self.sigma_in_context and sigma is None:
             raise ValueError("use_ada_conditioning=False: sigma is a context token and must be given")
+        self.ctx_generation += 1
         _lib.check(self.lib.mdt_train_encode_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
                                                  int(honour_modality), _ptr(sigma) if self.sigma_in_context else None, B,
                                                  None if drop is None else C.byref(drop), _ptr(ctx), C.byref(tape),
@@ -402,7 +410,11 @@ class HipScoreNetwork(nn.Module):
         device, so a seeded run masks the same elements."""
         if goals.dim() == 2:
             goals = goals[:, None, :]
-        if goals.shape[1] != 1 and self.goal_seq_len == 1:
+        # a goal SEQUENCE is reduced to its first entry only where the reference does it: when it is as long as the state
+        # sequence (mdtv_transformer.py:249 with states_length = n_obs_token, mdt_transformer.py:213/262 with 1); any
+        # other length reaches the shape check of the engine and raises, as the reference's Linear would
+        states_length = self.n_obs_token if self._arch == "mdtv" else 1
+        if goals.shape[1] == states_length and goals.shape[1] != 1 and self.goal_seq_len == 1:
             goals = goals[:, :1, :]
         goal_p = float(self._pdrops[4])
         if self.training and goal_p > 0.0:

@@ -449,3 +449,43 @@ def test_mark_dirty_picks_up_writes_the_version_counter_misses():
     assert_close(a.cpu(), fx["actions"], what="before")
     assert (a - b).abs().max().item() > 1e-3, "halved action_pred.weight must change the actions"
     assert torch.equal(a, c)
+
+
+def test_cached_context_is_not_poisoned_by_an_interleaved_encode():
+    """Inside ``cached_context`` a call with ANOTHER state / goal (classifier-free guidance's unconditional branch, a callback
+    evaluating something else) re-encodes on the same handle; later calls with the original pair must not decode against
+    that context (the engine's generation counter sends them through the full forward again)."""
+    meta, fx = load_fixture("g3_b8_smin1.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    other = {k: (v.flip(0).contiguous() if torch.is_tensor(v) else v) for k, v in state.items()}
+    sig = torch.full((meta["B"],), 2.5, device="cuda")
+    x = noise * 2.5
+    with torch.no_grad():
+        want = model(state, x, goal, sig).clone()
+        with model.cached_context(state, goal):
+            a = model(state, x, goal, sig).clone()
+            model(other, x, goal.flip(0).contiguous(), sig)       # overwrites the handle's cached context
+            b = model(state, x, goal, sig).clone()
+            u = model(state, x, goal, sig, uncond=True).clone()    # zeroed goal: another context again
+            c = model(state, x, goal, sig).clone()
+    assert_close(a.cpu(), want.cpu(), rtol=1e-5, atol=1e-6, what="cached call")
+    assert_close(b.cpu(), want.cpu(), rtol=1e-5, atol=1e-6, what="after an interleaved encode")
+    assert_close(c.cpu(), want.cpu(), rtol=1e-5, atol=1e-6, what="after an unconditional call")
+    assert (u - want).abs().max().item() > 1e-3
+
+
+def test_goal_sequences_are_sliced_only_where_the_reference_slices():
+    """preprocess_goals (mdtv_transformer.py:249) keeps goal[:, 0] only when the goal sequence is as long as the state
+    sequence; another length must surface as an error, not be cut silently."""
+    meta, fx = load_fixture("g3_b8_smin1.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sig = torch.full((meta["B"],), 2.5, device="cuda")
+    with torch.no_grad():
+        want = model(state, noise, goal, sig)
+        n_tok = state["state_images"].shape[1]
+        same = model(state, noise, goal.expand(-1, n_tok, -1).contiguous(), sig)   # as long as the states: first entry
+        assert torch.equal(want, same)
+        with pytest.raises(ValueError):
+            model(state, noise, goal.expand(-1, n_tok + 2, -1).contiguous(), sig)
