@@ -105,6 +105,9 @@ hipError_t mdt_launch_transpose_ld(const float* src, int64_t lds_, float* dst, i
                                    hipStream_t s, int slice_len = 0);
 // floats of scratch mdt_linear_bwd needs for an (M, N, K) layer
 int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K);
+// dW[n][k] = sum_m dY[m][n] X[m][k] from the row-major operands (mdt_train_kernels.hip: k_gemm_tn), S row slices of L rows
+hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
+                              int K, int S, int L, int accumulate, float* bpart, hipStream_t s);
 hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
                               int accumulate, hipStream_t s);
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);

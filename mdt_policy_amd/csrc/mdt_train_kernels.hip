@@ -1060,3 +1060,130 @@ hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks,
     hipLaunchKernelGGL(k_multi_axpby, dim3(n_blocks), dim3(256), 0, s, tab, blocks, a, b);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_tn: the weight gradient  dW[n][k] = sum_m dY[m][n] * X[m][k]  straight from the two row-major operands --
+// no transposed copy of dY, no packed copy of X^T (those were 0.64 ms of a 12.7 ms B = 1024 step and 6 ms of the
+// 48 ms masked-image head).  The reduction index m is the SLOW index of both operands, so both go through LDS in their
+// natural layout ([m][columns], 128-/512-byte coalesced row pieces) and the MFMA fragments are read with 4-byte LDS
+// reads: for v_mfma_f32_16x16x4_f32 lane l feeds A[i = l%16][kk = l/16] and B[kk = l/16][j = l%16]; with
+// A = X (i -> k column), B = dY (j -> n column), kk -> m, the lanes of a 16-lane group read 16 consecutive floats of one
+// LDS row and the 4 groups read rows 4h + e: conflict free with a row stride = 4 (mod 8) floats.  D[i][j] leaves every lane
+// with 4 consecutive k of one n: 16-byte stores.
+//   workgroup = 4 waves, tile = 64 (n) x 128 (k); wave w owns k-tiles 2w, 2w+1 and all 4 n-tiles: 8 accumulators, 32 MFMAs per
+//   16 rows of m; chunks of 32 rows double-buffered through registers (next chunk's 6 x 16-byte loads in flight during the
+//   MFMAs); 51 KB of LDS -> 3 workgroups per CU.
+//   grid.z = row slices (split of the reduction): slice z covers rows [z L, min(M, z L + L)) and writes its own (N, K) partial
+//   (summed afterwards in a fixed order by k_colsum: deterministic).  Workgroups of k-tile 0 also leave the column sums of
+//   their dY tile (the bias gradient's per-slice partials) in bpart[z][n].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
+                                                 float* __restrict__ out, int64_t slice_stride, int M, int N, int K, int L,
+                                                 int accumulate, float* __restrict__ bpart) {
+    constexpr int CM = 32, TN_ = 64, TK = 128, SY = TN_ + 4, SX = TK + 4;
+    __shared__ __attribute__((aligned(16))) float ys[2][CM * SY];
+    __shared__ __attribute__((aligned(16))) float xs[2][CM * SX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gk = (K + TK - 1) / TK;
+    const int bn = blockIdx.x / gk, bk = blockIdx.x - bn * gk;
+    const int n0 = bn * TN_, k0 = bk * TK;
+    const int z = blockIdx.z;
+    const int m_lo = z * L, m_hi = min(M, m_lo + L);
+    out += (int64_t)z * slice_stride;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging assignment: X chunk = 32 rows x 32 float4 (4 per thread), dY chunk = 32 rows x 16 float4 (2 per thread)
+    int xr[4], xc[4], yr[2], yc[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = tid + 256 * u; xr[u] = i >> 5; xc[u] = (i & 31) * 4; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int i = tid + 256 * u; yr[u] = i >> 4; yc[u] = (i & 15) * 4; }
+    f32x4 xv[4], yv[2];
+    auto fetch = [&](int mb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t m = min(mb + xr[u], m_hi - 1);
+            xv[u] = ldg4(X + m * ldx + min(k0 + xc[u], K - 4));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t m = min(mb + yr[u], m_hi - 1);
+            yv[u] = ldg4(dY + m * ldy + min(n0 + yc[u], N - 4));
+        }
+    };
+    auto stash = [&](int buf, int mb) {  // rows past the slice and columns past the matrix contribute zeros
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            *(f32x4*)(&xs[buf][xr[u] * SX + xc[u]]) = (mb + xr[u] < m_hi && k0 + xc[u] < K) ? xv[u] : zero4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            *(f32x4*)(&ys[buf][yr[u] * SY + yc[u]]) = (mb + yr[u] < m_hi && n0 + yc[u] < N) ? yv[u] : zero4;
+    };
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero4;
+    float bsum = 0.f;  // threads 0..63 of k-tile-0 workgroups: column sum of dY[:, n0 + tid]
+    const bool do_bias = bpart != nullptr && bk == 0 && tid < TN_;
+    const int l16 = lane & 15, h = lane >> 4;
+    const int nchunks = (m_hi - m_lo + CM - 1) / CM;
+    if (nchunks > 0) {
+        fetch(m_lo);
+        stash(0, m_lo);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch(m_lo + (c + 1) * CM);
+        const float* xb = xs[buf];
+        const float* yb = ys[buf];
+#pragma unroll
+        for (int s = 0; s < CM / 16; ++s) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 16 * s + 4 * h + e;
+                float a[2], b[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) a[j] = xb[row * SX + (2 * wave + j) * 16 + l16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = yb[row * SY + i * 16 + l16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int r = 0; r < CM; ++r) bsum += yb[r * SY + tid];
+        }
+        if (c + 1 < nchunks) stash(buf ^ 1, m_lo + (c + 1) * CM);
+        __syncthreads();
+    }
+    // lane holds out[n0 + 16 i + l16][k0 + 16 (2 wave + j) + 4 h .. + 3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + 16 * i + l16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + 16 * (2 * wave + j) + 4 * h;
+            if (n < N && k < K) {
+                float* p = out + (int64_t)n * K + k;
+                f32x4 v = acc[i][j];
+                if (accumulate) v += *(const f32x4*)p;
+                *(f32x4*)p = v;
+            }
+        }
+    }
+    if (do_bias && n0 + tid < N) bpart[(int64_t)z * N + n0 + tid] = bsum;
+}
+
+// dW partials of S row slices of L rows: out + z * slice_stride is slice z's (N, K) product; N, K multiples of 16
+// (16-byte aligned rows).  bpart: nullptr or (S, N) per-slice column sums of dY.
+hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
+                              int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
+    if (M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || S < 1) return hipErrorInvalidValue;
+    const int gn = (N + 63) / 64, gk = (K + 127) / 128;
+    hipLaunchKernelGGL(k_gemm_tn, dim3(gn * gk, 1, S), dim3(256), 0, s, dY, ldy, X, ldx, out, slice_stride, M, N, K, L, accumulate, bpart);
+    return hipGetLastError();
+}

@@ -39,11 +39,26 @@ static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     *L = (int)l;
 }
 
+// The same for k_gemm_tn (64 x 128 tiles, no transposed / packed copies to amortise): ~3 workgroups per CU, slices of at
+// least 128 rows -- small batches (B = 128: 1280 rows) need the split even more than large ones.
+static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
+    const int64_t tiles = ((N + 63) / 64) * ((K + 127) / 128);
+    static int64_t target = -1;
+    if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 768; }
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>((target + tiles - 1) / tiles, M / 128));
+    s = std::min<int64_t>(s, 64);
+    if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
+    const int64_t l = ((M + s - 1) / s + 31) / 32 * 32;
+    *S = (int)((M + l - 1) / l);
+    *L = (int)l;
+}
+
 int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K) {
-    int S, L;
+    int S, L, St, Lt;
     split_rows(M, N, K, &S, &L);
+    split_rows_tn(M, N, K, &St, &Lt);
     const int64_t Mp = (int64_t)S * L;
-    return (N + K) * Mp + (int64_t)S * N * K + N * (Mp / 32 + 2);
+    return std::max<int64_t>((N + K) * Mp + (int64_t)S * N * K + N * (Mp / 32 + 2), (int64_t)St * N * K + (int64_t)St * N + 64);
 }
 
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
@@ -51,7 +66,22 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
     // the bias gradient rides on the transpose the dW path needs anyway (per-32-row column partials)
     const bool bias_from_partials = a.dbias && a.dW && !(a.N % 16);
     if (a.dbias && !bias_from_partials) LAUNCH(mdt_launch_colsum(a.dY, a.ldy, a.M, a.N, a.dbias, a.accumulate_dw, s));
-    if (a.dW) {
+    // (bias_from_partials: the dW path below also leaves the bias gradient -- per-slice column sums of dY from k_gemm_tn,
+    //  or per-32-row partials from the transpose of the older path)
+    static int use_tn = -1;  // MDT_HIP_DW_TN=0: the transposed-copy + packed-copy + forward-GEMM path (A/B runs)
+    if (use_tn < 0) { const char* e = getenv("MDT_HIP_DW_TN"); use_tn = e ? atoi(e) : 1; }
+    if (a.dW && use_tn && !(a.N % 16) && !(a.ldy % 4) && !(a.ldx % 4)) {
+        // dW straight from dY and X (k_gemm_tn): S slices of the row reduction as one batched launch, partial products and
+        // the bias gradient's per-slice column sums added up in a fixed order afterwards
+        int S, L;
+        split_rows_tn(a.M, a.N, a.K, &S, &L);
+        float* parts = a.scratch;                              // [S][N][K] (S > 1)
+        float* bpart = parts + (int64_t)S * a.N * a.K;         // [S][N]
+        LAUNCH(mdt_launch_gemm_tn(a.dY, a.ldy, a.X, a.ldx, S > 1 ? parts : a.dW, (int64_t)a.N * a.K, a.M, a.N, a.K, S, L,
+                                  S > 1 ? 0 : a.accumulate_dw, a.dbias ? bpart : nullptr, s));
+        if (S > 1) LAUNCH(mdt_launch_colsum(parts, (int64_t)a.N * a.K, S, a.N * a.K, a.dW, a.accumulate_dw, s));
+        if (a.dbias) LAUNCH(mdt_launch_colsum(bpart, a.N, S, a.N, a.dbias, a.accumulate_dw, s));
+    } else if (a.dW) {
         if (a.N % 16) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: N must be a multiple of 16 for dW");
         int S, L;
         split_rows(a.M, a.N, a.K, &S, &L);
