@@ -224,7 +224,11 @@ __global__ __launch_bounds__(512) void k_attn_mid_bwd(const float* __restrict__ 
     __syncthreads();
     softmax_rows<NT>(S, ss, T, tid);  // S = P
     __syncthreads();
-    weighted_rows<HD, NT, false>(S, ss, vs, os, ST, T, tid);  // O = P V (the forward output, recomputed)
+    // the row products have (T / 4) * (HD / 4) items (156 for T = 102, HD = 24): the two that share an input run side by
+    // side on the two halves of the workgroup
+    float* g = d_qkv + (int64_t)b * T * ldg + h * HD;
+    if (tid < 256) weighted_rows<HD, 256, false>(S, ss, vs, os, ST, T, tid);            // O = P V (the forward output, recomputed)
+    else weighted_rows<HD, 256, true>(S, ss, dos, g + 2 * D, ldg, T, tid - 256);        // dV = P^T dO (before P is overwritten)
     __syncthreads();
     // sum_j P_ij dP_ij = dO_i . O_i
     for (int i = tid; i < T; i += NT) {
@@ -233,13 +237,11 @@ __global__ __launch_bounds__(512) void k_attn_mid_bwd(const float* __restrict__ 
         for (int c = 0; c < HD; ++c) acc = fmaf(dos[i * ST + c], os[i * ST + c], acc);
         rowdot[i] = acc;
     }
-    float* g = d_qkv + (int64_t)b * T * ldg + h * HD;
-    weighted_rows<HD, NT, true>(S, ss, dos, g + 2 * D, ldg, T, tid);  // dV = P^T dO (before P is overwritten)
     __syncthreads();
     outer_blocks<HD, NT, 1>(dos, vs, S, ss, T, scale, rowdot, tid);  // S = scale * P * (dO v^T - rowdot)
     __syncthreads();
-    weighted_rows<HD, NT, false>(S, ss, ks, g, ldg, T, tid);      // dQ = dS K
-    weighted_rows<HD, NT, true>(S, ss, qs, g + D, ldg, T, tid);   // dK = dS^T Q
+    if (tid < 256) weighted_rows<HD, 256, false>(S, ss, ks, g, ldg, T, tid);            // dQ = dS K
+    else weighted_rows<HD, 256, true>(S, ss, qs, g + D, ldg, T, tid - 256);             // dK = dS^T Q
 }
 
 size_t attn_mid_lds(int hd, int T, bool bwd) {
