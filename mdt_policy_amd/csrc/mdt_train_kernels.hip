@@ -510,15 +510,31 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
     __shared__ float P[16][17], dS[16][17];
     const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const int Tq = a.Tq, Tk = a.Tk;
-    for (int i = lane; i < Tq * HD; i += 64) {
-        const int r = i / HD, d = i - r * HD;
-        qs[r][d] = a.q[((int64_t)b * Tq + r) * a.ldq + h * HD + d];
-        os[r][d] = a.d_out[((int64_t)b * Tq + r) * a.ld_do + h * HD + d];
-    }
-    for (int i = lane; i < Tk * HD; i += 64) {
-        const int r = i / HD, d = i - r * HD;
-        ks[r][d] = a.k[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
-        vs[r][d] = a.v[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
+    {   // q / dO / k / v tiles: every 16-byte load of the wave is requested before the first one is consumed (one memory
+        // round trip instead of one per loop trip); rows are 16-byte aligned (HD and the leading dimensions are multiples of 4)
+        constexpr int H4 = HD / 4, NI = (16 * H4 + 63) / 64;  // float4 per row, trips for up to 16 rows
+        f32x4 tq[NI], to[NI], tk[NI], tv[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = lane + 64 * u;
+            const int rq = min(i / H4, Tq - 1), rk = min(i / H4, Tk - 1), c = 4 * (i % H4);
+            tq[u] = ldg4(a.q + ((int64_t)b * Tq + rq) * a.ldq + h * HD + c);
+            to[u] = ldg4(a.d_out + ((int64_t)b * Tq + rq) * a.ld_do + h * HD + c);
+            tk[u] = ldg4(a.k + ((int64_t)b * Tk + rk) * a.ldkv + h * HD + c);
+            tv[u] = ldg4(a.v + ((int64_t)b * Tk + rk) * a.ldkv + h * HD + c);
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = lane + 64 * u, r = i / H4, c = 4 * (i % H4);
+            if (r < Tq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qs[r][c + e] = tq[u][e]; os[r][c + e] = to[u][e]; }
+            }
+            if (r < Tk) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ks[r][c + e] = tk[u][e]; vs[r][c + e] = tv[u][e]; }
+            }
+        }
     }
     __syncthreads();
     if (a.rope) {  // the scores were formed on the rotated q / k
@@ -626,6 +642,8 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
 
 hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s) {
     if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
+    if (((a.ldq | a.ld_do | a.ldkv) & 3) || (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.d_out) & 15))
+        return hipErrorInvalidValue;  // 16-byte loads of the head slices
     if (a.rope && (a.hd < 32 || !a.rope_cos || !a.rope_sin)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)a.hd);
     const dim3 grid(a.B, a.H);
