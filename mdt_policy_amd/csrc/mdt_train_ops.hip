@@ -39,12 +39,12 @@ static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     *L = (int)l;
 }
 
-// The same for k_gemm_tn (64 x 128 tiles, no transposed / packed copies to amortise): ~3 workgroups per CU, slices of at
+// The same for k_gemm_tn (64 x 128 tiles, no transposed / packed copies to amortise): ~6 workgroups per CU queued (3 resident), slices of at
 // least 128 rows -- small batches (B = 128: 1280 rows) need the split even more than large ones.
 static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     const int64_t tiles = ((N + 63) / 64) * ((K + 127) / 128);
     static int64_t target = -1;
-    if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 768; }
+    if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 1536; }  // measured at B = 1024: 768 -> 11.27 ms step / 42.1 ms head, 1536 -> 11.18 / 41.4, 2304 -> 11.22 / 41.4
     int64_t s = std::max<int64_t>(1, std::min<int64_t>((target + tiles - 1) / tiles, M / 128));
     s = std::min<int64_t>(s, 64);
     if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
