@@ -77,6 +77,13 @@ typedef struct {
     int32_t no_goal_conditioning; /* 1: constructor kwarg goal_conditioned=False.  MDTV: the goal token FOLLOWS the
                                      state tokens (mdtv_transformer.py:284-299); MDT: no goal token at all, which
                                      the reference can only run with use_ada_conditioning=0 (mdt_transformer.py:326-334) */
+    int32_t proprio_dim;          /* MDT-V: width of state['state_obs'] (1..16; conf/model/model/mdtv_transformer.yaml:11) */
+    int32_t use_proprio;          /* MDT-V: 1 = every call carries state['state_obs'] (B, 1, proprio_dim), passed as
+                                     `tokens2`: proprio_emb (Linear(p, 2d), Mish, Linear(2d, d)) embeds it into one
+                                     more context token BEHIND the state tokens, and a goal_conditioned=False model
+                                     then has no goal token at all (mdtv_transformer.py:260-266, 284-299).  The
+                                     reference decides per call ('state_obs' in states); a handle is built for one
+                                     of the two context layouts, the facade keeps one handle per layout.          */
 } mdt_config;
 
 /* Human-readable message of the last failing call on this thread ("" if none). */
@@ -94,7 +101,7 @@ mdt_status mdt_destroy(mdt_model *m);
 /* Enumeration of the parameters the forward path READS, in the reference's state_dict order (the
  * checkpoint / positional-EMA contract, reference mdt/evaluation/utils.py:92-103).  Names are GCDenoiser
  * state_dict keys ("inner_model.…").  Parameters the reference carries but never reads on this path
- * (pos_emb in MDT-V, proprio_emb.*, *.rotary_pos_emb.freqs; reference mdtv_transformer.py:105,160-164,
+ * (pos_emb in MDT-V, proprio_emb.* unless use_proprio, *.rotary_pos_emb.freqs; reference mdtv_transformer.py:105,160-164,
  * 260-266) are not enumerated; mdt_load_param() accepts and ignores them. */
 int64_t     mdt_param_count(const mdt_model *m);
 const char *mdt_param_name(const mdt_model *m, int64_t index);
@@ -115,7 +122,8 @@ mdt_status mdt_reserve(mdt_model *m, int64_t max_batch);
  *   sigma  : (B,) device.  Read only when use_ada_conditioning == 0 (the sigma embedding is then the first
  *            context token, so the cached context is only valid for that sigma); may be NULL otherwise.
  *   tokens : MDT-V state['state_images'] (B, n_obs_token, obs_dim); MDT state['static'] (B,1,obs_dim)
- *   tokens2: MDT state['gripper'] (B,1,obs_dim); NULL for MDT-V
+ *   tokens2: MDT state['gripper'] (B,1,obs_dim); MDT-V: state['state_obs'] (B,1,proprio_dim) when the handle was
+ *            created with use_proprio, else NULL
  *   goal   : (B, 1, goal_dim)
  *   honour_modality: 1 = pick lang_emb when modality==LANG (MDT-V always; MDT forward_enc_only),
  *                    0 = always goal_emb (MDT.forward -> enc_only_forward, mdt_transformer.py:215)

@@ -25,7 +25,8 @@ class MDTConfig(C.Structure):
         "arch", "embed_dim", "n_heads", "n_enc_layers", "n_dec_layers", "action_dim", "obs_dim", "goal_dim",
         "n_obs_token", "goal_seq_len", "action_seq_len", "use_mlp_goal", "use_modality_encoder", "use_abs_pos_emb",
         "use_rot_embed", "use_ada_conditioning", "use_noise_encoder", "linear_output", "bias")] + [
-        ("sigma_data", C.c_float), ("no_goal_conditioning", C.c_int32)]
+        ("sigma_data", C.c_float), ("no_goal_conditioning", C.c_int32), ("proprio_dim", C.c_int32),
+        ("use_proprio", C.c_int32)]
 
 
 class GemmArgs(C.Structure):

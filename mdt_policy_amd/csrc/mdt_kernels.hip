@@ -625,6 +625,32 @@ hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// narrow-input Linear (+ activation): out[m][n] = act(b[n] + sum_a X[m][a] * WT[a][n]),  A <= 16   (VALU: the first layer
+// of proprio_emb, Linear(proprio_dim = 8, 2d), mdtv_transformer.py:160-164).  `pre` (optional) keeps the pre-activation
+// rows for the training tape.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_narrow_linear(const float* __restrict__ X, const float* __restrict__ WT,
+                                                       const float* __restrict__ b, float* __restrict__ pre,
+                                                       float* __restrict__ out, int64_t n, int A, int N, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t m = i / N;
+    const int c = (int)(i - m * N);
+    float acc = 0.f;
+    for (int a = 0; a < A; ++a) acc = fmaf(X[m * A + a], WT[(int64_t)a * N + c], acc);
+    acc += b[c];
+    if (pre) pre[i] = acc;
+    out[i] = apply_act1(acc, act);
+}
+hipError_t mdt_launch_narrow_linear(const float* X, const float* WT, const float* b, float* pre, float* out, int M, int A,
+                                    int N, int act, hipStream_t s) {
+    if (A < 1 || A > 16) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(k_narrow_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, WT, b, pre, out, n, A, N, act);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // action embedding: y[m][:] = (x[m][:] * c_in(sigma_b)) @ Wa^T + ba          (K = action_dim = 7: VALU)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_action_embed(const float* __restrict__ x, const float* __restrict__ sigma,

@@ -199,6 +199,13 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
     }
     raw(m->dec_ln_w, P + "decoder.ln.weight", D);
     if (xb) raw(m->dec_ln_b, P + "decoder.ln.bias", D);
+    if (c.use_proprio) {  // registered between decoder and sigma_emb (mdtv_transformer.py:160-164)
+        m->prop0_T = b.take((size_t)2 * D * c.proprio_dim);  // (Pd, 2D): k_narrow_linear reads rows of 2D
+        add_slot(P + "proprio_emb.0.weight", (int64_t)2 * D * c.proprio_dim, SLOT_TRANSPOSE, m->prop0_T, 2 * D, c.proprio_dim, 0);
+        raw(m->prop0_b, P + "proprio_emb.0.bias", 2 * D);
+        lin_begin(m->prop2, D, 2 * D, true);
+        lin_part(m->prop2, P + "proprio_emb.2", D, 0, true);
+    }
     lin_begin(m->sig1, 2 * D, D, true);
     lin_part(m->sig1, P + "sigma_emb.1", 2 * D, 0, true);
     lin_begin(m->sig3, D, 2 * D, true);
@@ -229,7 +236,7 @@ static bool is_ignored_param(const mdt_model* m, const std::string& name) {
         const size_t n = strlen(suf);
         return name.size() >= n && name.compare(name.size() - n, n, suf) == 0;
     };
-    if (name.rfind("inner_model.proprio_emb.", 0) == 0) return true;
+    if (!m->cfg.use_proprio && name.rfind("inner_model.proprio_emb.", 0) == 0) return true;
     if (ends_with(".rotary_pos_emb.freqs")) return true;
     if (name == "inner_model.pos_emb") return true;  // MDT-V (or MDT without abs pos emb) never reads it
     if (!m->cfg.use_modality_encoder && name.rfind("inner_model.lang_emb", 0) == 0) return false;
@@ -261,19 +268,29 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     // use_ada_conditioning the reference builds a plain TransformerDecoder and the flag is never read
     const int cond = !c.use_ada_conditioning ? COND_TOKEN : (c.use_noise_encoder ? COND_NOISE : COND_ADALN);
     const int sig_tok = cond == COND_TOKEN ? 1 : 0;
-    if (n_tok < 1 || sig_tok + 1 + n_tok > 16) return fail(MDT_ERR_UNSUPPORTED, "context length must be <= 16 tokens");
+    const bool prop = c.use_proprio != 0;
+    if (prop && c.arch != MDT_ARCH_MDTV)
+        return fail(MDT_ERR_INVALID_ARG, "use_proprio: only MDTVTransformer reads state['state_obs'] "
+                                         "(MDTTransformer.process_state_embeddings returns None, mdt_transformer.py:309-316)");
+    if (prop && (c.proprio_dim < 1 || c.proprio_dim > 16)) return fail(MDT_ERR_UNSUPPORTED, "proprio_dim must be 1..16");
+    if (n_tok < 1 || sig_tok + 1 + n_tok + (prop ? 1 : 0) > 16)
+        return fail(MDT_ERR_UNSUPPORTED, "context length must be <= 16 tokens");
     const bool gc = c.no_goal_conditioning == 0;
     if (!gc && c.arch == MDT_ARCH_MDT && c.use_ada_conditioning)
         return fail(MDT_ERR_UNSUPPORTED, "MDTTransformer with goal_conditioned=False needs use_ada_conditioning=False "
                                          "(the reference concatenates the absent sigma token, mdt_transformer.py:334)");
-    const int has_goal = (gc || c.arch == MDT_ARCH_MDTV) ? 1 : 0;
+    // MDT-V keeps the goal token of an un-conditioned model behind the state tokens -- unless the proprioceptive token
+    // takes that place (concatenate_inputs, mdtv_transformer.py:291-294)
+    const int has_goal = (gc || (c.arch == MDT_ARCH_MDTV && !prop)) ? 1 : 0;
     if (c.n_enc_layers < 0 || c.n_dec_layers < 1) return fail(MDT_ERR_INVALID_ARG, "bad layer counts");
     if (!(c.sigma_data > 0.f)) return fail(MDT_ERR_INVALID_ARG, "sigma_data must be > 0");
 
     mdt_model* m = new mdt_model();
     m->cfg = c;
     m->cond = cond; m->sig_tok = sig_tok;
-    m->D = c.embed_dim; m->H = c.n_heads; m->hd = hd; m->n_tok = n_tok; m->Te = sig_tok + has_goal + n_tok; m->Ta = c.action_seq_len;
+    m->D = c.embed_dim; m->H = c.n_heads; m->hd = hd; m->n_tok = n_tok; m->Te = sig_tok + has_goal + n_tok + (prop ? 1 : 0); m->Ta = c.action_seq_len;
+    m->Pd = prop ? c.proprio_dim : 0;
+    m->p_row = prop ? m->Te - 1 : -1;
     m->g_row = !has_goal ? -1 : (gc ? sig_tok : sig_tok + n_tok);
     m->tok_row = gc ? sig_tok + 1 : sig_tok;
     m->A = c.action_dim; m->Le = c.n_enc_layers; m->Ld = c.n_dec_layers; m->G = c.goal_dim; m->O = c.obs_dim;
@@ -559,6 +576,8 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     if (t0 && !sigma)
         return fail(MDT_ERR_INVALID_ARG, "encode: use_ada_conditioning=False puts sigma into the context; sigma is required");
     if (c.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "encode: MDT needs the gripper tokens");
+    if (m->p_row >= 0 && !tokens2)
+        return fail(MDT_ERR_INVALID_ARG, "encode: this handle was created with use_proprio; state_obs (tokens2) is required");
     if (misaligned(tokens) || misaligned(goal) || misaligned(tokens2) || misaligned(ctx_out))
         return fail(MDT_ERR_INVALID_ARG, "encode: pointers must be 16-byte aligned");
     MDT_TRY(check_loaded(m));
@@ -597,6 +616,12 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
         mdt_gemm_args b2 = gemm_args(tokens2, m->O, m->incam, m->h_enc, D, (int)B);
         b2.gin = 1; b2.gout = Te; b2.goff = m->tok_row + 1; b2.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(b2, s));
+    }
+    if (m->p_row >= 0) {  // proprioceptive token -> the last row          (process_state_embeddings, :260-266)
+        LAUNCH(mdt_launch_narrow_linear(tokens2, m->prop0_T, m->prop0_b, nullptr, m->hid, (int)B, m->Pd, 2 * D, MDT_ACT_MISH, s));
+        mdt_gemm_args a = gemm_args(m->hid, 2 * D, m->prop2, m->h_enc, D, (int)B);
+        a.gin = 1; a.gout = Te; a.goff = m->p_row;
+        LAUNCH(mdt_launch_gemm(a, s));
     }
     for (int l = 0; l < m->Le; ++l) {
         MDT_TRY(run_self_attn(m, m->enc[l], encoder_view(m), B, Te, false, ModRef(), s));

@@ -66,6 +66,12 @@ struct mdt_model {
     std::vector<LinPart> parts;
     mdt_train_state* train = nullptr;  // non-null after mdt_train_prepare()
     Lin tok, incam, goal0, goal2, lang0, lang2, sig1, sig3, kv_all, mod_all;
+    // proprioceptive token (cfg.use_proprio, MDT-V): proprio_emb = Linear(Pd, 2D) -> Mish -> Linear(2D, D)
+    // (mdtv_transformer.py:160-164, 260-266).  The first layer is Pd <= 16 wide: held transposed (Pd, 2D) and applied
+    // by k_narrow_linear; the second is an ordinary packed Linear.  p_row: the token's context row (the last), or -1.
+    Lin prop2;
+    float *prop0_T = nullptr, *prop0_b = nullptr;
+    int Pd = 0, p_row = -1;
     // MLP action head (linear_output = 0): action_pred.0 = Linear(d, HH) padded to HP = ceil16(HH) rows, action_pred.2
     // = Linear(HH, A) held as (A, HP) with zero pad columns.  HH = 100 in MDTVTransformer (mdtv_transformer.py:182),
     // embed_dim in MDTTransformer (mdt_transformer.py:174).  HP = 0 with the plain Linear head.

@@ -41,6 +41,7 @@ struct Tape {
     float* buf = nullptr;
     // inputs
     float *tokens, *tokens2, *goal, *action, *noised, *sigma;
+    float *p_pre = nullptr, *p_h = nullptr;  // proprio_emb: pre-activation and Mish output of its first layer (B, 2D)
     // encoder
     float *g_pre, *g_h;
     std::vector<BlockTape> enc;
@@ -153,7 +154,8 @@ static void carve_tape(const mdt_model* m, Bump& b, Tape& t, int64_t B) {
     const int D = m->D;
     const int64_t Me = B * m->Te, Ma = B * m->Ta;
     t.tokens = b.take(B * (m->cfg.arch == MDT_ARCH_MDTV ? m->n_tok : 1) * m->O);
-    t.tokens2 = b.take(m->cfg.arch == MDT_ARCH_MDT ? B * m->O : 0);
+    t.tokens2 = b.take(m->cfg.arch == MDT_ARCH_MDT ? B * m->O : B * m->Pd);  // MDT-V: state_obs (B, Pd) when use_proprio
+    t.p_pre = b.take(m->p_row >= 0 ? B * 2 * D : 0); t.p_h = b.take(m->p_row >= 0 ? B * 2 * D : 0);
     t.goal = b.take(B * m->G);
     t.action = b.take(Ma * m->A); t.noised = b.take(Ma * m->A); t.sigma = b.take(B);
     t.g_pre = b.take(B * 2 * D); t.g_h = b.take(B * 2 * D);
@@ -223,7 +225,7 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
     ts->t_d = b.take(Mx * D); ts->t_d2 = b.take(Mx * D); ts->t_3d = b.take(Mx * 3 * D); ts->t_4d = b.take(Mx * 4 * D);
     ts->d_mod = b.take(B * m->Ld * 6 * D); ts->d_kvx = b.take(Me * m->Ld * 2 * D);
     ts->pw = b.take(B * D); ts->pb = b.take(B * D);
-    ts->narrow = b.take((size_t)NARROW_SLICES * 16 * std::max(D, m->HP));
+    ts->narrow = b.take((size_t)NARROW_SLICES * 16 * std::max({D, m->HP, m->p_row >= 0 ? 2 * D : 0}));
     // Linear backward scratch: the largest need over every (rows, N, K) this model's backward runs
     int64_t need = 0;
     for (int64_t rows : {Ma, Me}) {
@@ -390,6 +392,10 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
     HIP_TRY(hipMemcpyAsync(t.tokens, tokens, (size_t)B * ntok_rows * m->O * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (c.arch == MDT_ARCH_MDT)
         HIP_TRY(hipMemcpyAsync(t.tokens2, tokens2, (size_t)B * m->O * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (m->p_row >= 0) {
+        if (!tokens2) return fail(MDT_ERR_INVALID_ARG, "this handle was created with use_proprio: state_obs (tokens2) is required");
+        HIP_TRY(hipMemcpyAsync(t.tokens2, tokens2, (size_t)B * m->Pd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     HIP_TRY(hipMemcpyAsync(t.goal, goal, (size_t)B * m->G * sizeof(float), hipMemcpyDeviceToDevice, s));
     t.lang = honour && c.use_modality_encoder && modality == MDT_MODALITY_LANG;
     const Lin& g0 = t.lang ? m->lang0 : m->goal0;
@@ -421,6 +427,12 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
         mdt_gemm_args b2 = gemm_args(t.tokens2, m->O, m->incam, x0, D, (int)B);
         b2.gin = 1; b2.gout = Te; b2.goff = m->tok_row + 1; b2.rowvec = pos1;
         LAUNCH(mdt_launch_gemm(b2, s));
+    }
+    if (m->p_row >= 0) {  // proprioceptive token: proprio_emb(state_obs) -> the last context row (mdtv_transformer.py:260-266)
+        LAUNCH(mdt_launch_narrow_linear(t.tokens2, m->prop0_T, m->prop0_b, t.p_pre, t.p_h, (int)B, m->Pd, 2 * D, MDT_ACT_MISH, s));
+        mdt_gemm_args a = gemm_args(t.p_h, 2 * D, m->prop2, x0, D, (int)B);
+        a.gin = 1; a.gout = Te; a.goff = m->p_row;
+        LAUNCH(mdt_launch_gemm(a, s));
     }
     // embedding dropout (self.drop): MDTTransformer drops every embedded goal / state token (mdt_transformer.py:220-227),
     // MDTVTransformer only the goal token it appends when goal_conditioned=False (mdtv_transformer.py:293-294)
@@ -706,6 +718,18 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
         MDT_TRY(lin_bwd(m, grads, g0, t.goal, m->G, ts->small, 2 * D, (int)B, d_goal, m->G, 0, s));
     } else {
         MDT_TRY(lin_bwd(m, grads, g2, t.goal, m->G, dg, D, (int)B, d_goal, m->G, 0, s));
+    }
+    if (m->p_row >= 0) {
+        // proprio_emb: token = Linear2(mish(Linear0(state_obs))); the narrow first layer's weight gradient lands in the
+        // reference's (2D, Pd) layout, summed over the row slices like action_emb's
+        float* dp = ts->t_d2;  // (B, D)
+        LAUNCH(mdt_launch_gather_rows(ts->dxe, dp, (int)B, D, 1, Te, m->p_row, s));
+        MDT_TRY(lin_bwd(m, grads, m->prop2, t.p_h, 2 * D, dp, D, (int)B, ts->small, 2 * D, 0, s));
+        LAUNCH(mdt_launch_act_bwd(t.p_pre, ts->small, ts->small, B * 2 * D, MDT_ACT_MISH, s));
+        LAUNCH(mdt_launch_colsum(ts->small, 2 * D, (int)B, 2 * D, grad_of(m, grads, m->prop0_b), 1, s));
+        LAUNCH(mdt_launch_narrow_dw(t.tokens2, ts->small, 2 * D, ts->narrow, NARROW_SLICES, (int)B, m->Pd, 2 * D, 1, s));
+        LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)m->Pd * 2 * D, NARROW_SLICES, m->Pd * 2 * D, grad_of(m, grads, m->prop0_T), 1, s));
+        if (d_tokens2) LAUNCH(mdt_launch_narrow_out(ts->small, 2 * D, m->prop0_T, d_tokens2, (int)B, m->Pd, 2 * D, s));
     }
     if (c.arch == MDT_ARCH_MDTV) {
         float* dt = ts->t_d2;  // (B*n_tok, D)

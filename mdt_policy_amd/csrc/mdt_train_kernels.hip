@@ -696,6 +696,36 @@ hipError_t mdt_launch_narrow_dx(const float* G, const float* W, float* out, int 
     return hipGetLastError();
 }
 
+// out[m][a] = sum_d G[m][d] * WT[a][d]   (A <= 16): one wavefront per row m, lanes stride over d
+__global__ __launch_bounds__(256) void k_narrow_out(const float* __restrict__ G, int64_t ldg, const float* __restrict__ WT,
+                                                    float* __restrict__ out, int M, int A, int D) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float acc[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) acc[a] = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float g = G[(int64_t)m * ldg + d];
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            if (a < A) acc[a] = fmaf(g, WT[(int64_t)a * D + d], acc[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        if (a < A) {
+            float v = acc[a];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) out[(int64_t)m * A + a] = v;
+        }
+    }
+}
+hipError_t mdt_launch_narrow_out(const float* G, int64_t ldg, const float* WT, float* out, int M, int A, int D, hipStream_t s) {
+    if (A < 1 || A > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_narrow_out, dim3((M + 3) / 4), dim3(256), 0, s, G, ldg, WT, out, M, A, D);
+    return hipGetLastError();
+}
+
 // partial[y][a][d] = sum_{m in slice y} G[m][a] * Y[m][d]   (A <= 16); summed over y by k_colsum.
 //   transposed = 0: rows of the result are a (action_pred.weight (A, D));  1: result stored (D, A) (action_emb.weight)
 __global__ __launch_bounds__(256) void k_narrow_dw(const float* __restrict__ G, const float* __restrict__ Y, int64_t ldy,

@@ -52,10 +52,10 @@ class GCDenoiser(nn.Module):
         c_in = 1 / (sigma ** 2 + sd ** 2) ** 0.5
         return c_skip, c_out, c_in
 
-    def _engine(self, allow_grad: bool = False):
+    def _engine(self, allow_grad: bool = False, state=None):
         self.inner_model._sigma_data = float(self.sigma_data)
         self.inner_model._guard_mode(allow_grad)
-        return self.inner_model.hip_engine(float(self.sigma_data))
+        return self.inner_model.hip_engine(float(self.sigma_data), state)
 
     def _wants_grad(self, *tensors) -> bool:
         return torch.is_grad_enabled() and (any(p.requires_grad for p in self.inner_model.parameters()) or
@@ -70,7 +70,8 @@ class GCDenoiser(nn.Module):
         prep = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0) \
             else t.float().contiguous().clone()
         if im._arch == "mdtv":
-            tok, tok2 = prep(state["state_images"]), None
+            # the proprioceptive input rides in the second token slot of the C ABI (include/mdt_hip.h: tokens2)
+            tok, tok2 = prep(state["state_images"]), (prep(state["state_obs"]) if eng.proprio else None)
             B = tok.shape[0]
         else:
             tok, tok2 = prep(state["static"]), prep(state["gripper"])
@@ -87,7 +88,7 @@ class GCDenoiser(nn.Module):
     def forward(self, state, action, goal, sigma, **kwargs):
         """D(x; sigma) = F(x*c_in, sigma)*c_out + x*c_skip (reference score_wrappers.py:65-80)."""
         im = self.inner_model
-        eng = self._engine()
+        eng = self._engine(state=state)
         goal = im._goals(goal, bool(kwargs.get("uncond", False)))
         if self._ctx_key is not None and self._ctx_key == (id(state), id(goal), action.shape[0], eng.ctx_generation):
             return eng.denoise_cached(action, sigma, 0)  # inside cached_context(): encoder hoisted
@@ -103,14 +104,14 @@ class GCDenoiser(nn.Module):
         if self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
             # training step: HIP forward with a tape + HIP backward behind torch.autograd
             from ._autograd import HipDiffusionLoss
-            eng = self._engine(allow_grad=True)
+            eng = self._engine(allow_grad=True, state=state)
             tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal, im._arch == "mdtv")
             a, nz = eng._in(action, (B, eng.Ta, eng.A)), eng._in(noise, (B, eng.Ta, eng.A))
             loss, model_output, ctx = HipDiffusionLoss.apply(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)),
                                                              im.train_dropout(), names, *params)
             im.latent_encoder_emb = ctx
             return loss, model_output
-        loss, model_output, ctx = self._engine().loss_fwd(state, action, im._goals(goal, False), noise, sigma)
+        loss, model_output, ctx = self._engine(state=state).loss_fwd(state, action, im._goals(goal, False), noise, sigma)
         im.latent_encoder_emb = ctx
         return loss, model_output
 
@@ -120,7 +121,7 @@ class GCDenoiser(nn.Module):
         if not kwargs.get("uncond", False) and \
                 self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
             from ._autograd import HipContextOnly
-            eng = self._engine(allow_grad=True)
+            eng = self._engine(allow_grad=True, state=state)
             tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal, True)
             sg = eng._in(sigma, (B,)) if eng.sigma_in_context else None  # the sigma token leads the context
             ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, im.train_dropout(), sg, names, *params)
@@ -138,7 +139,7 @@ class GCDenoiser(nn.Module):
         """Evaluate the (sigma-independent) encoder + cross-attention K/V once and reuse them for every
         ``self(state, x, goal, sigma)`` inside the block -- what the Python samplers in gc_sampling use."""
         im = self.inner_model
-        eng = self._engine()
+        eng = self._engine(state=state)
         if eng.sigma_in_context:  # use_ada_conditioning=False: sigma is a context token, nothing can be hoisted
             yield None
             return
@@ -158,6 +159,6 @@ class GCDenoiser(nn.Module):
     def sample_ddim(self, state, action, goal, sigmas):
         """Whole DDIM loop (reference gc_sampling.py:922-951) as one enqueue on the current stream."""
         im = self.inner_model
-        out, ctx = self._engine().sample_ddim(state, action, im._goals(goal, False), sigmas)
+        out, ctx = self._engine(state=state).sample_ddim(state, action, im._goals(goal, False), sigmas)
         im.latent_encoder_emb = ctx
         return out

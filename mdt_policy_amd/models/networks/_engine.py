@@ -52,8 +52,11 @@ class HipEngine:
         self.ctx_generation = 0  # bumped by every call that rewrites the handle's cached context (encoder output, K|V, folds)
         self.sigma_in_context = not cfg.use_ada_conditioning  # sigma embedding is the first context token
         # goal_conditioned=False: MDTV keeps the goal token (behind the state tokens), MDT has none
-        self.has_goal_token = not (cfg.no_goal_conditioning and cfg.arch == 1)
-        self.Te = int(self.sigma_in_context) + int(self.has_goal_token) + (cfg.n_obs_token if cfg.arch == 0 else 2)
+        # (and MDTV gives it up when the proprioceptive token takes that place, mdtv_transformer.py:291-294)
+        self.proprio = bool(cfg.use_proprio)
+        self.has_goal_token = not (cfg.no_goal_conditioning and (cfg.arch == 1 or self.proprio))
+        self.Te = int(self.sigma_in_context) + int(self.has_goal_token) + (cfg.n_obs_token if cfg.arch == 0 else 2) + \
+            int(self.proprio)
         self.Ta, self.A, self.D = cfg.action_seq_len, cfg.action_dim, cfg.embed_dim
 
     def __del__(self):
@@ -117,16 +120,21 @@ class HipEngine:
         return t
 
     def _tokens(self, state: dict):
-        if "state_obs" in state:
-            # the reference would embed it with proprio_emb and append one more context token
-            # (mdtv_transformer.py:260-266); no caller of the reference passes it
-            raise NotImplementedError("a proprioceptive 'state_obs' entry in the state dict is not implemented by the HIP "
-                                      "path (the reference's agents never pass one)")
         if self.cfg.arch == 0:
             tok = self._in(state["state_images"])
             if tok.dim() != 3 or tok.shape[1] != self.cfg.n_obs_token or tok.shape[2] != self.cfg.obs_dim:
                 raise ValueError(f"state_images must be (B,{self.cfg.n_obs_token},{self.cfg.obs_dim}), got {tuple(tok.shape)}")
-            return tok, None, tok.shape[0]
+            # 'state_obs' in states (mdtv_transformer.py:262) selects the context layout: HipScoreNetwork.hip_engine
+            # hands out the handle built for this state dict's layout
+            if ("state_obs" in state) != self.proprio:
+                raise RuntimeError("state dict and library handle disagree about the proprioceptive token; obtain the "
+                                   "engine with hip_engine(state=state)")
+            obs = None
+            if self.proprio:
+                obs = self._in(state["state_obs"])
+                if obs.numel() != tok.shape[0] * self.cfg.proprio_dim:
+                    raise ValueError(f"state_obs must be (B,1,{self.cfg.proprio_dim}), got {tuple(obs.shape)}")
+            return tok, obs, tok.shape[0]
         st, gr = self._in(state["static"]), self._in(state["gripper"])
         B = st.shape[0]
         if st.numel() != B * self.cfg.obs_dim or gr.numel() != B * self.cfg.obs_dim:
@@ -344,22 +352,28 @@ class HipScoreNetwork(nn.Module):
     def _hip_config(self, sigma_data: float) -> _lib.MDTConfig:
         raise NotImplementedError
 
-    def hip_engine(self, sigma_data: Optional[float] = None) -> HipEngine:
+    def hip_engine(self, sigma_data: Optional[float] = None, state: Optional[dict] = None) -> HipEngine:
         """The (lazily created) library handle.  sigma_data defaults to the value the owning GCDenoiser
-        registered (``_sigma_data``); it only matters for the preconditioned entry points."""
+        registered (``_sigma_data``); it only matters for the preconditioned entry points.  ``state``: the state dict of
+        the call -- MDTVTransformer embeds a proprioceptive ``state['state_obs']`` into one more context token when the
+        key is present (mdtv_transformer.py:260-266); the two context layouts live in two handles."""
         if sigma_data is None:
             sigma_data = getattr(self, "_sigma_data", 1.0)
         p = next(self.parameters())
-        key = (str(p.device), float(sigma_data))
+        proprio = self._arch == "mdtv" and state is not None and "state_obs" in state
+        key = (str(p.device), float(sigma_data), proprio)
         eng = self._engines.get(key)
         if eng is None:
-            eng = HipEngine(self, self._hip_config(float(sigma_data)), p.device)
-            self._engines = {key: eng}  # one live handle: a moved / re-scaled model drops the old arena
+            eng = HipEngine(self, self._hip_config(float(sigma_data), proprio), p.device)
+            # a moved / re-scaled model drops the old arenas; the other context layout of the same model stays
+            self._engines = {k: e for k, e in self._engines.items() if k[:2] == key[:2]}
+            self._engines[key] = eng
         return eng
 
     def __getstate__(self):  # copy.deepcopy / pickle (EMA copies, checkpoints of whole modules): never the library handle
         d = self.__dict__.copy()
         d["_engines"] = {}
+        d.pop("_ctx_engine", None)
         return d
 
     def mark_dirty(self) -> None:
@@ -380,6 +394,7 @@ class HipScoreNetwork(nn.Module):
     def _apply(self, fn, *a, **kw):  # .to()/.cuda()/.float(): parameters are re-created, drop stale handles
         out = super()._apply(fn, *a, **kw)
         self._engines = {}
+        self._ctx_engine = None
         return out
 
     def train_dropout(self):
@@ -427,15 +442,18 @@ class HipScoreNetwork(nn.Module):
     def forward(self, states, actions, goals, sigma, uncond: Optional[bool] = False):
         """Raw score network F(states, actions, goals, sigma) (reference mdtv_transformer.py:208-211)."""
         self._guard_mode()
-        eng = self.hip_engine()
+        eng = self.hip_engine(state=states)
         ctx = eng.encode(states, self._goals(goals, uncond), honour_modality=self._arch == "mdtv", sigma=sigma)
         self.latent_encoder_emb = ctx
+        self._ctx_engine = eng
         return eng.denoise_cached(actions, sigma, _lib.RAW_OUTPUT | _lib.RAW_INPUT)
 
     def forward_enc_only(self, states, actions=None, goals=None, sigma=None, uncond: Optional[bool] = False):
         """Context tokens (reference mdtv_transformer.py:213-222 / mdt_transformer.py:257-281)."""
         self._guard_mode()
-        ctx = self.hip_engine().encode(states, self._goals(goals, uncond), honour_modality=True, sigma=sigma)
+        eng = self.hip_engine(state=states)
+        ctx = eng.encode(states, self._goals(goals, uncond), honour_modality=True, sigma=sigma)
+        self._ctx_engine = eng
         if self._arch == "mdtv":  # MDTTransformer.forward_enc_only does not cache (mdt_transformer.py:257-281)
             self.latent_encoder_emb = ctx
         return ctx
@@ -446,7 +464,8 @@ class HipScoreNetwork(nn.Module):
             raise NotImplementedError("forward_dec_only needs the context tensor returned by the immediately "
                                       "preceding forward_enc_only()/forward() of this module")
         self._guard_mode()
-        return self.hip_engine().denoise_cached(actions, sigma, _lib.RAW_OUTPUT | _lib.RAW_INPUT)
+        eng = getattr(self, "_ctx_engine", None) or self.hip_engine()  # the handle that holds this context
+        return eng.denoise_cached(actions, sigma, _lib.RAW_OUTPUT | _lib.RAW_INPUT)
 
     def get_params(self):
         return self.parameters()

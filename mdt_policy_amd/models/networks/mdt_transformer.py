@@ -106,14 +106,14 @@ class MDTTransformer(HipScoreNetwork):
     # reference method names of the "as written" path (mdt_transformer.py:211-242)
     def enc_only_forward(self, states, actions, goals, sigma, uncond: Optional[bool] = False):
         self._guard_mode()
-        ctx = self.hip_engine().encode(states, self._goals(goals, uncond), honour_modality=False)
+        ctx = self.hip_engine(state=states).encode(states, self._goals(goals, uncond), honour_modality=False)
         self.latent_encoder_emb = ctx
         return ctx
 
     def dec_only_forward(self, context, actions, sigma):
         return self.forward_dec_only(context, actions, sigma)
 
-    def _hip_config(self, sigma_data: float) -> _lib.MDTConfig:
+    def _hip_config(self, sigma_data: float, proprio: bool = False) -> _lib.MDTConfig:
         return _lib.MDTConfig(
             arch=_lib.ARCH["mdt"], embed_dim=self.embed_dim, n_heads=self.n_heads, n_enc_layers=self.n_enc_layers,
             n_dec_layers=self.n_dec_layers, action_dim=self.action_dim, obs_dim=self.obs_dim, goal_dim=self.goal_dim,

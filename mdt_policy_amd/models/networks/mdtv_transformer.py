@@ -109,8 +109,9 @@ class MDTVTransformer(HipScoreNetwork):
         elif isinstance(module, MDTVTransformer):
             torch.nn.init.normal_(module.pos_emb, mean=0.0, std=0.02)
 
-    def _hip_config(self, sigma_data: float) -> _lib.MDTConfig:
+    def _hip_config(self, sigma_data: float, proprio: bool = False) -> _lib.MDTConfig:
         return _lib.MDTConfig(
+            proprio_dim=int(self.proprio_emb[0].in_features), use_proprio=int(proprio),
             arch=_lib.ARCH["mdtv"], embed_dim=self.embed_dim, n_heads=self.n_heads, n_enc_layers=self.n_enc_layers,
             n_dec_layers=self.n_dec_layers, action_dim=self.action_dim, obs_dim=self.obs_dim, goal_dim=self.goal_dim,
             n_obs_token=self.n_obs_token, goal_seq_len=self.goal_seq_len, action_seq_len=self.action_seq_len,

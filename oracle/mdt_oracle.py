@@ -219,8 +219,16 @@ def encode(P: Params, cfg: dict, state: dict, goal: Tensor, arch: str = "mdtv", 
         goal = _prep_goal(cfg, goal, tokens.shape[1])
         g = _goal_embed(P, cfg, goal, modality, True)
         s = _lin(P, "inner_model.tok_emb", tokens)
-        # concatenate_inputs (:284-299), no proprio: [goal, state] when goal_conditioned, else [state, drop(goal)]
-        h = torch.cat([g, s], dim=1) if cfg.get("goal_conditioned", True) else torch.cat([s, g], dim=1)
+        # concatenate_inputs (:284-299): [goal, state] when goal_conditioned, else [state, drop(goal)]; a
+        # proprioceptive 'state_obs' entry (process_state_embeddings :260-266) adds one token behind the state tokens
+        # and then an un-conditioned model carries NO goal token at all (:291-294)
+        parts = [g, s] if cfg.get("goal_conditioned", True) else [s]
+        if "state_obs" in state:
+            pe = _lin(P, "inner_model.proprio_emb.0", state["state_obs"].to(s.dtype))
+            parts.append(_lin(P, "inner_model.proprio_emb.2", F.mish(pe)))
+        elif not cfg.get("goal_conditioned", True):
+            parts.append(g)
+        h = torch.cat(parts, dim=1)
     else:
         goal = _prep_goal(cfg, goal, 1 if entry == "forward" else state["static"].shape[1])
         g = _goal_embed(P, cfg, goal, modality, entry != "forward")

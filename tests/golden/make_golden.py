@@ -631,6 +631,63 @@ def g15():
              decoder_pe=sd["decoder_pe"].numpy())
 
 
+G16_PROPRIO = {
+    # name: (config factory, overrides, B, ddim steps)
+    "tiny": ("mdtv_tiny", {}, 5, 4),
+    "default": ("mdtv_default", {}, 4, 10),
+    "tiny_no_goal_cond": ("mdtv_tiny", dict(goal_conditioned=False), 3, 3),
+    "tiny_no_ada": ("mdtv_tiny", dict(use_ada_conditioning=False), 3, 3),
+}
+
+
+def g16():
+    """The proprioceptive token: state['state_obs'] (B, 1, proprio_dim) -> proprio_emb -> one more context token behind
+    the state tokens (mdtv_transformer.py:260-266, 284-299).  Per case: one GCDenoiser.forward at per-sample sigmas, the
+    DDIM actions + context, and a training step (loss.backward() + a scalar hung on latent_encoder_emb) with the gradient
+    summaries of every parameter and the full input gradients (state_obs included)."""
+    from mdt.models.edm_diffusion import gc_sampling
+    for name, (factory, ov, B, n_steps) in G16_PROPRIO.items():
+        cfg, arch = getattr(configs, factory)(**ov), "mdtv"
+        model = build_reference(cfg, arch, seed=161, profile="rich")
+        inp = synthetic.sampler_inputs(B, cfg, 162, arch)
+        li = synthetic.loss_inputs(B, cfg, 163)
+        obs = synthetic.normal("state_obs", (B, 1, cfg["proprio_dim"]), 164)
+        state = make_state(inp, arch, "lang")
+        state["state_obs"] = torch.from_numpy(obs)
+        goal = torch.from_numpy(inp["goal"])
+        arrays = {}
+        with torch.no_grad():
+            x = torch.from_numpy(li["actions"]) + torch.from_numpy(li["noise_train"]) * torch.from_numpy(li["sigma"])[:, None, None]
+            arrays["denoised"] = model(state, x, goal, torch.from_numpy(li["sigma"])).numpy()
+            arrays["ctx_forward"] = model.inner_model.latent_encoder_emb.numpy()
+            sigmas = gc_sampling.get_sigmas_exponential(n_steps, 0.001, 80.0)
+            arrays["actions"] = gc_sampling.sample_ddim(model, state, torch.from_numpy(inp["noise"]) * 80.0, goal, sigmas,
+                                                        disable=True).numpy()
+            arrays["sigmas"] = sigmas.numpy()
+        leaves = {k: v.requires_grad_() for k, v in state.items() if torch.is_tensor(v)}
+        goal = goal.clone().requires_grad_()
+        loss, mo = model.loss(state, torch.from_numpy(li["actions"]), goal, torch.from_numpy(li["noise_train"]),
+                              torch.from_numpy(li["sigma"]))
+        ctx = model.inner_model.latent_encoder_emb
+        wctx = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), 165))
+        (loss + 0.1 * (ctx * wctx).sum() / ctx.numel()).backward()
+        summ = {}
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                summ[k] = None
+                continue
+            g = p.grad.detach().double()
+            summ[k] = [float(g.norm()), float(g.sum())] + [float(v) for v in g.flatten()[:6]]
+        for k, v in leaves.items():
+            arrays["d_" + k] = v.grad.numpy()
+        arrays["d_goal"] = goal.grad.numpy() if goal.grad is not None else np.zeros_like(inp["goal"])
+        arrays["model_output"] = mo.detach().numpy()
+        meta = dict(config=factory, overrides=ov, arch=arch, B=B, n_steps=n_steps, modality="lang", weight_seed=161,
+                    profile="rich", input_seed=162, loss_seed=163, obs_seed=164, ctx_seed=165, grads=summ,
+                    state_dict=[[k, list(v.shape)] for k, v in model.state_dict().items()])
+        save(f"g16_proprio_{name}.npz", meta, loss=np.array(loss.item(), np.float32), **arrays)
+
+
 def manifest():
     """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
     out = {}
@@ -653,7 +710,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "g14", "g15", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "g14", "g15", "g16", "manifest"]
     for w in which:
         print(w)
         globals()[w]()

@@ -254,8 +254,8 @@ def test_fails_loudly_instead_of_falling_back():
         model.train()(state, noise.cuda(), goal.cuda(), torch.ones(1, device="cuda"))  # dropout not implemented
     with torch.no_grad(), pytest.raises(Exception):
         model.eval()(state, noise.cuda(), goal.cuda()[:, :, :100], torch.ones(1, device="cuda"))  # bad goal shape
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="state_obs"):  # never silently drop a token
-        model.eval()(dict(state, state_obs=torch.zeros(1, 1, 8, device="cuda")), noise.cuda(), goal.cuda(),
+    with torch.no_grad(), pytest.raises(ValueError, match="state_obs"):  # the proprioceptive token (tests/test_proprio.py): bad width
+        model.eval()(dict(state, state_obs=torch.zeros(1, 1, 5, device="cuda")), noise.cuda(), goal.cuda(),
                      torch.ones(1, device="cuda"))
 
 
