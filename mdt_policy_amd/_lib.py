@@ -195,6 +195,7 @@ SYMBOLS = [
                                     _VP]),
     ("mdt_train_encode_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("mdt_tape_release", _I32, [_VP, _I32]),
+    ("mdt_denoise_vjp", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
     ("mdt_op_pack_weight_t", _I32, [_VP, _I64, _I64, _I64, _VP, _I64, _I64, _VP]),
     ("mdt_op_ln_fwd_train", _I32, [C.POINTER(LnTrainArgs), _VP]),
     ("mdt_op_ln_bwd", _I32, [C.POINTER(LnBwdArgs), _VP]),

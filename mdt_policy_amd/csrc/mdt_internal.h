@@ -122,6 +122,10 @@ hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s);
 hipError_t mdt_launch_loss_grad(const float* F, const float* act, const float* noised, const float* sigma, float sd,
                                 int64_t n, int per_sample, const float* gscale, float* dF, hipStream_t s);
 hipError_t mdt_launch_narrow_dx(const float* G, const float* W, float* out, int M, int A, int D, hipStream_t s);
+hipError_t mdt_launch_vjp_seed(const float* F, const float* x, const float* sigma, const float* v, float sd, int64_t n,
+                               int per_sample, float* den, float* dF, hipStream_t s);
+hipError_t mdt_launch_vjp_finish(const float* dxin, const float* sigma, const float* v, float sd, int64_t n, int per_sample,
+                                 float* out, hipStream_t s);
 // out[m][n] = act(b[n] + sum_a X[m][a] WT[a][n]), A <= 16; pre (optional): the pre-activation rows
 hipError_t mdt_launch_narrow_linear(const float* X, const float* WT, const float* b, float* pre, float* out, int M, int A,
                                     int N, int act, hipStream_t s);

@@ -842,7 +842,7 @@ __global__ void k_noise_input(const float* __restrict__ act, const float* __rest
                               const float* __restrict__ sigma, float* __restrict__ noised, int64_t n, int per_sample) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    noised[i] = act[i] + noise[i] * sigma[i / per_sample];
+    noised[i] = noise ? act[i] + noise[i] * sigma[i / per_sample] : act[i];  // noise == nullptr: the rows are given noisy
 }
 
 // single-workgroup deterministic reduction: loss = mean_i (F_i - (a_i - c_skip*noised_i)/c_out)^2

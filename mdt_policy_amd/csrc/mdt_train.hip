@@ -494,7 +494,7 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     }
     LAUNCH(mdt_launch_head(h, s));
     if (model_output) HIP_TRY(hipMemcpyAsync(model_output, t.F, (size_t)Ma * A * sizeof(float), hipMemcpyDeviceToDevice, s));
-    LAUNCH(mdt_launch_loss_reduce(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, loss_out, s));
+    if (loss_out) LAUNCH(mdt_launch_loss_reduce(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, loss_out, s));
     t.has_decoder = true;
     return MDT_OK;
 }
@@ -569,8 +569,9 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     mdt_linear_bwd_args a;
     memset(&a, 0, sizeof a);
     a.X = X; a.ldx = ldx; a.dY = dY; a.ldy = ldy;
-    a.dW = grads + ts->grad_off[first->w_slot];
-    a.dbias = first->b_slot >= 0 ? grads + ts->grad_off[first->b_slot] : nullptr;
+    // grads == nullptr: an input-gradient-only backward (mdt_denoise_vjp) -- no parameter gradient is formed
+    a.dW = grads ? grads + ts->grad_off[first->w_slot] : nullptr;
+    a.dbias = (grads && first->b_slot >= 0) ? grads + ts->grad_off[first->b_slot] : nullptr;
     a.accumulate_dw = 1;
     a.Wt = l.wt; a.dX = dX; a.ldxo = ldxo; a.accumulate_dx = acc_dx;
     a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
@@ -601,6 +602,7 @@ static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float
     if (shift_off < 0 && scale_off < 0) { a.mod = nullptr; a.d_mod = nullptr; }
     a.pw = ts->pw; a.pb = b ? ts->pb : nullptr; a.B = (int)B; a.rows_per_sample = T; a.D = m->D;
     LAUNCH(mdt_launch_ln_bwd(a, s));
+    if (!grads) return MDT_OK;
     if (b) LAUNCH(mdt_launch_colsum2(ts->pw, ts->pb, m->D, (int)B, m->D, grad_of(m, grads, w), grad_of(m, grads, b), 1, s));
     else LAUNCH(mdt_launch_colsum(ts->pw, m->D, (int)B, m->D, grad_of(m, grads, w), 1, s));
     return MDT_OK;
@@ -758,6 +760,8 @@ extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const
     return enc_bwd(m, *t, grads, d_tokens, d_tokens2, d_goal, s);
 }
 
+static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s);
+
 extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const float* g_loss, const float* g_ctx, float* grads,
                                          float* d_tokens, float* d_tokens2, float* d_goal, void* stream) {
     Tape* tp;
@@ -770,24 +774,41 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     MDT_TRY(reserve_scratch(m, t.B));
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta, Me = B * m->Te;
-    const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * D : D;
-    const int64_t mod_blk = m->cond == COND_ADALN ? 6 * D : 0;
     // ---- loss and action head: F = action_pred(ln(x_L))
     LAUNCH(mdt_launch_loss_grad(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, Ta * A, g_loss, ts->dF, s));
-    LAUNCH(mdt_launch_colsum(ts->dF, A, (int)Ma, A, grad_of(m, grads, m->bp), 1, s));
+    MDT_TRY(dec_bwd(m, t, grads, s));
+    // ---- context: K|V projections of all blocks, plus whatever other losses hung onto latent_encoder_emb
+    if (g_ctx) HIP_TRY(hipMemcpyAsync(ts->dxe, g_ctx, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MDT_TRY(lin_bwd(m, grads, m->kv_all, t.ctx, D, ts->d_kvx, (int64_t)m->Ld * 2 * D, (int)Me, ts->dxe, D, g_ctx ? 1 : 0, s));
+    return enc_bwd(m, t, grads, d_tokens, d_tokens2, d_goal, s);
+}
+
+// Decoder backward from ts->dF = d(raw network output F) down to ts->dx = d(action embedding rows y0); the K|V gradient of
+// every block is left in ts->d_kvx.  grads == nullptr: input gradients only (no parameter gradient, no sigma path).
+static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const int D = m->D, Ta = m->Ta, A = m->A;
+    const int64_t B = t.B, Ma = B * Ta;
+    const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * D : D;
+    const int64_t mod_blk = m->cond == COND_ADALN ? 6 * D : 0;
+    if (grads) LAUNCH(mdt_launch_colsum(ts->dF, A, (int)Ma, A, grad_of(m, grads, m->bp), 1, s));
     if (m->HP) {
         // F = action_pred.2(gelu(action_pred.0(ln))): the narrow layer on the (rows, HP) hidden rows, whose gradient
         // lands padded (A, HP) and is added into the (A, HH) slot; then GELU and the d x HP Linear on the GEMM
         const int HP = m->HP;
-        LAUNCH(mdt_launch_narrow_dw(ts->dF, t.hh, HP, ts->narrow, NARROW_SLICES, (int)Ma, A, HP, 0, s));
-        LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * HP, NARROW_SLICES, A * HP, ts->small, 0, s));
-        LAUNCH(mdt_launch_add_2d(ts->small, HP, grad_of(m, grads, m->Wp), m->HH, A, m->HH, s));
+        if (grads) {
+            LAUNCH(mdt_launch_narrow_dw(ts->dF, t.hh, HP, ts->narrow, NARROW_SLICES, (int)Ma, A, HP, 0, s));
+            LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * HP, NARROW_SLICES, A * HP, ts->small, 0, s));
+            LAUNCH(mdt_launch_add_2d(ts->small, HP, grad_of(m, grads, m->Wp), m->HH, A, m->HH, s));
+        }
         LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_4d, (int)Ma, A, HP, s));
         LAUNCH(mdt_launch_act_bwd(t.hpre, ts->t_4d, ts->t_4d, Ma * HP, MDT_ACT_GELU, s));
         MDT_TRY(lin_bwd(m, grads, m->head0, t.lnout, D, ts->t_4d, HP, (int)Ma, ts->t_d, D, 0, s));
     } else {
-        LAUNCH(mdt_launch_narrow_dw(ts->dF, t.lnout, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 0, s));
-        LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wp), 1, s));
+        if (grads) {
+            LAUNCH(mdt_launch_narrow_dw(ts->dF, t.lnout, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 0, s));
+            LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wp), 1, s));
+        }
         LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_d, (int)Ma, A, D, s));
     }
     MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
@@ -802,6 +823,7 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     // ---- action embedding: y0 = drop(action_emb(xin)); no gradient flows to the noisy actions
     LAUNCH(mdt_launch_dropout_rows(ts->dx, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed,
                                    s));
+    if (!grads) return MDT_OK;
     LAUNCH(mdt_launch_colsum(ts->dx, D, (int)Ma, D, grad_of(m, grads, m->ba), 1, s));
     LAUNCH(mdt_launch_narrow_dw(t.xin, ts->dx, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 1, s));
     LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wa), 1, s));
@@ -814,8 +836,45 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     } else if (m->cond == COND_NOISE) {
         MDT_TRY(sigma_bwd(m, t, grads, ts->d_mod, s));
     }
-    // ---- context: K|V projections of all blocks, plus whatever other losses hung onto latent_encoder_emb
-    if (g_ctx) HIP_TRY(hipMemcpyAsync(ts->dxe, g_ctx, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    MDT_TRY(lin_bwd(m, grads, m->kv_all, t.ctx, D, ts->d_kvx, (int64_t)m->Ld * 2 * D, (int)Me, ts->dxe, D, g_ctx ? 1 : 0, s));
-    return enc_bwd(m, t, grads, d_tokens, d_tokens2, d_goal, s);
+    return MDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector-Jacobian product of the denoiser w.r.t. its noisy-action input (what log_likelihood differentiates,
+// gc_sampling.py:469-487: torch.autograd.grad((d * v).sum(), action) with d = (action - D(action; sigma)) / sigma)
+// ------------------------------------------------------------------------------------------------
+extern "C" mdt_status mdt_denoise_vjp(mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                      int32_t modality, const float* x, const float* sigma, const float* v, int64_t batch,
+                                      float* denoised, float* vjp, void* stream) {
+    MDT_TRY(check_ready(m));
+    if (!tokens || !goal || !x || !sigma || !v || !denoised || !vjp || batch < 1)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_denoise_vjp: bad argument");
+    if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
+    hipStream_t s = (hipStream_t)stream;
+    mdt_tape_id id;
+    MDT_TRY(acquire_tape(m, batch, &id));
+    Tape& t = m->train->tapes[id];
+    t.drop = effective_dropout(nullptr);  // eval-mode forward: D(x; sigma) itself
+    const int honour = m->cfg.arch == MDT_ARCH_MDTV;
+    mdt_status st = reserve_scratch(m, batch);
+    if (st == MDT_OK) st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, sigma, nullptr, s);
+    // action := x, no noise: the tape's "noised" rows are x itself, F the raw network output
+    if (st == MDT_OK) st = dec_fwd(m, t, x, nullptr, sigma, nullptr, nullptr, s);
+    if (st == MDT_OK) {
+        mdt_train_state* ts = m->train;
+        const int64_t n = batch * m->Ta * m->A;
+        const int per = m->Ta * m->A;
+        // D = c_skip x + c_out F;  dF = c_out v
+        hipError_t e = mdt_launch_vjp_seed(t.F, t.noised, t.sigma, v, m->cfg.sigma_data, n, per, denoised, ts->dF, s);
+        if (e != hipSuccess) st = fail(MDT_ERR_HIP, "vjp seed launch failed: %s", hipGetErrorString(e));
+        if (st == MDT_OK) st = dec_bwd(m, t, nullptr, s);
+        if (st == MDT_OK) {
+            // y0 = action_emb(c_in x): d x = c_in (d y0 . Wa) + c_skip v
+            e = mdt_launch_narrow_out(ts->dx, m->D, m->Wa, ts->small, (int)(batch * m->Ta), m->A, m->D, s);
+            if (e == hipSuccess) e = mdt_launch_vjp_finish(ts->small, t.sigma, v, m->cfg.sigma_data, n, per, vjp, s);
+            if (e != hipSuccess) st = fail(MDT_ERR_HIP, "vjp finish launch failed: %s", hipGetErrorString(e));
+        }
+    }
+    t.in_use = false;
+    return st;
 }

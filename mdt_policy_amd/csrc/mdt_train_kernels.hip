@@ -679,6 +679,38 @@ hipError_t mdt_launch_loss_grad(const float* F, const float* act, const float* n
     return hipGetLastError();
 }
 
+// mdt_denoise_vjp: D = c_skip x + c_out F (score_wrappers.py:65-80) and the seed of its backward, dF = c_out v
+__global__ void k_vjp_seed(const float* __restrict__ F, const float* __restrict__ x, const float* __restrict__ sigma,
+                           const float* __restrict__ v, float sd, int64_t n, int per_sample, float* __restrict__ den,
+                           float* __restrict__ dF) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sg = sigma[i / per_sample];
+    const float den2 = sg * sg + sd * sd;
+    const float c_skip = sd * sd / den2, c_out = sg * sd / sqrtf(den2);
+    den[i] = fmaf(F[i], c_out, x[i] * c_skip);
+    dF[i] = c_out * v[i];
+}
+hipError_t mdt_launch_vjp_seed(const float* F, const float* x, const float* sigma, const float* v, float sd, int64_t n,
+                               int per_sample, float* den, float* dF, hipStream_t s) {
+    hipLaunchKernelGGL(k_vjp_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, F, x, sigma, v, sd, n, per_sample, den, dF);
+    return hipGetLastError();
+}
+// ... and its end: the network saw c_in x, the skip connection c_skip x
+__global__ void k_vjp_finish(const float* __restrict__ dxin, const float* __restrict__ sigma, const float* __restrict__ v,
+                             float sd, int64_t n, int per_sample, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sg = sigma[i / per_sample];
+    const float den2 = sg * sg + sd * sd;
+    out[i] = fmaf(dxin[i], 1.0f / sqrtf(den2), v[i] * (sd * sd / den2));
+}
+hipError_t mdt_launch_vjp_finish(const float* dxin, const float* sigma, const float* v, float sd, int64_t n, int per_sample,
+                                 float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_vjp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dxin, sigma, v, sd, n, per_sample, out);
+    return hipGetLastError();
+}
+
 // out[m][d] = sum_a G[m][a] * W[a][d]            (d(ln_out) = dF @ action_pred.weight, W is (A, D))
 __global__ void k_narrow_dx(const float* __restrict__ G, const float* __restrict__ W, float* __restrict__ out, int64_t n,
                             int A, int D) {

@@ -651,3 +651,104 @@ def sample_dpmpp_sde(model, state, action, goal, sigmas, extra_args=None, callba
             if scaler is not None:
                 action = scaler.clip_output(action)
     return action
+
+
+# ------------------------------------------------------------------------------------------------
+# log-likelihood (reference gc_sampling.py:468-490)
+# ------------------------------------------------------------------------------------------------
+# Dormand-Prince 5(4) tableau: node positions, stage weights (row i feeds stage i+1), the 5th-order solution
+# weights (= the last row: first-same-as-last) and the difference to the embedded 4th-order weights.
+_DP_C = (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
+_DP_A = (
+    (),
+    (1 / 5,),
+    (3 / 40, 9 / 40),
+    (44 / 45, -56 / 15, 32 / 9),
+    (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+    (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+    (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84),
+)
+_DP_E = (35 / 384 - 5179 / 57600, 0.0, 500 / 1113 - 7571 / 16695, 125 / 192 - 393 / 640, -2187 / 6784 + 92097 / 339200,
+         11 / 84 - 187 / 2100, -1 / 40)
+
+
+def _scaled_rms(parts, scale_parts):
+    """Root mean square of err / scale over ALL entries of a tuple state (one number: the step is shared)."""
+    num = sum(float(((p / s) ** 2).sum()) for p, s in zip(parts, scale_parts))
+    return math.sqrt(num / sum(p.numel() for p in parts))
+
+
+def _dopri5(fn, y0, t0, t1, rtol, atol, max_steps=10000):
+    """Adaptive Dormand-Prince 5(4) integration of y' = fn(t, y) from t0 to t1 for a tuple of tensors ``y0``: embedded
+    error estimate in a mixed absolute / relative norm, first-same-as-last stage reuse, step controller
+    h <- h * clip(0.9 * err^(-1/5), 0.2, 10), Hairer's starting step; the last step is shortened to end on t1.  The role
+    torchdiffeq.odeint(..., method='dopri5') plays in the reference (gc_sampling.py:486) -- that package is not a
+    dependency here."""
+    y = tuple(y0)
+    t, direction = float(t0), (1.0 if t1 >= t0 else -1.0)
+    k1 = fn(t, y)
+    scale = tuple(atol + rtol * p.abs() for p in y)
+    d0, d1 = _scaled_rms(y, scale), _scaled_rms(k1, scale)
+    h = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    y_probe = tuple(p + direction * h * k for p, k in zip(y, k1))
+    d2 = _scaled_rms(tuple(a - b for a, b in zip(fn(t + direction * h, y_probe), k1)), scale) / h
+    h = min(100 * h, max(1e-6, 1e-3 * h) if max(d1, d2) <= 1e-15 else (0.01 / max(d1, d2)) ** 0.2)
+    for _ in range(max_steps):
+        if (t1 - t) * direction <= 0:
+            return y
+        h = min(h, abs(t1 - t))
+        ks = [k1]
+        for i in range(1, 7):
+            yi = tuple(p + direction * h * sum(a * k[j] for a, k in zip(_DP_A[i], ks) if a != 0.0)
+                       for j, p in enumerate(y))
+            if i == 6:
+                y_new = yi
+            ks.append(fn(t + direction * _DP_C[i] * h, yi))
+        err = tuple(h * sum(e * k[j] for e, k in zip(_DP_E, ks) if e != 0.0) for j in range(len(y)))
+        scale = tuple(atol + rtol * torch.maximum(p.abs(), q.abs()) for p, q in zip(y, y_new))
+        ratio = _scaled_rms(err, scale)
+        if ratio <= 1.0:  # accept
+            t = t1 if h >= abs(t1 - t) else t + direction * h
+            y, k1 = y_new, ks[6]
+        h *= 10.0 if ratio == 0.0 else min(10.0, max(0.2, 0.9 * ratio ** -0.2))
+    raise RuntimeError("_dopri5: step budget exhausted before reaching the end of the interval")
+
+
+def _probe_signs(action):
+    """Rademacher probe of Hutchinson's trace estimator, drawn the way the reference draws it (gc_sampling.py:475)."""
+    return torch.randint_like(action, 2) * 2 - 1
+
+
+@torch.no_grad()
+def log_likelihood(model, state, action, goal, sigma_min, sigma_max, extra_args=None, atol=1e-4, rtol=1e-4):
+    """log p(action | state, goal) by integrating the probability-flow ODE dx/dsigma = (x - D(x; sigma)) / sigma from
+    sigma_min to sigma_max together with its divergence, estimated with one Rademacher probe v as v^T (d f / d x) v
+    (reference gc_sampling.py:468-490).  Returns (log-likelihood per sample, {'fevals': n}).
+
+    With this package's GCDenoiser the denoiser value and the vector-Jacobian product (dD/dx)^T v come from one HIP
+    forward + input-gradient-only backward (``mdt_denoise_vjp``); any other model is differentiated with
+    torch.autograd, as in the reference."""
+    extra_args = {} if extra_args is None else extra_args
+    v = _probe_signs(action)
+    fevals = 0
+    hip = isinstance(model, GCDenoiser) and not extra_args
+
+    def flow(sigma, y):
+        nonlocal fevals
+        x = y[0]
+        fevals += 1
+        if hip:
+            sg = torch.full((x.shape[0],), sigma, device=x.device, dtype=x.dtype)
+            denoised, jtv = model.denoise_vjp(state, x, goal, sg, v)
+            grad = (v - jtv) / sigma  # d/dx of sum(((x - D(x)) / sigma) * v)
+        else:
+            with torch.enable_grad():
+                x = x.detach().requires_grad_()
+                denoised = model(state, x, goal, x.new_full((x.shape[0],), sigma), **extra_args)
+                grad = torch.autograd.grad((to_d(x, sigma, denoised) * v).sum(), x)[0]
+        return to_d(x, sigma, denoised).detach(), (v * grad).flatten(1).sum(1)
+
+    latent, delta_ll = _dopri5(flow, (action, action.new_zeros([action.shape[0]])), float(sigma_min), float(sigma_max),
+                               rtol, atol)
+    ll_prior = torch.distributions.Normal(0, sigma_max).log_prob(latent).flatten(1).sum(1)
+    return ll_prior + delta_ll, {'fevals': fevals}

@@ -156,6 +156,14 @@ class GCDenoiser(nn.Module):
             self._ctx_key = prev
 
     @torch.no_grad()
+    def denoise_vjp(self, state, action, goal, sigma, v):
+        """(D(action; sigma), (dD/daction)^T v) in eval-mode arithmetic: what gc_sampling.log_likelihood needs from
+        autograd through ``self(state, action, goal, sigma)`` (reference gc_sampling.py:477-484), as one HIP forward
+        and an input-gradient-only HIP backward."""
+        im = self.inner_model
+        return self._engine(state=state).denoise_vjp(state, action, im._goals(goal, False), sigma, v)
+
+    @torch.no_grad()
     def sample_ddim(self, state, action, goal, sigmas):
         """Whole DDIM loop (reference gc_sampling.py:922-951) as one enqueue on the current stream."""
         im = self.inner_model

@@ -309,6 +309,22 @@ class HipEngine:
                                                  _ptr(d_goal), self._stream()))
         return grads, d_tok, d_tok2, d_goal
 
+    def denoise_vjp(self, state: dict, x: torch.Tensor, goal: torch.Tensor, sigma: torch.Tensor, v: torch.Tensor):
+        """(D(x; sigma), (dD/dx)^T v): the eval-mode denoiser and its vector-Jacobian product w.r.t. the noisy actions
+        (mdt_denoise_vjp: a tape-keeping forward plus an input-gradient-only backward)."""
+        self.train_prepare()
+        self.sync_params()
+        tok, tok2, B = self._tokens(state)
+        g = self._goal(goal, B)
+        x_, v_ = self._in(x, (B, self.Ta, self.A)), self._in(v, (B, self.Ta, self.A))
+        s = self._in(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma, (B,))
+        den = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
+        vjp = torch.empty_like(den)
+        self.ctx_generation += 1
+        _lib.check(self.lib.mdt_denoise_vjp(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(x_),
+                                            _ptr(s), _ptr(v_), B, _ptr(den), _ptr(vjp), self._stream()))
+        return den, vjp
+
     def tape_release(self, tape: int) -> None:
         _lib.check(self.lib.mdt_tape_release(self.handle, tape))
 

@@ -688,6 +688,63 @@ def g16():
         save(f"g16_proprio_{name}.npz", meta, loss=np.array(loss.item(), np.float32), **arrays)
 
 
+G17_LL = {
+    # name: (arch, config factory, overrides, B, sigma_min, sigma_max)
+    "mdtv_tiny": ("mdtv", "mdtv_tiny", {}, 3, 0.001, 80.0),
+    "mdt_tiny": ("mdt", "mdt_tiny", {}, 2, 0.01, 20.0),
+    "mdtv_default": ("mdtv", "mdtv_default", {}, 2, 0.001, 80.0),
+}
+
+
+def scipy_odeint(fn, y0, t, atol, rtol, method):
+    """Stand-in for torchdiffeq.odeint (not installed): scipy's Dormand-Prince RK45 over the flattened tuple state, so the
+    REFERENCE's own log_likelihood (ode_fn, Hutchinson term, prior term) runs unchanged.  The integrator is therefore not
+    the reference's: results agree with torchdiffeq's dopri5 to the requested tolerance, not bit for bit."""
+    from scipy.integrate import solve_ivp
+    assert method == "dopri5"
+    shapes = [tuple(p.shape) for p in y0]
+    sizes = [int(np.prod(sh)) for sh in shapes]
+
+    def unpack(flat):
+        out, o = [], 0
+        for sh, n in zip(shapes, sizes):
+            out.append(torch.from_numpy(flat[o:o + n].reshape(sh).astype(np.float32)))
+            o += n
+        return tuple(out)
+
+    def rhs(tt, flat):
+        out = fn(torch.tensor(tt, dtype=torch.float32), unpack(flat))
+        return np.concatenate([o.detach().double().numpy().ravel() for o in out])
+
+    flat0 = np.concatenate([p.detach().double().numpy().ravel() for p in y0])
+    sol = solve_ivp(rhs, (float(t[0]), float(t[-1])), flat0, method="RK45", rtol=rtol, atol=atol)
+    assert sol.success
+    end = unpack(sol.y[:, -1])
+    return tuple(torch.stack([a, b]) for a, b in zip(y0, end))
+
+
+def g17():
+    """log_likelihood of the REFERENCE (gc_sampling.py:468-490) with the integrator stand-in above.  Stored: the probe
+    signs v the run drew (seeded CPU generator), the log-likelihoods, the number of model evaluations."""
+    from mdt.models.edm_diffusion import gc_sampling
+    gc_sampling.odeint = scipy_odeint
+    for name, (arch, factory, ov, B, smin, smax) in G17_LL.items():
+        cfg = getattr(configs, factory)(**ov)
+        model = build_reference(cfg, arch, seed=171, profile="rich")
+        inp = synthetic.sampler_inputs(B, cfg, 172, arch)
+        li = synthetic.loss_inputs(B, cfg, 173)
+        state = make_state(inp, arch, "lang")
+        action = torch.from_numpy(li["actions"])
+        torch.manual_seed(174)
+        v = torch.randint_like(action, 2) * 2 - 1
+        torch.manual_seed(174)
+        ll, info = gc_sampling.log_likelihood(model, state, action, torch.from_numpy(inp["goal"]), smin, smax)
+        meta = dict(config=factory, overrides=ov, arch=arch, B=B, modality="lang", weight_seed=171, profile="rich",
+                    input_seed=172, loss_seed=173, probe_seed=174, sigma_min=smin, sigma_max=smax, fevals=info["fevals"],
+                    state_dict=[[k, list(v_.shape)] for k, v_ in model.state_dict().items()])
+        save(f"g17_loglik_{name}.npz", meta, ll=ll.numpy(), v=v.numpy())
+
+
 def manifest():
     """state_dict names + shapes IN ORDER (the checkpoint / positional-EMA contract, evaluation/utils.py:98)."""
     out = {}
@@ -710,7 +767,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "this script needs the reference checkout at /root/reference"
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "g14", "g15", "g16", "manifest"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13", "g14", "g15", "g16", "g17", "manifest"]
     for w in which:
         print(w)
         globals()[w]()
