@@ -290,3 +290,20 @@ def load() -> C.CDLL:
 def check(status: int) -> None:
     if status != 0:
         raise MDTHipError(status, load().mdt_last_error().decode("utf-8", "replace"))
+
+
+def call(fn, *args) -> None:
+    """``check(fn(*args))`` with one retry after ``torch.cuda.empty_cache()`` when a hipMalloc inside the library failed:
+    weights, workspace and tapes are raw HIP allocations, so memory that torch's caching allocator holds but does not use
+    looks exhausted to them although it is free."""
+    status = fn(*args)
+    if status != 0:
+        msg = load().mdt_last_error().decode("utf-8", "replace")
+        if "hipMalloc" in msg or "out of memory" in msg.lower():
+            import torch
+            torch.cuda.empty_cache()
+            status = fn(*args)
+            if status == 0:
+                return
+            msg = load().mdt_last_error().decode("utf-8", "replace")
+        raise MDTHipError(status, msg)

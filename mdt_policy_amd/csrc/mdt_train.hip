@@ -39,6 +39,11 @@ struct Tape {
     int lang = 0;  // 1: the goal went through lang_emb
     mdt_dropout drop = {0.f, 0.f, 0.f, 0.f, 0};
     float* buf = nullptr;
+    // stream of the last call that read or wrote the tape, and the event mdt_tape_release records on it: a later forward
+    // that reuses the buffers from ANOTHER stream waits for it (the release only marks the tape free on the host)
+    hipStream_t stream = nullptr;
+    hipEvent_t freed = nullptr;
+    bool freed_pending = false;
     // inputs
     float *tokens, *tokens2, *goal, *action, *noised, *sigma;
     float *p_pre = nullptr, *p_h = nullptr;  // proprio_emb: pre-activation and Mish output of its first layer (B, 2D)
@@ -115,7 +120,10 @@ extern "C" mdt_status mdt_train_prepare(mdt_model* m) {
 void mdt_train_free(mdt_model* m) {
     if (!m || !m->train) return;
     mdt_train_state* t = m->train;
-    for (Tape& tp : t->tapes) (void)hipFree(tp.buf);
+    for (Tape& tp : t->tapes) {
+        (void)hipFree(tp.buf);
+        if (tp.freed) (void)hipEventDestroy(tp.freed);
+    }
     (void)hipFree(t->scratch);
     (void)hipFree(t->wt_arena);
     for (const LinPart& p : m->parts) p.lin->wt = nullptr;
@@ -172,7 +180,7 @@ static void carve_tape(const mdt_model* m, Bump& b, Tape& t, int64_t B) {
     t.hpre = b.take(Ma * m->HP); t.hh = b.take(Ma * m->HP);
 }
 
-static mdt_status acquire_tape(mdt_model* m, int64_t B, mdt_tape_id* id) {
+static mdt_status acquire_tape(mdt_model* m, int64_t B, mdt_tape_id* id, hipStream_t s) {
     mdt_train_state* ts = m->train;
     int pick = -1;
     for (size_t i = 0; i < ts->tapes.size(); ++i)
@@ -196,6 +204,9 @@ static mdt_status acquire_tape(mdt_model* m, int64_t B, mdt_tape_id* id) {
     Bump real;
     real.base = t.buf;
     carve_tape(m, real, t, t.cap);
+    if (t.freed_pending && t.stream != s) HIP_TRY(hipStreamWaitEvent(s, t.freed, 0));  // its last reader ran elsewhere
+    t.freed_pending = false;
+    t.stream = s;
     t.in_use = true;
     t.B = B;
     t.has_decoder = false;
@@ -214,6 +225,10 @@ static mdt_status get_tape(mdt_model* m, mdt_tape_id id, Tape** out) {
 extern "C" mdt_status mdt_tape_release(mdt_model* m, mdt_tape_id id) {
     Tape* t;
     MDT_TRY(get_tape(m, id, &t));
+    // the backward that last read the tape may still be in flight on its stream: leave a marker there for the next user
+    if (!t->freed) HIP_TRY(hipEventCreateWithFlags(&t->freed, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(t->freed, t->stream));
+    t->freed_pending = true;
     t->in_use = false;
     return MDT_OK;
 }
@@ -527,7 +542,7 @@ extern "C" mdt_status mdt_train_encode_fwd(mdt_model* m, const float* tokens, co
     if (!tokens || !goal || !tape || batch < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_train_encode_fwd: bad argument");
     if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
     MDT_TRY(check_dropout(drop));
-    MDT_TRY(acquire_tape(m, batch, tape));
+    MDT_TRY(acquire_tape(m, batch, tape, (hipStream_t)stream));
     m->train->tapes[*tape].drop = effective_dropout(drop);
     mdt_status st = enc_fwd(m, m->train->tapes[*tape], tokens, tokens2, goal, modality, honour_modality, sigma, ctx_out,
                             (hipStream_t)stream);
@@ -545,7 +560,7 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
     if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
     hipStream_t s = (hipStream_t)stream;
     MDT_TRY(check_dropout(drop));
-    MDT_TRY(acquire_tape(m, batch, tape));
+    MDT_TRY(acquire_tape(m, batch, tape, s));
     Tape& t = m->train->tapes[*tape];
     t.drop = effective_dropout(drop);
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;  // MDTTransformer.forward always uses goal_emb (mdt_transformer.py:215)
@@ -755,6 +770,7 @@ extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const
     MDT_TRY(get_tape(m, tape, &t));
     if (!g_ctx || !grads) return fail(MDT_ERR_INVALID_ARG, "mdt_train_encode_bwd: null argument");
     hipStream_t s = (hipStream_t)stream;
+    t->stream = s;
     MDT_TRY(reserve_scratch(m, t->B));
     HIP_TRY(hipMemcpyAsync(m->train->dxe, g_ctx, (size_t)t->B * m->Te * m->D * sizeof(float), hipMemcpyDeviceToDevice, s));
     return enc_bwd(m, *t, grads, d_tokens, d_tokens2, d_goal, s);
@@ -770,6 +786,7 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     if (!grads) return fail(MDT_ERR_INVALID_ARG, "mdt_train_loss_bwd: null gradient buffer");
     if (!t.has_decoder) return fail(MDT_ERR_STATE, "tape %d holds an encoder-only forward: use mdt_train_encode_bwd", tape);
     hipStream_t s = (hipStream_t)stream;
+    t.stream = s;
     mdt_train_state* ts = m->train;
     MDT_TRY(reserve_scratch(m, t.B));
     const int D = m->D, Ta = m->Ta, A = m->A;
@@ -852,7 +869,7 @@ extern "C" mdt_status mdt_denoise_vjp(mdt_model* m, const float* tokens, const f
     if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "MDT needs the gripper tokens");
     hipStream_t s = (hipStream_t)stream;
     mdt_tape_id id;
-    MDT_TRY(acquire_tape(m, batch, &id));
+    MDT_TRY(acquire_tape(m, batch, &id, s));
     Tape& t = m->train->tapes[id];
     t.drop = effective_dropout(nullptr);  // eval-mode forward: D(x; sigma) itself
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
@@ -875,6 +892,6 @@ extern "C" mdt_status mdt_denoise_vjp(mdt_model* m, const float* tokens, const f
             if (e != hipSuccess) st = fail(MDT_ERR_HIP, "vjp finish launch failed: %s", hipGetErrorString(e));
         }
     }
-    t.in_use = false;
+    (void)mdt_tape_release(m, id);
     return st;
 }

@@ -61,7 +61,7 @@ class GCDenoiser(nn.Module):
         return torch.is_grad_enabled() and (any(p.requires_grad for p in self.inner_model.parameters()) or
                                             any(torch.is_tensor(t) and t.requires_grad for t in tensors))
 
-    def _train_inputs(self, eng, state, goal, honour_modality: bool):
+    def _train_inputs(self, eng, state, goal, honour_modality: bool, uncond: bool = False):
         """Encoder inputs as the contiguous fp32 tensors the C ABI takes, still attached to the autograd graph, and
         the parameters THIS forward reads: the others (proprio_emb, MDT-V's pos_emb, the other modality's goal
         embedder) stay out of the graph, so their .grad stays None and DistributedDataParallel's
@@ -77,7 +77,7 @@ class GCDenoiser(nn.Module):
             tok, tok2 = prep(state["static"]), prep(state["gripper"])
             B = tok.shape[0]
         eng._tokens(state)  # shape validation
-        g = prep(im._goals(goal, False))
+        g = prep(im._goals(goal, uncond))  # uncond: the goal is zeroed (preprocess_goals, mdtv_transformer.py:256-257)
         eng._goal(g, B)
         eng.train_prepare()
         unused = eng.unused_goal_embedder(state, honour_modality)
@@ -118,11 +118,10 @@ class GCDenoiser(nn.Module):
     def forward_context_only(self, state, action, goal, sigma, **kwargs):
         """Encoder tokens only (reference score_wrappers.py:82-97 -> inner_model.forward_enc_only)."""
         im = self.inner_model
-        if not kwargs.get("uncond", False) and \
-                self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
+        if self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
             from ._autograd import HipContextOnly
             eng = self._engine(allow_grad=True, state=state)
-            tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal, True)
+            tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal, True, bool(kwargs.get("uncond", False)))
             sg = eng._in(sigma, (B,)) if eng.sigma_in_context else None  # the sigma token leads the context
             ctx = HipContextOnly.apply(eng, state, tok, tok2, g, True, im.train_dropout(), sg, names, *params)
             if im._arch == "mdtv":

@@ -164,8 +164,8 @@ class HipEngine:
             s = self._in(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma, (B,))
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         self.ctx_generation += 1
-        _lib.check(self.lib.mdt_encode(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
-                                       int(honour_modality), _ptr(s), B, _ptr(ctx), self._stream()))
+        _lib.call(self.lib.mdt_encode, self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
+                                       int(honour_modality), _ptr(s), B, _ptr(ctx), self._stream())
         return ctx
 
     def denoise_cached(self, x: torch.Tensor, sigma: torch.Tensor, flags: int = 0) -> torch.Tensor:
@@ -177,7 +177,7 @@ class HipEngine:
         else:
             s = self._in(sigma, (B,))
         out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
-        _lib.check(self.lib.mdt_denoise_cached(self.handle, _ptr(x_), _ptr(s), B, flags, _ptr(out), self._stream()))
+        _lib.call(self.lib.mdt_denoise_cached, self.handle, _ptr(x_), _ptr(s), B, flags, _ptr(out), self._stream())
         return out
 
     def forward(self, state: dict, x: torch.Tensor, goal: torch.Tensor, sigma: torch.Tensor):
@@ -189,8 +189,8 @@ class HipEngine:
         out = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         self.ctx_generation += 1
-        _lib.check(self.lib.mdt_forward(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(x_),
-                                        _ptr(s), B, _ptr(out), _ptr(ctx), self._stream()))
+        _lib.call(self.lib.mdt_forward, self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(x_),
+                                        _ptr(s), B, _ptr(out), _ptr(ctx), self._stream())
         return out, ctx
 
     def sample_ddim(self, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas):
@@ -207,15 +207,15 @@ class HipEngine:
             n = sig.numel() - 1
             self._keep = sig  # the kernel that reads it is only enqueued: keep the (possibly converted) tensor alive
             self.ctx_generation += 1
-            _lib.check(self.lib.mdt_sample_ddim_dev(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
-                                                    _ptr(x_), _ptr(sig), n, B, _ptr(out), _ptr(ctx), self._stream()))
+            _lib.call(self.lib.mdt_sample_ddim_dev, self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
+                                                    _ptr(x_), _ptr(sig), n, B, _ptr(out), _ptr(ctx), self._stream())
             return out, ctx
         sig = [float(v) for v in (sigmas.detach().tolist() if torch.is_tensor(sigmas) else sigmas)]
         n = len(sig) - 1
         arr = (C.c_float * len(sig))(*sig)
         self.ctx_generation += 1
-        _lib.check(self.lib.mdt_sample_ddim(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
-                                            _ptr(x_), arr, n, B, _ptr(out), _ptr(ctx), self._stream()))
+        _lib.call(self.lib.mdt_sample_ddim, self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state),
+                                            _ptr(x_), arr, n, B, _ptr(out), _ptr(ctx), self._stream())
         return out, ctx
 
     def persist_status(self) -> int:
@@ -235,12 +235,12 @@ class HipEngine:
         mo = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         self.ctx_generation += 1
-        _lib.check(self.lib.mdt_loss_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(a),
-                                         _ptr(nz), _ptr(s), B, _ptr(loss), _ptr(mo), _ptr(ctx), self._stream()))
+        _lib.call(self.lib.mdt_loss_fwd, self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(a),
+                                         _ptr(nz), _ptr(s), B, _ptr(loss), _ptr(mo), _ptr(ctx), self._stream())
         return loss, mo, ctx
 
     def reserve(self, max_batch: int) -> None:
-        _lib.check(self.lib.mdt_reserve(self.handle, int(max_batch)))
+        _lib.call(self.lib.mdt_reserve, self.handle, int(max_batch))
 
     # -- training path (include/mdt_hip_train.h) ----------------------------------------------------
     def train_prepare(self) -> None:
@@ -248,7 +248,7 @@ class HipEngine:
         if getattr(self, "_grad_layout", None) is not None:
             return
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.mdt_train_prepare(self.handle))
+            _lib.call(self.lib.mdt_train_prepare, self.handle)
         self._uploaded.clear()  # every parameter is re-uploaded so that its transposed image exists
         n = self.lib.mdt_param_count(self.handle)
         self._grad_layout = {self.lib.mdt_param_name(self.handle, i).decode():
@@ -265,10 +265,10 @@ class HipEngine:
         ctx = torch.empty((B, self.Te, self.D), device=self.device, dtype=torch.float32)
         tape = C.c_int32(-1)
         self.ctx_generation += 1
-        _lib.check(self.lib.mdt_train_loss_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
+        _lib.call(self.lib.mdt_train_loss_fwd, self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
                                                _ptr(action), _ptr(noise), _ptr(sigma), B,
                                                None if drop is None else C.byref(drop), _ptr(loss), _ptr(mo), _ptr(ctx),
-                                               C.byref(tape), self._stream()))
+                                               C.byref(tape), self._stream())
         return loss, mo, ctx, int(tape.value)
 
     def train_encode_fwd(self, state: dict, tok, tok2, goal, honour_modality: bool, drop=None, sigma=None):
@@ -280,10 +280,10 @@ class HipEngine:
         if self.sigma_in_context and sigma is None:
             raise ValueError("use_ada_conditioning=False: sigma is a context token and must be given")
         self.ctx_generation += 1
-        _lib.check(self.lib.mdt_train_encode_fwd(self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
+        _lib.call(self.lib.mdt_train_encode_fwd, self.handle, _ptr(tok), _ptr(tok2), _ptr(goal), self._modality(state),
                                                  int(honour_modality), _ptr(sigma) if self.sigma_in_context else None, B,
                                                  None if drop is None else C.byref(drop), _ptr(ctx), C.byref(tape),
-                                                 self._stream()))
+                                                 self._stream())
         return ctx, int(tape.value)
 
     def _input_grads(self, tok, tok2, goal, needs):
@@ -297,16 +297,16 @@ class HipEngine:
         d_tok, d_tok2, d_goal = self._input_grads(tok, tok2, goal, needs)
         gl = None if g_loss is None else self._in(g_loss, ())
         gc = None if g_ctx is None else self._in(g_ctx)
-        _lib.check(self.lib.mdt_train_loss_bwd(self.handle, tape, _ptr(gl), _ptr(gc), _ptr(grads), _ptr(d_tok),
-                                               _ptr(d_tok2), _ptr(d_goal), self._stream()))
+        _lib.call(self.lib.mdt_train_loss_bwd, self.handle, tape, _ptr(gl), _ptr(gc), _ptr(grads), _ptr(d_tok),
+                                               _ptr(d_tok2), _ptr(d_goal), self._stream())
         return grads, d_tok, d_tok2, d_goal
 
     def train_encode_bwd(self, tape: int, g_ctx, tok, tok2, goal, needs):
         grads = torch.zeros(self._grad_numel, device=self.device, dtype=torch.float32)
         d_tok, d_tok2, d_goal = self._input_grads(tok, tok2, goal, needs)
         gc = self._in(g_ctx)
-        _lib.check(self.lib.mdt_train_encode_bwd(self.handle, tape, _ptr(gc), _ptr(grads), _ptr(d_tok), _ptr(d_tok2),
-                                                 _ptr(d_goal), self._stream()))
+        _lib.call(self.lib.mdt_train_encode_bwd, self.handle, tape, _ptr(gc), _ptr(grads), _ptr(d_tok), _ptr(d_tok2),
+                                                 _ptr(d_goal), self._stream())
         return grads, d_tok, d_tok2, d_goal
 
     def denoise_vjp(self, state: dict, x: torch.Tensor, goal: torch.Tensor, sigma: torch.Tensor, v: torch.Tensor):
@@ -321,8 +321,8 @@ class HipEngine:
         den = torch.empty((B, self.Ta, self.A), device=self.device, dtype=torch.float32)
         vjp = torch.empty_like(den)
         self.ctx_generation += 1
-        _lib.check(self.lib.mdt_denoise_vjp(self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(x_),
-                                            _ptr(s), _ptr(v_), B, _ptr(den), _ptr(vjp), self._stream()))
+        _lib.call(self.lib.mdt_denoise_vjp, self.handle, _ptr(tok), _ptr(tok2), _ptr(g), self._modality(state), _ptr(x_),
+                                            _ptr(s), _ptr(v_), B, _ptr(den), _ptr(vjp), self._stream())
         return den, vjp
 
     def tape_release(self, tape: int) -> None:

@@ -502,3 +502,61 @@ def test_hip_training_under_lightning_style_amp():
         if k in ref:
             assert_close(p.grad.cpu(), ref[k].cpu(), rtol=5e-3, atol=5e-3 * float(ref[k].abs().max()) + 1e-7, what=k)
     scaler.step(opt); scaler.update()
+
+
+@pytest.mark.gpu
+def test_context_only_uncond_under_autograd():
+    """forward_context_only(..., uncond=True) in a training step (classifier-free-guidance style auxiliary passes): the goal is
+    zeroed before the goal embedder (mdtv_transformer.py:256-257) and the call stays differentiable."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, state, goal, li = case("mdtv_tiny")
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    gstate = {k: (v.cuda().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+    ctx = model.forward_context_only(gstate, None, goal.cuda(), li["sigma"].cuda(), uncond=True)
+    w = torch.from_numpy(synthetic.normal("ctx_weight", tuple(ctx.shape), 9))
+    (ctx * w.cuda()).sum().backward()
+    P = {k: v.double().requires_grad_(v.dtype.is_floating_point) for k, v in params_of(meta).items()}
+    st64 = {k: (v.double().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+    c64 = O.encode(P, cfg, st64, torch.zeros_like(goal).double(), "mdtv", "enc_only")
+    (c64 * w.double()).sum().backward()
+    assert_close(ctx.detach().cpu(), c64.detach(), what="unconditional context")
+    assert_close(gstate["state_images"].grad.cpu(), st64["state_images"].grad, rtol=2e-3, atol=1e-5, what="d_state_images")
+    ref = P["inner_model.tok_emb.weight"].grad
+    assert_close(model.inner_model.tok_emb.weight.grad.cpu(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()), what="tok_emb")
+
+
+@pytest.mark.gpu
+def test_tape_reuse_across_streams_waits_for_the_previous_backward():
+    """A tape released at the end of a backward on stream A and picked up by a forward on stream B: mdt_tape_release leaves
+    an event on A that the next user waits for, so the new forward cannot overwrite activations the in-flight backward
+    still reads.  Alternating streams, every step's gradients must equal the single-stream result bit for bit."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, _, _, _ = case("mdtv_default")
+    B = 256
+    state, goal, _ = inputs_of(meta, batch=B)
+    li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(B, cfg, meta["loss_seed"]).items()}
+    model = GCDenoiser(cfg, 0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    gstate = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    ggoal = goal.cuda()
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss, _ = model.loss(gstate, li["actions"], ggoal, li["noise_train"], li["sigma"])
+        loss.backward()
+        return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).clone()
+
+    want = step()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for i in range(6):
+        s = streams[i % 2]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            got = step()
+        # no synchronisation between iterations: the next forward is enqueued while this backward may still run
+        assert torch.equal(got.cpu(), want.cpu()), f"step {i}"
