@@ -37,12 +37,14 @@ mdt_status mdt_op_swiglu_bwd(const float *u, const float *d_out, float *du, int6
 
 /* Unmasked multi-head self-attention over T <= 128 tokens (voltron Attention.forward):
  *   qkv (B*T, 3*H*hd) = q | k | v column blocks (row stride ld_qkv), head h at columns h*hd;
- *   out (B*T, H*hd) = softmax(q k^T * scale) v.   hd a multiple of 4, <= 64.  One workgroup per (sample, head). */
+ *   out (B*T, H*hd) = softmax(q k^T * scale) v.   hd in {16, 24, 32, 48, 64}.  One workgroup per (sample, head). */
 mdt_status mdt_op_attn_mid_fwd(const float *qkv, int64_t ld_qkv, float *out, int64_t ld_out, int64_t B, int32_t H,
                                int32_t hd, int32_t T, float scale, void *stream);
-/* d_qkv (B*T, 3*H*hd; same layout, overwritten) from d_out; the probabilities are recomputed from qkv. */
-mdt_status mdt_op_attn_mid_bwd(const float *qkv, int64_t ld_qkv, const float *d_out, int64_t ld_do, float *d_qkv,
-                               int64_t ld_dqkv, int64_t B, int32_t H, int32_t hd, int32_t T, float scale, void *stream);
+/* d_qkv (B*T, 3*H*hd; same layout, overwritten) from d_out; the probabilities are recomputed from qkv, `out` is the
+ * forward's output (its rows give sum_j P_ij dP_ij = d_out_i . out_i without a second P V product). */
+mdt_status mdt_op_attn_mid_bwd(const float *qkv, int64_t ld_qkv, const float *out, int64_t ld_out, const float *d_out,
+                               int64_t ld_do, float *d_qkv, int64_t ld_dqkv, int64_t B, int32_t H, int32_t hd, int32_t T,
+                               float scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -246,7 +246,7 @@ SYMBOLS = [
     ("mdt_op_swiglu_fwd", _I32, [_VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_swiglu_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_attn_mid_fwd", _I32, [_VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),
-    ("mdt_op_attn_mid_bwd", _I32, [_VP, _I64, _VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),
+    ("mdt_op_attn_mid_bwd", _I32, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),
     ("mdt_op_infonce_scratch", _I64, [_I64, _I64]),
     ("mdt_op_infonce", _I32, [C.POINTER(InfoNCEArgs), _VP]),
 ]

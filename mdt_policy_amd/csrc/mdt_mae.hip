@@ -2,9 +2,10 @@
 // self-attention over ~100 tokens with its backward, and the exported RMSNorm / SwishGLU row ops.
 //
 // The attention of the shipped decoder is 102 tokens x 8 heads of 24 (masked_transformer_decoder.py:68-121 builds
-// voltron Blocks of d = 192): 2 % of the head's FLOPs next to its Linears, and the f32-input MFMA runs at the f32 vector
-// rate on gfx950, so these are register-blocked VALU kernels over LDS-resident q / k / v: one workgroup per (sample, head),
-// 4 x 4 score blocks per thread (8 x 16-byte LDS reads per 64 FMAs), scores kept in LDS (rows padded to 16-byte multiples).
+// voltron Blocks of d = 192).  One workgroup of 8 waves per (sample, head) keeps q / k / v (and dO, O) and the T x T scores
+// in LDS; every product is 16 x 16 x 4 f32 MFMA tiles over those LDS operands (16-byte fragment reads, see below), the row
+// softmax in between is VALU work on 16 lanes per row.  (Round 2 started with 4 x 4 register-blocked VALU products: they
+// were LDS-bandwidth bound at 1 flop per byte read; the MFMA tiles need a quarter of that.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -15,15 +16,25 @@ namespace {
 
 constexpr int TMAX = 128;
 
-__device__ __forceinline__ int score_stride(int T) { return ((T + 3) & ~3) + 4; }  // floats; rows 16-byte aligned
+#ifdef MDT_DEBUG_TIMING
+// tuning-only build: thread 0 of workgroup (0, 0) stamps the shader clock at its phase boundaries (mdt_mae_debug_ts)
+__device__ unsigned long long g_mae_ts[16];
+#define MAE_TS(i) if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_mae_ts[i] = __builtin_readcyclecounter();
+#else
+#define MAE_TS(i)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// rows [0, T) of NB (T, HD) head slices: global (row stride ld[b]) -> LDS (row stride HD + 4, buffers T4 * (HD + 4) floats
-// apart); rows T .. T4-1 are zeroed.  All loads of a sweep (4 per buffer and thread) are requested from clamped addresses
-// before the first one is consumed -- a load behind a branch costs one memory round trip each.
+__device__ __forceinline__ int score_stride(int T) { return ((T + 15) & ~15) + 4; }  // floats: 4 (mod 8), >= ceil16(T)
+
+// rows [0, T) of NB (T, HD) head slices: global (row stride ld[b]) -> LDS (row stride HD + 4, buffers T16 * (HD + 4) floats
+// apart, T16 = ceil16(T)); rows T .. T16-1 are zeroed (reduction padding of the MFMA products).  All loads of a sweep (4 per
+// buffer and thread) are requested from clamped addresses before the first one is consumed -- a load behind a branch costs
+// one memory round trip each.
 template <int HD, int NT, int NB>
 __device__ __forceinline__ void load_rows(const float* const (&src)[NB], const int64_t (&ld)[NB], float* dst, int T, int tid) {
     constexpr int H4 = HD / 4, ST = HD + 4, U = 4;
-    const int T4 = (T + 3) & ~3, n = T4 * H4;
+    const int T16 = (T + 15) & ~15, n = T16 * H4;
     for (int i0 = tid; i0 < n; i0 += NT * U) {
         f32x4 v[NB][U];
 #pragma unroll
@@ -38,75 +49,176 @@ __device__ __forceinline__ void load_rows(const float* const (&src)[NB], const i
             if (i < n) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    *(f32x4*)(dst + b * T4 * ST + t * ST + 4 * c) = t < T ? v[b][u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    *(f32x4*)(dst + b * T16 * ST + t * ST + 4 * c) = t < T ? v[b][u] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     }
 }
 
-// S[i][j] = alpha * a_i . b_j for i, j < T (rows of a / b in LDS, stride HD + 4); 4 x 4 blocks per thread, 64 FMAs per
-// 8 x 16-byte LDS reads.  The 16 lanes of an LDS access group form a 4 x 4 patch of blocks: 4 distinct a-rows and 4
-// distinct b-rows per access, whose start banks differ (row stride 4 * (HD + 4) floats) -- conflict free.
-// MODE 0: store;  MODE 1: S[i][j] = S[i][j] * (value - rowdot[i]) * alpha   (dS from P and dP, in place)
-template <int HD, int NT, int MODE>
-__device__ __forceinline__ void outer_blocks(const float* a, const float* b, float* S, int sstride, int T, float alpha,
-                                             const float* rowdot, int tid) {
-    constexpr int H4 = HD / 4, ST = HD + 4;
-    const int nb = (T + 3) >> 2, nt = (nb + 3) >> 2;
-    for (int it = tid; it < nt * nt * 16; it += NT) {
-        const int tile = it >> 4, l = it & 15;
-        const int ti = tile / nt, tj = tile - ti * nt;
-        const int bi = 4 * ti + (l >> 2), bj = 4 * tj + (l & 3);
-        if (bi >= nb || bj >= nb) continue;
-        float acc[4][4];
+// --- MFMA products over LDS-resident operands (v_mfma_f32_16x16x4_f32; 64 lanes = 16 rows/cols x 4 k-groups g) -----------
+// One instruction multiplies a 16 x 4 by a 4 x 16 panel; WHICH four reduction indices a step covers is free as long as both
+// operands agree, so a lane fetches FOUR CONSECUTIVE reduction elements with one 16-byte LDS read (element e of k-group g is
+// index 16 c + 4 g + e) and feeds them to four successive MFMAs -- a quarter of the LDS instructions of 4-byte fragment reads.
+// Row strides of 4 (mod 8) floats keep those reads conflict free (8 consecutive rows start in 8 different 16-byte bank groups).
+// Accumulator layout: acc[r] = C[4 g + r][lane % 16].
+
+// S[i][j] = alpha * a_i . b_j over HD (rows of a / b in LDS, stride HD + 4).  A work item is a PAIR of column tiles of one
+// row tile: the a-fragments are read once and feed two independent accumulator chains (a dependent MFMA waits for its
+// predecessor; two chains keep the pipe busy).  Items are dealt round-robin to the waves.
+// MODE 0: store;  MODE 1: S[i][j] = S[i][j] * (value - rowdot[i]) * alpha   (dS from P and dP, in place).
+// Rows i >= T are not written; columns T .. T16-1 of the written rows are set to zero (they are reduction padding later).
+template <int HD, int NW, int MODE>
+__device__ __forceinline__ void mma_scores(const float* a, const float* b, float* S, int ss, int T, float alpha,
+                                           const float* rowdot, int wave, int lane) {
+    constexpr int ST = HD + 4, C16 = HD / 16, REM8 = (HD % 16) == 8;
+    const int n = (T + 15) >> 4, np = (n + 1) >> 1, m = lane & 15, g = lane >> 4;
+    for (int item = wave; item < n * np; item += NW) {
+        const int ti = item / np, tj0 = 2 * (item - ti * np);
+        const bool two = tj0 + 1 < n;
+        const float* ap = a + (16 * ti + m) * ST + 4 * g;
+        const float* bp0 = b + (16 * tj0 + m) * ST + 4 * g;
+        const float* bp1 = bp0 + (two ? 16 * ST : 0);  // odd tile count: the second chain repeats the first (discarded)
+        f32x4 av[C16 + 1], bv0[C16 + 1], bv1[C16 + 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < C16; ++c) {
+            av[c] = *(const f32x4*)(ap + 16 * c); bv0[c] = *(const f32x4*)(bp0 + 16 * c); bv1[c] = *(const f32x4*)(bp1 + 16 * c);
+        }
+        f32x2 a2 = {0.f, 0.f}, b20 = {0.f, 0.f}, b21 = {0.f, 0.f};
+        if (REM8) {
+            a2 = *(const f32x2*)(ap - 4 * g + 16 * C16 + 2 * g);
+            b20 = *(const f32x2*)(bp0 - 4 * g + 16 * C16 + 2 * g);
+            b21 = *(const f32x2*)(bp1 - 4 * g + 16 * C16 + 2 * g);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
-        const float* ap = a + 4 * bi * ST;  // rows up to T4 - 1 exist (zero padded)
-        const float* bp = b + 4 * bj * ST;
+        for (int c = 0; c < C16; ++c)
 #pragma unroll
-        for (int c4 = 0; c4 < H4; ++c4) {
-            f32x4 av[4], bv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { av[r] = *(const f32x4*)(ap + r * ST + 4 * c4); bv[r] = *(const f32x4*)(bp + r * ST + 4 * c4); }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[r][c] = fmaf(av[r].x, bv[c].x, acc[r][c]); acc[r][c] = fmaf(av[r].y, bv[c].y, acc[r][c]);
-                    acc[r][c] = fmaf(av[r].z, bv[c].z, acc[r][c]); acc[r][c] = fmaf(av[r].w, bv[c].w, acc[r][c]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], bv0[c][e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], bv1[c][e], acc1, 0, 0, 0);
+            }
+        if (REM8) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b20.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b21.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b20.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b21.y, acc1, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * bi + r;
-            if (i < T) {
-                float* p = S + i * sstride + 4 * bj;
-                f32x4 o;
-                if (MODE == 0) {
-                    o = (f32x4){acc[r][0], acc[r][1], acc[r][2], acc[r][3]} * alpha;
-                } else {
-                    const f32x4 pv = *(const f32x4*)p;
-                    const float rd = rowdot[i];
-                    o = pv * ((f32x4){acc[r][0], acc[r][1], acc[r][2], acc[r][3]} - rd) * alpha;
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            const f32x4 acc = h ? acc1 : acc0;
+            const int j = 16 * (tj0 + h) + m;
+            float pv[4] = {0.f, 0.f, 0.f, 0.f}, rd[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = min(16 * ti + 4 * g + r, T - 1);
+                    pv[r] = S[i * ss + j]; rd[r] = rowdot[i];
                 }
-                // columns >= T stay zero (the padding is part of later reductions)
-                if (4 * bj + 1 > T - 1) o.y = 0.f;
-                if (4 * bj + 2 > T - 1) o.z = 0.f;
-                if (4 * bj + 3 > T - 1) o.w = 0.f;
-                *(f32x4*)p = o;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + 4 * g + r;
+                if (i < T) {
+                    const float o = MODE == 1 ? pv[r] * (acc[r] - rd[r]) * alpha : acc[r] * alpha;
+                    S[i * ss + j] = j < T ? o : 0.f;
+                }
             }
         }
     }
 }
 
-// rows of S (T x T, stride sstride) -> softmax in place; 16 lanes per row (4 rows per wave at a time), 8 columns per lane
+// One ROW tile (16 rows, all NC = ceil(HD / 16) column tiles; HD = 24: the second one half empty) of
+// C[i][c] = sum_k W(i, k) * x[k][c]  (i < T, c < HD) with W(i, k) = S[i][k] (TRANS = false) or S[k][i] (TRANS = true).
+// The reduction runs over T16 = ceil16(T) indices: S is zero there (rows AND columns) and the rows of x are zero padded.
+// The W fragment of a 16-index chunk is read once and feeds NC independent accumulator chains; the next chunk's fragments
+// are requested before the current chunk's MFMAs issue.  dst: LDS (stride HD + 4) or global (stride ldd).
+template <int HD, bool TRANS>
+__device__ __forceinline__ void mma_rows_tile(const float* S, int ss, const float* x, float* dst, int64_t ldd, int T, int ti,
+                                              int lane) {
+    constexpr int ST = HD + 4, NC = (HD + 15) / 16;
+    const int n = (T + 15) >> 4, m = lane & 15, g = lane >> 4;
+    f32x4 acc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* sp = TRANS ? S + (4 * g) * ss + 16 * ti + m : S + (16 * ti + m) * ss + 4 * g;
+    const float* xp = x + (4 * g) * ST + m;
+    auto load_w = [&](int c) -> f32x4 {
+        if (TRANS) { const float* q = sp + 16 * c * ss; return (f32x4){q[0], q[ss], q[2 * ss], q[3 * ss]}; }
+        return *(const f32x4*)(sp + 16 * c);
+    };
+    auto load_x = [&](int c, int q) -> f32x4 {
+        const float* r = xp + 16 * c * ST + 16 * q;
+        return (f32x4){r[0], r[ST], r[2 * ST], r[3 * ST]};
+    };
+    f32x4 w = load_w(0), xv[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) xv[q] = load_x(0, q);
+    for (int c = 0; c < n; ++c) {
+        const int cn = min(c + 1, n - 1);
+        const f32x4 wn = load_w(cn);
+        f32x4 xn[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) xn[q] = load_x(cn, q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], xv[q][e], acc[q], 0, 0, 0);
+        w = wn;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) xv[q] = xn[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int col = 16 * q + m;
+        if (col < HD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + 4 * g + r;
+                if (i < T) dst[(int64_t)i * ldd + col] = acc[q][r];
+            }
+        }
+    }
+}
+
+// two such products whose row tiles are dealt to the waves as one list (14 items over 8 waves for T = 102)
+template <int HD, int NW, bool TRANS0, bool TRANS1>
+__device__ __forceinline__ void mma_rows_pair(const float* S, int ss, const float* x0, float* dst0, int64_t ld0, const float* x1,
+                                              float* dst1, int64_t ld1, int T, int wave, int lane) {
+    const int n = (T + 15) >> 4;
+    for (int t = wave; t < 2 * n; t += NW) {
+        if (t < n) mma_rows_tile<HD, TRANS0>(S, ss, x0, dst0, ld0, T, t, lane);
+        else mma_rows_tile<HD, TRANS1>(S, ss, x1, dst1, ld1, T, t - n, lane);
+    }
+}
+
+// reductions over the 16 lanes that share g (= over the 16 columns a lane group holds of one row) as DPP lane swaps inside
+// the 16-lane row: xor 1, xor 2 (quad permutes), then the half-row and full-row mirrors -- no LDS crossbar round trips
+template <int CTRL>
+__device__ __forceinline__ float dpp_swap(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp_swap<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_swap<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_swap<0x141>(v));  // row_half_mirror
+    return fmaxf(v, dpp_swap<0x140>(v));  // row_mirror
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp_swap<0xB1>(v);
+    v += dpp_swap<0x4E>(v);
+    v += dpp_swap<0x141>(v);
+    return v + dpp_swap<0x140>(v);
+}
+
+// rows of S (T x T, stride sstride) -> softmax in place; 16 lanes per row (4 rows per wave at a time), 8 columns per lane.
+// The scores arrive multiplied by log2(e) (folded into the caller's scale): exp(x - max) = 2^(x' - max').
 template <int NT>
 __device__ __forceinline__ void softmax_rows(float* S, int sstride, int T, int tid) {
     const int l16 = tid & 15, grp = tid >> 4;
-    for (int i = grp; i < T; i += NT / 16) {
-        float* row = S + i * sstride;
+    for (int i0 = 0; i0 < T; i0 += NT / 16) {
+        const int i = i0 + grp;
+        float* row = S + min(i, T - 1) * sstride;  // whole wave stays converged for the DPP reductions
         float x[8];
         float mx = -INFINITY;
 #pragma unroll
@@ -115,55 +227,18 @@ __device__ __forceinline__ void softmax_rows(float* S, int sstride, int T, int t
             x[u] = j < T ? row[j] : -INFINITY;
             mx = fmaxf(mx, x[u]);
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mx = group_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { x[u] = expf(x[u] - mx); sum += x[u]; }  // exp(-inf) = 0 for the padding
+        for (int u = 0; u < 8; ++u) { x[u] = __builtin_amdgcn_exp2f(x[u] - mx); sum += x[u]; }  // 2^(-inf) = 0 for the padding
+        const float inv = 1.0f / group_sum(sum);
+        if (i < T) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = l16 + 16 * u;
-            if (j < T) row[j] = x[u] * inv;
-        }
-    }
-}
-
-// out[r][:] = sum_k W(r, k) * x[k][:]   with W(r, k) = S[r][k] (TRANS = false) or S[k][r] (TRANS = true); 4 output rows x
-// one float4 column per thread, the reduction walked 4 at a time: 8 x 16-byte LDS reads per 64 FMAs.  S and x are zero
-// padded to a multiple of 4 rows / columns.  dst: LDS (stride HD + 4) or global (stride ldd).
-template <int HD, int NT, bool TRANS>
-__device__ __forceinline__ void weighted_rows(const float* S, int sstride, const float* x, float* dst, int64_t ldd, int T, int tid) {
-    constexpr int H4 = HD / 4, ST = HD + 4;
-    const int nb = (T + 3) >> 2;
-    for (int it = tid; it < nb * H4; it += NT) {
-        const int rb = it / H4, c4 = it - rb * H4;
-        f32x4 acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kb = 0; kb < nb; ++kb) {
-            f32x4 w[4], xv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // !TRANS: w[q] = S[4 rb + q][4 kb .. +3] (row of the output block);  TRANS: w[q] = S[4 kb + q][4 rb .. +3]
-                w[q] = *(const f32x4*)(S + (TRANS ? (4 * kb + q) * sstride + 4 * rb : (4 * rb + q) * sstride + 4 * kb));
-                xv[q] = *(const f32x4*)(x + (4 * kb + q) * ST + 4 * c4);
-            }
-            if (TRANS) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[0] += w[q].x * xv[q]; acc[1] += w[q].y * xv[q]; acc[2] += w[q].z * xv[q]; acc[3] += w[q].w * xv[q];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] += w[r].x * xv[0] + w[r].y * xv[1] + w[r].z * xv[2] + w[r].w * xv[3];
+            for (int u = 0; u < 8; ++u) {
+                const int j = l16 + 16 * u;
+                if (j < T) row[j] = x[u] * inv;
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * rb + r < T) *(f32x4*)(dst + (int64_t)(4 * rb + r) * ldd + 4 * c4) = acc[r];
     }
 }
 
@@ -172,81 +247,167 @@ __device__ __forceinline__ void zero_lds(float* p, int n, int tid) {
     for (int i = tid; i < (n >> 2); i += NT) *(f32x4*)(p + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+// 16 score rows of row tile ti against all T16 key columns, entirely in registers: acc[tj][r] = q_{16 ti + 4 g + r} . k_{16 tj + m}
+// (NTJ = 8 column tiles cover T <= 128; tiles tj >= n are skipped by a wave-uniform branch).
+template <int HD, int NTJ>
+__device__ __forceinline__ void score_row_tile(const float* a_rows, const float* b, int n, int lane, f32x4 (&acc)[NTJ]) {
+    constexpr int ST = HD + 4, C16 = HD / 16, REM8 = (HD % 16) == 8;
+    const int m = lane & 15, g = lane >> 4;
+    const float* ap = a_rows + m * ST + 4 * g;
+    f32x4 av[C16 + 1];
+#pragma unroll
+    for (int c = 0; c < C16; ++c) av[c] = *(const f32x4*)(ap + 16 * c);
+    f32x2 a2 = {0.f, 0.f};
+    if (REM8) a2 = *(const f32x2*)(a_rows + m * ST + 16 * C16 + 2 * g);
+#pragma unroll
+    for (int tj = 0; tj < NTJ; ++tj) {
+        acc[tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tj < n) {
+            const float* bp = b + (16 * tj + m) * ST;
+            f32x4 bv[C16 + 1];
+#pragma unroll
+            for (int c = 0; c < C16; ++c) bv[c] = *(const f32x4*)(bp + 4 * g + 16 * c);
+            f32x2 b2 = {0.f, 0.f};
+            if (REM8) b2 = *(const f32x2*)(bp + 16 * C16 + 2 * g);
+#pragma unroll
+            for (int c = 0; c < C16; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], bv[c][e], acc[tj], 0, 0, 0);
+            if (REM8) {
+                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc[tj], 0, 0, 0);
+                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc[tj], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Forward: every wave owns whole ROW tiles of one (sample, head): scores of its 16 rows against all keys stay in the MFMA
+// accumulators, the row softmax runs on them in registers (a row's 16 x n columns sit in one 16-lane group), the
+// probabilities pass through a wave-private 16 x T16 LDS tile only to change from accumulator to operand layout, and P V
+// follows at once -- no workgroup barrier after the q / k / v load, no T x T score matrix in LDS (67 KB per workgroup for
+// T = 102, hd = 24: two workgroups per CU, one loading while the other computes).
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_mid_fwd(const float* __restrict__ qkv, int64_t ld, float* __restrict__ out, int64_t ldo,
                                                       int H, int T, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NT = 256, ST = HD + 4;
-    const int tid = threadIdx.x, b = blockIdx.x, h = blockIdx.y, D = H * HD;
-    const int T4 = (T + 3) & ~3, ss = score_stride(T);
+    constexpr int NT = 256, NW = NT / 64, ST = HD + 4, NTJ = TMAX / 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x, h = blockIdx.y, D = H * HD;
+    const int T16 = (T + 15) & ~15, n = T16 >> 4, ss = score_stride(T), m = lane & 15, g = lane >> 4;
     float* qs = lds;
-    float* ks = qs + T4 * ST;
-    float* vs = ks + T4 * ST;
-    float* S = vs + T4 * ST;
+    float* ks = qs + T16 * ST;
+    float* vs = ks + T16 * ST;
+    float* ptile = vs + T16 * ST + wave * 16 * ss;  // this wave's 16 x T16 probabilities
     const float* base = qkv + (int64_t)b * T * ld + h * HD;
-    zero_lds<NT>(S, T4 * ss, tid);
+    MAE_TS(0)
     {
         const float* const src[3] = {base, base + D, base + 2 * D};
         const int64_t lds_[3] = {ld, ld, ld};
         load_rows<HD, NT, 3>(src, lds_, qs, T, tid);  // q | k | v are consecutive LDS buffers
     }
     __syncthreads();
-    outer_blocks<HD, NT, 0>(qs, ks, S, ss, T, scale, nullptr, tid);
-    __syncthreads();
-    softmax_rows<NT>(S, ss, T, tid);
-    __syncthreads();
-    weighted_rows<HD, NT, false>(S, ss, vs, out + (int64_t)b * T * ldo + h * HD, ldo, T, tid);
+    MAE_TS(1)
+    float* o = out + (int64_t)b * T * ldo + h * HD;
+    const float sl2 = scale * 1.44269504088896341f;  // softmax in base 2: exp(s x) = 2^(s x log2 e)
+    for (int ti = wave; ti < n; ti += NW) {
+        f32x4 acc[NTJ];
+        score_row_tile<HD, NTJ>(qs + 16 * ti * ST, ks, n, lane, acc);
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            if (tj < n) {
+                const bool live = 16 * tj + m < T;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[tj][r] = live ? acc[tj][r] * sl2 : -INFINITY;
+                    mx[r] = fmaxf(mx[r], acc[tj][r]);
+                }
+            }
+        }
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = group_max(mx[r]);
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            if (tj < n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[tj][r] = __builtin_amdgcn_exp2f(acc[tj][r] - mx[r]);  // 2^(-inf) = 0 for the padding
+                    sum[r] += acc[tj][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = 1.0f / group_sum(sum[r]);
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            if (tj < n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ptile[(4 * g + r) * ss + 16 * tj + m] = acc[tj][r] * sum[r];
+            }
+        }
+        // O rows of this tile = P V; the tile sits at row 0 of ptile: shift the base so that row 16 ti + m lands there
+        mma_rows_tile<HD, false>(ptile - 16 * ti * ss, ss, vs, o, ldo, T, ti, lane);
+    }
+    MAE_TS(4)
 }
 
+// Backward.  The forward output O arrives from the caller (autograd keeps it: it is the input of the projection that
+// follows), so sum_j P_ij dP_ij = dO_i . O_i needs no second P V product here.
 template <int HD>
-__global__ __launch_bounds__(512) void k_attn_mid_bwd(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ d_out,
-                                                      int64_t ldd, float* __restrict__ d_qkv, int64_t ldg, int H, int T, float scale) {
+__global__ __launch_bounds__(512) void k_attn_mid_bwd(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ fwd_out,
+                                                      int64_t ldf, const float* __restrict__ d_out, int64_t ldd,
+                                                      float* __restrict__ d_qkv, int64_t ldg, int H, int T, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NT = 512, ST = HD + 4;
-    const int tid = threadIdx.x, b = blockIdx.x, h = blockIdx.y, D = H * HD;
-    const int T4 = (T + 3) & ~3, ss = score_stride(T);
+    constexpr int NT = 512, NW = NT / 64, ST = HD + 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x, h = blockIdx.y, D = H * HD;
+    const int T16 = (T + 15) & ~15, n = T16 >> 4, ss = score_stride(T);
     float* qs = lds;
-    float* ks = qs + T4 * ST;
-    float* vs = ks + T4 * ST;
-    float* dos = vs + T4 * ST;
-    float* os = dos + T4 * ST;
-    float* S = os + T4 * ST;
-    float* rowdot = S + T4 * ss;
+    float* ks = qs + T16 * ST;
+    float* vs = ks + T16 * ST;
+    float* dos = vs + T16 * ST;
+    float* os = dos + T16 * ST;
+    float* S = os + T16 * ST;
+    float* rowdot = S + T16 * ss;
     const float* base = qkv + (int64_t)b * T * ld + h * HD;
-    zero_lds<NT>(S, T4 * ss, tid);
+    MAE_TS(5)
+    zero_lds<NT>(S, T16 * ss, tid);
     {
-        const float* const src[4] = {base, base + D, base + 2 * D, d_out + (int64_t)b * T * ldd + h * HD};
-        const int64_t lds_[4] = {ld, ld, ld, ldd};
-        load_rows<HD, NT, 4>(src, lds_, qs, T, tid);  // q | k | v | dO are consecutive LDS buffers
+        const float* const src[5] = {base, base + D, base + 2 * D, d_out + (int64_t)b * T * ldd + h * HD,
+                                     fwd_out + (int64_t)b * T * ldf + h * HD};
+        const int64_t lds_[5] = {ld, ld, ld, ldd, ldf};
+        load_rows<HD, NT, 5>(src, lds_, qs, T, tid);  // q | k | v | dO | O are consecutive LDS buffers
     }
     __syncthreads();
-    outer_blocks<HD, NT, 0>(qs, ks, S, ss, T, scale, nullptr, tid);
-    __syncthreads();
-    softmax_rows<NT>(S, ss, T, tid);  // S = P
-    __syncthreads();
-    // the row products have (T / 4) * (HD / 4) items (156 for T = 102, HD = 24): the two that share an input run side by
-    // side on the two halves of the workgroup
-    float* g = d_qkv + (int64_t)b * T * ldg + h * HD;
-    if (tid < 256) weighted_rows<HD, 256, false>(S, ss, vs, os, ST, T, tid);            // O = P V (the forward output, recomputed)
-    else weighted_rows<HD, 256, true>(S, ss, dos, g + 2 * D, ldg, T, tid - 256);        // dV = P^T dO (before P is overwritten)
-    __syncthreads();
-    // sum_j P_ij dP_ij = dO_i . O_i
-    for (int i = tid; i < T; i += NT) {
+    MAE_TS(6)
+    for (int i = tid; i < T; i += NT) {  // read again only after three more barriers
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < HD; ++c) acc = fmaf(dos[i * ST + c], os[i * ST + c], acc);
         rowdot[i] = acc;
     }
+    mma_scores<HD, NW, 0>(qs, ks, S, ss, T, scale * 1.44269504088896341f, nullptr, wave, lane);  // base-2 softmax
     __syncthreads();
-    outer_blocks<HD, NT, 1>(dos, vs, S, ss, T, scale, rowdot, tid);  // S = scale * P * (dO v^T - rowdot)
+    MAE_TS(7)
+    softmax_rows<NT>(S, ss, T, tid);  // S = P
     __syncthreads();
-    if (tid < 256) weighted_rows<HD, 256, false>(S, ss, ks, g, ldg, T, tid);            // dQ = dS K
-    else weighted_rows<HD, 256, true>(S, ss, qs, g + D, ldg, T, tid - 256);             // dK = dS^T Q
+    MAE_TS(8)
+    float* g = d_qkv + (int64_t)b * T * ldg + h * HD;
+    for (int t = wave; t < n; t += NW) mma_rows_tile<HD, true>(S, ss, dos, g + 2 * D, ldg, T, t, lane);  // dV = P^T dO (before P is overwritten)
+    __syncthreads();
+    MAE_TS(9)
+    MAE_TS(10)
+    mma_scores<HD, NW, 1>(dos, vs, S, ss, T, scale, rowdot, wave, lane);  // S = scale * P * (dO v^T - rowdot)
+    __syncthreads();
+    MAE_TS(11)
+    // dQ = dS K and dK = dS^T Q
+    mma_rows_pair<HD, NW, false, true>(S, ss, ks, g, ldg, qs, g + D, ldg, T, wave, lane);
+    MAE_TS(12)
 }
 
 size_t attn_mid_lds(int hd, int T, bool bwd) {
-    const int T4 = (T + 3) & ~3, ss = T4 + 4;
-    return ((size_t)(bwd ? 5 : 3) * T4 * (hd + 4) + (size_t)T4 * ss + (bwd ? TMAX : 0)) * sizeof(float);
+    const int T16 = (T + 15) & ~15, ss = T16 + 4;
+    if (!bwd) return ((size_t)3 * T16 * (hd + 4) + (size_t)4 * 16 * ss + 16) * sizeof(float);  // q k v + 4 waves' P tiles
+    return ((size_t)5 * T16 * (hd + 4) + (size_t)T16 * ss + TMAX + 16) * sizeof(float);
 }
 
 template <int HD>
@@ -258,18 +419,25 @@ hipError_t launch_fwd(const float* qkv, int64_t ld, float* out, int64_t ldo, int
     return hipGetLastError();
 }
 template <int HD>
-hipError_t launch_bwd(const float* qkv, int64_t ld, const float* d_out, int64_t ldd, float* d_qkv, int64_t ldg, int64_t B, int H, int T,
-                      float scale, hipStream_t s) {
+hipError_t launch_bwd(const float* qkv, int64_t ld, const float* fo, int64_t ldf, const float* d_out, int64_t ldd, float* d_qkv,
+                      int64_t ldg, int64_t B, int H, int T, float scale, hipStream_t s) {
     const size_t lds = attn_mid_lds(HD, T, true);
     hipError_t e = hipFuncSetAttribute((const void*)k_attn_mid_bwd<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_attn_mid_bwd<HD>), dim3((unsigned)B, H), dim3(512), lds, s, qkv, ld, d_out, ldd, d_qkv, ldg, H, T, scale);
+    hipLaunchKernelGGL((k_attn_mid_bwd<HD>), dim3((unsigned)B, H), dim3(512), lds, s, qkv, ld, fo, ldf, d_out, ldd, d_qkv, ldg, H, T,
+                       scale);
     return hipGetLastError();
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+#ifdef MDT_DEBUG_TIMING
+extern "C" int mdt_mae_debug_ts(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mae_ts), 16 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" mdt_status mdt_op_attn_mid_fwd(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, int64_t B, int32_t H, int32_t hd,
                                           int32_t T, float scale, void* stream) {
@@ -290,20 +458,23 @@ extern "C" mdt_status mdt_op_attn_mid_fwd(const float* qkv, int64_t ld_qkv, floa
     return MDT_OK;
 }
 
-extern "C" mdt_status mdt_op_attn_mid_bwd(const float* qkv, int64_t ld_qkv, const float* d_out, int64_t ld_do, float* d_qkv,
-                                          int64_t ld_dqkv, int64_t B, int32_t H, int32_t hd, int32_t T, float scale, void* stream) {
-    if (!qkv || !d_out || !d_qkv || B < 1 || H < 1 || T < 1) return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_mid_bwd: bad argument");
+extern "C" mdt_status mdt_op_attn_mid_bwd(const float* qkv, int64_t ld_qkv, const float* out, int64_t ld_out, const float* d_out,
+                                          int64_t ld_do, float* d_qkv, int64_t ld_dqkv, int64_t B, int32_t H, int32_t hd, int32_t T,
+                                          float scale, void* stream) {
+    if (!qkv || !out || !d_out || !d_qkv || B < 1 || H < 1 || T < 1)
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_mid_bwd: bad argument");
     if (T > TMAX) return mdt_fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_mid_bwd: T must be <= %d", TMAX);
-    if (!aligned16(qkv) || !aligned16(d_out) || !aligned16(d_qkv) || ld_qkv % 4 || ld_do % 4 || ld_dqkv % 4)
+    if (!aligned16(qkv) || !aligned16(out) || !aligned16(d_out) || !aligned16(d_qkv) || ld_qkv % 4 || ld_out % 4 || ld_do % 4 ||
+        ld_dqkv % 4)
         return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_mid_bwd: pointers 16-byte aligned, strides multiples of 4");
     if (attn_mid_lds(hd, T, true) > 160 * 1024) return mdt_fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_mid_bwd: (T, hd) does not fit LDS");
     hipStream_t s = (hipStream_t)stream;
     switch (hd) {
-        case 16: LAUNCH(launch_bwd<16>(qkv, ld_qkv, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
-        case 24: LAUNCH(launch_bwd<24>(qkv, ld_qkv, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
-        case 32: LAUNCH(launch_bwd<32>(qkv, ld_qkv, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
-        case 48: LAUNCH(launch_bwd<48>(qkv, ld_qkv, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
-        case 64: LAUNCH(launch_bwd<64>(qkv, ld_qkv, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
+        case 16: LAUNCH(launch_bwd<16>(qkv, ld_qkv, out, ld_out, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
+        case 24: LAUNCH(launch_bwd<24>(qkv, ld_qkv, out, ld_out, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
+        case 32: LAUNCH(launch_bwd<32>(qkv, ld_qkv, out, ld_out, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
+        case 48: LAUNCH(launch_bwd<48>(qkv, ld_qkv, out, ld_out, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
+        case 64: LAUNCH(launch_bwd<64>(qkv, ld_qkv, out, ld_out, d_out, ld_do, d_qkv, ld_dqkv, B, H, T, scale, s)); break;
         default: return mdt_fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_mid_bwd: head dim %d (supported 16/24/32/48/64)", hd);
     }
     return MDT_OK;

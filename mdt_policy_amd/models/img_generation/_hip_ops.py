@@ -172,19 +172,19 @@ class HipSelfAttention(torch.autograd.Function):
         q = _c(qkv)
         out = torch.empty((B, T, D), device=q.device, dtype=torch.float32)
         _lib.check(lib.mdt_op_attn_mid_fwd(q.data_ptr(), D3, out.data_ptr(), D, B, n_heads, D // n_heads, T, float(scale), _stream(q)))
-        ctx.save_for_backward(q)
+        ctx.save_for_backward(q, out)  # the output is kept anyway (input of the projection that follows)
         ctx.cfg = (n_heads, float(scale))
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
-        (q,) = ctx.saved_tensors
+        q, out = ctx.saved_tensors
         n_heads, scale = ctx.cfg
         B, T, D3 = q.shape
         D = D3 // 3
         d = _c(d_out)
         dq = torch.empty_like(q)
-        _lib.check(lib.mdt_op_attn_mid_bwd(q.data_ptr(), D3, d.data_ptr(), D, dq.data_ptr(), D3, B, n_heads, D // n_heads, T, scale,
-                                           _stream(d)))
+        _lib.check(lib.mdt_op_attn_mid_bwd(q.data_ptr(), D3, out.data_ptr(), D, d.data_ptr(), D, dq.data_ptr(), D3, B, n_heads,
+                                           D // n_heads, T, scale, _stream(d)))
         return dq, None, None

@@ -84,7 +84,7 @@ def _s():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,H,hd,T", [(3, 8, 24, 102), (2, 4, 16, 36), (1, 2, 64, 64), (2, 2, 32, 100), (2, 3, 32, 17), (5, 8, 48, 7), (2, 2, 24, 1)])
+@pytest.mark.parametrize("B,H,hd,T", [(3, 8, 24, 102), (2, 4, 16, 36), (1, 2, 64, 64), (2, 2, 32, 100), (2, 3, 32, 17), (5, 8, 48, 7), (2, 2, 24, 1), (2, 2, 16, 128), (1, 3, 24, 113)])
 def test_attention_mid_forward_and_backward(B, H, hd, T):
     L, lib = _lib()
     D = H * hd
@@ -99,7 +99,8 @@ def test_attention_mid_forward_and_backward(B, H, hd, T):
     L.check(lib.mdt_op_attn_mid_fwd(qd.data_ptr(), 3 * D, out.data_ptr(), D, B, H, hd, T, hd ** -0.5, _s()))
     assert_close(out.cpu(), ref.detach(), what="attention output")
     dq = torch.full((B, T, 3 * D), float("nan"), device="cuda")
-    L.check(lib.mdt_op_attn_mid_bwd(qd.data_ptr(), 3 * D, dod.data_ptr(), D, dq.data_ptr(), 3 * D, B, H, hd, T, hd ** -0.5, _s()))
+    L.check(lib.mdt_op_attn_mid_bwd(qd.data_ptr(), 3 * D, out.data_ptr(), D, dod.data_ptr(), D, dq.data_ptr(), 3 * D, B, H, hd, T,
+                                    hd ** -0.5, _s()))
     assert_close(dq.cpu(), q64.grad, rtol=1e-3, atol=1e-4, what="d_qkv")
 
 
