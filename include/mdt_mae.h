@@ -35,6 +35,15 @@ mdt_status mdt_op_rms_bwd(const float *x, const float *g, const float *dy, float
 mdt_status mdt_op_swiglu_fwd(const float *u, float *out, int64_t M, int32_t H, void *stream);
 mdt_status mdt_op_swiglu_bwd(const float *u, const float *d_out, float *du, int64_t M, int32_t H, void *stream);
 
+/* voltron LayerScale on a residual branch (Block.forward: x + layer_scale(branch)): out = x + gamma * z, rows of D (a multiple
+ * of 4, <= 1024); and the branch's backward: dz = gamma * g, dgamma = sum_rows g * z (overwritten).  scratch:
+ * mdt_op_scale_residual_bwd_scratch(M, D) floats. */
+mdt_status mdt_op_scale_residual_fwd(const float *x, const float *z, const float *gamma, float *out, int64_t M, int32_t D,
+                                     void *stream);
+int64_t mdt_op_scale_residual_bwd_scratch(int64_t M, int32_t D);
+mdt_status mdt_op_scale_residual_bwd(const float *g, const float *z, const float *gamma, float *dz, float *dgamma, int64_t M,
+                                     int32_t D, float *scratch, void *stream);
+
 /* Unmasked multi-head self-attention over T <= 128 tokens (voltron Attention.forward):
  *   qkv (B*T, 3*H*hd) = q | k | v column blocks (row stride ld_qkv), head h at columns h*hd;
  *   out (B*T, H*hd) = softmax(q k^T * scale) v.   hd in {16, 24, 32, 48, 64}.  One workgroup per (sample, head). */

@@ -431,6 +431,43 @@ hipError_t launch_bwd(const float* qkv, int64_t ld, const float* fo, int64_t ldf
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// LayerScale + residual: out = x + gamma * z over rows of D (voltron Block: x + layer_scale(branch(x))); one 16-byte column
+// group per thread, the row loop strided by the rows a workgroup holds at once.
+__global__ __launch_bounds__(256) void k_scale_residual_fwd(const float* __restrict__ x, const float* __restrict__ z,
+                                                            const float* __restrict__ gamma, float* __restrict__ out, int64_t n4,
+                                                            int D4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 g = ((const f32x4*)gamma)[i % D4];
+    ((f32x4*)out)[i] = ((const f32x4*)x)[i] + g * ((const f32x4*)z)[i];
+}
+
+// backward of the branch: dz = gamma * g, and the partial sums of dgamma = sum_rows g * z over this workgroup's row slice
+// (part[slice][D], added up by k_colsum).  256 threads = RL row lanes x D4 column groups.
+constexpr int SR_ROWS = 64;  // rows per workgroup
+__global__ __launch_bounds__(256) void k_scale_residual_bwd(const float* __restrict__ g, const float* __restrict__ z,
+                                                            const float* __restrict__ gamma, float* __restrict__ dz,
+                                                            float* __restrict__ part, int64_t M, int D4) {
+    __shared__ f32x4 red[256];
+    const int RL = 256 / D4, c = threadIdx.x % D4, rl = threadIdx.x / D4;
+    const int64_t r0 = (int64_t)blockIdx.x * SR_ROWS, r1 = min(r0 + SR_ROWS, M);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (rl < RL) {
+        const f32x4 gm = ((const f32x4*)gamma)[c];
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            const f32x4 gv = ((const f32x4*)g)[r * D4 + c], zv = ((const f32x4*)z)[r * D4 + c];
+            ((f32x4*)dz)[r * D4 + c] = gm * gv;
+            acc += gv * zv;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int q = 1; q < RL; ++q) acc += red[q * D4 + c];
+        ((f32x4*)part)[(int64_t)blockIdx.x * D4 + c] = acc;
+    }
+}
+
 }  // namespace
 
 #ifdef MDT_DEBUG_TIMING
@@ -495,6 +532,35 @@ extern "C" mdt_status mdt_op_rms_bwd(const float* x, const float* g, const float
     hipStream_t s = (hipStream_t)stream;
     LAUNCH(mdt_launch_rms_bwd(x, g, dy, dx, accumulate_dx, scratch, M, D, eps, s));
     if (dg) LAUNCH(mdt_launch_colsum(scratch, D, (int)((M + 3) / 4), D, dg, accumulate_dg, s));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_scale_residual_fwd(const float* x, const float* z, const float* gamma, float* out, int64_t M, int32_t D,
+                                                void* stream) {
+    if (!x || !z || !gamma || !out || M < 1 || D < 4 || D % 4 || D > 1024)
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_fwd: bad argument (D a multiple of 4, <= 1024)");
+    if (!aligned16(x) || !aligned16(z) || !aligned16(gamma) || !aligned16(out))
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_fwd: pointers must be 16-byte aligned");
+    const int64_t n4 = M * (D / 4);
+    hipLaunchKernelGGL(k_scale_residual_fwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, z, gamma, out,
+                       n4, D / 4);
+    LAUNCH(hipGetLastError());
+    return MDT_OK;
+}
+
+extern "C" int64_t mdt_op_scale_residual_bwd_scratch(int64_t M, int32_t D) { return ((M + SR_ROWS - 1) / SR_ROWS) * (int64_t)D; }
+
+extern "C" mdt_status mdt_op_scale_residual_bwd(const float* g, const float* z, const float* gamma, float* dz, float* dgamma,
+                                                int64_t M, int32_t D, float* scratch, void* stream) {
+    if (!g || !z || !gamma || !dz || !dgamma || !scratch || M < 1 || D < 4 || D % 4 || D > 1024)
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_bwd: bad argument (D a multiple of 4, <= 1024)");
+    if (!aligned16(g) || !aligned16(z) || !aligned16(gamma) || !aligned16(dz) || !aligned16(scratch))
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_bwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t slices = (M + SR_ROWS - 1) / SR_ROWS;
+    hipLaunchKernelGGL(k_scale_residual_bwd, dim3((unsigned)slices), dim3(256), 0, s, g, z, gamma, dz, scratch, M, D / 4);
+    LAUNCH(hipGetLastError());
+    LAUNCH(mdt_launch_colsum(scratch, D, (int)slices, D, dgamma, 0, s));
     return MDT_OK;
 }
 

@@ -161,6 +161,36 @@ class HipSwishGLU(torch.autograd.Function):
         return du.reshape(ctx.ushape)
 
 
+class HipScaleResidual(torch.autograd.Function):
+    """x + gamma * z (voltron LayerScale on a residual branch) in one pass; backward: dx = g, dz = gamma * g,
+    dgamma = sum_rows g * z in one more."""
+
+    @staticmethod
+    def forward(ctx, x, z, gamma):
+        lib = _lib.load()
+        D = x.shape[-1]
+        x2, z2, gm = _c(x).reshape(-1, D), _c(z).reshape(-1, D), _c(gamma)
+        out = torch.empty_like(x2)
+        _lib.check(lib.mdt_op_scale_residual_fwd(x2.data_ptr(), z2.data_ptr(), gm.data_ptr(), out.data_ptr(), x2.shape[0], D,
+                                                 _stream(x2)))
+        ctx.save_for_backward(z2, gm)
+        ctx.xshape = x.shape
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        z2, gm = ctx.saved_tensors
+        M, D = z2.shape
+        g2 = _c(g).reshape(M, D)
+        dz = torch.empty_like(z2)
+        dgamma = torch.empty_like(gm)
+        scratch = torch.empty(lib.mdt_op_scale_residual_bwd_scratch(M, D), device=g2.device, dtype=torch.float32)
+        _lib.check(lib.mdt_op_scale_residual_bwd(g2.data_ptr(), z2.data_ptr(), gm.data_ptr(), dz.data_ptr(), dgamma.data_ptr(), M, D,
+                                                 scratch.data_ptr(), _stream(g2)))
+        return g, dz.reshape(ctx.xshape), dgamma
+
+
 class HipSelfAttention(torch.autograd.Function):
     """qkv (B, T, 3 D) = q | k | v -> softmax(q k^T * scale) v (B, T, D), H heads, unmasked, T <= 128."""
 

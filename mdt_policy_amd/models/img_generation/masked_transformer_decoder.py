@@ -214,9 +214,9 @@ class MaskedTransformerImgDecoder(nn.Module):
         for blk in self.decoder_blocks:
             qkv = self._linear(ops.HipRMSNorm.apply(x, blk.pre_norm_attn.g), blk.attn.qkv)
             att = ops.HipSelfAttention.apply(qkv, blk.attn.n_heads, blk.attn.scale)
-            x = x + blk.layer_scale_attn.gamma * self._linear(att, blk.attn.proj)
+            x = ops.HipScaleResidual.apply(x, self._linear(att, blk.attn.proj), blk.layer_scale_attn.gamma)
             h = ops.HipSwishGLU.apply(self._linear(ops.HipRMSNorm.apply(x, blk.pre_norm_mlp.g), blk.mlp[0].project))
-            x = x + blk.layer_scale_mlp.gamma * self._linear(h, blk.mlp[1])
+            x = ops.HipScaleResidual.apply(x, self._linear(h, blk.mlp[1]), blk.layer_scale_mlp.gamma)
         x = ops.HipRMSNorm.apply(x, self.decoder_norm.g)
         rec = self._linear(x[:, context.shape[1]:], self.decoder_patch_prediction).reshape(B, X, n, -1)
         return rec, m, restore, vis.reshape(B, X * n_keep, d)

@@ -209,3 +209,23 @@ def test_hip_head_training_batch_against_the_oracle_on_gpu_fp64():
         if p.requires_grad:
             ref = P64[k].grad
             assert_close(p.grad.cpu(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()) + 1e-9, what=f"B=96 {k}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,D", [(306, 192), (5, 64), (4133, 384), (64, 1024)])
+def test_scale_residual_op(M, D):
+    """LayerScale on a residual branch, x + gamma * z, and its backward (dz, dgamma) against float64 torch."""
+    from mdt_policy_amd.models.img_generation import _hip_ops as ops
+    x = torch.from_numpy(synthetic.normal("sr_x", (M, D), 171)).cuda().requires_grad_()
+    z = torch.from_numpy(synthetic.normal("sr_z", (M, D), 172)).cuda().requires_grad_()
+    gamma = torch.from_numpy(synthetic.normal("sr_g", (D,), 173)).cuda().requires_grad_()
+    w = torch.from_numpy(synthetic.normal("sr_w", (M, D), 174))
+    out = ops.HipScaleResidual.apply(x, z, gamma)
+    (out * w.cuda()).sum().backward()
+    x64, z64, g64 = (t.detach().cpu().double().requires_grad_() for t in (x, z, gamma))
+    ref = x64 + g64 * z64
+    (ref * w.double()).sum().backward()
+    assert_close(out.detach().cpu(), ref.detach(), what="x + gamma z")
+    assert_close(x.grad.cpu(), x64.grad, what="dx")
+    assert_close(z.grad.cpu(), z64.grad, what="dz")
+    assert_close(gamma.grad.cpu(), g64.grad, rtol=1e-3, atol=1e-4 * float(g64.grad.abs().max()), what="dgamma")
