@@ -118,6 +118,16 @@ hipError_t mdt_launch_merge_fwd(const mdt_merge_args& a, hipStream_t s);
 hipError_t mdt_launch_merge_bwd(const mdt_merge_args& a, hipStream_t s);
 hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s);
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s);
+// a table of independent column sums run as one launch: dst[n] (+)= sum_m src[m * ld + n], m < M, n < N
+struct mdt_colsum_entry {
+    const float* src;
+    float* dst;
+    int64_t ld;
+    int32_t M, N, accumulate;
+};
+enum { MDT_COLSUM_TABLE = 80 };  // entries per launch (passed by value: 80 x 40 B of kernel arguments)
+struct mdt_colsum_table { mdt_colsum_entry e[MDT_COLSUM_TABLE]; };
+hipError_t mdt_launch_colsum_batched(const mdt_colsum_entry* entries, int n, hipStream_t s);
 hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s);
 hipError_t mdt_launch_loss_grad(const float* F, const float* act, const float* noised, const float* sigma, float sd,
                                 int64_t n, int per_sample, const float* gscale, float* dF, hipStream_t s);
@@ -142,7 +152,11 @@ hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream
 // dst[r][c] += src[r][c] for r < rows, c < cols (leading dimensions lds_ / ldd)
 hipError_t mdt_launch_add_2d(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int cols, hipStream_t s);
 // backward of a Linear through the forward GEMM kernel (mdt_train.hip); see mdt_linear_bwd_args
-mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s);
+// defer_bias (optional, with bias_space of at least 64 * N floats that stay valid until the caller runs the entry): the
+// per-slice bias partials are left in bias_space and *defer_bias describes their final column sum instead of launching it
+// (defer_bias->src == nullptr on return: the bias gradient was produced another way, nothing to run).
+mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsum_entry* defer_bias = nullptr,
+                          float* bias_space = nullptr);
 hipError_t mdt_launch_attention_long_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                                          const float* d_out, int64_t ld_do, float* dq, int64_t ld_dq, float* dk, float* dv,
                                          int64_t ld_dkv, int B, int H, int hd, int Tq, int Tk, float scale, hipStream_t s,

@@ -71,7 +71,35 @@ struct mdt_train_state {
     float* scratch = nullptr;
     int64_t scratch_cap = 0;  // batch capacity
     float *dx, *dxe, *t_d, *t_d2, *t_3d, *t_4d, *d_mod, *d_kvx, *pw, *pb, *narrow, *lin_scratch, *dF, *small;
+    // Small column sums of one backward (LayerNorm weight / bias partials, per-slice bias partials of the Linears) are
+    // collected here and run as ONE launch at the end (flush_deferred): their inputs live in defer_buf until then.
+    float* defer_buf = nullptr;
+    int64_t defer_cap = 0, defer_off = 0;  // floats
+    std::vector<mdt_colsum_entry> deferred;
 };
+
+static float* defer_take(mdt_train_state* ts, int64_t n) {
+    n = (n + 3) & ~(int64_t)3;
+    if (ts->defer_off + n > ts->defer_cap) return nullptr;
+    float* p = ts->defer_buf + ts->defer_off;
+    ts->defer_off += n;
+    return p;
+}
+
+static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    // entries of one launch run concurrently: two sums into the same gradient (a parameter read twice) go to successive launches
+    std::vector<mdt_colsum_entry>& d = ts->deferred;
+    size_t lo = 0;
+    for (size_t i = 0; i <= d.size(); ++i) {
+        bool cut = i == d.size();
+        for (size_t j = lo; !cut && j < i; ++j) cut = d[j].dst == d[i].dst;
+        if (cut && i > lo) { LAUNCH(mdt_launch_colsum_batched(d.data() + lo, (int)(i - lo), s)); lo = i; }
+    }
+    ts->deferred.clear();
+    ts->defer_off = 0;
+    return MDT_OK;
+}
 
 static const int NARROW_SLICES = 128;  // row slices of the narrow (A x D) weight gradients: 128 x 2 workgroups
 
@@ -240,6 +268,12 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
     ts->t_d = b.take(Mx * D); ts->t_d2 = b.take(Mx * D); ts->t_3d = b.take(Mx * 3 * D); ts->t_4d = b.take(Mx * 4 * D);
     ts->d_mod = b.take(B * m->Ld * 6 * D); ts->d_kvx = b.take(Me * m->Ld * 2 * D);
     ts->pw = b.take(B * D); ts->pb = b.take(B * D);
+    {   // deferred column sums: two partial tables per LayerNorm call, 64 slices of bias partials per Linear
+        int64_t widest = 4 * D;
+        for (const LinPart& p : m->parts) widest = std::max<int64_t>(widest, p.lin->N);
+        ts->defer_cap = (int64_t)(2 * m->Le + 3 * m->Ld + 2) * 2 * B * D + (int64_t)m->parts.size() * 64 * widest + 1024;
+        ts->defer_buf = b.take(ts->defer_cap);
+    }
     ts->narrow = b.take((size_t)NARROW_SLICES * 16 * std::max({D, m->HP, m->p_row >= 0 ? 2 * D : 0}));
     // Linear backward scratch: the largest need over every (rows, N, K) this model's backward runs
     int64_t need = 0;
@@ -590,7 +624,11 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     a.accumulate_dw = 1;
     a.Wt = l.wt; a.dX = dX; a.ldxo = ldxo; a.accumulate_dx = acc_dx;
     a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
-    return mdt_linear_bwd(a, s);
+    mdt_colsum_entry be;
+    float* space = a.dbias ? defer_take(ts, (int64_t)64 * l.N) : nullptr;
+    MDT_TRY(mdt_linear_bwd(a, s, space ? &be : nullptr, space));
+    if (space && be.src) ts->deferred.push_back(be);
+    return MDT_OK;
 }
 
 static int slot_of(const mdt_model* m, const float* dst) {
@@ -615,9 +653,19 @@ static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float
     a.dh = dh; a.ld_dh = m->D; a.dx = dx; a.accumulate = acc; a.d_mod = d_mod; a.d_mod_stride = modw;
     a.accumulate_dmod = acc_dmod;
     if (shift_off < 0 && scale_off < 0) { a.mod = nullptr; a.d_mod = nullptr; }
-    a.pw = ts->pw; a.pb = b ? ts->pb : nullptr; a.B = (int)B; a.rows_per_sample = T; a.D = m->D;
+    // per-sample partials of the weight / bias gradient: into the deferred area when their sums run at the end of the backward
+    float* pw = grads ? defer_take(ts, B * m->D) : nullptr;
+    float* pb = (grads && b) ? defer_take(ts, B * m->D) : nullptr;
+    const bool deferred = pw && (!b || pb);
+    a.pw = deferred ? pw : ts->pw; a.pb = b ? (deferred ? pb : ts->pb) : nullptr;
+    a.B = (int)B; a.rows_per_sample = T; a.D = m->D;
     LAUNCH(mdt_launch_ln_bwd(a, s));
     if (!grads) return MDT_OK;
+    if (deferred) {
+        ts->deferred.push_back(mdt_colsum_entry{pw, grad_of(m, grads, w), (int64_t)m->D, (int)B, m->D, 1});
+        if (b) ts->deferred.push_back(mdt_colsum_entry{pb, grad_of(m, grads, b), (int64_t)m->D, (int)B, m->D, 1});
+        return MDT_OK;
+    }
     if (b) LAUNCH(mdt_launch_colsum2(ts->pw, ts->pb, m->D, (int)B, m->D, grad_of(m, grads, w), grad_of(m, grads, b), 1, s));
     else LAUNCH(mdt_launch_colsum(ts->pw, m->D, (int)B, m->D, grad_of(m, grads, w), 1, s));
     return MDT_OK;
@@ -772,8 +820,10 @@ extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const
     hipStream_t s = (hipStream_t)stream;
     t->stream = s;
     MDT_TRY(reserve_scratch(m, t->B));
+    m->train->deferred.clear(); m->train->defer_off = 0;
     HIP_TRY(hipMemcpyAsync(m->train->dxe, g_ctx, (size_t)t->B * m->Te * m->D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return enc_bwd(m, *t, grads, d_tokens, d_tokens2, d_goal, s);
+    MDT_TRY(enc_bwd(m, *t, grads, d_tokens, d_tokens2, d_goal, s));
+    return flush_deferred(m, s);
 }
 
 static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s);
@@ -789,6 +839,7 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     t.stream = s;
     mdt_train_state* ts = m->train;
     MDT_TRY(reserve_scratch(m, t.B));
+    ts->deferred.clear(); ts->defer_off = 0;
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta, Me = B * m->Te;
     // ---- loss and action head: F = action_pred(ln(x_L))
@@ -797,7 +848,8 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     // ---- context: K|V projections of all blocks, plus whatever other losses hung onto latent_encoder_emb
     if (g_ctx) HIP_TRY(hipMemcpyAsync(ts->dxe, g_ctx, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     MDT_TRY(lin_bwd(m, grads, m->kv_all, t.ctx, D, ts->d_kvx, (int64_t)m->Ld * 2 * D, (int)Me, ts->dxe, D, g_ctx ? 1 : 0, s));
-    return enc_bwd(m, t, grads, d_tokens, d_tokens2, d_goal, s);
+    MDT_TRY(enc_bwd(m, t, grads, d_tokens, d_tokens2, d_goal, s));
+    return flush_deferred(m, s);
 }
 
 // Decoder backward from ts->dF = d(raw network output F) down to ts->dx = d(action embedding rows y0); the K|V gradient of

@@ -381,6 +381,51 @@ __global__ __launch_bounds__(256) void k_colsum2(const float* __restrict__ X0, c
         out[c] = accumulate ? out[c] + t : t;
     }
 }
+// many independent column sums in ONE launch (the training backward's small reductions -- LayerNorm weight / bias
+// partials of every block, per-slice bias partials of every Linear -- were ~60 launches of 6 workgroups per step, each a
+// serialized ~5 us): blockIdx.y = table entry, blockIdx.x = group of 32 columns, 8 row groups x 8 independent accumulators
+// per thread (64 rows in flight).  Rows are added in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void k_colsum_batched(mdt_colsum_table tab) {
+    __shared__ float part[8][32];
+    const mdt_colsum_entry e = tab.e[blockIdx.y];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    if (blockIdx.x * 32 >= e.N) return;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (c < e.N) {
+        int m = rg;
+        for (; m + 56 < e.M; m += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += e.src[(int64_t)(m + 8 * u) * e.ld + c];
+        }
+        for (; m < e.M; m += 8) acc[0] += e.src[(int64_t)m * e.ld + c];
+    }
+    part[rg][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (rg == 0 && c < e.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][cl];
+        e.dst[c] = e.accumulate ? e.dst[c] + t : t;
+    }
+}
+hipError_t mdt_launch_colsum_batched(const mdt_colsum_entry* entries, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += MDT_COLSUM_TABLE) {
+        mdt_colsum_table tab;
+        const int cnt = n - i0 < MDT_COLSUM_TABLE ? n - i0 : MDT_COLSUM_TABLE;
+        int gx = 1;
+        for (int i = 0; i < cnt; ++i) {
+            tab.e[i] = entries[i0 + i];
+            gx = gx > (entries[i0 + i].N + 31) / 32 ? gx : (entries[i0 + i].N + 31) / 32;
+        }
+        hipLaunchKernelGGL(k_colsum_batched, dim3(gx, cnt), dim3(256), 0, s, tab);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s);
 hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
                               int accumulate, hipStream_t s) {

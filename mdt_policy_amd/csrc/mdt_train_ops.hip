@@ -61,8 +61,9 @@ int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K) {
     return std::max<int64_t>((N + K) * Mp + (int64_t)S * N * K + N * (Mp / 32 + 2), (int64_t)St * N * K + (int64_t)St * N + 64);
 }
 
-mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
+mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsum_entry* defer_bias, float* bias_space) {
     if (a.M < 1 || a.N < 1 || a.K < 1 || (a.K % 16)) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: bad shape");
+    if (defer_bias) defer_bias->src = nullptr;
     // the bias gradient rides on the transpose the dW path needs anyway (per-32-row column partials)
     const bool bias_from_partials = a.dbias && a.dW && !(a.N % 16);
     if (a.dbias && !bias_from_partials) LAUNCH(mdt_launch_colsum(a.dY, a.ldy, a.M, a.N, a.dbias, a.accumulate_dw, s));
@@ -76,11 +77,13 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s) {
         int S, L;
         split_rows_tn(a.M, a.N, a.K, &S, &L);
         float* parts = a.scratch;                              // [S][N][K] (S > 1)
-        float* bpart = parts + (int64_t)S * a.N * a.K;         // [S][N]
+        const bool defer = a.dbias && defer_bias && bias_space && S <= 64;
+        float* bpart = defer ? bias_space : parts + (int64_t)S * a.N * a.K;  // [S][N]
         LAUNCH(mdt_launch_gemm_tn(a.dY, a.ldy, a.X, a.ldx, S > 1 ? parts : a.dW, (int64_t)a.N * a.K, a.M, a.N, a.K, S, L,
                                   S > 1 ? 0 : a.accumulate_dw, a.dbias ? bpart : nullptr, s));
         if (S > 1) LAUNCH(mdt_launch_colsum(parts, (int64_t)a.N * a.K, S, a.N * a.K, a.dW, a.accumulate_dw, s));
-        if (a.dbias) LAUNCH(mdt_launch_colsum(bpart, a.N, S, a.N, a.dbias, a.accumulate_dw, s));
+        if (defer) *defer_bias = mdt_colsum_entry{bpart, a.dbias, (int64_t)a.N, S, a.N, a.accumulate_dw};
+        else if (a.dbias) LAUNCH(mdt_launch_colsum(bpart, a.N, S, a.N, a.dbias, a.accumulate_dw, s));
     } else if (a.dW) {
         if (a.N % 16) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: N must be a multiple of 16 for dW");
         int S, L;

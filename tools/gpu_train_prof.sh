@@ -1,11 +1,8 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the training step benchmark (eval-mode arithmetic), summary -> gpurun_out/<tag>/
-# usage: tools/gpu_train_prof.sh <tag> [batch]
-TAG=${1:-trainprof}; B=${2:-128}
-OUT=$PWD/gpurun_out/$TAG
-mkdir -p $OUT
-export TMPDIR=/tmp
-( cd /tmp && MDT_TRAIN_BENCH_MODES=eval timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/prof -o train -- python $OLDPWD/tools/train_bench.py $B > $OUT/prof_run.txt 2> $OUT/prof.err ); echo "rocprof exit $?"
-DB=$(find $OUT/prof -name "*.db" | head -1)
-[ -n "$DB" ] && python tools/prof_summary.py $DB > $OUT/train_kernel_stats.txt && head -34 $OUT/train_kernel_stats.txt
-find $OUT/prof -type f -size +20M -delete
+# rocprofv3 kernel stats of the denoiser training step (B = 1024, eval mode): gpurun_out/train_prof/
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+rm -rf $R/gpurun_out/train_prof; mkdir -p $R/gpurun_out/train_prof
+cd $R
+MDT_TRAIN_BENCH_MODES=eval rocprofv3 --kernel-trace --stats -d gpurun_out/train_prof -o train -- python tools/train_bench.py 1024 > gpurun_out/train_prof/run.log 2>&1
+grep "B=" gpurun_out/train_prof/run.log
