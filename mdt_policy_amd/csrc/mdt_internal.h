@@ -85,6 +85,7 @@ hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float*
 hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* packed, int n_off, hipStream_t s);
 hipError_t mdt_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t s);
 hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s);
+hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_t s);  // equal shapes; one launch per 8 sets
 hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s);
 bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta);
 // ---- Perceiver resampler kernels ----

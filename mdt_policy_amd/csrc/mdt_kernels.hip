@@ -726,9 +726,12 @@ hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
 // (H*Te) x d combination and the residual add -- 12x fewer FLOPs than the two d x d projections and three
 // launches (q GEMM, attention, c_proj GEMM) fewer per block and step.  Exact algebra, fp32 rounding differs.
 // ------------------------------------------------------------------------------------------------
+// the folds of ALL decoder blocks of one sampler call are one launch: blockIdx.z picks the block's argument set
+struct mdt_xfold_table { mdt_xfold_args a[8]; };
 template <int TE, int SB>
-__global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_args a) {
+__global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const mdt_xfold_args& a = tab.a[blockIdx.z];
     const int n = threadIdx.x;            // output feature handled by this thread
     const int h = blockIdx.y;
     const int bg = blockIdx.x * SB;       // first sample of the group
@@ -789,20 +792,35 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_args a) {
     }
 }
 
-hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s) {
+// n argument sets of equal shape (B, H, hd, D, Te) -- the decoder blocks of one model -- folded by one launch (n <= 8 per
+// launch; more go in groups)
+hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_t s) {
     constexpr int SB = 4;
+    if (n < 1) return hipErrorInvalidValue;
+    const mdt_xfold_args& a = sets[0];
     if (a.D > 512 || a.Te < 1 || a.Te > 4) return hipErrorInvalidValue;
-    const dim3 grid((a.B + SB - 1) / SB, a.H);
+    for (int i = 1; i < n; ++i)
+        if (sets[i].B != a.B || sets[i].H != a.H || sets[i].hd != a.hd || sets[i].D != a.D || sets[i].Te != a.Te)
+            return hipErrorInvalidValue;
     const int threads = (a.D + 63) / 64 * 64;
     const size_t lds = (size_t)2 * SB * a.Te * a.hd * sizeof(float);
-    switch (a.Te) {
-        case 1: hipLaunchKernelGGL((k_xattn_fold<1, SB>), grid, dim3(threads), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((k_xattn_fold<2, SB>), grid, dim3(threads), lds, s, a); break;
-        case 3: hipLaunchKernelGGL((k_xattn_fold<3, SB>), grid, dim3(threads), lds, s, a); break;
-        default: hipLaunchKernelGGL((k_xattn_fold<4, SB>), grid, dim3(threads), lds, s, a); break;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        mdt_xfold_table tab;
+        const int cnt = n - i0 < 8 ? n - i0 : 8;
+        for (int i = 0; i < 8; ++i) tab.a[i] = sets[i0 + (i < cnt ? i : 0)];
+        const dim3 grid((a.B + SB - 1) / SB, a.H, cnt);
+        switch (a.Te) {
+            case 1: hipLaunchKernelGGL((k_xattn_fold<1, SB>), grid, dim3(threads), lds, s, tab); break;
+            case 2: hipLaunchKernelGGL((k_xattn_fold<2, SB>), grid, dim3(threads), lds, s, tab); break;
+            case 3: hipLaunchKernelGGL((k_xattn_fold<3, SB>), grid, dim3(threads), lds, s, tab); break;
+            default: hipLaunchKernelGGL((k_xattn_fold<4, SB>), grid, dim3(threads), lds, s, tab); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
-    return hipGetLastError();
+    return hipSuccess;
 }
+hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s) { return mdt_launch_xattn_fold_n(&a, 1, s); }
 
 // One workgroup (384 threads) per sample; body in mdt_tiles.h (xattn_tile)
 template <int NP>

@@ -636,16 +636,17 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     }
     if (m->xfold) {  // fold K|V into the cross-attention projections, once per context (sigma independent)
         const int64_t np = (int64_t)m->H * Te;
+        std::vector<mdt_xfold_args> sets(m->Ld);
         for (int l = 0; l < m->Ld; ++l) {
-            mdt_xfold_args f;
+            mdt_xfold_args& f = sets[l];
             memset(&f, 0, sizeof f);
             f.kv = m->kvx + (int64_t)l * 2 * D; f.ldkv = (int64_t)m->Ld * 2 * D;
             f.Wq = m->dec[l].xq_raw; f.bq = m->dec[l].xq.bias; f.WoT = m->dec[l].xo_T;
             f.U = m->xU + (int64_t)l * m->cap * np * D; f.Wf = m->xW + (int64_t)l * m->cap * np * D;
             f.c = m->xc + (int64_t)l * m->cap * np;
             f.B = (int)B; f.H = m->H; f.hd = m->hd; f.D = D; f.Te = Te;
-            LAUNCH(mdt_launch_xattn_fold(f, s));
         }
+        LAUNCH(mdt_launch_xattn_fold_n(sets.data(), m->Ld, s));  // every decoder block in one launch
     }
     m->cached_batch = B;
     return MDT_OK;
