@@ -112,6 +112,12 @@ int64_t     mdt_param_numel(const mdt_model *m, int64_t index);
  * arena.  Stream-ordered on `stream`; a host `src` must stay valid until the stream has passed. */
 mdt_status mdt_load_param(mdt_model *m, const char *name, const float *src, int64_t numel, void *stream);
 
+/* The same for n parameters at once -- a whole load_state_dict, or the re-upload of every parameter an optimizer step
+ * changed -- as ONE kernel launch for all device-resident sources (host sources take the mdt_load_param path).  A
+ * training loop calls this once per step. */
+mdt_status mdt_load_params(mdt_model *m, int32_t n, const char *const *names, const float *const *srcs,
+                           const int64_t *numels, void *stream);
+
 /* Pre-size the workspace for batches up to max_batch (avoids hipMalloc later, e.g. before graph capture). */
 mdt_status mdt_reserve(mdt_model *m, int64_t max_batch);
 

@@ -83,6 +83,17 @@ hipError_t mdt_launch_noise_input(const float* act, const float* noise, const fl
 hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float* noised, const float* sigma, float sd,
                                   int64_t n, int per_sample, float* loss, hipStream_t s);
 hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* packed, int n_off, hipStream_t s);
+// one move of a batched parameter upload (k_multi_load): src is (rows, K) row-major on the device
+enum { MDT_LOAD_RAW = 0, MDT_LOAD_PACK = 1, MDT_LOAD_PACK_T = 2, MDT_LOAD_TRANSPOSE = 3, MDT_LOAD_PAD_COLS = 4 };
+struct mdt_load_entry {
+    const float* src;
+    float* dst;
+    int32_t kind, rows, K;
+    int32_t p0;  // PACK: first packed row (n_off);  PACK_T: k offset in the W^T image (n_off);  PAD_COLS: row pitch
+    int32_t p1;  // PACK_T: 16-blocks along the image's k (= Lin.N / 16)
+    int32_t pad_;
+};
+hipError_t mdt_launch_multi_load(const mdt_load_entry* tab, const int2* blocks, int n_blocks, hipStream_t s);
 hipError_t mdt_launch_transpose(const float* src, float* dst, int R, int Cc, hipStream_t s);
 hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s);
 hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_t s);  // equal shapes; one launch per 8 sets

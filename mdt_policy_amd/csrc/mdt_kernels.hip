@@ -42,6 +42,63 @@ __global__ void k_pack_weight(const float* __restrict__ w, int n_rows, int K, fl
     packed[(((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4 + j] = w[idx];
 }
 
+// Every parameter image of one load_state_dict / optimizer step in ONE launch (mdt_load_params): a table of moves --
+// raw copies, fragment packs, transposed fragment packs (training), transposes, column pads -- and a (move, chunk) list,
+// one workgroup per 1024 source elements.  The per-parameter launches this replaces (~230 of 3-6 us for MDT-V) were
+// ~0.9 ms of every training step.
+__global__ __launch_bounds__(256) void k_multi_load(const mdt_load_entry* __restrict__ tab, const int2* __restrict__ blocks) {
+    const int2 bk = blocks[blockIdx.x];
+    const mdt_load_entry e = tab[bk.x];
+    const int64_t n = (int64_t)e.rows * e.K;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t idx = (int64_t)bk.y * 1024 + threadIdx.x + 256 * u;
+        if (e.kind == MDT_LOAD_PACK_T) {
+            // thread = (4 consecutive source rows, column): one 16-byte fragment slot of the W^T image (k_pack_weight_t4)
+            const int rows4 = (e.rows + 3) >> 2;
+            if (idx >= (int64_t)rows4 * e.K) continue;
+            const int r4 = (int)(idx / e.K), c = (int)(idx - (int64_t)r4 * e.K);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * r4 + j;
+                v[j] = r < e.rows ? e.src[(int64_t)r * e.K + c] : 0.f;
+            }
+            const int k = e.p0 + 4 * r4;
+            const int nt = c >> 4, ni = c & 15, kc = k >> 4, h = (k & 15) >> 2;
+            *(f32x4*)(e.dst + (((int64_t)nt * e.p1 + kc) * 64 + (ni + 16 * h)) * 4) = v;
+            continue;
+        }
+        if (e.kind == MDT_LOAD_PACK) {
+            // thread = 4 consecutive k of one row: a 16-byte read and one 16-byte fragment slot (K is a multiple of 16)
+            const int K4 = e.K >> 2;
+            if (idx >= (int64_t)e.rows * K4) continue;
+            const int r = (int)(idx / K4), c = 4 * (int)(idx - (int64_t)r * K4);
+            const int nn = r + e.p0;
+            const int nt = nn >> 4, ni = nn & 15, kc = c >> 4, h = (c & 15) >> 2;
+            *(f32x4*)(e.dst + (((int64_t)nt * (e.K >> 4) + kc) * 64 + (ni + 16 * h)) * 4) = *(const f32x4*)(e.src + (int64_t)r * e.K + c);
+            continue;
+        }
+        if (idx >= n) continue;
+        const float v = e.src[idx];
+        if (e.kind == MDT_LOAD_RAW) {
+            e.dst[idx] = v;
+        } else {
+            const int r = (int)(idx / e.K), c = (int)(idx - (int64_t)r * e.K);
+            if (e.kind == MDT_LOAD_TRANSPOSE) {
+                e.dst[(int64_t)c * e.rows + r] = v;
+            } else {  // MDT_LOAD_PAD_COLS: row pitch p0
+                e.dst[(int64_t)r * e.p0 + c] = v;
+            }
+        }
+    }
+}
+hipError_t mdt_launch_multi_load(const mdt_load_entry* tab, const int2* blocks, int n_blocks, hipStream_t s) {
+    if (n_blocks < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_multi_load, dim3(n_blocks), dim3(256), 0, s, tab, blocks);
+    return hipGetLastError();
+}
+
 #ifdef MDT_DEBUG_TIMING
 extern "C" int mdt_debug_set_timing_buffer(unsigned long long* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ts), &p, sizeof(p));

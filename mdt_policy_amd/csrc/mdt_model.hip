@@ -361,6 +361,11 @@ extern "C" mdt_status mdt_destroy(mdt_model* m) {
     (void)hipFree(m->arena);
     (void)hipFree(m->staging);
     (void)hipFree(m->ws);
+    if (m->tab_dev) (void)hipFree(m->tab_dev);
+    for (int i = 0; i < 2; ++i) {
+        if (m->tab_host[i]) (void)hipHostFree(m->tab_host[i]);
+        if (m->ev_tab[i]) (void)hipEventDestroy(m->ev_tab[i]);
+    }
     delete m;
     return MDT_OK;
 }
@@ -421,6 +426,97 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
             HIP_TRY(mdt_launch_pack_weight_t(dev_src, t->rows, t->K, t->K, t->lin->wt, t->n_off, t->lin->N / 16, s));
     }
     slot->loaded = true;
+    return MDT_OK;
+}
+
+// load_state_dict / the re-upload after an optimizer step as ONE launch: all `n` parameters (device pointers, reference
+// layout) are moved into their packed / transposed / raw images by k_multi_load.  Host-resident sources, and handles whose
+// table memory cannot be allocated, go through mdt_load_param one by one.
+extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const* names, const float* const* srcs,
+                                      const int64_t* numels, void* stream) {
+    if (!m || n < 0 || (n > 0 && (!names || !srcs || !numels))) return fail(MDT_ERR_INVALID_ARG, "mdt_load_params: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<mdt_load_entry> tab;
+    std::vector<int2> blocks;
+    std::vector<Slot*> touched;
+    auto add = [&](const float* src, float* dst, int kind, int rows, int K, int p0, int p1) {
+        mdt_load_entry e;
+        memset(&e, 0, sizeof e);
+        e.src = src; e.dst = dst; e.kind = kind; e.rows = rows; e.K = K; e.p0 = p0; e.p1 = p1;
+        const int64_t work = kind == MDT_LOAD_PACK_T ? (int64_t)((rows + 3) / 4) * K
+                             : kind == MDT_LOAD_PACK ? (int64_t)rows * (K / 4) : (int64_t)rows * K;
+        for (int64_t c = 0; c * 1024 < work; ++c) blocks.push_back(make_int2((int)tab.size(), (int)c));
+        tab.push_back(e);
+    };
+    for (int i = 0; i < n; ++i) {
+        if (!names[i] || !srcs[i]) return fail(MDT_ERR_INVALID_ARG, "mdt_load_params: null entry %d", i);
+        std::string nm(names[i]);
+        if (!m->cfg.use_modality_encoder && nm.rfind("inner_model.lang_emb", 0) == 0)
+            nm.replace(0, strlen("inner_model.lang_emb"), "inner_model.goal_emb");
+        Slot* slot = nullptr;
+        for (Slot& c : m->slots)
+            if (c.name == nm) { slot = &c; break; }
+        if (!slot) {
+            if (is_ignored_param(m, nm)) continue;
+            return fail(MDT_ERR_INVALID_ARG, "mdt_load_params: unknown parameter '%s'", names[i]);
+        }
+        if (numels[i] != slot->numel)
+            return fail(MDT_ERR_INVALID_ARG, "mdt_load_params: '%s' has %lld elements, expected %lld", names[i],
+                        (long long)numels[i], (long long)slot->numel);
+        hipPointerAttribute_t attr;
+        const hipError_t pe = hipPointerGetAttributes(&attr, srcs[i]);
+        if (pe != hipSuccess || attr.type != hipMemoryTypeDevice || ((uintptr_t)srcs[i] & 15)) {
+            (void)hipGetLastError();
+            MDT_TRY(mdt_load_param(m, names[i], srcs[i], numels[i], stream));  // host memory: the staged path
+            continue;
+        }
+        std::vector<Slot*> targets;
+        targets.push_back(slot);
+        for (Slot& e : m->extra)
+            if (e.name == nm) targets.push_back(&e);
+        for (Slot* t : targets) {
+            if (t->kind == SLOT_RAW) add(srcs[i], t->dst, MDT_LOAD_RAW, 1, (int)numels[i], 0, 0);
+            else if (t->kind == SLOT_PAD_COLS) add(srcs[i], t->dst, MDT_LOAD_PAD_COLS, t->rows, t->K, t->n_off, 0);
+            else if (t->kind == SLOT_TRANSPOSE) add(srcs[i], t->dst, MDT_LOAD_TRANSPOSE, t->rows, t->K, 0, 0);
+            else {
+                add(srcs[i], t->dst, MDT_LOAD_PACK, t->rows, t->K, t->n_off, 0);
+                if (t->lin && t->lin->wt) add(srcs[i], t->lin->wt, MDT_LOAD_PACK_T, t->rows, t->K, t->n_off, t->lin->N / 16);
+            }
+        }
+        touched.push_back(slot);
+    }
+    if (!tab.empty()) {
+        const size_t tab_bytes = (tab.size() * sizeof(mdt_load_entry) + 255) & ~(size_t)255;
+        const size_t total = tab_bytes + blocks.size() * sizeof(int2);
+        std::vector<char> bytes(total, 0);
+        memcpy(bytes.data(), tab.data(), tab.size() * sizeof(mdt_load_entry));
+        memcpy(bytes.data() + tab_bytes, blocks.data(), blocks.size() * sizeof(int2));
+        if (total > m->tab_cap) {
+            HIP_TRY(hipStreamSynchronize(s));  // rare: the first upload, or a larger parameter set than before
+            if (m->tab_dev) (void)hipFree(m->tab_dev);
+            for (int i = 0; i < 2; ++i)
+                if (m->tab_host[i]) (void)hipHostFree(m->tab_host[i]);
+            m->tab_dev = nullptr; m->tab_host[0] = m->tab_host[1] = nullptr; m->tab_cap = 0; m->tab_last.clear();
+            HIP_TRY(hipMalloc(&m->tab_dev, total * 2));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipHostMalloc(&m->tab_host[i], total * 2, hipHostMallocDefault));
+                if (!m->ev_tab[i]) HIP_TRY(hipEventCreateWithFlags(&m->ev_tab[i], hipEventDisableTiming));
+            }
+            m->tab_cap = total * 2;
+        }
+        if (m->tab_last != bytes) {  // new table: through the pinned buffer whose previous copy has long completed
+            const int t = m->tab_turn ^= 1;
+            HIP_TRY(hipEventSynchronize(m->ev_tab[t]));
+            memcpy(m->tab_host[t], bytes.data(), total);
+            HIP_TRY(hipMemcpyAsync(m->tab_dev, m->tab_host[t], total, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipEventRecord(m->ev_tab[t], s));
+            m->tab_last.swap(bytes);
+        }
+        LAUNCH(mdt_launch_multi_load((const mdt_load_entry*)m->tab_dev, (const int2*)((const char*)m->tab_dev + tab_bytes),
+                                     (int)blocks.size(), s));
+    }
+    for (Slot* t : touched) t->loaded = true;
+    m->cached_batch = 0;
     return MDT_OK;
 }
 

@@ -84,6 +84,15 @@ struct mdt_model {
     float *freqs = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;  // constant tables
     float* staging = nullptr;  // host->device parameter staging
     size_t staging_floats = 0;
+    // batched upload (mdt_load_params): move table + block list on the device, two pinned staging copies used in turn
+    // (ev_tab[i] marks the last asynchronous copy out of host buffer i), the bytes last uploaded (an optimizer keeps its
+    // parameters' storage, so step after step the table is identical and is not copied again)
+    void* tab_dev = nullptr;
+    void* tab_host[2] = {nullptr, nullptr};
+    hipEvent_t ev_tab[2] = {nullptr, nullptr};
+    size_t tab_cap = 0;
+    int tab_turn = 0;
+    std::vector<char> tab_last;
     // workspace
     float* ws = nullptr;
     int64_t cap = 0;

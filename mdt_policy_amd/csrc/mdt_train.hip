@@ -75,6 +75,10 @@ struct mdt_train_state {
     // collected here and run as ONE launch at the end (flush_deferred): their inputs live in defer_buf until then.
     float* defer_buf = nullptr;
     int64_t defer_cap = 0, defer_off = 0;  // floats
+    // the scratch serves one backward at a time: a backward on another stream waits for the previous one's end
+    hipStream_t scratch_stream = nullptr;
+    hipEvent_t scratch_done = nullptr;
+    bool scratch_pending = false;
     std::vector<mdt_colsum_entry> deferred;
 };
 
@@ -84,6 +88,22 @@ static float* defer_take(mdt_train_state* ts, int64_t n) {
     float* p = ts->defer_buf + ts->defer_off;
     ts->defer_off += n;
     return p;
+}
+
+// entry of every backward: order this stream behind the last user of the shared scratch
+static mdt_status scratch_enter(mdt_model* m, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    if (ts->scratch_pending && ts->scratch_stream != s) HIP_TRY(hipStreamWaitEvent(s, ts->scratch_done, 0));
+    ts->scratch_stream = s;
+    ts->scratch_pending = false;
+    return MDT_OK;
+}
+static mdt_status scratch_leave(mdt_model* m, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    if (!ts->scratch_done) HIP_TRY(hipEventCreateWithFlags(&ts->scratch_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ts->scratch_done, s));
+    ts->scratch_pending = true;
+    return MDT_OK;
 }
 
 static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
@@ -98,7 +118,7 @@ static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
     }
     ts->deferred.clear();
     ts->defer_off = 0;
-    return MDT_OK;
+    return scratch_leave(m, s);
 }
 
 static const int NARROW_SLICES = 128;  // row slices of the narrow (A x D) weight gradients: 128 x 2 workgroups
@@ -153,6 +173,7 @@ void mdt_train_free(mdt_model* m) {
         if (tp.freed) (void)hipEventDestroy(tp.freed);
     }
     (void)hipFree(t->scratch);
+    if (t->scratch_done) (void)hipEventDestroy(t->scratch_done);
     (void)hipFree(t->wt_arena);
     for (const LinPart& p : m->parts) p.lin->wt = nullptr;
     delete t;
@@ -819,6 +840,7 @@ extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const
     if (!g_ctx || !grads) return fail(MDT_ERR_INVALID_ARG, "mdt_train_encode_bwd: null argument");
     hipStream_t s = (hipStream_t)stream;
     t->stream = s;
+    MDT_TRY(scratch_enter(m, s));
     MDT_TRY(reserve_scratch(m, t->B));
     m->train->deferred.clear(); m->train->defer_off = 0;
     HIP_TRY(hipMemcpyAsync(m->train->dxe, g_ctx, (size_t)t->B * m->Te * m->D * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -838,6 +860,7 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     hipStream_t s = (hipStream_t)stream;
     t.stream = s;
     mdt_train_state* ts = m->train;
+    MDT_TRY(scratch_enter(m, s));
     MDT_TRY(reserve_scratch(m, t.B));
     ts->deferred.clear(); ts->defer_off = 0;
     const int D = m->D, Ta = m->Ta, A = m->A;
@@ -925,7 +948,8 @@ extern "C" mdt_status mdt_denoise_vjp(mdt_model* m, const float* tokens, const f
     Tape& t = m->train->tapes[id];
     t.drop = effective_dropout(nullptr);  // eval-mode forward: D(x; sigma) itself
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
-    mdt_status st = reserve_scratch(m, batch);
+    mdt_status st = scratch_enter(m, s);
+    if (st == MDT_OK) st = reserve_scratch(m, batch);
     if (st == MDT_OK) st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, sigma, nullptr, s);
     // action := x, no noise: the tape's "noised" rows are x itself, F the raw network output
     if (st == MDT_OK) st = dec_fwd(m, t, x, nullptr, sigma, nullptr, nullptr, s);
@@ -945,5 +969,6 @@ extern "C" mdt_status mdt_denoise_vjp(mdt_model* m, const float* tokens, const f
         }
     }
     (void)mdt_tape_release(m, id);
+    if (st == MDT_OK) st = scratch_leave(m, s);
     return st;
 }

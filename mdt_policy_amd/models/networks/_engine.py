@@ -86,6 +86,7 @@ class HipEngine:
             if self._calls % _RESYNC_EVERY == 0:
                 self._uploaded.clear()
         seen = 0
+        changed = []  # (key, source tensor, tag)
         for name, p in self.module.named_parameters():
             key = "inner_model." + name
             if key not in self.expected:
@@ -99,8 +100,16 @@ class HipEngine:
             src = p.detach()
             if not src.is_contiguous():
                 src = src.contiguous()
-            _lib.check(self.lib.mdt_load_param(self.handle, key.encode(), src.data_ptr(), src.numel(), stream))
-            self._uploaded[key] = tag
+            changed.append((key, src, tag))
+        if changed:  # every changed parameter in ONE launch (a training step changes all of them)
+            n = len(changed)
+            names = (C.c_char_p * n)(*[k.encode() for k, _, _ in changed])
+            srcs = (C.c_void_p * n)(*[t.data_ptr() for _, t, _ in changed])
+            numels = (C.c_int64 * n)(*[t.numel() for _, t, _ in changed])
+            _lib.check(self.lib.mdt_load_params(self.handle, n, names, srcs, numels, stream))
+            for key, _, tag in changed:
+                self._uploaded[key] = tag
+            self._keep_src = [t for _, t, _ in changed]  # non-contiguous parameters were copied: keep those alive
         if seen != len(self.expected):
             have = {"inner_model." + n for n, _ in self.module.named_parameters()}
             raise RuntimeError(f"module lacks parameters the HIP path needs: {sorted(set(self.expected) - have)[:5]}")

@@ -553,10 +553,13 @@ def test_tape_reuse_across_streams_waits_for_the_previous_backward():
     want = step()
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    gots = []
     for i in range(6):
         s = streams[i % 2]
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            got = step()
+            gots.append(step())
         # no synchronisation between iterations: the next forward is enqueued while this backward may still run
-        assert torch.equal(got.cpu(), want.cpu()), f"step {i}"
+    torch.cuda.synchronize()
+    for i, got in enumerate(gots):
+        assert torch.equal(got, want), f"step {i}"

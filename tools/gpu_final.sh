@@ -19,7 +19,7 @@ echo "== batch sweep"; timeout 300 python tools/latency.py 1 2 4 8 16 32 64 128 
 echo "== training step B=1024"
 ( cd /tmp && MDT_TRAIN_BENCH_MODES=eval timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/train -o train -- python $R/tools/train_bench.py 1024 > $OUT/train_run.txt 2> $OUT/train.err )
 DB=$(find $OUT/train -name "*.db" | head -1); python tools/prof_summary.py $DB > $OUT/train_kernel_stats.txt; cat $OUT/train_run.txt | tail -2
-timeout 200 python tools/train_bench.py 128 1024 2>&1 | grep "B=" | tee $OUT/train_bench.txt
+( timeout 200 python tools/train_bench.py 128; timeout 200 python tools/train_bench.py 1024 ) 2>&1 | grep "B=" | tee $OUT/train_bench.txt
 echo "== MGF head"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/mae -o mae -- python $R/tools/mae_bench.py 1024 > $OUT/mae_run.txt 2> $OUT/mae.err )
 DB=$(find $OUT/mae -name "*.db" | head -1); python tools/prof_summary.py $DB > $OUT/mae_kernel_stats.txt

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Copy the summaries of one tools/gpu_final.sh run (gpurun_out/<tag>/) into profiles/r<NN>_*, each with a header naming the
+round, the commit the run was built from and the command.   usage: python tools/install_profiles.py <tag> <round> <commit>"""
+import os
+import sys
+
+tag, rnd, commit = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(R, "gpurun_out", tag)
+dst = os.path.join(R, "profiles")
+pre = f"r{rnd:02d}_"
+head = f"# Round {rnd} (final, commit {commit}) -- "
+
+
+def read(name):
+    with open(os.path.join(src, name)) as f:
+        return f.read()
+
+
+def lines(name, pat):
+    return "".join(l for l in read(name).splitlines(True) if pat in l)
+
+
+def write(name, text):
+    with open(os.path.join(dst, pre + name), "w") as f:
+        f.write(text)
+    print("wrote", pre + name)
+
+
+bench = read("bench.json").strip().splitlines()[-1]
+write("bench.json", bench + "\n")
+stats = read("bench_kernel_stats.txt").splitlines(True)
+write("bench_kernel_stats.txt",
+      head + "rocprofv3 --kernel-trace --stats of 'python bench.py --steps 5 --warmup 2 --no-cpu-baseline' (MI355X, 1 GPU), "
+      "tools/gpu_final.sh\n# 7 sampler calls x (encoder + fold + 10 decoder steps) + the 210-launch dominant-kernel timing leg; bench "
+      f"line of the same build and box: profiles/{pre}bench.json\n" + "".join(stats[:32]))
+write("bench_pmc.txt",
+      head + "rocprofv3 --kernel-trace --pmc (two separate passes) of 'python bench.py --steps 3 --warmup 1 --no-cpu-baseline', "
+      "tools/gpu_final.sh\n" + read("bench_pmc.txt"))
+lat = read("lat_kernel_stats.txt").splitlines(True)
+write("rollout_b1_kernel_stats.txt",
+      head + "rollout batch B = 1: rocprofv3 --kernel-trace --stats of 'python tools/latency.py 1' (sampler calls under the "
+      "profiler), MI355X\n" + lines("lat_run.txt", "B=") + "# per-kernel summary of the whole run\n" + "".join(lat[:17]) +
+      "# the LAST call (250 dispatches): durations and the idle gap in front of each kernel (tools/prof_gaps.py)\n" +
+      "".join(read("lat_gaps.txt").splitlines(True)[:16]))
+write("batch_sweep.txt",
+      f"# tools/latency.py on MI355X (end of round {rnd}, commit {commit}): one sample_ddim call = encoder + 10 DDIM steps, MDT-V "
+      "default, fp32\n" + read("sweep.txt"))
+tr = read("train_kernel_stats.txt").splitlines(True)
+write("train_step_kernel_stats.txt",
+      head + "rocprofv3 --kernel-trace --stats of 'MDT_TRAIN_BENCH_MODES=eval python tools/train_bench.py 1024' (loss forward + "
+      "backward + torch fused AdamW at B = 1024; times under the profiler), MI355X\n" + lines("train_run.txt", "B=") +
+      "# without the profiler (same box):\n" + "".join("# " + l for l in read("train_bench.txt").splitlines(True)) + "".join(tr[:36]))
+mae = read("mae_kernel_stats.txt").splitlines(True)
+write("mae_kernel_stats.txt",
+      head + "masked generative foresight head: rocprofv3 --kernel-trace --stats of 'python tools/mae_bench.py 1024' (forward + "
+      "backward, B = 1024), MI355X\n# without the profiler (same box):\n" + read("mae_bench.txt") + "".join(mae[:34]))
