@@ -117,6 +117,8 @@ class MaskedTransformerImgDecoder(nn.Module):
         self.decoder_patch_prediction = nn.Linear(decoder_embed_dim, (patch_size ** 2) * in_channels, bias=True)
         self.video_gen = video_gen
         self._packs = ops.PackedWeights()
+        from ...utils import weight_cache
+        weight_cache.track(self)
         self.initialize_weights()
 
     # -- initialisation (reference :176-203) ---------------------------------------------------------

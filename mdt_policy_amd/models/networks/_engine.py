@@ -369,6 +369,8 @@ class HipScoreNetwork(nn.Module):
     _arch = "mdtv"
 
     def _init_common(self):
+        from ...utils import weight_cache
+        weight_cache.track(self)  # fused torch optimizers do not bump version counters: an optimizer hook marks us dirty
         self.latent_encoder_emb = None
         self._engines: Dict[tuple, HipEngine] = {}
         self._sigma_data = 1.0

@@ -123,6 +123,8 @@ class MAPBlock(nn.Module):
         self._handle: Optional[C.c_void_p] = None
         self._handle_device = None
         self._uploaded: Dict[str, tuple] = {}
+        from ....utils import weight_cache
+        weight_cache.track(self)
         self._grad_layout = None
 
     # -- library handle --------------------------------------------------------------------------

@@ -97,6 +97,8 @@ class PerceiverResampler(nn.Module):
     def __init__(self, dim: int, depth: int, dim_head: int = 64, heads: int = 8, num_latents: int = 64,
                  num_time_embeds: int = 4, ff_mult: int = 4, activation: str = "gelu", trainable: bool = True):
         super().__init__()
+        from ....utils import weight_cache
+        weight_cache.track(self)
         self.dim = dim
         self.num_queries = num_latents
         self._cfg = dict(dim=dim, depth=depth, dim_head=dim_head, heads=heads, num_latents=num_latents,
