@@ -198,6 +198,8 @@ SYMBOLS = [
     ("mdt_tape_release", _I32, [_VP, _I32]),
     ("mdt_denoise_vjp", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
     ("mdt_op_pack_weight_t", _I32, [_VP, _I64, _I64, _I64, _VP, _I64, _I64, _VP]),
+    ("mdt_op_pack_many", _I32, [_I32, C.POINTER(C.c_void_p), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), _VP]),
     ("mdt_op_ln_fwd_train", _I32, [C.POINTER(LnTrainArgs), _VP]),
     ("mdt_op_ln_bwd", _I32, [C.POINTER(LnBwdArgs), _VP]),
     ("mdt_op_attn_bwd", _I32, [C.POINTER(AttnBwdArgs), _VP]),

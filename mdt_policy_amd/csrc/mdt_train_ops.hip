@@ -273,6 +273,78 @@ static mdt_status upload_opt_table(OptTable& g_opt, const mdt_opt_tensor* tensor
     return MDT_OK;
 }
 
+// a byte blob (move table + block list of k_multi_load) through the same content-keyed slots
+static mdt_status upload_blob(OptTable& g_opt, const std::vector<char>& bytes, const void** dev, OptSlot** used, hipStream_t s) {
+    for (OptSlot& sl : g_opt.slots)
+        if (sl.dev && sl.key.size() == bytes.size() && memcmp(sl.key.data(), bytes.data(), bytes.size()) == 0) {
+            *dev = sl.dev; *used = &sl;
+            sl.last_use = ++g_opt.clock;
+            return MDT_OK;
+        }
+    OptSlot* lru = &g_opt.slots[0];
+    for (OptSlot& c : g_opt.slots)
+        if (c.last_use < lru->last_use) lru = &c;
+    OptSlot& sl = *lru;
+    sl.last_use = ++g_opt.clock;
+    if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.busy) HIP_TRY(hipEventSynchronize(sl.ev));
+    if (bytes.size() > sl.cap) {
+        if (sl.dev) HIP_TRY(hipFree(sl.dev));
+        if (sl.host) HIP_TRY(hipHostFree(sl.host));
+        sl.dev = sl.host = nullptr; sl.cap = 0;
+        HIP_TRY(hipMalloc(&sl.dev, bytes.size() * 2));
+        HIP_TRY(hipHostMalloc(&sl.host, bytes.size() * 2, hipHostMallocDefault));
+        sl.cap = bytes.size() * 2;
+    }
+    memcpy(sl.host, bytes.data(), bytes.size());
+    HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, bytes.size(), hipMemcpyHostToDevice, s));
+    sl.key = bytes;
+    sl.tab_bytes = 0; sl.n_blocks = 0;
+    *dev = sl.dev; *used = &sl;
+    return MDT_OK;
+}
+
+// Fragment-packed images of n Linear weights (N_i, K_i) -- the forward operand into wp[i] and, where wt[i] is given, the image
+// of W^T for dX = dY W -- in ONE launch (a training step re-packs every weight of a module after its optimizer step).
+extern "C" mdt_status mdt_op_pack_many(int32_t n, const float* const* srcs, const int32_t* N, const int32_t* K, float* const* wp,
+                                       float* const* wt, void* stream) {
+    if (n < 0 || (n > 0 && (!srcs || !N || !K || !wp))) return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_many: bad argument");
+    if (n == 0) return MDT_OK;
+    std::vector<mdt_load_entry> tab;
+    std::vector<int2> blocks;
+    auto add = [&](const float* src, float* dst, int kind, int rows, int Kc, int p1) {
+        mdt_load_entry e;
+        memset(&e, 0, sizeof e);
+        e.src = src; e.dst = dst; e.kind = kind; e.rows = rows; e.K = Kc; e.p0 = 0; e.p1 = p1;
+        const int64_t work = kind == MDT_LOAD_PACK_T ? (int64_t)((rows + 3) / 4) * Kc : (int64_t)rows * (Kc / 4);
+        for (int64_t c = 0; c * 1024 < work; ++c) blocks.push_back(make_int2((int)tab.size(), (int)c));
+        tab.push_back(e);
+    };
+    for (int i = 0; i < n; ++i) {
+        if (!srcs[i] || !wp[i] || N[i] < 16 || K[i] < 16 || (N[i] % 16) || (K[i] % 16) || ((uintptr_t)srcs[i] & 15) || ((uintptr_t)wp[i] & 15))
+            return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_many: entry %d (N, K multiples of 16; 16-byte aligned pointers)", i);
+        add(srcs[i], wp[i], MDT_LOAD_PACK, N[i], K[i], 0);
+        if (wt && wt[i]) add(srcs[i], wt[i], MDT_LOAD_PACK_T, N[i], K[i], N[i] / 16);
+    }
+    const size_t tab_bytes = (tab.size() * sizeof(mdt_load_entry) + 255) & ~(size_t)255;
+    std::vector<char> bytes(tab_bytes + blocks.size() * sizeof(int2), 0);
+    memcpy(bytes.data(), tab.data(), tab.size() * sizeof(mdt_load_entry));
+    memcpy(bytes.data() + tab_bytes, blocks.data(), blocks.size() * sizeof(int2));
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32) return fail(MDT_ERR_INVALID_ARG, "device index %d out of range", dev);
+    OptTable& g_opt = g_opt_dev[dev];
+    std::lock_guard<std::mutex> lock(g_opt.mu);
+    hipStream_t s = (hipStream_t)stream;
+    const void* d = nullptr;
+    OptSlot* slot = nullptr;
+    MDT_TRY(upload_blob(g_opt, bytes, &d, &slot, s));
+    LAUNCH(mdt_launch_multi_load((const mdt_load_entry*)d, (const int2*)((const char*)d + tab_bytes), (int)blocks.size(), s));
+    HIP_TRY(hipEventRecord(slot->ev, s));
+    slot->busy = true;
+    return MDT_OK;
+}
+
 extern "C" mdt_status mdt_op_multi_adamw(const mdt_opt_tensor* tensors, int32_t n, float lr, float beta1, float beta2,
                                          float eps, float weight_decay, int64_t step, void* stream) {
     if (!tensors || n < 0 || step < 1) return fail(MDT_ERR_INVALID_ARG, "mdt_op_multi_adamw: bad argument");

@@ -41,6 +41,39 @@ class PackedWeights:
     def invalidate(self) -> None:
         self._cache.clear()
 
+    def refresh(self, weights, need_t: bool) -> None:
+        """Bring the images of every weight in ``weights`` (nn.Linear / Conv2d weight parameters) up to date with ONE launch
+        (mdt_op_pack_many); ``get`` then finds them cached.  The image buffers are kept across refreshes."""
+        stale = []
+        for w in weights:
+            ent = self._cache.get(id(w))
+            tag = (w.data_ptr(), w._version, need_t)
+            if ent is not None and ent[0][:2] == tag[:2] and (ent[0][2] or not need_t):
+                continue
+            w2d = w.reshape(w.shape[0], -1)
+            N, K = w2d.shape
+            if N % 16 or K % 16:
+                raise ValueError(f"Linear ({N}, {K}): both dimensions must be multiples of 16 for the packed MFMA operand")
+            src = _c(w2d)
+            wp = ent[1] if ent is not None and ent[1].numel() == N * K else torch.empty(N * K, device=src.device, dtype=torch.float32)
+            wt = None
+            if need_t:
+                wt = ent[2] if ent is not None and ent[2] is not None else torch.empty(N * K, device=src.device, dtype=torch.float32)
+            stale.append((w, src, N, K, wp, wt, tag))
+        if not stale:
+            return
+        n = len(stale)
+        lib = _lib.load()
+        srcs = (C.c_void_p * n)(*[e[1].data_ptr() for e in stale])
+        Ns = (C.c_int32 * n)(*[e[2] for e in stale])
+        Ks = (C.c_int32 * n)(*[e[3] for e in stale])
+        wps = (C.c_void_p * n)(*[e[4].data_ptr() for e in stale])
+        wts = (C.c_void_p * n)(*[(e[5].data_ptr() if e[5] is not None else None) for e in stale])
+        _lib.check(lib.mdt_op_pack_many(n, srcs, Ns, Ks, wps, wts, _stream(stale[0][1])))
+        for w, src, N, K, wp, wt, tag in stale:
+            self._cache[id(w)] = (tag, wp, wt)
+        self._keep = [e[1] for e in stale]  # converted / re-laid-out sources stay alive until the launch has run
+
     def get(self, w2d: torch.Tensor, key_param: torch.Tensor, need_t: bool):
         tag = (key_param.data_ptr(), key_param._version, need_t)
         ent = self._cache.get(id(key_param))

@@ -200,6 +200,9 @@ class MaskedTransformerImgDecoder(nn.Module):
         if context.shape[1] + X * n > 128:
             raise NotImplementedError(f"{context.shape[1] + X * n} decoder tokens: the HIP attention covers up to 128 "
                                       "(the shipped 112 x 112 / 16 configuration has 102)")
+        # every Linear's packed images (and, under autograd, the W^T images of the backward) in one launch
+        self._packs.refresh([m.weight for m in self.modules() if isinstance(m, (nn.Linear, nn.Conv2d))],
+                            need_t=torch.is_grad_enabled())
         emb_context = self._linear(context.float(), self.encoder2decoder)
         shuffle, m, restore, n_keep = self.mask(n, B, context.device, self.mask_ratio, noise)
         keep = shuffle[:, :n_keep]
