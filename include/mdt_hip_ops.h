@@ -63,6 +63,12 @@ typedef struct {
      * training path's weight gradients.                                                              */
     int32_t batch;
     int64_t bs_a, bs_w, bs_out;
+    /* training: a second (M, N) operand laid out like `out` (row stride ldo, same row remap), plain prologue, no residual:
+     *   aux_mode 1: aux = the value BEFORE `act` (after bias): one launch leaves both u and act(u);
+     *   aux_mode 2: out = value * act'(aux)  -- `act` names the activation whose derivative is taken, the value itself is
+     *               not activated (dX of the Linear that follows an activation: d_u = (dY W) * act'(u)).            */
+    const float *aux;
+    int32_t aux_mode;
 } mdt_gemm_args;
 
 mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);

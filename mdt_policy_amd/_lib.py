@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("shift_off", C.c_int32), ("scale_off", C.c_int32), ("rows_per_sample", C.c_int32), ("act", C.c_int32),
         ("residual", C.c_int32), ("gate_off", C.c_int32), ("gin", C.c_int32), ("gout", C.c_int32),
         ("goff", C.c_int32), ("rowvec", C.c_void_p), ("batch", C.c_int32), ("bs_a", C.c_int64), ("bs_w", C.c_int64),
-        ("bs_out", C.c_int64)]
+        ("bs_out", C.c_int64), ("aux", C.c_void_p), ("aux_mode", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -116,7 +116,7 @@ class LinearBwdArgs(C.Structure):
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("dY", C.c_void_p), ("ldy", C.c_int64), ("Wt", C.c_void_p),
                 ("dW", C.c_void_p), ("dbias", C.c_void_p), ("dX", C.c_void_p), ("ldxo", C.c_int64),
                 ("accumulate_dw", C.c_int32), ("accumulate_dx", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
-                ("K", C.c_int32), ("scratch", C.c_void_p)]
+                ("K", C.c_int32), ("scratch", C.c_void_p), ("dx_act_u", C.c_void_p), ("dx_act", C.c_int32)]
 
 
 class OptTensor(C.Structure):

@@ -458,7 +458,9 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     }
     // (not for the batched split-K products of the weight gradients: few output rows there come with a DEEP reduction --
     // N = 192 layers of the masked-image decoder: 595 us as 16-column split-K tiles vs ~300 us tiled)
-    if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096) {
+    // the training hooks of the epilogue (aux) exist in the plain-prologue, non-residual tiled kernels only
+    if (a.aux_mode && (!a.aux || a.ln || a.residual || a.batch > 1 || a.K > 512)) return hipErrorInvalidValue;
+    if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {
         hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4, a.batch > 1 ? a.batch : 1), dim3(512), 0, s, a, g_zeros);
         return hipGetLastError();
     }

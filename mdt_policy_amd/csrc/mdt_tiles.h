@@ -417,9 +417,24 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
             const bool mok = m0 + i * 16 + (lane & 15) < a.M;
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                f32x4 v = apply_act(acc[i][j] + bias_v[j], a.act);
+                const bool ok = mok && nt0 + j < N16;
+                f32x4 v = acc[i][j] + bias_v[j];
+                if constexpr (PRO == PRO_PLAIN && !RES && !COH) {
+                    // training hooks (mdt_gemm_args.aux): keep the pre-activation beside the activated value, or turn the
+                    // product into the gradient of the activation below it
+                    if (a.aux_mode == 2) {
+                        const f32x4 u = *(const f32x4*)(a.aux + ooff[i] + ncol[j]);  // rows clamped above: in bounds
+                        v.x *= apply_act_grad1(u.x, a.act); v.y *= apply_act_grad1(u.y, a.act);
+                        v.z *= apply_act_grad1(u.z, a.act); v.w *= apply_act_grad1(u.w, a.act);
+                    } else {
+                        if (a.aux_mode == 1 && ok) st4(const_cast<float*>(a.aux) + ooff[i] + ncol[j], v);
+                        v = apply_act(v, a.act);
+                    }
+                } else {
+                    v = apply_act(v, a.act);
+                }
                 if constexpr (RES) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
-                if (mok && nt0 + j < N16) st4(a.out + ooff[i] + ncol[j], v);
+                if (ok) st4(a.out + ooff[i] + ncol[j], v);
             }
         }
     }

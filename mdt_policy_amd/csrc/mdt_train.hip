@@ -418,8 +418,11 @@ static mdt_status block_fwd(mdt_model* m, const EncBlock& e, const DecBlock* d, 
     mdt_ln_train_args l2 = ln_args(t.x2, e.ln2_w, e.ln2_b, t.h2, t.st2, M, D);
     ln_cond(l2, mod, modw, c.sh2, c.sc2, T);
     LAUNCH(mdt_launch_ln_fwd_train(l2, s));
-    LAUNCH(mdt_launch_gemm(gemm_args(t.h2, D, e.fc, t.u, 4 * D, M), s));
-    LAUNCH(mdt_launch_act_fwd(t.u, t.hid, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
+    {   // c_fc and its GELU in one launch: the epilogue leaves the pre-activation u (the backward's operand) beside gelu(u)
+        mdt_gemm_args g = gemm_args(t.h2, D, e.fc, t.hid, 4 * D, M);
+        g.act = MDT_ACT_GELU; g.aux = t.u; g.aux_mode = 1;
+        LAUNCH(mdt_launch_gemm(g, s));
+    }
     LAUNCH(mdt_launch_gemm(gemm_args(t.hid, 4 * D, e.proj2, t.mo, D, M), s));
     LAUNCH(mdt_launch_merge_fwd(merge_args(t.x2, t.mo, c.g2 >= 0 ? mod + c.g2 : nullptr, modw, t.x3, B, T, D, dr.mlp_p,
                                            site_id(blk, SITE_MLP), dr.seed), s));
@@ -630,7 +633,7 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
 // ------------------------------------------------------------------------------------------------
 // gradient slots of a (possibly stacked) Linear: every reference Linear inside `l`
 static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float* X, int64_t ldx, const float* dY, int64_t ldy,
-                          int M, float* dX, int64_t ldxo, int acc_dx, hipStream_t s) {
+                          int M, float* dX, int64_t ldxo, int acc_dx, hipStream_t s, const float* act_u = nullptr, int act = 0) {
     mdt_train_state* ts = m->train;
     const LinPart* first = nullptr;  // the part at row 0: the stack's gradient region starts at its slot
     for (const LinPart& p : m->parts)
@@ -645,6 +648,7 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     a.accumulate_dw = 1;
     a.Wt = l.wt; a.dX = dX; a.ldxo = ldxo; a.accumulate_dx = acc_dx;
     a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
+    a.dx_act_u = act_u; a.dx_act = act;
     mdt_colsum_entry be;
     float* space = a.dbias ? defer_take(ts, (int64_t)64 * l.N) : nullptr;
     MDT_TRY(mdt_linear_bwd(a, s, space ? &be : nullptr, space));
@@ -721,8 +725,8 @@ static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const
         if (c.g2 >= 0) { g.dgate = d_mod + c.g2; g.dgate_stride = modw; }
         LAUNCH(mdt_launch_merge_bwd(g, s));
     }
-    MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, ts->t_d, D, M, ts->t_4d, 4 * D, 0, s));
-    LAUNCH(mdt_launch_act_bwd(t.u, ts->t_4d, ts->t_4d, (int64_t)M * 4 * D, MDT_ACT_GELU, s));
+    // d_u = (d_mo W_proj) * gelu'(u): the GELU backward is the epilogue of c_proj's input-gradient product
+    MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, ts->t_d, D, M, ts->t_4d, 4 * D, 0, s, t.u, MDT_ACT_GELU));
     MDT_TRY(lin_bwd(m, grads, e.fc, t.h2, D, ts->t_4d, 4 * D, M, ts->t_d2, D, 0, s));
     MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, c.sh2, c.sc2, ts->t_d2, dx, 1, d_mod, B, T, s, acc_dmod));
     if (d) {

@@ -117,6 +117,10 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsu
         w.wp = const_cast<float*>(a.Wt); w.bias = nullptr; w.N = a.K; w.K = a.N;
         mdt_gemm_args g = gemm_args(a.dY, a.ldy, w, a.dX, a.ldxo, a.M);
         g.residual = a.accumulate_dx;
+        if (a.dx_act_u) {  // dX = (dY W) * act'(u): the activation's backward rides on this product's epilogue
+            if (a.accumulate_dx || a.N > 512) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: dx_act_u needs accumulate_dx = 0 and N <= 512");
+            g.aux = a.dx_act_u; g.aux_mode = 2; g.act = a.dx_act;
+        }
         LAUNCH(mdt_launch_gemm(g, s));
     }
     return MDT_OK;
