@@ -120,6 +120,7 @@ int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K);
 // dW[n][k] = sum_m dY[m][n] X[m][k] from the row-major operands (mdt_train_kernels.hip: k_gemm_tn), S row slices of L rows
 hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
                               int K, int S, int L, int accumulate, float* bpart, hipStream_t s);
+int mdt_gemm_tn_ktile(int K);  // 128 or 192: the k-tile width k_gemm_tn picks for K columns
 hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
                               int accumulate, hipStream_t s);
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);
@@ -164,7 +165,7 @@ hipError_t mdt_launch_add_inplace(const float* x, float* y, int64_t n, hipStream
 // dst[r][c] += src[r][c] for r < rows, c < cols (leading dimensions lds_ / ldd)
 hipError_t mdt_launch_add_2d(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int cols, hipStream_t s);
 // backward of a Linear through the forward GEMM kernel (mdt_train.hip); see mdt_linear_bwd_args
-// defer_bias (optional, with bias_space of at least 64 * N floats that stay valid until the caller runs the entry): the
+// defer_bias (optional, with bias_space of at least 256 * N floats that stay valid until the caller runs the entry): the
 // per-slice bias partials are left in bias_space and *defer_bias describes their final column sum instead of launching it
 // (defer_bias->src == nullptr on return: the bias gradient was produced another way, nothing to run).
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsum_entry* defer_bias = nullptr,

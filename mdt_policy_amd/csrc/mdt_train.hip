@@ -292,7 +292,7 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
     {   // deferred column sums: two partial tables per LayerNorm call, 64 slices of bias partials per Linear
         int64_t widest = 4 * D;
         for (const LinPart& p : m->parts) widest = std::max<int64_t>(widest, p.lin->N);
-        ts->defer_cap = (int64_t)(2 * m->Le + 3 * m->Ld + 2) * 2 * B * D + (int64_t)m->parts.size() * 64 * widest + 1024;
+        ts->defer_cap = (int64_t)(2 * m->Le + 3 * m->Ld + 2) * 2 * B * D + (int64_t)m->parts.size() * 256 * widest + 1024;
         ts->defer_buf = b.take(ts->defer_cap);
     }
     ts->narrow = b.take((size_t)NARROW_SLICES * 16 * std::max({D, m->HP, m->p_row >= 0 ? 2 * D : 0}));
@@ -650,7 +650,7 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
     a.dx_act_u = act_u; a.dx_act = act;
     mdt_colsum_entry be;
-    float* space = a.dbias ? defer_take(ts, (int64_t)64 * l.N) : nullptr;
+    float* space = a.dbias ? defer_take(ts, (int64_t)256 * l.N) : nullptr;
     MDT_TRY(mdt_linear_bwd(a, s, space ? &be : nullptr, space));
     if (space && be.src) ts->deferred.push_back(be);
     return MDT_OK;

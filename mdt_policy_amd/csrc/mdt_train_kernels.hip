@@ -1202,12 +1202,16 @@ hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks,
 //   (summed afterwards in a fixed order by k_colsum: deterministic).  Workgroups of k-tile 0 also leave the column sums of
 //   their dY tile (the bias gradient's per-slice partials) in bpart[z][n].
 // ------------------------------------------------------------------------------------------------
+// KT = 16-wide k-tiles per wave: 2 (tile 64 x 128) or 3 (64 x 192, for K = 192 / 576 / ... where 128-wide tiles would leave
+// a quarter of the last one empty: the masked-image head's d = 192 layers).
+template <int KT>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
                                                  float* __restrict__ out, int64_t slice_stride, int M, int N, int K, int L,
                                                  int accumulate, float* __restrict__ bpart) {
-    constexpr int CM = 32, TN_ = 64, TK = 128, SY = TN_ + 4, SX = TK + 4;
-    __shared__ __attribute__((aligned(16))) float ys[2][CM * SY];
-    __shared__ __attribute__((aligned(16))) float xs[2][CM * SX];
+    constexpr int CM = 32, TN_ = 64, TK = 64 * KT, SY = TN_ + 4, SX = TK + 4, XU = TK / 32, X4 = TK / 4;
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];  // ys[2][CM * SY] | xs[2][CM * SX]  (51 / 68 KB)
+    float (*ys)[CM * SY] = (float (*)[CM * SY])tn_lds;
+    float (*xs)[CM * SX] = (float (*)[CM * SX])(tn_lds + 2 * CM * SY);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gk = (K + TK - 1) / TK;
     const int bn = blockIdx.x / gk, bk = blockIdx.x - bn * gk;
@@ -1216,16 +1220,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
     const int m_lo = z * L, m_hi = min(M, m_lo + L);
     out += (int64_t)z * slice_stride;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // staging assignment: X chunk = 32 rows x 32 float4 (4 per thread), dY chunk = 32 rows x 16 float4 (2 per thread)
-    int xr[4], xc[4], yr[2], yc[2];
+    // staging assignment: X chunk = 32 rows x TK/4 float4 (4 or 6 per thread), dY chunk = 32 rows x 16 float4 (2 per thread)
+    int xr[XU], xc[XU], yr[2], yc[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = tid + 256 * u; xr[u] = i >> 5; xc[u] = (i & 31) * 4; }
+    for (int u = 0; u < XU; ++u) { const int i = tid + 256 * u; xr[u] = i / X4; xc[u] = (i - xr[u] * X4) * 4; }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int i = tid + 256 * u; yr[u] = i >> 4; yc[u] = (i & 15) * 4; }
-    f32x4 xv[4], yv[2];
+    f32x4 xv[XU], yv[2];
     auto fetch = [&](int mb) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < XU; ++u) {
             const int64_t m = min(mb + xr[u], m_hi - 1);
             xv[u] = ldg4(X + m * ldx + min(k0 + xc[u], K - 4));
         }
@@ -1237,17 +1241,17 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
     };
     auto stash = [&](int buf, int mb) {  // rows past the slice and columns past the matrix contribute zeros
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < XU; ++u)
             *(f32x4*)(&xs[buf][xr[u] * SX + xc[u]]) = (mb + xr[u] < m_hi && k0 + xc[u] < K) ? xv[u] : zero4;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             *(f32x4*)(&ys[buf][yr[u] * SY + yc[u]]) = (mb + yr[u] < m_hi && n0 + yc[u] < N) ? yv[u] : zero4;
     };
-    f32x4 acc[4][2];
+    f32x4 acc[4][KT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero4;
+        for (int j = 0; j < KT; ++j) acc[i][j] = zero4;
     float bsum = 0.f;  // threads 0..63 of k-tile-0 workgroups: column sum of dY[:, n0 + tid]
     const bool do_bias = bpart != nullptr && bk == 0 && tid < TN_;
     const int l16 = lane & 15, h = lane >> 4;
@@ -1267,15 +1271,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = 16 * s + 4 * h + e;
-                float a[2], b[4];
+                float a[KT], b[4];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) a[j] = xb[row * SX + (2 * wave + j) * 16 + l16];
+                for (int j = 0; j < KT; ++j) a[j] = xb[row * SX + (KT * wave + j) * 16 + l16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) b[i] = yb[row * SY + i * 16 + l16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[i], acc[i][j], 0, 0, 0);
             }
         }
         if (do_bias) {
@@ -1285,13 +1289,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
         if (c + 1 < nchunks) stash(buf ^ 1, m_lo + (c + 1) * CM);
         __syncthreads();
     }
-    // lane holds out[n0 + 16 i + l16][k0 + 16 (2 wave + j) + 4 h .. + 3]
+    // lane holds out[n0 + 16 i + l16][k0 + 16 (KT wave + j) + 4 h .. + 3]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + 16 * i + l16;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + 16 * (2 * wave + j) + 4 * h;
+        for (int j = 0; j < KT; ++j) {
+            const int k = k0 + 16 * (KT * wave + j) + 4 * h;
             if (n < N && k < K) {
                 float* p = out + (int64_t)n * K + k;
                 f32x4 v = acc[i][j];
@@ -1308,7 +1312,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
 hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
                               int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
     if (M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || S < 1) return hipErrorInvalidValue;
-    const int gn = (N + 63) / 64, gk = (K + 127) / 128;
-    hipLaunchKernelGGL(k_gemm_tn, dim3(gn * gk, 1, S), dim3(256), 0, s, dY, ldy, X, ldx, out, slice_stride, M, N, K, L, accumulate, bpart);
+    const int gn = (N + 63) / 64;
+    constexpr size_t lds2 = (size_t)2 * 32 * (68 + 132) * sizeof(float), lds3 = (size_t)2 * 32 * (68 + 196) * sizeof(float);
+    if (mdt_gemm_tn_ktile(K) == 192) {
+        static bool attr = false;  // 67.6 KB: above the default dynamic-LDS limit
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_gemm_tn<3>, dim3(gn * ((K + 191) / 192), 1, S), dim3(256), lds3, s, dY, ldy, X, ldx, out, slice_stride, M, N,
+                           K, L, accumulate, bpart);
+    } else {
+        hipLaunchKernelGGL(k_gemm_tn<2>, dim3(gn * ((K + 127) / 128), 1, S), dim3(256), lds2, s, dY, ldy, X, ldx, out, slice_stride, M, N,
+                           K, L, accumulate, bpart);
+    }
     return hipGetLastError();
+}
+// k-tile width k_gemm_tn uses for a K-column product: the one that pads K less (128 on a tie)
+int mdt_gemm_tn_ktile(int K) {
+    const int p128 = (K + 127) / 128 * 128, p192 = (K + 191) / 192 * 192;
+    return p192 < p128 ? 192 : 128;
 }

@@ -42,11 +42,14 @@ static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
 // The same for k_gemm_tn (64 x 128 tiles, no transposed / packed copies to amortise): ~6 workgroups per CU queued (3 resident), slices of at
 // least 128 rows -- small batches (B = 128: 1280 rows) need the split even more than large ones.
 static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
-    const int64_t tiles = ((N + 63) / 64) * ((K + 127) / 128);
+    const int tk = mdt_gemm_tn_ktile((int)K);
+    const int64_t tiles = ((N + 63) / 64) * ((K + tk - 1) / tk);
     static int64_t target = -1;
     if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 1536; }  // measured at B = 1024: 768 -> 11.27 ms step / 42.1 ms head, 1536 -> 11.18 / 41.4, 2304 -> 11.22 / 41.4
     int64_t s = std::max<int64_t>(1, std::min<int64_t>((target + tiles - 1) / tiles, M / 128));
-    s = std::min<int64_t>(s, 64);
+    static int64_t cap = -1;
+    if (cap < 0) { const char* e = getenv("MDT_HIP_TN_SLICES"); cap = e ? atoll(e) : 128; }  // measured: masked-image head 37.7 ms (64) -> 37.2 (128) = (192, 256); denoiser step unchanged
+    s = std::min<int64_t>(s, cap);
     if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
     const int64_t l = ((M + s - 1) / s + 31) / 32 * 32;
     *S = (int)((M + l - 1) / l);
@@ -77,7 +80,7 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsu
         int S, L;
         split_rows_tn(a.M, a.N, a.K, &S, &L);
         float* parts = a.scratch;                              // [S][N][K] (S > 1)
-        const bool defer = a.dbias && defer_bias && bias_space && S <= 64;
+        const bool defer = a.dbias && defer_bias && bias_space && S <= 256;
         float* bpart = defer ? bias_space : parts + (int64_t)S * a.N * a.K;  // [S][N]
         LAUNCH(mdt_launch_gemm_tn(a.dY, a.ldy, a.X, a.ldx, S > 1 ? parts : a.dW, (int64_t)a.N * a.K, a.M, a.N, a.K, S, L,
                                   S > 1 ? 0 : a.accumulate_dw, a.dbias ? bpart : nullptr, s));
