@@ -493,6 +493,16 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     // ... unless the output is so wide that they would be thousands (the stacked adaLN projection of a training batch:
     // 1024 x 9216 -> 9216 workgroups that each re-read their weight tile): then the scored choice stands
     if (a.M <= g_mdt_mid_max && (int64_t)((a.M + 15) / 16) * ((a.N + 63) / 64) <= 4096) geo = 6;
+    // training-sized row counts without a LayerNorm prologue (forward / input-gradient products of a B = 1024 step, the
+    // masked-image head's 104 k rows): 4 waves x 32 x 192 tiles -- two or three co-resident per CU, each weight fragment reused by
+    // one wave only -- beat every 8-wave geometry whenever N is a multiple of 192 (tools/gemm_train_shapes.py: 10240 x 1536 x 384
+    // 126 -> 107 us, 104448 x 192 x 768 372 -> 282 us, 104448 x 576 x 192 332 -> 233 us); N = 384 keeps the choices above
+    // (36.5 vs 38.4 us at K = 384, the co-resident 32 x 128 tiles at K = 1536)
+    {
+        static int g9 = -1;
+        if (g9 < 0) { const char* e = getenv("MDT_HIP_GEO_TRAIN"); g9 = e ? atoi(e) : 9; }
+        if (g9 && !a.ln && a.M >= 4096 && a.N % 192 == 0 && a.N != 384 && a.batch <= 1) geo = g9;
+    }
     if (a.batch > 1) {  // split-K partial products (deep reductions): geometry chosen for those, env override for A/B runs
         static int bgeo = -1;
         if (bgeo < 0) { const char* e = getenv("MDT_HIP_BATCH_GEO"); bgeo = e ? atoi(e) : 5; }
