@@ -1331,6 +1331,9 @@ hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int6
 }
 // k-tile width k_gemm_tn uses for a K-column product: the one that pads K less (128 on a tie)
 int mdt_gemm_tn_ktile(int K) {
+    static int force = -1;  // MDT_HIP_TN_KTILE=128|192: A/B runs
+    if (force < 0) { const char* e = getenv("MDT_HIP_TN_KTILE"); force = e ? atoi(e) : 0; }
+    if (force == 128 || force == 192) return force;
     const int p128 = (K + 127) / 128 * 128, p192 = (K + 191) / 192 * 192;
     return p192 < p128 ? 192 : 128;
 }
