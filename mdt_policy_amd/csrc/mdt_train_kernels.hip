@@ -473,8 +473,10 @@ hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* o
 // RoPE on rows held in LDS: feature pairs (2i, 2i+1), i < 16, of row r rotate by angle pos(r) * freq_i
 // (position_embeddings.py:56-70,138-142; tables cos/sin[pos][i], 16 x 16).  sign = -1 applies the transpose, which is
 // what carries a gradient with respect to the rotated vector back to the unrotated one.
+// LDS rows of these kernels are HD + 4 floats apart: 16-byte aligned, so that every inner loop below moves four features per
+// LDS instruction (the first versions read 4 bytes per FMA operand and were bound by LDS instruction issue).
 template <int HD>
-__device__ __forceinline__ void rope_rows(float (*rows)[HD + 1], int T, const float* __restrict__ rc,
+__device__ __forceinline__ void rope_rows(float (*rows)[HD + 4], int T, const float* __restrict__ rc,
                                           const float* __restrict__ rs, float sign, int lane) {
     for (int e = lane; e < T * 16; e += 64) {
         const int r = e >> 4, i = e & 15;
@@ -487,21 +489,48 @@ __device__ __forceinline__ void rope_rows(float (*rows)[HD + 1], int T, const fl
     }
 }
 
+// NB head slices (rows of HD floats at column h * HD) of one sample: global -> LDS, all 16-byte loads of the wave requested
+// before the first is consumed.  T[b] rows each (<= 16), rows beyond are left alone.
+template <int HD, int NB>
+__device__ __forceinline__ void load_head_rows(const float* const (&src)[NB], const int64_t (&ld)[NB], const int (&T)[NB],
+                                               float (*const (&dst)[NB])[HD + 4], int lane) {
+    constexpr int H4 = HD / 4, NI = (16 * H4 + 63) / 64;
+    f32x4 t[NB][NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = lane + 64 * u, r = i / H4, c = 4 * (i - r * H4);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) t[b][u] = ldg4(src[b] + (int64_t)min(r, T[b] - 1) * ld[b] + c);
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = lane + 64 * u, r = i / H4, c = 4 * (i - r * H4);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (r < T[b]) *(f32x4*)&dst[b][r][c] = t[b][u];
+    }
+}
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
+    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc);
+    return fmaf(a.w, b.w, acc);
+}
+
 // training forward with dropout on the probabilities: out = (mask/(1-p) * softmax(q k^T / sqrt(hd))) v
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, float scale) {
-    __shared__ float qs[16][HD + 1], ks[16][HD + 1], vs[16][HD + 1];
+    __shared__ __attribute__((aligned(16))) float qs[16][HD + 4], ks[16][HD + 4], vs[16][HD + 4];
     __shared__ float P[16][17];
+    constexpr int H4 = HD / 4;
     const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const int Tq = a.Tq, Tk = a.Tk;
-    for (int i = lane; i < Tq * HD; i += 64) {
-        const int r = i / HD, d = i - r * HD;
-        qs[r][d] = a.q[((int64_t)b * Tq + r) * a.ldq + h * HD + d];
-    }
-    for (int i = lane; i < Tk * HD; i += 64) {
-        const int r = i / HD, d = i - r * HD;
-        ks[r][d] = a.k[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
-        vs[r][d] = a.v[((int64_t)b * Tk + r) * a.ldkv + h * HD + d];
+    {
+        const float* const src[3] = {a.q + (int64_t)b * Tq * a.ldq + h * HD, a.k + (int64_t)b * Tk * a.ldkv + h * HD,
+                                     a.v + (int64_t)b * Tk * a.ldkv + h * HD};
+        const int64_t ld[3] = {a.ldq, a.ldkv, a.ldkv};
+        const int T[3] = {Tq, Tk, Tk};
+        float (*const dst[3])[HD + 4] = {qs, ks, vs};
+        load_head_rows<HD, 3>(src, ld, T, dst, lane);
     }
     __syncthreads();
     if (a.rope) {
@@ -509,16 +538,20 @@ __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, fl
         rope_rows<HD>(ks, Tk, a.rope_cos, a.rope_sin, 1.f, lane);
         __syncthreads();
     }
+    // one (query, key) pair per lane
+    for (int e = lane; e < Tq * Tk; e += 64) {
+        const int i = e / Tk, j = e - i * Tk;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < H4; ++c) s = dot4(*(const f32x4*)&qs[i][4 * c], *(const f32x4*)&ks[j][4 * c], s);
+        P[i][j] = (!a.causal || j <= i) ? s * scale : -INFINITY;
+    }
+    __syncthreads();
     if (lane < Tq) {
         const int i = lane;
         float sc[16];
         float mx = -INFINITY;
-        for (int j = 0; j < Tk; ++j) {
-            float s = 0.f;
-            for (int d = 0; d < HD; ++d) s = fmaf(qs[i][d], ks[j][d], s);
-            sc[j] = (!a.causal || j <= i) ? s * scale : -INFINITY;
-            mx = fmaxf(mx, sc[j]);
-        }
+        for (int j = 0; j < Tk; ++j) { sc[j] = P[i][j]; mx = fmaxf(mx, sc[j]); }
         float sum = 0.f;
         for (int j = 0; j < Tk; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
         const float inv = 1.f / sum;
@@ -526,16 +559,18 @@ __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, fl
         for (int j = 0; j < Tk; ++j) P[i][j] = sc[j] * inv * dropout_scale(a.seed, a.site, base + j, a.p);
     }
     __syncthreads();
-    for (int e = lane; e < Tq * HD; e += 64) {
-        const int i = e / HD, d = e - i * HD;
-        float acc = 0.f;
-        for (int j = 0; j < Tk; ++j) acc = fmaf(P[i][j], vs[j][d], acc);
-        a.out[((int64_t)b * Tq + i) * a.ldo + h * HD + d] = acc;
+    for (int e = lane; e < Tq * H4; e += 64) {  // (row, four features) per lane
+        const int i = e / H4, c = 4 * (e - i * H4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Tk; ++j) acc += P[i][j] * *(const f32x4*)&vs[j][c];
+        *(f32x4*)(a.out + ((int64_t)b * Tq + i) * a.ldo + h * HD + c) = acc;
     }
 }
 
 hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s) {
     if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
+    if (((a.ldq | a.ldkv | a.ldo) & 3) || (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.out) & 15))
+        return hipErrorInvalidValue;  // 16-byte loads / stores of the head slices
     if (a.rope && (a.hd < 32 || !a.rope_cos || !a.rope_sin)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)a.hd);
     const dim3 grid(a.B, a.H);
@@ -551,35 +586,18 @@ hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s
 
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scale) {
-    __shared__ float qs[16][HD + 1], ks[16][HD + 1], vs[16][HD + 1], os[16][HD + 1];
+    __shared__ __attribute__((aligned(16))) float qs[16][HD + 4], ks[16][HD + 4], vs[16][HD + 4], os[16][HD + 4];
     __shared__ float P[16][17], dS[16][17];
+    constexpr int H4 = HD / 4;
     const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const int Tq = a.Tq, Tk = a.Tk;
-    {   // q / dO / k / v tiles: every 16-byte load of the wave is requested before the first one is consumed (one memory
-        // round trip instead of one per loop trip); rows are 16-byte aligned (HD and the leading dimensions are multiples of 4)
-        constexpr int H4 = HD / 4, NI = (16 * H4 + 63) / 64;  // float4 per row, trips for up to 16 rows
-        f32x4 tq[NI], to[NI], tk[NI], tv[NI];
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = lane + 64 * u;
-            const int rq = min(i / H4, Tq - 1), rk = min(i / H4, Tk - 1), c = 4 * (i % H4);
-            tq[u] = ldg4(a.q + ((int64_t)b * Tq + rq) * a.ldq + h * HD + c);
-            to[u] = ldg4(a.d_out + ((int64_t)b * Tq + rq) * a.ld_do + h * HD + c);
-            tk[u] = ldg4(a.k + ((int64_t)b * Tk + rk) * a.ldkv + h * HD + c);
-            tv[u] = ldg4(a.v + ((int64_t)b * Tk + rk) * a.ldkv + h * HD + c);
-        }
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = lane + 64 * u, r = i / H4, c = 4 * (i % H4);
-            if (r < Tq) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { qs[r][c + e] = tq[u][e]; os[r][c + e] = to[u][e]; }
-            }
-            if (r < Tk) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ks[r][c + e] = tk[u][e]; vs[r][c + e] = tv[u][e]; }
-            }
-        }
+    {   // q / k / v / dO tiles (rows are 16-byte aligned: HD and the leading dimensions are multiples of 4)
+        const float* const src[4] = {a.q + (int64_t)b * Tq * a.ldq + h * HD, a.k + (int64_t)b * Tk * a.ldkv + h * HD,
+                                     a.v + (int64_t)b * Tk * a.ldkv + h * HD, a.d_out + (int64_t)b * Tq * a.ld_do + h * HD};
+        const int64_t ld[4] = {a.ldq, a.ldkv, a.ldkv, a.ld_do};
+        const int T[4] = {Tq, Tk, Tk, Tq};
+        float (*const dst[4])[HD + 4] = {qs, ks, vs, os};
+        load_head_rows<HD, 4>(src, ld, T, dst, lane);
     }
     __syncthreads();
     if (a.rope) {  // the scores were formed on the rotated q / k
@@ -592,9 +610,10 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
     for (int e = lane; e < Tq * Tk; e += 64) {
         const int i = e / Tk, j = e - i * Tk;
         float s = 0.f, t = 0.f;
-        for (int d = 0; d < HD; ++d) {
-            s = fmaf(qs[i][d], ks[j][d], s);
-            t = fmaf(os[i][d], vs[j][d], t);
+#pragma unroll
+        for (int c = 0; c < H4; ++c) {
+            s = dot4(*(const f32x4*)&qs[i][4 * c], *(const f32x4*)&ks[j][4 * c], s);
+            t = dot4(*(const f32x4*)&os[i][4 * c], *(const f32x4*)&vs[j][4 * c], t);
         }
         P[i][j] = (!a.causal || j <= i) ? s * scale : -INFINITY;
         dS[i][j] = t;
@@ -625,61 +644,66 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
         for (int j = 0; j < Tk; ++j) dS[i][j] = sc[j] * (dp[j] - delta) * scale;
     }
     __syncthreads();
+    // (row, four features) per lane from here on
+    float* dqp = a.dq + (int64_t)b * Tq * a.ld_dq + h * HD;
+    float* dkp = a.dk + (int64_t)b * Tk * a.ld_dkv + h * HD;
+    float* dvp = a.dv + (int64_t)b * Tk * a.ld_dkv + h * HD;
     if (a.rope) {
         // gradients with respect to the ROTATED q / k: computed into the (no longer needed) dO / V tiles, rotated back
         // by the transpose, then stored.  dV first, while dO is still intact.
-        for (int e = lane; e < Tk * HD; e += 64) {
-            const int j = e / HD, d = e - j * HD;
-            float av = 0.f;
-            for (int i = 0; i < Tq; ++i) av = fmaf(P[i][j], os[i][d], av);
-            float* pv = a.dv + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
+        for (int e = lane; e < Tk * H4; e += 64) {
+            const int j = e / H4, c = 4 * (e - j * H4);
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < Tq; ++i) av += P[i][j] * *(const f32x4*)&os[i][c];
+            f32x4* pv = (f32x4*)(dvp + (int64_t)j * a.ld_dkv + c);
             *pv = a.accumulate_kv ? *pv + av : av;
         }
         __syncthreads();
-        for (int e = lane; e < Tq * HD; e += 64) {
-            const int i = e / HD, d = e - i * HD;
-            float acc = 0.f;
-            for (int j = 0; j < Tk; ++j) acc = fmaf(dS[i][j], ks[j][d], acc);
-            os[i][d] = acc;                                   // dQ_rot
+        for (int e = lane; e < Tq * H4; e += 64) {
+            const int i = e / H4, c = 4 * (e - i * H4);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < Tk; ++j) acc += dS[i][j] * *(const f32x4*)&ks[j][c];
+            *(f32x4*)&os[i][c] = acc;                              // dQ_rot
         }
-        for (int e = lane; e < Tk * HD; e += 64) {
-            const int j = e / HD, d = e - j * HD;
-            float ak = 0.f;
-            for (int i = 0; i < Tq; ++i) ak = fmaf(dS[i][j], qs[i][d], ak);
-            vs[j][d] = ak;                                    // dK_rot
+        for (int e = lane; e < Tk * H4; e += 64) {
+            const int j = e / H4, c = 4 * (e - j * H4);
+            f32x4 ak = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < Tq; ++i) ak += dS[i][j] * *(const f32x4*)&qs[i][c];
+            *(f32x4*)&vs[j][c] = ak;                               // dK_rot
         }
         __syncthreads();
         rope_rows<HD>(os, Tq, a.rope_cos, a.rope_sin, -1.f, lane);
         rope_rows<HD>(vs, Tk, a.rope_cos, a.rope_sin, -1.f, lane);
         __syncthreads();
-        for (int e = lane; e < Tq * HD; e += 64) {
-            const int i = e / HD, d = e - i * HD;
-            a.dq[((int64_t)b * Tq + i) * a.ld_dq + h * HD + d] = os[i][d];
+        for (int e = lane; e < Tq * H4; e += 64) {
+            const int i = e / H4, c = 4 * (e - i * H4);
+            *(f32x4*)(dqp + (int64_t)i * a.ld_dq + c) = *(const f32x4*)&os[i][c];
         }
-        for (int e = lane; e < Tk * HD; e += 64) {
-            const int j = e / HD, d = e - j * HD;
-            float* pk = a.dk + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
-            *pk = a.accumulate_kv ? *pk + vs[j][d] : vs[j][d];
+        for (int e = lane; e < Tk * H4; e += 64) {
+            const int j = e / H4, c = 4 * (e - j * H4);
+            f32x4* pk = (f32x4*)(dkp + (int64_t)j * a.ld_dkv + c);
+            const f32x4 v = *(const f32x4*)&vs[j][c];
+            *pk = a.accumulate_kv ? *pk + v : v;
         }
         return;
     }
-    // dQ[i][d] = sum_j dS[i][j] K[j][d]
-    for (int e = lane; e < Tq * HD; e += 64) {
-        const int i = e / HD, d = e - i * HD;
-        float acc = 0.f;
-        for (int j = 0; j < Tk; ++j) acc = fmaf(dS[i][j], ks[j][d], acc);
-        a.dq[((int64_t)b * Tq + i) * a.ld_dq + h * HD + d] = acc;
+    // dQ[i][:] = sum_j dS[i][j] K[j][:]
+    for (int e = lane; e < Tq * H4; e += 64) {
+        const int i = e / H4, c = 4 * (e - i * H4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Tk; ++j) acc += dS[i][j] * *(const f32x4*)&ks[j][c];
+        *(f32x4*)(dqp + (int64_t)i * a.ld_dq + c) = acc;
     }
-    // dK[j][d] = sum_i dS[i][j] Q[i][d] ;  dV[j][d] = sum_i P[i][j] dO[i][d]
-    for (int e = lane; e < Tk * HD; e += 64) {
-        const int j = e / HD, d = e - j * HD;
-        float ak = 0.f, av = 0.f;
+    // dK[j][:] = sum_i dS[i][j] Q[i][:] ;  dV[j][:] = sum_i P[i][j] dO[i][:]
+    for (int e = lane; e < Tk * H4; e += 64) {
+        const int j = e / H4, c = 4 * (e - j * H4);
+        f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < Tq; ++i) {
-            ak = fmaf(dS[i][j], qs[i][d], ak);
-            av = fmaf(P[i][j], os[i][d], av);
+            ak += dS[i][j] * *(const f32x4*)&qs[i][c];
+            av += P[i][j] * *(const f32x4*)&os[i][c];
         }
-        float* pk = a.dk + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
-        float* pv = a.dv + ((int64_t)b * Tk + j) * a.ld_dkv + h * HD + d;
+        f32x4* pk = (f32x4*)(dkp + (int64_t)j * a.ld_dkv + c);
+        f32x4* pv = (f32x4*)(dvp + (int64_t)j * a.ld_dkv + c);
         *pk = a.accumulate_kv ? *pk + ak : ak;
         *pv = a.accumulate_kv ? *pv + av : av;
     }
@@ -687,8 +711,9 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
 
 hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s) {
     if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
-    if (((a.ldq | a.ld_do | a.ldkv) & 3) || (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.d_out) & 15))
-        return hipErrorInvalidValue;  // 16-byte loads of the head slices
+    if (((a.ldq | a.ld_do | a.ldkv | a.ld_dq | a.ld_dkv) & 3) ||
+        (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.d_out | (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) & 15))
+        return hipErrorInvalidValue;  // 16-byte loads / stores of the head slices
     if (a.rope && (a.hd < 32 || !a.rope_cos || !a.rope_sin)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)a.hd);
     const dim3 grid(a.B, a.H);
