@@ -19,6 +19,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
     return v;
 }
+// batched wave reduction: N independent sums advance through the 6 butterfly steps together, so the ~100-cycle
+// ds_bpermute latency of a step is paid once per step instead of once per value
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float t[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], off, 64);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += t[i];
+    }
+}
+
 
 // exact-erf GELU (nn.GELU default).  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding
 // level): one rcp, one exp and a degree-5 Horner chain instead of libm erff's ~40 instructions -- the c_fc

@@ -101,20 +101,6 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 #define MDT_TS_HWID()
 #endif
 
-// batched wave reduction: N independent sums advance through the 6 butterfly steps together, so the ~100-cycle
-// ds_bpermute latency of a step is paid once per step instead of once per value
-template <int N>
-__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float t[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], off, WAVE);
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] += t[i];
-    }
-}
-
 // The enclosing kernel says with KSTEP_PRIO whether a k-step's MFMA block runs at raised issue priority: it pays where
 // loader waves share the SIMDs with the MFMA waves (k_gemm_pipe: mlp.c_proj 37.6 -> 36.1 us) and costs 1-3 % where
 // every wave does both (k_gemm).  -DMDT_NO_KSTEP_PRIO switches it off for A/B runs.
