@@ -489,3 +489,62 @@ def test_goal_sequences_are_sliced_only_where_the_reference_slices():
         assert torch.equal(want, same)
         with pytest.raises(ValueError):
             model(state, noise, goal.expand(-1, n_tok + 2, -1).contiguous(), sig)
+
+
+def test_batched_parameter_upload_matches_the_per_parameter_path():
+    """mdt_load_params (every parameter in one launch; host-resident sources fall back to the staged per-parameter copy) must
+    leave exactly the images mdt_load_param leaves: same sampled actions, bit for bit, from two handles loaded either way --
+    with and without the W^T images of the training path, and with one source on the host."""
+    import ctypes as C
+    from mdt_policy_amd import _lib
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx = load_fixture("g1_tiny_mdtv.npz")
+    P = params_of(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sig = sampling().get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    lib = _lib.load()
+
+    def actions(loader, train):
+        model = GCDenoiser(cfg_of(meta), sigma_data=0.5)
+        model.load_state_dict(P)
+        model = model.cuda().eval()
+        eng = model.inner_model.hip_engine(0.5, state)
+        if train:
+            eng.train_prepare()
+        stream = torch.cuda.current_stream().cuda_stream
+        named = [("inner_model." + n, p.detach()) for n, p in model.inner_model.named_parameters() if "inner_model." + n in eng.expected]
+        keep = loader(eng, named, stream)
+        eng._uploaded = {k: (p.data_ptr(), p._version) for k, p in
+                         (("inner_model." + n, p) for n, p in model.inner_model.named_parameters()) if k in eng.expected}
+        with torch.no_grad():
+            out = sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, sig).clone()
+        torch.cuda.synchronize()
+        del keep
+        return out
+
+    def one_by_one(eng, named, stream):
+        for k, t in named:
+            _lib.check(lib.mdt_load_param(eng.handle, k.encode(), t.data_ptr(), t.numel(), stream))
+        return named
+
+    def batched(eng, named, stream):
+        named = [(k, (t.cpu() if i == 3 else t)) for i, (k, t) in enumerate(named)]  # one host-resident source
+        n = len(named)
+        names = (C.c_char_p * n)(*[k.encode() for k, _ in named])
+        srcs = (C.c_void_p * n)(*[t.data_ptr() for _, t in named])
+        numels = (C.c_int64 * n)(*[t.numel() for _, t in named])
+        _lib.check(lib.mdt_load_params(eng.handle, n, names, srcs, numels, stream))
+        torch.cuda.synchronize()
+        return named
+
+    for train in (False, True):
+        a, b = actions(one_by_one, train), actions(batched, train)
+        assert torch.equal(a, b), f"train images = {train}"
+        assert_close(a.cpu(), fx["actions"], what="actions")
+    # an unknown name is refused, nothing is launched
+    eng = GCDenoiser(cfg_of(meta), sigma_data=0.5).cuda().inner_model.hip_engine(0.5, state)
+    t = torch.zeros(4, device="cuda")
+    names = (C.c_char_p * 1)(b"inner_model.no_such.weight")
+    srcs = (C.c_void_p * 1)(t.data_ptr())
+    numels = (C.c_int64 * 1)(4)
+    assert lib.mdt_load_params(eng.handle, 1, names, srcs, numels, torch.cuda.current_stream().cuda_stream) != 0
