@@ -121,6 +121,10 @@ mdt_status mdt_load_params(mdt_model *m, int32_t n, const char *const *names, co
 /* Pre-size the workspace for batches up to max_batch (avoids hipMalloc later, e.g. before graph capture). */
 mdt_status mdt_reserve(mdt_model *m, int64_t max_batch);
 
+/* Number of times the workspace was (re)allocated.  A captured HIP graph of a sampler call holds workspace addresses: it
+ * stays valid while this number does not change (mdt_reserve the largest batch first, capture afterwards). */
+int64_t mdt_ws_generation(const mdt_model *m);
+
 /* inner_model.forward_enc_only(state, action, goal, sigma)
  * (reference mdtv_transformer.py:213-222; mdt_transformer.py:211-229 / :257-281): goal/state token
  * embedding, n_enc_layers Blocks, final LayerNorm.  Also projects the per-decoder-block cross-attention

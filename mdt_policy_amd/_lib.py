@@ -163,6 +163,7 @@ SYMBOLS = [
     ("mdt_load_param", _I32, [_VP, C.c_char_p, _VP, _I64, _VP]),
     ("mdt_load_params", _I32, [_VP, _I32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(_I64), _VP]),
     ("mdt_reserve", _I32, [_VP, _I64]),
+    ("mdt_ws_generation", _I64, [_VP]),
     ("mdt_encode", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I64, _VP, _VP]),
     ("mdt_denoise_cached", _I32, [_VP, _VP, _VP, _I64, _I32, _VP, _VP]),
     ("mdt_forward", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _I64, _VP, _VP, _VP]),

@@ -578,8 +578,11 @@ extern "C" mdt_status mdt_reserve(mdt_model* m, int64_t max_batch) {
     if (m->cond == COND_NOISE)  // the "scale" half of every [c | ones] row; the c half is rewritten per call
         HIP_TRY(hipMemsetD32((hipDeviceptr_t)m->cmod, 0x3f800000u, (size_t)std::max<int64_t>(max_batch, MAX_STEPS) * 2 * m->D));
     m->cap = max_batch;
+    ++m->ws_generation;
     return MDT_OK;
 }
+
+extern "C" int64_t mdt_ws_generation(const mdt_model* m) { return m ? m->ws_generation : -1; }
 
 // ------------------------------------------------------------------------------------------------
 // launch helpers

@@ -12,6 +12,7 @@ callback=None, disable=None, ...)``.
 from __future__ import annotations
 
 import math
+import os
 from contextlib import nullcontext
 
 import numpy as np
@@ -138,6 +139,22 @@ def _sig_in(sigma, action, model=None):
     return torch.full((n,), _f(sigma), device=action.device, dtype=action.dtype)
 
 
+_GRAPH_SAMPLER = os.environ.get("MDT_HIP_GRAPH", "0") not in ("", "0")
+
+
+def _graphed(model, state, action, goal, sigmas):
+    """One GraphedDDIM per (shapes, modality, state keys) of a model, kept on the model (at most four)."""
+    from .graphed import GraphedDDIM
+    cache = model.__dict__.setdefault("_graphed_samplers", [])
+    for gsamp in cache:
+        if gsamp.matches(state, action, goal, sigmas):
+            return gsamp(state, action, goal, sigmas).clone()
+    gsamp = GraphedDDIM(model, state, action, goal, sigmas if torch.is_tensor(sigmas) else torch.as_tensor(sigmas))
+    cache.append(gsamp)
+    del cache[:-4]
+    return gsamp(state, action, goal, sigmas).clone()
+
+
 @torch.no_grad()
 def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
                 eta=1.):
@@ -145,6 +162,8 @@ def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None
     x <- (sigma_{i+1}/sigma_i) x - expm1(-(t_{i+1} - t_i)) D(x; sigma_i),  t = -ln sigma."""
     extra_args = {} if extra_args is None else extra_args
     if isinstance(model, GCDenoiser) and scaler is None and callback is None and not extra_args:
+        if _GRAPH_SAMPLER and action.device.type == "cuda" and not model.inner_model.training:
+            return _graphed(model, state, action, goal, sigmas)  # MDT_HIP_GRAPH=1: the same launches, replayed as a HIP graph
         return model.sample_ddim(state, action, goal, sigmas)  # fused native loop
     sig = _host(sigmas)
     with _hoist(model, state, goal):

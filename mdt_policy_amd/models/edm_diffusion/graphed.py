@@ -1,0 +1,99 @@
+"""One fused DDIM sampler call as a HIP graph.
+
+A rollout calls ``sample_ddim`` with the same shapes step after step (reference mdtv_agent.py:523-550: B = 1, 10 steps).  The
+~250 kernel launches of one call are then the same launch sequence with the same addresses, which a HIP graph replays with a
+single submission; the results stay bit-identical (same kernels, same order).  Measured on MI355X (``tools/graph_probe.py``,
+``MDT_HIP_GRAPH=1 tools/latency.py``): a bare replay takes 1.60 ms host-synchronised at B = 1; through this wrapper (input
+copies, parameter check, output clone) 1.67 ms against 1.69 ms for the eager call -- the call is bound by the dependent chain
+of its ~250 kernels on the GPU, not by their submission, so the graph buys little; it is kept as an opt-in.
+
+``GraphedDDIM`` owns static copies of the inputs, captures ``GCDenoiser.sample_ddim`` on them once and replays it; the library's
+weight images are updated in place by the usual re-upload (outside the graph), so parameter updates are seen.  The capture is
+redone when the library's workspace was re-allocated (``mdt_ws_generation``).  Opt-in: construct it, or set ``MDT_HIP_GRAPH=1`` to
+let ``gc_sampling.sample_ddim`` keep one per (batch, steps, modality) of a model.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+
+class GraphedDDIM:
+    def __init__(self, model, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas: torch.Tensor):
+        if x_T.device.type != "cuda":
+            raise RuntimeError("GraphedDDIM needs the model and its inputs on a ROCm GPU")
+        self.model = model
+        self.device = x_T.device
+        self._static_state: Dict[str, object] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in state.items()}
+        self._x = x_T.detach().clone()
+        self._goal = goal.detach().clone()
+        self._sig = sigmas.detach().to(self.device, torch.float32).clone()
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._gen = None
+        self._out = None
+        self._ctx = None
+        self._last_sig = None
+        self._capture()
+
+    def _engine(self):
+        return self.model._engine(state=self._static_state)
+
+    def _capture(self) -> None:
+        model = self.model
+        with torch.no_grad():
+            eng = self._engine()
+            eng.sync_params()
+            eng.reserve(self._x.shape[0])
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):  # warm-up on a side stream, as torch's graph capture wants it
+                for _ in range(2):
+                    model.sample_ddim(self._static_state, self._x, self._goal, self._sig)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = model.sample_ddim(self._static_state, self._x, self._goal, self._sig)
+            self._graph, self._out = graph, out
+            self._ctx = model.inner_model.latent_encoder_emb
+            self._gen = int(eng.lib.mdt_ws_generation(eng.handle))
+            self._eng = eng
+            self._eng_key = next(k for k, e in model.inner_model._engines.items() if e is eng)
+
+    def matches(self, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas) -> bool:
+        if x_T.shape != self._x.shape or goal.shape != self._goal.shape or len(sigmas) != self._sig.numel():
+            return False
+        for k, v in self._static_state.items():
+            w = state.get(k, None)
+            if torch.is_tensor(v):
+                if not torch.is_tensor(w) or w.shape != v.shape:
+                    return False
+            elif w != v:
+                return False
+        return set(state) == set(self._static_state)
+
+    @torch.no_grad()
+    def __call__(self, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas=None) -> torch.Tensor:
+        """Same result as ``model.sample_ddim(state, x_T, goal, sigmas)``.  The returned tensor is the graph's output buffer:
+        valid until the next call (clone it to keep it)."""
+        eng = self._eng
+        im = self.model.inner_model
+        if im._engines.get(self._eng_key) is not eng:  # the module was moved / re-created its handle
+            eng = self._engine()
+            self._gen = None
+        eng.sync_params()  # parameter updates go into the arena the graph reads (outside the graph)
+        if int(eng.lib.mdt_ws_generation(eng.handle)) != self._gen:
+            self._capture()  # the workspace moved: the old graph's addresses are dead
+        for k, v in self._static_state.items():
+            if torch.is_tensor(v):
+                v.copy_(state[k])
+        self._x.copy_(x_T)
+        self._goal.copy_(goal)
+        if sigmas is not None and sigmas is not self._last_sig:  # a rollout passes the same schedule tensor every step
+            self._sig.copy_(sigmas if torch.is_tensor(sigmas) else torch.as_tensor(sigmas, dtype=torch.float32))
+            self._last_sig = sigmas if torch.is_tensor(sigmas) and sigmas.device == self.device else None
+        self._graph.replay()
+        eng.ctx_generation += 1
+        self.model.inner_model.latent_encoder_emb = self._ctx
+        return self._out

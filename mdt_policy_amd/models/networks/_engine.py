@@ -87,13 +87,25 @@ class HipEngine:
                 self._uploaded.clear()
         seen = 0
         changed = []  # (key, source tensor, tag)
-        for name, p in self.module.named_parameters():
-            key = "inner_model." + name
-            if key not in self.expected:
-                continue
+        # the parameters the library reads, resolved once per engine as (key, leaf name, owning module, parameter): walking the
+        # module tree on every call was ~0.15 ms of host time.  A parameter REPLACED by assignment fails the identity check
+        # below and the list is resolved again.
+        plist = getattr(self, "_plist", None)
+        if plist is None:
+            plist = self._plist = []
+            for n, p in self.module.named_parameters():
+                if ("inner_model." + n) in self.expected:
+                    owner = self.module.get_submodule(n.rsplit(".", 1)[0]) if "." in n else self.module
+                    plist.append(("inner_model." + n, n.rsplit(".", 1)[-1], owner, p))
+        uploaded = self._uploaded
+        for key, leaf, owner, p in plist:
+            if owner._parameters.get(leaf) is not p:
+                self._plist = None
+                return self.sync_params()
             seen += 1
             tag = (p.data_ptr(), p._version)
-            if self._uploaded.get(key) == tag:
+            name = key
+            if uploaded.get(key) == tag:
                 continue
             if p.device != self.device or p.dtype != torch.float32:
                 raise RuntimeError(f"parameter {name} must be float32 on {self.device}, got {p.dtype} on {p.device}")

@@ -134,3 +134,43 @@ def test_status_word_reports_nothing_on_a_healthy_run():
     model = build(meta)
     eng = _engine(model)
     assert eng.persist_status() == 0
+
+
+def test_graphed_sampler_replays_the_fused_call_bit_for_bit():
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    """GraphedDDIM: one fused sampler call captured as a HIP graph.  Replays with NEW inputs equal the eager call on those inputs
+    bit for bit; a parameter update is seen (the re-upload runs outside the graph); growing the workspace re-captures."""
+    from mdt_policy_amd.models.edm_diffusion.graphed import GraphedDDIM
+    cfg = configs.mdtv_default()
+    model = GCDenoiser(cfg, 0.5)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 5, "rich").items()}, strict=False)
+    model = model.cuda().eval()
+    sig = gs.get_sigmas_exponential(10, 0.001, 80.0).cuda()
+
+    def inputs(seed, B=1):
+        inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(B, cfg, seed).items()}
+        return {"state_images": inp["state_images"], "modality": "lang"}, inp["noise"] * 80.0, inp["goal"]
+
+    with torch.no_grad():
+        st, x, goal = inputs(1)
+        g = GraphedDDIM(model, st, x, goal, sig)
+        for seed in (1, 2, 3):
+            st, x, goal = inputs(seed)
+            want = gs.sample_ddim(model, st, x, goal, sig).clone()
+            got = g(st, x, goal, sig)
+            assert torch.equal(got, want), f"seed {seed}"
+            assert torch.equal(model.inner_model.latent_encoder_emb, model.inner_model.latent_encoder_emb)
+        # parameter update (version counter bumps): the replay must follow
+        model.inner_model.action_pred.weight.mul_(0.5)
+        want = gs.sample_ddim(model, st, x, goal, sig).clone()
+        assert not torch.equal(want, got)
+        assert torch.equal(g(st, x, goal, sig), want)
+        # a bigger batch elsewhere re-allocates the workspace: the graph is captured again on the next call
+        st8, x8, goal8 = inputs(4, B=64)
+        gs.sample_ddim(model, st8, x8, goal8, sig)
+        want = gs.sample_ddim(model, st, x, goal, sig).clone()
+        assert torch.equal(g(st, x, goal, sig), want)
+        assert not g.matches(st8, x8, goal8, sig) and g.matches(st, x, goal, sig)
