@@ -347,3 +347,36 @@ def test_ctypes_prototypes_mirror_the_headers():
     assert set(protos) == set(table)
     for n, kinds in protos.items():
         assert table[n] == kinds, (n, table[n], kinds)
+
+
+def test_optimizer_hook_marks_only_the_modules_that_own_a_stepped_parameter():
+    """utils/weight_cache.py: torch's fused optimizers do not bump parameter version counters, so an optimizer post-step hook marks
+    the registered facade modules dirty -- those that own one of the stepped parameters, and only those."""
+    import torch
+    from mdt_policy_amd.utils import weight_cache
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(3))
+            self.dirty = 0
+            weight_cache.track(self)
+
+        def mark_dirty(self):
+            self.dirty += 1
+
+    a, b = Holder(), Holder()
+    a.w.grad, b.w.grad = torch.ones(3), torch.ones(3)
+    torch.optim.SGD(a.parameters(), lr=0.1).step()
+    assert (a.dirty, b.dirty) == (1, 0)
+    torch.optim.AdamW(list(a.parameters()) + list(b.parameters()), lr=0.1).step()
+    assert (a.dirty, b.dirty) == (2, 1)
+    other = torch.nn.Parameter(torch.zeros(2))
+    other.grad = torch.ones(2)
+    torch.optim.SGD([other], lr=0.1).step()
+    assert (a.dirty, b.dirty) == (2, 1)
+    del a  # tracked weakly: a dead module is simply gone
+    import gc
+    gc.collect()
+    torch.optim.SGD(b.parameters(), lr=0.1).step()
+    assert b.dirty == 2
