@@ -27,7 +27,7 @@ def run(M, N, K, geos):
         res.append(f"g{geo} {us:6.1f}us {2*M*N*K/us/1e6:5.1f}TF")
     lib.mdt_op_set_gemm_geometry(0)
     print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(res), flush=True)
-geos = [0, 1, 2, 3, 5, 7, 8, 9]
+geos = [int(x) for x in os.environ.get("GEOS", "0,1,2,3,5,7,8,9").split(",")]
 for (M, N, K) in [(10240, 384, 384), (10240, 1152, 384), (10240, 1536, 384), (10240, 384, 1536), (4096, 384, 384), (4096, 1152, 384), (4096, 1536, 384), (4096, 384, 1536),
                   (104448, 192, 192), (104448, 576, 192), (104448, 1536, 192), (104448, 192, 768), (104448, 192, 576), (104448, 192, 1536)]:
     run(M, N, K, geos)
