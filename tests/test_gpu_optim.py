@@ -130,3 +130,47 @@ def test_torch_fused_optimizer_steps_are_seen_by_the_weight_cache():
     st = {"state_images": inp["state_images"].cpu(), "modality": "lang"}
     want = O.denoise(P, cfg, st, x.cpu(), inp["goal"].cpu(), li["sigma"].cpu(), 0.5, "mdtv")
     assert_close(got.cpu(), want, what="forward after two fused optimizer steps")
+
+
+@pytest.mark.gpu
+def test_five_training_steps_follow_the_oracle_trajectory():
+    """End to end: five optimizer steps of the HIP path (loss forward, HIP backward, FusedAdamW, batched re-upload) against the
+    same five steps taken on the CPU with float64 autograd through the oracle and torch.optim.AdamW -- the loss of every step
+    and every parameter after the last one."""
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    from mdt_policy_amd.optim import FusedAdamW
+    from oracle import mdt_oracle as O
+    cfg = configs.mdtv_tiny()
+    torch.manual_seed(0)
+    model = GCDenoiser(cfg, 0.5)
+    P = {k: v.detach().clone().double().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    B = 6
+    inp = {k: torch.from_numpy(v) for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
+    li = {k: torch.from_numpy(v) for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
+    state = {"state_images": inp["state_images"].cuda(), "modality": "lang"}
+    st64 = {"state_images": inp["state_images"].double(), "modality": "lang"}
+    opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.05)
+    trainable = [v for k, v in P.items() if v.requires_grad and not k.endswith("rotary_pos_emb.freqs")]
+    ref_opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=0.05)
+    for step in range(5):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model.loss(state, li["actions"].cuda(), inp["goal"].cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
+        loss.backward()
+        opt.step()
+        ref_opt.zero_grad(set_to_none=True)
+        l64, _ = O.loss(P, cfg, st64, li["actions"].double(), inp["goal"].double(), li["noise_train"].double(),
+                        li["sigma"].double(), arch="mdtv")
+        l64.backward()
+        ref_opt.step()
+        assert abs(loss.item() - l64.item()) <= 2e-3 * abs(l64.item()), f"step {step}: {loss.item()} vs {l64.item()}"
+    got = model.state_dict()
+    for k, v in P.items():
+        if not v.requires_grad or v.grad is None:
+            continue  # parameters the forward does not read (pos_emb, proprio_emb, the other goal embedder) only decay
+        # Adam's update has size lr whatever the gradient's: an element whose gradient is rounding noise may step the other way
+        # (5 steps x lr = 5e-3 at most); everything else must agree to fp32 accuracy
+        d = (got[k].cpu().double() - v.detach()).abs()
+        assert float(d.max()) <= 5.1e-3, k
+        assert float((d > 2e-5 + 2e-3 * v.detach().abs()).double().mean()) <= 2e-3, f"{k}: too many elements off"
