@@ -14,15 +14,33 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p;
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
+// Wave-wide sums without LDS-crossbar round trips (ds_bpermute, ~100 cycles per butterfly step): DPP lane swaps inside a
+// 16-lane row (xor 1, xor 2 as quad permutes, then the half-row and full-row mirrors leave the row's sum in every lane), then
+// row_bcast:15 / row_bcast:31 carry the running total across the four rows into lane 63, which v_readlane hands to everyone.
+// MDT_SHFL_REDUCE (tuning build) restores the butterfly.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_get(float v) {  // lanes of rows outside ROWS receive 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef MDT_SHFL_REDUCE
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
     return v;
+#else
+    v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_get<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
+    v += dpp_get<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_get<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
-// batched wave reduction: N independent sums advance through the 6 butterfly steps together, so the ~100-cycle
-// ds_bpermute latency of a step is paid once per step instead of once per value
+// N independent sums advancing together (the steps of different sums interleave: no step waits for its own result)
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#ifdef MDT_SHFL_REDUCE
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         float t[N];
@@ -31,6 +49,22 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] += t[i];
     }
+#else
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_get<0xB1, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_get<0x4E, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_get<0x141, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_get<0x140, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_get<0x142, 0xa>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_get<0x143, 0xc>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
+#endif
 }
 
 
