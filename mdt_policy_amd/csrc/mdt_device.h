@@ -37,6 +37,45 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 #endif
 }
+// the same for each 32-lane half of the wave (two rows of activations normalised side by side): every lane receives the sum
+// of its own half
+__device__ __forceinline__ float half_wave_sum(float v) {
+#ifdef MDT_SHFL_REDUCE
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+#else
+    v += dpp_get<0xB1, 0xf>(v);
+    v += dpp_get<0x4E, 0xf>(v);
+    v += dpp_get<0x141, 0xf>(v);
+    v += dpp_get<0x140, 0xf>(v);
+    v += dpp_get<0x142, 0xa>(v);  // lanes of rows 1 / 3 now hold the sums of lanes 0..31 / 32..63
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return (threadIdx.x & 32) ? hi : lo;
+#endif
+}
+// wave-wide maximum, same route (rows outside a step's mask keep their own value)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_keep(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float wave_max(float v) {
+#ifdef MDT_SHFL_REDUCE
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+#else
+    v = fmaxf(v, dpp_keep<0xB1, 0xf>(v));
+    v = fmaxf(v, dpp_keep<0x4E, 0xf>(v));
+    v = fmaxf(v, dpp_keep<0x141, 0xf>(v));
+    v = fmaxf(v, dpp_keep<0x140, 0xf>(v));
+    v = fmaxf(v, dpp_keep<0x142, 0xa>(v));
+    v = fmaxf(v, dpp_keep<0x143, 0xc>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
+}
 // N independent sums advancing together (the steps of different sums interleave: no step waits for its own result)
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_row_lse(const float* __restrict__ S, in
     const float sc = expf(logit_scale[0]);
     float mx = -INFINITY;
     for (int j = lane; j < B; j += 64) mx = fmaxf(mx, sc * S[(int64_t)row * ld + j]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     float sum = 0.f;
     for (int j = lane; j < B; j += 64) sum += expf(sc * S[(int64_t)row * ld + j] - mx);
     sum = wave_sum(sum);

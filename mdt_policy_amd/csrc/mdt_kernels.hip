@@ -1068,8 +1068,7 @@ __global__ __launch_bounds__(256) void k_attn_long(const float* __restrict__ q, 
         float* row = S + qi * Tkp;
         float mx = -INFINITY;
         for (int f = lane; f < Tk; f += 64) mx = fmaxf(mx, row[f]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mx = wave_max(mx);
         float sum = 0.f;
         for (int f = lane; f < Tk; f += 64) {
             const float e = expf(row[f] - mx);

@@ -456,8 +456,7 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
             v[i] = sel4(c4 < n4, v[i], zero4);
             sum += hsum4(v[i]);
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        sum = half_wave_sum(sum);
         const float mean = sum / (float)a.K;
         float sq = 0.f;
 #pragma unroll
@@ -465,8 +464,7 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
             const int c4 = l32 + 32 * i;
             if (c4 < n4) sq += hsq4(v[i] - mean);
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        sq = half_wave_sum(sq);
         if (l32 == 0) { s_mean[r] = mean; s_rstd[r] = 1.0f / sqrtf(sq / (float)a.K + 1e-5f); }
         __syncthreads();
     }

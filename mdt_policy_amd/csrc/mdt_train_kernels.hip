@@ -816,8 +816,7 @@ __global__ __launch_bounds__(256) void k_narrow_out(const float* __restrict__ G,
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         if (a < A) {
-            float v = acc[a];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const float v = wave_sum(acc[a]);
             if (lane == 0) out[(int64_t)m * A + a] = v;
         }
     }
@@ -1000,8 +999,7 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd(const float* __restrict__
         float* dr = dS + qi * Tkp;
         float mx = -INFINITY;
         for (int f = lane; f < Tk; f += 64) mx = fmaxf(mx, pr[f]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mx = wave_max(mx);
         float sum = 0.f;
         for (int f = lane; f < Tk; f += 64) { const float e = expf(pr[f] - mx); pr[f] = e; sum += e; }
         sum = wave_sum(sum);
