@@ -62,37 +62,54 @@ def build_model(device):
 
 
 def time_dominant_kernel(device, M):
-    """The fused MFMA GEMM is >95 % of the algorithmic FLOPs; time its largest instance (MLP c_fc: LayerNorm +
-    adaLN-modulate prologue, N=1536, K=384, GELU epilogue) alone with HIP events on the launch stream."""
+    """The dominant kernel of the path: the fused MLP sublayer k_mlp (LayerNorm + adaLN-modulate prologue -> c_fc (N = 1536,
+    K = 384) -> GELU -> c_proj (N = 384, K = 1536) -> gate, one launch, 40 launches per sampler call, a third of its FLOPs),
+    timed alone through the op-level C ABI with HIP events on the launch stream."""
     from mdt_policy_amd import _lib
     lib = _lib.load()
     D, N = 384, 1536
     g = torch.Generator().manual_seed(0)
     A = torch.randn(M, D, generator=g).to(device)
-    W = (torch.randn(N, D, generator=g) * 0.02).to(device)
+    W1 = (torch.randn(N, D, generator=g) * 0.02).to(device)
+    W2 = (torch.randn(D, N, generator=g) * 0.02).to(device)
     lw = torch.ones(D, device=device)
     mod = torch.randn(6 * D, generator=g).to(device)
-    P = torch.zeros(N * D, device=device)
-    out = torch.empty(M, N, device=device)
+    P1, P2 = torch.zeros(N * D, device=device), torch.zeros(N * D, device=device)
+    S = 4 * D // 512
+    parts = torch.empty(S, M, D, device=device)
     s = torch.cuda.current_stream(device).cuda_stream
-    _lib.check(lib.mdt_op_pack_weight(W.data_ptr(), N, D, P.data_ptr(), 0, N, s))
-    a = _lib.GemmArgs()
-    a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = A.data_ptr(), D, P.data_ptr(), out.data_ptr(), N, M, N, D
-    a.ln, a.ln_w, a.mod, a.mod_stride, a.shift_off, a.scale_off = 1, lw.data_ptr(), mod.data_ptr(), 0, 3 * D, 4 * D
-    a.rows_per_sample, a.act, a.gate_off, a.gin, a.gout, a.goff = 10, _lib.ACT["gelu"], -1, 1, 1, 0
+    _lib.check(lib.mdt_op_pack_weight(W1.data_ptr(), N, D, P1.data_ptr(), 0, N, s))
+    _lib.check(lib.mdt_op_pack_weight(W2.data_ptr(), D, N, P2.data_ptr(), 0, D, s))
+    f, p = _lib.GemmArgs(), _lib.GemmArgs()
+    f.A, f.lda, f.Wp, f.M, f.N, f.K = A.data_ptr(), D, P1.data_ptr(), M, N, D
+    p.A, p.lda, p.Wp, p.M, p.N, p.K, p.ldo = A.data_ptr(), D, P2.data_ptr(), M, D, N, D
+    f.ln, f.ln_w, f.act = 1, lw.data_ptr(), _lib.ACT["gelu"]
+    f.mod = p.mod = mod.data_ptr()
+    f.mod_stride = p.mod_stride = 0
+    f.shift_off, f.scale_off, f.gate_off, p.shift_off, p.scale_off, p.gate_off = 3 * D, 4 * D, -1, -1, -1, 5 * D
+    for a in (f, p):
+        a.rows_per_sample, a.gin, a.gout, a.goff = 10, 1, 1, 0
+    n = C.c_int32(0)
+
+    def launch():
+        _lib.check(lib.mdt_op_mlp(C.byref(f), C.byref(p), parts.data_ptr(), M * D, C.byref(n), s))
     for _ in range(10):
-        _lib.check(lib.mdt_op_gemm(C.byref(a), s))
+        launch()
     reps = 200
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        _lib.check(lib.mdt_op_gemm(C.byref(a), s))
+        launch()
     e1.record()
     torch.cuda.synchronize(device)
     us = e0.elapsed_time(e1) * 1e3 / reps
-    tf = 2.0 * M * N * D / (us * 1e-6) / 1e12
-    return {"name": f"k_gemm LN+mod->c_fc->GELU ({M}x{N}x{D})", "avg_us": round(us, 2), "achieved": round(tf, 2),
-            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+    flops = 2.0 * M * N * D * 2
+    tf = flops / (us * 1e-6) / 1e12
+    # algorithmic bytes of one launch (SURVEY.md 8(d) accounting): rows read once, both weight images once, the S slabs written
+    alg = 4 * (M * D + 2 * N * D + S * M * D)
+    return {"name": f"k_mlp LN+mod -> c_fc -> GELU -> c_proj -> gate ({M} rows, d={D}, hidden {N}: {flops / 1e9:.2f} GFLOP per launch)",
+            "avg_us": round(us, 2), "achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            "algorithmic_bytes_per_launch": alg}
 
 
 def other_configs(device):
@@ -258,15 +275,21 @@ def cpu_baseline(cfg, P, batch, n_denoise, budget_s, threads, only=None):
                 "seconds": round(best, 3), "reps": reps}
 
     if only is not None:  # child process: exactly one leg
+        if len(only) > 3 and only[3]:  # worker of the all-host-threads leg: warm up, report, wait for "go", one timed run
+            torch.set_num_threads(only[0])
+            run(16, bool(only[1]))
+            print("READY", flush=True)
+            sys.stdin.readline()
+            return {"seconds": run(int(only[3]), bool(only[1])), "sample_batch": int(only[3])}
         return leg(only[0], bool(only[1]), float(only[2]))
     import subprocess
-    plan = [(threads, False), (ncpu, False), (1, False), (threads, True), (1, True)]
+    plan = [(threads, False), (1, False), (threads, True), (1, True)]
     legs, seen = [], set()
     for nt, hoist in plan:
         if (nt, hoist) in seen:
             continue
         seen.add((nt, hoist))
-        per = budget_s / len(plan)
+        per = budget_s / (len(plan) + 1)
         # every leg runs in its own process under a hard time limit: with all host threads the oracle's tiny matrices
         # spend their time in thread barriers and a single call can take minutes -- such a leg is reported as unfinished
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{nt},{int(hoist)},{per}", "--batch", str(batch),
@@ -278,6 +301,50 @@ def cpu_baseline(cfg, P, batch, n_denoise, budget_s, threads, only=None):
             legs.append({"threads": nt, "mode": "hoisted" if hoist else "as_written", "value": None,
                          "note": f"did not finish within {2.0 * per + 20:.0f} s ({type(e).__name__})"})
         log(f"cpu baseline leg {legs[-1]}")
+    # ALL host threads.  One process with every thread spends its time in thread barriers on these small
+    # matrices (a B = 16 probe at 256 threads does not finish in 30 s); the way this workload uses a whole host is the way it
+    # uses N GPUs: shard the batch.  P worker processes of `threads` threads each (P * threads = host threads) sample their
+    # own shard at the same time; value = all chunks / the wall time from the common start to the last worker's finish.
+    nproc = ncpu // max(1, threads)
+    if nproc >= 2 and legs[0].get("value"):
+        shard = max(16, min(batch, int(legs[0]["value"] * 4) // 16 * 16))  # ~4 s per worker at the single-process rate
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{threads},0,0,{shard}", "--batch", str(batch),
+               "--denoise-steps", str(n_denoise)]
+        procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                  env=dict(os.environ, HIP_VISIBLE_DEVICES="")) for _ in range(nproc)]
+        entry = {"threads": ncpu, "mode": "as_written", "processes": nproc, "threads_per_process": threads, "sample_batch": shard * nproc}
+        try:
+            import select
+            deadline = time.perf_counter() + 120.0
+            for pr in procs:  # every worker has imported torch and run its warm-up
+                while True:
+                    if not select.select([pr.stdout], [], [], max(0.0, deadline - time.perf_counter()))[0]:
+                        raise TimeoutError("workers not ready within 120 s")
+                    line = pr.stdout.readline()
+                    if line.startswith("READY") or not line:
+                        break
+            t0 = time.perf_counter()
+            for pr in procs:
+                pr.stdin.write("go\n"); pr.stdin.flush()
+            outs = []
+            for pr in procs:
+                if not select.select([pr.stdout], [], [], max(0.0, t0 + 120.0 - time.perf_counter()))[0]:
+                    raise TimeoutError("a worker did not finish within 120 s")
+                outs.append(json.loads(pr.stdout.readline()))
+            wall = time.perf_counter() - t0
+            entry.update(value=round(shard * nproc / wall, 2), seconds=round(wall, 3), reps=1,
+                         slowest_worker_s=round(max(o["seconds"] for o in outs), 3))
+        except Exception as e:
+            entry.update(value=None, note=f"{type(e).__name__}: {e}")
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        legs.insert(1, entry)
+        log(f"cpu baseline leg {entry}")
+    else:
+        legs.insert(1, {"threads": ncpu, "mode": "as_written", "value": legs[0].get("value"),
+                        "note": f"host has {ncpu} threads: the {threads}-thread leg IS the all-threads leg"})
     head = legs[0]
     return {"value": head["value"], "unit": "action-chunks/s", "cores": head["threads"], "kind": "port",
             "sample": f"oracle sample_ddim, B={head['sample_batch']}, {n_denoise} steps, fp32, encoder re-run every step "
@@ -290,12 +357,13 @@ def main():
     args = parse()
     if args.cpu_leg:  # child of cpu_baseline(): CPU only, no GPU, no distributed
         from mdt_policy_amd import configs, synthetic
-        nt, hoist, budget = args.cpu_leg.split(",")
+        nt, hoist, budget, *rest = args.cpu_leg.split(",")
+        shard = int(rest[0]) if rest else 0
         cfg = configs.mdtv_default()
         from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
         shapes = [(k, tuple(v.shape)) for k, v in GCDenoiser(cfg, sigma_data=0.5).state_dict().items()]
         P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=0, profile="init").items()}
-        print(json.dumps(cpu_baseline(cfg, P, args.batch, args.denoise_steps, float(budget), int(nt), only=(int(nt), int(hoist), float(budget)))), flush=True)
+        print(json.dumps(cpu_baseline(cfg, P, args.batch, args.denoise_steps, float(budget), int(nt), only=(int(nt), int(hoist), float(budget), shard))), flush=True)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -362,6 +430,25 @@ def main():
         wall, gpu_s = t[0].item(), t[1].item()
     assert torch.isfinite(out).all()
     log(f"timed {args.steps} steps: wall {wall:.4f}s gpu {gpu_s:.4f}s")
+    # spread (median of >= 50 timed iterations): the same step again, every call between its own pair of
+    # HIP events on the launch stream; `value` stays the contract's K-step mean, this tells box-to-box noise from change
+    n_spread = max(50, args.steps)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_spread)]
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize(device)
+    per_call = torch.tensor(sorted(a.elapsed_time(b) for a, b in evs), dtype=torch.float64)
+    if dist is not None:
+        dist.barrier()
+        pc = per_call.to(device)
+        dist.all_reduce(pc, op=dist.ReduceOp.MAX)  # rank-wise order statistics: the slowest rank at every quantile
+        per_call = pc.cpu()
+    q = lambda f: float(per_call[min(n_spread - 1, int(round(f * (n_spread - 1))))])
+    spread = {"calls": n_spread, "median_ms": round(q(0.5), 4), "p10_ms": round(q(0.1), 4), "p90_ms": round(q(0.9), 4),
+              "min_ms": round(float(per_call[0]), 4), "max_ms": round(float(per_call[-1]), 4), "mean_ms": round(float(per_call.mean()), 4),
+              "what": "per-call HIP-event times of one more run of the same step (each call bracketed on the launch stream)"}
     gather_ok = None
     if dist is not None and os.environ.get("MDT_BENCH_VERIFY_GATHER") == "1":
         # every rank checks the gathered tensor: shape (world * B, Ta, A) and block r == rank r's own actions
@@ -387,6 +474,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "median_ms": spread["median_ms"], "p10_ms": spread["p10_ms"], "p90_ms": spread["p90_ms"],
+            "value_at_median": round(B * world / (spread["median_ms"] * 1e-3), 1),
+            "spread": spread,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -413,13 +503,13 @@ def main():
             log("dominant kernel timed")
             # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc pass of the same kernel and shape (profiles/)
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_kernel_pmc.json")
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_dominant_kernel_pmc.json")
             if B == 256 and os.path.exists(pmc):
                 with open(pmc) as f:
                     j = json.load(f)
                 res["roofline"]["traffic"] = j["hbm_side_bytes_per_launch"]
                 res["roofline"]["traffic_scope"] = ("bytes per launch of the dominant kernel (TCC_EA0 read x128 B + write "
-                                                    "x64 B, rocprofv3 --pmc pass committed as profiles/r02_dominant_kernel_pmc.json); "
+                                                    "x64 B, rocprofv3 --pmc pass committed as profiles/r03_dominant_kernel_pmc.json); "
                                                     f"algorithmic {j['algorithmic_bytes_per_launch']} B")
         except Exception as e:  # diagnostic leg only; never hides the main number
             res["roofline"]["dominant_kernel"] = {"error": str(e)}

@@ -69,9 +69,34 @@ typedef struct {
      *               not activated (dX of the Linear that follows an activation: d_u = (dY W) * act'(u)).            */
     const float *aux;
     int32_t aux_mode;
+    /* merge-on-read (consumer side of mdt_op_mlp): a_parts >= 2 means the activation rows are the SUM of a_parts arrays
+     * A, A + a_part_stride, ... (floats; same lda), added in that fixed order -- the partial slabs a fused MLP launch left;
+     * needs the LayerNorm prologue (whole rows per wave) and the wide tiles (N >= 1024, M > 1400 rows).  a_merged (optional,
+     * may not alias any part): the summed rows are also written there (row stride lda) by the column-0 tiles, so that
+     * the next residual GEMM finds the residual stream in one place.  0 / 1 = plain A.                              */
+    int32_t a_parts;
+    int64_t a_part_stride;
+    float *a_merged;
 } mdt_gemm_args;
 
 mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);
+
+/* The whole MLP sublayer of a (Conditioned)Block as ONE launch (transformer_blocks.py:160-181, 296-309):
+ *     x + gate * ( act( prologue(x) @ W1^T + b1 ) @ W2^T + b2 )
+ * `fc` describes the first Linear as for mdt_op_gemm (A = x rows with lda, M, K = D, N = 4D, LayerNorm (+ modulate)
+ * prologue, act; `out` ignored), `proj` the second (Wp, bias, N = D, K = 4D, mod / mod_stride / gate_off /
+ * rows_per_sample for the gate; A / out ignored).  A workgroup owns 32 rows and ONE 512-wide slice of the hidden layer:
+ * it keeps its (32 x 512) slice of act(.) in LDS and multiplies it by the matching K-slice of W2, so the hidden layer never
+ * reaches memory and the S = 4D / 512 slices of a row tile produce S partial slabs
+ *     parts[0] = x + gate * (h_0 W2_0^T + b2),   parts[s] = gate * (h_s W2_s^T)        (slab s at parts + s * part_stride)
+ * whose sum IN THE ORDER 0, 1, .., S-1 is the sublayer's output (deterministic: no atomics).  The consumer adds them on
+ * read (mdt_gemm_args.a_parts, mdt_head_args.y_parts).  *n_parts returns S.  Needs D a multiple of 128, D <= 512, and
+ * parts (S * part_stride floats, part_stride >= M * D) not aliasing x -- except S == 1, where parts may be x itself. */
+mdt_status mdt_op_mlp(const mdt_gemm_args *fc, const mdt_gemm_args *proj, float *parts, int64_t part_stride,
+                      int32_t *n_parts, void *stream);
+/* Tuning / test hook: the model-level entry points run the MLP sublayer through mdt_op_mlp from `rows` rows (B * horizon)
+ * on; 0 = never (the two-GEMM sequence), -1 = default (1401, or MDT_HIP_MLP_FUSE_MIN from the environment). */
+void mdt_op_set_mlp_fuse_min(int32_t rows);
 
 /* Tuning / test hook: force the workgroup geometry of every following GEMM launch in this process.
  * 0 = heuristic (default): for M <= 192 rows (rollout-sized batches) the split-K small-M kernel -- one workgroup per
@@ -123,6 +148,8 @@ typedef struct {
     const float *Wa, *ba;      /* action_emb.weight TRANSPOSED to (A, D) row-major, bias (D)          */
     int32_t no_ln;             /* 1: y is used as it is (the MLP head's hidden layer), ln_w / ln_b only have to be
                                 * readable for D floats                                                */
+    int32_t y_parts;           /* >= 2: the rows are the sum of y_parts arrays y, y + y_part_stride, ... (the slabs  */
+    int64_t y_part_stride;     /* mdt_op_mlp left), added in that order; 0 / 1 = plain y                             */
 } mdt_head_args;
 
 mdt_status mdt_op_head(const mdt_head_args *args, void *stream);

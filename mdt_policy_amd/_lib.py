@@ -37,7 +37,8 @@ class GemmArgs(C.Structure):
         ("shift_off", C.c_int32), ("scale_off", C.c_int32), ("rows_per_sample", C.c_int32), ("act", C.c_int32),
         ("residual", C.c_int32), ("gate_off", C.c_int32), ("gin", C.c_int32), ("gout", C.c_int32),
         ("goff", C.c_int32), ("rowvec", C.c_void_p), ("batch", C.c_int32), ("bs_a", C.c_int64), ("bs_w", C.c_int64),
-        ("bs_out", C.c_int64), ("aux", C.c_void_p), ("aux_mode", C.c_int32)]
+        ("bs_out", C.c_int64), ("aux", C.c_void_p), ("aux_mode", C.c_int32), ("a_parts", C.c_int32),
+        ("a_part_stride", C.c_int64), ("a_merged", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -65,7 +66,7 @@ class HeadArgs(C.Structure):
         ("x", C.c_void_p), ("sigma", C.c_void_p), ("sigma_stride", C.c_int64), ("out", C.c_void_p),
         ("M", C.c_int32), ("D", C.c_int32), ("A", C.c_int32), ("rows_per_sample", C.c_int32), ("mode", C.c_int32),
         ("step", C.c_void_p), ("sigma_data", C.c_float), ("y_next", C.c_void_p), ("Wa", C.c_void_p),
-        ("ba", C.c_void_p), ("no_ln", C.c_int32)]
+        ("ba", C.c_void_p), ("no_ln", C.c_int32), ("y_parts", C.c_int32), ("y_part_stride", C.c_int64)]
 
 
 class LnTrainArgs(C.Structure):
@@ -178,7 +179,9 @@ SYMBOLS = [
     ("mdt_op_packed_numel", _I64, [_I64, _I64]),
     ("mdt_op_pack_weight", _I32, [_VP, _I64, _I64, _VP, _I64, _I64, _VP]),
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
+    ("mdt_op_mlp", _I32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _VP, _I64, C.POINTER(_I32), _VP]),
     ("mdt_op_set_gemm_geometry", None, [_I32]),
+    ("mdt_op_set_mlp_fuse_min", None, [_I32]),
     ("mdt_op_attention", _I32, [C.POINTER(AttnArgs), _VP]),
     ("mdt_op_attn_proj", _I32, [C.POINTER(GemmArgs), _VP, _I64, _I32, _I32, _I32, _VP]),
     ("mdt_op_xattn_fold", _I32, [C.POINTER(XFoldArgs), _VP]),

@@ -31,29 +31,61 @@ def needs_build() -> bool:
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_persist.h"]]
     deps += [os.path.join(INCLUDE, f) for f in ("mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h")]
+    deps.append(os.path.abspath(__file__))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HEADERS = ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_persist.h"]
+PUBLIC_HEADERS = ["mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h"]
+
+
+def _compile_one(args):
+    src, obj, defines, verbose = args
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", "-Wall", "-Wno-unused-function",
+           f"-I{INCLUDE}", f"-I{CSRC}", "-o", obj] + [f"-D{d}" for d in defines] + [src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n" + res.stdout + res.stderr)
+    return res.stderr
+
+
 def build_library(force: bool = False, verbose: bool = False, out: str = None, defines=()) -> str:
-    """Compile csrc/*.hip -> csrc/libmdt_hip.so for gfx950; returns the library path.
-    ``out`` / ``defines`` build an experimental variant next to the product library (tuning A/B runs)."""
+    """Compile csrc/*.hip -> csrc/libmdt_hip.so for gfx950; returns the library path.  Every translation unit is compiled
+    to its own object (in parallel; objects are kept under csrc/build/ and reused while the source and the headers are
+    older), then linked.  ``out`` / ``defines`` build an experimental variant next to the product library (tuning A/B runs)."""
     if out is None and not force and not needs_build():
         return LIB
     out = out or LIB
-    tmp = f"{out}.tmp.{os.getpid()}"  # compile next to the target, then rename: concurrent importers never see a torn file
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", "-o", tmp] + [f"-D{d}" for d in defines]
-    cmd += [os.path.join(CSRC, f) for f in SOURCES]
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    tag = hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:8] if defines else "default"
+    objdir = os.path.join(CSRC, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(p) for p in [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, h) for h in PUBLIC_HEADERS]
+                + [os.path.abspath(__file__)])
+    jobs, objs = [], []
+    for f in SOURCES:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(objdir, f.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
+            jobs.append((src, obj, tuple(defines), verbose))
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
+        for warn in ex.map(_compile_one, jobs):
+            if verbose and warn.strip():
+                print(warn, file=sys.stderr)
+    tmp = f"{out}.tmp.{os.getpid()}"  # link next to the target, then rename: concurrent importers never see a torn file
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, out)
-    if verbose and res.stderr.strip():
-        print(res.stderr, file=sys.stderr)
     return out
 
 

@@ -65,6 +65,10 @@ int mdt_gemm_kchunk(int K, int ln, int cap);
 // the current device's buffer of zeros (stands in for absent bias / LayerNorm-bias vectors); nullptr on failure
 const float* mdt_zeros();
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s);
+// the MLP sublayer as one launch (k_mlp): S = mdt_mlp_slices(D) partial slabs at parts + s * part_stride
+bool mdt_mlp_supported(const mdt_gemm_args& fc, const mdt_gemm_args& proj);
+int mdt_mlp_slices(int D);
+hipError_t mdt_launch_mlp(const mdt_gemm_args& fc, const mdt_gemm_args& proj, float* parts, int64_t part_stride, hipStream_t s);
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin, hipStream_t s);
 // one sample's self-attention fused into its output projection p (rollout batch 1); see mdt_kernels.hip
 bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope);

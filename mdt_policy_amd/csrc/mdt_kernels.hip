@@ -120,6 +120,28 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     gemm_tile<MTILES, NTW, NWAVES, PRO, RES, false>(a, kchunk, by, bx, lds, zeros, threadIdx.x);
 }
 
+// the same wide tile reading its rows as the sum of XP partial slabs (the output of a fused MLP launch, k_mlp below)
+template <int NTW, int PRO, int XP>
+__global__ __launch_bounds__(512) void k_gemm_merge(mdt_gemm_args a, int kchunk, int grid_n, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / grid_n, bx = logical - by * grid_n;
+    gemm_tile<2, NTW, 8, PRO, false, false, XP>(a, kchunk, by, bx, lds, zeros, threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mlp: the MLP sublayer as one launch; workgroup = (row tile of 32, 512-wide slice of the hidden layer); body in
+// mdt_tiles.h (mlp_tile).  The S slices of a row tile are neighbours in the logical order, so they share an XCD's L2.
+// ------------------------------------------------------------------------------------------------
+template <int NTW2, int PRO>
+__global__ __launch_bounds__(512) void k_mlp(mdt_gemm_args f, mdt_gemm_args p, float* __restrict__ parts, int64_t part_stride,
+                                             int n_slices, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / n_slices, s = logical - by * n_slices;
+    mlp_tile<NTW2, PRO>(f, p, parts, part_stride, by, s, lds, zeros, threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_gemm_pipe: the plain-prologue GEMM for K that does not fit LDS in one piece (mlp.c_proj, K = 4d), with
 // LW extra LOADER waves.  vmcnt retires a wave's loads in order, so an MFMA wave that also fetched the next
@@ -446,6 +468,8 @@ hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_
     }
 }
 
+static hipError_t launch_gemm_merge(const mdt_gemm_args& a, hipStream_t s);
+
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
     hipError_t ze = ensure_zeros();
@@ -460,6 +484,7 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     // N = 192 layers of the masked-image decoder: 595 us as 16-column split-K tiles vs ~300 us tiled)
     // the training hooks of the epilogue (aux) exist in the plain-prologue, non-residual tiled kernels only
     if (a.aux_mode && (!a.aux || a.ln || a.residual || a.batch > 1 || a.K > 512)) return hipErrorInvalidValue;
+    if (a.a_parts > 1) return launch_gemm_merge(a, s);
     if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {
         hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4, a.batch > 1 ? a.batch : 1), dim3(512), 0, s, a, g_zeros);
         return hipGetLastError();
@@ -537,6 +562,85 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
 }
 
 extern "C" void mdt_op_set_gemm_geometry(int32_t geo) { g_mdt_gemm_force = geo; }
+
+// ---- fused MLP sublayer (k_mlp) ----
+bool mdt_mlp_supported(const mdt_gemm_args& f, const mdt_gemm_args& p) {
+    const int D = f.K;
+    return D >= 128 && D <= 512 && D % 128 == 0 && f.N == 4 * D && p.N == D && p.K == 4 * D && f.ln && f.batch <= 1 &&
+           f.gin == 1 && f.gout == 1 && f.goff == 0 && f.rowvec == nullptr && !f.aux_mode && f.a_parts <= 1 && f.M >= 1 &&
+           f.rows_per_sample >= 1 && p.rows_per_sample >= 1;
+}
+int mdt_mlp_slices(int D) { return 4 * D / 512; }
+
+template <int NTW2, int PRO>
+static hipError_t launch_mlp_t(const mdt_gemm_args& f, const mdt_gemm_args& p, float* parts, int64_t part_stride, hipStream_t s) {
+    const int S = mdt_mlp_slices(f.K), gm = (f.M + 31) / 32;
+    const size_t lds = (size_t)32 * (f.K + 4 + 516) * sizeof(float);
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp<NTW2, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_mlp<NTW2, PRO>), dim3(gm * S), dim3(512), lds, s, f, p, parts, part_stride, S, g_zeros);
+    return hipGetLastError();
+}
+template <int NTW2>
+static hipError_t launch_mlp_pro(const mdt_gemm_args& f, const mdt_gemm_args& p, float* parts, int64_t part_stride, hipStream_t s) {
+    if (f.mod != nullptr && f.shift_off >= 0)
+        return f.mod_stride == 0 ? launch_mlp_t<NTW2, PRO_LN_MOD_BCAST>(f, p, parts, part_stride, s)
+                                 : launch_mlp_t<NTW2, PRO_LN_MOD_ROWS>(f, p, parts, part_stride, s);
+    return launch_mlp_t<NTW2, PRO_LN>(f, p, parts, part_stride, s);
+}
+hipError_t mdt_launch_mlp(const mdt_gemm_args& f, const mdt_gemm_args& p, float* parts, int64_t part_stride, hipStream_t s) {
+    if (!mdt_mlp_supported(f, p)) return hipErrorInvalidValue;
+    hipError_t ze = ensure_zeros();
+    if (ze != hipSuccess) return ze;
+    switch (f.K / 128) {
+        case 1: return launch_mlp_pro<1>(f, p, parts, part_stride, s);
+        case 2: return launch_mlp_pro<2>(f, p, parts, part_stride, s);
+        case 3: return launch_mlp_pro<3>(f, p, parts, part_stride, s);
+        default: return launch_mlp_pro<4>(f, p, parts, part_stride, s);
+    }
+}
+
+// a LayerNorm-prologue GEMM whose rows are the sum of a.a_parts slabs (2..4): wide tiles only
+template <int NTW, int PRO, int XP>
+static hipError_t launch_gemm_merge_t(const mdt_gemm_args& a, hipStream_t s) {
+    const int NTC = 8 * NTW * 16;
+    const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + 31) / 32;
+    const size_t lds = (size_t)32 * (a.K + 4) * sizeof(float);
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_merge<NTW, PRO, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_gemm_merge<NTW, PRO, XP>), dim3(gn * gm), dim3(512), lds, s, a, a.K, gn, g_zeros);
+    return hipGetLastError();
+}
+template <int NTW, int PRO>
+static hipError_t launch_gemm_merge_x(const mdt_gemm_args& a, hipStream_t s) {
+    switch (a.a_parts) {
+        case 2: return launch_gemm_merge_t<NTW, PRO, 2>(a, s);
+        case 3: return launch_gemm_merge_t<NTW, PRO, 3>(a, s);
+        case 4: return launch_gemm_merge_t<NTW, PRO, 4>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <int NTW>
+static hipError_t launch_gemm_merge_pro(const mdt_gemm_args& a, hipStream_t s) {
+    if (a.mod != nullptr && a.shift_off >= 0)
+        return a.mod_stride == 0 ? launch_gemm_merge_x<NTW, PRO_LN_MOD_BCAST>(a, s) : launch_gemm_merge_x<NTW, PRO_LN_MOD_ROWS>(a, s);
+    return launch_gemm_merge_x<NTW, PRO_LN>(a, s);
+}
+static hipError_t launch_gemm_merge(const mdt_gemm_args& a, hipStream_t s) {
+    if (!a.ln || a.K > 512 || a.residual || a.batch > 1 || a.aux_mode || a.a_parts > 4 || (a.N & 15)) return hipErrorInvalidValue;
+    // 32 x 384 tiles when they divide N (qkv of d = 384: 1152), else 32 x 512
+    return (a.N % 384 == 0) ? launch_gemm_merge_pro<3>(a, s) : launch_gemm_merge_pro<4>(a, s);
+}
 
 // ------------------------------------------------------------------------------------------------
 // small attention: one workgroup per sample.  The sample's q / k / v rows (all heads) are staged in LDS with
@@ -766,19 +870,28 @@ hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t s
 // one wave per action-token row; A <= 16
 // ------------------------------------------------------------------------------------------------
 // body in mdt_tiles.h (head_rows): each wave handles 2 rows
-template <int AMAX>
+template <int AMAX, int XP>
 __global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __restrict__ zeros) {
     const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     if (base >= a.M) return;  // wave-uniform
-    head_rows<AMAX, false>(a, base, threadIdx.x & 63, zeros);
+    head_rows<AMAX, false, XP>(a, base, threadIdx.x & 63, zeros);
 }
 
 hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
     hipError_t e = ensure_zeros();
     if (e != hipSuccess) return e;
     const int grid = (a.M + 7) / 8;  // 4 waves x 2 rows per workgroup
-    if (a.A <= 8) hipLaunchKernelGGL((k_head<8>), dim3(grid), dim3(256), 0, s, a, g_zeros);
-    else hipLaunchKernelGGL((k_head<16>), dim3(grid), dim3(256), 0, s, a, g_zeros);
+    if (a.y_parts > 1) {  // rows = the sum of a fused MLP's slabs
+        if (a.A > 8 || a.y_parts > 4) return hipErrorInvalidValue;
+        switch (a.y_parts) {
+            case 2: hipLaunchKernelGGL((k_head<8, 2>), dim3(grid), dim3(256), 0, s, a, g_zeros); break;
+            case 3: hipLaunchKernelGGL((k_head<8, 3>), dim3(grid), dim3(256), 0, s, a, g_zeros); break;
+            default: hipLaunchKernelGGL((k_head<8, 4>), dim3(grid), dim3(256), 0, s, a, g_zeros); break;
+        }
+        return hipGetLastError();
+    }
+    if (a.A <= 8) hipLaunchKernelGGL((k_head<8, 1>), dim3(grid), dim3(256), 0, s, a, g_zeros);
+    else hipLaunchKernelGGL((k_head<16, 1>), dim3(grid), dim3(256), 0, s, a, g_zeros);
     return hipGetLastError();
 }
 

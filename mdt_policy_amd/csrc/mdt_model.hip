@@ -366,6 +366,7 @@ extern "C" mdt_status mdt_destroy(mdt_model* m) {
         if (m->tab_host[i]) (void)hipHostFree(m->tab_host[i]);
         if (m->ev_tab[i]) (void)hipEventDestroy(m->ev_tab[i]);
     }
+    if (m->ev_tab_use) (void)hipEventDestroy(m->ev_tab_use);
     delete m;
     return MDT_OK;
 }
@@ -497,6 +498,7 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
             for (int i = 0; i < 2; ++i)
                 if (m->tab_host[i]) (void)hipHostFree(m->tab_host[i]);
             m->tab_dev = nullptr; m->tab_host[0] = m->tab_host[1] = nullptr; m->tab_cap = 0; m->tab_last.clear();
+            m->tab_used = false;
             HIP_TRY(hipMalloc(&m->tab_dev, total * 2));
             for (int i = 0; i < 2; ++i) {
                 HIP_TRY(hipHostMalloc(&m->tab_host[i], total * 2, hipHostMallocDefault));
@@ -504,6 +506,10 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
             }
             m->tab_cap = total * 2;
         }
+        // the table buffer is shared by every stream that calls in: a caller on another stream than the last one first orders
+        // itself behind that stream's copy and kernel (a hit would read a table still in flight, a miss overwrite one in use)
+        if (!m->ev_tab_use) HIP_TRY(hipEventCreateWithFlags(&m->ev_tab_use, hipEventDisableTiming));
+        if (m->tab_used && m->tab_stream != s) HIP_TRY(hipStreamWaitEvent(s, m->ev_tab_use, 0));
         if (m->tab_last != bytes) {  // new table: through the pinned buffer whose previous copy has long completed
             const int t = m->tab_turn ^= 1;
             HIP_TRY(hipEventSynchronize(m->ev_tab[t]));
@@ -514,6 +520,8 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
         }
         LAUNCH(mdt_launch_multi_load((const mdt_load_entry*)m->tab_dev, (const int2*)((const char*)m->tab_dev + tab_bytes),
                                      (int)blocks.size(), s));
+        HIP_TRY(hipEventRecord(m->ev_tab_use, s));
+        m->tab_stream = s; m->tab_used = true;
     }
     for (Slot* t : touched) t->loaded = true;
     m->cached_batch = 0;
@@ -605,13 +613,24 @@ static int64_t g_attn_proj_max_batch() {
     return v;
 }
 
+// the residual stream as the previous sublayer left it: one array (parts <= 1: V.y) or the partial slabs of a fused MLP
+// launch, to be summed by whoever reads them next
+struct Stream {
+    const float* base = nullptr;
+    int parts = 1;
+    int64_t stride = 0;
+};
+
 static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, bool causal,
-                                ModRef mr, hipStream_t s) {
+                                ModRef mr, hipStream_t s, Stream in = Stream()) {
     float* x = V.y;
     const int D = m->D, M = (int)(B * T);
     mdt_gemm_args g = gemm_args(x, D, e.qkv, V.qkv, 3 * D, M);
     g.ln = 1; g.ln_w = e.ln1_w; g.ln_b = e.ln1_b;
     g.rows_per_sample = T;
+    if (in.parts > 1) {  // rows = sum of the MLP slabs; the column-0 tiles also leave the sum in V.y for the residual below
+        g.A = in.base; g.a_parts = in.parts; g.a_part_stride = in.stride; g.a_merged = x;
+    }
     if (mr.mod && mr.shift >= 0) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = mr.shift; g.scale_off = mr.scale; }
     LAUNCH(mdt_launch_gemm(g, s));
     mdt_gemm_args p = gemm_args(V.att, D, e.proj, x, D, M);
@@ -632,17 +651,39 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
     return MDT_OK;
 }
 
-static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, ModRef mr, hipStream_t s) {
+// row count from which the MLP sublayer runs as ONE launch (k_mlp) that leaves partial slabs instead of the residual
+// stream (MDT_HIP_MLP_FUSE_MIN overrides; 0 disables): below it the wide tiles do not fill the chip
+static int g_mlp_fuse_override = -1;  // mdt_op_set_mlp_fuse_min (tests / A-B runs)
+static int g_mlp_fuse_min_rows() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_MLP_FUSE_MIN"); v = e ? atoi(e) : 1401; if (v == 0) v = 1 << 30; }
+    return g_mlp_fuse_override >= 0 ? (g_mlp_fuse_override == 0 ? 1 << 30 : g_mlp_fuse_override) : v;
+}
+extern "C" void mdt_op_set_mlp_fuse_min(int32_t rows) { g_mlp_fuse_override = rows; }
+
+// `out` (optional): when given and the fused launch applies, the sublayer's output is left as slabs in V.hid (described in
+// *out) and V.y is NOT updated -- the caller hands *out to the next reader; otherwise V.y is updated in place.
+static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, ModRef mr, hipStream_t s,
+                          Stream* out = nullptr) {
     float* x = V.y;
     const int D = m->D, M = (int)(B * T);
     mdt_gemm_args g = gemm_args(x, D, e.fc, V.hid, 4 * D, M);
     g.ln = 1; g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = MDT_ACT_GELU;
     g.rows_per_sample = T;
     if (mr.mod && mr.shift >= 0) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = mr.shift; g.scale_off = mr.scale; }
-    LAUNCH(mdt_launch_gemm(g, s));
     mdt_gemm_args p = gemm_args(V.hid, 4 * D, e.proj2, x, D, M);
     p.residual = 1; p.rows_per_sample = T;
     if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
+    if (out) *out = Stream();
+    if (out && M >= g_mlp_fuse_min_rows() && mdt_mlp_slices(D) >= 2 && mdt_mlp_supported(g, p)) {
+        // the hidden buffer (M x 4D) is free in this form: it holds the S <= 4 slabs of (M x D)
+        p.ldo = D;
+        const int64_t stride = (int64_t)M * D;
+        LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
+        out->base = V.hid; out->parts = mdt_mlp_slices(D); out->stride = stride;
+        return MDT_OK;
+    }
+    LAUNCH(mdt_launch_gemm(g, s));
     LAUNCH(mdt_launch_gemm(p, s));
     return MDT_OK;
 }
@@ -778,9 +819,13 @@ static int64_t cond_width(const mdt_model* m) {
 
 // the Ld decoder blocks on the residual stream V.y: ConditionedBlock (transformer_blocks.py:291-309), NoiseBlock
 // (:335-341) or the plain cross-attending Block (:209-214), by m->cond
+// `fin` (optional): the caller's next reader (the action head) can sum MLP slabs itself; then the last block may leave its
+// output as slabs, described in *fin.  Without it the residual stream ends in V.y.
 static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, const float* mod_row, int64_t mod_stride,
-                                     hipStream_t s) {
+                                     hipStream_t s, Stream* fin = nullptr) {
     const int D = m->D, Ta = m->Ta, M = (int)(B * Ta);
+    Stream cur;  // where the residual stream lives between blocks
+    if (fin) *fin = Stream();
     for (int l = 0; l < m->Ld; ++l) {
         const DecBlock& d = m->dec[l];
         ModRef ma, mx, mm;  // self-attention half, cross-attention query, MLP half
@@ -791,7 +836,8 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
         } else if (m->cond == COND_NOISE) {
             ma = mx = ModRef(mod_row, mod_stride, 0, D, -1);  // ln(x)*1 + c, residual ungated; MLP unconditioned
         }
-        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, ma, s));
+        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, ma, s, cur));
+        cur = Stream();
         // cross attention: ln3 (biased LayerNorm) -> q ; K|V precomputed ; never gated
         if (m->xfold) {
             const int64_t np = (int64_t)m->H * m->Te;
@@ -820,8 +866,10 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
             p.residual = 1; p.rows_per_sample = Ta;
             LAUNCH(mdt_launch_gemm(p, s));
         }
-        MDT_TRY(run_mlp(m, d, V, B, Ta, mm, s));
+        const bool last = l == m->Ld - 1;
+        MDT_TRY(run_mlp(m, d, V, B, Ta, mm, s, (!last || fin) ? &cur : nullptr));
     }
+    if (fin) *fin = cur;
     return MDT_OK;
 }
 
@@ -884,8 +932,11 @@ extern "C" mdt_status mdt_denoise_cached(mdt_model* m, const float* x, const flo
     MDT_TRY(run_modulation(m, sigma, 1, scalar ? 1 : (int)batch, s));
     LAUNCH(mdt_launch_action_embed(x, (flags & MDT_RAW_INPUT) ? nullptr : sigma, sst, m->cfg.sigma_data, m->Wa, m->ba,
                                    m->y, (int)(batch * m->Ta), m->A, m->D, m->Ta, s));
-    MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, cond_row(m, 0), scalar ? 0 : modw, s));
+    Stream fin;
+    const bool head_sums = m->HP == 0 && m->A <= 8;  // the one-launch head adds MLP slabs itself
+    MDT_TRY(run_decoder_blocks(m, decoder_view(m, 0), batch, cond_row(m, 0), scalar ? 0 : modw, s, head_sums ? &fin : nullptr));
     mdt_head_args h = head_args(m, m->y, batch, x, sigma, sst, out, (flags & MDT_RAW_OUTPUT) ? MDT_HEAD_RAW : MDT_HEAD_DENOISED);
+    if (fin.parts > 1) { h.y = fin.base; h.y_parts = fin.parts; h.y_part_stride = fin.stride; }
     return run_head(m, h, m->hid, nullptr, s);
 }
 
@@ -963,10 +1014,13 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
         for (int w = 0; w < ways; ++w) {
             const int64_t nb = b0[w + 1] - b0[w];
             const View V = decoder_view(m, b0[w]);
-            MDT_TRY(run_decoder_blocks(m, V, nb, cond_row(m, i), 0, st[w]));
+            Stream fin;
+            const bool head_sums = m->HP == 0 && m->A <= 8;  // the one-launch head adds MLP slabs itself
+            MDT_TRY(run_decoder_blocks(m, V, nb, cond_row(m, i), 0, st[w], head_sums ? &fin : nullptr));
             const float* xin = (i == 0 ? x_T : m->xbuf) + b0[w] * xs;
             float* xout = (last ? out : m->xbuf) + b0[w] * xs;
             mdt_head_args h = head_args(m, V.y, nb, xin, m->steps + 4 * i + 3, 0, xout, MDT_HEAD_DDIM);
+            if (fin.parts > 1) { h.y = fin.base; h.y_parts = fin.parts; h.y_part_stride = fin.stride; }
             h.step = m->steps + 4 * i;
             if (!last) { h.y_next = V.y; h.Wa = m->Wa; h.ba = m->ba; }
             MDT_TRY(run_head(m, h, V.hid, m->steps + 4 * (i + 1) + 3, st[w]));
@@ -1049,6 +1103,23 @@ extern "C" mdt_status mdt_op_gemm(const mdt_gemm_args* a, void* stream) {
     if (misaligned(a->A) || misaligned(a->Wp) || misaligned(a->out) || misaligned(a->bias) || misaligned(a->mod))
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_gemm: pointers must be 16-byte aligned");
     LAUNCH(mdt_launch_gemm(*a, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_mlp(const mdt_gemm_args* fc, const mdt_gemm_args* proj, float* parts, int64_t part_stride,
+                                 int32_t* n_parts, void* stream) {
+    if (!fc || !proj || !fc->A || !fc->Wp || !proj->Wp || !parts || !fc->ln_w)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp: null pointer");
+    if (!mdt_mlp_supported(*fc, *proj))
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_mlp: needs D = fc.K a multiple of 128 (<= 512), fc.N = proj.K = 4 D, proj.N = D, "
+                                         "a LayerNorm prologue and plain output rows");
+    if (fc->lda % 4 || proj->ldo % 4 || proj->ldo < proj->N || part_stride < (int64_t)fc->M * proj->ldo)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp: lda / ldo multiples of 4, part_stride >= M * ldo required");
+    if (misaligned(fc->A) || misaligned(fc->Wp) || misaligned(proj->Wp) || misaligned(parts) || misaligned(fc->bias) ||
+        misaligned(proj->bias) || misaligned(fc->mod) || misaligned(proj->mod) || (part_stride & 3))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp: pointers must be 16-byte aligned");
+    LAUNCH(mdt_launch_mlp(*fc, *proj, parts, part_stride, (hipStream_t)stream));
+    if (n_parts) *n_parts = mdt_mlp_slices(fc->K);
     return MDT_OK;
 }
 

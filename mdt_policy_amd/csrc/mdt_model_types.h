@@ -92,6 +92,9 @@ struct mdt_model {
     hipEvent_t ev_tab[2] = {nullptr, nullptr};
     size_t tab_cap = 0;
     int tab_turn = 0;
+    hipEvent_t ev_tab_use = nullptr;   // behind the last k_multi_load that read tab_dev ...
+    hipStream_t tab_stream = nullptr;  // ... on this stream; a caller on another stream waits for it first
+    bool tab_used = false;
     std::vector<char> tab_last;
     // workspace
     float* ws = nullptr;

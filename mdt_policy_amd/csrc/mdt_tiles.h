@@ -138,9 +138,13 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 // re-read / re-normalise the same activation rows at N / (128*NTW) instead of N / 64.
 // Activation tile -> LDS (shared by the GEMM kernels): plain copy of the (MT x klen) chunk at column k0, or LayerNorm
 // (+ adaLN modulate) of whole rows (k0 = 0, klen = K <= 512).  All global loads of the phase are in flight together.
-template <int MTILES, int NWAVES, int PRO, bool COH>
+// XP > 1 (LayerNorm prologues only): the rows are the sum of XP slabs a.A + x * a.a_part_stride (the partial outputs of
+// the fused MLP launch, mlp_tile below), added in slab order; `merge_out` (the column-0 workgroup of a row tile passes
+// a.a_merged, the others nullptr) also receives the summed rows.
+template <int MTILES, int NWAVES, int PRO, bool COH, int XP = 1>
 __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* lds, int stride, int m0, int k0, int klen,
-                                                const float* __restrict__ zeros, int tid, int lane, int wave) {
+                                                const float* __restrict__ zeros, int tid, int lane, int wave,
+                                                float* merge_out = nullptr) {
     constexpr int MT = MTILES * 16;
     constexpr int NT = 64 * NWAVES;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -164,6 +168,17 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
             const int64_t m = min(m0 + r0 + r, a.M - 1);
 #pragma unroll
             for (int p = 0; p < 2; ++p) v[r][p] = LA.ld4(m * a.lda + cc[p]);
+        }
+        f32x4 vx[XP > 1 ? XP - 1 : 1][RPW][2];
+        if constexpr (XP > 1) {
+#pragma unroll
+            for (int x = 1; x < XP; ++x)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int64_t m = min(m0 + r0 + r, a.M - 1);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) vx[x - 1][r][p] = LA.ld4((int64_t)x * a.a_part_stride + m * a.lda + cc[p]);
+                }
         }
         const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
 #pragma unroll
@@ -199,6 +214,17 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
             }
         }
         const float inv_k = 1.0f / (float)klen;
+        if constexpr (XP > 1) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int x = 1; x < XP; ++x) v[r][p] = v[r][p] + vx[x - 1][r][p];  // slab order: deterministic
+                    if (merge_out != nullptr && cv[p] && m0 + r0 + r < a.M)
+                        st4(merge_out + (int64_t)(m0 + r0 + r) * a.lda + cc[p], v[r][p]);
+                }
+        }
         float red[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
@@ -282,7 +308,7 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
 //   branch around a load makes hipcc wait vmcnt(0) right behind it -- one full L2 round trip per load.
 // No thread leaves early (the persistent kernel follows the tile with a barrier).
 // ------------------------------------------------------------------------------------------------
-template <int MTILES, int NTW, int NWAVES, int PRO, bool RES, bool COH>
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES, bool COH, int XP = 1>
 __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, int by, int bx, float* lds,
                                           const float* __restrict__ zeros, int tid) {
     MDT_TS(0)
@@ -360,7 +386,8 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
     for (int k0 = 0; k0 < a.K; k0 += kchunk) {
         const int klen = min(kchunk, a.K - k0);
         if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
-        gemm_stage_tile<MTILES, NWAVES, PRO, COH>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave);
+        gemm_stage_tile<MTILES, NWAVES, PRO, COH, XP>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave,
+                                                      bx == 0 ? a.a_merged : nullptr);
         MDT_TS(1)
         __syncthreads();
         MDT_TS(2)
@@ -425,6 +452,159 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
         }
     }
     MDT_TS(4)
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused MLP tile:  the whole MLP sublayer  x + gate * (act(prologue(x) W1^T + b1) W2^T + b2)  for row tile `by` and hidden
+// slice `s` (512 of the 4D hidden columns).  Phase 1 is gemm_tile<2, 4, 8> on W1's rows [512 s, 512 s + 512) with the
+// activated (32 x 512) result kept in LDS; phase 2 multiplies it by the matching K-slice of W2 (all D output columns: wave w
+// owns NTW2 = D / 128 column tiles) and stores the PARTIAL product as slab s (slab 0 also carries b2 and the residual x).
+// The hidden layer never reaches memory, the second GEMM has no prologue and no launch; the S = 4D / 512 slabs are added in
+// slab order by whoever reads them next (gemm_stage_tile / head_rows with XP = S).  512 threads;
+// lds: 32 * (D + 4) + 32 * 516 floats.  `f` = the first Linear's arguments (A = x), `p` = the second's.
+// ------------------------------------------------------------------------------------------------
+template <int NTW2, int PRO>
+__device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_args& p, float* __restrict__ parts,
+                                         int64_t part_stride, int by, int s, float* lds, const float* __restrict__ zeros,
+                                         int tid) {
+    MDT_TS(0)
+    MDT_TS_HWID()
+    constexpr int MTILES = 2, NWAVES = 8, MT = 32, HS = 512, HSTR = HS + 4, NTW1 = 4;
+    constexpr bool KSTEP_PRIO = false;
+    constexpr int R1 = 3, R2 = NTW2 == 1 ? 6 : (NTW2 == 2 ? 4 : 3);
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m0 = by * MT;
+    const int D = f.K, stride1 = D + 4;
+    float* xn = lds;                  // [32][D + 4]   normalised (+ modulated) rows
+    float* hs = lds + MT * stride1;   // [32][516]     this slice of the activated hidden layer
+    const int nq = 4 * (lane >> 4);
+
+    // ---- phase 1 operands: weight ring of W1 rows [512 s + 64 wave, + 64), bias ----
+    const int K16a = D >> 4;
+    const int nt1 = (s * NWAVES + wave) * NTW1;
+    const float* wp1[NTW1];
+    f32x4 ring1[R1][NTW1], acc1[MTILES][NTW1], b1[NTW1];
+#pragma unroll
+    for (int j = 0; j < NTW1; ++j) wp1[j] = f.Wp + (int64_t)(nt1 + j) * K16a * 256 + lane * 4;
+#pragma unroll
+    for (int u = 0; u < R1 - 1; ++u)
+#pragma unroll
+        for (int j = 0; j < NTW1; ++j) ring1[u][j] = ldg4(wp1[j] + min(u, K16a - 1) * 256);
+    {
+        const float* bp = f.bias != nullptr ? f.bias : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW1; ++j) b1[j] = ldg4(bp + (nt1 + j) * 16 + nq);
+    }
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW1; ++j) acc1[i][j] = zero4;
+    gemm_stage_tile<MTILES, NWAVES, PRO, false>(f, xn, stride1, m0, 0, D, zeros, tid, lane, wave);
+    MDT_TS(1)
+    __syncthreads();
+    MDT_TS(2)
+    {
+        constexpr int NTW = NTW1, R = R1;
+        const int K16 = K16a, nk = K16a, stride = stride1, kg = 0;
+        const float* (&wp)[NTW] = wp1;
+        f32x4 (&ring)[R][NTW] = ring1;
+        f32x4 (&acc)[MTILES][NTW] = acc1;
+        const float* ap = xn + (lane & 15) * stride + 4 * (lane >> 4);
+        f32x4 av[MTILES];
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) av[i] = *(const f32x4*)(ap + i * 16 * stride);
+        int kc = 0;
+        for (; kc + R <= nk; kc += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
+        }
+        if (kc < nk) {
+            const int rem = nk - kc;
+#pragma unroll
+            for (int u = 0; u < R - 1; ++u)
+                if (u < rem) MDT_KSTEP(u, kc + u)
+        }
+    }
+    MDT_TS(3)
+    // ---- phase 2 operands, requested before the activation epilogue so that they travel while it runs: the first
+    //      fragments of W2's K-slice [512 s, 512 s + 512), then bias / gate / residual rows of the output tile ----
+    const int K16b = HS >> 4;  // k16 steps of the slice
+    const float* wp2[NTW2];
+    f32x4 ring2[R2][NTW2], acc2[MTILES][NTW2], b2[NTW2], gate_v[MTILES][NTW2], res_v[MTILES][NTW2];
+    int ncol[NTW2];
+#pragma unroll
+    for (int j = 0; j < NTW2; ++j) {
+        const int nt = wave * NTW2 + j;
+        wp2[j] = p.Wp + ((int64_t)nt * (p.K >> 4) + (int64_t)s * K16b) * 256 + lane * 4;
+        ncol[j] = nt * 16 + nq;
+    }
+#pragma unroll
+    for (int u = 0; u < R2 - 1; ++u)
+#pragma unroll
+        for (int j = 0; j < NTW2; ++j) ring2[u][j] = ldg4(wp2[j] + u * 256);
+    const bool gated = p.mod != nullptr && p.gate_off >= 0;
+    {
+        const float* bp = (s == 0 && p.bias != nullptr) ? p.bias : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW2; ++j) b2[j] = ldg4(bp + ncol[j]);
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) {
+            const int64_t m = min(m0 + i * 16 + (lane & 15), f.M - 1);
+            const float* gp = gated ? p.mod + p.gate_off + (p.mod_stride == 0 ? 0 : (m / p.rows_per_sample) * p.mod_stride)
+                                    : zeros;
+            const float* rp = s == 0 ? f.A + m * f.lda : zeros;  // slab 0 carries the residual stream
+#pragma unroll
+            for (int j = 0; j < NTW2; ++j) {
+                gate_v[i][j] = ldg4(gp + ncol[j]);
+                res_v[i][j] = ldg4(rp + ncol[j]);
+                acc2[i][j] = zero4;
+            }
+        }
+    }
+    // ---- activation epilogue of phase 1 -> LDS (lane holds hidden[i*16 + lane%16][tile*16 + 4*(lane/16) .. +3]) ----
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW1; ++j)
+            *(f32x4*)(hs + (i * 16 + (lane & 15)) * HSTR + (wave * NTW1 + j) * 16 + nq) = apply_act(acc1[i][j] + b1[j], f.act);
+    MDT_TS(4)
+    __syncthreads();
+    {
+        constexpr int NTW = NTW2, R = R2;
+        const int K16 = K16b, nk = K16b, stride = HSTR, kg = 0;
+        const float* (&wp)[NTW] = wp2;
+        f32x4 (&ring)[R][NTW] = ring2;
+        f32x4 (&acc)[MTILES][NTW] = acc2;
+        const float* ap = hs + (lane & 15) * stride + 4 * (lane >> 4);
+        f32x4 av[MTILES];
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i) av[i] = *(const f32x4*)(ap + i * 16 * stride);
+        int kc = 0;
+        for (; kc + R <= nk; kc += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
+        }
+        if (kc < nk) {
+            const int rem = nk - kc;
+#pragma unroll
+            for (int u = 0; u < R - 1; ++u)
+                if (u < rem) MDT_KSTEP(u, kc + u)
+        }
+    }
+    MDT_TS(5)
+    float* out = parts + (int64_t)s * part_stride;
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i) {
+        const int m = m0 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < NTW2; ++j) {
+            f32x4 v = acc2[i][j] + b2[j];
+            v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
+            if (m < f.M) st4(out + (int64_t)m * p.ldo + ncol[j], v);
+        }
+    }
+    MDT_TS(6)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -785,7 +965,7 @@ __device__ __forceinline__ float edm_c_in(float sigma, float sd) { return 1.0f /
 // twice); AMAX (8 or 16) bounds the action dimension at compile time so no load sits behind a branch.
 // The caller guarantees base < a.M (wave-uniform).
 // ------------------------------------------------------------------------------------------------
-template <int AMAX, bool COH>
+template <int AMAX, bool COH, int XP = 1>
 __device__ __forceinline__ void head_rows(const mdt_head_args& a, int base, int lane, const float* __restrict__ zeros) {
     constexpr int RW = 2;
     const int n4 = a.D >> 2;
@@ -811,6 +991,15 @@ __device__ __forceinline__ void head_rows(const mdt_head_args& a, int base, int 
         for (int r = 0; r < RW; ++r) v[r][p] = LY.ld4(row[r] * a.D + cc[p]);
         w[p] = ldg4(a.ln_w + cc[p]);
         bb[p] = ldg4(lnb + cc[p]);
+    }
+    f32x4 vx[XP > 1 ? XP - 1 : 1][RW][2];  // the other slabs of a fused MLP's output (mlp_tile): summed in slab order
+    if constexpr (XP > 1) {
+#pragma unroll
+        for (int x = 1; x < XP; ++x)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) vx[x - 1][r][p] = LY.ld4((int64_t)x * a.y_part_stride + row[r] * a.D + cc[p]);
     }
 #pragma unroll
     for (int c = 0; c < AMAX; ++c) {
@@ -841,6 +1030,14 @@ __device__ __forceinline__ void head_rows(const mdt_head_args& a, int base, int 
     }
     // ---- LayerNorm of the rows ----
     const float inv_d = 1.0f / (float)a.D;
+    if constexpr (XP > 1) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int x = 1; x < XP; ++x) v[r][p] = v[r][p] + vx[x - 1][r][p];
+    }
     float red[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {

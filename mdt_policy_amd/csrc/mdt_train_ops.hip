@@ -217,6 +217,7 @@ struct OptSlot {
     void* host = nullptr;  // pinned
     size_t cap = 0;
     hipEvent_t ev = nullptr;  // recorded behind the kernel that last read `dev`
+    hipStream_t stream = nullptr;  // ... and the stream it was recorded on (the upload was enqueued there as well)
     bool busy = false;
     std::vector<char> key;    // the caller's table bytes this slot holds
     size_t tab_bytes = 0;
@@ -242,6 +243,8 @@ static mdt_status upload_opt_table(OptTable& g_opt, const mdt_opt_tensor* tensor
             *n_blocks = sl.n_blocks;
             *used = &sl;
             sl.last_use = ++g_opt.clock;
+            // a hit from ANOTHER stream: the table's copy (and its last reader) were enqueued elsewhere -- order behind them
+            if (sl.busy && sl.stream != s) HIP_TRY(hipStreamWaitEvent(s, sl.ev, 0));
             return MDT_OK;
         }
     std::vector<int2> blocks;
@@ -286,6 +289,7 @@ static mdt_status upload_blob(OptTable& g_opt, const std::vector<char>& bytes, c
         if (sl.dev && sl.key.size() == bytes.size() && memcmp(sl.key.data(), bytes.data(), bytes.size()) == 0) {
             *dev = sl.dev; *used = &sl;
             sl.last_use = ++g_opt.clock;
+            if (sl.busy && sl.stream != s) HIP_TRY(hipStreamWaitEvent(s, sl.ev, 0));  // see upload_opt_table
             return MDT_OK;
         }
     OptSlot* lru = &g_opt.slots[0];
@@ -349,6 +353,7 @@ extern "C" mdt_status mdt_op_pack_many(int32_t n, const float* const* srcs, cons
     LAUNCH(mdt_launch_multi_load((const mdt_load_entry*)d, (const int2*)((const char*)d + tab_bytes), (int)blocks.size(), s));
     HIP_TRY(hipEventRecord(slot->ev, s));
     slot->busy = true;
+    slot->stream = s;
     return MDT_OK;
 }
 
@@ -371,6 +376,7 @@ extern "C" mdt_status mdt_op_multi_adamw(const mdt_opt_tensor* tensors, int32_t 
     LAUNCH(mdt_launch_multi_adamw(tab, blocks, nb, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)std::sqrt(bc2), s));
     HIP_TRY(hipEventRecord(slot->ev, s));
     slot->busy = true;
+    slot->stream = s;
     return MDT_OK;
 }
 
@@ -390,5 +396,6 @@ extern "C" mdt_status mdt_op_multi_ema(const mdt_opt_tensor* tensors, int32_t n,
     LAUNCH(mdt_launch_multi_axpby(tab, blocks, nb, decay, 1.0f - decay, s));
     HIP_TRY(hipEventRecord(slot->ev, s));
     slot->busy = true;
+    slot->stream = s;
     return MDT_OK;
 }

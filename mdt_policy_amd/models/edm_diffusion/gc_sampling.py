@@ -481,13 +481,15 @@ _DPM_NODES = {1: (), 2: (1 / 2,), 3: (1 / 3, 2 / 3)}
 class _EpsEvaluator:
     """eps(x, t) = (x - D(x; sigma(t))) / sigma(t) of a denoiser, counting its evaluations."""
 
-    def __init__(self, model, state, goal, extra_args):
+    def __init__(self, model, state, goal, extra_args, on_eval=None):
         self.model, self.state, self.goal, self.kw = model, state, goal, (extra_args or {})
-        self.evals = 0
+        self.evals, self.on_eval = 0, on_eval
 
     def __call__(self, x, t):
         sig = _sigma(t)
         self.evals += 1
+        if self.on_eval is not None:
+            self.on_eval()
         return (x - self.model(self.state, x, self.goal, _sig_in(sig, x, self.model), **self.kw)) / _f(sig)
 
 
@@ -567,22 +569,26 @@ def sample_dpm_fast(model, state, action, goal, sigma_min, sigma_max, n, scaler=
     if eta and not t_end > t_start:
         raise ValueError('eta must be 0 for reverse sampling')
     noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    with _hoist(model, state, goal):
+        return _dpm_fast_run(_EpsEvaluator(model, state, goal, extra_args), action, t_start, t_end, n, eta, s_noise,
+                             noise_sampler, callback)
+
+
+def _dpm_fast_run(eps, action, t_start, t_end, n, eta, s_noise, noise_sampler, callback):
     m = n // 3 + 1
     grid = torch.linspace(_f(t_start), _f(t_end), m + 1)
     orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]
-    with _hoist(model, state, goal):
-        eps = _EpsEvaluator(model, state, goal, extra_args)
-        for i, order in enumerate(orders):
-            t, t_next = grid[i], grid[i + 1]
-            t_det, s_up = _ancestral_split(t, t_next, t_end, eta)
-            e0 = eps(action, t)
-            if callback is not None:
-                callback({'x': action, 'i': i, 't': t, 't_up': t, 'denoised': action - _f(_sigma(t)) * e0,
-                          'sigma': _sigma(t), 'sigma_hat': _sigma(t)})
-            nodes = _DPM_NODES[order]
-            action = _dpm_combine(action, t, t_det, nodes, _dpm_stages(eps, action, t, t_det, nodes, e0))
-            if _f(s_up) != 0:
-                action = action + _f(s_up) * s_noise * noise_sampler(_sigma(t), _sigma(t_next))
+    for i, order in enumerate(orders):
+        t, t_next = grid[i], grid[i + 1]
+        t_det, s_up = _ancestral_split(t, t_next, t_end, eta)
+        e0 = eps(action, t)
+        if callback is not None:
+            callback({'x': action, 'i': i, 't': t, 't_up': t, 'denoised': action - _f(_sigma(t)) * e0,
+                      'sigma': _sigma(t), 'sigma_hat': _sigma(t)})
+        nodes = _DPM_NODES[order]
+        action = _dpm_combine(action, t, t_det, nodes, _dpm_stages(eps, action, t, t_det, nodes, e0))
+        if _f(s_up) != 0:
+            action = action + _f(s_up) * s_noise * noise_sampler(_sigma(t), _sigma(t_next))
     return action
 
 
@@ -599,39 +605,135 @@ def sample_dpm_adaptive(model, state, action, goal, sigma_min, sigma_max, extra_
         raise ValueError('order should be 2 or 3')
     t_start = _t(torch.tensor(float(sigma_max))).to(torch.float32)
     t_end = _t(torch.tensor(float(sigma_min))).to(torch.float32)
-    forward = bool(t_end > t_start)
-    if eta and not forward:
+    if eta and not bool(t_end > t_start):
         raise ValueError('eta must be 0 for reverse sampling')
     noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    with _hoist(model, state, goal):
+        action, info = _dpm_adaptive_run(_EpsEvaluator(model, state, goal, extra_args), action, t_start, t_end, order, rtol, atol,
+                                         h_init, pcoeff, icoeff, dcoeff, accept_safety, eta, s_noise, noise_sampler, callback)
+    return (action, info) if return_info else action
+
+
+def _dpm_adaptive_run(eps, action, t_start, t_end, order, rtol, atol, h_init, pcoeff, icoeff, dcoeff, accept_safety, eta,
+                      s_noise, noise_sampler, callback):
+    forward = bool(t_end > t_start)
     ctl = _StepControl(abs(h_init) if forward else -abs(h_init), pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
     info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
     nodes_hi = _DPM_NODES[order]
     nodes_lo = nodes_hi[:-1]  # order 2: () ; order 3: (1/3,) -- the same first node, so the pair shares eps_1
     s, prev = t_start, action
-    with _hoist(model, state, goal):
-        eps = _EpsEvaluator(model, state, goal, extra_args)
-        while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
-            t = torch.minimum(t_end, s + ctl.h) if forward else torch.maximum(t_end, s + ctl.h)
-            t_det, s_up = _ancestral_split(s, t, t_end, eta)
-            stages = _dpm_stages(eps, action, s, t_det, nodes_hi, eps(action, s))
-            low = _dpm_combine(action, s, t_det, nodes_lo, stages)
-            high = _dpm_combine(action, s, t_det, nodes_hi, stages)
-            denoised = action - _f(_sigma(s)) * stages[0]
-            tol = torch.clamp(rtol * torch.maximum(low.abs(), prev.abs()), min=atol)
-            error = torch.linalg.norm((low - high) / tol) / action.numel() ** 0.5
-            if ctl.update(error):
-                prev = low
-                action = high if _f(s_up) == 0 else high + _f(s_up) * s_noise * noise_sampler(_sigma(s), _sigma(t))
-                s = t
-                info['n_accept'] += 1
-            else:
-                info['n_reject'] += 1
-            info['steps'] += 1
-            info['nfe'] = eps.evals
-            if callback is not None:
-                callback({'x': action, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised, 'error': error,
-                          'h': ctl.h, 'sigma': _sigma(s), 'sigma_hat': _sigma(s), **info})
-    return (action, info) if return_info else action
+    while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+        t = torch.minimum(t_end, s + ctl.h) if forward else torch.maximum(t_end, s + ctl.h)
+        t_det, s_up = _ancestral_split(s, t, t_end, eta)
+        stages = _dpm_stages(eps, action, s, t_det, nodes_hi, eps(action, s))
+        low = _dpm_combine(action, s, t_det, nodes_lo, stages)
+        high = _dpm_combine(action, s, t_det, nodes_hi, stages)
+        denoised = action - _f(_sigma(s)) * stages[0]
+        tol = torch.clamp(rtol * torch.maximum(low.abs(), prev.abs()), min=atol)
+        error = torch.linalg.norm((low - high) / tol) / action.numel() ** 0.5
+        if ctl.update(error):
+            prev = low
+            action = high if _f(s_up) == 0 else high + _f(s_up) * s_noise * noise_sampler(_sigma(s), _sigma(t))
+            s = t
+            info['n_accept'] += 1
+        else:
+            info['n_reject'] += 1
+        info['steps'] += 1
+        info['nfe'] = eps.evals
+        if callback is not None:
+            callback({'x': action, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised, 'error': error,
+                      'h': ctl.h, 'sigma': _sigma(s), 'sigma_hat': _sigma(s), **info})
+    return action, info
+
+
+class PIDStepSizeController(_StepControl):
+    """The reference's controller by its own name and call form (gc_sampling.py:495-521) over _StepControl."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        super().__init__(h, pcoeff, icoeff, dcoeff, order, accept_safety, eps)
+
+    @staticmethod
+    def limiter(action):
+        return 1 + math.atan(action - 1)
+
+    def propose_step(self, error):
+        return self.update(error)
+
+
+class DPMSolver(torch.nn.Module):
+    """The reference's solver object by its own name and method set (gc_sampling.py:524-670), for code that builds
+    ``DPMSolver(model, ...)`` directly; the work is done by the routines above.  ``eps_cache`` dictionaries carry the stage
+    values under the reference's keys ('eps', 'eps_r1', 'eps_r2') and are honoured the same way (by key, whatever nodes
+    produced them)."""
+    _KEYS = ('eps', 'eps_r1', 'eps_r2')
+
+    def __init__(self, model, extra_args=None, eps_callback=None, info_callback=None):
+        super().__init__()
+        self.model = model
+        self.extra_args = {} if extra_args is None else extra_args
+        self.eps_callback = eps_callback
+        self.info_callback = info_callback
+
+    def t(self, sigma):
+        return -sigma.log()
+
+    def sigma(self, t):
+        return t.neg().exp()
+
+    def _evaluator(self, state, goal):
+        return _EpsEvaluator(self.model, state, goal, self.extra_args, self.eps_callback)
+
+    def eps(self, eps_cache, key, state, action, goal, t, *args, **kwargs):
+        if key in eps_cache:
+            return eps_cache[key], eps_cache
+        e = self._evaluator(state, goal)(action, t)
+        return e, {key: e, **eps_cache}
+
+    def _step(self, nodes, state, action, goal, t, t_next, eps_cache):
+        cache = dict(eps_cache or {})
+        ev = self._evaluator(state, goal)
+        if 'eps' not in cache:
+            cache['eps'] = ev(action, t)
+        stage = [1]
+
+        def staged(u, s):  # stage k of _dpm_stages <-> key k of the reference's cache
+            key = self._KEYS[stage[0]]
+            stage[0] += 1
+            if key not in cache:
+                cache[key] = ev(u, s)
+            return cache[key]
+        out = _dpm_combine(action, t, t_next, nodes, _dpm_stages(staged, action, t, t_next, nodes, cache['eps']))
+        return out, cache
+
+    def dpm_solver_1_step(self, state, action, goal, t, t_next, eps_cache=None):
+        return self._step((), state, action, goal, t, t_next, eps_cache)
+
+    def dpm_solver_2_step(self, state, action, goal, t, t_next, r1=1 / 2, eps_cache=None):
+        return self._step((r1,), state, action, goal, t, t_next, eps_cache)
+
+    def dpm_solver_3_step(self, state, action, goal, t, t_next, r1=1 / 3, r2=2 / 3, eps_cache=None):
+        return self._step((r1, r2), state, action, goal, t, t_next, eps_cache)
+
+    def dpm_solver_fast(self, state, action, goal, t_start, t_end, nfe, eta=0., s_noise=1., noise_sampler=None):
+        t_start, t_end = torch.as_tensor(t_start), torch.as_tensor(t_end)
+        if eta and not t_end > t_start:
+            raise ValueError('eta must be 0 for reverse sampling')
+        noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+        with _hoist(self.model, state, goal):
+            return _dpm_fast_run(self._evaluator(state, goal), action, t_start, t_end, nfe, eta, s_noise, noise_sampler,
+                                 self.info_callback)
+
+    def dpm_solver_adaptive(self, state, action, goal, t_start, t_end, order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0.,
+                            icoeff=1., dcoeff=0., accept_safety=0.81, eta=0., s_noise=1., noise_sampler=None):
+        if order not in (2, 3):
+            raise ValueError('order should be 2 or 3')
+        t_start, t_end = torch.as_tensor(t_start, dtype=torch.float32), torch.as_tensor(t_end, dtype=torch.float32)
+        if eta and not bool(t_end > t_start):
+            raise ValueError('eta must be 0 for reverse sampling')
+        noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+        with _hoist(self.model, state, goal):
+            return _dpm_adaptive_run(self._evaluator(state, goal), action, t_start, t_end, order, rtol, atol, h_init, pcoeff,
+                                     icoeff, dcoeff, accept_safety, eta, s_noise, noise_sampler, self.info_callback)
 
 
 @torch.no_grad()

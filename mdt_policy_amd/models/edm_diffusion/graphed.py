@@ -90,9 +90,10 @@ class GraphedDDIM:
                 v.copy_(state[k])
         self._x.copy_(x_T)
         self._goal.copy_(goal)
-        if sigmas is not None and sigmas is not self._last_sig:  # a rollout passes the same schedule tensor every step
+        if sigmas is not None:
+            # n + 1 floats: always copied -- a caller may rewrite its schedule tensor in place (same object, new values), and
+            # an identity check would then replay the old noise levels without any error
             self._sig.copy_(sigmas if torch.is_tensor(sigmas) else torch.as_tensor(sigmas, dtype=torch.float32))
-            self._last_sig = sigmas if torch.is_tensor(sigmas) and sigmas.device == self.device else None
         self._graph.replay()
         eng.ctx_generation += 1
         self.model.inner_model.latent_encoder_emb = self._ctx

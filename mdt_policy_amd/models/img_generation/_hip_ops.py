@@ -55,10 +55,13 @@ class PackedWeights:
             if N % 16 or K % 16:
                 raise ValueError(f"Linear ({N}, {K}): both dimensions must be multiples of 16 for the packed MFMA operand")
             src = _c(w2d)
-            wp = ent[1] if ent is not None and ent[1].numel() == N * K else torch.empty(N * K, device=src.device, dtype=torch.float32)
+            # image buffers are reused across refreshes -- but only on the parameter's CURRENT device (.to('cuda:1') moves the
+            # parameter, not the images)
+            reuse = ent is not None and ent[1].numel() == N * K and ent[1].device == src.device
+            wp = ent[1] if reuse else torch.empty(N * K, device=src.device, dtype=torch.float32)
             wt = None
             if need_t:
-                wt = ent[2] if ent is not None and ent[2] is not None else torch.empty(N * K, device=src.device, dtype=torch.float32)
+                wt = ent[2] if reuse and ent[2] is not None else torch.empty(N * K, device=src.device, dtype=torch.float32)
             stale.append((w, src, N, K, wp, wt, tag))
         if not stale:
             return
@@ -69,7 +72,8 @@ class PackedWeights:
         Ks = (C.c_int32 * n)(*[e[3] for e in stale])
         wps = (C.c_void_p * n)(*[e[4].data_ptr() for e in stale])
         wts = (C.c_void_p * n)(*[(e[5].data_ptr() if e[5] is not None else None) for e in stale])
-        _lib.check(lib.mdt_op_pack_many(n, srcs, Ns, Ks, wps, wts, _stream(stale[0][1])))
+        with torch.cuda.device(stale[0][1].device):  # the library keeps its tables per CURRENT device
+            _lib.check(lib.mdt_op_pack_many(n, srcs, Ns, Ks, wps, wts, _stream(stale[0][1])))
         for w, src, N, K, wp, wt, tag in stale:
             self._cache[id(w)] = (tag, wp, wt)
         self._keep = [e[1] for e in stale]  # converted / re-laid-out sources stay alive until the launch has run

@@ -149,10 +149,22 @@ class MaskedTransformerImgDecoder(nn.Module):
         self._packs.invalidate()
         return out
 
+    def _apply(self, fn, *a, **kw):  # .to() / .cuda(): the parameters are re-created, the packed images belong to the old ones
+        out = super()._apply(fn, *a, **kw)
+        if getattr(self, "_packs", None) is not None:
+            self._packs = ops.PackedWeights()
+        return out
+
     def __getstate__(self):
         d = self.__dict__.copy()
         d["_packs"] = ops.PackedWeights()
         return d
+
+    def __setstate__(self, state):  # the copy is a new module: register it with the optimizer hook (utils/weight_cache.py)
+        super().__setstate__(state)
+        from ...utils import weight_cache
+        weight_cache.track(self)
+        self.mark_dirty()
 
     # -- helpers -------------------------------------------------------------------------------------
     def _linear(self, x, lin) -> torch.Tensor:
@@ -172,9 +184,19 @@ class MaskedTransformerImgDecoder(nn.Module):
         g = R // p
         return imgs.reshape(B, X, Cn, g, p, g, p).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, X, g * g, Cn * p * p)
 
-    def mask(self, n_patches: int, bsz: int, device, mask_ratio: Optional[float] = None, noise: Optional[torch.Tensor] = None):
+    def mask(self, ctx_patches: torch.Tensor, mask_ratio: Optional[float] = None):
+        """The reference's method by its own signature (:126-171): per-sample random masking of (bsz, ctx, n_patches, d)
+        patch embeddings, the same patches for every frame -> (visible_patches, mask (1 = removed), restore_idxs).  The
+        forward below does not come through here (it never embeds the patches it would drop); this is for callers of the
+        reference API."""
+        bsz, ctx_len, n_patches, d = ctx_patches.shape
+        shuffle, m, restore, n_keep = self._mask_indices(n_patches, bsz, ctx_patches.device, mask_ratio)
+        visible = torch.gather(ctx_patches, 2, shuffle[:, None, :n_keep, None].expand(bsz, ctx_len, n_keep, d))
+        return visible, m, restore
+
+    def _mask_indices(self, n_patches: int, bsz: int, device, mask_ratio: Optional[float] = None, noise: Optional[torch.Tensor] = None):
         """Per-sample random masking, the SAME patches for both frames (reference :124-171, symmetric branch): returns
-        (shuffle_idxs, mask (1 = removed), restore_idxs).  ``noise`` (bsz, n_patches) replaces the uniform draw."""
+        (shuffle_idxs, mask (1 = removed), restore_idxs, n_keep).  ``noise`` (bsz, n_patches) replaces the uniform draw."""
         if not self.symmetric_mask:
             raise NotImplementedError("symmetric_mask=False: the reference sorts its (bsz, ctx, n_patches) noise over the ctx axis "
                                       "(masked_transformer_decoder.py:159) and keeps patches 0/1 only; not implemented")
@@ -204,7 +226,7 @@ class MaskedTransformerImgDecoder(nn.Module):
         self._packs.refresh([m.weight for m in self.modules() if isinstance(m, (nn.Linear, nn.Conv2d))],
                             need_t=torch.is_grad_enabled())
         emb_context = self._linear(context.float(), self.encoder2decoder)
-        shuffle, m, restore, n_keep = self.mask(n, B, context.device, self.mask_ratio, noise)
+        shuffle, m, restore, n_keep = self._mask_indices(n, B, context.device, self.mask_ratio, noise)
         keep = shuffle[:, :n_keep]
         gidx = keep[:, None, :, None]
         # only the visible patches are embedded: the masked ones never reach the blocks (the reference embeds all 2 x 49

@@ -415,6 +415,12 @@ class HipScoreNetwork(nn.Module):
         d.pop("_ctx_engine", None)
         return d
 
+    def __setstate__(self, state):  # the copy is a new module: the optimizer hook has to know it, and it owns no images yet
+        super().__setstate__(state)
+        from ...utils import weight_cache
+        weight_cache.track(self)
+        self.mark_dirty()
+
     def mark_dirty(self) -> None:
         """Public escape hatch of the weight cache (see HipEngine.invalidate): call after writing parameters through
         ``.data`` or a foreign fused optimizer."""

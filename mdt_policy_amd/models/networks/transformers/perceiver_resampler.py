@@ -127,6 +127,12 @@ class PerceiverResampler(nn.Module):
         d["_handle"], d["_handle_device"], d["_uploaded"], d["_grad_layout"] = None, None, {}, None
         return d
 
+    def __setstate__(self, state):  # the copy is a new module: register it with the optimizer hook (utils/weight_cache.py)
+        super().__setstate__(state)
+        from ....utils import weight_cache
+        weight_cache.track(self)
+        self.mark_dirty()
+
     def _apply(self, fn, *a, **kw):  # .to()/.cuda(): parameters are re-created, drop the stale handle
         out = super()._apply(fn, *a, **kw)
         self._drop_handle()

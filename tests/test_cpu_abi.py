@@ -380,3 +380,32 @@ def test_optimizer_hook_marks_only_the_modules_that_own_a_stepped_parameter():
     gc.collect()
     torch.optim.SGD(b.parameters(), lr=0.1).step()
     assert b.dirty == 2
+
+
+def test_copies_of_the_facade_modules_are_tracked_by_the_optimizer_hook():
+    """copy.deepcopy / pickle go through __getstate__ / __setstate__, not __init__: the copy has to register itself with
+    utils/weight_cache.py as well, or a fused torch optimizer stepping the COPY (an EMA or target network that is trained)
+    would leave its packed weight images stale (fused optimizers never bump the version counters the cache keys on)."""
+    import copy
+    import pickle
+    import torch
+    from mdt_policy_amd import configs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    from mdt_policy_amd.models.img_generation.masked_transformer_decoder import MaskedTransformerImgDecoder
+    from mdt_policy_amd.models.networks.transformers.map_pool import MAPBlock
+    from mdt_policy_amd.models.networks.transformers.perceiver_resampler import PerceiverResampler
+    from mdt_policy_amd.utils import weight_cache
+
+    mods = [GCDenoiser(configs.mdtv_tiny(), 0.5).inner_model,
+            MaskedTransformerImgDecoder(resolution=32, patch_size=16, decoder_depth=1, decoder_embed_dim=48, decoder_n_heads=2,
+                                        context_dim=32, mask_ratio=0.75),
+            MAPBlock(n_latents=1, embed_dim=64, n_heads=4, output_dim=None), PerceiverResampler(dim=64, depth=1, dim_head=16, heads=2, num_latents=3)]
+    for m in mods:
+        for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+            assert clone in weight_cache._tracked, type(m).__name__
+            marks = []
+            clone.mark_dirty = lambda marks=marks: marks.append(1)
+            p = next(q for q in clone.parameters() if q.requires_grad)
+            p.grad = torch.zeros_like(p)
+            torch.optim.SGD([p], lr=0.1).step()
+            assert marks, f"{type(m).__name__}: the optimizer hook did not reach the copy"

@@ -34,3 +34,52 @@ def test_bench_two_ranks_over_rccl():
     assert j["collective"]["backend"] == "nccl" and j["collective"]["rccl_ranks"] == 2
     assert j["collective"]["gather_verified"] is True  # shape (2 B, 10, 7), rank-ordered blocks equal to each rank's own output
     assert j["value"] > 0
+
+
+_RAGGED_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MDT_ROOT"])
+from mdt_policy_amd import configs, sharding, synthetic
+from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+cfg = configs.mdtv_tiny()
+model = GCDenoiser(cfg, 0.5)
+shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=3, profile="rich").items()})
+model = model.to(dev).eval()
+total = 2 * 8 + 1                                   # 17 chunks over 2 ranks: shards of 9 and 8 -> the padded (ragged) gather
+inp = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.sampler_inputs(total, cfg, seed=4).items()}   # replicated request
+state = {"state_images": inp["state_images"], "modality": "lang"}
+sig = gs.get_sigmas_exponential(4, 0.001, 80.0)
+fn = lambda s, x, g, sg: gs.sample_ddim(model, s, x, g, sg)
+with torch.no_grad():
+    got = sharding.sample_sharded(fn, state, inp["noise"] * 80.0, inp["goal"], sig)
+    whole = fn(state, inp["noise"] * 80.0, inp["goal"], sig)                  # every rank also samples the whole request
+torch.cuda.synchronize()
+lo, hi = sharding.shard_bounds(total, rank, world)
+ok = got.shape == whole.shape and torch.allclose(got, whole, rtol=1e-4, atol=1e-5) and hi - lo == (9 if rank == 0 else 8)
+flag = torch.tensor([1 if ok else 0], device=dev)
+dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+if rank == 0:
+    print("RAGGED_OK" if flag.item() == 1 else "RAGGED_BAD", dist.get_backend(), tuple(got.shape), flush=True)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
+def test_ragged_shards_over_rccl(tmp_path):
+    """sharding.sample_sharded with a request that does not divide by the ranks (17 chunks, 2 ranks): the padded
+    all_gather_into_tensor branch over RCCL -- the other collective shape of the multi-GPU path (the equal-shard one is
+    covered by the bench launch above; both run on gloo in tests/test_sharding_gloo.py)."""
+    script = tmp_path / "ragged_worker.py"
+    script.write_text(_RAGGED_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MDT_ROOT=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "RAGGED_OK nccl (17, 10, 7)" in res.stdout, res.stdout[-500:]

@@ -433,3 +433,162 @@ def test_collapsed_cross_attention(lib, D, H, Te, Ta, bias):
     o = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Ta, D) @ Wo.double().T + (bo.double() if bias else 0)
     assert_close(t["y"].cpu().view(B, Ta, D), (yd + o).float(), rtol=2e-4, atol=2e-4, what="collapsed cross attention")
     assert not torch.isnan(U).any() and not torch.isnan(c).any()
+
+
+# ------------------------------------------------------------------------------------------------
+# fused MLP sublayer (mdt_op_mlp) and the readers of its partial slabs (mdt_gemm_args.a_parts, mdt_head_args.y_parts)
+# ------------------------------------------------------------------------------------------------
+def _gemm_args(lib, keep, A, lda, Wp, N, K, M, out=None, ldo=0, bias=None):
+    a = lib.GemmArgs()
+    a.A, a.lda, a.Wp, a.M, a.N, a.K = A.data_ptr(), lda, Wp.data_ptr(), M, N, K
+    if out is not None:
+        a.out, a.ldo = out.data_ptr(), ldo
+    if bias is not None:
+        bd = dev(bias); keep.append(bd); a.bias = bd.data_ptr()
+    a.shift_off = a.scale_off = a.gate_off = -1
+    a.rows_per_sample, a.gin, a.gout, a.goff = 1, 1, 1, 0
+    return a
+
+
+def run_mlp(lib, x, W1, W2, ln_w, ln_b=None, b1=None, b2=None, mod=None, mod_stride=0, offs=None, rps=1):
+    """-> (slabs (S, M, D) on the host, S).  offs = (shift, scale, gate) offsets inside a mod row or None."""
+    M, D = x.shape
+    keep = []
+    xd, P1, P2 = dev(x), pack(lib, W1), pack(lib, W2)
+    S = 4 * D // 512
+    parts = torch.full((S, M, D), float("nan"), device="cuda")
+    f = _gemm_args(lib, keep, xd, D, P1, 4 * D, D, M, bias=b1)
+    p = _gemm_args(lib, keep, xd, D, P2, D, 4 * D, M, bias=b2)
+    p.ldo = D
+    f.ln, f.act = 1, lib.ACT["gelu"]
+    lw = dev(ln_w); keep.append(lw); f.ln_w = lw.data_ptr()
+    if ln_b is not None:
+        lb = dev(ln_b); keep.append(lb); f.ln_b = lb.data_ptr()
+    if mod is not None:
+        md = dev(mod); keep.append(md)
+        f.mod = p.mod = md.data_ptr()
+        f.mod_stride = p.mod_stride = mod_stride
+        f.shift_off, f.scale_off, p.gate_off = offs
+        f.rows_per_sample = p.rows_per_sample = rps
+    n = C.c_int32(0)
+    lib.check(lib.load().mdt_op_mlp(C.byref(f), C.byref(p), parts.data_ptr(), M * D, C.byref(n), stream()))
+    torch.cuda.synchronize()
+    assert n.value == S
+    return parts, S
+
+
+def ref_mlp(x, W1, W2, ln_w, ln_b, b1, b2, shift=None, scale=None, gate=None):
+    x = x.double()
+    h = F.layer_norm(x, (x.shape[1],), ln_w.double(), None if ln_b is None else ln_b.double(), 1e-5)
+    if shift is not None:
+        h = shift.double() + h * scale.double()
+    u = h @ W1.double().T + (0 if b1 is None else b1.double())
+    v = F.gelu(u) @ W2.double().T + (0 if b2 is None else b2.double())
+    return x + (v if gate is None else gate.double() * v)
+
+
+@pytest.mark.parametrize("M,D,case", [(2560, 384, "bcast"), (2560, 384, "rows"), (2560, 384, "plain_bias"), (1777, 384, "bcast"),
+                                      (45, 384, "rows"), (320, 512, "bcast"), (200, 256, "rows"), (96, 128, "plain_bias")])
+def test_fused_mlp_slabs_sum_to_the_sublayer(lib, M, D, case):
+    """k_mlp: LayerNorm (+ modulate) -> c_fc -> GELU -> c_proj -> gate -> residual as one launch; the slabs it leaves add
+    up (in slab order) to the float64 sublayer, slab 0 carrying the residual and the second bias."""
+    g = torch.Generator().manual_seed(M + D + len(case))
+    T = 10 if M % 10 == 0 else (5 if M % 5 == 0 else 1)
+    x = torch.randn(M, D, generator=g) * 1.5 + 0.2
+    W1 = torch.randn(4 * D, D, generator=g) / math.sqrt(D)
+    W2 = torch.randn(D, 4 * D, generator=g) / math.sqrt(4 * D)
+    lw = torch.randn(D, generator=g) * 0.2 + 1
+    kw, ref = {}, {}
+    lb = b1 = b2 = None
+    if case == "plain_bias":
+        lb, b1, b2 = torch.randn(D, generator=g) * 0.2, torch.randn(4 * D, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    else:
+        nb = M // T if case == "rows" else 1
+        mod = torch.randn(nb, 6 * D, generator=g) * 0.5
+        kw = dict(mod=mod, mod_stride=6 * D if case == "rows" else 0, offs=(3 * D, 4 * D, 5 * D), rps=T)
+        pick = (lambda o: mod[:, o:o + D].repeat_interleave(T, 0)) if case == "rows" else (lambda o: mod[:, o:o + D])
+        ref = dict(shift=pick(3 * D), scale=pick(4 * D), gate=pick(5 * D))
+    parts, S = run_mlp(lib, x, W1, W2, lw, ln_b=lb, b1=b1, b2=b2, **kw)
+    got = parts[0].clone()
+    for s in range(1, S):
+        got += parts[s]
+    want = ref_mlp(x, W1, W2, lw, lb, b1, b2, **ref).float()
+    assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4, what=f"fused mlp {M}x{D} {case}")
+
+
+@pytest.mark.parametrize("M,N,XP,case", [(2560, 1152, 3, "bcast"), (2560, 1152, 3, "rows"), (1530, 1152, 3, "ln"),
+                                         (640, 1536, 4, "bcast"), (77, 768, 2, "ln")])
+def test_gemm_reads_the_sum_of_slabs(lib, M, N, XP, case):
+    """mdt_gemm_args.a_parts: the LayerNorm prologue adds XP slabs in order, bit-identical to the same GEMM on the
+    pre-summed rows, and leaves the sum in a_merged."""
+    g = torch.Generator().manual_seed(M + N + XP)
+    D = 128 * XP
+    T = 10 if M % 10 == 0 else 1
+    slabs = torch.randn(XP, M, D, generator=g)
+    W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g)
+    lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    summed = slabs[0].clone()
+    for s in range(1, XP):
+        summed = summed + slabs[s]            # fp32, slab order: what the kernel does
+    kw = {}
+    if case != "ln":
+        nb = M // T if case == "rows" else 1
+        mod = torch.randn(nb, 2 * D, generator=g) * 0.5
+        kw = dict(mod=mod, mod_stride=2 * D if case == "rows" else 0, shift_off=0, scale_off=D, rps=T)
+    try:
+        lib.load().mdt_op_set_gemm_geometry(3 if N % 384 == 0 else 4)
+        want = run_gemm(lib, summed, W, bias=b, ln_w=lw, ln_b=lb, **kw)
+    finally:
+        lib.load().mdt_op_set_gemm_geometry(0)
+    keep = []
+    sd, Pd = dev(slabs), pack(lib, W)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    merged = torch.full((M, D), float("nan"), device="cuda")
+    a = _gemm_args(lib, keep, sd, D, Pd, N, D, M, out=out, ldo=N, bias=b)
+    a.ln = 1
+    for name, t in (("ln_w", lw), ("ln_b", lb)):
+        td = dev(t); keep.append(td); setattr(a, name, td.data_ptr())
+    if kw:
+        md = dev(kw["mod"]); keep.append(md)
+        a.mod, a.mod_stride, a.shift_off, a.scale_off, a.rows_per_sample = md.data_ptr(), kw["mod_stride"], 0, D, T
+    a.a_parts, a.a_part_stride, a.a_merged = XP, M * D, merged.data_ptr()
+    lib.check(lib.load().mdt_op_gemm(C.byref(a), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(merged.cpu(), summed), "a_merged is not the slab-order sum"
+    assert torch.equal(out.cpu(), want), "merge-on-read GEMM differs from the GEMM on the summed rows"
+
+
+@pytest.mark.parametrize("M,XP", [(2560, 3), (77, 4), (10, 2)])
+def test_head_reads_the_sum_of_slabs(lib, M, XP):
+    """mdt_head_args.y_parts: identical to the head on the pre-summed rows (DDIM mode with the next step's embedding)."""
+    g = torch.Generator().manual_seed(M + XP)
+    D, A, T = 128 * XP, 7, 10 if M % 10 == 0 else 1
+    slabs = torch.randn(XP, M, D, generator=g)
+    summed = slabs[0].clone()
+    for s in range(1, XP):
+        summed = summed + slabs[s]
+    lw = torch.randn(D, generator=g) * 0.2 + 1
+    Wp, bp = torch.randn(A, D, generator=g) / math.sqrt(D), torch.randn(A, generator=g) * 0.1
+    WaT, ba = torch.randn(A, D, generator=g) * 0.3, torch.randn(D, generator=g) * 0.1
+    x = torch.randn(M, A, generator=g)
+    sig = torch.tensor([3.0]); step = torch.tensor([0.6, 0.4, 1.8, 3.0])
+
+    def run(y, parts):
+        keep = [dev(t) for t in (y, lw, Wp, bp, x, sig, step, WaT, ba)]
+        yd, lwd, Wpd, bpd, xd, sd, std, Wad, bad = keep
+        out = torch.full((M, A), float("nan"), device="cuda")
+        ynext = torch.full((M, D), float("nan"), device="cuda")
+        a = lib.HeadArgs()
+        a.y, a.ln_w, a.Wp, a.bp, a.x, a.sigma, a.sigma_stride, a.out = (yd.data_ptr(), lwd.data_ptr(), Wpd.data_ptr(), bpd.data_ptr(),
+                                                                      xd.data_ptr(), sd.data_ptr(), 0, out.data_ptr())
+        a.M, a.D, a.A, a.rows_per_sample, a.mode, a.step, a.sigma_data = M, D, A, T, lib.HEAD["ddim"], std.data_ptr(), 0.5
+        a.y_next, a.Wa, a.ba = ynext.data_ptr(), Wad.data_ptr(), bad.data_ptr()
+        if parts > 1:
+            a.y_parts, a.y_part_stride = parts, M * D
+        lib.check(lib.load().mdt_op_head(C.byref(a), stream()))
+        torch.cuda.synchronize()
+        return out.cpu(), ynext.cpu()
+
+    want, want_next = run(summed, 1)
+    got, got_next = run(slabs, XP)
+    assert torch.equal(got, want) and torch.equal(got_next, want_next)

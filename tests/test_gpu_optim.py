@@ -133,6 +133,46 @@ def test_torch_fused_optimizer_steps_are_seen_by_the_weight_cache():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("how", ["deepcopy", "pickle"])
+def test_fused_optimizer_steps_on_a_copy_of_the_module_are_seen(how):
+    """A module made by copy.deepcopy / pickle never ran __init__: it registers with the optimizer hook in __setstate__.
+    Two fused-AdamW steps on the COPY (after the copy has been used once, so that it owns uploaded images), then the HIP
+    forward of the copy against the oracle on the copy's updated parameters."""
+    import copy
+    import pickle
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    from oracle import mdt_oracle as O
+    from tests.helpers import assert_close
+    cfg = configs.mdtv_tiny()
+    torch.manual_seed(0)
+    orig = GCDenoiser(cfg, 0.5).cuda().eval()
+    model = copy.deepcopy(orig) if how == "deepcopy" else pickle.loads(pickle.dumps(orig))
+    B = 4
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
+    li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
+    state = {"state_images": inp["state_images"], "modality": "lang"}
+    x = li["actions"] + li["noise_train"] * li["sigma"][:, None, None]
+    with torch.no_grad():
+        first = model(state, x, inp["goal"], li["sigma"]).clone()  # uploads the copy's images
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-2, fused=True)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model.loss(state, li["actions"], inp["goal"], li["noise_train"], li["sigma"])
+        loss.backward()
+        opt.step()
+    with torch.no_grad():
+        got = model(state, x, inp["goal"], li["sigma"])
+        untouched = orig(state, x, inp["goal"], li["sigma"])
+    assert not torch.equal(got, first)
+    assert torch.equal(untouched, first), "stepping the copy changed the original"
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    st = {"state_images": inp["state_images"].cpu(), "modality": "lang"}
+    want = O.denoise(P, cfg, st, x.cpu(), inp["goal"].cpu(), li["sigma"].cpu(), 0.5, "mdtv")
+    assert_close(got.cpu(), want, what=f"forward of the {how} copy after two fused optimizer steps")
+
+
+@pytest.mark.gpu
 def test_five_training_steps_follow_the_oracle_trajectory():
     """End to end: five optimizer steps of the HIP path (loss forward, HIP backward, FusedAdamW, batched re-upload) against the
     same five steps taken on the CPU with float64 autograd through the oracle and torch.optim.AdamW -- the loss of every step

@@ -23,6 +23,7 @@ def _lib():
 def _restore_switch():
     yield
     _lib().mdt_op_set_persist(-1)
+    _lib().mdt_op_set_mlp_fuse_min(-1)
 
 
 def _engine(model):
@@ -31,6 +32,9 @@ def _engine(model):
 
 def _sample(model, state, x_T, goal, sig, persist):
     _lib().mdt_op_set_persist(1 if persist else 0)
+    # the persistent kernel walks the two-GEMM MLP phases; large batches of the launch path fuse them into one launch that
+    # adds the partial products in another order -- compare like with like
+    _lib().mdt_op_set_mlp_fuse_min(-1 if persist else 0)
     eng = _engine(model)
     n0 = eng.persist_launches()
     with torch.no_grad():
