@@ -276,6 +276,13 @@ def cpu_baseline(cfg, P, batch, n_denoise, budget_s, threads, only=None):
 
     if only is not None:  # child process: exactly one leg
         if len(only) > 3 and only[3]:  # worker of the all-host-threads leg: warm up, report, wait for "go", one timed run
+            if len(only) > 4 and only[4] >= 0 and hasattr(os, "sched_setaffinity"):
+                # its own block of logical CPUs (what numactl / taskset do for a batch-sharded deployment): unpinned, 16 x 16
+                # OpenMP threads migrate over 256 CPUs and spin in each other's barriers (measured 88 chunks/s for the host)
+                cpus = sorted(os.sched_getaffinity(0))
+                mine = cpus[only[4] * only[0]:(only[4] + 1) * only[0]]
+                if len(mine) == only[0]:
+                    os.sched_setaffinity(0, mine)
             torch.set_num_threads(only[0])
             run(16, bool(only[1]))
             print("READY", flush=True)
@@ -307,12 +314,14 @@ def cpu_baseline(cfg, P, batch, n_denoise, budget_s, threads, only=None):
     # own shard at the same time; value = all chunks / the wall time from the common start to the last worker's finish.
     nproc = ncpu // max(1, threads)
     if nproc >= 2 and legs[0].get("value"):
-        shard = max(16, min(batch, int(legs[0]["value"] * 4) // 16 * 16))  # ~4 s per worker at the single-process rate
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{threads},0,0,{shard}", "--batch", str(batch),
-               "--denoise-steps", str(n_denoise)]
-        procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
-                                  env=dict(os.environ, HIP_VISIBLE_DEVICES="")) for _ in range(nproc)]
-        entry = {"threads": ncpu, "mode": "as_written", "processes": nproc, "threads_per_process": threads, "sample_batch": shard * nproc}
+        shard = max(16, min(batch, int(legs[0]["value"] * 2) // 16 * 16))  # ~2 s per worker at the single-process rate
+        cmd = lambda i: [sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{threads},0,0,{shard},{i}", "--batch", str(batch),
+                         "--denoise-steps", str(n_denoise)]
+        procs = [subprocess.Popen(cmd(i), stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                  env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_WAIT_POLICY="PASSIVE", OMP_PROC_BIND="false"))
+                 for i in range(nproc)]
+        entry = {"threads": ncpu, "mode": "as_written", "processes": nproc, "threads_per_process": threads, "sample_batch": shard * nproc,
+                 "pinning": "each worker on its own block of logical CPUs (sched_setaffinity)"}
         try:
             import select
             deadline = time.perf_counter() + 120.0
@@ -359,11 +368,12 @@ def main():
         from mdt_policy_amd import configs, synthetic
         nt, hoist, budget, *rest = args.cpu_leg.split(",")
         shard = int(rest[0]) if rest else 0
+        widx = int(rest[1]) if len(rest) > 1 else -1
         cfg = configs.mdtv_default()
         from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
         shapes = [(k, tuple(v.shape)) for k, v in GCDenoiser(cfg, sigma_data=0.5).state_dict().items()]
         P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, seed=0, profile="init").items()}
-        print(json.dumps(cpu_baseline(cfg, P, args.batch, args.denoise_steps, float(budget), int(nt), only=(int(nt), int(hoist), float(budget), shard))), flush=True)
+        print(json.dumps(cpu_baseline(cfg, P, args.batch, args.denoise_steps, float(budget), int(nt), only=(int(nt), int(hoist), float(budget), shard, widx))), flush=True)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

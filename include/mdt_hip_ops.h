@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-enum { MDT_ACT_NONE = 0, MDT_ACT_GELU = 1, MDT_ACT_MISH = 2, MDT_ACT_SILU = 3 };
+enum { MDT_ACT_NONE = 0, MDT_ACT_GELU = 1, MDT_ACT_MISH = 2, MDT_ACT_SILU = 3,
+       MDT_ACT_SWIGLU = 4 /* only as mdt_linear_bwd_args.dx_act: the layer below is a SwishGLU, dX has 2K columns */ };
 enum { MDT_HEAD_DENOISED = 0, MDT_HEAD_DDIM = 1, MDT_HEAD_RAW = 2 };
 
 /* Number of floats of the fragment-packed image of an (N, K) Linear weight (N, K multiples of 16). */
@@ -36,6 +37,10 @@ int64_t mdt_op_packed_numel(int64_t N, int64_t K);
  * consecutive-k values W[n][k0 + 4*(l>>4) .. +3] -- the operand order of v_mfma_f32_16x16x4_f32. */
 mdt_status mdt_op_pack_weight(const float *w, int64_t n_rows, int64_t K, float *packed, int64_t n_off,
                               int64_t N_total, void *stream);
+/* The packed image of a SwishGLU project weight (2H, K) for mdt_gemm_args.aux_mode 3: 16-row tile 2t holds projected rows
+ * [16t, 16t+16), tile 2t+1 the gate rows [H + 16t, H + 16t + 16) (voltron SwishGLU / transformer_blocks.py:54-62:
+ * projected, gate = project(x).tensor_split(2, dim=-1)).  H % 16 == 0, K % 16 == 0. */
+mdt_status mdt_op_pack_weight_glu(const float *w, int64_t H2, int64_t K, float *packed, void *stream);
 
 typedef struct {
     const float *A;        /* (M, K) activations, row stride lda (multiple of 4)                      */
@@ -66,7 +71,14 @@ typedef struct {
     /* training: a second (M, N) operand laid out like `out` (row stride ldo, same row remap), plain prologue, no residual:
      *   aux_mode 1: aux = the value BEFORE `act` (after bias): one launch leaves both u and act(u);
      *   aux_mode 2: out = value * act'(aux)  -- `act` names the activation whose derivative is taken, the value itself is
-     *               not activated (dX of the Linear that follows an activation: d_u = (dY W) * act'(u)).            */
+     *               not activated (dX of the Linear that follows an activation: d_u = (dY W) * act'(u)).
+     *   aux_mode 3: SwishGLU forward on the producing Linear (N = 2H columns [projected | gate]; Wp packed by
+     *               mdt_op_pack_weight_glu, which interleaves the two halves tile by tile so that one wave holds a projected
+     *               column and its gate): aux (M, 2H, row stride 2 * ldo) = u in its natural column order, out (M, H, row
+     *               stride ldo) = projected * silu(gate).  N % 32 == 0.
+     *   aux_mode 4: SwishGLU backward on the input-gradient product of the Linear that FOLLOWS it (N = H columns of
+     *               d_out): aux = u (M, 2H, row stride ldo), out (M, 2H, row stride ldo) = [value * silu(gate) |
+     *               value * projected * silu'(gate)].                                                              */
     const float *aux;
     int32_t aux_mode;
     /* merge-on-read (consumer side of mdt_op_mlp): a_parts >= 2 means the activation rows are the SUM of a_parts arrays

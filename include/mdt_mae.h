@@ -55,6 +55,18 @@ mdt_status mdt_op_attn_mid_bwd(const float *qkv, int64_t ld_qkv, const float *ou
                                int64_t ld_do, float *d_qkv, int64_t ld_dqkv, int64_t B, int32_t H, int32_t hd, int32_t T,
                                float scale, void *stream);
 
+/* compute_loss of the decoder (masked_transformer_decoder.py:228-262, symmetric mask) in one pass each way:
+ *   loss = 1/2 sum_{x in {0,1}} [ sum_{b,n} mask[b][n] * mean_e (rec[b][x][n][e] - target[b][x][n][e])^2 ] / sum(mask)
+ * with target = patchify(imgs): element e = (ph * P + pw) * C + c of patch n = (gh, gw) is imgs[b][x][c][gh P + ph][gw P + pw]
+ * (:206-213) -- read straight out of the images, no patchified copy.  rec (B, X, n, P*P*C) contiguous, imgs (B, X, C, R, R)
+ * contiguous, mask (B, n) of 0 / 1.  partial: B * X * n floats of scratch; loss: 1 float; mask_sum: 1 float (kept for the
+ * backward).  Deterministic (per-patch sums, then one fixed-order reduction). */
+mdt_status mdt_op_patch_mse_fwd(const float *rec, const float *imgs, const float *mask, float *partial, float *loss,
+                                float *mask_sum, int64_t B, int32_t X, int32_t C_, int32_t R, int32_t P, void *stream);
+/* d_rec = g * d loss / d rec, g a device scalar (the incoming gradient); zero on the visible patches. */
+mdt_status mdt_op_patch_mse_bwd(const float *rec, const float *imgs, const float *mask, const float *mask_sum, const float *g,
+                                float *d_rec, int64_t B, int32_t X, int32_t C_, int32_t R, int32_t P, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,7 +147,7 @@ class InfoNCEArgs(C.Structure):
 INFONCE_MODE = {"symmetric": 0, "img_to_text": 1, "text_to_img": 2}
 ARCH = {"mdtv": 0, "mdt": 1}
 MODALITY = {"vis": 0, "lang": 1}
-ACT = {"none": 0, "gelu": 1, "mish": 2, "silu": 3}
+ACT = {"none": 0, "gelu": 1, "mish": 2, "silu": 3, "swiglu": 4}
 HEAD = {"denoised": 0, "ddim": 1, "raw": 2}
 RAW_OUTPUT, RAW_INPUT, SIGMA_SCALAR = 1, 2, 4
 
@@ -178,6 +178,7 @@ SYMBOLS = [
     ("mdt_fnv1_32", C.c_uint32, [C.c_char_p, C.c_uint64, C.c_uint32]),
     ("mdt_op_packed_numel", _I64, [_I64, _I64]),
     ("mdt_op_pack_weight", _I32, [_VP, _I64, _I64, _VP, _I64, _I64, _VP]),
+    ("mdt_op_pack_weight_glu", _I32, [_VP, _I64, _I64, _VP, _VP]),
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
     ("mdt_op_mlp", _I32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _VP, _I64, C.POINTER(_I32), _VP]),
     ("mdt_op_set_gemm_geometry", None, [_I32]),
@@ -257,6 +258,8 @@ SYMBOLS = [
     ("mdt_op_swiglu_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_attn_mid_fwd", _I32, [_VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),
     ("mdt_op_attn_mid_bwd", _I32, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),
+    ("mdt_op_patch_mse_fwd", _I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _VP]),
+    ("mdt_op_patch_mse_bwd", _I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _VP]),
     ("mdt_op_infonce_scratch", _I64, [_I64, _I64]),
     ("mdt_op_infonce", _I32, [C.POINTER(InfoNCEArgs), _VP]),
 ]

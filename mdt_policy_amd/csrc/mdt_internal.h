@@ -87,6 +87,7 @@ hipError_t mdt_launch_noise_input(const float* act, const float* noise, const fl
 hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float* noised, const float* sigma, float sd,
                                   int64_t n, int per_sample, float* loss, hipStream_t s);
 hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* packed, int n_off, hipStream_t s);
+hipError_t mdt_launch_pack_weight_glu(const float* w, int H, int K, float* packed, hipStream_t s);
 // one move of a batched parameter upload (k_multi_load): src is (rows, K) row-major on the device
 enum { MDT_LOAD_RAW = 0, MDT_LOAD_PACK = 1, MDT_LOAD_PACK_T = 2, MDT_LOAD_TRANSPOSE = 3, MDT_LOAD_PAD_COLS = 4 };
 struct mdt_load_entry {

@@ -42,6 +42,22 @@ __global__ void k_pack_weight(const float* __restrict__ w, int n_rows, int K, fl
     packed[(((int64_t)nt * K16 + kc) * 64 + (ni + 16 * h)) * 4 + j] = w[idx];
 }
 
+// SwishGLU project weight (2H, K): 16-row tile 2t of the image = projected rows [16t, +16), tile 2t+1 = gate rows [H + 16t, +16)
+__global__ void k_pack_weight_glu(const float* __restrict__ w, int H, int K, float* __restrict__ packed) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K4 = K >> 2;
+    if (idx >= (int64_t)2 * H * K4) return;
+    const int r = (int)(idx / K4), c = 4 * (int)(idx - (int64_t)r * K4);
+    const int half = r >= H, rr = r - half * H;
+    const int nt = 2 * (rr >> 4) + half, ni = rr & 15, kc = c >> 4, h = (c & 15) >> 2;
+    *(f32x4*)(packed + (((int64_t)nt * (K >> 4) + kc) * 64 + (ni + 16 * h)) * 4) = *(const f32x4*)(w + (int64_t)r * K + c);
+}
+hipError_t mdt_launch_pack_weight_glu(const float* w, int H, int K, float* packed, hipStream_t s) {
+    const int64_t n = (int64_t)2 * H * (K >> 2);
+    hipLaunchKernelGGL(k_pack_weight_glu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, H, K, packed);
+    return hipGetLastError();
+}
+
 // Every parameter image of one load_state_dict / optimizer step in ONE launch (mdt_load_params): a table of moves --
 // raw copies, fragment packs, transposed fragment packs (training), transposes, column pads -- and a (move, chunk) list,
 // one workgroup per 1024 source elements.  The per-parameter launches this replaces (~230 of 3-6 us for MDT-V) were
@@ -484,6 +500,11 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     // N = 192 layers of the masked-image decoder: 595 us as 16-column split-K tiles vs ~300 us tiled)
     // the training hooks of the epilogue (aux) exist in the plain-prologue, non-residual tiled kernels only
     if (a.aux_mode && (!a.aux || a.ln || a.residual || a.batch > 1 || a.K > 512)) return hipErrorInvalidValue;
+    if (a.aux_mode == 3) {  // SwishGLU forward: pairs of column tiles per wave -> the even-NTW geometries only
+        if ((a.N & 31) || a.gin != 1 || a.gout != 1 || a.goff != 0 || a.act != MDT_ACT_NONE) return hipErrorInvalidValue;
+        const int kc = mdt_gemm_kchunk(a.K, 0, 384);
+        return (a.N % 256 == 0) ? launch_gemm_pro<2, 4, 4>(a, kc, s) : launch_gemm_pro<2, 2, 4>(a, kc, s);
+    }
     if (a.a_parts > 1) return launch_gemm_merge(a, s);
     if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {
         hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4, a.batch > 1 ? a.batch : 1), dim3(512), 0, s, a, g_zeros);
@@ -1006,9 +1027,10 @@ hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s) { retur
 
 // One workgroup (384 threads) per sample; body in mdt_tiles.h (xattn_tile)
 template <int NP>
-__global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const float* __restrict__ zeros) {
+__global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const float* __restrict__ zeros, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    xattn_tile<NP, false>(a, MDT_SAMPLE_REMAP(blockIdx.x, gridDim.x), lds, zeros, threadIdx.x);
+    xattn_tile<NP, false>(a, MDT_SAMPLE_REMAP(blockIdx.x, gridDim.x), lds, zeros, threadIdx.x, blockIdx.y * rows_per_wg,
+                          (blockIdx.y + 1) * rows_per_wg);
 }
 
 // which configurations the collapsed path covers (others keep the q GEMM + attention + c_proj GEMM sequence)
@@ -1027,10 +1049,16 @@ hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     const int NP = a.H * a.Te;
     const size_t lds = ((size_t)a.Ta * a.D + (size_t)a.Ta * NP * (a.D / 32) + (size_t)a.Ta * NP) * sizeof(float);
+    // rollout-sized batches: a sample's rows over several workgroups (1 row each up to 4 samples, 2 up to 8): one workgroup
+    // walking all 10 rows was 9.5 us of every decoder block at B = 1 -- the largest kernel of the rollout call
+    static int split_max = -1;
+    if (split_max < 0) { const char* e = getenv("MDT_HIP_XATTN_SPLIT_MAX"); split_max = e ? atoi(e) : 8; }
+    const int rpw = a.B > split_max ? a.Ta : (a.B <= 4 ? 1 : 2);
+    const dim3 grid(a.B, (a.Ta + rpw - 1) / rpw);
     switch (NP) {
-        case 32: hipLaunchKernelGGL((k_xattn_apply<32>), dim3(a.B), dim3(384), lds, s, a, g_zeros); break;
-        case 24: hipLaunchKernelGGL((k_xattn_apply<24>), dim3(a.B), dim3(384), lds, s, a, g_zeros); break;
-        default: hipLaunchKernelGGL((k_xattn_apply<16>), dim3(a.B), dim3(384), lds, s, a, g_zeros); break;
+        case 32: hipLaunchKernelGGL((k_xattn_apply<32>), grid, dim3(384), lds, s, a, g_zeros, rpw); break;
+        case 24: hipLaunchKernelGGL((k_xattn_apply<24>), grid, dim3(384), lds, s, a, g_zeros, rpw); break;
+        default: hipLaunchKernelGGL((k_xattn_apply<16>), grid, dim3(384), lds, s, a, g_zeros, rpw); break;
     }
     return hipGetLastError();
 }

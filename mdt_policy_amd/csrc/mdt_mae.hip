@@ -404,6 +404,178 @@ __global__ __launch_bounds__(512) void k_attn_mid_bwd(const float* __restrict__ 
     MAE_TS(12)
 }
 
+// acc[kt][q] += sum over the 16 rows i of a wave-private tile  W[i][16 kt + .] * x[i][16 q + .]   (kt < n key tiles, q < NC
+// feature tiles): the contribution of ONE query tile to dV = P^T dO or dK = dS^T Q.  W: 16 x ss tile in LDS (row i, key
+// column), read transposed (lane: key 16 kt + m, the four rows 4 g + e); x: the tile's 16 rows of dO / Q (stride HD + 4).
+template <int HD, int NTJ>
+__device__ __forceinline__ void mma_acc_trans(const float* W, int ss, const float* xrows, int n, int lane,
+                                              f32x4 (&acc)[NTJ][(HD + 15) / 16]) {
+    constexpr int ST = HD + 4, NC = (HD + 15) / 16;
+    const int m = lane & 15, g = lane >> 4;
+    const float* xp = xrows + (4 * g) * ST + m;
+    f32x4 xv[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const float* r = xp + 16 * q;
+        xv[q] = (f32x4){r[0], r[ST], r[2 * ST], r[3 * ST]};
+    }
+    const float* wp = W + (4 * g) * ss + m;
+#pragma unroll
+    for (int kt = 0; kt < NTJ; ++kt) {
+        if (kt < n) {
+            const float* w = wp + 16 * kt;
+            const f32x4 wv = (f32x4){w[0], w[ss], w[2 * ss], w[3 * ss]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) acc[kt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xv[q][e], acc[kt][q], 0, 0, 0);
+        }
+    }
+}
+
+// Backward, second form (default): like the forward, every wave owns whole QUERY tiles and keeps their score rows in the MFMA
+// accumulators -- P (recomputed, softmax in registers), dP = dO V^T and dS = P (dP - dO.O) never exist as a T x T matrix.  Per
+// query tile the wave passes P, then dS, through ONE wave-private 16 x T16 LDS tile (accumulator -> operand layout): dQ rows
+// go straight to memory, the tile's contributions to dV = P^T dO and dK = dS^T Q accumulate in registers (T16 x hd each) across
+// the wave's tiles.  One workgroup barrier after the loads, none inside; the four waves' dK / dV partials then meet in the
+// (now free) q / k / v / dO buffers in a fixed order.  80 KB of LDS at T = 102, hd = 24 (the first form: 115 KB, five
+// barrier-separated phases): two workgroups per CU, one loading or reducing while the other multiplies.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ fwd_out,
+                                                       int64_t ldf, const float* __restrict__ d_out, int64_t ldd,
+                                                       float* __restrict__ d_qkv, int64_t ldg, int H, int T, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 256, NW = NT / 64, ST = HD + 4, NTJ = TMAX / 16, NC = (HD + 15) / 16, H4 = HD / 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x, h = blockIdx.y, D = H * HD;
+    const int T16 = (T + 15) & ~15, n = T16 >> 4, ss = score_stride(T), m = lane & 15, g = lane >> 4;
+    float* qs = lds;
+    float* ks = qs + T16 * ST;
+    float* vs = ks + T16 * ST;
+    float* dos = vs + T16 * ST;
+    float* rowdot = dos + T16 * ST;                    // [T16]
+    float* ptile = rowdot + T16 + wave * 16 * ss;      // this wave's 16 x T16 tile (P, then dS)
+    const float* base = qkv + (int64_t)b * T * ld + h * HD;
+    const float* dob = d_out + (int64_t)b * T * ldd + h * HD;
+    const float* fob = fwd_out + (int64_t)b * T * ldf + h * HD;
+    {
+        const float* const src[4] = {base, base + D, base + 2 * D, dob};
+        const int64_t lds_[4] = {ld, ld, ld, ldd};
+        load_rows<HD, NT, 4>(src, lds_, qs, T, tid);   // q | k | v | dO are consecutive LDS buffers
+    }
+    for (int i = tid; i < T16; i += NT) {              // rowdot_i = dO_i . O_i  (= sum_j P_ij dP_ij), straight from memory
+        const int64_t ic = min(i, T - 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < H4; ++c) {
+            const f32x4 a = ldg4(dob + ic * ldd + 4 * c), o = ldg4(fob + ic * ldf + 4 * c);
+            acc += (a.x * o.x + a.y * o.y) + (a.z * o.z + a.w * o.w);
+        }
+        rowdot[i] = i < T ? acc : 0.f;
+    }
+    __syncthreads();
+    float* gq = d_qkv + (int64_t)b * T * ldg + h * HD;
+    const float sl2 = scale * 1.44269504088896341f;    // softmax in base 2
+    f32x4 dK[NTJ][NC], dV[NTJ][NC];
+#pragma unroll
+    for (int kt = 0; kt < NTJ; ++kt)
+#pragma unroll
+        for (int q = 0; q < NC; ++q) { dK[kt][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[kt][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int ti = wave; ti < n; ti += NW) {
+        f32x4 acc[NTJ], dp[NTJ];
+        score_row_tile<HD, NTJ>(qs + 16 * ti * ST, ks, n, lane, acc);
+        score_row_tile<HD, NTJ>(dos + 16 * ti * ST, vs, n, lane, dp);   // dP rows = dO rows . V rows
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sum[4] = {0.f, 0.f, 0.f, 0.f}, rd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd[r] = rowdot[16 * ti + 4 * g + r];
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            if (tj < n) {
+                const bool live = 16 * tj + m < T;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[tj][r] = live ? acc[tj][r] * sl2 : -INFINITY;
+                    mx[r] = fmaxf(mx[r], acc[tj][r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = group_max(mx[r]);
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            if (tj < n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[tj][r] = __builtin_amdgcn_exp2f(acc[tj][r] - mx[r]);
+                    sum[r] += acc[tj][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = 1.0f / group_sum(sum[r]);
+        // P -> tile; dS = scale * P * (dP - rowdot) stays in `dp`
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            if (tj < n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = acc[tj][r] * sum[r];
+                    ptile[(4 * g + r) * ss + 16 * tj + m] = pv;
+                    dp[tj][r] = pv * (dp[tj][r] - rd[r]) * scale;
+                }
+            }
+        }
+        mma_acc_trans<HD, NTJ>(ptile, ss, dos + 16 * ti * ST, n, lane, dV);   // dV += P_tile^T dO_tile
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            if (tj < n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ptile[(4 * g + r) * ss + 16 * tj + m] = dp[tj][r];
+            }
+        }
+        mma_rows_tile<HD, false>(ptile - 16 * ti * ss, ss, ks, gq, ldg, T, ti, lane);   // dQ rows of this tile = dS K
+        mma_acc_trans<HD, NTJ>(ptile, ss, qs + 16 * ti * ST, n, lane, dK);     // dK += dS_tile^T Q_tile
+    }
+    __syncthreads();   // everyone is done with q / k / v / dO: the four buffers now take the partial sums
+    // waves 0, 1 store their partials (dK -> buffers 0 / 1, dV -> 2 / 3), waves 2, 3 add theirs to them, then everybody adds
+    // the two halves and writes the rows out: ((w0 + w2) + (w1 + w3)), a fixed order
+    float* bK = lds + (wave & 1) * T16 * ST;
+    float* bV = lds + (2 + (wave & 1)) * T16 * ST;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((wave >> 1) == pass) {
+#pragma unroll
+            for (int kt = 0; kt < NTJ; ++kt) {
+                if (kt < n) {
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const int col = 16 * q + m;
+                        if (col < HD) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int o = (16 * kt + 4 * g + r) * ST + col;
+                                bK[o] = pass ? bK[o] + dK[kt][q][r] : dK[kt][q][r];
+                                bV[o] = pass ? bV[o] + dV[kt][q][r] : dV[kt][q][r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < T * H4; i += NT) {
+        const int t = i / H4, c = i - t * H4;
+        const int o = t * ST + 4 * c;
+        *(f32x4*)(gq + D + (int64_t)t * ldg + 4 * c) = *(const f32x4*)(lds + o) + *(const f32x4*)(lds + T16 * ST + o);
+        *(f32x4*)(gq + 2 * D + (int64_t)t * ldg + 4 * c) = *(const f32x4*)(lds + 2 * T16 * ST + o) + *(const f32x4*)(lds + 3 * T16 * ST + o);
+    }
+}
+
+size_t attn_mid_lds2(int hd, int T) {
+    const int T16 = (T + 15) & ~15, ss = T16 + 4;
+    return ((size_t)4 * T16 * (hd + 4) + T16 + (size_t)4 * 16 * ss) * sizeof(float);
+}
+
 size_t attn_mid_lds(int hd, int T, bool bwd) {
     const int T16 = (T + 15) & ~15, ss = T16 + 4;
     if (!bwd) return ((size_t)3 * T16 * (hd + 4) + (size_t)4 * 16 * ss + 16) * sizeof(float);  // q k v + 4 waves' P tiles
@@ -421,6 +593,16 @@ hipError_t launch_fwd(const float* qkv, int64_t ld, float* out, int64_t ldo, int
 template <int HD>
 hipError_t launch_bwd(const float* qkv, int64_t ld, const float* fo, int64_t ldf, const float* d_out, int64_t ldd, float* d_qkv,
                       int64_t ldg, int64_t B, int H, int T, float scale, hipStream_t s) {
+    static int form = -1;  // MDT_HIP_ATTN_BWD=1: the first form (T x T matrices in LDS, five phases), for A/B runs
+    if (form < 0) { const char* e = getenv("MDT_HIP_ATTN_BWD"); form = e ? atoi(e) : 2; }
+    if (form == 2 && HD <= 32) {  // (hd 48 / 64: the T16 x hd accumulators of dK and dV no longer fit the registers)
+        const size_t lds2 = attn_mid_lds2(HD, T);
+        hipError_t e2 = hipFuncSetAttribute((const void*)k_attn_mid_bwd2<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL((k_attn_mid_bwd2<HD>), dim3((unsigned)B, H), dim3(256), lds2, s, qkv, ld, fo, ldf, d_out, ldd, d_qkv, ldg, H,
+                           T, scale);
+        return hipGetLastError();
+    }
     const size_t lds = attn_mid_lds(HD, T, true);
     hipError_t e = hipFuncSetAttribute((const void*)k_attn_mid_bwd<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -573,5 +755,100 @@ extern "C" mdt_status mdt_op_swiglu_fwd(const float* u, float* out, int64_t M, i
 extern "C" mdt_status mdt_op_swiglu_bwd(const float* u, const float* d_out, float* du, int64_t M, int32_t H, void* stream) {
     if (!u || !d_out || !du || M < 1 || H < 1) return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_swiglu_bwd: bad argument");
     LAUNCH(mdt_launch_swiglu_bwd(u, d_out, du, M, H, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// masked per-patch MSE (compute_loss, masked_transformer_decoder.py:228-262) without the patchified copy of the images and
+// the five elementwise passes over (B, 2, n, 768) tensors: one workgroup per (b, x, patch) reads its 768 reconstruction
+// values (coalesced) and the patch's pixels out of the image planes, sums the squares; one more workgroup adds the per-patch
+// sums in a fixed order.  Visible patches (mask 0) are skipped.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int64_t img_index(int64_t bx, int patch, int e, int C_, int R, int P) {
+    const int g = R / P, gh = patch / g, gw = patch - gh * g;
+    const int c = e % C_, pp = e / C_, ph = pp / P, pw = pp - ph * P;
+    return ((bx * C_ + c) * R + gh * P + ph) * (int64_t)R + gw * P + pw;
+}
+__global__ __launch_bounds__(256) void k_patch_mse_fwd(const float* __restrict__ rec, const float* __restrict__ imgs,
+                                                       const float* __restrict__ mask, float* __restrict__ partial, int X, int n,
+                                                       int C_, int R, int P) {
+    const int64_t blk = blockIdx.x;  // (b * X + x) * n + patch
+    const int patch = (int)(blk % n);
+    const int64_t bx = blk / n, b = bx / X;
+    __shared__ float part[4];
+    if (mask[b * n + patch] == 0.f) {
+        if (threadIdx.x == 0) partial[blk] = 0.f;
+        return;
+    }
+    const int E = P * P * C_;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        const float d = rec[blk * E + e] - imgs[img_index(bx, patch, e, C_, R, P)];
+        s = fmaf(d, d, s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blk] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)E;
+}
+// one workgroup: loss and sum(mask) (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void k_patch_mse_reduce(const float* __restrict__ partial, const float* __restrict__ mask,
+                                                           float* __restrict__ loss, float* __restrict__ mask_sum, int64_t B, int X,
+                                                           int n) {
+    __shared__ float ps[16], ms[16];
+    float s = 0.f, m = 0.f;
+    for (int64_t i = threadIdx.x; i < B * X * n; i += 1024) s += partial[i];  // visible patches hold 0
+    for (int64_t i = threadIdx.x; i < B * n; i += 1024) m += mask[i];
+    s = wave_sum(s); m = wave_sum(m);
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = s; ms[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.f, tm = 0.f;
+        for (int w = 0; w < 16; ++w) { ts += ps[w]; tm += ms[w]; }
+        *mask_sum = tm;
+        *loss = ts / tm / (float)X;
+    }
+}
+__global__ __launch_bounds__(256) void k_patch_mse_bwd(const float* __restrict__ rec, const float* __restrict__ imgs,
+                                                       const float* __restrict__ mask, const float* __restrict__ mask_sum,
+                                                       const float* __restrict__ g, float* __restrict__ d_rec, int X, int n, int C_,
+                                                       int R, int P) {
+    const int64_t blk = blockIdx.x;
+    const int patch = (int)(blk % n);
+    const int64_t bx = blk / n, b = bx / X;
+    const int E = P * P * C_;
+    const bool on = mask[b * n + patch] != 0.f;
+    const float k = on ? 2.0f * g[0] / ((float)E * mask_sum[0] * (float)X) : 0.f;
+    for (int e = threadIdx.x; e < E; e += 256)
+        d_rec[blk * E + e] = on ? k * (rec[blk * E + e] - imgs[img_index(bx, patch, e, C_, R, P)]) : 0.f;
+}
+}  // namespace
+
+extern "C" mdt_status mdt_op_patch_mse_fwd(const float* rec, const float* imgs, const float* mask, float* partial, float* loss,
+                                           float* mask_sum, int64_t B, int32_t X, int32_t C_, int32_t R, int32_t P, void* stream) {
+    if (!rec || !imgs || !mask || !partial || !loss || !mask_sum || B < 1 || X < 1 || C_ < 1 || P < 1 || R < P || (R % P))
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_patch_mse_fwd: bad argument");
+    const int n = (R / P) * (R / P);
+    if (B * X * n > ((int64_t)1 << 31) - 1) return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_patch_mse_fwd: batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_patch_mse_fwd, dim3((unsigned)(B * X * n)), dim3(256), 0, s, rec, imgs, mask, partial, X, n, C_, R, P);
+    LAUNCH(hipGetLastError());
+    hipLaunchKernelGGL(k_patch_mse_reduce, dim3(1), dim3(1024), 0, s, partial, mask, loss, mask_sum, B, X, n);
+    LAUNCH(hipGetLastError());
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_patch_mse_bwd(const float* rec, const float* imgs, const float* mask, const float* mask_sum,
+                                           const float* g, float* d_rec, int64_t B, int32_t X, int32_t C_, int32_t R, int32_t P,
+                                           void* stream) {
+    if (!rec || !imgs || !mask || !mask_sum || !g || !d_rec || B < 1 || X < 1 || C_ < 1 || P < 1 || R < P || (R % P))
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_patch_mse_bwd: bad argument");
+    const int n = (R / P) * (R / P);
+    if (B * X * n > ((int64_t)1 << 31) - 1) return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_patch_mse_bwd: batch too large");
+    hipLaunchKernelGGL(k_patch_mse_bwd, dim3((unsigned)(B * X * n)), dim3(256), 0, (hipStream_t)stream, rec, imgs, mask, mask_sum, g,
+                       d_rec, X, n, C_, R, P);
+    LAUNCH(hipGetLastError());
     return MDT_OK;
 }

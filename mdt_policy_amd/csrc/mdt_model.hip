@@ -1094,6 +1094,13 @@ extern "C" mdt_status mdt_op_pack_weight(const float* w, int64_t n_rows, int64_t
     return MDT_OK;
 }
 
+extern "C" mdt_status mdt_op_pack_weight_glu(const float* w, int64_t H2, int64_t K, float* packed, void* stream) {
+    if (!w || !packed || H2 < 32 || (H2 % 32) || K < 16 || (K % 16) || misaligned(w) || misaligned(packed))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_glu: (2H, K) with H and K multiples of 16, 16-byte aligned pointers");
+    LAUNCH(mdt_launch_pack_weight_glu(w, (int)(H2 / 2), (int)K, packed, (hipStream_t)stream));
+    return MDT_OK;
+}
+
 extern "C" mdt_status mdt_op_gemm(const mdt_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->Wp || !a->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_gemm: null pointer");
     if (a->N % 16 || a->K % 16 || a->lda % 4 || a->ldo % 4 || a->M < 1)

@@ -20,6 +20,9 @@
 // XCD-aware block id: the dispatcher places block b on XCD b % 8 (speed-only assumption); give every XCD a
 // contiguous range of logical tiles so the row tiles it touches stay in its private L2.  Bijective for any n.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+#ifdef MDT_NO_XCD_REMAP  // A/B build: dispatch order = logical order (a row tile's column tiles land on different XCDs)
+    return bid;
+#endif
     const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
@@ -169,16 +172,32 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
 #pragma unroll
             for (int p = 0; p < 2; ++p) v[r][p] = LA.ld4(m * a.lda + cc[p]);
         }
-        f32x4 vx[XP > 1 ? XP - 1 : 1][RPW][2];
         if constexpr (XP > 1) {
+            // the other slabs, summed in slab order -- in two batches of rows so that at most half of them are in flight
+            // (all at once the kernel spilled: 5 MB of scratch traffic per launch); the column-0 workgroup also leaves the sum
+            // in a.a_merged for the residual GEMM that follows
+            constexpr int HB = RPW / 2 > 0 ? RPW / 2 : 1;
 #pragma unroll
-            for (int x = 1; x < XP; ++x)
+            for (int r0b = 0; r0b < RPW; r0b += HB) {
+                f32x4 vx[XP - 1][HB][2];
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    const int64_t m = min(m0 + r0 + r, a.M - 1);
+                for (int x = 1; x < XP; ++x)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) vx[x - 1][r][p] = LA.ld4((int64_t)x * a.a_part_stride + m * a.lda + cc[p]);
-                }
+                    for (int r = 0; r < HB; ++r) {
+                        const int64_t m = min(m0 + r0 + r0b + r, a.M - 1);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) vx[x - 1][r][p] = LA.ld4((int64_t)x * a.a_part_stride + m * a.lda + cc[p]);
+                    }
+#pragma unroll
+                for (int r = 0; r < HB; ++r)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                        for (int x = 1; x < XP; ++x) v[r0b + r][p] = v[r0b + r][p] + vx[x - 1][r][p];
+                        if (merge_out != nullptr && cv[p] && m0 + r0 + r0b + r < a.M)
+                            st4(merge_out + (int64_t)(m0 + r0 + r0b + r) * a.lda + cc[p], v[r0b + r][p]);
+                    }
+            }
         }
         const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
 #pragma unroll
@@ -214,17 +233,6 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
             }
         }
         const float inv_k = 1.0f / (float)klen;
-        if constexpr (XP > 1) {
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                    for (int x = 1; x < XP; ++x) v[r][p] = v[r][p] + vx[x - 1][r][p];  // slab order: deterministic
-                    if (merge_out != nullptr && cv[p] && m0 + r0 + r < a.M)
-                        st4(merge_out + (int64_t)(m0 + r0 + r) * a.lda + cc[p], v[r][p]);
-                }
-        }
         float red[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
@@ -357,9 +365,14 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
     {
         const float* biasp = a.bias != nullptr ? a.bias : zeros;
         const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
+        // SwishGLU forward (aux_mode 3): the weight image interleaves the projected / gate halves tile by tile
+        // (mdt_op_pack_weight_glu); bias and output columns are the NATURAL ones: tile T -> half T & 1, columns 16 (T >> 1)
+        constexpr bool AUX_HOOKS = PRO == PRO_PLAIN && !RES && !COH;
+        const bool glu_fwd = AUX_HOOKS && (NTW % 2 == 0) && a.aux_mode == 3;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            ncol[j] = min(nt0 + j, N16 - 1) * 16 + nq;
+            const int T = min(nt0 + j, N16 - 1);
+            ncol[j] = (glu_fwd ? (T & 1) * (a.N >> 1) + (T >> 1) * 16 : T * 16) + nq;
             bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
         }
 #pragma unroll
@@ -439,6 +452,27 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
                         const f32x4 u = *(const f32x4*)(a.aux + ooff[i] + ncol[j]);  // rows clamped above: in bounds
                         v.x *= apply_act_grad1(u.x, a.act); v.y *= apply_act_grad1(u.y, a.act);
                         v.z *= apply_act_grad1(u.z, a.act); v.w *= apply_act_grad1(u.w, a.act);
+                    } else if (a.aux_mode == 4) {
+                        // SwishGLU backward: v = d_out[m][c..c+3]; u row = [projected | gate] beside it; two stores
+                        const f32x4 pj = *(const f32x4*)(a.aux + ooff[i] + ncol[j]);
+                        const f32x4 gt = *(const f32x4*)(a.aux + ooff[i] + a.N + ncol[j]);
+                        f32x4 dg;
+                        dg.x = v.x * pj.x * act_silu_grad(gt.x); dg.y = v.y * pj.y * act_silu_grad(gt.y);
+                        dg.z = v.z * pj.z * act_silu_grad(gt.z); dg.w = v.w * pj.w * act_silu_grad(gt.w);
+                        v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
+                        if (ok) st4(a.out + ooff[i] + a.N + ncol[j], dg);
+                    } else if (a.aux_mode == 3) {
+                        if constexpr (NTW % 2 == 0) {
+                            // even tile: projected, odd tile: its gate (same lane, same columns): u -> aux (row stride 2 ldo),
+                            // projected * silu(gate) -> out, stored by the even tile
+                            if (ok) st4(const_cast<float*>(a.aux) + 2 * ooff[i] + ncol[j], v);
+                            if ((j & 1) == 0) {
+                                const f32x4 gt = acc[i][(j + 1) % NTW] + bias_v[(j + 1) % NTW];
+                                v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
+                            } else {
+                                continue;  // the gate tile has no column of its own in `out`
+                            }
+                        }
                     } else {
                         if (a.aux_mode == 1 && ok) st4(const_cast<float*>(a.aux) + ooff[i] + ncol[j], v);
                         v = apply_act(v, a.act);
@@ -623,6 +657,19 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
     const ActLd<COH> LA(a.A), LO(a.out);
     float* s_mean = s_stat;
     float* s_rstd = s_stat + 16;
+    // epilogue operands (bias, row vector, gate, old output) are requested NOW by every wave -- wave 0 alone uses them, the
+    // others' copies are L1 hits: no load sits behind a branch, and the epilogue does not start with a memory round trip (a
+    // rollout-sized call is a chain of ~250 such kernels)
+    const int e_row = m0 + (lane & 15);
+    const int64_t e_mc = min(e_row, a.M - 1);
+    const int e_ncol = n_tile * 16 + 4 * (lane >> 4);
+    const int64_t e_orow = a.gin == 1 ? e_mc * a.gout + a.goff : (e_mc / a.gin) * a.gout + (e_mc % a.gin) + a.goff;
+    const int64_t e_oo = e_orow * a.ldo + e_ncol;
+    const f32x4 e_bias = ldg4((a.bias != nullptr ? a.bias : zeros) + e_ncol) + ldg4((a.rowvec != nullptr ? a.rowvec : zeros) + e_ncol);
+    const bool e_gated = a.residual && a.gate_off >= 0;
+    const f32x4 e_gate = ldg4(e_gated ? a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (e_mc / a.rows_per_sample) * a.mod_stride) + e_ncol
+                                      : zeros + e_ncol);
+    const f32x4 e_res = LO.ld4(a.residual ? e_oo : 0);
     if (a.ln) {  // row statistics: 32 threads per row, whole row in registers (K <= 512)
         const int r = tid >> 5, l32 = tid & 31;
         const int64_t m = min(m0 + r, a.M - 1);
@@ -691,20 +738,10 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
         f32x4 v = *(const f32x4*)(red + lane * 4);
 #pragma unroll
         for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)(red + (w * 64 + lane) * 4);
-        // ---- epilogue (as gemm_tile): lane holds out[mrow][ncol .. ncol+3]
-        const int ncol = n_tile * 16 + kq;
-        const float* biasp = a.bias != nullptr ? a.bias : zeros;
-        const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
-        v = apply_act(v + ldg4(biasp + ncol) + ldg4(rvp + ncol), a.act);
-        const int64_t orow = a.gin == 1 ? mc * a.gout + a.goff : (mc / a.gin) * a.gout + (mc % a.gin) + a.goff;
-        const int64_t oo = orow * a.ldo + ncol;
-        if (a.residual) {
-            f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
-            if (a.gate_off >= 0)
-                g = ldg4(a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (mc / a.rows_per_sample) * a.mod_stride) + ncol);
-            v = LO.ld4(oo) + g * v;
-        }
-        if (mok) st4(a.out + oo, v);
+        // ---- epilogue (as gemm_tile): lane holds out[mrow][ncol .. ncol+3]; operands fetched at entry
+        v = apply_act(v + e_bias, a.act);
+        if (a.residual) v = e_res + (e_gated ? e_gate * v : v);
+        if (mok) st4(a.out + e_oo, v);
     }
 }
 
@@ -733,6 +770,14 @@ __device__ __forceinline__ void attn_proj_tile(const mdt_gemm_args& a, const flo
     f32x4 wf[KS];
 #pragma unroll
     for (int u = 0; u < KS; ++u) wf[u] = ldg4(wbase + (h * KS + u) * 256);
+    // epilogue operands requested now by every wave (wave 0 uses them): no round trip behind the reduction
+    const int e_ncol = n_tile * 16 + 4 * (lane >> 4);
+    const int64_t e_mc = min(lane & 15, T - 1);
+    const int64_t e_oo = ((int64_t)b * T + e_mc) * a.ldo + e_ncol;
+    const f32x4 e_bias = ldg4((a.bias != nullptr ? a.bias : zeros) + e_ncol);
+    const bool e_gated = a.residual && a.gate_off >= 0;
+    const f32x4 e_gate = ldg4(e_gated ? a.mod + a.gate_off + (int64_t)b * a.mod_stride + e_ncol : zeros + e_ncol);
+    const f32x4 e_res = LO.ld4(a.residual ? e_oo : 0);
     float* qs = lds + h * (3 * 16 * ST + 16 * 17);  // [16][ST] q, later the attention output
     float* ks = qs + 16 * ST;
     float* vs = ks + 16 * ST;
@@ -790,17 +835,9 @@ __device__ __forceinline__ void attn_proj_tile(const mdt_gemm_args& a, const flo
 #pragma unroll
         for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)(red + (w * 64 + lane) * 4);
         const bool mok = mrow < T;
-        const int64_t mc = min(mrow, T - 1);
-        const int ncol = n_tile * 16 + kq;
-        const float* biasp = a.bias != nullptr ? a.bias : zeros;
-        v = v + ldg4(biasp + ncol);
-        const int64_t oo = ((int64_t)b * T + mc) * a.ldo + ncol;
-        if (a.residual) {
-            f32x4 g = (f32x4){1.f, 1.f, 1.f, 1.f};
-            if (a.gate_off >= 0) g = ldg4(a.mod + a.gate_off + (int64_t)b * a.mod_stride + ncol);  // the sample's conditioning row
-            v = LO.ld4(oo) + g * v;
-        }
-        if (mok) st4(a.out + oo, v);
+        v = v + e_bias;
+        if (a.residual) v = e_res + (e_gated ? e_gate * v : v);
+        if (mok) st4(a.out + e_oo, v);
     }
 }
 
@@ -1127,8 +1164,11 @@ __device__ __forceinline__ void head_rows(const mdt_head_args& a, int base, int 
 // Every global operand (U, Wf, y rows, LayerNorm vectors) is requested before the first dependent instruction.
 // lds: Ta*D + Ta*NP*(D/32) + Ta*NP floats.
 // ------------------------------------------------------------------------------------------------
+// [t_lo, t_hi): the rows of the sample this workgroup owns (every row is independent of the others: rollout-sized batches
+// split a sample over several workgroups, each fetching U / Wf again -- L2 hits -- but walking 1-2 rows instead of 10)
 template <int NP, bool COH>
-__device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, float* lds, const float* __restrict__ zeros, int tid) {
+__device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, float* lds, const float* __restrict__ zeros, int tid,
+                                           int t_lo = 0, int t_hi = 1 << 30) {
     constexpr int NT = 384, RMAX = 4;
     MDT_TS(0)
     MDT_TS_HWID()
@@ -1206,14 +1246,14 @@ __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, floa
         const float rstd = 1.0f / sqrtf(red[r] * inv_d + 1e-5f);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            if (cv[p] && t < Ta && wave < 6) *(f32x4*)(xn + t * D + cc[p]) = v[r][p] * rstd * lw[p] + lb[p];
+            if (cv[p] && t < Ta && wave < 6 && t >= t_lo && t < t_hi) *(f32x4*)(xn + t * D + cc[p]) = v[r][p] * rstd * lw[p] + lb[p];
     }
     MDT_TS(1)
     __syncthreads();
     MDT_TS(2)
     // ---- partial dots: part[t][p][seg] = xn[t][seg*32..] . U[p][seg*32..] ----
     if (dlive) {
-        for (int t = 0; t < Ta; ++t) {
+        for (int t = max(t_lo, 0); t < min(Ta, t_hi); ++t) {
             const float* xr = xn + t * D + 4 * dsg;
             float acc = 0.f;
 #pragma unroll
@@ -1228,7 +1268,7 @@ __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, floa
     MDT_TS(3)
     __syncthreads();
     // ---- masked softmax per (row, head) over the Te context tokens: key j visible iff j <= t (top-left causal) ----
-    if (tid < Ta * a.H) {
+    if (tid < Ta * a.H && tid / a.H >= t_lo && tid / a.H < t_hi) {
         const int t = tid / a.H, h = tid % a.H;
         const int nk = min(Te, t + 1);
         float sc[4];
@@ -1258,7 +1298,7 @@ __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, floa
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int t = tg * rpt + r;
-            if (r < rpt && t < Ta) {
+            if (r < rpt && t < Ta && t >= t_lo && t < t_hi) {
                 f32x4 acc = bo;
 #pragma unroll
                 for (int p = 0; p < NP; p += 4) {

@@ -123,6 +123,10 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsu
         if (a.dx_act_u) {  // dX = (dY W) * act'(u): the activation's backward rides on this product's epilogue
             if (a.accumulate_dx || a.N > 512) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: dx_act_u needs accumulate_dx = 0 and N <= 512");
             g.aux = a.dx_act_u; g.aux_mode = 2; g.act = a.dx_act;
+            if (a.dx_act == MDT_ACT_SWIGLU) {  // dX (M, 2K; ldxo) from d = dY W (M, K) and u (M, 2K; ldxo)
+                if (a.ldxo < 2 * (int64_t)a.K) return fail(MDT_ERR_INVALID_ARG, "linear_bwd: SwishGLU backward writes 2 K columns (ldxo >= 2 K)");
+                g.aux_mode = 4; g.act = MDT_ACT_NONE;
+            }
         }
         LAUNCH(mdt_launch_gemm(g, s));
     }

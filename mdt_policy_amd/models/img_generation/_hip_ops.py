@@ -78,6 +78,20 @@ class PackedWeights:
             self._cache[id(w)] = (tag, wp, wt)
         self._keep = [e[1] for e in stale]  # converted / re-laid-out sources stay alive until the launch has run
 
+    def get_glu(self, w: torch.Tensor) -> torch.Tensor:
+        """The tile-interleaved image of a SwishGLU project weight (2H, K) (mdt_op_pack_weight_glu), cached like the others."""
+        tag = (w.data_ptr(), w._version)
+        ent = self._cache.get(("glu", id(w)))
+        if ent is not None and ent[0] == tag:
+            return ent[1]
+        src = _c(w)
+        img = ent[1] if ent is not None and ent[1].device == src.device and ent[1].numel() == src.numel() else torch.empty(src.numel(), device=src.device, dtype=torch.float32)
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.load().mdt_op_pack_weight_glu(src.data_ptr(), src.shape[0], src.shape[1], img.data_ptr(), _stream(src)))
+        self._cache[("glu", id(w))] = (tag, img, None)
+        self._keep_glu = src
+        return img
+
     def get(self, w2d: torch.Tensor, key_param: torch.Tensor, need_t: bool):
         tag = (key_param.data_ptr(), key_param._version, need_t)
         ent = self._cache.get(id(key_param))
@@ -97,6 +111,80 @@ class PackedWeights:
             _lib.check(lib.mdt_op_pack_weight_t(src.data_ptr(), N, K, K, wt.data_ptr(), 0, N, s))
         self._cache[id(key_param)] = (tag, wp, wt)
         return wp, wt
+
+
+def _linear_bwd(lib, x2, dY, N, K, wt, need_x, need_w, need_b, dx_cols=None, act_u=None, act=0):
+    """mdt_op_linear_bwd on contiguous (M, K) x2 / (M, N) dY -> (dX, dW, db); dx_cols / act_u / act: the activation below
+    rides on the input-gradient product (SwishGLU: dX has 2 K columns)."""
+    M = x2.shape[0]
+    dW = torch.empty((N, K), device=dY.device, dtype=torch.float32) if need_w else None
+    db = torch.empty((N,), device=dY.device, dtype=torch.float32) if need_b else None
+    xc = K if dx_cols is None else dx_cols
+    dX = torch.empty((M, xc), device=dY.device, dtype=torch.float32) if need_x else None
+    scratch = torch.empty(max(1, lib.mdt_op_linear_bwd_scratch(M, N, K)), device=dY.device, dtype=torch.float32)
+    a = _lib.LinearBwdArgs(X=x2.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None if wt is None else wt.data_ptr(),
+                           dW=None if dW is None else dW.data_ptr(), dbias=None if db is None else db.data_ptr(),
+                           dX=None if dX is None else dX.data_ptr(), ldxo=xc, accumulate_dw=0, accumulate_dx=0, M=M, N=N, K=K,
+                           scratch=scratch.data_ptr(), dx_act_u=None if (act_u is None or dX is None) else act_u.data_ptr(), dx_act=act)
+    _lib.check(lib.mdt_op_linear_bwd(C.byref(a), _stream(dY)))
+    return dX, dW, db
+
+
+class HipSwiGLUMLP(torch.autograd.Function):
+    """The block's MLP, y = (projected * silu(gate)) W1^T + b1 with [projected | gate] = x W0^T + b0 (voltron
+    ``nn.Sequential(SwishGLU(d, h), nn.Linear(h, d))``), with the SwishGLU riding on the GEMMs around it: forward on the
+    EPILOGUE of the project product (mdt_gemm_args.aux_mode 3: the weight image interleaves the two halves tile by tile, one
+    launch leaves u and projected * silu(gate)), backward on the epilogue of mlp.1's input-gradient product
+    (mdt_linear_bwd_args.dx_act = SWIGLU: d_u straight from dY W1 and u).  Two elementwise passes over (rows, 2h) and
+    (rows, h) tensors less each way than Linear -> SwishGLU -> Linear."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, packs: PackedWeights):
+        lib = _lib.load()
+        H2, K = w0.shape
+        H, N1 = H2 // 2, w1.shape[0]
+        x2 = _c(x).reshape(-1, K)
+        M = x2.shape[0]
+        s = _stream(x2)
+        need_t = torch.is_grad_enabled() and (x.requires_grad or w0.requires_grad)
+        wg = packs.get_glu(w0)
+        w1p, _ = packs.get(w1, w1, need_t)
+        u = torch.empty((M, H2), device=x2.device, dtype=torch.float32)
+        h = torch.empty((M, H), device=x2.device, dtype=torch.float32)
+        a = _lib.GemmArgs()
+        a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = x2.data_ptr(), K, wg.data_ptr(), h.data_ptr(), H, M, H2, K
+        a.bias = None if b0 is None else _c(b0).data_ptr()
+        a.shift_off, a.scale_off, a.gate_off, a.rows_per_sample, a.gin, a.gout, a.goff = -1, -1, -1, 1, 1, 1, 0
+        a.aux, a.aux_mode = u.data_ptr(), 3
+        _lib.check(lib.mdt_op_gemm(C.byref(a), s))
+        y = torch.empty((M, N1), device=x2.device, dtype=torch.float32)
+        g = _lib.GemmArgs()
+        g.A, g.lda, g.Wp, g.out, g.ldo, g.M, g.N, g.K = h.data_ptr(), H, w1p.data_ptr(), y.data_ptr(), N1, M, N1, H
+        g.bias = None if b1 is None else _c(b1).data_ptr()
+        g.shift_off, g.scale_off, g.gate_off, g.rows_per_sample, g.gin, g.gout, g.goff = -1, -1, -1, 1, 1, 1, 0
+        _lib.check(lib.mdt_op_gemm(C.byref(g), s))
+        ctx.save_for_backward(x2, u, h, w0, b0, w1, b1)
+        ctx.packs, ctx.xshape = packs, x.shape
+        return y.reshape(*x.shape[:-1], N1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x2, u, h, w0, b0, w1, b1 = ctx.saved_tensors
+        H2, K = w0.shape
+        H, N1 = H2 // 2, w1.shape[0]
+        M = x2.shape[0]
+        dY = _c(gy).reshape(M, N1)
+        nx, nw0, nb0, nw1, nb1 = (ctx.needs_input_grad[i] for i in range(5))
+        need_u = nx or nw0 or (b0 is not None and nb0)
+        w1t = ctx.packs.get(w1, w1, True)[1] if need_u else None
+        # mlp.1: dW1 = dY^T h, db1, and d_u = swiglu'(u) (dY W1) in the same launch sequence
+        du, dW1, db1 = _linear_bwd(lib, h, dY, N1, H, w1t, need_u, nw1, b1 is not None and nb1, dx_cols=H2, act_u=u, act=_lib.ACT["swiglu"])
+        dX = dW0 = db0 = None
+        if need_u:
+            w0t = ctx.packs.get(w0, w0, True)[1] if nx else None
+            dX, dW0, db0 = _linear_bwd(lib, x2, du, H2, K, w0t, nx, nw0, b0 is not None and nb0)
+        return (None if dX is None else dX.reshape(ctx.xshape), dW0, db0, dW1, db1, None)
 
 
 class HipLinear(torch.autograd.Function):
@@ -226,6 +314,36 @@ class HipScaleResidual(torch.autograd.Function):
         _lib.check(lib.mdt_op_scale_residual_bwd(g2.data_ptr(), z2.data_ptr(), gm.data_ptr(), dz.data_ptr(), dgamma.data_ptr(), M, D,
                                                  scratch.data_ptr(), _stream(g2)))
         return g, dz.reshape(ctx.xshape), dgamma
+
+
+class HipPatchMSE(torch.autograd.Function):
+    """compute_loss (reference :228-262): masked per-patch MSE of both frames straight from the images (no patchified copy),
+    one pass forward and one backward (mdt_op_patch_mse_fwd / _bwd) instead of ~10 elementwise passes over 300 MB tensors."""
+
+    @staticmethod
+    def forward(ctx, rec, imgs, mask, patch: int):
+        lib = _lib.load()
+        B, X, n, E = rec.shape
+        Cn, R = imgs.shape[2], imgs.shape[3]
+        r, im, mk = _c(rec), _c(imgs), _c(mask)
+        partial = torch.empty(B * X * n, device=r.device, dtype=torch.float32)
+        out = torch.empty(2, device=r.device, dtype=torch.float32)  # loss, sum(mask)
+        _lib.check(lib.mdt_op_patch_mse_fwd(r.data_ptr(), im.data_ptr(), mk.data_ptr(), partial.data_ptr(), out.data_ptr(),
+                                            out.data_ptr() + 4, B, X, Cn, R, patch, _stream(r)))
+        ctx.save_for_backward(r, im, mk, out)
+        ctx.cfg = (B, X, Cn, R, patch)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        r, im, mk, out = ctx.saved_tensors
+        B, X, Cn, R, patch = ctx.cfg
+        gg = _c(g.reshape(1).float())
+        d = torch.empty_like(r)
+        _lib.check(lib.mdt_op_patch_mse_bwd(r.data_ptr(), im.data_ptr(), mk.data_ptr(), out.data_ptr() + 4, gg.data_ptr(), d.data_ptr(),
+                                            B, X, Cn, R, patch, _stream(r)))
+        return d, None, None, None
 
 
 class HipSelfAttention(torch.autograd.Function):

@@ -242,8 +242,9 @@ class MaskedTransformerImgDecoder(nn.Module):
             qkv = self._linear(ops.HipRMSNorm.apply(x, blk.pre_norm_attn.g), blk.attn.qkv)
             att = ops.HipSelfAttention.apply(qkv, blk.attn.n_heads, blk.attn.scale)
             x = ops.HipScaleResidual.apply(x, self._linear(att, blk.attn.proj), blk.layer_scale_attn.gamma)
-            h = ops.HipSwishGLU.apply(self._linear(ops.HipRMSNorm.apply(x, blk.pre_norm_mlp.g), blk.mlp[0].project))
-            x = ops.HipScaleResidual.apply(x, self._linear(h, blk.mlp[1]), blk.layer_scale_mlp.gamma)
+            z = ops.HipSwiGLUMLP.apply(ops.HipRMSNorm.apply(x, blk.pre_norm_mlp.g), blk.mlp[0].project.weight, blk.mlp[0].project.bias,
+                                       blk.mlp[1].weight, blk.mlp[1].bias, self._packs)
+            x = ops.HipScaleResidual.apply(x, z, blk.layer_scale_mlp.gamma)
         x = ops.HipRMSNorm.apply(x, self.decoder_norm.g)
         rec = self._linear(x[:, context.shape[1]:], self.decoder_patch_prediction).reshape(B, X, n, -1)
         return rec, m, restore, vis.reshape(B, X * n_keep, d)
@@ -251,7 +252,7 @@ class MaskedTransformerImgDecoder(nn.Module):
     def compute_loss(self, imgs: torch.Tensor, ctx_reconstructions: torch.Tensor, mask: torch.Tensor, restore_idxs: torch.Tensor):
         """Mean squared error per patch of frame 0 and frame K over the REMOVED patches, averaged (reference :228-262)."""
         assert self.norm_pixel_loss, "`norm_pixel_loss` should always be true... false only for visualizations!"
-        per_patch = ((ctx_reconstructions - self.patchify(imgs.float())) ** 2).mean(dim=-1)
-        zero = (per_patch[:, 0] * mask).sum() / mask.sum()
-        k = (per_patch[:, 1] * mask).sum() / mask.sum()
-        return (zero + k) / 2
+        if ctx_reconstructions.device.type != "cuda":
+            raise RuntimeError("MaskedTransformerImgDecoder runs only on a ROCm GPU; there is no CPU execution path in mdt_policy_amd")
+        # = (sum_x (per_patch[:, x] * mask).sum() / mask.sum()) / 2 with per_patch = ((rec - patchify(imgs)) ** 2).mean(-1)
+        return ops.HipPatchMSE.apply(ctx_reconstructions.float(), imgs.float(), mask.float(), self.patch_size)

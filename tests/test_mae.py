@@ -229,3 +229,31 @@ def test_scale_residual_op(M, D):
     assert_close(x.grad.cpu(), x64.grad, what="dx")
     assert_close(z.grad.cpu(), z64.grad, what="dz")
     assert_close(gamma.grad.cpu(), g64.grad, rtol=1e-3, atol=1e-4 * float(g64.grad.abs().max()), what="dgamma")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,H", [(306, 192, 768), (37, 64, 48), (4100, 192, 768), (64, 128, 128)])
+def test_swiglu_on_the_gemm_epilogues(M, K, H):
+    """SwishGLU riding on the GEMMs around it: forward on the project product (aux_mode 3: interleaved weight image, u and
+    projected * silu(gate) from one launch), backward on mlp.1's input-gradient product (dx_act = SWIGLU), through the fused
+    autograd function against float64 torch of Linear -> SwishGLU -> Linear."""
+    from mdt_policy_amd.models.img_generation import _hip_ops as ops
+    N1 = 80 if K == 64 else K
+    x = torch.from_numpy(synthetic.normal("g_x", (M, K), 181)).cuda().requires_grad_()
+    w0 = torch.from_numpy(synthetic.normal("g_w0", (2 * H, K), 182, std=K ** -0.5)).cuda().requires_grad_()
+    b0 = torch.from_numpy(synthetic.normal("g_b0", (2 * H,), 183, std=0.3)).cuda().requires_grad_()
+    w1 = torch.from_numpy(synthetic.normal("g_w1", (N1, H), 184, std=H ** -0.5)).cuda().requires_grad_()
+    b1 = torch.from_numpy(synthetic.normal("g_b1", (N1,), 185, std=0.3)).cuda().requires_grad_()
+    wy = torch.from_numpy(synthetic.normal("g_wy", (M, N1), 186))
+    y = ops.HipSwiGLUMLP.apply(x, w0, b0, w1, b1, ops.PackedWeights())
+    (y * wy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    r = [t.detach().cpu().double().requires_grad_() for t in (x, w0, b0, w1, b1)]
+    u = r[0] @ r[1].T + r[2]
+    p, g = u.tensor_split(2, dim=-1)
+    ref = (p * torch.nn.functional.silu(g)) @ r[3].T + r[4]
+    (ref * wy.double()).sum().backward()
+    assert_close(y.detach().cpu(), ref.detach(), what="fused SwishGLU MLP output")
+    for name, got, want in zip(("dx", "dW0", "db0", "dW1", "db1"), (x, w0, b0, w1, b1), r):
+        sc = float(want.grad.abs().max())
+        assert_close(got.grad.cpu(), want.grad, rtol=2e-3, atol=2e-3 * sc, what=name)
