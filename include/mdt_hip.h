@@ -21,6 +21,7 @@
 #ifndef MDT_HIP_H
 #define MDT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -210,6 +211,18 @@ double mdt_flops_per_chunk(const mdt_model *m, int32_t n_steps);
  * `seed` -- pyhash passes its seed (default 0) as the initial value (src/FNV1.h:36-39, src/Hash.h:113,167), NOT the
  * standard offset basis 0x811c9dc5.  Chaining: pass the previous result as `seed`. */
 uint32_t mdt_fnv1_32(const void *buf, uint64_t len, uint32_t seed);
+
+/* Where the library's LARGE, batch-sized buffers come from: workspaces, training tapes and backward scratch (the weight
+ * arenas and small tables stay hipMalloc'ed).  By default they are raw hipMalloc's; a host framework with its own caching
+ * allocator (PyTorch) would then see "out of memory" while its own pool sits on gigabytes of cached-but-free blocks -- or the
+ * other way round.  With an allocator installed the buffers live in the host's pool: `alloc(bytes, user)` returns a device
+ * pointer (256-byte aligned, on the current device) or NULL when it cannot; `free_(ptr, user)` releases one -- the library
+ * calls it only after hipDeviceSynchronize() (growing a buffer) or from the destroy functions.  NULL, NULL restores
+ * hipMalloc / hipFree; buffers are released through whatever allocated them.  Process-wide; install it before the first
+ * forward.  (The Python facade installs torch.cuda.caching_allocator_alloc / _delete.) */
+typedef void *(*mdt_alloc_fn)(size_t bytes, void *user);
+typedef void (*mdt_free_fn)(void *ptr, void *user);
+mdt_status mdt_set_allocator(mdt_alloc_fn alloc, mdt_free_fn free_, void *user);
 
 #ifdef __cplusplus
 }

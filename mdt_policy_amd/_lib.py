@@ -156,6 +156,7 @@ _VP, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = [
     ("mdt_last_error", C.c_char_p, []),
     ("mdt_version", C.c_char_p, []),
+    ("mdt_set_allocator", _I32, [_VP, _VP, _VP]),
     ("mdt_create", _I32, [C.POINTER(MDTConfig), C.POINTER(_VP)]),
     ("mdt_destroy", _I32, [_VP]),
     ("mdt_param_count", _I64, [_VP]),

@@ -61,6 +61,10 @@ static inline mdt_gemm_args gemm_args(const float* A, int64_t lda, const Lin& w,
     return g;
 }
 
+// batch-sized buffers (workspace, tapes, backward scratch): through the installed allocator (mdt_set_allocator) or hipMalloc
+hipError_t mdt_dev_malloc(void** p, size_t bytes);
+hipError_t mdt_dev_free(void* p);
+
 int mdt_gemm_kchunk(int K, int ln, int cap);
 // the current device's buffer of zeros (stands in for absent bias / LayerNorm-bias vectors); nullptr on failure
 const float* mdt_zeros();

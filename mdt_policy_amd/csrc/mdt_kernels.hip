@@ -933,22 +933,20 @@ hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
 struct mdt_xfold_table { mdt_xfold_args a[8]; };
 template <int TE, int SB>
 __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const mdt_xfold_args& a = tab.a[blockIdx.z];
     const int n = threadIdx.x;            // output feature handled by this thread
     const int h = blockIdx.y;
     const int bg = blockIdx.x * SB;       // first sample of the group
     const int HD = a.hd, D = a.D, P = a.H * TE;
-    float* Ks = lds;                      // [SB][TE][HD]
-    float* Vs = Ks + SB * TE * HD;        // [SB][TE][HD]
-    for (int i = threadIdx.x; i < SB * TE * HD; i += blockDim.x) {
-        const int d = i % HD, j = (i / HD) % TE, sb = i / (HD * TE);
-        const int b = min(bg + sb, a.B - 1);
-        const float* row = a.kv + (int64_t)(b * TE + j) * a.ldkv + h * HD + d;
-        Ks[i] = row[0];
-        Vs[i] = row[D];
-    }
-    __syncthreads();
+    // The K / V values of the group's context rows are the same for every lane: they are read with UNIFORM addresses straight
+    // from memory (scalar loads into SGPRs, one operand of each FMA) -- as LDS broadcasts (the first form) every FMA waited
+    // for its own ds_read and the kernel ran at a third of the VALU rate (95 us per sampler call at B = 256).
+    const float* krow[SB][TE];
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+        for (int j = 0; j < TE; ++j)
+            krow[sb][j] = a.kv + (int64_t)(min(bg + sb, a.B - 1) * TE + j) * a.ldkv + h * HD;  // K at +0, V at +D
     const float scale = 1.0f / sqrtf((float)HD);
     if (n < D) {
         float accU[SB][TE], accW[SB][TE];
@@ -964,14 +962,16 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
                 wo[e] = a.WoT[(int64_t)(h * HD + d0 + e) * D + n];  // c_proj.weight^T row, coalesced over n
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
+            for (int sb = 0; sb < SB; ++sb)
 #pragma unroll
-                for (int sb = 0; sb < SB; ++sb)
+                for (int j = 0; j < TE; ++j) {
+                    const float* kr = krow[sb][j] + d0;
 #pragma unroll
-                    for (int j = 0; j < TE; ++j) {
-                        accU[sb][j] = fmaf(wq[e], Ks[(sb * TE + j) * HD + d0 + e], accU[sb][j]);
-                        accW[sb][j] = fmaf(wo[e], Vs[(sb * TE + j) * HD + d0 + e], accW[sb][j]);
+                    for (int e = 0; e < 8; ++e) {
+                        accU[sb][j] = fmaf(wq[e], kr[e], accU[sb][j]);
+                        accW[sb][j] = fmaf(wo[e], kr[D + e], accW[sb][j]);
                     }
+                }
         }
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb) {
@@ -988,8 +988,9 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
     if (threadIdx.x < SB * TE) {
         const int sb = threadIdx.x / TE, j = threadIdx.x % TE;
         if (bg + sb < a.B) {
+            const float* kr = a.kv + (int64_t)((bg + sb) * TE + j) * a.ldkv + h * HD;
             float acc = 0.f;
-            for (int d = 0; d < HD; ++d) acc = fmaf(a.bq[h * HD + d], Ks[(sb * TE + j) * HD + d], acc);
+            for (int d = 0; d < HD; ++d) acc = fmaf(a.bq[h * HD + d], kr[d], acc);
             a.c[(int64_t)(bg + sb) * P + h * TE + j] = acc * scale;
         }
     }
@@ -1006,7 +1007,7 @@ hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_
         if (sets[i].B != a.B || sets[i].H != a.H || sets[i].hd != a.hd || sets[i].D != a.D || sets[i].Te != a.Te)
             return hipErrorInvalidValue;
     const int threads = (a.D + 63) / 64 * 64;
-    const size_t lds = (size_t)2 * SB * a.Te * a.hd * sizeof(float);
+    const size_t lds = 0;
     for (int i0 = 0; i0 < n; i0 += 8) {
         mdt_xfold_table tab;
         const int cnt = n - i0 < 8 ? n - i0 : 8;

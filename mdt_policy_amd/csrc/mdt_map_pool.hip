@@ -347,12 +347,12 @@ extern "C" mdt_status mdt_map_pool_create(const mdt_map_pool_config* cfg, mdt_ma
 extern "C" mdt_status mdt_map_pool_destroy(mdt_map_pool* p) {
     if (!p) return MDT_OK;
     (void)hipDeviceSynchronize();
-    for (MTape& t : p->tapes) (void)hipFree(t.buf);
-    (void)hipFree(p->tscratch);
+    for (MTape& t : p->tapes) (void)mdt_dev_free(t.buf);
+    (void)mdt_dev_free(p->tscratch);
     (void)hipFree(p->wt_arena);
     (void)hipFree(p->arena);
     (void)hipFree(p->staging);
-    (void)hipFree(p->ws);
+    (void)mdt_dev_free(p->ws);
     delete p;
     return MDT_OK;
 }
@@ -455,10 +455,10 @@ extern "C" mdt_status mdt_map_pool_forward(mdt_map_pool* p, const float* x, int6
     if (batch > p->cap_b || n_tokens > p->cap_n) {
         const int64_t B = std::max(batch, p->cap_b);
         const int N = std::max((int)n_tokens, p->cap_n);
-        if (p->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->ws)); p->ws = nullptr; p->cap_b = 0; p->cap_n = 0; }
+        if (p->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(mdt_dev_free(p->ws)); p->ws = nullptr; p->cap_b = 0; p->cap_n = 0; }
         Bump count;
         carve_ws(p, count, B, N);
-        HIP_TRY(hipMalloc((void**)&p->ws, count.off * sizeof(float)));
+        HIP_TRY(mdt_dev_malloc((void**)&p->ws, count.off * sizeof(float)));
         p->cap_b = B; p->cap_n = N;
     }
     Bump real;
@@ -520,10 +520,10 @@ static void carve_scratch(mdt_map_pool* p, Bump& b, int64_t B, int N) {
 static mdt_status reserve_scratch(mdt_map_pool* p, int64_t B, int N) {
     if (B > p->ts_b || N > p->ts_n) {
         B = std::max(B, p->ts_b); N = std::max(N, p->ts_n);
-        if (p->tscratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->tscratch)); p->tscratch = nullptr; }
+        if (p->tscratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(mdt_dev_free(p->tscratch)); p->tscratch = nullptr; }
         Bump count;
         carve_scratch(p, count, B, N);
-        HIP_TRY(hipMalloc((void**)&p->tscratch, count.off * sizeof(float)));
+        HIP_TRY(mdt_dev_malloc((void**)&p->tscratch, count.off * sizeof(float)));
         p->ts_b = B; p->ts_n = N;
     }
     Bump real;
@@ -553,10 +553,10 @@ extern "C" mdt_status mdt_map_pool_forward_train(mdt_map_pool* p, const float* x
     if (t.cap < batch || t.cap_n < n_tokens) {
         const int64_t B = std::max(batch, t.cap);
         const int N = std::max((int)n_tokens, t.cap_n);
-        if (t.buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(t.buf)); t.buf = nullptr; t.cap = 0; t.cap_n = 0; }
+        if (t.buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(mdt_dev_free(t.buf)); t.buf = nullptr; t.cap = 0; t.cap_n = 0; }
         Bump count;
         carve_tape(p, count, t, B, N);
-        HIP_TRY(hipMalloc((void**)&t.buf, count.off * sizeof(float)));
+        HIP_TRY(mdt_dev_malloc((void**)&t.buf, count.off * sizeof(float)));
         t.cap = B; t.cap_n = N;
     }
     Bump real;

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "mdt_internal.h"
@@ -46,6 +47,50 @@ extern "C" uint32_t mdt_fnv1_32(const void* buf, uint64_t len, uint32_t seed) {
         h ^= p[i];
     }
     return h;
+}
+
+// ---- pluggable allocator of the batch-sized buffers (include/mdt_hip.h: mdt_set_allocator) ----
+#include <mutex>
+namespace {
+std::mutex g_alloc_mu;
+mdt_alloc_fn g_alloc = nullptr;
+mdt_free_fn g_free = nullptr;
+void* g_alloc_user = nullptr;
+std::unordered_map<void*, std::pair<mdt_free_fn, void*>>* g_custom_free = nullptr;
+}  // namespace
+
+extern "C" mdt_status mdt_set_allocator(mdt_alloc_fn alloc, mdt_free_fn free_, void* user) {
+    if ((alloc == nullptr) != (free_ == nullptr)) return fail(MDT_ERR_INVALID_ARG, "mdt_set_allocator: give both functions or neither");
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    g_alloc = alloc; g_free = free_; g_alloc_user = user;
+    return MDT_OK;
+}
+
+hipError_t mdt_dev_malloc(void** p, size_t bytes) {
+    mdt_alloc_fn fn; mdt_free_fn ff; void* user;
+    { std::lock_guard<std::mutex> lock(g_alloc_mu); fn = g_alloc; ff = g_free; user = g_alloc_user; }
+    if (fn == nullptr) return hipMalloc(p, bytes);
+    void* q = fn(bytes, user);
+    if (q == nullptr) { *p = nullptr; return hipErrorOutOfMemory; }
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    if (!g_custom_free) g_custom_free = new std::unordered_map<void*, std::pair<mdt_free_fn, void*>>();
+    (*g_custom_free)[q] = std::make_pair(ff, user);
+    *p = q;
+    return hipSuccess;
+}
+
+hipError_t mdt_dev_free(void* p) {
+    if (p == nullptr) return hipSuccess;
+    std::pair<mdt_free_fn, void*> how(nullptr, nullptr);
+    {
+        std::lock_guard<std::mutex> lock(g_alloc_mu);
+        if (g_custom_free) {
+            auto it = g_custom_free->find(p);
+            if (it != g_custom_free->end()) { how = it->second; g_custom_free->erase(it); }
+        }
+    }
+    if (how.first) { how.first(p, how.second); return hipSuccess; }
+    return hipFree(p);
 }
 
 extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32)"; }
@@ -328,7 +373,6 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     m->staging_floats = mx;
     e = hipMalloc((void**)&m->staging, mx * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(m->arena); delete m; return fail(MDT_ERR_HIP, "hipMalloc(staging) failed: %s", hipGetErrorString(e)); }
-    m->steps_host.resize(MAX_STEPS * 4);
     // the collapsed cross-attention needs a step-independent context and an unconditioned query input
     m->xfold = cond == COND_ADALN && !c.use_rot_embed && mdt_xattn_apply_supported(m->D, m->H, m->Te, m->Ta);
     if (const char* x = getenv("MDT_HIP_XFOLD")) m->xfold = m->xfold && atoi(x) != 0;
@@ -360,7 +404,7 @@ extern "C" mdt_status mdt_destroy(mdt_model* m) {
     mdt_persist_free(m);
     (void)hipFree(m->arena);
     (void)hipFree(m->staging);
-    (void)hipFree(m->ws);
+    (void)mdt_dev_free(m->ws);
     if (m->tab_dev) (void)hipFree(m->tab_dev);
     for (int i = 0; i < 2; ++i) {
         if (m->tab_host[i]) (void)hipHostFree(m->tab_host[i]);
@@ -558,6 +602,7 @@ static void carve_ws(mdt_model* m, Bump& b, int64_t B) {
     m->noised = b.take(Ra * m->A);
     m->Fbuf = b.take(Ra * m->A);
     m->steps = b.take(MAX_STEPS * 4);
+    m->sigs = b.take(MAX_STEPS + 1);
     if (m->xfold) {
         const int64_t np = (int64_t)m->H * m->Te;
         m->xU = b.take((size_t)m->Ld * B * np * D);
@@ -572,14 +617,14 @@ extern "C" mdt_status mdt_reserve(mdt_model* m, int64_t max_batch) {
     if (max_batch * std::max(m->Te, m->Ta) > (int64_t)1 << 24) return fail(MDT_ERR_INVALID_ARG, "batch too large");
     if (m->ws) {
         HIP_TRY(hipDeviceSynchronize());  // previous work may still read the old workspace
-        HIP_TRY(hipFree(m->ws));
+        HIP_TRY(mdt_dev_free(m->ws));
         m->ws = nullptr;
         m->cap = 0;
         m->cached_batch = 0;
     }
     Bump count;
     carve_ws(m, count, max_batch);
-    HIP_TRY(hipMalloc((void**)&m->ws, count.off * sizeof(float)));
+    HIP_TRY(mdt_dev_malloc((void**)&m->ws, count.off * sizeof(float)));
     Bump real;
     real.base = m->ws;
     carve_ws(m, real, max_batch);
@@ -962,21 +1007,15 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
     if (!per_step_ctx) MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, nullptr, 0, ctx_out, s));
     else { MDT_TRY(check_loaded(m)); MDT_TRY(mdt_reserve(m, batch)); }
     // per-step scalars, fp32 like the reference's 0-dim tensor math (gc_sampling.py:946-950):
-    //   t = -ln(sigma); ratio = exp(-t_next)/exp(-t); coef = -expm1(-(t_next - t))
-    if (sigmas_dev) {  // the schedule lives on the device (mdtv_agent.py:660-667): no copy, no synchronisation
-        LAUNCH(mdt_launch_ddim_steps(sigmas_dev, n_steps, m->steps, s));
-    } else {
-        float* sh = m->steps_host.data();
-        for (int i = 0; i < n_steps; ++i) {
-            const float t = -logf(sigmas[i]), tn = -logf(sigmas[i + 1]);
-            const float h = tn - t;
-            sh[4 * i + 0] = expf(-tn) / expf(-t);
-            sh[4 * i + 1] = -expm1f(-h);
-            sh[4 * i + 2] = sigmas[i + 1];
-            sh[4 * i + 3] = sigmas[i];
-        }
-        HIP_TRY(hipMemcpyAsync(m->steps, sh, (size_t)n_steps * 4 * sizeof(float), hipMemcpyHostToDevice, s));
+    // t = -ln(sigma); ratio = exp(-t_next)/exp(-t); coef = -expm1(-(t_next - t)) -- by ONE routine (k_ddim_steps, on the device)
+    // whether the schedule arrives in host memory (the reference's CPU default) or on the device (mdtv_agent.py:660-667: no
+    // copy, no synchronisation then), so that the eager call, the call with device sigmas and the graph replay of either give
+    // the same bits (host libm and the device's expf / logf differ in the last place)
+    if (!sigmas_dev) {
+        HIP_TRY(hipMemcpyAsync(m->sigs, sigmas, (size_t)(n_steps + 1) * sizeof(float), hipMemcpyHostToDevice, s));
+        sigmas_dev = m->sigs;
     }
+    LAUNCH(mdt_launch_ddim_steps(sigmas_dev, n_steps, m->steps, s));
     MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));  // one row of conditioning vectors per step
     // ---- cut the batch into sample-aligned slices (multiples of 16 samples = 5 row tiles) on separate streams ----
     int ways = per_step_ctx ? 1 : m->ways;  // the encoder works on whole-batch buffers

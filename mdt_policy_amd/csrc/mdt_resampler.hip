@@ -164,12 +164,12 @@ extern "C" mdt_status mdt_resampler_create(const mdt_resampler_config* cfg, mdt_
 extern "C" mdt_status mdt_resampler_destroy(mdt_resampler* r) {
     if (!r) return MDT_OK;
     (void)hipDeviceSynchronize();
-    for (RTape& t : r->tapes) (void)hipFree(t.buf);
-    (void)hipFree(r->tscratch);
+    for (RTape& t : r->tapes) (void)mdt_dev_free(t.buf);
+    (void)mdt_dev_free(r->tscratch);
     (void)hipFree(r->wt_arena);
     (void)hipFree(r->arena);
     (void)hipFree(r->staging);
-    (void)hipFree(r->ws);
+    (void)mdt_dev_free(r->ws);
     delete r;
     return MDT_OK;
 }
@@ -229,13 +229,13 @@ static mdt_status reserve(mdt_resampler* r, int64_t rows, int64_t B) {
     B = std::max(B, r->cap_b);
     if (r->ws) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(r->ws));
+        HIP_TRY(mdt_dev_free(r->ws));
         r->ws = nullptr;
         r->cap_rows = r->cap_b = 0;
     }
     Bump count;
     carve(r, count, rows, B);
-    HIP_TRY(hipMalloc((void**)&r->ws, count.off * sizeof(float)));
+    HIP_TRY(mdt_dev_malloc((void**)&r->ws, count.off * sizeof(float)));
     Bump real;
     real.base = r->ws;
     carve(r, real, rows, B);
@@ -374,10 +374,10 @@ static void carve_rscratch(mdt_resampler* r, Bump& b, int64_t rows, int64_t B) {
 static mdt_status rscratch(mdt_resampler* r, int64_t rows, int64_t B) {
     if (rows > r->ts_rows || B > r->ts_b) {
         rows = std::max(rows, r->ts_rows); B = std::max(B, r->ts_b);
-        if (r->tscratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(r->tscratch)); r->tscratch = nullptr; }
+        if (r->tscratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(mdt_dev_free(r->tscratch)); r->tscratch = nullptr; }
         Bump count;
         carve_rscratch(r, count, rows, B);
-        HIP_TRY(hipMalloc((void**)&r->tscratch, count.off * sizeof(float)));
+        HIP_TRY(mdt_dev_malloc((void**)&r->tscratch, count.off * sizeof(float)));
         r->ts_rows = rows; r->ts_b = B;
     }
     Bump real;
@@ -413,10 +413,10 @@ extern "C" mdt_status mdt_resampler_forward_train(mdt_resampler* r, const float*
     }
     RTape& t = r->tapes[pick];
     if (t.cap_rows < rows || t.cap_b < batch) {
-        if (t.buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(t.buf)); t.buf = nullptr; }
+        if (t.buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(mdt_dev_free(t.buf)); t.buf = nullptr; }
         Bump count;
         carve_rtape(r, count, t, rows, batch);
-        HIP_TRY(hipMalloc((void**)&t.buf, count.off * sizeof(float)));
+        HIP_TRY(mdt_dev_malloc((void**)&t.buf, count.off * sizeof(float)));
         t.cap_rows = rows; t.cap_b = batch;
     }
     Bump real;

@@ -169,10 +169,10 @@ void mdt_train_free(mdt_model* m) {
     if (!m || !m->train) return;
     mdt_train_state* t = m->train;
     for (Tape& tp : t->tapes) {
-        (void)hipFree(tp.buf);
+        (void)mdt_dev_free(tp.buf);
         if (tp.freed) (void)hipEventDestroy(tp.freed);
     }
-    (void)hipFree(t->scratch);
+    (void)mdt_dev_free(t->scratch);
     if (t->scratch_done) (void)hipEventDestroy(t->scratch_done);
     (void)hipFree(t->wt_arena);
     for (const LinPart& p : m->parts) p.lin->wt = nullptr;
@@ -244,10 +244,10 @@ static mdt_status acquire_tape(mdt_model* m, int64_t B, mdt_tape_id* id, hipStre
     }
     Tape& t = ts->tapes[pick];
     if (t.cap < B) {
-        if (t.buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(t.buf)); t.buf = nullptr; t.cap = 0; }
+        if (t.buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(mdt_dev_free(t.buf)); t.buf = nullptr; t.cap = 0; }
         Bump count;
         carve_tape(m, count, t, B);
-        HIP_TRY(hipMalloc((void**)&t.buf, count.off * sizeof(float)));
+        HIP_TRY(mdt_dev_malloc((void**)&t.buf, count.off * sizeof(float)));
         t.cap = B;
     }
     Bump real;
@@ -316,10 +316,10 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
 static mdt_status reserve_scratch(mdt_model* m, int64_t B) {
     mdt_train_state* ts = m->train;
     if (B > ts->scratch_cap) {
-        if (ts->scratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ts->scratch)); ts->scratch = nullptr; }
+        if (ts->scratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(mdt_dev_free(ts->scratch)); ts->scratch = nullptr; }
         Bump count;
         carve_scratch(m, count, ts, B);
-        HIP_TRY(hipMalloc((void**)&ts->scratch, count.off * sizeof(float)));
+        HIP_TRY(mdt_dev_malloc((void**)&ts->scratch, count.off * sizeof(float)));
         ts->scratch_cap = B;
     }
     Bump real;

@@ -139,7 +139,29 @@ def _sig_in(sigma, action, model=None):
     return torch.full((n,), _f(sigma), device=action.device, dtype=action.dtype)
 
 
-_GRAPH_SAMPLER = os.environ.get("MDT_HIP_GRAPH", "0") not in ("", "0")
+# MDT_HIP_GRAPH: "1" = every fused DDIM call replays a HIP graph, "0" = never, unset = "auto": rollout-sized batches (B <= 8)
+# from the third call with the same shapes on -- a rollout repeats one call for hundreds of steps (mdtv_agent.py:721-760) and
+# its ~250 launches take the host longer to submit than the GPU to run (B = 1, host-synchronised: 1.56 ms eager, 1.43 ms
+# replayed; tools/graph_probe.py), a one-off call is not worth a capture
+_GRAPH_MODE = os.environ.get("MDT_HIP_GRAPH", "auto")
+_GRAPH_SAMPLER = _GRAPH_MODE not in ("", "0", "auto")
+_GRAPH_AUTO_MAX_BATCH, _GRAPH_AUTO_AFTER = 8, 2
+
+
+def _graph_wanted(model, state, action, goal, sigmas) -> bool:
+    if action.device.type != "cuda" or model.inner_model.training or torch.cuda.is_current_stream_capturing():
+        return False
+    if _GRAPH_SAMPLER:
+        return True
+    if _GRAPH_MODE != "auto" or action.shape[0] > _GRAPH_AUTO_MAX_BATCH:
+        return False
+    key = (tuple(action.shape), tuple(goal.shape), len(sigmas),
+           tuple(sorted((k, tuple(v.shape) if torch.is_tensor(v) else v) for k, v in state.items())))
+    seen = model.__dict__.setdefault("_graph_seen", {})
+    seen[key] = seen.get(key, 0) + 1
+    if len(seen) > 16:
+        seen.clear()
+    return seen.get(key, 0) > _GRAPH_AUTO_AFTER
 
 
 def _graphed(model, state, action, goal, sigmas):
@@ -162,8 +184,8 @@ def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None
     x <- (sigma_{i+1}/sigma_i) x - expm1(-(t_{i+1} - t_i)) D(x; sigma_i),  t = -ln sigma."""
     extra_args = {} if extra_args is None else extra_args
     if isinstance(model, GCDenoiser) and scaler is None and callback is None and not extra_args:
-        if _GRAPH_SAMPLER and action.device.type == "cuda" and not model.inner_model.training:
-            return _graphed(model, state, action, goal, sigmas)  # MDT_HIP_GRAPH=1: the same launches, replayed as a HIP graph
+        if _graph_wanted(model, state, action, goal, sigmas):
+            return _graphed(model, state, action, goal, sigmas)  # the same launches, replayed as a HIP graph
         return model.sample_ddim(state, action, goal, sigmas)  # fused native loop
     sig = _host(sigmas)
     with _hoist(model, state, goal):

@@ -5,7 +5,9 @@ A rollout calls ``sample_ddim`` with the same shapes step after step (reference 
 single submission; the results stay bit-identical (same kernels, same order).  Measured on MI355X (``tools/graph_probe.py``,
 ``MDT_HIP_GRAPH=1 tools/latency.py``): a bare replay takes 1.60 ms host-synchronised at B = 1; through this wrapper (input
 copies, parameter check, output clone) 1.67 ms against 1.69 ms for the eager call -- the call is bound by the dependent chain
-of its ~250 kernels on the GPU, not by their submission, so the graph buys little; it is kept as an opt-in.
+of its ~250 kernels on the GPU.  Round 3 shortened the chain (1.42 ms of GPU time): now the host needs longer to submit it than
+the GPU to run it and the replay wins -- 1.43 against 1.56 ms -- so ``gc_sampling.sample_ddim`` switches rollout-sized calls to
+it by itself (``MDT_HIP_GRAPH`` unset: from the third call with the same shapes on, B <= 8).
 
 ``GraphedDDIM`` owns static copies of the inputs, captures ``GCDenoiser.sample_ddim`` on them once and replays it; the library's
 weight images are updated in place by the usual re-upload (outside the graph), so parameter updates are seen.  The capture is

@@ -42,6 +42,8 @@ class HipEngine:
         self.device = device
         self.cfg = cfg
         handle = C.c_void_p()
+        from ...utils import torch_allocator
+        torch_allocator.install()  # workspace / tapes / scratch live in torch's caching allocator, not beside it
         with torch.cuda.device(device):
             _lib.check(self.lib.mdt_create(C.byref(cfg), C.byref(handle)))
         self.handle = handle

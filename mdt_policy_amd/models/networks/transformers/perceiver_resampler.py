@@ -173,6 +173,8 @@ class PerceiverResampler(nn.Module):
             self._drop_handle()
             cfg = _lib.ResamplerConfig(**self._cfg)
             h = C.c_void_p()
+            from ....utils import torch_allocator
+            torch_allocator.install()  # workspace / tapes / scratch live in torch's caching allocator
             with torch.cuda.device(device):
                 _lib.check(lib.mdt_resampler_create(C.byref(cfg), C.byref(h)))
             self._handle, self._handle_device = h, device

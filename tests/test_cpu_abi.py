@@ -341,7 +341,8 @@ def test_ctypes_prototypes_mirror_the_headers():
                 else:
                     t = a.replace("const ", "").split()[0]
                     kinds.append({"int32_t": "i32", "uint32_t": "i32", "int64_t": "i64", "uint64_t": "i64", "float": "f32",
-                                  "double": "f64", "mdt_tape_id": "i32"}[t])  # typedef int32_t mdt_tape_id
+                                  "double": "f64", "mdt_tape_id": "i32",  # typedef int32_t mdt_tape_id
+                                  "mdt_alloc_fn": "ptr", "mdt_free_fn": "ptr"}[t])  # function-pointer typedefs (mdt_set_allocator)
             protos[name] = kinds
     table = {n: [_kind(t) for t in argt] for n, _, argt in _lib.SYMBOLS}
     assert set(protos) == set(table)

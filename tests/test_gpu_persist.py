@@ -20,7 +20,11 @@ def _lib():
 
 
 @pytest.fixture(autouse=True)
-def _restore_switch():
+def _restore_switch(monkeypatch):
+    # these tests count the persistent kernel's launches and compare launch paths: the automatic switch of repeated
+    # rollout-sized calls to graph replay (gc_sampling._GRAPH_MODE "auto") stays off unless a test turns it on
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    monkeypatch.setattr(gs, "_GRAPH_MODE", "0")
     yield
     _lib().mdt_op_set_persist(-1)
     _lib().mdt_op_set_mlp_fuse_min(-1)
@@ -178,3 +182,38 @@ def test_graphed_sampler_replays_the_fused_call_bit_for_bit():
         want = gs.sample_ddim(model, st, x, goal, sig).clone()
         assert torch.equal(g(st, x, goal, sig), want)
         assert not g.matches(st8, x8, goal8, sig) and g.matches(st, x, goal, sig)
+
+
+def test_rollout_sized_calls_switch_to_graph_replay_by_themselves(monkeypatch):
+    """MDT_HIP_GRAPH unset ("auto"): the third call with the same rollout-sized shapes (B <= 8, eval, no grad) and every one
+    after it replays a captured graph -- same bits as the eager launches; a large batch never does."""
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    cfg = configs.mdtv_default()
+    model = GCDenoiser(cfg, 0.5)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 5, "rich").items()}, strict=False)
+    model = model.cuda().eval()
+    sig = gs.get_sigmas_exponential(10, 0.001, 80.0).cuda()
+
+    def inputs(seed, B):
+        inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(B, cfg, seed).items()}
+        return {"state_images": inp["state_images"], "modality": "lang"}, inp["noise"] * 80.0, inp["goal"]
+
+    monkeypatch.setattr(gs, "_GRAPH_MODE", "0")
+    monkeypatch.setattr(gs, "_GRAPH_SAMPLER", False)
+    eager = []
+    with torch.no_grad():
+        for seed in range(6):
+            eager.append(gs.sample_ddim(model, *inputs(seed, 1), sig).clone())
+    assert not model.__dict__.get("_graphed_samplers")
+    monkeypatch.setattr(gs, "_GRAPH_MODE", "auto")
+    with torch.no_grad():
+        for seed in range(6):
+            out = gs.sample_ddim(model, *inputs(seed, 1), sig)
+            assert torch.equal(out, eager[seed]), seed
+            assert bool(model.__dict__.get("_graphed_samplers")) == (seed >= gs._GRAPH_AUTO_AFTER), seed
+        for _ in range(4):
+            gs.sample_ddim(model, *inputs(9, 64), sig)
+    assert len(model._graphed_samplers) == 1

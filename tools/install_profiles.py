@@ -55,3 +55,25 @@ mae = read("mae_kernel_stats.txt").splitlines(True)
 write("mae_kernel_stats.txt",
       head + "masked generative foresight head: rocprofv3 --kernel-trace --stats of 'python tools/mae_bench.py 1024' (forward + "
       "backward, B = 1024), MI355X\n# without the profiler (same box):\n" + read("mae_bench.txt") + "".join(mae[:34]))
+# the dominant kernel's HBM-side traffic per launch, for bench.py's roofline.traffic (PMC counters cannot be read from inside
+# the bench process): the fused MLP launch's row of the PMC table above
+import json
+for l in read("bench_pmc.txt").splitlines():
+    if l.startswith("k_mlp<"):
+        f = [x.strip() for x in l.split("|")]
+        rd, wr = float(f[6]), float(f[7])
+        M, D, N, S = 2560, 384, 1536, 3
+        write("dominant_kernel_pmc.json", json.dumps({
+            "kernel": f"{f[0]} (LN + modulate -> c_fc -> GELU -> c_proj -> gate, {M} rows, d = {D}, hidden {N}; B = 256)",
+            "source": f"rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum of the bench command "
+                      f"itself (own pass, tools/gpu_final.sh; table profiles/{pre}bench_pmc.txt), per launch, {f[2]} dispatches",
+            "read_bytes": int(rd * 1e6), "write_bytes": int(wr * 1e6), "hbm_side_bytes_per_launch": int((rd + wr) * 1e6),
+            "l2_hit": float(f[8]), "mfma_busy_frac_at_2.4GHz": float(f[5]), "avg_us_under_pmc": float(f[3]),
+            "units": "guide MI355X_MICROARCH.md 'HBM': EA read requests are 128-B requests on gfx950 (FETCH_SIZE = RDREQ x 64 B reports "
+                     "half) -> x128 B; write requests x64 B (calibrated in round 1 on a GEMM whose output size is exact)",
+            "algorithmic_bytes_per_launch": 4 * (M * D + 2 * N * D + S * M * D),
+            "note": "reads exceed the algorithmic 13.4 MB because each of the 8 XCD L2s fetches both 2.36 MB weight images once (served "
+                    "by the 256 MB Infinity Cache, which these memory-side counters include): 8 x 4.7 + 3.9 MB of rows; the writes are "
+                    "exactly the three partial slabs (3 x 3.9 MB).  The hidden layer (15.7 MB per launch in round 2) never leaves the CU."
+        }, indent=2) + "\n")
+        break
