@@ -136,6 +136,15 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm(mdt_gemm_args a, int kchun
     gemm_tile<MTILES, NTW, NWAVES, PRO, RES, false>(a, kchunk, by, bx, lds, zeros, threadIdx.x);
 }
 
+// SwishGLU riding on a plain-prologue product's epilogue (mdt_gemm_args.aux_mode 3 forward / 4 backward): own instantiations
+template <int MTILES, int NTW, int NWAVES, int GLU>
+__global__ __launch_bounds__(64 * NWAVES) void k_gemm_glu(mdt_gemm_args a, int kchunk, int grid_n, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / grid_n, bx = logical - by * grid_n;
+    gemm_tile<MTILES, NTW, NWAVES, PRO_PLAIN, false, false, 1, GLU>(a, kchunk, by, bx, lds, zeros, threadIdx.x);
+}
+
 // the same wide tile reading its rows as the sum of XP partial slabs (the output of a fused MLP launch, k_mlp below)
 template <int NTW, int PRO, int XP>
 __global__ __launch_bounds__(512) void k_gemm_merge(mdt_gemm_args a, int kchunk, int grid_n, const float* __restrict__ zeros) {
@@ -374,6 +383,22 @@ static hipError_t launch_gemm_r(const mdt_gemm_args& a, int kchunk, hipStream_t 
     return hipGetLastError();
 }
 
+template <int MTILES, int NTW, int NWAVES, int GLU>
+static hipError_t launch_gemm_glu(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
+    const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
+    const int gn = (a.N + NTC - 1) / NTC, gm = (a.M + MT - 1) / MT;
+    const size_t lds = (size_t)MT * (kchunk + 4) * sizeof(float);
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_glu<MTILES, NTW, NWAVES, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_gemm_glu<MTILES, NTW, NWAVES, GLU>), dim3(gn * gm), dim3(64 * NWAVES), lds, s, a, kchunk, gn, g_zeros);
+    return hipGetLastError();
+}
+
 template <int MTILES, int NTW, int NWAVES, int LW, bool RES>
 static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
     const int MT = MTILES * 16, NTC = NWAVES * NTW * 16;
@@ -500,10 +525,13 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     // N = 192 layers of the masked-image decoder: 595 us as 16-column split-K tiles vs ~300 us tiled)
     // the training hooks of the epilogue (aux) exist in the plain-prologue, non-residual tiled kernels only
     if (a.aux_mode && (!a.aux || a.ln || a.residual || a.batch > 1 || a.K > 512)) return hipErrorInvalidValue;
-    if (a.aux_mode == 3) {  // SwishGLU forward: pairs of column tiles per wave -> the even-NTW geometries only
-        if ((a.N & 31) || a.gin != 1 || a.gout != 1 || a.goff != 0 || a.act != MDT_ACT_NONE) return hipErrorInvalidValue;
+    if (a.aux_mode == 3 || a.aux_mode == 4) {  // SwishGLU on the epilogue: own kernels (4 waves; forward: pairs of column tiles per wave)
+        if ((a.N & (a.aux_mode == 3 ? 31 : 15)) || a.gin != 1 || a.gout != 1 || a.goff != 0 || a.act != MDT_ACT_NONE)
+            return hipErrorInvalidValue;
         const int kc = mdt_gemm_kchunk(a.K, 0, 384);
-        return (a.N % 256 == 0) ? launch_gemm_pro<2, 4, 4>(a, kc, s) : launch_gemm_pro<2, 2, 4>(a, kc, s);
+        if (a.aux_mode == 3)
+            return (a.N % 256 == 0) ? launch_gemm_glu<2, 4, 4, 3>(a, kc, s) : launch_gemm_glu<2, 2, 4, 3>(a, kc, s);
+        return (a.N % 192 == 0) ? launch_gemm_glu<2, 3, 4, 4>(a, kc, s) : launch_gemm_glu<2, 2, 4, 4>(a, kc, s);
     }
     if (a.a_parts > 1) return launch_gemm_merge(a, s);
     if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {

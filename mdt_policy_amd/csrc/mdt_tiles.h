@@ -316,7 +316,9 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
 //   branch around a load makes hipcc wait vmcnt(0) right behind it -- one full L2 round trip per load.
 // No thread leaves early (the persistent kernel follows the tile with a barrier).
 // ------------------------------------------------------------------------------------------------
-template <int MTILES, int NTW, int NWAVES, int PRO, bool RES, bool COH, int XP = 1>
+// GLU (compile time; 0 in every kernel but k_gemm_glu): 3 = SwishGLU forward on this product's epilogue, 4 = SwishGLU backward
+// (mdt_gemm_args.aux_mode 3 / 4) -- their own instantiations, so that the plain kernels carry none of their code
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES, bool COH, int XP = 1, int GLU = 0>
 __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, int by, int bx, float* lds,
                                           const float* __restrict__ zeros, int tid) {
     MDT_TS(0)
@@ -367,8 +369,7 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
         const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
         // SwishGLU forward (aux_mode 3): the weight image interleaves the projected / gate halves tile by tile
         // (mdt_op_pack_weight_glu); bias and output columns are the NATURAL ones: tile T -> half T & 1, columns 16 (T >> 1)
-        constexpr bool AUX_HOOKS = PRO == PRO_PLAIN && !RES && !COH;
-        const bool glu_fwd = AUX_HOOKS && (NTW % 2 == 0) && a.aux_mode == 3;
+        constexpr bool glu_fwd = GLU == 3 && (NTW % 2 == 0);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int T = min(nt0 + j, N16 - 1);
@@ -445,34 +446,32 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
             for (int j = 0; j < NTW; ++j) {
                 const bool ok = mok && nt0 + j < N16;
                 f32x4 v = acc[i][j] + bias_v[j];
-                if constexpr (PRO == PRO_PLAIN && !RES && !COH) {
+                if constexpr (GLU == 4) {
+                    // SwishGLU backward: v = d_out[m][c..c+3]; u row = [projected | gate] beside it; two stores
+                    const f32x4 pj = *(const f32x4*)(a.aux + ooff[i] + ncol[j]);  // rows clamped above: in bounds
+                    const f32x4 gt = *(const f32x4*)(a.aux + ooff[i] + a.N + ncol[j]);
+                    f32x4 dg;
+                    dg.x = v.x * pj.x * act_silu_grad(gt.x); dg.y = v.y * pj.y * act_silu_grad(gt.y);
+                    dg.z = v.z * pj.z * act_silu_grad(gt.z); dg.w = v.w * pj.w * act_silu_grad(gt.w);
+                    v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
+                    if (ok) st4(a.out + ooff[i] + a.N + ncol[j], dg);
+                } else if constexpr (GLU == 3 && NTW % 2 == 0) {
+                    // even tile: projected, odd tile: its gate (same lane, same columns): u -> aux (row stride 2 ldo),
+                    // projected * silu(gate) -> out, stored by the even tile
+                    if (ok) st4(const_cast<float*>(a.aux) + 2 * ooff[i] + ncol[j], v);
+                    if ((j & 1) == 0) {
+                        const f32x4 gt = acc[i][(j + 1) % NTW] + bias_v[(j + 1) % NTW];
+                        v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
+                    } else {
+                        continue;  // the gate tile has no column of its own in `out`
+                    }
+                } else if constexpr (PRO == PRO_PLAIN && !RES && !COH) {
                     // training hooks (mdt_gemm_args.aux): keep the pre-activation beside the activated value, or turn the
                     // product into the gradient of the activation below it
                     if (a.aux_mode == 2) {
                         const f32x4 u = *(const f32x4*)(a.aux + ooff[i] + ncol[j]);  // rows clamped above: in bounds
                         v.x *= apply_act_grad1(u.x, a.act); v.y *= apply_act_grad1(u.y, a.act);
                         v.z *= apply_act_grad1(u.z, a.act); v.w *= apply_act_grad1(u.w, a.act);
-                    } else if (a.aux_mode == 4) {
-                        // SwishGLU backward: v = d_out[m][c..c+3]; u row = [projected | gate] beside it; two stores
-                        const f32x4 pj = *(const f32x4*)(a.aux + ooff[i] + ncol[j]);
-                        const f32x4 gt = *(const f32x4*)(a.aux + ooff[i] + a.N + ncol[j]);
-                        f32x4 dg;
-                        dg.x = v.x * pj.x * act_silu_grad(gt.x); dg.y = v.y * pj.y * act_silu_grad(gt.y);
-                        dg.z = v.z * pj.z * act_silu_grad(gt.z); dg.w = v.w * pj.w * act_silu_grad(gt.w);
-                        v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
-                        if (ok) st4(a.out + ooff[i] + a.N + ncol[j], dg);
-                    } else if (a.aux_mode == 3) {
-                        if constexpr (NTW % 2 == 0) {
-                            // even tile: projected, odd tile: its gate (same lane, same columns): u -> aux (row stride 2 ldo),
-                            // projected * silu(gate) -> out, stored by the even tile
-                            if (ok) st4(const_cast<float*>(a.aux) + 2 * ooff[i] + ncol[j], v);
-                            if ((j & 1) == 0) {
-                                const f32x4 gt = acc[i][(j + 1) % NTW] + bias_v[(j + 1) % NTW];
-                                v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
-                            } else {
-                                continue;  // the gate tile has no column of its own in `out`
-                            }
-                        }
                     } else {
                         if (a.aux_mode == 1 && ok) st4(const_cast<float*>(a.aux) + ooff[i] + ncol[j], v);
                         v = apply_act(v, a.act);
