@@ -138,6 +138,10 @@ mdt_status mdt_op_attention(const mdt_attn_args *args, void *stream);
  * Replaces Attention.forward's SDPA + c_proj (transformer_blocks.py:142-157) for one sample. */
 mdt_status mdt_op_attn_proj(const mdt_gemm_args *proj, const float *qkv, int64_t ldq, int32_t hd, int32_t T, int32_t causal,
                             void *stream);
+/* (More than 64 samples: the same contract for a LARGE batch, M = samples * T rows, causal, residual, hd in {16, 32, 48} --
+ * the attention of each 32-row tile is computed in the prologue of the tiled projection GEMM, k_attn_proj_wide; the
+ * model-level entry points use it from `rows` rows on: 0 = never (attention launch + projection GEMM), -1 = default 1401.) */
+void mdt_op_set_attn_wide_min(int32_t rows);
 
 mdt_status mdt_op_layernorm(const float *in, const float *w, const float *b, float *out, int64_t M, int32_t D,
                             void *stream);

@@ -78,6 +78,9 @@ hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, c
 bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope);
 hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int H, int hd, int T, int causal,
                                 hipStream_t s);
+// the same for a LARGE batch: the causal attention of a 32-row tile computed in the projection's prologue (k_attn_proj_wide)
+bool mdt_attn_proj_wide_supported(const mdt_gemm_args& p, int H, int hd, int T, int causal, int rope);
+hipError_t mdt_launch_attn_proj_wide(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int H, int hd, int T, hipStream_t s);
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
                                 hipStream_t s);
 hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,

@@ -329,6 +329,19 @@ __global__ __launch_bounds__(512) void k_attn_proj_smallm(mdt_gemm_args a, const
     attn_proj_tile<HD, false>(a, qkv, ldq, T, causal, scale, blockIdx.x, blockIdx.y, lds, red, zeros, threadIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_attn_proj_wide: the self-attention output projection of a LARGE batch with the (causal) attention of the tile's rows
+// computed in its prologue (mdt_tiles.h: attn_stage_tile) -- replaces k_attn + the projection GEMM (20 us -> one launch per
+// decoder block at B = 256).  32 x 128 tiles, 8 waves, residual epilogue (out += gate * value).
+// ------------------------------------------------------------------------------------------------
+template <int HD, int TKC>
+__global__ __launch_bounds__(512) void k_attn_proj_wide(mdt_gemm_args a, mdt_attn_pro ap, int grid_n, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / grid_n, bx = logical - by * grid_n;
+    gemm_tile<2, 1, 8, PRO_ATTN, true, false, 1, 0, HD, TKC>(a, a.K, by, bx, lds, zeros, threadIdx.x, &ap);
+}
+
 // 256 KiB of zeros per device: stands in for absent bias / rowvec / LayerNorm-bias vectors.  ensure_zeros() points
 // g_zeros at the CURRENT device's buffer (a process normally drives one GPU; a second one gets its own buffer).
 static const int ZEROS_FLOATS = 65536;
@@ -510,6 +523,41 @@ hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_
 }
 
 static hipError_t launch_gemm_merge(const mdt_gemm_args& a, hipStream_t s);
+
+bool mdt_attn_proj_wide_supported(const mdt_gemm_args& p, int H, int hd, int T, int causal, int rope) {
+    return H == 8 && (hd == 16 || hd == 32 || hd == 48) && p.K == H * hd && T >= 1 && T <= 16 && causal && !rope && p.residual &&
+           p.M >= T && p.M % T == 0 && p.rows_per_sample == T && !(p.N & 15) && p.gin == 1 && p.gout == 1 && p.goff == 0 && !p.ln &&
+           p.act == MDT_ACT_NONE && p.rowvec == nullptr && p.batch <= 1 && !p.aux_mode;
+}
+
+template <int HD, int TKC>
+static hipError_t launch_attn_proj_wide_t(const mdt_gemm_args& p, const mdt_attn_pro& ap, hipStream_t s) {
+    const int gn = (p.N + 127) / 128, gm = (p.M + 31) / 32;
+    const size_t lds = ((size_t)32 * (p.K + 4) + (size_t)(32 + 2 * 48) * (4 * HD + 16)) * sizeof(float);
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
+    if (lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_proj_wide<HD, TKC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_attn_proj_wide<HD, TKC>), dim3(gn * gm), dim3(512), lds, s, p, ap, gn, g_zeros);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_attn_proj_wide(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int H, int hd, int T, hipStream_t s) {
+    if (!mdt_attn_proj_wide_supported(p, H, hd, T, 1, 0)) return hipErrorInvalidValue;
+    hipError_t ze = ensure_zeros();
+    if (ze != hipSuccess) return ze;
+    mdt_attn_pro ap;
+    ap.qkv = qkv; ap.ldq = ldq; ap.T = T; ap.scale = 1.0f / sqrtf((float)hd);
+    const bool t10 = T <= 10;
+    switch (hd) {
+        case 16: return t10 ? launch_attn_proj_wide_t<16, 10>(p, ap, s) : launch_attn_proj_wide_t<16, 16>(p, ap, s);
+        case 32: return t10 ? launch_attn_proj_wide_t<32, 10>(p, ap, s) : launch_attn_proj_wide_t<32, 16>(p, ap, s);
+        default: return t10 ? launch_attn_proj_wide_t<48, 10>(p, ap, s) : launch_attn_proj_wide_t<48, 16>(p, ap, s);
+    }
+}
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;

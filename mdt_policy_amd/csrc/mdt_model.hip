@@ -666,6 +666,15 @@ struct Stream {
     int64_t stride = 0;
 };
 
+// row count from which the self-attention runs in the prologue of its output projection (MDT_HIP_ATTN_WIDE_MIN; 0 disables)
+static int g_attn_wide_override = -1;  // mdt_op_set_attn_wide_min (tests / A-B runs)
+static int g_attn_wide_min_rows() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_WIDE_MIN"); v = e ? atoi(e) : 1401; if (v == 0) v = 1 << 30; }
+    return g_attn_wide_override >= 0 ? (g_attn_wide_override == 0 ? 1 << 30 : g_attn_wide_override) : v;
+}
+extern "C" void mdt_op_set_attn_wide_min(int32_t rows) { g_attn_wide_override = rows; }
+
 static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, bool causal,
                                 ModRef mr, hipStream_t s, Stream in = Stream()) {
     float* x = V.y;
@@ -684,6 +693,12 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
     if (B <= g_attn_proj_max_batch() && mdt_attn_proj_supported(p, m->H, m->hd, T, m->cfg.use_rot_embed)) {
         // rollout batch: attention and projection in one launch (the attention output never leaves the workgroup)
         LAUNCH(mdt_launch_attn_proj(p, V.qkv, 3 * D, m->H, m->hd, T, causal, s));
+        return MDT_OK;
+    }
+    if (M >= g_attn_wide_min_rows() && mdt_attn_proj_wide_supported(p, m->H, m->hd, T, causal, m->cfg.use_rot_embed)) {
+        // large batch: the causal attention of each 32-row tile in the projection's prologue (no attention launch, no
+        // round trip of the attention output)
+        LAUNCH(mdt_launch_attn_proj_wide(p, V.qkv, 3 * D, m->H, m->hd, T, s));
         return MDT_OK;
     }
     mdt_attn_args a;
@@ -1215,6 +1230,12 @@ extern "C" mdt_status mdt_op_xattn_apply(const mdt_xapply_args* a, void* stream)
 extern "C" mdt_status mdt_op_attn_proj(const mdt_gemm_args* proj, const float* qkv, int64_t ldq, int32_t hd, int32_t T,
                                        int32_t causal, void* stream) {
     if (!proj || !qkv || !proj->Wp || !proj->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_proj: null argument");
+    if (T >= 1 && proj->M / T > 64 && mdt_attn_proj_wide_supported(*proj, 8, hd, T, causal, 0)) {
+        if (misaligned(qkv) || misaligned(proj->Wp) || misaligned(proj->out) || (ldq & 3))
+            return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_proj: pointers must be 16-byte aligned, ldq a multiple of 4");
+        LAUNCH(mdt_launch_attn_proj_wide(*proj, qkv, ldq, 8, hd, T, (hipStream_t)stream));  // many samples: the tiled form
+        return MDT_OK;
+    }
     if (!mdt_attn_proj_supported(*proj, 8, hd, T, 0))
         return fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_proj: needs 8 heads of 16/32/48/64 (K = 8 * hd), T <= 16 rows per sample "
                                          "(M = samples * T, at most 64 samples), a plain projection");

@@ -70,7 +70,16 @@ struct ActLd<true> {
 
 // prologue kinds: plain copy | LayerNorm | LayerNorm + modulate with ONE broadcast row (sampler: one sigma per
 // step) | LayerNorm + modulate with a per-sample row (GCDenoiser.forward / loss with per-sample sigma)
-enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_LN_MOD_BCAST = 2, PRO_LN_MOD_ROWS = 3 };
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_LN_MOD_BCAST = 2, PRO_LN_MOD_ROWS = 3,
+       PRO_ATTN = 4 /* the activation tile is the causal self-attention output of the tile's rows, computed here (attn_stage_tile) */ };
+
+// what the attention prologue (PRO_ATTN) needs beside the projection's own mdt_gemm_args
+struct mdt_attn_pro {
+    const float* qkv;   // (M, 3 D) rows: q | k | v column blocks of D = H * hd each
+    int64_t ldq;
+    int T;              // rows per sample (<= 16); key j visible to query i of the same sample iff j <= i
+    float scale;
+};
 
 // output store of the GEMM epilogues.  -DMDT_ST_WT (tuning build) makes it a write-through (sc0 sc1) store so that the
 // tile does not stay dirty in L2 until the end-of-kernel write-back.
@@ -308,6 +317,122 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
 }
 
 // ------------------------------------------------------------------------------------------------
+// Attention prologue of the self-attention output projection (PRO_ATTN; large batches): the activation tile of the
+// projection -- softmax_causal(q k^T / sqrt(hd)) v for the tile's 32 rows, all 8 heads -- is computed HERE instead of by a
+// launch of its own (k_attn: 8 us of every decoder block at B = 256, plus a kernel boundary and a round trip of the attention
+// output).  Causal attention only looks BACK inside a sample, so a 32-row tile needs the q rows of the tile and the k / v rows
+// from the first row of its first sample on: at most 32 + T - 1 <= 47 rows.  The 3 column workgroups of a row tile repeat it
+// (0.2 % of the FLOPs).  Heads are done in two halves of 4 (LDS: 49.7 KB activation tile + 100 KB of q / k / v half rows);
+// all global loads of both halves are requested up front.  Thread = (head of the half, row, quarter of the head dimension);
+// the 4 quarters of a dot product meet through DPP quad swaps (no LDS round trip).  512 threads, H = 8.
+//   xa: activation tile [32][stride]; scratch: (32 + 2 * 48) * (4 * HD + 16) floats behind it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+template <int HD, int TKC>
+__device__ __forceinline__ void attn_stage_tile(const mdt_gemm_args& a, const mdt_attn_pro& ap, float* xa, int stride, int m0,
+                                                float* scratch, int tid) {
+    // row stride = 16 (mod 64) floats: the 16 lanes one ds_read_b128 cycle serves -- 4 (row, head) pairs x 4 quarters, 12 floats
+    // apart -- then fall into 16 different 16-byte bank groups (with the usual + 4 padding they collide 2-3 ways and the
+    // attention, all LDS reads, took 3.5 us per half instead of ~1.5)
+    constexpr int HH = 4, HHD = HH * HD, ST = HHD + 16, H4 = HHD / 4, KVR = 48, DS = HD / 4, NL = 12;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int T = ap.T, D = 2 * HHD;
+    const int kv0 = (m0 / T) * T;                       // first key / value row the tile can see
+    const int nkv = min(m0 + 32, a.M) - kv0;            // <= 32 + T - 1 <= 47
+    float* qs = scratch;                                // [32][ST]
+    float* ks = qs + 32 * ST;                           // [KVR][ST]
+    float* vs = ks + KVR * ST;                          // [KVR][ST]
+    const int nq4 = 32 * H4, nk4 = nkv * H4, total = nq4 + 2 * nk4;   // float4 items of one half
+    // ---- every global load of both halves, now ----
+    f32x4 t[2][NL];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = min(tid + 512 * u, total - 1);
+            int64_t src;
+            if (idx < nq4) {
+                const int r = idx / H4, c = idx - r * H4;
+                src = (int64_t)min(m0 + r, a.M - 1) * ap.ldq + hh * HHD + 4 * c;
+            } else {
+                const int i2 = idx - nq4, which = i2 >= nk4, i3 = i2 - which * nk4, r = i3 / H4, c = i3 - r * H4;
+                src = (int64_t)(kv0 + r) * ap.ldq + (1 + which) * D + hh * HHD + 4 * c;
+            }
+            t[hh][u] = ldg4(ap.qkv + src);
+        }
+    // ---- this thread's (head, row, quarter) ----
+    const int lp = tid & 3, pr = tid >> 2, r = pr & 31, hl = pr >> 5;   // 128 pairs = 4 heads x 32 rows
+    const int m = m0 + r;
+    const bool valid = m < a.M;
+    const int mc = min(m, a.M - 1), smp = mc / T, tq = mc - smp * T;   // position inside the sample: keys 0 .. tq
+    const int kb = smp * T - kv0;                                       // the sample's first row in ks / vs
+    const int d0 = hl * HD + lp * DS;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if (hh) __syncthreads();                        // everyone is done reading the first half's rows
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = tid + 512 * u;
+            if (idx < total) {
+                float* dst;
+                if (idx < nq4) { const int rr = idx / H4; dst = qs + rr * ST + 4 * (idx - rr * H4); }
+                else {
+                    const int i2 = idx - nq4, which = i2 >= nk4, i3 = i2 - which * nk4, rr = i3 / H4;
+                    dst = (which ? vs : ks) + rr * ST + 4 * (i3 - rr * H4);
+                }
+                *(f32x4*)dst = t[hh][u];
+            }
+        }
+        __syncthreads();
+        float q[DS];
+#pragma unroll
+        for (int d = 0; d < DS; d += 4) {
+            const f32x4 x = *(const f32x4*)(qs + r * ST + d0 + d);
+            q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+        }
+        float sc[TKC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TKC; ++j) {
+            const float* kp = ks + min(kb + min(j, tq), KVR - 1) * ST + d0;   // clamped: masked keys re-read a visible one
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < DS; d += 4) {
+                const f32x4 x = *(const f32x4*)(kp + d);
+                dot = fmaf(q[d], x.x, dot); dot = fmaf(q[d + 1], x.y, dot); dot = fmaf(q[d + 2], x.z, dot); dot = fmaf(q[d + 3], x.w, dot);
+            }
+            dot = quad_sum(dot);                        // the four quarters of the head dimension
+            sc[j] = j <= tq ? dot * ap.scale : -INFINITY;
+            mx = fmaxf(mx, sc[j]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TKC; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }   // key 0 is always visible: mx is finite
+        const float inv = 1.0f / sum;
+        float o[DS];
+#pragma unroll
+        for (int d = 0; d < DS; ++d) o[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TKC; ++j) {
+            const float pj = sc[j] * inv;
+            const float* vp = vs + min(kb + min(j, tq), KVR - 1) * ST + d0;
+#pragma unroll
+            for (int d = 0; d < DS; d += 4) {
+                const f32x4 x = *(const f32x4*)(vp + d);
+                o[d] = fmaf(pj, x.x, o[d]); o[d + 1] = fmaf(pj, x.y, o[d + 1]); o[d + 2] = fmaf(pj, x.z, o[d + 2]); o[d + 3] = fmaf(pj, x.w, o[d + 3]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DS; d += 4)
+            *(f32x4*)(xa + r * stride + hh * HHD + d0 + d) = valid ? (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]} : zero4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused GEMM tile:  out = epilogue( prologue(A) @ W^T ) for row tile `by` and column tile `bx`
 //   64 * NWAVES threads; tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns); full K.
 //   wave w owns NTW column tiles and ALL row tiles of the workgroup tile.
@@ -318,9 +443,9 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
 // ------------------------------------------------------------------------------------------------
 // GLU (compile time; 0 in every kernel but k_gemm_glu): 3 = SwishGLU forward on this product's epilogue, 4 = SwishGLU backward
 // (mdt_gemm_args.aux_mode 3 / 4) -- their own instantiations, so that the plain kernels carry none of their code
-template <int MTILES, int NTW, int NWAVES, int PRO, bool RES, bool COH, int XP = 1, int GLU = 0>
+template <int MTILES, int NTW, int NWAVES, int PRO, bool RES, bool COH, int XP = 1, int GLU = 0, int AHD = 48, int ATKC = 16>
 __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, int by, int bx, float* lds,
-                                          const float* __restrict__ zeros, int tid) {
+                                          const float* __restrict__ zeros, int tid, const mdt_attn_pro* ap = nullptr) {
     MDT_TS(0)
     MDT_TS_HWID()
     constexpr int MT = MTILES * 16;
@@ -400,8 +525,11 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
     for (int k0 = 0; k0 < a.K; k0 += kchunk) {
         const int klen = min(kchunk, a.K - k0);
         if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
-        gemm_stage_tile<MTILES, NWAVES, PRO, COH, XP>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave,
-                                                      bx == 0 ? a.a_merged : nullptr);
+        if constexpr (PRO == PRO_ATTN)
+            attn_stage_tile<AHD, ATKC>(a, *ap, lds, stride, m0, lds + MT * stride, tid);
+        else
+            gemm_stage_tile<MTILES, NWAVES, PRO, COH, XP>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave,
+                                                          bx == 0 ? a.a_merged : nullptr);
         MDT_TS(1)
         __syncthreads();
         MDT_TS(2)

@@ -315,8 +315,41 @@ def test_attention_fused_into_projection_per_sample(lib, hd, T, causal, gated, B
     a.residual, a.rows_per_sample, a.gin, a.gout = 1, T, 1, 1
     lib.check(lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()))
     assert_close(out.cpu(), want.float(), rtol=1e-4, atol=2e-5, what="attention + projection")
-    a.M = 65 * T  # more samples than the fused kernel takes
-    assert lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()) == 2
+    if not causal or hd == 64:
+        a.M = 65 * T  # more samples than the per-sample kernel takes, and no tiled form for this case
+        assert lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()) == 2
+
+
+@pytest.mark.parametrize("hd,T,gated,B", [(48, 10, True, 256), (48, 10, False, 77), (32, 16, True, 70), (16, 7, True, 201),
+                                          (48, 1, True, 100), (32, 13, True, 65)])
+def test_attention_in_the_projection_prologue_for_large_batches(lib, hd, T, gated, B):
+    """mdt_op_attn_proj with more than 64 samples (k_attn_proj_wide): the causal attention of every 32-row tile -- rows of
+    3-4 samples, keys reaching back into the previous tile's rows -- is computed in the prologue of the tiled projection;
+    against float64, and bit-for-bit against the attention launch + projection GEMM it replaces."""
+    g = torch.Generator().manual_seed(hd + T + B)
+    H, D, N = 8, 8 * hd, 8 * hd
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g) * 0.1
+    gate, y0 = torch.randn(B, 6 * N, generator=g), torch.randn(B * T, N, generator=g)
+    q3 = qkv.view(B, T, 3 * D)
+    att = ref_attn(q3[..., :D], q3[..., D:2 * D], q3[..., 2 * D:], H, True).double().reshape(B * T, D)
+    upd = att @ W.double().T + b.double()
+    if gated:
+        upd = gate[:, 2 * N:3 * N].double().repeat_interleave(T, 0) * upd
+    want = y0.double() + upd
+    qd, Pd, bd, gd, out = dev(qkv), pack(lib, W), dev(b), dev(gate), dev(y0).clone()
+    a = lib.GemmArgs()
+    a.A, a.lda, a.Wp, a.bias, a.out, a.ldo, a.M, a.N, a.K = None, D, Pd.data_ptr(), bd.data_ptr(), out.data_ptr(), N, B * T, N, D
+    a.shift_off = a.scale_off = -1
+    a.gate_off = 2 * N if gated else -1
+    a.mod, a.mod_stride = (gd.data_ptr(), 6 * N) if gated else (None, 0)
+    a.residual, a.rows_per_sample, a.gin, a.gout = 1, T, 1, 1
+    lib.check(lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, 1, stream()))
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), want.float(), rtol=1e-4, atol=2e-5, what="attention in the projection's prologue")
+    # the two launches it replaces
+    att_gpu = run_attn(lib, q3[..., :D], q3[..., D:2 * D], q3[..., 2 * D:], H, True).reshape(B * T, D)
+    assert_close(att_gpu, att.float(), rtol=1e-4, atol=1e-5, what="attention launch")
 
 
 def test_attention_matches_sdpa_is_causal_for_rectangular_scores(lib):

@@ -28,6 +28,7 @@ def _restore_switch(monkeypatch):
     yield
     _lib().mdt_op_set_persist(-1)
     _lib().mdt_op_set_mlp_fuse_min(-1)
+    _lib().mdt_op_set_attn_wide_min(-1)
 
 
 def _engine(model):
@@ -39,6 +40,7 @@ def _sample(model, state, x_T, goal, sig, persist):
     # the persistent kernel walks the two-GEMM MLP phases; large batches of the launch path fuse them into one launch that
     # adds the partial products in another order -- compare like with like
     _lib().mdt_op_set_mlp_fuse_min(-1 if persist else 0)
+    _lib().mdt_op_set_attn_wide_min(-1 if persist else 0)  # likewise: attention in the projection's prologue sums in another order
     eng = _engine(model)
     n0 = eng.persist_launches()
     with torch.no_grad():
