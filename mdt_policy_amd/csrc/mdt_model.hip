@@ -695,7 +695,11 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
         LAUNCH(mdt_launch_attn_proj(p, V.qkv, 3 * D, m->H, m->hd, T, causal, s));
         return MDT_OK;
     }
-    if (M >= g_attn_wide_min_rows() && mdt_attn_proj_wide_supported(p, m->H, m->hd, T, causal, m->cfg.use_rot_embed)) {
+    // (up to one workgroup per CU: its 156 KB of LDS allow no second one, so beyond 256 tiles -- B > 272 -- the workgroups
+    //  queue up behind each other while the plain projection keeps three per CU in flight: B = 512 10.35 vs 10.13 ms)
+    const int64_t wide_tiles = (int64_t)((M + 31) / 32) * ((D + 127) / 128);
+    if (M >= g_attn_wide_min_rows() && (wide_tiles <= 256 || g_attn_wide_override > 0) &&
+        mdt_attn_proj_wide_supported(p, m->H, m->hd, T, causal, m->cfg.use_rot_embed)) {
         // large batch: the causal attention of each 32-row tile in the projection's prologue (no attention launch, no
         // round trip of the attention output)
         LAUNCH(mdt_launch_attn_proj_wide(p, V.qkv, 3 * D, m->H, m->hd, T, s));
