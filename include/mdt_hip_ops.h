@@ -177,9 +177,10 @@ typedef struct {
     const float *Wq;               /* cross_att.query.weight (D, D) row-major (reference layout)               */
     const float *bq;               /* cross_att.query.bias (D)                                                 */
     const float *WoT;              /* cross_att.c_proj.weight TRANSPOSED: WoT[d][n] = Wo[n][d]                 */
-    float *U, *Wf;                 /* out: (B, H*Te, D) each                                                   */
-    float *c;                      /* out: (B, H*Te)                                                           */
-    int32_t B, H, hd, D, Te;
+    float *U, *Wf;                 /* out: B images of 4 H * D floats each, opaque: MFMA weight-fragment order, every head */
+                                   /* padded to 4 context tokens (row p = 4 h + j; mdt_kernels.hip "Collapsed ...")        */
+    float *c;                      /* out: (B, 4 H)                                                                        */
+    int32_t B, H, hd, D, Te;       /* H in {4, 8}, D = H * hd <= 512 a multiple of 64, 1 <= Te <= 4                        */
 } mdt_xfold_args;
 mdt_status mdt_op_xattn_fold(const mdt_xfold_args *args, void *stream);
 
@@ -189,9 +190,19 @@ typedef struct {
     const float *ln_w, *ln_b;      /* ln3 weight / bias (D)                                                    */
     const float *U, *Wf, *c;       /* from mdt_op_xattn_fold                                                   */
     const float *bo;               /* cross_att.c_proj.bias (D) or NULL                                        */
-    int32_t B, H, D, Te, Ta;
+    int32_t B, H, D, Te, Ta;       /* D a multiple of 128, Ta <= 16                                             */
 } mdt_xapply_args;
 mdt_status mdt_op_xattn_apply(const mdt_xapply_args *args, void *stream);
+
+/* The middle of a ConditionedBlock for a batch of at most one sample per compute unit, ONE launch, one workgroup per sample
+ * (k_attn_xattn): mdt_op_attn_proj's contract (causal self-attention of the sample's T rows -> c_proj + gate + residual,
+ * transformer_blocks.py:296-300) followed by mdt_op_xattn_apply's on the same rows (:301-305); the rows between the two
+ * sublayers stay in the workgroup's LDS and x->y == proj->out is written once.  8 heads of 48 (K = N = ldo = 384, ldq = 3 K),
+ * T = x->Ta <= 16, proj->M = x->B * T; results equal the two launches bit for bit.  The model-level entry points use it
+ * from 1401 rows up to 256 samples (MDT_HIP_ATTN_XATTN_MIN / MDT_HIP_ATTN_XATTN_MAX_B; mdt_op_set_attn_wide_min(0) switches
+ * it off together with the tiled form). */
+mdt_status mdt_op_attn_xattn(const mdt_gemm_args *proj, const float *qkv, int64_t ldq, const mdt_xapply_args *x, int32_t hd,
+                             int32_t T, void *stream);
 
 /* y = (x * c_in(sigma)) Wa^T + ba   (c_in omitted when sigma == NULL); WaT = action_emb.weight transposed to (A, D) */
 mdt_status mdt_op_action_embed(const float *x, const float *sigma, int64_t sigma_stride, float sigma_data,

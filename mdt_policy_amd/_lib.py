@@ -189,6 +189,7 @@ SYMBOLS = [
     ("mdt_op_attn_proj", _I32, [C.POINTER(GemmArgs), _VP, _I64, _I32, _I32, _I32, _VP]),
     ("mdt_op_xattn_fold", _I32, [C.POINTER(XFoldArgs), _VP]),
     ("mdt_op_xattn_apply", _I32, [C.POINTER(XApplyArgs), _VP]),
+    ("mdt_op_attn_xattn", _I32, [C.POINTER(GemmArgs), _VP, _I64, C.POINTER(XApplyArgs), _I32, _I32, _VP]),
     ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_head", _I32, [C.POINTER(HeadArgs), _VP]),
     ("mdt_op_action_embed", _I32, [_VP, _VP, _I64, _F, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _VP]),

@@ -81,6 +81,10 @@ hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_
 // the same for a LARGE batch: the causal attention of a 32-row tile computed in the projection's prologue (k_attn_proj_wide)
 bool mdt_attn_proj_wide_supported(const mdt_gemm_args& p, int H, int hd, int T, int causal, int rope);
 hipError_t mdt_launch_attn_proj_wide(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int H, int hd, int T, hipStream_t s);
+// one workgroup per sample: self-attention -> projection -> collapsed cross-attention (k_attn_xattn); x.y == p.out
+bool mdt_attn_xattn_supported(const mdt_gemm_args& p, const mdt_xapply_args& x, int H, int hd, int T, int causal, int rope);
+hipError_t mdt_launch_attn_xattn(const mdt_gemm_args& p, const float* qkv, int64_t ldq, const mdt_xapply_args& x, int H, int hd,
+                                 int T, hipStream_t s);
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
                                 hipStream_t s);
 hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,
@@ -111,6 +115,7 @@ hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s);
 hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_t s);  // equal shapes; one launch per 8 sets
 hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s);
 bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta);
+size_t mdt_xattn_lds_floats(int D, int H);  // LDS floats of the collapsed cross-attention body (xattn_tile)
 // ---- Perceiver resampler kernels ----
 // media (B, T, n, D) + time_pos_emb[t] * mask[b][t] -> out (same shape); mask may be nullptr
 hipError_t mdt_launch_add_time_emb(const float* media, const float* tpe, const uint8_t* mask, float* out, int64_t B,

@@ -342,6 +342,16 @@ __global__ __launch_bounds__(512) void k_attn_proj_wide(mdt_gemm_args a, mdt_att
     gemm_tile<2, 1, 8, PRO_ATTN, true, false, 1, 0, HD, TKC>(a, a.K, by, bx, lds, zeros, threadIdx.x, &ap);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_attn_xattn: one workgroup per SAMPLE through self-attention, its output projection and the collapsed cross-attention
+// (mdt_tiles.h: attn_xattn_tile) -- replaces k_attn_proj_wide + k_xattn_apply for batches of at most one sample per CU.
+// ------------------------------------------------------------------------------------------------
+template <int HD, int TKC>
+__global__ __launch_bounds__(512) void k_attn_xattn(mdt_gemm_args a, mdt_attn_pro at, mdt_xapply_args x, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    attn_xattn_tile<HD, TKC, 32>(a, at, x, MDT_SAMPLE_REMAP(blockIdx.x, gridDim.x), lds, zeros, threadIdx.x);
+}
+
 // 256 KiB of zeros per device: stands in for absent bias / rowvec / LayerNorm-bias vectors.  ensure_zeros() points
 // g_zeros at the CURRENT device's buffer (a process normally drives one GPU; a second one gets its own buffer).
 static const int ZEROS_FLOATS = 65536;
@@ -557,6 +567,41 @@ hipError_t mdt_launch_attn_proj_wide(const mdt_gemm_args& p, const float* qkv, i
         case 32: return t10 ? launch_attn_proj_wide_t<32, 10>(p, ap, s) : launch_attn_proj_wide_t<32, 16>(p, ap, s);
         default: return t10 ? launch_attn_proj_wide_t<48, 10>(p, ap, s) : launch_attn_proj_wide_t<48, 16>(p, ap, s);
     }
+}
+
+bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta);
+
+// Self-attention + projection + collapsed cross-attention of one sample per workgroup: `p` = the projection's arguments
+// (as for mdt_launch_attn_proj_wide), `x` = the cross-attention's (x.y == p.out).  Head dimension 48 (d = 384).
+bool mdt_attn_xattn_supported(const mdt_gemm_args& p, const mdt_xapply_args& x, int H, int hd, int T, int causal, int rope) {
+    return mdt_attn_proj_wide_supported(p, H, hd, T, causal, rope) && hd == 48 && p.N == p.K && p.ldo == p.N && x.y == p.out &&
+           x.D == p.N && x.H == H && H == 8 && x.Ta == T && (int64_t)x.B * T == p.M &&
+           mdt_xattn_apply_supported(x.D, x.H, x.Te, x.Ta);
+}
+
+template <int HD, int TKC>
+static hipError_t launch_attn_xattn_t(const mdt_gemm_args& p, const mdt_attn_pro& at, const mdt_xapply_args& x, hipStream_t s) {
+    const int D = 8 * HD;
+    const size_t lds = ((size_t)16 * (D + 4) + (size_t)48 * (D + 16)) * sizeof(float);
+    static bool attr_dev[MAX_DEVICES] = {false};
+    bool& attr = attr_dev[current_device()];
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_xattn<HD, TKC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_attn_xattn<HD, TKC>), dim3(x.B), dim3(512), lds, s, p, at, x, g_zeros);
+    return hipGetLastError();
+}
+
+hipError_t mdt_launch_attn_xattn(const mdt_gemm_args& p, const float* qkv, int64_t ldq, const mdt_xapply_args& x, int H, int hd,
+                                 int T, hipStream_t s) {
+    if (!mdt_attn_xattn_supported(p, x, H, hd, T, 1, 0) || ldq != 3 * (int64_t)p.K) return hipErrorInvalidValue;
+    hipError_t ze = ensure_zeros();
+    if (ze != hipSuccess) return ze;
+    mdt_attn_pro at;
+    at.qkv = qkv; at.ldq = ldq; at.T = T; at.scale = 1.0f / sqrtf((float)hd);
+    return T <= 10 ? launch_attn_xattn_t<48, 10>(p, at, x, s) : launch_attn_xattn_t<48, 16>(p, at, x, s);
 }
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
@@ -1004,16 +1049,23 @@ hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
 // (k_xattn_apply): LayerNorm, H*Te dot products of length d, H masked softmaxes over Te values, a
 // (H*Te) x d combination and the residual add -- 12x fewer FLOPs than the two d x d projections and three
 // launches (q GEMM, attention, c_proj GEMM) fewer per block and step.  Exact algebra, fp32 rounding differs.
+// Both folded matrices are stored as MFMA WEIGHT IMAGES (the fragment order of k_pack_weight) with every head padded to 4
+// context tokens, p = 4 h + j (NPP = 4 H rows; rows of absent tokens are zero):
+//     U  image: weight (NPP x D):   block (p / 16, d / 16), lane (p % 16) + 16 ((d % 16) / 4), element d % 4
+//     Wf image: weight (D x NPP):   block (n / 16, p / 16), lane (n % 16) + 16 ((p % 16) / 4), element p % 4  ( = j )
+// so that k_xattn_apply's two contractions are a handful of v_mfma_f32_16x16x4_f32 per wave (mdt_tiles.h: xattn_tile).
 // ------------------------------------------------------------------------------------------------
 // the folds of ALL decoder blocks of one sampler call are one launch: blockIdx.z picks the block's argument set
 struct mdt_xfold_table { mdt_xfold_args a[8]; };
+template <int R>
+__device__ __forceinline__ float quad_bcast(float v) { return dpp_keep<R * 0x55, 0xf>(v); }  // lane R of every lane quad
 template <int TE, int SB>
 __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
     const mdt_xfold_args& a = tab.a[blockIdx.z];
-    const int n = threadIdx.x;            // output feature handled by this thread
+    const int n = threadIdx.x;            // output feature handled by this thread (blockDim = D rounded up to 64)
     const int h = blockIdx.y;
     const int bg = blockIdx.x * SB;       // first sample of the group
-    const int HD = a.hd, D = a.D, P = a.H * TE;
+    const int HD = a.hd, D = a.D, NPP = 4 * a.H, K16 = D >> 4, KP16 = NPP >> 4;
     // The K / V values of the group's context rows are the same for every lane: they are read with UNIFORM addresses straight
     // from memory (scalar loads into SGPRs, one operand of each FMA) -- as LDS broadcasts (the first form) every FMA waited
     // for its own ds_read and the kernel ran at a third of the VALU rate (95 us per sampler call at B = 256).
@@ -1024,50 +1076,66 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
         for (int j = 0; j < TE; ++j)
             krow[sb][j] = a.kv + (int64_t)(min(bg + sb, a.B - 1) * TE + j) * a.ldkv + h * HD;  // K at +0, V at +D
     const float scale = 1.0f / sqrtf((float)HD);
-    if (n < D) {
-        float accU[SB][TE], accW[SB][TE];
+    const int nc = min(n, D - 1);         // threads beyond D (D % 64 != 0) compute a duplicate and store nothing
+    float accU[SB][4], accW[SB][4];
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { accU[sb][j] = 0.f; accW[sb][j] = 0.f; }
+    for (int d0 = 0; d0 < HD; d0 += 8) {  // HD is a multiple of 16: 8 rows of each weight in flight per lane
+        float wq[8], wo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wq[e] = a.Wq[(int64_t)(h * HD + d0 + e) * D + nc];   // query.weight row (out feature h*hd+d), coalesced over n
+            wo[e] = a.WoT[(int64_t)(h * HD + d0 + e) * D + nc];  // c_proj.weight^T row, coalesced over n
+        }
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb)
 #pragma unroll
-            for (int j = 0; j < TE; ++j) { accU[sb][j] = 0.f; accW[sb][j] = 0.f; }
-        for (int d0 = 0; d0 < HD; d0 += 8) {  // HD is a multiple of 16: 8 rows of each weight in flight per lane
-            float wq[8], wo[8];
+            for (int j = 0; j < TE; ++j) {
+                const float* kr = krow[sb][j] + d0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                wq[e] = a.Wq[(int64_t)(h * HD + d0 + e) * D + n];   // query.weight row (out feature h*hd+d), coalesced over n
-                wo[e] = a.WoT[(int64_t)(h * HD + d0 + e) * D + n];  // c_proj.weight^T row, coalesced over n
-            }
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb)
-#pragma unroll
-                for (int j = 0; j < TE; ++j) {
-                    const float* kr = krow[sb][j] + d0;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        accU[sb][j] = fmaf(wq[e], kr[e], accU[sb][j]);
-                        accW[sb][j] = fmaf(wo[e], kr[D + e], accW[sb][j]);
-                    }
-                }
-        }
-#pragma unroll
-        for (int sb = 0; sb < SB; ++sb) {
-            if (bg + sb < a.B) {
-#pragma unroll
-                for (int j = 0; j < TE; ++j) {
-                    const int64_t o = ((int64_t)(bg + sb) * P + h * TE + j) * D + n;
-                    a.U[o] = accU[sb][j] * scale;
-                    a.Wf[o] = accW[sb][j];
+                for (int e = 0; e < 8; ++e) {
+                    accU[sb][j] = fmaf(wq[e], kr[e], accU[sb][j]);
+                    accW[sb][j] = fmaf(wo[e], kr[D + e], accW[sb][j]);
                 }
             }
+    }
+    // ---- stores in fragment order.  Wf: this thread's 4 tokens ARE one fragment quad (elements j of lane n % 16 + 16 (h % 4)
+    //      in block (n / 16, h / 4)).  U: a quad holds 4 consecutive features of ONE token, so the 4 threads of a lane quad
+    //      transpose their (feature, token) values through DPP: thread q of the quad ends with token q ----
+    const int q = n & 3;
+    const int64_t uoff = (((int64_t)(h >> 2) * K16 + (n >> 4)) * 64 + ((h & 3) * 4 + q) + 16 * ((n & 15) >> 2)) * 4;
+    const int64_t woff = (((int64_t)(n >> 4) * KP16 + (h >> 2)) * 64 + (n & 15) + 16 * (h & 3)) * 4;
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        // element r of my fragment quad = token q's value held by thread r of the lane quad (all 16 broadcasts are executed by
+        // every lane, the token is picked afterwards: no DPP under divergent control flow)
+        f32x4 uq;
+#define MDT_QTOK(R) \
+    { \
+        const float b0 = quad_bcast<R>(accU[sb][0]), b1 = quad_bcast<R>(accU[sb][1]); \
+        const float b2 = quad_bcast<R>(accU[sb][2]), b3 = quad_bcast<R>(accU[sb][3]); \
+        uq[R] = (q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3))) * scale; \
+    }
+        MDT_QTOK(0) MDT_QTOK(1) MDT_QTOK(2) MDT_QTOK(3)
+#undef MDT_QTOK
+        if (n < D && bg + sb < a.B) {
+            float* Ub = a.U + (int64_t)(bg + sb) * NPP * D;
+            float* Wb = a.Wf + (int64_t)(bg + sb) * NPP * D;
+            *(f32x4*)(Ub + uoff) = uq;                         // token q >= TE: the accumulators were never touched: zeros
+            *(f32x4*)(Wb + woff) = (f32x4){accW[sb][0], accW[sb][1], accW[sb][2], accW[sb][3]};
         }
     }
-    if (threadIdx.x < SB * TE) {
-        const int sb = threadIdx.x / TE, j = threadIdx.x % TE;
+    if (threadIdx.x < SB * 4) {
+        const int sb = threadIdx.x >> 2, j = threadIdx.x & 3;
         if (bg + sb < a.B) {
-            const float* kr = a.kv + (int64_t)((bg + sb) * TE + j) * a.ldkv + h * HD;
             float acc = 0.f;
-            for (int d = 0; d < HD; ++d) acc = fmaf(a.bq[h * HD + d], kr[d], acc);
-            a.c[(int64_t)(bg + sb) * P + h * TE + j] = acc * scale;
+            if (j < TE) {
+                const float* kr = a.kv + (int64_t)((bg + sb) * TE + j) * a.ldkv + h * HD;
+                for (int d = 0; d < HD; ++d) acc = fmaf(a.bq[h * HD + d], kr[d], acc);
+            }
+            a.c[(int64_t)(bg + sb) * NPP + h * 4 + j] = acc * scale;
         }
     }
 }
@@ -1078,7 +1146,7 @@ hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_
     constexpr int SB = 4;
     if (n < 1) return hipErrorInvalidValue;
     const mdt_xfold_args& a = sets[0];
-    if (a.D > 512 || a.Te < 1 || a.Te > 4) return hipErrorInvalidValue;
+    if (a.D > 512 || a.D % 64 || a.Te < 1 || a.Te > 4 || (a.H != 4 && a.H != 8) || a.hd % 16) return hipErrorInvalidValue;
     for (int i = 1; i < n; ++i)
         if (sets[i].B != a.B || sets[i].H != a.H || sets[i].hd != a.hd || sets[i].D != a.D || sets[i].Te != a.Te)
             return hipErrorInvalidValue;
@@ -1102,41 +1170,30 @@ hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_
 }
 hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s) { return mdt_launch_xattn_fold_n(&a, 1, s); }
 
-// One workgroup (384 threads) per sample; body in mdt_tiles.h (xattn_tile)
-template <int NP>
-__global__ __launch_bounds__(384) void k_xattn_apply(mdt_xapply_args a, const float* __restrict__ zeros, int rows_per_wg) {
+// One workgroup (512 threads) per sample; body in mdt_tiles.h (xattn_tile)
+template <int NPP>
+__global__ __launch_bounds__(512) void k_xattn_apply(mdt_xapply_args a, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    xattn_tile<NP, false>(a, MDT_SAMPLE_REMAP(blockIdx.x, gridDim.x), lds, zeros, threadIdx.x, blockIdx.y * rows_per_wg,
-                          (blockIdx.y + 1) * rows_per_wg);
+    xattn_tile<NPP, false>(a, MDT_SAMPLE_REMAP(blockIdx.x, gridDim.x), lds, zeros, threadIdx.x);
 }
 
 // which configurations the collapsed path covers (others keep the q GEMM + attention + c_proj GEMM sequence)
 bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta) {
-    const int NP = H * Te, n4 = D / 4;
-    if (D % 32 || D > 512 || Te < 1 || Te > 4 || Ta > 16) return false;
-    if (NP != 32 && NP != 24 && NP != 16) return false;
-    if (NP * (D / 32) > 384 || n4 > 384) return false;
-    const int ntg = 384 / n4;
-    return (Ta + ntg - 1) / ntg <= 4;
+    return D >= 128 && D <= 512 && D % 128 == 0 && (H == 4 || H == 8) && Te >= 1 && Te <= 4 && Ta >= 1 && Ta <= 16;
+}
+// floats of LDS xattn_tile needs
+size_t mdt_xattn_lds_floats(int D, int H) {
+    const int npp = 4 * H, ks = 8 / (npp / 16);
+    return (size_t)16 * (D + 4) + (size_t)(ks + 1) * 16 * (npp + 4);
 }
 
 hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s) {
     if (!mdt_xattn_apply_supported(a.D, a.H, a.Te, a.Ta)) return hipErrorInvalidValue;
     hipError_t e = ensure_zeros();
     if (e != hipSuccess) return e;
-    const int NP = a.H * a.Te;
-    const size_t lds = ((size_t)a.Ta * a.D + (size_t)a.Ta * NP * (a.D / 32) + (size_t)a.Ta * NP) * sizeof(float);
-    // rollout-sized batches: a sample's rows over several workgroups (1 row each up to 4 samples, 2 up to 8): one workgroup
-    // walking all 10 rows was 9.5 us of every decoder block at B = 1 -- the largest kernel of the rollout call
-    static int split_max = -1;
-    if (split_max < 0) { const char* e = getenv("MDT_HIP_XATTN_SPLIT_MAX"); split_max = e ? atoi(e) : 8; }
-    const int rpw = a.B > split_max ? a.Ta : (a.B <= 4 ? 1 : 2);
-    const dim3 grid(a.B, (a.Ta + rpw - 1) / rpw);
-    switch (NP) {
-        case 32: hipLaunchKernelGGL((k_xattn_apply<32>), grid, dim3(384), lds, s, a, g_zeros, rpw); break;
-        case 24: hipLaunchKernelGGL((k_xattn_apply<24>), grid, dim3(384), lds, s, a, g_zeros, rpw); break;
-        default: hipLaunchKernelGGL((k_xattn_apply<16>), grid, dim3(384), lds, s, a, g_zeros, rpw); break;
-    }
+    const size_t lds = mdt_xattn_lds_floats(a.D, a.H) * sizeof(float);
+    if (a.H == 8) hipLaunchKernelGGL((k_xattn_apply<32>), dim3(a.B), dim3(512), lds, s, a, g_zeros);
+    else hipLaunchKernelGGL((k_xattn_apply<16>), dim3(a.B), dim3(512), lds, s, a, g_zeros);
     return hipGetLastError();
 }
 

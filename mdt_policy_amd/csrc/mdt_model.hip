@@ -604,7 +604,7 @@ static void carve_ws(mdt_model* m, Bump& b, int64_t B) {
     m->steps = b.take(MAX_STEPS * 4);
     m->sigs = b.take(MAX_STEPS + 1);
     if (m->xfold) {
-        const int64_t np = (int64_t)m->H * m->Te;
+        const int64_t np = (int64_t)4 * m->H;  // every head padded to 4 context tokens (fragment order, k_xattn_fold)
         m->xU = b.take((size_t)m->Ld * B * np * D);
         m->xW = b.take((size_t)m->Ld * B * np * D);
         m->xc = b.take((size_t)m->Ld * B * np);
@@ -675,8 +675,24 @@ static int g_attn_wide_min_rows() {
 }
 extern "C" void mdt_op_set_attn_wide_min(int32_t rows) { g_attn_wide_override = rows; }
 
+// row count from which (and batch up to which) one workgroup per sample runs self-attention, projection AND the collapsed
+// cross-attention (k_attn_xattn); MDT_HIP_ATTN_XATTN_MIN (0 disables); mdt_op_set_attn_wide_min(0) switches it off too
+static int g_attn_xattn_min_rows() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_XATTN_MIN"); v = e ? atoi(e) : 1401; if (v == 0) v = 1 << 30; }
+    return g_attn_wide_override == 0 ? 1 << 30 : v;
+}
+static int g_attn_xattn_max_batch() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_XATTN_MAX_B"); v = e ? atoi(e) : 512; }
+    return v;
+}
+
+// `fx` (optional): the collapsed cross-attention that follows on the same rows; when the one-sample-per-workgroup kernel takes
+// both, *fused is set and the caller skips its own launch.
 static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, bool causal,
-                                ModRef mr, hipStream_t s, Stream in = Stream()) {
+                                ModRef mr, hipStream_t s, Stream in = Stream(), const mdt_xapply_args* fx = nullptr,
+                                bool* fused = nullptr) {
     float* x = V.y;
     const int D = m->D, M = (int)(B * T);
     mdt_gemm_args g = gemm_args(x, D, e.qkv, V.qkv, 3 * D, M);
@@ -693,6 +709,12 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
     if (B <= g_attn_proj_max_batch() && mdt_attn_proj_supported(p, m->H, m->hd, T, m->cfg.use_rot_embed)) {
         // rollout batch: attention and projection in one launch (the attention output never leaves the workgroup)
         LAUNCH(mdt_launch_attn_proj(p, V.qkv, 3 * D, m->H, m->hd, T, causal, s));
+        return MDT_OK;
+    }
+    if (fx && fused && M >= g_attn_xattn_min_rows() && B <= g_attn_xattn_max_batch() &&
+        mdt_attn_xattn_supported(p, *fx, m->H, m->hd, T, causal, m->cfg.use_rot_embed)) {
+        LAUNCH(mdt_launch_attn_xattn(p, V.qkv, 3 * D, *fx, m->H, m->hd, T, s));
+        *fused = true;
         return MDT_OK;
     }
     // (up to one workgroup per CU: its 156 KB of LDS allow no second one, so beyond 256 tiles -- B > 272 -- the workgroups
@@ -839,7 +861,7 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
         LAUNCH(mdt_launch_gemm(a, s));
     }
     if (m->xfold) {  // fold K|V into the cross-attention projections, once per context (sigma independent)
-        const int64_t np = (int64_t)m->H * Te;
+        const int64_t np = (int64_t)4 * m->H;
         std::vector<mdt_xfold_args> sets(m->Ld);
         for (int l = 0; l < m->Ld; ++l) {
             mdt_xfold_args& f = sets[l];
@@ -900,18 +922,23 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
         } else if (m->cond == COND_NOISE) {
             ma = mx = ModRef(mod_row, mod_stride, 0, D, -1);  // ln(x)*1 + c, residual ungated; MLP unconditioned
         }
-        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, ma, s, cur));
-        cur = Stream();
         // cross attention: ln3 (biased LayerNorm) -> q ; K|V precomputed ; never gated
+        mdt_xapply_args x;
+        memset(&x, 0, sizeof x);
         if (m->xfold) {
-            const int64_t np = (int64_t)m->H * m->Te;
-            mdt_xapply_args x;
-            memset(&x, 0, sizeof x);
+            const int64_t np = (int64_t)4 * m->H;
             x.y = V.y; x.ln_w = d.ln3_w; x.ln_b = d.ln3_b; x.bo = d.xproj.bias;
             x.U = m->xU + ((int64_t)l * m->cap + V.b0) * np * D;
             x.Wf = m->xW + ((int64_t)l * m->cap + V.b0) * np * D;
             x.c = m->xc + ((int64_t)l * m->cap + V.b0) * np;
             x.B = (int)B; x.H = m->H; x.D = D; x.Te = m->Te; x.Ta = Ta;
+        }
+        bool xdone = false;
+        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, ma, s, cur, m->xfold ? &x : nullptr, &xdone));
+        cur = Stream();
+        if (xdone) {
+            // self-attention, projection and cross-attention went as one launch (one workgroup per sample)
+        } else if (m->xfold) {
             LAUNCH(mdt_launch_xattn_apply(x, s));
         } else {
             mdt_gemm_args q = gemm_args(V.y, D, d.xq, V.qx, D, M);
@@ -1217,8 +1244,10 @@ extern "C" mdt_status mdt_op_attention(const mdt_attn_args* a, void* stream) {
 extern "C" mdt_status mdt_op_xattn_fold(const mdt_xfold_args* a, void* stream) {
     if (!a || !a->kv || !a->Wq || !a->bq || !a->WoT || !a->U || !a->Wf || !a->c)
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_fold: null pointer");
-    if (a->H * a->hd != a->D || a->Te < 1 || a->Te > 4 || a->D > 512)
-        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_fold: need H*hd == D <= 512 and 1 <= Te <= 4");
+    if (a->H * a->hd != a->D || a->Te < 1 || a->Te > 4 || a->D > 512 || a->D % 64 || (a->H != 4 && a->H != 8) || a->hd % 16)
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_fold: need 4 or 8 heads of a multiple of 16, H*hd == D <= 512 and 1 <= Te <= 4");
+    if (misaligned(a->U) || misaligned(a->Wf) || misaligned(a->c))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_fold: U / Wf / c must be 16-byte aligned");
     LAUNCH(mdt_launch_xattn_fold(*a, (hipStream_t)stream));
     return MDT_OK;
 }
@@ -1244,6 +1273,20 @@ extern "C" mdt_status mdt_op_attn_proj(const mdt_gemm_args* proj, const float* q
         return fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_proj: needs 8 heads of 16/32/48/64 (K = 8 * hd), T <= 16 rows per sample "
                                          "(M = samples * T, at most 64 samples), a plain projection");
     LAUNCH(mdt_launch_attn_proj(*proj, qkv, ldq, 8, hd, T, causal, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_attn_xattn(const mdt_gemm_args* proj, const float* qkv, int64_t ldq, const mdt_xapply_args* x,
+                                        int32_t hd, int32_t T, void* stream) {
+    if (!proj || !qkv || !x || !proj->Wp || !proj->out || !x->ln_w || !x->U || !x->Wf || !x->c)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_xattn: null argument");
+    if (misaligned(qkv) || misaligned(proj->Wp) || misaligned(proj->out) || misaligned(x->U) || misaligned(x->Wf) || (ldq & 3))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_xattn: pointers must be 16-byte aligned, ldq a multiple of 4");
+    if (!mdt_attn_xattn_supported(*proj, *x, 8, hd, T, 1, 0) || ldq != 3 * (int64_t)proj->K)
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_xattn: needs 8 heads of 48 (K = N = ldo = 384, ldq = 3 K), a gated / residual projection "
+                                         "on M = x->B * T rows, T = x->Ta <= 16, x->y == proj->out and a (D, H, Te, Ta) "
+                                         "mdt_op_xattn_apply supports");
+    LAUNCH(mdt_launch_attn_xattn(*proj, qkv, ldq, *x, 8, hd, T, (hipStream_t)stream));
     return MDT_OK;
 }
 

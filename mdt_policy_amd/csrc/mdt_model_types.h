@@ -108,7 +108,7 @@ struct mdt_model {
     int ways = 1;
     // collapsed cross-attention (k_xattn_fold / k_xattn_apply): folded projections per sample and decoder block
     bool xfold = false;
-    float *xU = nullptr, *xW = nullptr, *xc = nullptr;  // [Ld][cap][H*Te][D], same, [Ld][cap][H*Te]
+    float *xU = nullptr, *xW = nullptr, *xc = nullptr;  // [Ld][cap][4 H * D] weight images (fragment order), same, [Ld][cap][4 H]
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     void* persist = nullptr;  // mdt_persist_state (mdt_persist.hip): the persistent decoder kernel's buffers
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};

@@ -267,7 +267,7 @@ __device__ PH_INLINE void ph_prefetch(PHASE_ARGS, int nbusy_) {
 
 #define PHASE_CALL P, zeros, r0, nrows, s0, ns, slot, npx, lds_off
 
-template <int MODE, int HD, int TKC, int NP>  // MODE 0 = WIDE, 1 = SMALL; head dim, key bound (10 / 16), H * Te
+template <int MODE, int HD, int TKC, int NP>  // MODE 0 = WIDE, 1 = SMALL; head dim, key bound (10 / 16), 4 H
 __global__ __launch_bounds__(512) void k_decoder_persist(const mdt_pphase* __restrict__ prog, int nphases, mdt_pctl* ctl, int S,
                                                         int B, int Ta, const float* __restrict__ zeros, unsigned* err_host,
                                                         unsigned long long* dbg) {
@@ -362,8 +362,8 @@ struct PersistVariant { int mode, hd, tkc, np; persist_kernel_t fn; };
 // Te = 3) and the two d = 128 test-size models; Ta <= 10.  Anything else keeps the launch sequence.
 #define PV(MODE, HD, TKC, NP) {MODE, HD, TKC, NP, k_decoder_persist<MODE, HD, TKC, NP>}
 static const PersistVariant g_variants[] = {
-    PV(0, 48, 10, 32), PV(1, 48, 10, 32), PV(0, 64, 10, 24), PV(1, 64, 10, 24),
-    PV(0, 16, 10, 32), PV(1, 16, 10, 32), PV(0, 16, 10, 24), PV(1, 16, 10, 24),
+    PV(0, 48, 10, 32), PV(1, 48, 10, 32), PV(0, 64, 10, 32), PV(1, 64, 10, 32),
+    PV(0, 16, 10, 32), PV(1, 16, 10, 32),
 };
 static persist_kernel_t find_variant(int mode, int hd, int Ta, int np) {
     const int tkc = Ta <= 10 ? 10 : 16;
@@ -445,7 +445,7 @@ static mdt_status persist_init(mdt_model* m) {
     // one workgroup per CU, the same number on each of the 8 XCDs, at most 32 per XCD (counter spacing)
     if (p->n_cu % 8 != 0 || p->n_cu / 8 > 32 || p->n_cu / 8 < 8) return MDT_OK;  // usable stays false
     for (int mode = 0; mode < 2; ++mode) {
-        persist_kernel_t fn = find_variant(mode, m->hd, m->Ta, m->H * m->Te);
+        persist_kernel_t fn = find_variant(mode, m->hd, m->Ta, 4 * m->H);
         if (!fn) return MDT_OK;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PERSIST_LDS_BYTES));
         int nb = 0;
@@ -470,9 +470,7 @@ bool mdt_persist_supported(mdt_model* m, int64_t B) {
     if (m->H % 2) return false;
     if (m->hd != 16 && m->hd != 32 && m->hd != 48 && m->hd != 64) return false;
     if (m->D > 512 || m->D % 32 || m->Ta > 16 || m->A > 8) return false;
-    if (!find_variant(0, m->hd, m->Ta, m->H * m->Te)) return false;
-    const int np = m->H * m->Te;
-    if (np != 32 && np != 24 && np != 16) return false;
+    if (m->H != 8 || !find_variant(0, m->hd, m->Ta, 4 * m->H)) return false;  // the collapsed cross-attention's image: 4 H rows
     if (!mdt_xattn_apply_supported(m->D, m->H, m->Te, m->Ta)) return false;
     const bool small = B <= persist_small_max(), wide = B >= persist_wide_min();
     if (!small && !wide) return false;
@@ -481,7 +479,7 @@ bool mdt_persist_supported(mdt_model* m, int64_t B) {
     const int64_t attn_half = (int64_t)3 * m->Ta * (m->H / 2) * m->hd + (int64_t)(m->H / 2) * m->Ta * 16 * lp;
     if (attn_half > LDS_BODY_FLOATS / 2) return false;
     if ((int64_t)8 * (3 * 16 * (m->hd + 4) + 16 * 17) > LDS_BODY_FLOATS) return false;
-    if ((int64_t)m->Ta * m->D + (int64_t)m->Ta * np * (m->D / 32) + (int64_t)m->Ta * np > LDS_BODY_FLOATS) return false;
+    if ((int64_t)mdt_xattn_lds_floats(m->D, m->H) > LDS_BODY_FLOATS) return false;
     if ((int64_t)32 * (m->D + 4) > LDS_BODY_FLOATS) return false;
     // buffer-resource offsets are 32-bit byte offsets
     if ((int64_t)B * m->Ta * 4 * m->D * 4 >= ((int64_t)1 << 32)) return false;
@@ -499,7 +497,7 @@ static void set_pf(mdt_pphase& ph, int i, const float* p, int64_t floats, int64_
 static void build_program(mdt_model* m, int64_t B, int n_steps, const float* x_T, float* out, bool small,
                           std::vector<mdt_pphase>& prog) {
     const int D = m->D, Ta = m->Ta, M = (int)(B * Ta);
-    const int64_t np = (int64_t)m->H * m->Te;
+    const int64_t np = (int64_t)4 * m->H;  // rows of the folded cross-attention images (heads padded to 4 context tokens)
     prog.clear();
     auto lin_floats = [](const Lin& l) { return (int64_t)l.N * l.K; };
     for (int i = 0; i < n_steps; ++i) {

@@ -433,6 +433,87 @@ __device__ __forceinline__ void attn_stage_tile(const mdt_gemm_args& a, const md
 }
 
 // ------------------------------------------------------------------------------------------------
+// ONE sample's causal self-attention (8 heads of HD, T <= TKC <= 16 rows) -> xa (rows >= T zero): the attention stage of
+// attn_xattn_tile.  q | k | v of a row are adjacent (ldq == 3 D), so the sample's rows are ONE contiguous block of T * 3 D
+// floats: thread t requests float4 items t, t + 512, ... of it and puts them at the same (row, column) in LDS -- no division,
+// no 64-bit arithmetic per request (the general stage above spends ~1100 integer instructions per thread on its 9 + 28
+// addresses: 9.5 k cycles from entry until the rows are in LDS even on an idle chip, all VALU issue).  Row stride 3 D + 16 =
+// 16 (mod 64) floats: same bank behaviour as above.  Thread = (head, row, quarter of the head dimension).  512 threads.
+//   scratch: 16 * (3 D + 16) floats.  `after_loads`: see attn_stage_tile.
+// ------------------------------------------------------------------------------------------------
+template <int HD, int TKC, class F>
+__device__ __forceinline__ void attn_sample_tile(const mdt_attn_pro& ap, float* xa, int stride, int m0, float* scratch, int tid,
+                                                 F after_loads) {
+    constexpr int D = 8 * HD, R4 = 3 * D / 4, ST3 = 3 * D + 16, DS = HD / 4;
+    constexpr int NL = (TKC * R4 + 511) / 512;          // 6 float4 per thread for 10 rows of d = 384, 9 for 16
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int T = ap.T, total = T * R4;
+    const f32x4* src = (const f32x4*)(ap.qkv + (int64_t)m0 * (3 * D));
+    f32x4 t[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) t[u] = src[min(tid + 512 * u, total - 1)];
+    after_loads();
+    const int lp = tid & 3, pr = tid >> 2, r = pr & 15, hl = pr >> 4;   // 128 pairs = 8 heads x 16 rows
+    const bool valid = r < T;
+    const int tq = min(r, T - 1);                        // keys 0 .. tq
+    const int d0 = hl * HD + lp * DS;
+    {
+        int rr = tid / R4, c = tid - rr * R4;            // item tid + 512 u sits at (row rr, float4 column c)
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            if (tid + 512 * u < total) *(f32x4*)(scratch + rr * ST3 + 4 * c) = t[u];
+            c += 512 % R4; rr += 512 / R4;
+            if (c >= R4) { c -= R4; ++rr; }
+        }
+    }
+    __syncthreads();
+#ifdef MDT_TS_ROWS_LANDED
+    MDT_TS(7)
+#endif
+    float q[DS];
+#pragma unroll
+    for (int d = 0; d < DS; d += 4) {
+        const f32x4 x = *(const f32x4*)(scratch + r * ST3 + d0 + d);
+        q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+    }
+    float sc[TKC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) {
+        const float* kp = scratch + min(j, tq) * ST3 + D + d0;   // clamped: masked keys re-read a visible one
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < DS; d += 4) {
+            const f32x4 x = *(const f32x4*)(kp + d);
+            dot = fmaf(q[d], x.x, dot); dot = fmaf(q[d + 1], x.y, dot); dot = fmaf(q[d + 2], x.z, dot); dot = fmaf(q[d + 3], x.w, dot);
+        }
+        dot = quad_sum(dot);                             // the four quarters of the head dimension
+        sc[j] = j <= tq ? dot * ap.scale : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }   // key 0 is always visible: mx is finite
+    const float inv = 1.0f / sum;
+    float o[DS];
+#pragma unroll
+    for (int d = 0; d < DS; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TKC; ++j) {
+        const float pj = sc[j] * inv;
+        const float* vp = scratch + min(j, tq) * ST3 + 2 * D + d0;
+#pragma unroll
+        for (int d = 0; d < DS; d += 4) {
+            const f32x4 x = *(const f32x4*)(vp + d);
+            o[d] = fmaf(pj, x.x, o[d]); o[d + 1] = fmaf(pj, x.y, o[d + 1]); o[d + 2] = fmaf(pj, x.z, o[d + 2]); o[d + 3] = fmaf(pj, x.w, o[d + 3]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DS; d += 4)
+        *(f32x4*)(xa + r * stride + d0 + d) = valid ? (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]} : zero4;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused GEMM tile:  out = epilogue( prologue(A) @ W^T ) for row tile `by` and column tile `bx`
 //   64 * NWAVES threads; tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns); full K.
 //   wave w owns NTW column tiles and ALL row tiles of the workgroup tile.
@@ -1284,37 +1365,100 @@ __device__ __forceinline__ void head_rows(const mdt_head_args& a, int base, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// collapsed cross-attention of sample b (see k_xattn_fold / k_xattn_apply in mdt_kernels.hip).  Threads 0..383 work
-// (wider workgroups idle their other threads but must call: the body holds workgroup barriers).  Work split:
-//   dots : thread = (pair p = (h, j), segment of 32 features): P * D/32 <= 384 items, U segment in 8 VGPR quads
-//   comb : thread = (float4 column c4, row group tg): D/4 * ntg <= 384 items, all P Wf quads of the column in VGPRs
-// Every global operand (U, Wf, y rows, LayerNorm vectors) is requested before the first dependent instruction.
-// lds: Ta*D + Ta*NP*(D/32) + Ta*NP floats.
+// collapsed cross-attention of sample b (see k_xattn_fold / k_xattn_apply in mdt_kernels.hip) on the MFMA pipe.  512 threads.
+//   ln3 of the sample's Ta <= 16 rows -> LDS (one 16-row activation tile, rows >= Ta zero)
+//   scores  S[t][p] = xn[t] . U[p]          : U (NPP x D, NPP = 4 H: head h's Te <= 4 context tokens at p = 4 h + j) is a
+//             WEIGHT image in fragment order (k_xattn_fold writes it so): wave w takes score tile w % (NPP/16) and the
+//             k-slice w / (NPP/16) of D; the slices' partial tiles meet in LDS and are added in slice order
+//   softmax per (row, head) over the keys j <= min(t, Te - 1) (top-left causal), probabilities of absent keys 0
+//   out[t][n] = sum_p P[t][p] Wf[p][n]      : Wf^T (D x NPP) in fragment order too; wave w owns columns [w D/8, (w+1) D/8)
+//   y[t] += out[t] + bo
+// Every global operand -- 6 + 6 weight fragments per lane at d = 384, the rows, the LayerNorm vectors -- is requested at
+// entry.  (The first form walked the rows with scalar FMAs from 40 VGPR quads of operands per thread: 12.1 us per launch at
+// B = 256 and 7.2 us at B = 1 with the rows spread over ten workgroups.)
+//   lds: 16 (D + 4) + (8 / (NPP/16) + 1) * 16 * (NPP + 4) floats.  D % 128 == 0, D <= 512.
+// YL: the sample's rows are read from LDS (`yl`, row stride `yls` floats: attn_xattn_tile leaves the projection's output
+// there); the new rows still go to a.y.
 // ------------------------------------------------------------------------------------------------
-// [t_lo, t_hi): the rows of the sample this workgroup owns (every row is independent of the others: rollout-sized batches
-// split a sample over several workgroups, each fetching U / Wf again -- L2 hits -- but walking 1-2 rows instead of 10)
-template <int NP, bool COH>
+// the sample's operands that do not depend on its rows, in two groups: the fragments of its folded matrices (cold: 98 KB
+// that another workgroup used one step ago) and the shared vectors.  attn_xattn_tile requests the first group at ITS entry, a
+// whole attention + projection ahead of their use, and the second before the projection's epilogue; xattn_tile consumes them.
+// DMAX: compile-time bound of D (sizes the register arrays).
+template <int NPP, int DMAX = 512>
+struct mdt_xattn_req {
+    static constexpr int NTU = NPP / 16, KS = 8 / NTU, KP16 = NPP / 16, KLMAX = DMAX / 16 / KS, NTWMAX = DMAX / 128;
+    f32x4 u[KLMAX];                // score fragments: tile wave % NTU, k-blocks of slice wave / NTU
+    f32x4 wf[NTWMAX][KP16];        // combination fragments: column tiles wave * NTW .. + NTW - 1
+    f32x4 cb;                      // score constants of the softmax thread's head
+    f32x4 lw[2], lb[2];            // ln3 weight / bias at the lane's two float4 columns
+    f32x4 bo[NTWMAX];              // output bias at the lane's output columns
+};
+// DX: 0 = D is a.D (run time); otherwise D == DX == DMAX is known at compile time (attn_xattn_tile: all offsets fold)
+template <int NPP, int DMAX, int DX = 0>
+__device__ __forceinline__ void xattn_request_u(const mdt_xapply_args& a, int b, int tid, mdt_xattn_req<NPP, DMAX>& q) {
+    constexpr int NTU = NPP / 16, KS = 8 / NTU, KLMAX = DMAX / 16 / KS;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int D = DX ? DX : a.D, K16 = D >> 4, KL = K16 / KS;
+    const float* Ub = a.U + (int64_t)b * NPP * D;
+    const int ntu = wave % NTU, ks = wave / NTU;
+#pragma unroll
+    for (int kk = 0; kk < KLMAX; ++kk)
+        q.u[kk] = MDT_LD_STREAM(Ub + ((int64_t)(ntu * K16 + min(ks * KL + kk, K16 - 1)) * 64 + lane) * 4);
+    q.cb = ldg4(a.c + (int64_t)b * NPP + 4 * min(tid >> 4, NPP / 4 - 1));   // softmax thread (t, h) = (tid % 16, tid / 16)
+}
+template <int NPP, int DMAX, int DX = 0>
+__device__ __forceinline__ void xattn_request_wf(const mdt_xapply_args& a, int b, int tid, mdt_xattn_req<NPP, DMAX>& q) {
+    constexpr int KP16 = NPP / 16, NTWMAX = DMAX / 128;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int D = DX ? DX : a.D, N16 = D >> 4, NTW = D >> 7;
+    const float* Wb = a.Wf + (int64_t)b * NPP * D;
+#pragma unroll
+    for (int j = 0; j < NTWMAX; ++j)
+#pragma unroll
+        for (int kc = 0; kc < KP16; ++kc)
+            q.wf[j][kc] = MDT_LD_STREAM(Wb + ((int64_t)(min(wave * NTW + min(j, NTW - 1), N16 - 1) * KP16 + kc) * 64 + lane) * 4);
+}
+template <int NPP, int DMAX, int DX = 0>
+__device__ __forceinline__ void xattn_request_vec(const mdt_xapply_args& a, const float* __restrict__ zeros, int tid,
+                                                  mdt_xattn_req<NPP, DMAX>& q) {
+    constexpr int NTWMAX = DMAX / 128;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int D = DX ? DX : a.D, n4 = D >> 2, NTW = D >> 7;
+    const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = 4 * min(lane + 64 * p, n4 - 1);
+        q.lw[p] = ldg4(a.ln_w + c);
+        q.lb[p] = ldg4(lnb + c);
+    }
+    const float* bop = a.bo != nullptr ? a.bo : zeros;
+#pragma unroll
+    for (int j = 0; j < NTWMAX; ++j) q.bo[j] = ldg4(bop + (wave * NTW + min(j, NTW - 1)) * 16 + 4 * (lane >> 4));
+}
+
+template <int NPP, bool COH, bool YL = false, int DMAX = 512, int DX = 0>
 __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, float* lds, const float* __restrict__ zeros, int tid,
-                                           int t_lo = 0, int t_hi = 1 << 30) {
-    constexpr int NT = 384, RMAX = 4;
-    MDT_TS(0)
-    MDT_TS_HWID()
+                                           const float* yl = nullptr, int yls = 0, const mdt_xattn_req<NPP, DMAX>* pre = nullptr) {
+    constexpr int NTU = NPP / 16, KS = 8 / NTU, KP16 = NPP / 16, PS = NPP + 4;
+    constexpr int KLMAX = DMAX / 16 / KS, NTWMAX = DMAX / 128;   // D <= DMAX
+    if constexpr (!YL) {
+        MDT_TS(0)
+        MDT_TS_HWID()
+    }
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
-    const int D = a.D, Ta = a.Ta, Te = a.Te;
-    const int n4 = D >> 2, NS = D >> 5;                  // float4 per row, 32-feature segments per row
-    float* xn = lds;                                     // [Ta][D] normalised rows
-    float* part = xn + Ta * D;                           // [Ta][NP][NS] partial dots
-    float* prob = part + Ta * NP * NS;                   // [Ta][NP] probabilities
-    const float* Ub = a.U + (int64_t)b * NP * D;
-    const float* Wb = a.Wf + (int64_t)b * NP * D;
+    const int D = DX ? DX : a.D, Ta = a.Ta, Te = a.Te;
+    const int n4 = D >> 2, K16 = D >> 4;
+    const int KL = K16 / KS, NTW = D >> 7;
+    const int xs = D + 4;
+    float* xn = lds;                                     // [16][xs] normalised rows
+    float* part = xn + 16 * xs;                          // [KS][16][PS] partial score tiles
+    float* prob = part + KS * 16 * PS;                   // [16][PS] probabilities
     const ActLd<COH> LY(a.y);
     const int64_t yoff = (int64_t)b * Ta * D;
-    float* yb = a.y + yoff;
 
-    // Loads are requested in the order they are consumed (vmcnt retires in order): the sample's rows and the ln3
-    // vectors first, then the U segment, then the Wf column and the old rows for the residual.
-    // ---- LayerNorm (ln3: weight + bias) of the sample's rows: wave w < 6 takes rows w, w+6, ... ----
+    // ---- requests, in the order they are consumed (vmcnt retires in order) ----
+    // LayerNorm: wave w takes rows w and w + 8
     int cc[2];
     bool cv[2];
 #pragma unroll
@@ -1322,119 +1466,225 @@ __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, floa
         cv[p] = lane + 64 * p < n4;
         cc[p] = 4 * min(lane + 64 * p, n4 - 1);
     }
-    constexpr int RW = 3;  // rows per wave (Ta <= 16 < 6 * 3)
-    const int lw6 = min(wave, 5);
-    f32x4 v[RW][2], lw[2], lb[2];
+    f32x4 v[2][2];
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) v[r][p] = LY.ld4(yoff + (int64_t)min(lw6 + 6 * r, Ta - 1) * D + cc[p]);
-    const float* lnb = a.ln_b != nullptr ? a.ln_b : zeros;
+        for (int p = 0; p < 2; ++p) {
+            const int row = min(wave + 8 * r, Ta - 1);
+            if constexpr (YL) v[r][p] = *(const f32x4*)(yl + row * yls + cc[p]);
+            else v[r][p] = LY.ld4(yoff + (int64_t)row * D + cc[p]);
+        }
+    // LayerNorm vectors, this wave's score fragments (tile ntu, k-blocks [ks KL, ks KL + KL)) and combination fragments
+    // (column tiles wave * NTW .. + NTW - 1, both k-blocks of the NPP probabilities), bias, score constants
+    mdt_xattn_req<NPP, DMAX> q;
+    if constexpr (YL) q = *pre;
+    else {
+        xattn_request_vec<NPP, DMAX, DX>(a, zeros, tid, q);
+        xattn_request_u<NPP, DMAX, DX>(a, b, tid, q);
+        xattn_request_wf<NPP, DMAX, DX>(a, b, tid, q);
+    }
+    const int ntu = wave % NTU, ks = wave / NTU;
+    // old rows at this lane's output position: row lane % 16, columns tile * 16 + 4 (lane / 16) .. + 3
+    const int orow = min(lane & 15, Ta - 1), nq = 4 * (lane >> 4);
+    f32x4 yold[NTWMAX];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) { lw[p] = ldg4(a.ln_w + cc[p]); lb[p] = ldg4(lnb + cc[p]); }
-    // ---- dots operand: 8 float4 of U[p], INTERLEAVED over the row (float4 index dsg + NS*i): consecutive lanes read
-    //      consecutive 16-byte pieces both from global memory and, for the normalised rows, from LDS ----
-    const int dp = min(tid / NS, NP - 1), dsg = tid % NS;
-    const bool dlive = tid < NP * NS;
-    f32x4 u[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = MDT_LD_STREAM(Ub + (int64_t)dp * D + 4 * (dsg + NS * i));
-    // ---- comb operands: Wf[p][c4] for all p, old y rows of the thread's row group ----
-    const int ntg = NT / n4;                             // row groups (4 for d = 384, 3 for d = 512)
-    const int rpt = (Ta + ntg - 1) / ntg;                // rows per group (<= RMAX, checked by the launcher)
-    const int c4 = tid % n4, tg = tid / n4;
-    const bool clive = tg < ntg;
-    f32x4 wf[NP], yold[RMAX];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) wf[p] = MDT_LD_STREAM(Wb + (int64_t)p * D + 4 * c4);
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) yold[r] = LY.ld4(yoff + (int64_t)min(tg * rpt + r, Ta - 1) * D + 4 * c4);
-    const f32x4 bo = ldg4((a.bo != nullptr ? a.bo : zeros) + 4 * c4);
+    for (int j = 0; j < NTWMAX; ++j) {
+        const int nc = (wave * NTW + min(j, NTW - 1)) * 16 + nq;
+        if constexpr (YL) yold[j] = *(const f32x4*)(yl + orow * yls + nc);
+        else yold[j] = LY.ld4(yoff + (int64_t)orow * D + nc);
+    }
+
+    // ---- LayerNorm (ln3: weight + bias) -> xn; rows >= Ta of the tile are zero ----
     const float inv_d = 1.0f / (float)D;
-    float red[RW];
+    float red[2];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
+    for (int r = 0; r < 2; ++r) {
         red[r] = 0.f;
 #pragma unroll
         for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p], zero4); red[r] += hsum4(v[r][p]); }
     }
-    wave_sum_n<RW>(red);
+    wave_sum_n<2>(red);
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
+    for (int r = 0; r < 2; ++r) {
         const float mean = red[r] * inv_d;
         red[r] = 0.f;
 #pragma unroll
         for (int p = 0; p < 2; ++p) { v[r][p] = sel4(cv[p], v[r][p] - mean, zero4); red[r] += hsq4(v[r][p]); }
     }
-    wave_sum_n<RW>(red);
+    wave_sum_n<2>(red);
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int t = wave + 6 * r;
+    for (int r = 0; r < 2; ++r) {
+        const int t = wave + 8 * r;
         const float rstd = 1.0f / sqrtf(red[r] * inv_d + 1e-5f);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            if (cv[p] && t < Ta && wave < 6 && t >= t_lo && t < t_hi) *(f32x4*)(xn + t * D + cc[p]) = v[r][p] * rstd * lw[p] + lb[p];
+            if (cv[p]) *(f32x4*)(xn + t * xs + cc[p]) = t < Ta ? v[r][p] * rstd * q.lw[p] + q.lb[p] : zero4;
     }
+    if constexpr (YL) { MDT_TS(5) } else { MDT_TS(1) }
+    __syncthreads();
+    if constexpr (!YL) { MDT_TS(2) }
+    // ---- partial scores of this wave's k-slice: lane ends with S[t = lane % 16][p = ntu * 16 + 4 (lane / 16) .. + 3] ----
+    {
+        const float* xp = xn + (lane & 15) * xs + 4 * (lane >> 4) + ks * KL * 16;
+        f32x4 acc = zero4;
+#pragma unroll
+        for (int kk = 0; kk < KLMAX; ++kk)
+            if (kk < KL) {
+                const f32x4 av = *(const f32x4*)(xp + kk * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.u[kk][e], av[e], acc, 0, 0, 0);
+            }
+        *(f32x4*)(part + (ks * 16 + (lane & 15)) * PS + ntu * 16 + 4 * (lane >> 4)) = acc;
+    }
+    if constexpr (!YL) { MDT_TS(3) }
+    __syncthreads();
+    // ---- masked softmax per (row, head): key j visible iff j <= t (top-left causal) and j < Te ----
+    if (tid < 4 * NPP) {
+        const int t = tid & 15, h = tid >> 4;
+        f32x4 sc = q.cb;
+#pragma unroll
+        for (int sl = 0; sl < KS; ++sl) sc += *(const f32x4*)(part + (sl * 16 + t) * PS + 4 * h);   // fixed order
+        const int nk = min(Te, t + 1);
+        float mx = sc.x;
+        if (nk > 1) mx = fmaxf(mx, sc.y);
+        if (nk > 2) mx = fmaxf(mx, sc.z);
+        if (nk > 3) mx = fmaxf(mx, sc.w);
+        f32x4 e;
+        e.x = expf(sc.x - mx);
+        e.y = nk > 1 ? expf(sc.y - mx) : 0.f;
+        e.z = nk > 2 ? expf(sc.z - mx) : 0.f;
+        e.w = nk > 3 ? expf(sc.w - mx) : 0.f;
+        const float inv = 1.0f / ((e.x + e.y) + (e.z + e.w));
+        *(f32x4*)(prob + t * PS + 4 * h) = t < Ta ? e * inv : zero4;
+    }
+    __syncthreads();
+    // ---- combination + residual: y[t][n .. n + 3] = old + bo + sum_p P[t][p] Wf[p][n ..] ----
+    {
+        const float* pp = prob + (lane & 15) * PS + 4 * (lane >> 4);
+        f32x4 pv[KP16];
+#pragma unroll
+        for (int kc = 0; kc < KP16; ++kc) pv[kc] = *(const f32x4*)(pp + kc * 16);
+        float* yb = a.y + yoff + (int64_t)(lane & 15) * D;
+#pragma unroll
+        for (int j = 0; j < NTWMAX; ++j)
+            if (j < NTW) {
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int kc = 0; kc < KP16; ++kc)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wf[j][kc][e], pv[kc][e], acc, 0, 0, 0);
+                if ((lane & 15) < Ta) *(f32x4*)(yb + (wave * NTW + j) * 16 + nq) = yold[j] + (q.bo[j] + acc);
+            }
+    }
+    if constexpr (YL) { MDT_TS(6) } else { MDT_TS(4) }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attn_xattn_tile: ONE SAMPLE per workgroup through the middle of a decoder block (k_attn_xattn; batches that give every CU
+// one sample): causal self-attention of the sample's T rows (attn_stage_tile, all 8 heads in one pass, no halo) -> output
+// projection on the MFMA pipe (one 16-row tile, wave w owns columns [w D/8, (w+1) D/8)) + gate + residual -> the rows stay in
+// LDS -> ln3 and the collapsed cross-attention on them (xattn_tile<.., YL>) -> the residual stream is written ONCE.
+// Replaces k_attn_proj_wide + k_xattn_apply: one launch, no round trip of the rows between them, and the sample's folded
+// operands (98 KB, cold: another workgroup used them one step ago) travel while the projection and its epilogue run.
+//   a = the projection's arguments (A unused: the activation tile is computed here), at = q | k | v rows, x = the cross-
+//   attention's arguments (x.y == a.out).  512 threads; D = 8 * HD.
+//   the q | k | v rows of the sample are one contiguous block (at.ldq == 3 D).
+//   lds: 16 * (D + 4) + 48 * (D + 16) floats (the attention's rows; afterwards the projected rows + xattn_tile's scratch).
+// ------------------------------------------------------------------------------------------------
+template <int HD, int TKC, int NPP>
+__device__ __forceinline__ void attn_xattn_tile(const mdt_gemm_args& a, const mdt_attn_pro& at, const mdt_xapply_args& x, int b,
+                                                float* lds, const float* __restrict__ zeros, int tid) {
+    constexpr int MTILES = 1, NTW = HD / 16, D = 8 * HD, K16 = D / 16;
+    constexpr bool KSTEP_PRIO = false;
+    constexpr int R = NTW == 1 ? 6 : (NTW == 2 ? 4 : 3);   // deeper rings change nothing here (measured: R = 4, 6)
+    MDT_TS(0)
+    MDT_TS_HWID()
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, wave = tid >> 6;
+    const int T = at.T, m0 = b * T;
+    constexpr int stride = D + 4;
+    float* xa = lds;                       // [16][stride]: the attention output = the projection's activation tile
+    float* scr = xa + 16 * stride;         // 16 x (3 D + 16): q | k | v rows; then yl [16][stride] and xattn_tile's scratch
+    float* yl = scr;
+    float* xscr = scr + 16 * stride;
+
+    const int nt0 = wave * NTW;
+    const float* wp[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wp[j] = a.Wp + (int64_t)(nt0 + j) * K16 * 256 + lane * 4;
+    f32x4 ring[R][NTW];
+    f32x4 acc[MTILES][NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[0][j] = zero4;
+    const int nq = 4 * (lane >> 4);
+    const bool gated = a.gate_off >= 0;
+    int ncol[NTW];
+    f32x4 bias_v[NTW], gate_v[NTW], res_v[NTW];
+    mdt_xattn_req<NPP, D> xq;
+
+    // ---- the sample's causal self-attention -> xa (rows >= T zero).  Behind its q / k / v requests: the projection's first
+    //      weight fragments and its epilogue operands ----
+    attn_sample_tile<HD, TKC>(at, xa, stride, m0, scr, tid, [&]() {
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
+        const float* biasp = a.bias != nullptr ? a.bias : zeros;
+        const int m = min(m0 + min(lane & 15, T - 1), a.M - 1);
+        const float* gp = zeros;
+        if (gated) gp = a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            ncol[j] = (nt0 + j) * 16 + nq;
+            bias_v[j] = ldg4(biasp + ncol[j]);
+            gate_v[j] = ldg4(gp + ncol[j]);
+            res_v[j] = ldg4(a.out + (int64_t)m * a.ldo + ncol[j]);
+        }
+    });
     MDT_TS(1)
     __syncthreads();
     MDT_TS(2)
-    // ---- partial dots: part[t][p][seg] = xn[t][seg*32..] . U[p][seg*32..] ----
-    if (dlive) {
-        for (int t = max(t_lo, 0); t < min(Ta, t_hi); ++t) {
-            const float* xr = xn + t * D + 4 * dsg;
-            float acc = 0.f;
+    // The cross-attention's fragments of the sample's folded operands are cold (98 KB per sample that another workgroup used
+    // one step ago: 25 MB per launch).  Requested at entry they held the q / k / v rows back (rows in LDS after 13.7 k cycles
+    // instead of 7.6 k: the whole chip asks for 41 MB at once); requested here, the score half travels under the projection
+    // (vmcnt retires in order: the k loop's first fragment waits ~1 k cycles behind it) ...
+    xattn_request_u<NPP, D, D>(x, b, tid, xq);
+
+    // ---- projection: 16 x D x D, transposed-form MFMA k-steps on the ring ----
+    {
+        int kg = 0;
+        const int nk = K16;
+        const float* ap = xa + (lane & 15) * stride + 4 * (lane >> 4);
+        f32x4 av[MTILES];
+        av[0] = *(const f32x4*)ap;
+        int kc = 0;
+        for (; kc + R <= nk; kc += R) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4 x = *(const f32x4*)(xr + 4 * NS * i);
-                acc = fmaf(x.x, u[i].x, acc); acc = fmaf(x.y, u[i].y, acc);
-                acc = fmaf(x.z, u[i].z, acc); acc = fmaf(x.w, u[i].w, acc);
-            }
-            part[(t * NP + dp) * NS + dsg] = acc;
+            for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
         }
+        if (kc < nk) {
+            const int rem = nk - kc;
+#pragma unroll
+            for (int u = 0; u < R - 1; ++u)
+                if (u < rem) MDT_KSTEP(u, kc + u)
+        }
+        (void)kg;
     }
     MDT_TS(3)
-    __syncthreads();
-    // ---- masked softmax per (row, head) over the Te context tokens: key j visible iff j <= t (top-left causal) ----
-    if (tid < Ta * a.H && tid / a.H >= t_lo && tid / a.H < t_hi) {
-        const int t = tid / a.H, h = tid % a.H;
-        const int nk = min(Te, t + 1);
-        float sc[4];
-        float mx = -INFINITY;
+    // ... and the combination half + the ln3 / bias vectors behind the k loop's last weight fragment: nothing queues behind
+    // them, and they have the epilogue, ln3, the scores and the softmax to arrive
+    xattn_request_wf<NPP, D, D>(x, b, tid, xq);
+    xattn_request_vec<NPP, D, D>(x, zeros, tid, xq);
+    // ---- epilogue: out = old + gate * (acc + bias) -> LDS rows (lane holds row lane % 16, columns ncol .. ncol + 3) ----
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sc[j] = -INFINITY;
-            if (j < nk) {
-                const int p = h * Te + j;
-                float acc = a.c[(int64_t)b * NP + p];
-                for (int sgi = 0; sgi < NS; ++sgi) acc += part[(t * NP + p) * NS + sgi];  // fixed order
-                sc[j] = acc;
-                mx = fmaxf(mx, acc);
-            }
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sc[j] = j < nk ? expf(sc[j] - mx) : 0.f; sum += sc[j]; }
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < Te) prob[t * NP + h * Te + j] = sc[j] * inv;
+    for (int j = 0; j < NTW; ++j) {
+        f32x4 v = acc[0][j] + bias_v[j];
+        v = res_v[j] + (gated ? gate_v[j] * v : v);
+        *(f32x4*)(yl + (lane & 15) * stride + ncol[j]) = v;
     }
     __syncthreads();
-    // ---- combine + residual: y[t][c4] += bo + sum_p prob[t][p] * Wf[p][c4] ----
-    if (clive) {
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int t = tg * rpt + r;
-            if (r < rpt && t < Ta && t >= t_lo && t < t_hi) {
-                f32x4 acc = bo;
-#pragma unroll
-                for (int p = 0; p < NP; p += 4) {
-                    const f32x4 pr = *(const f32x4*)(prob + t * NP + p);  // broadcast read of 4 probabilities
-                    acc += pr.x * wf[p] + pr.y * wf[p + 1] + pr.z * wf[p + 2] + pr.w * wf[p + 3];
-                }
-                *(f32x4*)(yb + (int64_t)t * D + 4 * c4) = yold[r] + acc;
-            }
-        }
-    }
     MDT_TS(4)
+    // ---- ln3 -> scores against U -> masked softmax -> Wf combination -> residual -> x.y ----
+    xattn_tile<NPP, false, true, D, D>(x, b, xscr, zeros, tid, yl, stride, &xq);
 }

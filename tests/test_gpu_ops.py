@@ -432,7 +432,8 @@ def test_head(lib, mode):
 
 
 @pytest.mark.parametrize("D,H,Te,Ta,bias", [(384, 8, 4, 10, False), (512, 8, 3, 10, True), (128, 8, 4, 10, False),
-                                            (384, 8, 3, 7, True), (256, 8, 2, 16, False)])
+                                            (384, 8, 3, 7, True), (256, 8, 2, 16, False), (128, 4, 4, 10, True),
+                                            (384, 8, 1, 10, False)])
 def test_collapsed_cross_attention(lib, D, H, Te, Ta, bias):
     """k_xattn_fold + k_xattn_apply == y + c_proj(softmax_causal((ln3(y) Wq^T + bq) K^T / sqrt(hd)) V) + bo."""
     g = torch.Generator().manual_seed(D + Te + Ta)
@@ -443,7 +444,7 @@ def test_collapsed_cross_attention(lib, D, H, Te, Ta, bias):
     Wo, bo = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
     lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
     t = {k: dev(v) for k, v in dict(y=y, kv=kv, Wq=Wq, bq=bq, WoT=Wo.T, bo=bo, lw=lw, lb=lb).items()}
-    NP = H * Te
+    NP = 4 * H  # rows of the folded images: every head padded to 4 context tokens
     U = torch.full((B * NP * D,), float("nan"), device="cuda")
     Wf = torch.full((B * NP * D,), float("nan"), device="cuda")
     c = torch.full((B * NP,), float("nan"), device="cuda")
@@ -466,6 +467,74 @@ def test_collapsed_cross_attention(lib, D, H, Te, Ta, bias):
     o = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Ta, D) @ Wo.double().T + (bo.double() if bias else 0)
     assert_close(t["y"].cpu().view(B, Ta, D), (yd + o).float(), rtol=2e-4, atol=2e-4, what="collapsed cross attention")
     assert not torch.isnan(U).any() and not torch.isnan(c).any()
+
+
+@pytest.mark.parametrize("T,Te,gated,bias,B", [(10, 4, True, False, 256), (10, 4, False, True, 77), (16, 3, True, True, 130),
+                                               (7, 2, True, False, 201), (1, 4, True, True, 96)])
+def test_one_sample_per_workgroup_through_attention_projection_and_cross_attention(lib, T, Te, gated, bias, B):
+    """mdt_op_attn_xattn (k_attn_xattn): causal self-attention -> c_proj + gate + residual -> ln3 -> collapsed cross-attention of
+    one sample per workgroup, the rows between the sublayers never leaving LDS; against float64 and bit-for-bit against the two
+    launches it replaces (mdt_op_attn_proj in its tiled form, then mdt_op_xattn_apply)."""
+    g = torch.Generator().manual_seed(17 * T + Te + B)
+    H, hd = 8, 48
+    D = N = H * hd
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g) * 0.1
+    gate, y0 = torch.randn(B, 6 * N, generator=g), torch.randn(B * T, N, generator=g) * 2
+    kv = torch.randn(B * Te, 2 * D, generator=g)
+    Wq, bq = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
+    Wo, bo = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
+    lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    # float64: the two sublayers
+    q3 = qkv.view(B, T, 3 * D)
+    att = ref_attn(q3[..., :D], q3[..., D:2 * D], q3[..., 2 * D:], H, True).double().reshape(B * T, D)
+    upd = att @ W.double().T + b.double()
+    if gated:
+        upd = gate[:, 2 * N:3 * N].double().repeat_interleave(T, 0) * upd
+    y1 = (y0.double() + upd).view(B, T, D)
+    kd = kv.double()
+    K, V = kd[:, :D].view(B, Te, D), kd[:, D:].view(B, Te, D)
+    q = F.layer_norm(y1, (D,), lw.double(), lb.double(), 1e-5) @ Wq.double().T + bq.double()
+    qh, kh, vh = (x.view(B, -1, H, hd).transpose(1, 2) for x in (q, K, V))
+    sc = qh @ kh.transpose(-2, -1) / math.sqrt(hd)
+    sc = sc.masked_fill(~torch.ones(T, Te, dtype=torch.bool).tril(), float("-inf"))
+    o = (sc.softmax(-1) @ vh).transpose(1, 2).reshape(B, T, D) @ Wo.double().T + (bo.double() if bias else 0)
+    want = (y1 + o).reshape(B * T, D).float()
+    # device operands
+    t = {k: dev(v) for k, v in dict(kv=kv, Wq=Wq, bq=bq, WoT=Wo.T, bo=bo, lw=lw, lb=lb, b=b, gate=gate, qkv=qkv).items()}
+    Pd = pack(lib, W)
+    NP = 4 * H  # rows of the folded images: every head padded to 4 context tokens
+    U, Wf, c = (torch.empty(n, device="cuda") for n in (B * NP * D, B * NP * D, B * NP))
+    f = lib.XFoldArgs()
+    f.kv, f.ldkv, f.Wq, f.bq, f.WoT = t["kv"].data_ptr(), 2 * D, t["Wq"].data_ptr(), t["bq"].data_ptr(), t["WoT"].data_ptr()
+    f.U, f.Wf, f.c, f.B, f.H, f.hd, f.D, f.Te = U.data_ptr(), Wf.data_ptr(), c.data_ptr(), B, H, hd, D, Te
+    lib.check(lib.load().mdt_op_xattn_fold(C.byref(f), stream()))
+
+    def args(out):
+        a = lib.GemmArgs()
+        a.A, a.lda, a.Wp, a.bias, a.out, a.ldo, a.M, a.N, a.K = None, D, Pd.data_ptr(), t["b"].data_ptr(), out.data_ptr(), N, B * T, N, D
+        a.shift_off = a.scale_off = -1
+        a.gate_off = 2 * N if gated else -1
+        a.mod, a.mod_stride = (t["gate"].data_ptr(), 6 * N) if gated else (None, 0)
+        a.residual, a.rows_per_sample, a.gin, a.gout = 1, T, 1, 1
+        x = lib.XApplyArgs()
+        x.y, x.ln_w, x.ln_b, x.U, x.Wf, x.c = out.data_ptr(), t["lw"].data_ptr(), t["lb"].data_ptr(), U.data_ptr(), Wf.data_ptr(), c.data_ptr()
+        x.bo = t["bo"].data_ptr() if bias else None
+        x.B, x.H, x.D, x.Te, x.Ta = B, H, D, Te, T
+        return a, x
+
+    one, two = dev(y0).clone(), dev(y0).clone()
+    a, x = args(one)
+    lib.check(lib.load().mdt_op_attn_xattn(C.byref(a), t["qkv"].data_ptr(), 3 * D, C.byref(x), hd, T, stream()))
+    a2, x2 = args(two)
+    lib.check(lib.load().mdt_op_attn_proj(C.byref(a2), t["qkv"].data_ptr(), 3 * D, hd, T, 1, stream()))
+    lib.check(lib.load().mdt_op_xattn_apply(C.byref(x2), stream()))
+    torch.cuda.synchronize()
+    assert_close(one.cpu(), want, rtol=2e-4, atol=2e-4, what="attention + projection + cross-attention, one launch")
+    assert torch.equal(one, two), "the one-launch form differs from attn_proj + xattn_apply"
+    # what it refuses: other head dimensions, a cross-attention on other rows
+    x.y = two.data_ptr()
+    assert lib.load().mdt_op_attn_xattn(C.byref(a), t["qkv"].data_ptr(), 3 * D, C.byref(x), hd, T, stream()) == 2
 
 
 # ------------------------------------------------------------------------------------------------

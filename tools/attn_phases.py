@@ -10,7 +10,7 @@ g = torch.Generator().manual_seed(0)
 qkv = torch.randn(B * Ta, 3 * D, generator=g).to(dev); out = torch.empty(B * Ta, D, device=dev)
 a = _lib.AttnArgs(); a.q, a.ldq, a.k, a.v, a.ldkv = qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D
 a.out, a.ldo, a.B, a.H, a.hd, a.Tq, a.Tk, a.causal = out.data_ptr(), D, B, H, hd, Ta, Ta, 1
-NP = H * Te
+NP = 4 * H
 U = torch.randn(B * NP * D, generator=g).to(dev) * 0.05; Wf = torch.randn(B * NP * D, generator=g).to(dev) * 0.05
 c = torch.zeros(B * NP, device=dev); y = torch.randn(B * Ta, D, generator=g).to(dev); lw = torch.ones(D, device=dev)
 x = _lib.XApplyArgs(); x.y, x.ln_w, x.U, x.Wf, x.c = y.data_ptr(), lw.data_ptr(), U.data_ptr(), Wf.data_ptr(), c.data_ptr()
