@@ -180,7 +180,7 @@ typedef struct {
     float *U, *Wf;                 /* out: B images of 4 H * D floats each, opaque: MFMA weight-fragment order, every head */
                                    /* padded to 4 context tokens (row p = 4 h + j; mdt_kernels.hip "Collapsed ...")        */
     float *c;                      /* out: (B, 4 H)                                                                        */
-    int32_t B, H, hd, D, Te;       /* H in {4, 8}, D = H * hd <= 512 a multiple of 64, 1 <= Te <= 4                        */
+    int32_t B, H, hd, D, Te;       /* H in {4, 8}, D = H * hd <= 512 a multiple of 128, 1 <= Te <= 4                       */
 } mdt_xfold_args;
 mdt_status mdt_op_xattn_fold(const mdt_xfold_args *args, void *stream);
 

@@ -659,7 +659,16 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     // tiles double the workgroup count; measured 4-17 % faster per sampler call up to M ~ 1400, slower beyond 2000
     // ... unless the output is so wide that they would be thousands (the stacked adaLN projection of a training batch:
     // 1024 x 9216 -> 9216 workgroups that each re-read their weight tile): then the scored choice stands
-    if (a.M <= g_mdt_mid_max && (int64_t)((a.M + 15) / 16) * ((a.N + 63) / 64) <= 4096) geo = 6;
+    if (a.M <= g_mdt_mid_max && (int64_t)((a.M + 15) / 16) * ((a.N + 63) / 64) <= 4096) {
+        geo = 6;
+        // ... except where 4-wave 32 x 192 tiles come out as (nearly) whole rounds of one workgroup per CU: the encoder's
+        // and the B ~ 100..140 decoder's wide products (tools/gemm_shapes.py: 1024 x 1152 18.9 -> 17.5 us, 1024 x 1536 22.0 ->
+        // 18.3, 1024 x 3072 33.7 -> 28.0, 1280 x 1152 21.6 -> 17.8; 1280 x 1536 -- 320 tiles -- 27.8 vs 28.5: stays)
+        if (a.N % 192 == 0 && a.N >= 1152 && a.K <= 512 && a.batch <= 1) {
+            const int cnt9 = gm * (a.N / 192);
+            if ((float)cnt9 / (float)(((cnt9 + 255) / 256) * 256) >= 0.75f) geo = 9;
+        }
+    }
     // training-sized row counts without a LayerNorm prologue (forward / input-gradient products of a B = 1024 step, the
     // masked-image head's 104 k rows): 4 waves x 32 x 192 tiles -- two or three co-resident per CU, each weight fragment reused by
     // one wave only -- beat every 8-wave geometry whenever N is a multiple of 192 (tools/gemm_train_shapes.py: 10240 x 1536 x 384
@@ -1057,74 +1066,74 @@ hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // the folds of ALL decoder blocks of one sampler call are one launch: blockIdx.z picks the block's argument set
 struct mdt_xfold_table { mdt_xfold_args a[8]; };
-template <int R>
-__device__ __forceinline__ float quad_bcast(float v) { return dpp_keep<R * 0x55, 0xf>(v); }  // lane R of every lane quad
-template <int TE, int SB>
+// One workgroup = (8 samples, head h, decoder block): both folds as MFMA products with K = hd.  The 32 activation rows are
+// (sample, token) pairs -- 4 rows per sample, rows of absent tokens zero, which also zeroes their rows of the images --
+//   U : transposed form, A = Wq^T fragment (4 dwords per lane from 4 rows of query.weight), B = K rows: the lane ends with 4
+//       consecutive features of one (sample, token) = one 16-byte slot of the U image
+//   Wf: plain form, A = V rows, B = c_proj.weight^T fragment: the lane ends with the 4 tokens of one (sample, feature) = one
+//       16-byte slot of the Wf image
+// wave w owns the feature tiles w, w + 8, ...  (The first form: one thread per feature, K / V as scalar operands of 1500 FMAs
+// per thread -- a third of the VALU rate, 93 us per sampler call at B = 256.)
+template <int TE>
 __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
+    constexpr int SB = 8, K16MAX = 4;     // samples per workgroup; hd <= 64
     const mdt_xfold_args& a = tab.a[blockIdx.z];
-    const int n = threadIdx.x;            // output feature handled by this thread (blockDim = D rounded up to 64)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.y;
     const int bg = blockIdx.x * SB;       // first sample of the group
-    const int HD = a.hd, D = a.D, NPP = 4 * a.H, K16 = D >> 4, KP16 = NPP >> 4;
-    // The K / V values of the group's context rows are the same for every lane: they are read with UNIFORM addresses straight
-    // from memory (scalar loads into SGPRs, one operand of each FMA) -- as LDS broadcasts (the first form) every FMA waited
-    // for its own ds_read and the kernel ran at a third of the VALU rate (95 us per sampler call at B = 256).
-    const float* krow[SB][TE];
-#pragma unroll
-    for (int sb = 0; sb < SB; ++sb)
-#pragma unroll
-        for (int j = 0; j < TE; ++j)
-            krow[sb][j] = a.kv + (int64_t)(min(bg + sb, a.B - 1) * TE + j) * a.ldkv + h * HD;  // K at +0, V at +D
+    const int HD = a.hd, D = a.D, NPP = 4 * a.H, K16 = D >> 4, KP16 = NPP >> 4, KH = HD >> 4;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float scale = 1.0f / sqrtf((float)HD);
-    const int nc = min(n, D - 1);         // threads beyond D (D % 64 != 0) compute a duplicate and store nothing
-    float accU[SB][4], accW[SB][4];
+    // ---- activation fragments: row lane % 16 of M-tile mt = (sample bg + 4 mt + (lane % 16) / 4, token (lane % 16) % 4) ----
+    const int rs = (lane & 15) >> 2, rt = lane & 3, kq = 4 * (lane >> 4);
+    f32x4 kf[2][K16MAX], vf[2][K16MAX];
 #pragma unroll
-    for (int sb = 0; sb < SB; ++sb)
+    for (int mt = 0; mt < 2; ++mt) {
+        const int smp = bg + 4 * mt + rs;
+        const bool live = smp < a.B && rt < TE;
+        const float* row = a.kv + (int64_t)(min(smp, a.B - 1) * TE + min(rt, TE - 1)) * a.ldkv + h * HD + kq;  // K at +0, V at +D
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { accU[sb][j] = 0.f; accW[sb][j] = 0.f; }
-    for (int d0 = 0; d0 < HD; d0 += 8) {  // HD is a multiple of 16: 8 rows of each weight in flight per lane
-        float wq[8], wo[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            wq[e] = a.Wq[(int64_t)(h * HD + d0 + e) * D + nc];   // query.weight row (out feature h*hd+d), coalesced over n
-            wo[e] = a.WoT[(int64_t)(h * HD + d0 + e) * D + nc];  // c_proj.weight^T row, coalesced over n
+        for (int kc = 0; kc < K16MAX; ++kc) {
+            const int ko = min(kc, KH - 1) * 16;
+            kf[mt][kc] = sel4(live, ldg4(row + ko), zero4);
+            vf[mt][kc] = sel4(live, ldg4(row + D + ko), zero4);
         }
+    }
+    for (int nt = wave; nt < K16; nt += 8) {
+        // weight fragments of feature tile nt: element e of k-block kc = weight row h hd + 16 kc + 4 (lane / 16) + e, column 16 nt + lane % 16
+        float wq[K16MAX][4], wo[K16MAX][4];
 #pragma unroll
-        for (int sb = 0; sb < SB; ++sb)
+        for (int kc = 0; kc < K16MAX; ++kc)
 #pragma unroll
-            for (int j = 0; j < TE; ++j) {
-                const float* kr = krow[sb][j] + d0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    accU[sb][j] = fmaf(wq[e], kr[e], accU[sb][j]);
-                    accW[sb][j] = fmaf(wo[e], kr[D + e], accW[sb][j]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int64_t o = (int64_t)(h * HD + min(kc, KH - 1) * 16 + kq + e) * D + nt * 16 + (lane & 15);
+                wq[kc][e] = a.Wq[o];
+                wo[kc][e] = a.WoT[o];
             }
-    }
-    // ---- stores in fragment order.  Wf: this thread's 4 tokens ARE one fragment quad (elements j of lane n % 16 + 16 (h % 4)
-    //      in block (n / 16, h / 4)).  U: a quad holds 4 consecutive features of ONE token, so the 4 threads of a lane quad
-    //      transpose their (feature, token) values through DPP: thread q of the quad ends with token q ----
-    const int q = n & 3;
-    const int64_t uoff = (((int64_t)(h >> 2) * K16 + (n >> 4)) * 64 + ((h & 3) * 4 + q) + 16 * ((n & 15) >> 2)) * 4;
-    const int64_t woff = (((int64_t)(n >> 4) * KP16 + (h >> 2)) * 64 + (n & 15) + 16 * (h & 3)) * 4;
 #pragma unroll
-    for (int sb = 0; sb < SB; ++sb) {
-        // element r of my fragment quad = token q's value held by thread r of the lane quad (all 16 broadcasts are executed by
-        // every lane, the token is picked afterwards: no DPP under divergent control flow)
-        f32x4 uq;
-#define MDT_QTOK(R) \
-    { \
-        const float b0 = quad_bcast<R>(accU[sb][0]), b1 = quad_bcast<R>(accU[sb][1]); \
-        const float b2 = quad_bcast<R>(accU[sb][2]), b3 = quad_bcast<R>(accU[sb][3]); \
-        uq[R] = (q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3))) * scale; \
-    }
-        MDT_QTOK(0) MDT_QTOK(1) MDT_QTOK(2) MDT_QTOK(3)
-#undef MDT_QTOK
-        if (n < D && bg + sb < a.B) {
-            float* Ub = a.U + (int64_t)(bg + sb) * NPP * D;
-            float* Wb = a.Wf + (int64_t)(bg + sb) * NPP * D;
-            *(f32x4*)(Ub + uoff) = uq;                         // token q >= TE: the accumulators were never touched: zeros
-            *(f32x4*)(Wb + woff) = (f32x4){accW[sb][0], accW[sb][1], accW[sb][2], accW[sb][3]};
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 accU = zero4, accW = zero4;
+#pragma unroll
+            for (int kc = 0; kc < K16MAX; ++kc)
+                if (kc < KH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        accU = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[kc][e], kf[mt][kc][e], accU, 0, 0, 0);
+                        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[mt][kc][e], wo[kc][e], accW, 0, 0, 0);
+                    }
+                }
+            // U: lane holds (sample bg + 4 mt + rs, token rt), features 16 nt + 4 (lane / 16) .. + 3
+            {
+                const int smp = bg + 4 * mt + rs, pp = 4 * h + rt;
+                if (smp < a.B)
+                    *(f32x4*)(a.U + (int64_t)smp * NPP * D + (((int64_t)(pp >> 4) * K16 + nt) * 64 + (pp & 15) + 16 * (lane >> 4)) * 4) = accU * scale;
+            }
+            // Wf: lane holds (sample bg + 4 mt + lane / 16, tokens 0..3), feature 16 nt + lane % 16
+            {
+                const int smp = bg + 4 * mt + (lane >> 4);
+                if (smp < a.B)
+                    *(f32x4*)(a.Wf + (int64_t)smp * NPP * D + (((int64_t)nt * KP16 + (h >> 2)) * 64 + (lane & 15) + 16 * (h & 3)) * 4) = accW;
+            }
         }
     }
     if (threadIdx.x < SB * 4) {
@@ -1143,25 +1152,24 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
 // n argument sets of equal shape (B, H, hd, D, Te) -- the decoder blocks of one model -- folded by one launch (n <= 8 per
 // launch; more go in groups)
 hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_t s) {
-    constexpr int SB = 4;
+    constexpr int SB = 8;
     if (n < 1) return hipErrorInvalidValue;
     const mdt_xfold_args& a = sets[0];
-    if (a.D > 512 || a.D % 64 || a.Te < 1 || a.Te > 4 || (a.H != 4 && a.H != 8) || a.hd % 16) return hipErrorInvalidValue;
+    if (a.D > 512 || a.D % 128 || a.Te < 1 || a.Te > 4 || (a.H != 4 && a.H != 8) || a.hd % 16 || a.hd > 64 || (a.ldkv & 3))
+        return hipErrorInvalidValue;
     for (int i = 1; i < n; ++i)
         if (sets[i].B != a.B || sets[i].H != a.H || sets[i].hd != a.hd || sets[i].D != a.D || sets[i].Te != a.Te)
             return hipErrorInvalidValue;
-    const int threads = (a.D + 63) / 64 * 64;
-    const size_t lds = 0;
     for (int i0 = 0; i0 < n; i0 += 8) {
         mdt_xfold_table tab;
         const int cnt = n - i0 < 8 ? n - i0 : 8;
         for (int i = 0; i < 8; ++i) tab.a[i] = sets[i0 + (i < cnt ? i : 0)];
         const dim3 grid((a.B + SB - 1) / SB, a.H, cnt);
         switch (a.Te) {
-            case 1: hipLaunchKernelGGL((k_xattn_fold<1, SB>), grid, dim3(threads), lds, s, tab); break;
-            case 2: hipLaunchKernelGGL((k_xattn_fold<2, SB>), grid, dim3(threads), lds, s, tab); break;
-            case 3: hipLaunchKernelGGL((k_xattn_fold<3, SB>), grid, dim3(threads), lds, s, tab); break;
-            default: hipLaunchKernelGGL((k_xattn_fold<4, SB>), grid, dim3(threads), lds, s, tab); break;
+            case 1: hipLaunchKernelGGL((k_xattn_fold<1>), grid, dim3(512), 0, s, tab); break;
+            case 2: hipLaunchKernelGGL((k_xattn_fold<2>), grid, dim3(512), 0, s, tab); break;
+            case 3: hipLaunchKernelGGL((k_xattn_fold<3>), grid, dim3(512), 0, s, tab); break;
+            default: hipLaunchKernelGGL((k_xattn_fold<4>), grid, dim3(512), 0, s, tab); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -1244,10 +1244,11 @@ extern "C" mdt_status mdt_op_attention(const mdt_attn_args* a, void* stream) {
 extern "C" mdt_status mdt_op_xattn_fold(const mdt_xfold_args* a, void* stream) {
     if (!a || !a->kv || !a->Wq || !a->bq || !a->WoT || !a->U || !a->Wf || !a->c)
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_fold: null pointer");
-    if (a->H * a->hd != a->D || a->Te < 1 || a->Te > 4 || a->D > 512 || a->D % 64 || (a->H != 4 && a->H != 8) || a->hd % 16)
-        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_fold: need 4 or 8 heads of a multiple of 16, H*hd == D <= 512 and 1 <= Te <= 4");
-    if (misaligned(a->U) || misaligned(a->Wf) || misaligned(a->c))
-        return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_fold: U / Wf / c must be 16-byte aligned");
+    if (a->H * a->hd != a->D || a->Te < 1 || a->Te > 4 || a->D > 512 || a->D % 128 || (a->H != 4 && a->H != 8) || a->hd % 16)
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_fold: need 4 or 8 heads of 16 / 32 / 48 / 64, H*hd == D <= 512 a multiple of 128 "
+                                         "and 1 <= Te <= 4");
+    if (misaligned(a->U) || misaligned(a->Wf) || misaligned(a->c) || misaligned(a->kv) || (a->ldkv & 3))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_fold: kv / U / Wf / c must be 16-byte aligned, ldkv a multiple of 4");
     LAUNCH(mdt_launch_xattn_fold(*a, (hipStream_t)stream));
     return MDT_OK;
 }
