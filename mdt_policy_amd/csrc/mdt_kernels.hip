@@ -662,11 +662,12 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.M <= g_mdt_mid_max && (int64_t)((a.M + 15) / 16) * ((a.N + 63) / 64) <= 4096) {
         geo = 6;
         // ... except where 4-wave 32 x 192 tiles come out as (nearly) whole rounds of one workgroup per CU: the encoder's
-        // and the B ~ 100..140 decoder's wide products (tools/gemm_shapes.py: 1024 x 1152 18.9 -> 17.5 us, 1024 x 1536 22.0 ->
-        // 18.3, 1024 x 3072 33.7 -> 28.0, 1280 x 1152 21.6 -> 17.8; 1280 x 1536 -- 320 tiles -- 27.8 vs 28.5: stays)
+        // and the B ~ 120..140 decoder's wide products (tools/gemm_shapes.py: 1024 x 1536 22.0 -> 18.3 us, 1024 x 3072 33.7 ->
+        // 28.0, 1280 x 1152 21.6 -> 17.8; 1280 x 1536 -- 320 tiles -- 27.8 vs 28.5: stays; 1024 x 1152 -- 192 tiles -- wins
+        // alone, 18.9 -> 17.5, and loses inside the encoder, 18.1 -> 19.5: stays)
         if (a.N % 192 == 0 && a.N >= 1152 && a.K <= 512 && a.batch <= 1) {
             const int cnt9 = gm * (a.N / 192);
-            if ((float)cnt9 / (float)(((cnt9 + 255) / 256) * 256) >= 0.75f) geo = 9;
+            if ((float)cnt9 / (float)(((cnt9 + 255) / 256) * 256) >= 0.9f) geo = 9;
         }
     }
     // training-sized row counts without a LayerNorm prologue (forward / input-gradient products of a B = 1024 step, the
