@@ -199,7 +199,7 @@ mdt_status mdt_op_xattn_apply(const mdt_xapply_args *args, void *stream);
  * transformer_blocks.py:296-300) followed by mdt_op_xattn_apply's on the same rows (:301-305); the rows between the two
  * sublayers stay in the workgroup's LDS and x->y == proj->out is written once.  8 heads of 48 (K = N = ldo = 384, ldq = 3 K),
  * T = x->Ta <= 16, proj->M = x->B * T; results equal the two launches bit for bit.  The model-level entry points use it
- * from 1401 rows up to 256 samples (MDT_HIP_ATTN_XATTN_MIN / MDT_HIP_ATTN_XATTN_MAX_B; mdt_op_set_attn_wide_min(0) switches
+ * from 1401 rows up to 512 samples (MDT_HIP_ATTN_XATTN_MIN / MDT_HIP_ATTN_XATTN_MAX_B; mdt_op_set_attn_wide_min(0) switches
  * it off together with the tiled form). */
 mdt_status mdt_op_attn_xattn(const mdt_gemm_args *proj, const float *qkv, int64_t ldq, const mdt_xapply_args *x, int32_t hd,
                              int32_t T, void *stream);

@@ -675,8 +675,9 @@ static int g_attn_wide_min_rows() {
 }
 extern "C" void mdt_op_set_attn_wide_min(int32_t rows) { g_attn_wide_override = rows; }
 
-// row count from which (and batch up to which) one workgroup per sample runs self-attention, projection AND the collapsed
-// cross-attention (k_attn_xattn); MDT_HIP_ATTN_XATTN_MIN (0 disables); mdt_op_set_attn_wide_min(0) switches it off too
+// row count from which (and batch up to which: two rounds of one workgroup per CU) one workgroup per sample runs self-attention,
+// projection AND the collapsed cross-attention (k_attn_xattn); MDT_HIP_ATTN_XATTN_MIN (0 disables) / MDT_HIP_ATTN_XATTN_MAX_B;
+// mdt_op_set_attn_wide_min(0) switches it off too
 static int g_attn_xattn_min_rows() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_XATTN_MIN"); v = e ? atoi(e) : 1401; if (v == 0) v = 1 << 30; }
