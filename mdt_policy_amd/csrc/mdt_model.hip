@@ -1257,7 +1257,11 @@ extern "C" mdt_status mdt_op_xattn_fold(const mdt_xfold_args* a, void* stream) {
 extern "C" mdt_status mdt_op_xattn_apply(const mdt_xapply_args* a, void* stream) {
     if (!a || !a->y || !a->ln_w || !a->U || !a->Wf || !a->c) return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_apply: null pointer");
     if (!mdt_xattn_apply_supported(a->D, a->H, a->Te, a->Ta))
-        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_apply: unsupported (D, H, Te, Ta) = (%d, %d, %d, %d)", a->D, a->H, a->Te, a->Ta);
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_apply: unsupported (D, H, Te, Ta) = (%d, %d, %d, %d): needs 4 or 8 heads, D <= 512 a "
+                                         "multiple of 128, 1 <= Te <= 4, Ta <= 16", a->D, a->H, a->Te, a->Ta);
+    if (misaligned(a->y) || misaligned(a->U) || misaligned(a->Wf) || misaligned(a->c) || misaligned(a->ln_w) || misaligned(a->ln_b) ||
+        misaligned(a->bo))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_apply: pointers must be 16-byte aligned");
     LAUNCH(mdt_launch_xattn_apply(*a, (hipStream_t)stream));
     return MDT_OK;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-TAG=${1:-r3s}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
+TAG=${1:-attn_xattn_ab}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
 timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x --timeout 300 -p no:cacheprovider -k "one_sample_per_workgroup or projection_prologue or collapsed" > $OUT/pytest_op.log 2>&1; echo "op tests exit $?" | tee -a $OUT/summary.txt; tail -5 $OUT/pytest_op.log
 MDT_HIP_LIB=$R/mdt_policy_amd/csrc/libmdt_hip_dbg.so ROWS_LANDED=1 timeout 100 python tools/attn_xattn_phases.py 256 2>&1 | grep -v amdgpu.ids | tee $OUT/phases.txt
 for rep in 1 2; do

@@ -8,6 +8,7 @@ from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
 dev = torch.device("cuda")
 cfg, P, model = bench.build_model(dev)
 sig = gs.get_sigmas_exponential(10, 0.001, 80.0)
+if os.environ.get("LAT_DEV_SIG") == "1": sig = sig.to(dev)  # the schedule on the device, as the agent builds it (no copy per call)
 for B in [int(x) for x in (sys.argv[1:] or ["1", "4", "16", "64", "256", "1024"])]:
     inp = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.sampler_inputs(B, cfg, seed=1).items()}
     st = {"state_images": inp["state_images"], "modality": "lang"}
