@@ -185,23 +185,34 @@ class MaskedTransformerImgDecoder(nn.Module):
         return imgs.reshape(B, X, Cn, g, p, g, p).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, X, g * g, Cn * p * p)
 
     def mask(self, ctx_patches: torch.Tensor, mask_ratio: Optional[float] = None):
-        """The reference's method by its own signature (:126-171): per-sample random masking of (bsz, ctx, n_patches, d)
-        patch embeddings, the same patches for every frame -> (visible_patches, mask (1 = removed), restore_idxs).  The
+        """The reference's method by its own signature (:126-171): random masking of (bsz, ctx, n_patches, d) patch embeddings
+        -> (visible_patches, mask (1 = removed), restore_idxs); ``symmetric_mask``: the same patches for every frame.  The
         forward below does not come through here (it never embeds the patches it would drop); this is for callers of the
         reference API."""
         bsz, ctx_len, n_patches, d = ctx_patches.shape
-        shuffle, m, restore, n_keep = self._mask_indices(n_patches, bsz, ctx_patches.device, mask_ratio)
-        visible = torch.gather(ctx_patches, 2, shuffle[:, None, :n_keep, None].expand(bsz, ctx_len, n_keep, d))
+        shuffle, m, restore, n_keep = self._mask_indices(n_patches, bsz, ctx_patches.device, mask_ratio, ctx_len=ctx_len)
+        idx = shuffle[:, None, :n_keep, None] if self.symmetric_mask else shuffle[:, :, :n_keep, None]
+        visible = torch.gather(ctx_patches, 2, idx.expand(bsz, ctx_len, n_keep, d))
         return visible, m, restore
 
-    def _mask_indices(self, n_patches: int, bsz: int, device, mask_ratio: Optional[float] = None, noise: Optional[torch.Tensor] = None):
-        """Per-sample random masking, the SAME patches for both frames (reference :124-171, symmetric branch): returns
-        (shuffle_idxs, mask (1 = removed), restore_idxs, n_keep).  ``noise`` (bsz, n_patches) replaces the uniform draw."""
-        if not self.symmetric_mask:
-            raise NotImplementedError("symmetric_mask=False: the reference sorts its (bsz, ctx, n_patches) noise over the ctx axis "
-                                      "(masked_transformer_decoder.py:159) and keeps patches 0/1 only; not implemented")
+    def _mask_indices(self, n_patches: int, bsz: int, device, mask_ratio: Optional[float] = None, noise: Optional[torch.Tensor] = None,
+                      ctx_len: int = 2):
+        """(shuffle_idxs, mask (1 = removed), restore_idxs, n_keep) as the reference's ``mask`` builds them (:124-171).
+        symmetric_mask: per-sample shuffle of the patches, shared by the frames; ``noise`` (bsz, n_patches) replaces the draw.
+        Otherwise the reference's other branch AS IT IS WRITTEN: (bsz, ctx, n_patches) noise argsorted over the CTX axis
+        (:159-160), so shuffle / restore hold frame indices 0 .. ctx-1, the "visible" patches of a frame are its patches
+        shuffle[:, c, :n_keep] (i.e. patch 0 or 1), and the mask -- constant along the axis it is gathered on (:167-169) --
+        removes the patches n_keep .. n-1 of every frame; ``noise`` is (bsz, ctx, n_patches) then."""
         ratio = self.mask_ratio if mask_ratio is None else mask_ratio
         n_keep = int(n_patches * (1 - ratio))
+        if not self.symmetric_mask:
+            if noise is None:
+                noise = torch.rand(bsz, ctx_len, n_patches, device=device)
+            shuffle = torch.argsort(noise, dim=1)
+            restore = torch.argsort(shuffle, dim=1)
+            m = torch.ones(bsz, ctx_len, n_patches, device=device)
+            m[:, :, :n_keep] = 0
+            return shuffle, torch.gather(m, 1, restore), restore, n_keep
         if noise is None:
             noise = torch.rand(bsz, n_patches, device=device)
         shuffle = torch.argsort(noise, dim=1)
@@ -226,16 +237,22 @@ class MaskedTransformerImgDecoder(nn.Module):
         self._packs.refresh([m.weight for m in self.modules() if isinstance(m, (nn.Linear, nn.Conv2d))],
                             need_t=torch.is_grad_enabled())
         emb_context = self._linear(context.float(), self.encoder2decoder)
-        shuffle, m, restore, n_keep = self._mask_indices(n, B, context.device, self.mask_ratio, noise)
-        keep = shuffle[:, :n_keep]
-        gidx = keep[:, None, :, None]
+        shuffle, m, restore, n_keep = self._mask_indices(n, B, context.device, self.mask_ratio, noise, ctx_len=X)
+        # the patch of every visible slot: shared by the frames, or per frame (symmetric_mask = False)
+        gidx = shuffle[:, None, :n_keep, None] if self.symmetric_mask else shuffle[:, :, :n_keep, None]
         # only the visible patches are embedded: the masked ones never reach the blocks (the reference embeds all 2 x 49
         # and gathers 2 x 12)
         pix = torch.gather(self._conv_patches(target_images.float()), 2, gidx.expand(B, X, n_keep, self.in_channels * self.patch_size ** 2))
         pe = self.decoder_pe.to(context.device)
         vis = ops.HipLinear.apply(pix, self.patch2embed.proj.weight, self.patch2embed.proj.bias, self._packs)
         vis = vis + torch.gather(pe.expand(B, n, d)[:, None].expand(B, X, n, d), 2, gidx.expand(B, X, n_keep, d))
-        tokens = self.mask_token.reshape(1, 1, 1, d).expand(B, X, n, d).scatter(2, gidx.expand(B, X, n_keep, d), vis)
+        if self.symmetric_mask:
+            tokens = self.mask_token.reshape(1, 1, 1, d).expand(B, X, n, d).scatter(2, gidx.expand(B, X, n_keep, d), vis)
+        else:
+            # the reference's un-shuffle with its (bsz, ctx, n_patches) restore_idxs (:243-248): position p of frame c takes
+            # slot restore[b, c, p] of [visible | mask tokens]
+            slots = torch.cat([vis, self.mask_token.reshape(1, 1, 1, d).expand(B, X, n - n_keep, d)], dim=2)
+            tokens = torch.gather(slots, 2, restore[..., None].expand(B, X, n, d))
         tokens = tokens + pe[None] + self.ctx_dec_pe[:, :2]      # position embedding a second time, as the reference (:268-271)
         x = torch.cat([emb_context, tokens.reshape(B, X * n, d)], dim=1)
         for blk in self.decoder_blocks:
@@ -255,4 +272,9 @@ class MaskedTransformerImgDecoder(nn.Module):
         if ctx_reconstructions.device.type != "cuda":
             raise RuntimeError("MaskedTransformerImgDecoder runs only on a ROCm GPU; there is no CPU execution path in mdt_policy_amd")
         # = (sum_x (per_patch[:, x] * mask).sum() / mask.sum()) / 2 with per_patch = ((rec - patchify(imgs)) ** 2).mean(-1)
+        if mask.dim() == 3:  # symmetric_mask = False: every frame against its own mask (:256-258)
+            X = mask.shape[1]
+            terms = [ops.HipPatchMSE.apply(ctx_reconstructions[:, x:x + 1].float(), imgs[:, x:x + 1].float(), mask[:, x].float(),
+                                           self.patch_size) for x in range(X)]
+            return sum(terms) / X
         return ops.HipPatchMSE.apply(ctx_reconstructions.float(), imgs.float(), mask.float(), self.patch_size)

@@ -560,6 +560,10 @@ G15_MAE = {
     "tiny": (dict(resolution=64, patch_size=16, decoder_depth=2, decoder_embed_dim=64, decoder_n_heads=4, context_dim=128,
                   mlp_ratio=4, in_channels=3, norm_pixel_loss=True, num_images=2, mask_ratio=0.5, symmetric_mask=True,
                   img_gen_frame_diff=3), 5, 4),
+    # the non-default masking branch as the reference writes it (masked_transformer_decoder.py:158-170, 236-248, 256-258)
+    "tiny_asym": (dict(resolution=64, patch_size=16, decoder_depth=2, decoder_embed_dim=64, decoder_n_heads=4, context_dim=128,
+                       mlp_ratio=4, in_channels=3, norm_pixel_loss=True, num_images=2, mask_ratio=0.5, symmetric_mask=False,
+                       img_gen_frame_diff=3), 5, 4),
 }
 
 

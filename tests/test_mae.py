@@ -13,7 +13,7 @@ from mdt_policy_amd import synthetic
 from oracle import mae_oracle as O
 from tests.helpers import assert_close, load_fixture
 
-CASES = ["default", "tiny"]
+CASES = ["default", "tiny", "tiny_asym"]  # tiny_asym: symmetric_mask = False, the reference's other masking branch as written
 
 
 def case(name):
