@@ -191,8 +191,18 @@ typedef struct {
     const float *U, *Wf, *c;       /* from mdt_op_xattn_fold                                                   */
     const float *bo;               /* cross_att.c_proj.bias (D) or NULL                                        */
     int32_t B, H, D, Te, Ta;       /* D a multiple of 128, Ta <= 16                                             */
+    float *y_out;                  /* NULL: y is updated in place; else the new rows go here and y stays as it is */
 } mdt_xapply_args;
 mdt_status mdt_op_xattn_apply(const mdt_xapply_args *args, void *stream);
+
+/* Rollout batches: mdt_op_xattn_apply and the LayerNorm(+ modulate)-prologue Linear that follows it on the same rows (mlp.c_fc,
+ * transformer_blocks.py:301-307) in ONE launch (k_xattn_gemm_smallm): every 16-column workgroup of the Linear repeats the
+ * sample's cross-attention on the MFMA pipe and multiplies its output rows straight out of LDS; the workgroup of column 0
+ * writes the new rows to x->y_out, which must be given and differ from x->y (the other workgroups may still be reading x->y).
+ * `g` as for mdt_op_gemm with g->A == x->y, lda = K = x->D, M = x->B * x->Ta, rows_per_sample = x->Ta, no residual / row remap /
+ * split input.  Results equal the two launches bit for bit.  The model-level entry points use it up
+ * to 8 samples (MDT_HIP_XATTN_FC_MAX_B). */
+mdt_status mdt_op_xattn_gemm(const mdt_xapply_args *x, const mdt_gemm_args *g, void *stream);
 
 /* The middle of a ConditionedBlock for a batch of at most one sample per compute unit, ONE launch, one workgroup per sample
  * (k_attn_xattn): mdt_op_attn_proj's contract (causal self-attention of the sample's T rows -> c_proj + gate + residual,

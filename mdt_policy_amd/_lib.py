@@ -57,7 +57,7 @@ class XFoldArgs(C.Structure):
 class XApplyArgs(C.Structure):
     _fields_ = [("y", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("U", C.c_void_p), ("Wf", C.c_void_p),
                 ("c", C.c_void_p), ("bo", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
-                ("Te", C.c_int32), ("Ta", C.c_int32)]
+                ("Te", C.c_int32), ("Ta", C.c_int32), ("y_out", C.c_void_p)]
 
 
 class HeadArgs(C.Structure):
@@ -190,6 +190,7 @@ SYMBOLS = [
     ("mdt_op_xattn_fold", _I32, [C.POINTER(XFoldArgs), _VP]),
     ("mdt_op_xattn_apply", _I32, [C.POINTER(XApplyArgs), _VP]),
     ("mdt_op_attn_xattn", _I32, [C.POINTER(GemmArgs), _VP, _I64, C.POINTER(XApplyArgs), _I32, _I32, _VP]),
+    ("mdt_op_xattn_gemm", _I32, [C.POINTER(XApplyArgs), C.POINTER(GemmArgs), _VP]),
     ("mdt_op_layernorm", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_head", _I32, [C.POINTER(HeadArgs), _VP]),
     ("mdt_op_action_embed", _I32, [_VP, _VP, _I64, _F, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _VP]),

@@ -114,6 +114,9 @@ hipError_t mdt_launch_transpose(const float* src, float* dst, int R, int Cc, hip
 hipError_t mdt_launch_xattn_fold(const mdt_xfold_args& a, hipStream_t s);
 hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_t s);  // equal shapes; one launch per 8 sets
 hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s);
+// the collapsed cross-attention + the LayerNorm-prologue Linear on its output rows in one launch (k_xattn_gemm_smallm)
+bool mdt_xattn_gemm_supported(const mdt_xapply_args& x, const mdt_gemm_args& g);
+hipError_t mdt_launch_xattn_gemm(const mdt_xapply_args& x, const mdt_gemm_args& g, hipStream_t s);
 bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta);
 size_t mdt_xattn_lds_floats(int D, int H);  // LDS floats of the collapsed cross-attention body (xattn_tile)
 // ---- Perceiver resampler kernels ----

@@ -467,6 +467,22 @@ __global__ __launch_bounds__(512) void k_gemm_smallm(mdt_gemm_args a, const floa
 }
 
 static int g_mdt_mid_max = 1400;    // rows up to which the 16 x 64 tiled geometry is used (env MDT_HIP_MID_MAX)
+// k_xattn_gemm_smallm: the collapsed cross-attention of sample b and, on its output rows, 16 columns (blockIdx.x) of the
+// LayerNorm + modulate -> Linear that follows (mlp.c_fc) -- rollout batches: the cross-attention launch (one workgroup, 6.5 us
+// of latency per decoder block at B = 1) disappears into the c_fc launch, whose 96 workgroups each repeat it on the MFMA pipe
+// (48 MFMAs per wave, the sample's 98 KB of folded operands from L2); workgroup 0 writes the residual stream.
+template <int NPP>
+__global__ __launch_bounds__(512) void k_xattn_gemm_smallm(mdt_xapply_args x, mdt_gemm_args a, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float s_stat[32];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    const int b = blockIdx.y, ys = x.D + 4;
+    float* yo = lds;                       // [16][D + 4]: the sample's rows after the cross-attention
+    xattn_tile<NPP, false, false, 512, 0, true>(x, b, lds + 16 * ys, zeros, threadIdx.x, nullptr, 0, nullptr, yo, ys, blockIdx.x == 0);
+    __syncthreads();
+    gemm_smallm_tile<false, true>(a, blockIdx.x, b * x.Ta, s_stat, red, zeros, threadIdx.x, yo, ys, x.Ta);
+}
+
 static int g_mdt_smallm_max = -1;  // rows up to which k_gemm_smallm is used (env MDT_HIP_SMALLM_MAX, default below)
 
 int mdt_gemm_kchunk(int K, int ln, int cap) {
@@ -1194,6 +1210,35 @@ bool mdt_xattn_apply_supported(int D, int H, int Te, int Ta) {
 size_t mdt_xattn_lds_floats(int D, int H) {
     const int npp = 4 * H, ks = 8 / (npp / 16);
     return (size_t)16 * (D + 4) + (size_t)(ks + 1) * 16 * (npp + 4);
+}
+
+// Cross-attention + the Linear behind it in one launch (rollout batches): `x` as for mdt_launch_xattn_apply with a SEPARATE
+// output array (x.y_out != x.y: the workgroups that repeat a sample's cross-attention read x.y while one of them writes), `g` =
+// the Linear on the same rows (g.A == x.y, LayerNorm prologue, K = x.D, M = x.B * x.Ta, no residual, plain row mapping).
+bool mdt_xattn_gemm_supported(const mdt_xapply_args& x, const mdt_gemm_args& g) {
+    return mdt_xattn_apply_supported(x.D, x.H, x.Te, x.Ta) && x.y_out != nullptr && x.y_out != x.y && g.ln && g.K == x.D && g.A == x.y &&
+           g.lda == x.D &&
+           g.M == x.B * x.Ta && !(g.N & 15) && !g.residual && g.batch <= 1 && !g.aux_mode && g.a_parts <= 1 && g.gin == 1 &&
+           g.gout == 1 && g.goff == 0 && g.rows_per_sample == x.Ta;
+}
+template <int NPP>
+static hipError_t launch_xattn_gemm_t(const mdt_xapply_args& x, const mdt_gemm_args& g, hipStream_t s) {
+    const size_t lds = ((size_t)16 * (x.D + 4) + mdt_xattn_lds_floats(x.D, x.H)) * sizeof(float);
+    static size_t lds_attr_dev[MAX_DEVICES] = {0};
+    size_t& lds_attr = lds_attr_dev[current_device()];
+    if (lds > lds_attr) {  // up to 78 KB of dynamic LDS at d = 512
+        hipError_t e = hipFuncSetAttribute((const void*)k_xattn_gemm_smallm<NPP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((k_xattn_gemm_smallm<NPP>), dim3(g.N >> 4, x.B), dim3(512), lds, s, x, g, g_zeros);
+    return hipGetLastError();
+}
+hipError_t mdt_launch_xattn_gemm(const mdt_xapply_args& x, const mdt_gemm_args& g, hipStream_t s) {
+    if (!mdt_xattn_gemm_supported(x, g)) return hipErrorInvalidValue;
+    hipError_t e = ensure_zeros();
+    if (e != hipSuccess) return e;
+    return x.H == 8 ? launch_xattn_gemm_t<32>(x, g, s) : launch_xattn_gemm_t<16>(x, g, s);
 }
 
 hipError_t mdt_launch_xattn_apply(const mdt_xapply_args& a, hipStream_t s) {

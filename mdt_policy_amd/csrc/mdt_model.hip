@@ -750,15 +750,17 @@ extern "C" void mdt_op_set_mlp_fuse_min(int32_t rows) { g_mlp_fuse_override = ro
 
 // `out` (optional): when given and the fused launch applies, the sublayer's output is left as slabs in V.hid (described in
 // *out) and V.y is NOT updated -- the caller hands *out to the next reader; otherwise V.y is updated in place.
+// `pre_x` (optional; rollout batches): the collapsed cross-attention that is still to run on these rows -- it goes into the
+// c_fc launch (k_xattn_gemm_smallm); the caller has checked mdt_xattn_gemm_supported.
 static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_t B, int T, ModRef mr, hipStream_t s,
-                          Stream* out = nullptr) {
+                          Stream* out = nullptr, const mdt_xapply_args* pre_x = nullptr) {
     float* x = V.y;
     const int D = m->D, M = (int)(B * T);
     mdt_gemm_args g = gemm_args(x, D, e.fc, V.hid, 4 * D, M);
     g.ln = 1; g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = MDT_ACT_GELU;
     g.rows_per_sample = T;
     if (mr.mod && mr.shift >= 0) { g.mod = mr.mod; g.mod_stride = mr.stride; g.shift_off = mr.shift; g.scale_off = mr.scale; }
-    mdt_gemm_args p = gemm_args(V.hid, 4 * D, e.proj2, x, D, M);
+    mdt_gemm_args p = gemm_args(V.hid, 4 * D, e.proj2, pre_x ? pre_x->y_out : x, D, M);  // pre_x: the residual stream moves to its y_out
     p.residual = 1; p.rows_per_sample = T;
     if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
     if (out) *out = Stream();
@@ -770,9 +772,18 @@ static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_
         out->base = V.hid; out->parts = mdt_mlp_slices(D); out->stride = stride;
         return MDT_OK;
     }
-    LAUNCH(mdt_launch_gemm(g, s));
+    if (pre_x) LAUNCH(mdt_launch_xattn_gemm(*pre_x, g, s));
+    else LAUNCH(mdt_launch_gemm(g, s));
     LAUNCH(mdt_launch_gemm(p, s));
     return MDT_OK;
+}
+
+// batch up to which the cross-attention of a decoder block runs inside the c_fc launch that follows it (rollout batches;
+// MDT_HIP_XATTN_FC_MAX_B, 0 disables)
+static int g_xattn_fc_max_batch() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_XATTN_FC_MAX_B"); v = e ? atoi(e) : 2; }  // B = 4: 1.67 vs 1.58 ms per call
+    return v;
 }
 
 // sigma_emb: sinusoidal(ln(sigma)/4) -> Linear -> Mish -> Linear for R sigmas (mdtv_transformer.py:105-110,282-288);
@@ -911,6 +922,7 @@ static int64_t cond_width(const mdt_model* m) {
 static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, const float* mod_row, int64_t mod_stride,
                                      hipStream_t s, Stream* fin = nullptr) {
     const int D = m->D, Ta = m->Ta, M = (int)(B * Ta);
+    View W = V;  // W.y / W.att trade places whenever a block's cross-attention runs inside its c_fc launch (rollout batches)
     Stream cur;  // where the residual stream lives between blocks
     if (fin) *fin = Stream();
     for (int l = 0; l < m->Ld; ++l) {
@@ -928,38 +940,50 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
         memset(&x, 0, sizeof x);
         if (m->xfold) {
             const int64_t np = (int64_t)4 * m->H;
-            x.y = V.y; x.ln_w = d.ln3_w; x.ln_b = d.ln3_b; x.bo = d.xproj.bias;
+            x.y = W.y; x.ln_w = d.ln3_w; x.ln_b = d.ln3_b; x.bo = d.xproj.bias;
             x.U = m->xU + ((int64_t)l * m->cap + V.b0) * np * D;
             x.Wf = m->xW + ((int64_t)l * m->cap + V.b0) * np * D;
             x.c = m->xc + ((int64_t)l * m->cap + V.b0) * np;
             x.B = (int)B; x.H = m->H; x.D = D; x.Te = m->Te; x.Ta = Ta;
         }
+        // rollout batches: the cross-attention runs inside the c_fc launch (run_mlp below), if that launch is the small-M kernel
+        // (the workgroups that repeat the cross-attention read W.y while one of them writes: the new rows go to W.att, which is
+        //  free here, and the two trade places -- an even number of blocks ends in V.y again) ...
+        bool x_in_fc = false;
+        if (m->xfold) {
+            mdt_gemm_args gf = gemm_args(W.y, D, d.fc, W.hid, 4 * D, M);
+            gf.ln = 1; gf.rows_per_sample = Ta;
+            x.y_out = W.att;
+            x_in_fc = B <= g_xattn_fc_max_batch() && M <= 192 && m->Ld % 2 == 0 && mdt_xattn_gemm_supported(x, gf);
+            if (!x_in_fc) x.y_out = nullptr;
+        }
         bool xdone = false;
-        MDT_TRY(run_self_attn(m, d, V, B, Ta, true, ma, s, cur, m->xfold ? &x : nullptr, &xdone));
+        MDT_TRY(run_self_attn(m, d, W, B, Ta, true, ma, s, cur, m->xfold ? &x : nullptr, &xdone));
         cur = Stream();
         if (xdone) {
             // self-attention, projection and cross-attention went as one launch (one workgroup per sample)
         } else if (m->xfold) {
-            LAUNCH(mdt_launch_xattn_apply(x, s));
+            if (!x_in_fc) LAUNCH(mdt_launch_xattn_apply(x, s));
         } else {
-            mdt_gemm_args q = gemm_args(V.y, D, d.xq, V.qx, D, M);
+            mdt_gemm_args q = gemm_args(W.y, D, d.xq, W.qx, D, M);
             q.ln = 1; q.ln_w = d.ln3_w; q.ln_b = d.ln3_b; q.rows_per_sample = Ta;
             if (mx.mod) { q.mod = mx.mod; q.mod_stride = mx.stride; q.shift_off = mx.shift; q.scale_off = mx.scale; }
             LAUNCH(mdt_launch_gemm(q, s));
             mdt_attn_args a;
             memset(&a, 0, sizeof a);
-            a.q = V.qx; a.ldq = D;
-            a.k = V.kvx + (int64_t)l * 2 * D; a.v = a.k + D; a.ldkv = (int64_t)m->Ld * 2 * D;
-            a.out = V.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Ta; a.Tk = m->Te;
+            a.q = W.qx; a.ldq = D;
+            a.k = W.kvx + (int64_t)l * 2 * D; a.v = a.k + D; a.ldkv = (int64_t)m->Ld * 2 * D;
+            a.out = W.att; a.ldo = D; a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Ta; a.Tk = m->Te;
             a.causal = 1;  // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
             a.rope = m->cfg.use_rot_embed;
             LAUNCH(mdt_launch_attention(a, m->rope_cos, m->rope_sin, s));
-            mdt_gemm_args p = gemm_args(V.att, D, d.xproj, V.y, D, M);
+            mdt_gemm_args p = gemm_args(W.att, D, d.xproj, W.y, D, M);
             p.residual = 1; p.rows_per_sample = Ta;
             LAUNCH(mdt_launch_gemm(p, s));
         }
         const bool last = l == m->Ld - 1;
-        MDT_TRY(run_mlp(m, d, V, B, Ta, mm, s, (!last || fin) ? &cur : nullptr));
+        MDT_TRY(run_mlp(m, d, W, B, Ta, mm, s, (!last || fin) ? &cur : nullptr, x_in_fc ? &x : nullptr));
+        if (x_in_fc) std::swap(W.y, W.att);
     }
     if (fin) *fin = cur;
     return MDT_OK;
@@ -1259,8 +1283,8 @@ extern "C" mdt_status mdt_op_xattn_apply(const mdt_xapply_args* a, void* stream)
     if (!mdt_xattn_apply_supported(a->D, a->H, a->Te, a->Ta))
         return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_apply: unsupported (D, H, Te, Ta) = (%d, %d, %d, %d): needs 4 or 8 heads, D <= 512 a "
                                          "multiple of 128, 1 <= Te <= 4, Ta <= 16", a->D, a->H, a->Te, a->Ta);
-    if (misaligned(a->y) || misaligned(a->U) || misaligned(a->Wf) || misaligned(a->c) || misaligned(a->ln_w) || misaligned(a->ln_b) ||
-        misaligned(a->bo))
+    if (misaligned(a->y) || misaligned(a->y_out) || misaligned(a->U) || misaligned(a->Wf) || misaligned(a->c) || misaligned(a->ln_w) ||
+        misaligned(a->ln_b) || misaligned(a->bo))
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_apply: pointers must be 16-byte aligned");
     LAUNCH(mdt_launch_xattn_apply(*a, (hipStream_t)stream));
     return MDT_OK;
@@ -1279,6 +1303,20 @@ extern "C" mdt_status mdt_op_attn_proj(const mdt_gemm_args* proj, const float* q
         return fail(MDT_ERR_UNSUPPORTED, "mdt_op_attn_proj: needs 8 heads of 16/32/48/64 (K = 8 * hd), T <= 16 rows per sample "
                                          "(M = samples * T, at most 64 samples), a plain projection");
     LAUNCH(mdt_launch_attn_proj(*proj, qkv, ldq, 8, hd, T, causal, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_xattn_gemm(const mdt_xapply_args* x, const mdt_gemm_args* g, void* stream) {
+    if (!x || !g || !x->y || !x->ln_w || !x->U || !x->Wf || !x->c || !g->Wp || !g->out || !g->ln_w)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_gemm: null argument");
+    if (misaligned(x->y) || misaligned(x->y_out) || misaligned(x->U) || misaligned(x->Wf) || misaligned(x->c) || misaligned(g->Wp) ||
+        misaligned(g->out))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_gemm: pointers must be 16-byte aligned");
+    if (!mdt_xattn_gemm_supported(*x, *g))
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_gemm: needs a cross-attention mdt_op_xattn_apply supports with its own output array "
+                                         "(y_out != y) and a LayerNorm-prologue Linear on the same rows (A == x->y, lda = K = D, M = B * Ta, "
+                                         "rows_per_sample = Ta, N a multiple of 16, no residual / row remap)");
+    LAUNCH(mdt_launch_xattn_gemm(*x, *g, (hipStream_t)stream));
     return MDT_OK;
 }
 

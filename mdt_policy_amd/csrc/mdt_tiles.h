@@ -856,9 +856,12 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
 // 4 consecutive k), LayerNorm / modulate applied in registers from per-row statistics the workgroup computes first.
 // 512 threads.  s_stat: 32 floats, red: 8*64*4 floats of LDS.
 // ------------------------------------------------------------------------------------------------
-template <bool COH>
+// XL: the tile's rows are read from LDS (`xl`, row stride `xls` floats, row 0 = row m0; k_xattn_gemm_smallm leaves the
+// cross-attention's output there) instead of a.A; `rows` (<= 16) of the tile are real.
+template <bool COH, bool XL = false>
 __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_tile, int m0, float* s_stat, float* red,
-                                                 const float* __restrict__ zeros, int tid) {
+                                                 const float* __restrict__ zeros, int tid, const float* xl = nullptr, int xls = 0,
+                                                 int rows = 16) {
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int K16 = a.K >> 4;
@@ -887,7 +890,8 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c4 = l32 + 32 * i;
-            v[i] = LA.ld4(m * a.lda + 4 * min(c4, n4 - 1));
+            if constexpr (XL) v[i] = *(const f32x4*)(xl + min(r, rows - 1) * xls + 4 * min(c4, n4 - 1));
+            else v[i] = LA.ld4(m * a.lda + 4 * min(c4, n4 - 1));
             v[i] = sel4(c4 < n4, v[i], zero4);
             sum += hsum4(v[i]);
         }
@@ -905,9 +909,10 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
     }
     const int mrow = m0 + (lane & 15);
     const int64_t mc = min(mrow, a.M - 1);
-    const bool mok = mrow < a.M;
+    const bool mok = mrow < a.M && (lane & 15) < rows;
     const int kq = 4 * (lane >> 4);
     const int64_t xoff = mc * a.lda + kq;
+    const float* xlp = XL ? xl + min(lane & 15, rows - 1) * xls + kq : nullptr;
     const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
     const bool modded = a.ln && a.mod != nullptr && a.shift_off >= 0;
     const float* mrw = modded ? a.mod + (a.mod_stride == 0 ? 0 : (mc / a.rows_per_sample) * a.mod_stride) : zeros;
@@ -919,7 +924,8 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
         for (int u = 0; u < 4; ++u) {
             const int ks = min(ks0 + 8 * u, K16 - 1);
             wf[u] = ldg4(wbase + ks * 256);
-            xv[u] = LA.ld4(xoff + ks * 16);
+            if constexpr (XL) xv[u] = *(const f32x4*)(xlp + ks * 16);
+            else xv[u] = LA.ld4(xoff + ks * 16);
             if (a.ln) {
                 lw[u] = ldg4(a.ln_w + ks * 16 + kq);
                 lb[u] = a.ln_b ? ldg4(a.ln_b + ks * 16 + kq) : zero4;
@@ -1436,9 +1442,12 @@ __device__ __forceinline__ void xattn_request_vec(const mdt_xapply_args& a, cons
     for (int j = 0; j < NTWMAX; ++j) q.bo[j] = ldg4(bop + (wave * NTW + min(j, NTW - 1)) * 16 + 4 * (lane >> 4));
 }
 
-template <int NPP, bool COH, bool YL = false, int DMAX = 512, int DX = 0>
+// OL: the new rows ALSO go to LDS (`yo`, row stride `yos`: k_xattn_gemm_smallm multiplies them on the spot) and reach a.y only
+// if `wr` (one workgroup of those that repeat the sample's cross-attention writes it).
+template <int NPP, bool COH, bool YL = false, int DMAX = 512, int DX = 0, bool OL = false>
 __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, float* lds, const float* __restrict__ zeros, int tid,
-                                           const float* yl = nullptr, int yls = 0, const mdt_xattn_req<NPP, DMAX>* pre = nullptr) {
+                                           const float* yl = nullptr, int yls = 0, const mdt_xattn_req<NPP, DMAX>* pre = nullptr,
+                                           float* yo = nullptr, int yos = 0, bool wr = true) {
     constexpr int NTU = NPP / 16, KS = 8 / NTU, KP16 = NPP / 16, PS = NPP + 4;
     constexpr int KLMAX = DMAX / 16 / KS, NTWMAX = DMAX / 128;   // D <= DMAX
     if constexpr (!YL) {
@@ -1565,7 +1574,7 @@ __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, floa
         f32x4 pv[KP16];
 #pragma unroll
         for (int kc = 0; kc < KP16; ++kc) pv[kc] = *(const f32x4*)(pp + kc * 16);
-        float* yb = a.y + yoff + (int64_t)(lane & 15) * D;
+        float* yb = (a.y_out != nullptr ? a.y_out : a.y) + yoff + (int64_t)(lane & 15) * D;
 #pragma unroll
         for (int j = 0; j < NTWMAX; ++j)
             if (j < NTW) {
@@ -1574,7 +1583,9 @@ __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, floa
                 for (int kc = 0; kc < KP16; ++kc)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wf[j][kc][e], pv[kc][e], acc, 0, 0, 0);
-                if ((lane & 15) < Ta) *(f32x4*)(yb + (wave * NTW + j) * 16 + nq) = yold[j] + (q.bo[j] + acc);
+                const f32x4 yn = yold[j] + (q.bo[j] + acc);
+                if constexpr (OL) *(f32x4*)(yo + (lane & 15) * yos + (wave * NTW + j) * 16 + nq) = yn;
+                if ((lane & 15) < Ta && wr) *(f32x4*)(yb + (wave * NTW + j) * 16 + nq) = yn;
             }
     }
     if constexpr (YL) { MDT_TS(6) } else { MDT_TS(4) }

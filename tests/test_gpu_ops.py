@@ -537,6 +537,71 @@ def test_one_sample_per_workgroup_through_attention_projection_and_cross_attenti
     assert lib.load().mdt_op_attn_xattn(C.byref(a), t["qkv"].data_ptr(), 3 * D, C.byref(x), hd, T, stream()) == 2
 
 
+@pytest.mark.parametrize("D,H,Te,Ta,B,mod", [(384, 8, 4, 10, 1, True), (384, 8, 4, 10, 8, True), (512, 8, 3, 10, 3, False),
+                                             (128, 4, 2, 16, 5, True), (256, 8, 1, 7, 2, True)])
+def test_cross_attention_inside_the_linear_that_follows_it(lib, D, H, Te, Ta, B, mod):
+    """mdt_op_xattn_gemm (k_xattn_gemm_smallm, rollout batches): y += cross-attention, then GELU(LN-mod(y) W^T + b) with every
+    16-column workgroup repeating the cross-attention -- bit-for-bit the two launches (mdt_op_xattn_apply, mdt_op_gemm), and
+    against float64."""
+    g = torch.Generator().manual_seed(D + 7 * Te + Ta + B)
+    hd, N, NP = D // H, 4 * D, 4 * H
+    y0 = torch.randn(B * Ta, D, generator=g) * 2
+    kv = torch.randn(B * Te, 2 * D, generator=g)
+    Wq, bq = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
+    Wo, bo = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
+    lw3, lb3 = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    lw2, lb2 = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g) * 0.1
+    modv = torch.randn(6 * D, generator=g) * 0.5
+    t = {k: dev(v) for k, v in dict(kv=kv, Wq=Wq, bq=bq, WoT=Wo.T, bo=bo, lw3=lw3, lb3=lb3, lw2=lw2, lb2=lb2, b=b, mod=modv).items()}
+    Pd = pack(lib, W)
+    U, Wf, c = (torch.empty(n, device="cuda") for n in (B * NP * D, B * NP * D, B * NP))
+    f = lib.XFoldArgs()
+    f.kv, f.ldkv, f.Wq, f.bq, f.WoT = t["kv"].data_ptr(), 2 * D, t["Wq"].data_ptr(), t["bq"].data_ptr(), t["WoT"].data_ptr()
+    f.U, f.Wf, f.c, f.B, f.H, f.hd, f.D, f.Te = U.data_ptr(), Wf.data_ptr(), c.data_ptr(), B, H, hd, D, Te
+    lib.check(lib.load().mdt_op_xattn_fold(C.byref(f), stream()))
+
+    def args(y, out):
+        x = lib.XApplyArgs()
+        x.y, x.ln_w, x.ln_b, x.U, x.Wf, x.c, x.bo = (y.data_ptr(), t["lw3"].data_ptr(), t["lb3"].data_ptr(), U.data_ptr(), Wf.data_ptr(),
+                                                     c.data_ptr(), t["bo"].data_ptr())
+        x.B, x.H, x.D, x.Te, x.Ta = B, H, D, Te, Ta
+        a = lib.GemmArgs()
+        a.A, a.lda, a.Wp, a.bias, a.out, a.ldo, a.M, a.N, a.K = y.data_ptr(), D, Pd.data_ptr(), t["b"].data_ptr(), out.data_ptr(), N, B * Ta, N, D
+        a.ln, a.ln_w, a.ln_b, a.act = 1, t["lw2"].data_ptr(), t["lb2"].data_ptr(), 1
+        a.shift_off = a.scale_off = a.gate_off = -1
+        if mod:
+            a.mod, a.mod_stride, a.shift_off, a.scale_off = t["mod"].data_ptr(), 0, 3 * D, 4 * D
+        a.rows_per_sample, a.gin, a.gout = Ta, 1, 1
+        return x, a
+
+    y1, y2, y1n = dev(y0).clone(), dev(y0).clone(), torch.full((B * Ta, D), float("nan"), device="cuda")
+    o1, o2 = torch.empty(B * Ta, N, device="cuda"), torch.empty(B * Ta, N, device="cuda")
+    x, a = args(y1, o1)
+    assert lib.load().mdt_op_xattn_gemm(C.byref(x), C.byref(a), stream()) == 2  # in place: the repeating workgroups would race
+    x.y_out = y1n.data_ptr()
+    lib.check(lib.load().mdt_op_xattn_gemm(C.byref(x), C.byref(a), stream()))
+    x2, a2 = args(y2, o2)
+    lib.check(lib.load().mdt_op_xattn_apply(C.byref(x2), stream()))
+    lib.check(lib.load().mdt_op_gemm(C.byref(a2), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y1.cpu(), y0), "the input rows must stay as they are"
+    assert torch.equal(y1n, y2) and torch.equal(o1, o2), "the one-launch form differs from xattn_apply + gemm"
+    y1 = y1n
+    yd, kd = y0.double().view(B, Ta, D), kv.double()
+    K, V = kd[:, :D].view(B, Te, D), kd[:, D:].view(B, Te, D)
+    q = F.layer_norm(yd, (D,), lw3.double(), lb3.double(), 1e-5) @ Wq.double().T + bq.double()
+    qh, kh, vh = (z.view(B, -1, H, hd).transpose(1, 2) for z in (q, K, V))
+    sc = (qh @ kh.transpose(-2, -1) / math.sqrt(hd)).masked_fill(~torch.ones(Ta, Te, dtype=torch.bool).tril(), float("-inf"))
+    ynew = yd + (sc.softmax(-1) @ vh).transpose(1, 2).reshape(B, Ta, D) @ Wo.double().T + bo.double()
+    h = F.layer_norm(ynew, (D,), lw2.double(), lb2.double(), 1e-5)
+    if mod:
+        h = modv[3 * D:4 * D].double() + h * modv[4 * D:5 * D].double()
+    want = F.gelu(h.reshape(B * Ta, D) @ W.double().T + b.double())
+    assert_close(y1.cpu(), ynew.reshape(B * Ta, D).float(), rtol=2e-4, atol=2e-4, what="residual stream after the cross-attention")
+    assert_close(o1.cpu(), want.float(), rtol=2e-4, atol=3e-4, what="c_fc on the cross-attention's output")
+
+
 # ------------------------------------------------------------------------------------------------
 # fused MLP sublayer (mdt_op_mlp) and the readers of its partial slabs (mdt_gemm_args.a_parts, mdt_head_args.y_parts)
 # ------------------------------------------------------------------------------------------------
