@@ -160,11 +160,11 @@ __global__ __launch_bounds__(512) void k_gemm_merge(mdt_gemm_args a, int kchunk,
 // ------------------------------------------------------------------------------------------------
 template <int NTW2, int PRO>
 __global__ __launch_bounds__(512) void k_mlp(mdt_gemm_args f, mdt_gemm_args p, float* __restrict__ parts, int64_t part_stride,
-                                             int n_slices, const float* __restrict__ zeros) {
+                                             int n_slices, const float* __restrict__ zeros, int skew) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int by = logical / n_slices, s = logical - by * n_slices;
-    mlp_tile<NTW2, PRO>(f, p, parts, part_stride, by, s, lds, zeros, threadIdx.x);
+    mlp_tile<NTW2, PRO>(f, p, parts, part_stride, by, s, lds, zeros, threadIdx.x, skew);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -743,7 +743,8 @@ int mdt_mlp_slices(int D) { return 4 * D / 512; }
 template <int NTW2, int PRO>
 static hipError_t launch_mlp_t(const mdt_gemm_args& f, const mdt_gemm_args& p, float* parts, int64_t part_stride, hipStream_t s) {
     const int S = mdt_mlp_slices(f.K), gm = (f.M + 31) / 32;
-    const size_t lds = (size_t)32 * (f.K + 4 + 516) * sizeof(float);
+    const size_t lds = (size_t)32 * (f.K + 4 + 516) * sizeof(float) + 16 * sizeof(int);  // + the wave flags of mlp_tile
+    static const int skew = [] { const char* e = getenv("MDT_HIP_MLP_SKEW"); return e ? atoi(e) : (18 | 256); }();  // k-steps of wave skew (0 = lockstep + barrier) | 256 = MFMA loops at raised priority
     static size_t lds_attr_dev[MAX_DEVICES] = {0};
     size_t& lds_attr = lds_attr_dev[current_device()];
     if (lds > lds_attr) {
@@ -751,7 +752,7 @@ static hipError_t launch_mlp_t(const mdt_gemm_args& f, const mdt_gemm_args& p, f
         if (e != hipSuccess) return e;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL((k_mlp<NTW2, PRO>), dim3(gm * S), dim3(512), lds, s, f, p, parts, part_stride, S, g_zeros);
+    hipLaunchKernelGGL((k_mlp<NTW2, PRO>), dim3(gm * S), dim3(512), lds, s, f, p, parts, part_stride, S, g_zeros, skew);
     return hipGetLastError();
 }
 template <int NTW2>

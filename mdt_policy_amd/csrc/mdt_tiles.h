@@ -97,9 +97,10 @@ __device__ __forceinline__ float hsq4(f32x4 v) { return (v.x * v.x + v.y * v.y) 
 #if defined(MDT_DEBUG_TIMING) && defined(MDT_TILES_TIMING_OWNER)
 // tuning-only build (-DMDT_DEBUG_TIMING): thread 0 of every workgroup records shader-clock stamps of its phases
 __device__ unsigned long long* g_dbg_ts = nullptr;
+// (thread 256 -- wave 4, the SIMD partner of wave 0 -- stamps too, into a second block of rows behind the grid's)
 #define MDT_TS(i)                                                                         \
-    if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
-        g_dbg_ts[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();            \
+    if ((threadIdx.x & 255) == 0 && g_dbg_ts != nullptr) {                               \
+        g_dbg_ts[((size_t)blockIdx.x + (threadIdx.x >> 8) * gridDim.x) * 8 + (i)] = __builtin_readcyclecounter(); \
     }
 #define MDT_TS_HWID()                                                                     \
     if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
@@ -124,24 +125,41 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 #ifndef MDT_RING_ADD
 #define MDT_RING_ADD 0  // tuning builds: deeper weight-fragment rings (tools/gpu_ring_ab.sh)
 #endif
+// The prefetches of a k-step are written at its top and must be ISSUED there: left alone, the machine scheduler sinks the
+// loads of one ring slot out of three down to their first use (one exposed L2 round trip per three k-steps in every GEMM
+// loop of this file).  A scheduling barrier that only scalar / vector ALU instructions may cross pins memory instructions
+// and MFMAs to the k-step they were written in.  -DMDT_NO_SCHED_PIN: A/B build.
+#ifdef MDT_NO_SCHED_PIN
+#define MDT_SCHED_PIN
+#else
+#define MDT_SCHED_PIN __builtin_amdgcn_sched_barrier(0x6);
+#endif
 // one k-step of the MFMA main loop (uses the enclosing kernel's ring / wp / ap / stride / acc / kg / K16): prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
 #define MDT_KSTEP(U, KC)                                                                                  \
     {                                                                                                     \
         const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
         _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                      \
             ldg4(wp[j] + kpf * 256);                                                                      \
-        f32x4 avn[MTILES]; /* activation fragments of the NEXT k-step: their LDS latency hides under the MFMAs */ \
+        MDT_SCHED_PIN                                                                                     \
+        MDT_PRIO(1)                                                                                       \
+        MDT_KSTEP_MFMAS(U, 0)                                                                             \
+        MDT_SCHED_PIN                                                                                     \
+        f32x4 avn[MTILES]; /* activation fragments of the NEXT k-step, requested behind the first quarter of the MFMAs: \
+                              whatever LDS wait the compiler puts at the top of a step then finds them long landed */ \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
             *(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16);                           \
-        MDT_PRIO(1)                                                                                       \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-            _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                          \
-                _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                               \
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][e], av[i][e], acc[i][j], 0, 0, 0);  \
-            }                                                                                             \
-        }                                                                                                 \
+        MDT_SCHED_PIN                                                                                     \
+        MDT_KSTEP_MFMAS(U, 1)                                                                             \
+        MDT_KSTEP_MFMAS(U, 2)                                                                             \
+        MDT_KSTEP_MFMAS(U, 3)                                                                             \
         MDT_PRIO(0)                                                                                       \
+        MDT_SCHED_PIN                                                                                     \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
+    }
+#define MDT_KSTEP_MFMAS(U, E)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                                  \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                                       \
+            __builtin_amdgcn_mfma_f32_16x16x4f32(ring[(U)][j][(E)], av[i][(E)], acc[i][j], 0, 0, 0);      \
     }
 
 // Geometry: NWAVES waves (4 or 8); tile = (MTILES*16 rows) x (NWAVES * NTW * 16 columns), full K.  Wave w owns NTW
@@ -696,6 +714,34 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
     MDT_TS(4)
 }
 
+// wave-level LDS flags of mlp_tile (no fences: LDS serves a CU's requests in order, a wave's flag store is issued behind its
+// data stores and their lgkmcnt has retired; vmcnt -- the weight ring in flight -- is never waited on here).  The accesses
+// are volatile, and address-space inference leaves volatile accesses alone: without the explicit LDS pointer type they
+// become FLAT instructions, which count on vmcnt as well and would drain the weight ring at every poll.
+typedef __attribute__((address_space(3))) int mdt_lds_int;
+typedef int mdt_i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) mdt_i32x4 mdt_lds_i32x4;
+__device__ __forceinline__ void mlp_set_flag(int* f, int lane) {
+    if (lane == 0) *(volatile mdt_lds_int*)(mdt_lds_int*)f = 1;
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void mlp_wait_flag(const int* f) {
+    while (__builtin_amdgcn_readfirstlane(*(const volatile mdt_lds_int*)(const mdt_lds_int*)f) == 0) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+}
+// chunk c of the hidden slice = the 64 columns wave c produced; `ready` caches what this wave has already seen
+__device__ __forceinline__ void mlp_wait_chunk(const int* flg, int c, unsigned& ready) {
+    while (!((ready >> c) & 1u)) {
+        const volatile mdt_lds_i32x4* q = (const volatile mdt_lds_i32x4*)(const mdt_lds_int*)flg;
+        const mdt_i32x4 a = q[0], b = q[1];
+        const unsigned m = (a.x != 0) | ((a.y != 0) << 1) | ((a.z != 0) << 2) | ((a.w != 0) << 3) | ((b.x != 0) << 4) |
+                           ((b.y != 0) << 5) | ((b.z != 0) << 6) | ((b.w != 0) << 7);
+        ready = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+        if (!((ready >> c) & 1u)) __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused MLP tile:  the whole MLP sublayer  x + gate * (act(prologue(x) W1^T + b1) W2^T + b2)  for row tile `by` and hidden
 // slice `s` (512 of the 4D hidden columns).  Phase 1 is gemm_tile<2, 4, 8> on W1's rows [512 s, 512 s + 512) with the
@@ -705,22 +751,37 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
 // slab order by whoever reads them next (gemm_stage_tile / head_rows with XP = S).  512 threads;
 // lds: 32 * (D + 4) + 32 * 516 floats.  `f` = the first Linear's arguments (A = x), `p` = the second's.
 // ------------------------------------------------------------------------------------------------
+// SKEW (`skew` > 0): the two waves that share a SIMD (w and w + 4) run `skew` k-steps apart instead of in lockstep, and the
+// workgroup barrier between the two products is replaced by one "my 64 hidden columns are in LDS" flag per wave that the
+// second product's K walk checks at its 64-column chunk boundaries (natural K order: the sums are bit-identical).  While
+// the early wave of a SIMD runs its GELU epilogue (VALU) the late one still has MFMAs of the first product to issue, and
+// while the late one runs its GELU the early one is already multiplying the chunks that are ready: the activation block
+// and the early wave's final epilogue move under the partner's MFMAs.  lds: + 16 ints behind the hidden slice.
 template <int NTW2, int PRO>
 __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_args& p, float* __restrict__ parts,
                                          int64_t part_stride, int by, int s, float* lds, const float* __restrict__ zeros,
-                                         int tid) {
+                                         int tid, int skew_arg = 0) {
+    const int skew = skew_arg & 0xff;
+    const bool prio = (skew_arg & 0x100) != 0;  // MFMA loops at raised issue priority (the partner's VALU epilogue fills the gaps)
     MDT_TS(0)
     MDT_TS_HWID()
     constexpr int MTILES = 2, NWAVES = 8, MT = 32, HS = 512, HSTR = HS + 4, NTW1 = 4;
     constexpr bool KSTEP_PRIO = false;
+#ifdef MDT_MLP_RING  // tuning builds: depth of both weight-fragment rings
+    constexpr int R1 = MDT_MLP_RING, R2 = MDT_MLP_RING;
+#else
     constexpr int R1 = 3, R2 = NTW2 == 1 ? 6 : (NTW2 == 2 ? 4 : 3);
+#endif
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int m0 = by * MT;
     const int D = f.K, stride1 = D + 4;
     float* xn = lds;                  // [32][D + 4]   normalised (+ modulated) rows
     float* hs = lds + MT * stride1;   // [32][516]     this slice of the activated hidden layer
+    int* flg = (int*)(hs + MT * HSTR);  // [0..7] wave w's hidden columns are in LDS; [8..11] early wave w passed k-step `skew`
     const int nq = 4 * (lane >> 4);
+    const bool late = skew > 0 && wave >= NWAVES / 2;  // the second wave of its SIMD (waves go to SIMDs round-robin)
+    if (tid < 16) flg[tid] = 0;
 
     // ---- phase 1 operands: weight ring of W1 rows [512 s + 64 wave, + 64), bias ----
     const int K16a = D >> 4;
@@ -756,7 +817,17 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
         f32x4 av[MTILES];
 #pragma unroll
         for (int i = 0; i < MTILES; ++i) av[i] = *(const f32x4*)(ap + i * 16 * stride);
+        if (late) mlp_wait_flag(flg + 8 + (wave & 3));
+        if (prio) __builtin_amdgcn_s_setprio(2);
+        // the early wave walks `skew` k-steps (whole ring rounds) before it lets its partner start: two loops, so that no
+        // control flow inside a loop body makes the compiler's LDS-counter bookkeeping pessimistic
+        const int ksk = late ? 0 : min(skew, nk) / R * R;
         int kc = 0;
+        for (; kc < ksk; kc += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
+        }
+        if (!late) mlp_set_flag(flg + 8 + (wave & 3), lane);
         for (; kc + R <= nk; kc += R) {
 #pragma unroll
             for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
@@ -767,6 +838,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
             for (int u = 0; u < R - 1; ++u)
                 if (u < rem) MDT_KSTEP(u, kc + u)
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
     }
     MDT_TS(3)
     // ---- phase 2 operands, requested before the activation epilogue so that they travel while it runs: the first
@@ -811,7 +883,14 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
         for (int j = 0; j < NTW1; ++j)
             *(f32x4*)(hs + (i * 16 + (lane & 15)) * HSTR + (wave * NTW1 + j) * 16 + nq) = apply_act(acc1[i][j] + b1[j], f.act);
     MDT_TS(4)
-    __syncthreads();
+    unsigned ready = 0xffu;  // bit c: the 64 hidden columns of chunk c (wave c's) are known to be in LDS
+    if (skew > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's hidden columns have landed
+        mlp_set_flag(flg + wave, lane);
+        ready = 0;
+    } else {
+        __syncthreads();
+    }
     {
         constexpr int NTW = NTW2, R = R2;
         const int K16 = K16b, nk = K16b, stride = HSTR, kg = 0;
@@ -820,19 +899,29 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
         f32x4 (&acc)[MTILES][NTW] = acc2;
         const float* ap = hs + (lane & 15) * stride + 4 * (lane >> 4);
         f32x4 av[MTILES];
+        mlp_wait_chunk(flg, 0, ready);
+        if (prio) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int i = 0; i < MTILES; ++i) av[i] = *(const f32x4*)(ap + i * 16 * stride);
+        // a k-step prefetches the activation fragments of the NEXT one: the chunk that step belongs to must be there
+#define MDT_KSTEP_C(U, KC)                                                         \
+    {                                                                              \
+        if ((((KC) + 1) & 3) == 0 && (KC) + 1 < nk) mlp_wait_chunk(flg, ((KC) + 1) >> 2, ready); \
+        MDT_KSTEP(U, KC)                                                           \
+    }
         int kc = 0;
         for (; kc + R <= nk; kc += R) {
 #pragma unroll
-            for (int u = 0; u < R; ++u) MDT_KSTEP(u, kc + u)
+            for (int u = 0; u < R; ++u) MDT_KSTEP_C(u, kc + u)
         }
         if (kc < nk) {
             const int rem = nk - kc;
 #pragma unroll
             for (int u = 0; u < R - 1; ++u)
-                if (u < rem) MDT_KSTEP(u, kc + u)
+                if (u < rem) MDT_KSTEP_C(u, kc + u)
         }
+#undef MDT_KSTEP_C
+        if (prio) __builtin_amdgcn_s_setprio(0);
     }
     MDT_TS(5)
     float* out = parts + (int64_t)s * part_stride;

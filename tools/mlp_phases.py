@@ -32,14 +32,19 @@ assert lib.mdt_debug_set_timing_buffer(buf.data_ptr()) == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); launch(); e1.record(); torch.cuda.synchronize()
 lib.mdt_debug_set_timing_buffer(None)
-t = buf.cpu().numpy().reshape(-1, 8); t = t[t[:, 0] != 0]
-base = t[:, 0].min()
-names = ["stage rows (load + LN + LDS)", "barrier", "phase-1 MFMA loop", "W2 / gate / residual requests + GELU -> LDS", "barrier + phase-2 MFMA loop", "final epilogue"]
-print(f"k_mlp: {len(t)} workgroups, event {e0.elapsed_time(e1) * 1e3:.1f} us, first entry -> last stamp {t[:, 6].max() - base} clk")
-for i, nm in enumerate(names):
-    v = t[:, i + 1] - t[:, i]
-    print(f"   {nm:44s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}  max {v.max():9.0f}")
-v = t[:, 6] - t[:, 0]
-print(f"   {'total inside the workgroup':44s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}  max {v.max():9.0f}")
-st = t[:, 0] - base
-print(f"   {'entry offset behind the first workgroup':44s} mean {st.mean():9.0f}  p50 {np.percentile(st, 50):9.0f}  p90 {np.percentile(st, 90):9.0f}  max {st.max():9.0f}")
+tall = buf.cpu().numpy().reshape(-1, 8); G = 240
+base = tall[:G, 0].min()
+names = ["stage rows (load + LN + LDS)", "barrier", "phase-1 MFMA loop (+ skew wait)", "W2 / gate / residual requests + GELU -> LDS", "(barrier +) phase-2 MFMA loop", "final epilogue"]
+print(f"k_mlp: {G} workgroups, event {e0.elapsed_time(e1) * 1e3:.1f} us, MDT_HIP_MLP_SKEW={os.environ.get('MDT_HIP_MLP_SKEW', 'default')}")
+for half, who in ((0, "wave 0 (early wave of its SIMD)"), (1, "wave 4 (its SIMD partner)")):
+    t = tall[half * G:(half + 1) * G]
+    if not (t[:, 0] != 0).all(): continue
+    print(f" {who}: first entry -> last stamp {t[:, 6].max() - base} clk")
+    for i, nm in enumerate(names):
+        v = t[:, i + 1] - t[:, i]
+        print(f"   {nm:44s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}  max {v.max():9.0f}")
+    v = t[:, 6] - t[:, 0]
+    print(f"   {'total inside the workgroup':44s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}  max {v.max():9.0f}")
+    v = t[:, 3] - tall[:G, 0]; print(f"   {'entry (wave 0) -> phase-1 loop done':44s} mean {v.mean():9.0f}")
+    v = t[:, 4] - tall[:G, 0]; print(f"   {'entry (wave 0) -> hidden columns in LDS':44s} mean {v.mean():9.0f}")
+    v = t[:, 5] - tall[:G, 0]; print(f"   {'entry (wave 0) -> phase-2 loop done':44s} mean {v.mean():9.0f}")
