@@ -109,6 +109,11 @@ mdt_status mdt_op_mlp(const mdt_gemm_args *fc, const mdt_gemm_args *proj, float 
 /* Tuning / test hook: the model-level entry points run the MLP sublayer through mdt_op_mlp from `rows` rows (B * horizon)
  * on; 0 = never (the two-GEMM sequence), -1 = default (1401, or MDT_HIP_MLP_FUSE_MIN from the environment). */
 void mdt_op_set_mlp_fuse_min(int32_t rows);
+/* Tuning / test hook: wave schedule inside mdt_op_mlp's kernel.  Low byte = number of k-steps the second wave of every
+ * SIMD starts behind the first (0 = lockstep with a workgroup barrier between the two products), | 256 = MFMA loops at
+ * raised issue priority; -1 = default (18 | 256, or MDT_HIP_MLP_SKEW from the environment).  Every setting produces the
+ * same bits (the K order of both products does not depend on it). */
+void mdt_op_set_mlp_skew(int32_t v);
 
 /* Tuning / test hook: force the workgroup geometry of every following GEMM launch in this process.
  * 0 = heuristic (default): for M <= 192 rows (rollout-sized batches) the split-K small-M kernel -- one workgroup per

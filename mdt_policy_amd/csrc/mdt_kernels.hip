@@ -740,11 +740,21 @@ bool mdt_mlp_supported(const mdt_gemm_args& f, const mdt_gemm_args& p) {
 }
 int mdt_mlp_slices(int D) { return 4 * D / 512; }
 
+// mlp_tile's wave schedule: low byte = k-steps the second wave of a SIMD starts behind the first (0: lockstep, workgroup
+// barrier between the two products), | 256 = MFMA loops at raised issue priority.  Measured at B = 256 (tools/gpu_skew_ab3.sh,
+// profiles/r03_mlp_skew_ab.txt): 0 -> 4.89, 6 -> 4.86, 18 | 256 -> 4.82 ms per sampler call.  MDT_HIP_MLP_SKEW / the hook: A/B runs, tests.
+static int g_mlp_skew = -1;
+static int mlp_skew() {
+    if (g_mlp_skew < 0) { const char* e = getenv("MDT_HIP_MLP_SKEW"); g_mlp_skew = e ? atoi(e) & 0x1ff : (18 | 256); }
+    return g_mlp_skew;
+}
+extern "C" void mdt_op_set_mlp_skew(int32_t v) { g_mlp_skew = v < 0 ? -1 : (v & 0x1ff); }
+
 template <int NTW2, int PRO>
 static hipError_t launch_mlp_t(const mdt_gemm_args& f, const mdt_gemm_args& p, float* parts, int64_t part_stride, hipStream_t s) {
     const int S = mdt_mlp_slices(f.K), gm = (f.M + 31) / 32;
     const size_t lds = (size_t)32 * (f.K + 4 + 516) * sizeof(float) + 16 * sizeof(int);  // + the wave flags of mlp_tile
-    static const int skew = [] { const char* e = getenv("MDT_HIP_MLP_SKEW"); return e ? atoi(e) : (18 | 256); }();  // k-steps of wave skew (0 = lockstep + barrier) | 256 = MFMA loops at raised priority
+    const int skew = mlp_skew();
     static size_t lds_attr_dev[MAX_DEVICES] = {0};
     size_t& lds_attr = lds_attr_dev[current_device()];
     if (lds > lds_attr) {

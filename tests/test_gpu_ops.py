@@ -683,6 +683,31 @@ def test_fused_mlp_slabs_sum_to_the_sublayer(lib, M, D, case):
     assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4, what=f"fused mlp {M}x{D} {case}")
 
 
+@pytest.mark.parametrize("M,D", [(2560, 384), (1777, 384), (320, 512), (96, 128)])
+def test_fused_mlp_wave_schedules_give_the_same_bits(lib, M, D):
+    """mdt_op_set_mlp_skew: the two waves of a SIMD in lockstep with a workgroup barrier between the products, or k-steps
+    apart with per-wave LDS flags (with / without raised MFMA priority) -- the K order never changes, so every schedule
+    must reproduce the lockstep bits, launch after launch (a missed flag would show up as a stale hidden column)."""
+    g = torch.Generator().manual_seed(M * 3 + D)
+    x = torch.randn(M, D, generator=g) * 1.5 + 0.2
+    W1 = torch.randn(4 * D, D, generator=g) / math.sqrt(D)
+    W2 = torch.randn(D, 4 * D, generator=g) / math.sqrt(4 * D)
+    lw = torch.randn(D, generator=g) * 0.2 + 1
+    mod = torch.randn(1, 6 * D, generator=g) * 0.5
+    kw = dict(mod=mod, mod_stride=0, offs=(3 * D, 4 * D, 5 * D), rps=1)
+    L = lib.load()
+    try:
+        L.mdt_op_set_mlp_skew(0)
+        want, _ = run_mlp(lib, x, W1, W2, lw, **kw)
+        for v in (3, 6, 18, 24, 40, 6 | 256, 18 | 256, 21 | 256, 255 | 256):
+            L.mdt_op_set_mlp_skew(v)
+            for rep in range(6):
+                got, _ = run_mlp(lib, x, W1, W2, lw, **kw)
+                assert torch.equal(got, want), f"schedule {v} (launch {rep}) differs from lockstep"
+    finally:
+        L.mdt_op_set_mlp_skew(-1)
+
+
 @pytest.mark.parametrize("M,N,XP,case", [(2560, 1152, 3, "bcast"), (2560, 1152, 3, "rows"), (1530, 1152, 3, "ln"),
                                          (640, 1536, 4, "bcast"), (77, 768, 2, "ln")])
 def test_gemm_reads_the_sum_of_slabs(lib, M, N, XP, case):
