@@ -81,13 +81,18 @@ struct mdt_attn_pro {
     float scale;
 };
 
-// output store of the GEMM epilogues.  -DMDT_ST_WT (tuning build) makes it a write-through (sc0 sc1) store so that the
-// tile does not stay dirty in L2 until the end-of-kernel write-back.
+// output store of the epilogues: a WRITE-THROUGH (sc0 sc1) store, so that the tile does not stay dirty in L2 until the
+// end-of-kernel write-back (a launch that leaves B dirty bytes pays B / 6 TB/s at its boundary: 2 us behind the 11.8 MB of a
+// fused MLP's slabs or of q | k | v; with one tile per CU nothing else hides it).  With three fat launches per block it pays
+// 1.9 % per sampler call at B = 256 (round 1, six thin launches: +1 %, inside the noise; B = 1024, the training step and the
+// MGF head do not care: several tiles per CU hide the write-back).  -DMDT_ST_PLAIN: A/B build (plain stores).
 __device__ __forceinline__ void st4(float* p, f32x4 v) {
-#ifdef MDT_ST_WT
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
+#if defined(MDT_ST_PLAIN)
     *(f32x4*)p = v;
+#elif defined(MDT_ST_NT)
+    __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #endif
 }
 __device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a : b; }
@@ -1044,7 +1049,7 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
         // ---- epilogue (as gemm_tile): lane holds out[mrow][ncol .. ncol+3]; operands fetched at entry
         v = apply_act(v + e_bias, a.act);
         if (a.residual) v = e_res + (e_gated ? e_gate * v : v);
-        if (mok) st4(a.out + e_oo, v);
+        if (mok) *(f32x4*)(a.out + e_oo) = v;  // (rollout-sized launches: plain stores, write-through costs them 0.8 %)
     }
 }
 
@@ -1140,7 +1145,7 @@ __device__ __forceinline__ void attn_proj_tile(const mdt_gemm_args& a, const flo
         const bool mok = mrow < T;
         v = v + e_bias;
         if (a.residual) v = e_res + (e_gated ? e_gate * v : v);
-        if (mok) st4(a.out + e_oo, v);
+        if (mok) *(f32x4*)(a.out + e_oo) = v;  // (rollout-sized launches: plain stores, write-through costs them 0.8 %)
     }
 }
 
@@ -1674,7 +1679,7 @@ __device__ __forceinline__ void xattn_tile(const mdt_xapply_args& a, int b, floa
                     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q.wf[j][kc][e], pv[kc][e], acc, 0, 0, 0);
                 const f32x4 yn = yold[j] + (q.bo[j] + acc);
                 if constexpr (OL) *(f32x4*)(yo + (lane & 15) * yos + (wave * NTW + j) * 16 + nq) = yn;
-                if ((lane & 15) < Ta && wr) *(f32x4*)(yb + (wave * NTW + j) * 16 + nq) = yn;
+                if ((lane & 15) < Ta && wr) st4(yb + (wave * NTW + j) * 16 + nq, yn);
             }
     }
     if constexpr (YL) { MDT_TS(6) } else { MDT_TS(4) }
