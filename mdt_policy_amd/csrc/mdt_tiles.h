@@ -139,12 +139,24 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 #else
 #define MDT_SCHED_PIN __builtin_amdgcn_sched_barrier(0x6);
 #endif
+// timing experiments only (WRONG results; tools/gpu_alone.sh, profiles/r03_mlp_alone_probe.txt): k-steps without their weight
+// loads (-DMDT_EXP_NOLOAD) / without their LDS reads (-DMDT_EXP_NOLDS)
+#ifdef MDT_EXP_NOLOAD
+#define MDT_EXP_LDG(p, old) (old)
+#else
+#define MDT_EXP_LDG(p, old) ldg4(p)
+#endif
+#ifdef MDT_EXP_NOLDS
+#define MDT_EXP_LDS(x, old) (old)
+#else
+#define MDT_EXP_LDS(x, old) (x)
+#endif
 // one k-step of the MFMA main loop (uses the enclosing kernel's ring / wp / ap / stride / acc / kg / K16): prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
 #define MDT_KSTEP(U, KC)                                                                                  \
     {                                                                                                     \
         const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
         _Pragma("unroll") for (int j = 0; j < NTW; ++j) ring[((U) + R - 1) % R][j] =                      \
-            ldg4(wp[j] + kpf * 256);                                                                      \
+            MDT_EXP_LDG(wp[j] + kpf * 256, ring[((U) + R - 1) % R][j]);                                   \
         MDT_SCHED_PIN                                                                                     \
         MDT_PRIO(1)                                                                                       \
         MDT_KSTEP_MFMAS(U, 0)                                                                             \
@@ -152,7 +164,7 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
         f32x4 avn[MTILES]; /* activation fragments of the NEXT k-step, requested behind the first quarter of the MFMAs: \
                               whatever LDS wait the compiler puts at the top of a step then finds them long landed */ \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
-            *(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16);                           \
+            MDT_EXP_LDS(*(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16), av[i]);       \
         MDT_SCHED_PIN                                                                                     \
         MDT_KSTEP_MFMAS(U, 1)                                                                             \
         MDT_KSTEP_MFMAS(U, 2)                                                                             \

@@ -1,5 +1,6 @@
 #!/bin/bash
-# scheduling barriers in the GEMM k-steps (product) vs -DMDT_NO_SCHED_PIN, with and without the k_mlp wave skew
+# scheduling barriers in the GEMM k-steps (product) vs -DMDT_NO_SCHED_PIN (libmdt_hip_nopin.so), with and without the k_mlp wave skew;
+# phase stamps of both waves of a SIMD from the -DMDT_DEBUG_TIMING build (libmdt_hip_dbg.so)
 TAG=${1:-pin}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
 timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -n 3 --timeout 300 -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "tests exit $?"; tail -2 $OUT/pytest.log
 for rep in 1 2; do for lib in libmdt_hip.so libmdt_hip_nopin.so; do for v in 0 6; do
