@@ -36,6 +36,27 @@ def test_bench_two_ranks_over_rccl():
     assert j["value"] > 0
 
 
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_bench_two_ranks_sharing_one_gpu_over_gloo():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, barrier + synchronize around the timed
+    region, MAX over ranks, one gather of the sampled actions per call, rank 0 prints ONE JSON line) on a box with a single GPU:
+    both ranks use device 0 and gather through gloo (MDT_BENCH_SHARE_GPU / MDT_BENCH_BACKEND; the numbers mean nothing)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MDT_BENCH_VERIFY_GATHER="1", MDT_BENCH_SHARE_GPU="1", MDT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "32", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the bench line"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 2 and j["warmup"] == 1
+    assert j["config"]["global_batch"] == 2 * j["config"]["batch_per_gpu"] == 64
+    assert j["collective"]["backend"] == "gloo" and j["collective"]["ranks"] == 2 and j["collective"]["rccl_ranks"] == 0
+    assert j["collective"]["gather_verified"] is True
+    assert j["value"] > 0 and abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
+
+
 _RAGGED_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["MDT_ROOT"])
