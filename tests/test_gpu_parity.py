@@ -95,6 +95,29 @@ def test_g3_b256_full_size(tag):
     assert_close(out.cpu(), fx["actions"], what=f"B=256 actions ({tag})")
 
 
+def test_b256_sampler_call_is_bit_reproducible_across_wave_schedules():
+    """The full-size call 150 times over: the same bits every time, and the same bits whether the fused MLP launch runs its
+    waves in lockstep (workgroup barrier) or skewed with LDS flags (a lost flag or a stale hidden column would differ)."""
+    from mdt_policy_amd import _lib
+    L = _lib.load()
+    meta, fx = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    sig = torch.from_numpy(fx["sigmas"])
+    gs = sampling()
+    try:
+        with torch.no_grad():
+            L.mdt_op_set_mlp_skew(0)
+            want = gs.sample_ddim(model, state, noise * meta["sigma_max"], goal, sig).clone()
+            L.mdt_op_set_mlp_skew(-1)
+            for i in range(150):
+                got = gs.sample_ddim(model, state, noise * meta["sigma_max"], goal, sig)
+                if i % 10 == 0 or i == 149:
+                    assert torch.equal(got, want), f"call {i} differs from the lockstep result"
+    finally:
+        L.mdt_op_set_mlp_skew(-1)
+
+
 def test_g3_eval_schedule_and_hoisting():
     meta, fx = load_fixture("g3_b8_smin1.npz")
     model = build(meta)
