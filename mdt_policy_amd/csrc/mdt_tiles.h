@@ -102,8 +102,12 @@ __device__ __forceinline__ float hsq4(f32x4 v) { return (v.x * v.x + v.y * v.y) 
 #if defined(MDT_DEBUG_TIMING) && defined(MDT_TILES_TIMING_OWNER)
 // tuning-only build (-DMDT_DEBUG_TIMING): thread 0 of every workgroup records shader-clock stamps of its phases
 __device__ unsigned long long* g_dbg_ts = nullptr;
-// (thread 256 -- wave 4, the SIMD partner of wave 0 -- stamps too, into a second block of rows behind the grid's)
 #define MDT_TS(i)                                                                         \
+    if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
+        g_dbg_ts[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();            \
+    }
+// mlp_tile: thread 256 -- wave 4, the SIMD partner of wave 0 -- stamps too, into a second block of rows behind the grid's
+#define MDT_TS2(i)                                                                        \
     if ((threadIdx.x & 255) == 0 && g_dbg_ts != nullptr) {                               \
         g_dbg_ts[((size_t)blockIdx.x + (threadIdx.x >> 8) * gridDim.x) * 8 + (i)] = __builtin_readcyclecounter(); \
     }
@@ -116,6 +120,7 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
     }
 #else
 #define MDT_TS(i)
+#define MDT_TS2(i)
 #define MDT_TS_HWID()
 #endif
 
@@ -780,7 +785,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
                                          int tid, int skew_arg = 0) {
     const int skew = skew_arg & 0xff;
     const bool prio = (skew_arg & 0x100) != 0;  // MFMA loops at raised issue priority (the partner's VALU epilogue fills the gaps)
-    MDT_TS(0)
+    MDT_TS2(0)
     MDT_TS_HWID()
     constexpr int MTILES = 2, NWAVES = 8, MT = 32, HS = 512, HSTR = HS + 4, NTW1 = 4;
     constexpr bool KSTEP_PRIO = false;
@@ -821,9 +826,9 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
 #pragma unroll
         for (int j = 0; j < NTW1; ++j) acc1[i][j] = zero4;
     gemm_stage_tile<MTILES, NWAVES, PRO, false>(f, xn, stride1, m0, 0, D, zeros, tid, lane, wave);
-    MDT_TS(1)
+    MDT_TS2(1)
     __syncthreads();
-    MDT_TS(2)
+    MDT_TS2(2)
     {
         constexpr int NTW = NTW1, R = R1;
         const int K16 = K16a, nk = K16a, stride = stride1, kg = 0;
@@ -857,7 +862,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
     }
-    MDT_TS(3)
+    MDT_TS2(3)
     // ---- phase 2 operands, requested before the activation epilogue so that they travel while it runs: the first
     //      fragments of W2's K-slice [512 s, 512 s + 512), then bias / gate / residual rows of the output tile ----
     const int K16b = HS >> 4;  // k16 steps of the slice
@@ -899,7 +904,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
 #pragma unroll
         for (int j = 0; j < NTW1; ++j)
             *(f32x4*)(hs + (i * 16 + (lane & 15)) * HSTR + (wave * NTW1 + j) * 16 + nq) = apply_act(acc1[i][j] + b1[j], f.act);
-    MDT_TS(4)
+    MDT_TS2(4)
     unsigned ready = 0xffu;  // bit c: the 64 hidden columns of chunk c (wave c's) are known to be in LDS
     if (skew > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's hidden columns have landed
@@ -940,7 +945,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
 #undef MDT_KSTEP_C
         if (prio) __builtin_amdgcn_s_setprio(0);
     }
-    MDT_TS(5)
+    MDT_TS2(5)
     float* out = parts + (int64_t)s * part_stride;
 #pragma unroll
     for (int i = 0; i < MTILES; ++i) {
@@ -952,7 +957,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
             if (m < f.M) st4(out + (int64_t)m * p.ldo + ncol[j], v);
         }
     }
-    MDT_TS(6)
+    MDT_TS2(6)
 }
 
 // ------------------------------------------------------------------------------------------------
