@@ -973,6 +973,7 @@ template <bool COH, bool XL = false>
 __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_tile, int m0, float* s_stat, float* red,
                                                  const float* __restrict__ zeros, int tid, const float* xl = nullptr, int xls = 0,
                                                  int rows = 16) {
+    MDT_TS(0)
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int K16 = a.K >> 4;
@@ -1016,7 +1017,9 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
         }
         sq = half_wave_sum(sq);
         if (l32 == 0) { s_mean[r] = mean; s_rstd[r] = 1.0f / sqrtf(sq / (float)a.K + 1e-5f); }
+        MDT_TS(1)
         __syncthreads();
+        MDT_TS(2)
     }
     const int mrow = m0 + (lane & 15);
     const int64_t mc = min(mrow, a.M - 1);
@@ -1057,8 +1060,10 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
             }
         }
     }
+    MDT_TS(3)
     *(f32x4*)(red + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
+    MDT_TS(4)
     if (wave == 0) {
         f32x4 v = *(const f32x4*)(red + lane * 4);
 #pragma unroll
@@ -1068,6 +1073,7 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
         if (a.residual) v = e_res + (e_gated ? e_gate * v : v);
         if (mok) *(f32x4*)(a.out + e_oo) = v;  // (rollout-sized launches: plain stores, write-through costs them 0.8 %)
     }
+    MDT_TS(5)
 }
 
 // ------------------------------------------------------------------------------------------------
