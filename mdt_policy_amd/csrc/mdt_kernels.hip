@@ -1048,18 +1048,18 @@ hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t s
 // action head: decoder LN -> action_pred -> EDM combine -> (DDIM update) -> (next step's embedding)
 // one wave per action-token row; A <= 16
 // ------------------------------------------------------------------------------------------------
-// body in mdt_tiles.h (head_rows): each wave handles 2 rows
+// body in mdt_tiles.h (head_rows): each wave handles ONE row
 template <int AMAX, int XP>
 __global__ __launch_bounds__(256) void k_head(mdt_head_args a, const float* __restrict__ zeros) {
-    const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int base = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (base >= a.M) return;  // wave-uniform
-    head_rows<AMAX, false, XP>(a, base, threadIdx.x & 63, zeros);
+    head_rows<AMAX, false, XP, 1>(a, base, threadIdx.x & 63, zeros);
 }
 
 hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
     hipError_t e = ensure_zeros();
     if (e != hipSuccess) return e;
-    const int grid = (a.M + 7) / 8;  // 4 waves x 2 rows per workgroup
+    const int grid = (a.M + 3) / 4;  // 4 waves x 1 row per workgroup
     if (a.y_parts > 1) {  // rows = the sum of a fused MLP's slabs
         if (a.A > 8 || a.y_parts > 4) return hipErrorInvalidValue;
         switch (a.y_parts) {

@@ -1329,13 +1329,15 @@ __device__ __forceinline__ float edm_c_in(float sigma, float sd) { return 1.0f /
 
 // ------------------------------------------------------------------------------------------------
 // action head rows: decoder LN -> action_pred -> EDM combine -> (DDIM update) -> (next step's embedding) for rows
-// base, base + 1 (one wave per RW = 2 rows so that the action_pred / action_emb weight fragments it fetches are used
+// base .. base + RW - 1 (RW = 2: the action_pred / action_emb weight fragments a wave fetches are used
 // twice); AMAX (8 or 16) bounds the action dimension at compile time so no load sits behind a branch.
 // The caller guarantees base < a.M (wave-uniform).
 // ------------------------------------------------------------------------------------------------
-template <int AMAX, bool COH, int XP = 1>
+// RW = rows per wave: 2 in the persistent kernel (the fragments of action_pred / action_emb it fetches are used twice), 1 in
+// k_head (twice the waves, half the dot products per wave: the launch is a latency chain -- B = 256 sampler call 4.712 -> 4.686 ms,
+// four rows per wave 4.705).
+template <int AMAX, bool COH, int XP = 1, int RW = 2>
 __device__ __forceinline__ void head_rows(const mdt_head_args& a, int base, int lane, const float* __restrict__ zeros) {
-    constexpr int RW = 2;
     const int n4 = a.D >> 2;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const ActLd<COH> LY(a.y), LX(a.x);
