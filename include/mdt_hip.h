@@ -218,11 +218,19 @@ uint32_t mdt_fnv1_32(const void *buf, uint64_t len, uint32_t seed);
  * other way round.  With an allocator installed the buffers live in the host's pool: `alloc(bytes, user)` returns a device
  * pointer (256-byte aligned, on the current device) or NULL when it cannot; `free_(ptr, user)` releases one -- the library
  * calls it only after hipDeviceSynchronize() (growing a buffer) or from the destroy functions.  NULL, NULL restores
- * hipMalloc / hipFree; buffers are released through whatever allocated them.  Process-wide; install it before the first
- * forward.  (The Python facade installs torch.cuda.caching_allocator_alloc / _delete.) */
+ * hipMalloc / hipFree; buffers are released through whatever allocated them.  The switch is PROCESS-WIDE and takes effect for
+ * every later allocation of every component (denoiser handles, Perceiver resampler, contrastive head, training tapes), whenever
+ * it is made: buffers that already exist stay with the allocator they came from.  (The Python facade installs
+ * torch.cuda.caching_allocator_alloc / _delete on every engine construction -- idempotent.) */
 typedef void *(*mdt_alloc_fn)(size_t bytes, void *user);
 typedef void (*mdt_free_fn)(void *ptr, void *user);
 mdt_status mdt_set_allocator(mdt_alloc_fn alloc, mdt_free_fn free_, void *user);
+
+/* Host shutdown: restore hipMalloc / hipFree AND forget the release callbacks of the buffers the installed allocator handed
+ * out so far -- a later destroy call then DROPS such a buffer instead of calling `free_` (the host's pool is going away with
+ * the process; its callbacks may already be gone).  The Python facade calls it from an atexit hook, so that a handle whose
+ * finaliser runs during interpreter teardown never calls into a freed ctypes closure. */
+mdt_status mdt_allocator_detach(void);
 
 #ifdef __cplusplus
 }

@@ -206,7 +206,7 @@ mdt_status mdt_op_xattn_apply(const mdt_xapply_args *args, void *stream);
  * writes the new rows to x->y_out, which must be given and differ from x->y (the other workgroups may still be reading x->y).
  * `g` as for mdt_op_gemm with g->A == x->y, lda = K = x->D, M = x->B * x->Ta, rows_per_sample = x->Ta, no residual / row remap /
  * split input.  Results equal the two launches bit for bit.  The model-level entry points use it up
- * to 8 samples (MDT_HIP_XATTN_FC_MAX_B). */
+ * to 2 samples (MDT_HIP_XATTN_FC_MAX_B overrides; B = 4 measured slower: 1.67 vs 1.58 ms per call). */
 mdt_status mdt_op_xattn_gemm(const mdt_xapply_args *x, const mdt_gemm_args *g, void *stream);
 
 /* The middle of a ConditionedBlock for a batch of at most one sample per compute unit, ONE launch, one workgroup per sample

@@ -157,6 +157,7 @@ SYMBOLS = [
     ("mdt_last_error", C.c_char_p, []),
     ("mdt_version", C.c_char_p, []),
     ("mdt_set_allocator", _I32, [_VP, _VP, _VP]),
+    ("mdt_allocator_detach", _I32, []),
     ("mdt_create", _I32, [C.POINTER(MDTConfig), C.POINTER(_VP)]),
     ("mdt_destroy", _I32, [_VP]),
     ("mdt_param_count", _I64, [_VP]),

@@ -41,13 +41,18 @@ PUBLIC_HEADERS = ["mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool
 
 def _compile_one(args):
     src, obj, defines, verbose = args
+    tmp = f"{obj}.tmp.{os.getpid()}"  # compile beside the target, then rename: several ranks that find a stale library and
+    #                                   build at the same time never link each other's half-written objects
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", "-Wall", "-Wno-unused-function",
-           f"-I{INCLUDE}", f"-I{CSRC}", "-o", obj] + [f"-D{d}" for d in defines] + [src]
+           f"-I{INCLUDE}", f"-I{CSRC}", "-o", tmp] + [f"-D{d}" for d in defines] + [src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n" + res.stdout + res.stderr)
+    os.replace(tmp, obj)
     return res.stderr
 
 

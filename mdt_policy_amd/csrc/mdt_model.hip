@@ -66,6 +66,14 @@ extern "C" mdt_status mdt_set_allocator(mdt_alloc_fn alloc, mdt_free_fn free_, v
     return MDT_OK;
 }
 
+extern "C" mdt_status mdt_allocator_detach(void) {
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    g_alloc = nullptr; g_free = nullptr; g_alloc_user = nullptr;
+    // the entries stay, with a null callback: mdt_dev_free must still tell these pointers from hipMalloc'ed ones
+    if (g_custom_free) for (auto& kv : *g_custom_free) kv.second = std::make_pair((mdt_free_fn)nullptr, (void*)nullptr);
+    return MDT_OK;
+}
+
 hipError_t mdt_dev_malloc(void** p, size_t bytes) {
     mdt_alloc_fn fn; mdt_free_fn ff; void* user;
     { std::lock_guard<std::mutex> lock(g_alloc_mu); fn = g_alloc; ff = g_free; user = g_alloc_user; }
@@ -82,14 +90,18 @@ hipError_t mdt_dev_malloc(void** p, size_t bytes) {
 hipError_t mdt_dev_free(void* p) {
     if (p == nullptr) return hipSuccess;
     std::pair<mdt_free_fn, void*> how(nullptr, nullptr);
+    bool custom = false;
     {
         std::lock_guard<std::mutex> lock(g_alloc_mu);
         if (g_custom_free) {
             auto it = g_custom_free->find(p);
-            if (it != g_custom_free->end()) { how = it->second; g_custom_free->erase(it); }
+            if (it != g_custom_free->end()) { how = it->second; custom = true; g_custom_free->erase(it); }
         }
     }
-    if (how.first) { how.first(p, how.second); return hipSuccess; }
+    if (custom) {  // from an installed allocator: its callback, or nothing at all once the host detached (mdt_allocator_detach)
+        if (how.first) how.first(p, how.second);
+        return hipSuccess;
+    }
     return hipFree(p);
 }
 
@@ -764,7 +776,8 @@ static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_
     p.residual = 1; p.rows_per_sample = T;
     if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
     if (out) *out = Stream();
-    if (out && M >= g_mlp_fuse_min_rows() && mdt_mlp_slices(D) >= 2 && mdt_mlp_supported(g, p)) {
+    // (never with `pre_x`: the caller skipped its own cross-attention launch because the c_fc launch was to run it)
+    if (out && !pre_x && M >= g_mlp_fuse_min_rows() && mdt_mlp_slices(D) >= 2 && mdt_mlp_supported(g, p)) {
         // the hidden buffer (M x 4D) is free in this form: it holds the S <= 4 slabs of (M x D)
         p.ldo = D;
         const int64_t stride = (int64_t)M * D;

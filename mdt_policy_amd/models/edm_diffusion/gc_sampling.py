@@ -148,6 +148,13 @@ _GRAPH_SAMPLER = _GRAPH_MODE not in ("", "0", "auto")
 _GRAPH_AUTO_MAX_BATCH, _GRAPH_AUTO_AFTER = 8, 2
 
 
+def _graph_key(state, action, goal, sigmas):
+    """Hashable for any `state` content: tensors by shape, everything else by type and repr (a list or dict value is legal)."""
+    return (tuple(action.shape), tuple(goal.shape), len(sigmas),
+            tuple(sorted((str(k), tuple(v.shape) if torch.is_tensor(v) else (type(v).__name__, repr(v)))
+                         for k, v in state.items())))
+
+
 def _graph_wanted(model, state, action, goal, sigmas) -> bool:
     if action.device.type != "cuda" or model.inner_model.training or torch.cuda.is_current_stream_capturing():
         return False
@@ -155,8 +162,9 @@ def _graph_wanted(model, state, action, goal, sigmas) -> bool:
         return True
     if _GRAPH_MODE != "auto" or action.shape[0] > _GRAPH_AUTO_MAX_BATCH:
         return False
-    key = (tuple(action.shape), tuple(goal.shape), len(sigmas),
-           tuple(sorted((k, tuple(v.shape) if torch.is_tensor(v) else v) for k, v in state.items())))
+    key = _graph_key(state, action, goal, sigmas)
+    if key in model.__dict__.get("_graph_failed", ()):
+        return False  # a capture of this call failed once: it stays eager
     seen = model.__dict__.setdefault("_graph_seen", {})
     seen[key] = seen.get(key, 0) + 1
     if len(seen) > 16:
@@ -185,7 +193,17 @@ def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None
     extra_args = {} if extra_args is None else extra_args
     if isinstance(model, GCDenoiser) and scaler is None and callback is None and not extra_args:
         if _graph_wanted(model, state, action, goal, sigmas):
-            return _graphed(model, state, action, goal, sigmas)  # the same launches, replayed as a HIP graph
+            if _GRAPH_SAMPLER:
+                return _graphed(model, state, action, goal, sigmas)  # the same launches, replayed as a HIP graph
+            try:  # auto mode: a capture that fails (another thread allocating / synchronising while torch's global capture
+                #   mode is on, ...) must not break a rollout the eager path would have served
+                return _graphed(model, state, action, goal, sigmas)
+            except Exception as exc:  # noqa: BLE001 -- whatever the capture raised, the eager launches below still work
+                model.__dict__.setdefault("_graph_failed", set()).add(_graph_key(state, action, goal, sigmas))
+                model.__dict__.pop("_graphed_samplers", None)
+                import warnings
+                warnings.warn(f"mdt_policy_amd: HIP-graph capture of sample_ddim failed ({exc!r}); this call shape stays eager")
+                torch.cuda.synchronize()
         return model.sample_ddim(state, action, goal, sigmas)  # fused native loop
     sig = _host(sigmas)
     with _hoist(model, state, goal):

@@ -49,4 +49,21 @@ def install() -> bool:
         lib = _lib.load()
         _lib.check(lib.mdt_set_allocator(a, f, None))
         _installed = (a, f)
+        # The callbacks must outlive every handle: a module global alone can be cleared at interpreter shutdown before a
+        # surviving HipEngine.__del__ / resampler destroy runs, and the library would call a freed ffi closure.  Pin them on
+        # the CDLL object AND leak one reference each (never collected); at exit switch the library back to its own
+        # hipMalloc / hipFree pair -- buffers that came from torch are then dropped without a call into a half torn-down torch
+        # (mdt_allocator_detach, include/mdt_hip.h).
+        lib._mdt_allocator_callbacks = (a, f)
+        C.pythonapi.Py_IncRef(C.py_object(a))
+        C.pythonapi.Py_IncRef(C.py_object(f))
+        import atexit
+        atexit.register(_uninstall_at_exit, lib)
         return True
+
+
+def _uninstall_at_exit(lib) -> None:
+    try:
+        lib.mdt_allocator_detach()
+    except Exception:  # pragma: no cover -- shutdown path
+        pass

@@ -199,6 +199,48 @@ def test_against_oracle_random_batch_sizes():
         assert_close(got.cpu(), want, what=f"B={B}")
 
 
+# one batch size per regime of the launch dispatcher (mdt_model.hip: run_self_attn / run_mlp / run_decoder_blocks and the
+# geometry choice of mdt_launch_gemm): half-height 16 x 64 tiles (192 < M <= 1400 rows: B = 20 ... 140), the last batch before
+# / the first batch on the one-workgroup-per-sample middle + the fused MLP launch (1401 rows: B = 140 | 141), the second round
+# of per-sample workgroups (B = 257 ... 512), and the first batch beyond it (B = 513: k_attn + GEMM + k_xattn_apply again)
+REGIME_BATCHES = (20, 64, 128, 140, 141, 257, 300, 512, 513)
+
+
+@pytest.mark.parametrize("B", REGIME_BATCHES)
+def test_every_dispatcher_regime_against_the_oracle(B):
+    """3-step sample_ddim (gc_sampling.py:922-951) on fresh seeded inputs, HIP vs the CPU oracle, at one batch size per
+    kernel-selection regime: the op-level tests pin each kernel, this pins their composition."""
+    meta, _ = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    cfg, P = cfg_of(meta), params_of(meta)
+    sig = O.get_sigmas_exponential(3, 0.01, 80.0)
+    m2 = dict(meta, B=B, input_seed=700 + B)
+    state, goal, noise = inputs_of(m2)
+    want = O.sample_ddim(P, cfg, state, noise * 80.0, goal, sig, hoist=True)
+    with torch.no_grad():
+        got = sampling().sample_ddim(model, {"state_images": state["state_images"].cuda(), "modality": "lang"},
+                                     noise.cuda() * 80.0, goal.cuda(), sig)
+    assert_close(got.cpu(), want, what=f"B={B} actions")
+
+
+@pytest.mark.parametrize("B", (128, 300))
+def test_denoiser_forward_with_per_sample_sigma_in_the_mid_batch_regimes(B):
+    """GCDenoiser.forward (score_wrappers.py:65-80) with one sigma per sample (adaLN rows per sample: PRO_LN_MOD_ROWS, the
+    per-sample gate of the epilogues) at batch sizes between the small-M and the B = 256 kernels, HIP vs the oracle."""
+    meta, _ = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    cfg, P = cfg_of(meta), params_of(meta)
+    m2 = dict(meta, B=B, input_seed=900 + B)
+    state, goal, noise = inputs_of(m2)
+    g = torch.Generator().manual_seed(31 + B)
+    sigma = torch.exp(torch.rand(B, generator=g) * 8.0 - 5.0)  # 0.0067 ... 20
+    x = noise * sigma[:, None, None]
+    want = O.denoise(P, cfg, state, x, goal, sigma)
+    with torch.no_grad():
+        got = model({"state_images": state["state_images"].cuda(), "modality": "lang"}, x.cuda(), goal.cuda(), sigma.cuda())
+    assert_close(got.cpu(), want, what=f"B={B} denoised, per-sample sigma")
+
+
 def test_full_size_properties():
     """Size-independent properties at B=256: determinism and batch independence (a sample's actions do not
     depend on what else is in the batch).  Bit-exact between batches served by the same GEMM kernel (the k-order of
