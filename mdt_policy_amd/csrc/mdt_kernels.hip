@@ -28,6 +28,7 @@
 
 #define MDT_TILES_TIMING_OWNER  // this translation unit owns the -DMDT_DEBUG_TIMING stamp buffer
 #include "mdt_tiles.h"  // the tile bodies (shared with the persistent decoder kernel, mdt_persist.hip)
+#include "mdt_tall.h"   // the tall LDS-staged GEMM body (round 4)
 
 // ------------------------------------------------------------------------------------------------
 // weight packing
@@ -440,6 +441,40 @@ static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStre
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gemm_tall: 128-row tiles, both operands through LDS by LDS-DMA (body: mdt_tall.h).  Plain prologue, K % 32 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int NT, int NS, bool RES, int LW>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void k_gemm_tall(mdt_gemm_args a, int grid_n, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical / grid_n, bx = logical - by * grid_n;
+    gemm_tall_tile<WM, WN, NT, NS, RES, LW>(a, by, bx, lds, zeros, threadIdx.x);
+}
+bool mdt_gemm_tall_supported(const mdt_gemm_args& a) {
+    return !a.ln && a.a_parts <= 1 && a.batch <= 1 && a.K % MDT_TALL_BK == 0 && (a.N & 15) == 0 && a.M >= 1 && (a.lda & 3) == 0 &&
+           (a.aux_mode == 0 || ((a.aux_mode == 1 || a.aux_mode == 2) && !a.residual));
+}
+template <int WM, int WN, int NT, int NS, bool RES, int LW>
+static hipError_t launch_gemm_tall_r(const mdt_gemm_args& a, hipStream_t s) {
+    constexpr int BM = WM * 64, BN = WN * NT * 16;
+    const int gn = (a.N + BN - 1) / BN, gm = (a.M + BM - 1) / BM;
+    const size_t lds = (size_t)NS * (BM + BN) * MDT_TALL_BK * sizeof(float);
+    static bool attr_dev[MAX_DEVICES] = {false};
+    bool& done = attr_dev[current_device()];
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tall<WM, WN, NT, NS, RES, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL((k_gemm_tall<WM, WN, NT, NS, RES, LW>), dim3(gn * gm), dim3(64 * (WM * WN + LW)), lds, s, a, gn, g_zeros);
+    return hipGetLastError();
+}
+template <int WM, int WN, int NT, int NS, int LW = 0>
+static hipError_t launch_gemm_tall(const mdt_gemm_args& a, hipStream_t s) {
+    return a.residual ? launch_gemm_tall_r<WM, WN, NT, NS, true, LW>(a, s) : launch_gemm_tall_r<WM, WN, NT, NS, false, LW>(a, s);
+}
+
 template <int MTILES, int NTW, int NWAVES, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
     return a.residual ? launch_gemm_r<MTILES, NTW, NWAVES, PRO, true>(a, kchunk, s)
@@ -710,7 +745,23 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
             if (a.N < 1024 && gn) geo = gn;
         }
     }
+    if (geo >= 10 && !mdt_gemm_tall_supported(a)) geo = 0;  // (forced geometry on a product the tall body does not take)
     switch (geo) {
+        // the tall body (mdt_tall.h): 128-row tiles, operands by LDS-DMA
+        case 10: return launch_gemm_tall<2, 2, 4, 2>(a, s);  // 4 waves 128 x 128, 2 stages (64 KiB: two workgroups per CU)
+        case 11: return launch_gemm_tall<2, 4, 2, 3>(a, s);  // 8 waves 128 x 128, 3 stages (96 KiB: one per CU)
+        case 12: return launch_gemm_tall<2, 2, 2, 2>(a, s);  // 4 waves 128 x 64,  2 stages (48 KiB: three per CU)
+        case 13: return launch_gemm_tall<2, 2, 6, 2>(a, s);  // 4 waves 128 x 192, 2 stages (80 KiB: two per CU)
+        case 14: return launch_gemm_tall<2, 2, 4, 3>(a, s);  // 4 waves 128 x 128, 3 stages (96 KiB)
+        case 15: return launch_gemm_tall<2, 4, 3, 2>(a, s);  // 8 waves 128 x 192, 2 stages (80 KiB)
+        case 16: return launch_gemm_tall<2, 2, 3, 2>(a, s);  // 4 waves 128 x 96,  2 stages (56 KiB: two per CU)
+        // ... with ONE loader wave issuing every DMA request of the workgroup
+        case 20: return launch_gemm_tall<2, 2, 4, 2, 1>(a, s);  // 4 + 1 waves 128 x 128, 2 stages
+        case 21: return launch_gemm_tall<2, 4, 2, 3, 1>(a, s);  // 8 + 1 waves 128 x 128, 3 stages
+        case 22: return launch_gemm_tall<2, 2, 2, 2, 1>(a, s);  // 4 + 1 waves 128 x 64,  2 stages
+        case 23: return launch_gemm_tall<2, 2, 2, 3, 1>(a, s);  // 4 + 1 waves 128 x 64,  3 stages (72 KiB: two per CU)
+        case 24: return launch_gemm_tall<2, 2, 4, 3, 1>(a, s);  // 4 + 1 waves 128 x 128, 3 stages
+        case 26: return launch_gemm_tall<2, 2, 3, 2, 1>(a, s);  // 4 + 1 waves 128 x 96,  2 stages
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
         case 2:
             if (!a.ln && a.K > 512 && !g_mdt_gemm_nopipe) {  // multi-chunk K: loader waves double-buffer the activation chunk

@@ -157,6 +157,7 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 #define MDT_EXP_LDS(x, old) (x)
 #endif
 // one k-step of the MFMA main loop (uses the enclosing kernel's ring / wp / ap / stride / acc / kg / K16): prefetch the fragment R-1 steps ahead (clamped, never branches), then 4 MFMAs per tile pair
+#ifndef MDT_KSTEP_SPREAD
 #define MDT_KSTEP(U, KC)                                                                                  \
     {                                                                                                     \
         const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
@@ -178,6 +179,40 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
         MDT_SCHED_PIN                                                                                     \
         _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
     }
+#else
+/* A/B form: the step's NTW fragment requests are SPREAD over the step, one in front of each quarter of its MFMAs, instead of
+   going out back to back at its top (tools/micro/wstream_probe.hip: 8 waves x 4 requests in one burst queue at the CU's one
+   address path and keep the issuing waves from their MFMAs: 117 -> 109 us for k_mlp's first product alone) */
+#define MDT_KSTEP_LD1(U, J)                                                                               \
+    if constexpr ((J) < NTW) {                                                                            \
+        ring[((U) + R - 1) % R][(J) < NTW ? (J) : 0] =                                                    \
+            MDT_EXP_LDG(wp[(J) < NTW ? (J) : 0] + kpf * 256, ring[((U) + R - 1) % R][(J) < NTW ? (J) : 0]); \
+        MDT_SCHED_PIN                                                                                     \
+    }
+#define MDT_KSTEP(U, KC)                                                                                  \
+    {                                                                                                     \
+        const int kpf = min(kg + (KC) + R - 1, K16 - 1);                                                  \
+        MDT_KSTEP_LD1(U, 0)                                                                               \
+        MDT_PRIO(1)                                                                                       \
+        MDT_KSTEP_MFMAS(U, 0)                                                                             \
+        MDT_SCHED_PIN                                                                                     \
+        f32x4 avn[MTILES];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) avn[i] =                                       \
+            MDT_EXP_LDS(*(const f32x4*)(ap + i * 16 * stride + min((KC) + 1, nk - 1) * 16), av[i]);       \
+        MDT_SCHED_PIN                                                                                     \
+        MDT_KSTEP_LD1(U, 1)                                                                               \
+        MDT_KSTEP_MFMAS(U, 1)                                                                             \
+        MDT_SCHED_PIN                                                                                     \
+        MDT_KSTEP_LD1(U, 2)                                                                               \
+        MDT_KSTEP_MFMAS(U, 2)                                                                             \
+        MDT_SCHED_PIN                                                                                     \
+        MDT_KSTEP_LD1(U, 3)                                                                               \
+        MDT_KSTEP_MFMAS(U, 3)                                                                             \
+        MDT_PRIO(0)                                                                                       \
+        MDT_SCHED_PIN                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < MTILES; ++i) av[i] = avn[i];                                \
+    }
+#endif
 #define MDT_KSTEP_MFMAS(U, E)                                                                             \
     _Pragma("unroll") for (int i = 0; i < MTILES; ++i) {                                                  \
         _Pragma("unroll") for (int j = 0; j < NTW; ++j) acc[i][j] =                                       \

@@ -118,6 +118,88 @@ def test_gemm_every_geometry(lib, geo, M, N, K, ln):
     assert_close(heur, ref, rtol=1e-5, atol=1e-5, what="heuristic choice vs tiled")
 
 
+TALL_GEOS = [10, 11, 12, 13, 14, 15, 16, 20, 21, 22, 23, 24, 26]
+
+
+@pytest.mark.parametrize("geo", TALL_GEOS)
+@pytest.mark.parametrize("M,N,K", [(2560, 1152, 384), (10240, 384, 1536), (300, 192, 64), (129, 1536, 384), (1, 16, 32),
+                                   (4000, 576, 192), (128, 112, 96)])
+def test_gemm_tall_body_bit_equals_the_row_tile_body(lib, geo, M, N, K):
+    """The tall body (mdt_tall.h: 128-row tiles, both operands staged in LDS by LDS-DMA, XOR-swizzled activation image) walks
+    K in the same order as gemm_tile: every geometry gives the same BITS -- full tiles, ragged rows, partial column tiles,
+    a single 32-deep K block -- and the right values against float64."""
+    g = torch.Generator().manual_seed(geo * 0 + M + N + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    y0 = torch.randn(M, N, generator=g)
+    want = (y0.double() + A.double() @ W.double().T + b.double()).float()
+    try:
+        lib.load().mdt_op_set_gemm_geometry(1)
+        ref = run_gemm(lib, A, W, bias=b, residual_into=y0)
+        lib.load().mdt_op_set_gemm_geometry(geo)
+        got = run_gemm(lib, A, W, bias=b, residual_into=y0)
+    finally:
+        lib.load().mdt_op_set_gemm_geometry(0)
+    assert_close(got, want, rtol=1e-4, atol=1e-4, what=f"tall geometry {geo}")
+    assert torch.equal(got, ref), "tall body and row-tile body disagree bitwise"
+
+
+@pytest.mark.parametrize("geo", [10, 11, 13])
+def test_gemm_tall_body_epilogues(lib, geo):
+    """Every epilogue the tall body carries, against the row-tile body (bitwise) and float64: bias + GELU, per-sample gate +
+    residual, token-row remap + row vector, and the two training hooks (aux_mode 1: pre-activation kept; 2: act'(aux))."""
+    L = lib.load()
+    g = torch.Generator().manual_seed(geo)
+    B, T, D, K = 31, 10, 384, 1536
+    M = B * T
+    A, W = torch.randn(M, K, generator=g), torch.randn(D, K, generator=g) / math.sqrt(K)
+    y0, mod, b = torch.randn(M, D, generator=g), torch.randn(B, 6 * D, generator=g), torch.randn(D, generator=g)
+    tok, Wt, pos = torch.randn(B * 3, 128, generator=g), torch.randn(D, 128, generator=g) / 10, torch.randn(D, generator=g)
+    outs = {}
+    try:
+        for gsel in (1, geo):
+            L.mdt_op_set_gemm_geometry(gsel)
+            o = {}
+            o["gelu"] = run_gemm(lib, A, W, bias=b, act="gelu")
+            o["gated"] = run_gemm(lib, A, W, residual_into=y0, mod=mod, mod_stride=6 * D, rps=T, gate_off=5 * D)
+            o["remap"] = run_gemm(lib, tok, Wt, gin=3, gout=4, goff=1, rowvec=pos, out_rows=B * 4)
+            # training hooks through the raw argument block
+            Ad, Pd, bd = dev(A), pack(lib, W), dev(b)
+            for mode in (1, 2):
+                out = torch.full((M, D), float("nan"), device="cuda")
+                aux = torch.full((M, D), float("nan"), device="cuda") if mode == 1 else dev(y0)
+                a = lib.GemmArgs()
+                a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = Ad.data_ptr(), K, Pd.data_ptr(), out.data_ptr(), D, M, D, K
+                a.bias = bd.data_ptr() if mode == 1 else None
+                a.shift_off = a.scale_off = a.gate_off = -1
+                a.rows_per_sample = a.gin = a.gout = 1
+                a.act, a.aux, a.aux_mode = lib.ACT["gelu"], aux.data_ptr(), mode
+                # (aux needs K <= 512 in the row-tile body: use a K slice for this pair)
+                a.K, a.lda = 384, K
+                Pk = pack(lib, W[:, :384].contiguous())
+                a.Wp = Pk.data_ptr()
+                lib.check(L.mdt_op_gemm(C.byref(a), stream()))
+                torch.cuda.synchronize()
+                o[f"aux{mode}"] = out.cpu()
+                if mode == 1:
+                    o["aux1_pre"] = aux.cpu()
+            outs[gsel] = o
+    finally:
+        L.mdt_op_set_gemm_geometry(0)
+    for k in outs[1]:
+        a_, b_ = outs[1][k], outs[geo][k]
+        assert torch.equal(torch.nan_to_num(a_, nan=7.0), torch.nan_to_num(b_, nan=7.0)), f"{k}: tall body differs from the row-tile body"
+    v = A.double() @ W.double().T
+    assert_close(outs[geo]["gelu"], F.gelu(v + b.double()).float(), rtol=1e-4, atol=1e-4, what="bias + GELU")
+    assert_close(outs[geo]["gated"], (y0.double() + v * mod[:, 5 * D:].double().repeat_interleave(T, 0)).float(), rtol=1e-4,
+                 atol=1e-4, what="gated residual")
+    u = A[:, :384].double() @ W[:, :384].double().T
+    assert_close(outs[geo]["aux1_pre"], (u + b.double()).float(), rtol=1e-4, atol=1e-4, what="aux_mode 1: pre-activation")
+    assert_close(outs[geo]["aux1"], F.gelu(u + b.double()).float(), rtol=1e-4, atol=1e-4, what="aux_mode 1: activated")
+    y64 = y0.double().requires_grad_()
+    F.gelu(y64).sum().backward()
+    assert_close(outs[geo]["aux2"], (u * y64.grad).float(), rtol=1e-4, atol=2e-4, what="aux_mode 2: value * act'(aux)")
+
+
 @pytest.mark.parametrize("M", [1, 10, 16, 17, 40, 160, 192, 193])
 @pytest.mark.parametrize("case", ["plain", "ln_mod_rows", "ln_bias_bcast", "gated_residual_k1536", "remap_gelu"])
 def test_gemm_small_m_kernel_matches_reference_and_tiled(lib, M, case):
