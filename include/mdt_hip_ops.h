@@ -116,12 +116,18 @@ void mdt_op_set_mlp_fuse_min(int32_t rows);
 void mdt_op_set_mlp_skew(int32_t v);
 
 /* Tuning / test hook: force the workgroup geometry of every following GEMM launch in this process.
- * 0 = heuristic (default): for M <= 192 rows (rollout-sized batches) the split-K small-M kernel -- one workgroup per
- * 16 columns, K divided between its 8 waves -- for M <= 1400 the half-height tiled geometry 6, otherwise the widest
- * tiled geometry that still fills the chip;
- * 1 = 4 waves 32x64; 2 = 8 waves 32x128; 3 = 8 waves 32x384; 4 = 8 waves 32x512; 5 = 4 waves 32x128; 6 = 4 waves 16x64.
- * The tiled geometries compute bit-identical results (same k order per output element); the small-M kernel agrees
- * to rounding.  MDT_HIP_SMALLM_MAX / MDT_HIP_MID_MAX (environment) move the two row thresholds (0 disables). */
+ * 0 = heuristic (default): up to 15 rows the split-K small-M kernel -- one workgroup per 16 columns, K divided between its
+ * 8 waves --; up to 512 rows the same kernel for the products whose half-height tiling would have fewer than 60 (LayerNorm
+ * prologue) / 100 (plain, <= 192 rows) / 160 (plain, <= 512 rows) tiles; up to 1400 rows the half-height tiled geometry 6;
+ * beyond, the widest row-tile geometry that still fills the chip;
+ * 1 = 4 waves 32x64; 2 = 8 waves 32x128; 3 = 8 waves 32x384; 4 = 8 waves 32x512; 5 = 4 waves 32x128; 6 = 4 waves 16x64;
+ * 7 = 4 waves 64x128; 8 = 4 waves 32x256; 9 = 4 waves 32x192;
+ * 10 / 12 / 16 = the TALL body (128-row tiles, both operands staged in LDS by LDS-DMA; plain prologue, K % 32 == 0;
+ * anything else falls back to the heuristic): 4 waves 128x128 / 128x64 / 128x96; 23 = 128x64 with a loader wave, 3 stages;
+ * -1 = the split-K small-M kernel wherever it applies.
+ * Row-tile and tall geometries compute bit-identical results (same k order per output element); the small-M kernel agrees
+ * to rounding.  MDT_HIP_SMALLM_MAX / MDT_HIP_SMALLM_TILES / MDT_HIP_SMALLM_ROWS / MDT_HIP_MID_MAX (environment) move the
+ * thresholds. */
 void mdt_op_set_gemm_geometry(int32_t geometry);
 
 typedef struct {

@@ -63,6 +63,8 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, d
     if out is None and not force and not needs_build():
         return LIB
     out = out or LIB
+    if os.environ.get("MDT_BUILD_PERSIST", "0") not in ("", "0"):  # opt-in: the persistent decoder kernel (mdt_persist.hip)
+        defines = tuple(defines) + ("MDT_WITH_PERSIST",)
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     tag = hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:8] if defines else "default"

@@ -444,13 +444,23 @@ static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStre
 // ------------------------------------------------------------------------------------------------
 // k_gemm_tall: 128-row tiles, both operands through LDS by LDS-DMA (body: mdt_tall.h).  Plain prologue, K % 32 == 0.
 // ------------------------------------------------------------------------------------------------
+__constant__ int g_tall_stagger = 0;
 template <int WM, int WN, int NT, int NS, bool RES, int LW>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void k_gemm_tall(mdt_gemm_args a, int grid_n, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int by = logical / grid_n, bx = logical - by * grid_n;
+    // Workgroups that share a CU must not walk their stages in lockstep (the first round of a launch is dispatched all at once:
+    // every co-resident pair would sit at its barrier / wait for its fragments at the same moment, with nobody multiplying).
+    // The dispatcher fills the CUs round-robin, so workgroup b and b + 256 are (as a rule) neighbours on a CU: the later ones
+    // start a fraction of a stage behind.  Speed only.
+    if (g_tall_stagger > 0) {
+        const int slot = (blockIdx.x >> 8) % 3;
+        for (int i = 0; i < slot * g_tall_stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 clocks each
+    }
     gemm_tall_tile<WM, WN, NT, NS, RES, LW>(a, by, bx, lds, zeros, threadIdx.x);
 }
+extern "C" void mdt_op_set_tall_stagger(int32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tall_stagger), &v, sizeof(v)); }
 bool mdt_gemm_tall_supported(const mdt_gemm_args& a) {
     return !a.ln && a.a_parts <= 1 && a.batch <= 1 && a.K % MDT_TALL_BK == 0 && (a.N & 15) == 0 && a.M >= 1 && (a.lda & 3) == 0 &&
            (a.aux_mode == 0 || ((a.aux_mode == 1 || a.aux_mode == 2) && !a.residual));
@@ -518,6 +528,8 @@ __global__ __launch_bounds__(512) void k_xattn_gemm_smallm(mdt_xapply_args x, md
     gemm_smallm_tile<false, true>(a, blockIdx.x, b * x.Ta, s_stat, red, zeros, threadIdx.x, yo, ys, x.Ta);
 }
 
+static int g_mdt_smallm_rows = 512;   // ... up to this many rows (env MDT_HIP_SMALLM_ROWS)
+static int g_mdt_smallm_tiles = 0;    // 0: the measured rule below; > 0 (env MDT_HIP_SMALLM_TILES): one threshold for every product (A/B runs): fewer 16 x 64 tiles than this -> the split-K kernel (env MDT_HIP_SMALLM_TILES)
 static int g_mdt_smallm_max = -1;  // rows up to which k_gemm_smallm is used (env MDT_HIP_SMALLM_MAX, default below)
 
 int mdt_gemm_kchunk(int K, int ln, int cap) {
@@ -536,7 +548,7 @@ static hipError_t launch_gemm_pro(const mdt_gemm_args& a, int kchunk, hipStream_
     return launch_gemm_t<MTILES, NTW, NWAVES, PRO_LN>(a, kchunk, s);
 }
 
-int g_mdt_gemm_force = 0;  // tuning hook: 0 = heuristic, else 1..6 selects a geometry below
+int g_mdt_gemm_force = 0;  // tuning hook: 0 = heuristic, 1.. selects a geometry below, -1 = the split-K small-M kernel
 static const bool g_mdt_gemm_nopipe = getenv("MDT_HIP_NOPIPE") != nullptr;  // A/B switch for k_gemm_pipe
 
 // Self-attention of ONE sample fused into its output projection (k_attn_proj_smallm).  `p` is the projection's GEMM
@@ -661,9 +673,13 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (ze != hipSuccess) return ze;
     if (g_mdt_smallm_max < 0) {
         const char* e = getenv("MDT_HIP_SMALLM_MAX");
-        g_mdt_smallm_max = e ? atoi(e) : 192;  // measured crossover with the tiled kernel: M ~ 240 (tools/latency.py)
+        g_mdt_smallm_max = e ? atoi(e) : 15;  // one row tile; beyond it the tile-count rule below decides (round 1 had 192 rows here, before the half-height tiles)
         const char* f = getenv("MDT_HIP_MID_MAX");
         if (f) g_mdt_mid_max = atoi(f);
+        const char* t = getenv("MDT_HIP_SMALLM_TILES");
+        if (t) g_mdt_smallm_tiles = atoi(t);
+        const char* r = getenv("MDT_HIP_SMALLM_ROWS");
+        if (r) g_mdt_smallm_rows = atoi(r);
     }
     // (not for the batched split-K products of the weight gradients: few output rows there come with a DEEP reduction --
     // N = 192 layers of the masked-image decoder: 595 us as 16-column split-K tiles vs ~300 us tiled)
@@ -678,7 +694,16 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         return (a.N % 192 == 0) ? launch_gemm_glu<2, 3, 4, 4>(a, kc, s) : launch_gemm_glu<2, 2, 4, 4>(a, kc, s);
     }
     if (a.a_parts > 1) return launch_gemm_merge(a, s);
-    if (a.M <= g_mdt_smallm_max && !g_mdt_gemm_force && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {
+    // ... and beyond one row tile, the products whose half-height (16 x 64) tiling would leave most of the chip empty keep the
+    // split-K kernel, which has 4x the workgroups: fewer than 60 tiles behind a LayerNorm prologue (every 16-column workgroup
+    // repeats the row statistics), fewer than 100 / 160 (up to 192 / 512 rows) behind a plain one -- the two N = 384 residual
+    // projections of a block at B = 12 ... 32.  Measured per sampler call (tools/latency.py, profiles/r04_lowbatch.txt):
+    // B = 8 1.79 -> 1.69 ms, 10 2.06 -> 1.72, 16 2.43 -> 1.74, 19 2.93 -> 2.07, 24 2.36 -> 2.17, 32 2.39 -> 2.19.
+    const int64_t tiles6 = (int64_t)((a.M + 15) / 16) * ((a.N + 63) / 64);
+    const bool few_tiles = a.M <= g_mdt_smallm_rows &&
+                           tiles6 < (g_mdt_smallm_tiles > 0 ? g_mdt_smallm_tiles : (a.ln ? 60 : (a.M <= 192 ? 100 : 160)));
+    // (geometry hook -1: the split-K kernel wherever it applies -- tests that pin it against its fused variants)
+    if ((a.M <= g_mdt_smallm_max || few_tiles || g_mdt_gemm_force < 0) && g_mdt_gemm_force <= 0 && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {
         hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4, a.batch > 1 ? a.batch : 1), dim3(512), 0, s, a, g_zeros);
         return hipGetLastError();
     }
@@ -736,11 +761,11 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         if (bgeo < 0) { const char* e = getenv("MDT_HIP_BATCH_GEO"); bgeo = e ? atoi(e) : 5; }
         geo = bgeo;
     }
-    if (g_mdt_gemm_force) geo = g_mdt_gemm_force;
+    if (g_mdt_gemm_force > 0) geo = g_mdt_gemm_force;
     {   // tuning hooks (A/B runs): geometry of the wide (N >= 1024) / narrow products of large batches
         static int gw = -1, gn = -1;
         if (gw < 0) { const char* e = getenv("MDT_HIP_GEO_WIDE"); gw = e ? atoi(e) : 0; const char* f = getenv("MDT_HIP_GEO_NARROW"); gn = f ? atoi(f) : 0; }
-        if (a.M > g_mdt_mid_max && a.batch <= 1 && !g_mdt_gemm_force) {
+        if (a.M > g_mdt_mid_max && a.batch <= 1 && g_mdt_gemm_force <= 0) {
             if (a.N >= 1024 && gw) geo = gw;
             if (a.N < 1024 && gn) geo = gn;
         }
@@ -749,19 +774,10 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     switch (geo) {
         // the tall body (mdt_tall.h): 128-row tiles, operands by LDS-DMA
         case 10: return launch_gemm_tall<2, 2, 4, 2>(a, s);  // 4 waves 128 x 128, 2 stages (64 KiB: two workgroups per CU)
-        case 11: return launch_gemm_tall<2, 4, 2, 3>(a, s);  // 8 waves 128 x 128, 3 stages (96 KiB: one per CU)
         case 12: return launch_gemm_tall<2, 2, 2, 2>(a, s);  // 4 waves 128 x 64,  2 stages (48 KiB: three per CU)
-        case 13: return launch_gemm_tall<2, 2, 6, 2>(a, s);  // 4 waves 128 x 192, 2 stages (80 KiB: two per CU)
-        case 14: return launch_gemm_tall<2, 2, 4, 3>(a, s);  // 4 waves 128 x 128, 3 stages (96 KiB)
-        case 15: return launch_gemm_tall<2, 4, 3, 2>(a, s);  // 8 waves 128 x 192, 2 stages (80 KiB)
         case 16: return launch_gemm_tall<2, 2, 3, 2>(a, s);  // 4 waves 128 x 96,  2 stages (56 KiB: two per CU)
         // ... with ONE loader wave issuing every DMA request of the workgroup
-        case 20: return launch_gemm_tall<2, 2, 4, 2, 1>(a, s);  // 4 + 1 waves 128 x 128, 2 stages
-        case 21: return launch_gemm_tall<2, 4, 2, 3, 1>(a, s);  // 8 + 1 waves 128 x 128, 3 stages
-        case 22: return launch_gemm_tall<2, 2, 2, 2, 1>(a, s);  // 4 + 1 waves 128 x 64,  2 stages
         case 23: return launch_gemm_tall<2, 2, 2, 3, 1>(a, s);  // 4 + 1 waves 128 x 64,  3 stages (72 KiB: two per CU)
-        case 24: return launch_gemm_tall<2, 2, 4, 3, 1>(a, s);  // 4 + 1 waves 128 x 128, 3 stages
-        case 26: return launch_gemm_tall<2, 2, 3, 2, 1>(a, s);  // 4 + 1 waves 128 x 96,  2 stages
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
         case 2:
             if (!a.ln && a.K > 512 && !g_mdt_gemm_nopipe) {  // multi-chunk K: loader waves double-buffer the activation chunk

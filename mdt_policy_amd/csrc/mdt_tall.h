@@ -31,9 +31,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "mdt_device.h"
 #include "mdt_internal.h"
+#include "mdt_tiles.h"   // MDT_TS stamps (tuning builds), xcd_remap
 
 #define MDT_TALL_BK 32
 
@@ -65,6 +67,8 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
     static_assert((A_DMA + B_DMA) % NLOAD == 0, "stage does not split evenly over the loading waves");
     static_assert((NS - 2) * DMA_PER_WAVE <= 63, "vmcnt is a 6-bit counter");
     static_assert(BM == 128, "the A image is written for 128-row tiles");
+    MDT_TS(0)
+    MDT_TS_HWID()
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const bool loader = LW ? wave == NWAVES : true, compute = wave < NWAVES;
@@ -139,7 +143,13 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
     }
     const int boff = A_FLOATS + (wn * NT * 2) * 256 + lane * 4;   // + (2 j + s) * 256
 
+#if defined(MDT_DEBUG_TIMING) && defined(MDT_TILES_TIMING_OWNER)
+    unsigned long long t_sync = 0;   // cycles between arriving at a stage's wait and leaving its barrier
+#endif
     for (int kt = 0; kt < KT; ++kt) {
+#if defined(MDT_DEBUG_TIMING) && defined(MDT_TILES_TIMING_OWNER)
+        const unsigned long long ts_a = __builtin_readcyclecounter();
+#endif
         if constexpr (!LW) {
             // my requests of stage kt have landed (at most NS - 2 younger stages of mine stay in flight) ...
             if (kt + NS - 1 <= KT) tall_wait_vm<(NS - 2) * DMA_PER_WAVE>();
@@ -148,6 +158,10 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
         // ... and so have everybody else's; stage kt - 1 has been read by all
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#if defined(MDT_DEBUG_TIMING) && defined(MDT_TILES_TIMING_OWNER)
+        t_sync += __builtin_readcyclecounter() - ts_a;
+        if (kt == 0) { MDT_TS(1) }
+#endif
         if constexpr (!LW) {
             if (kt + NS - 1 < KT) request(kt + NS - 1);
         }
@@ -171,58 +185,89 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[s][j][e], af[s][i][e], acc[i][j], 0, 0, 0);
     }
 
+    MDT_TS(3)
+#if defined(MDT_DEBUG_TIMING) && defined(MDT_TILES_TIMING_OWNER)
+    if (threadIdx.x == 0 && g_dbg_ts != nullptr) g_dbg_ts[(size_t)blockIdx.x * 8 + 5] = t_sync;
+#endif
     // ---- epilogue: lane holds out[m0 + wm*64 + i*16 + lane%16][(n0t + wn*NT + j)*16 + 4*(lane/16) .. +3] ----
+    // The common cases are their own straight-line instantiations (ACT / AUX fixed, FULL: no row or column of the tile is
+    // outside the matrix, so no store carries a predicate).  With everything decided per value at run time -- activation
+    // switch, training hooks, `ok` masks as exec-mask branches -- the epilogue was ~140 instructions per 16 x 16 tile: 9.3 k
+    // cycles for a 128 x 128 tile alone on its CU against 49 k of MFMA issue (profiles/r04_tall_phases.txt).
     const int nq = 4 * (lane >> 4);
     const float* biasp = a.bias != nullptr ? a.bias : zeros;
     const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;
     const bool gated = RES && a.gate_off >= 0;
-    int ncol[NT];
-    f32x4 bias_v[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int T = min(n0t + wn * NT + j, N16 - 1);
-        ncol[j] = T * 16 + nq;
-        bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int mr = m0 + wm * 64 + i * 16 + (lane & 15);
-        const int m = min(mr, a.M - 1);
-        const int64_t orow = a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
-        const int64_t oo = orow * a.ldo;
-        f32x4 gate_v[NT], res_v[NT], aux_v[NT];
-        if constexpr (RES) {
-            const float* gp = gated ? a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride)
-                                    : zeros;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                gate_v[j] = ldg4(gp + ncol[j]);
-                res_v[j] = ldg4(a.out + oo + ncol[j]);
-            }
-        } else {
-            if (a.aux_mode == 2) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) aux_v[j] = ldg4(a.aux + oo + ncol[j]);
-            }
-        }
+    auto epilogue = [&](auto ACT_, auto AUX_, auto FULL_) {
+        constexpr int ACT = decltype(ACT_)::value, AUX = decltype(AUX_)::value;   // -1: read a.act / a.aux_mode at run time
+        constexpr bool FULL = decltype(FULL_)::value;
+        const int act = ACT >= 0 ? ACT : a.act, aux_mode = AUX >= 0 ? AUX : a.aux_mode;
+        int ncol[NT];
+        f32x4 bias_v[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const bool ok = mr < a.M && n0t + wn * NT + j < N16;
-            f32x4 v = acc[i][j] + bias_v[j];
-            if constexpr (RES) {
-                v = apply_act(v, a.act);
-                v = res_v[j] + (gated ? gate_v[j] * v : v);
-            } else {
-                if (a.aux_mode == 2) {
-                    const f32x4 u = aux_v[j];
-                    v.x *= apply_act_grad1(u.x, a.act); v.y *= apply_act_grad1(u.y, a.act);
-                    v.z *= apply_act_grad1(u.z, a.act); v.w *= apply_act_grad1(u.w, a.act);
-                } else {
-                    if (a.aux_mode == 1 && ok) *(f32x4*)(const_cast<float*>(a.aux) + oo + ncol[j]) = v;
-                    v = apply_act(v, a.act);
-                }
-            }
-            if (ok) *(f32x4*)(a.out + oo + ncol[j]) = v;
+            const int T = FULL ? n0t + wn * NT + j : min(n0t + wn * NT + j, N16 - 1);
+            ncol[j] = T * 16 + nq;
+            bias_v[j] = ldg4(biasp + ncol[j]) + ldg4(rvp + ncol[j]);
         }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mr = m0 + wm * 64 + i * 16 + (lane & 15);
+            const int m = FULL ? mr : min(mr, a.M - 1);
+            const int64_t orow = a.gin == 1 ? (int64_t)m * a.gout + a.goff : (int64_t)(m / a.gin) * a.gout + (m % a.gin) + a.goff;
+            float* orp = a.out + orow * a.ldo;
+            const float* axp = a.aux + orow * a.ldo;
+            f32x4 gate_v[NT], res_v[NT], aux_v[NT];
+            if constexpr (RES) {
+                const float* gp = gated ? a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (int64_t)(m / a.rows_per_sample) * a.mod_stride)
+                                        : zeros;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    gate_v[j] = ldg4(gp + ncol[j]);
+                    res_v[j] = ldg4(orp + ncol[j]);
+                }
+            } else if (aux_mode == 2) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) aux_v[j] = ldg4(axp + ncol[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const bool ok = FULL || (mr < a.M && n0t + wn * NT + j < N16);
+                f32x4 v = acc[i][j] + bias_v[j];
+                if constexpr (RES) {
+                    v = apply_act(v, act);
+                    v = res_v[j] + (gated ? gate_v[j] * v : v);
+                } else if (aux_mode == 2) {
+                    const f32x4 u = aux_v[j];
+                    v.x *= apply_act_grad1(u.x, act); v.y *= apply_act_grad1(u.y, act);
+                    v.z *= apply_act_grad1(u.z, act); v.w *= apply_act_grad1(u.w, act);
+                } else {
+                    if (aux_mode == 1 && ok) *(f32x4*)(const_cast<float*>(axp) + ncol[j]) = v;
+                    v = apply_act(v, act);
+                }
+                if (ok) *(f32x4*)(orp + ncol[j]) = v;
+            }
+        }
+    };
+    using std::integral_constant;
+    const bool full = m0 + BM <= a.M && n0t + BN / 16 <= N16;
+    typedef integral_constant<bool, true> T_;
+    typedef integral_constant<bool, false> F_;
+#define MDT_TALL_EPI(ACT, AUX)                                                \
+    {                                                                         \
+        if (full) epilogue(integral_constant<int, ACT>(), integral_constant<int, AUX>(), T_()); \
+        else epilogue(integral_constant<int, ACT>(), integral_constant<int, AUX>(), F_());      \
     }
+    if constexpr (RES) {
+        if (a.act == MDT_ACT_NONE) MDT_TALL_EPI(MDT_ACT_NONE, 0)
+        else epilogue(integral_constant<int, -1>(), integral_constant<int, 0>(), F_());
+    } else {
+        if (a.aux_mode == 0 && a.act == MDT_ACT_NONE) MDT_TALL_EPI(MDT_ACT_NONE, 0)
+        else if (a.aux_mode == 0 && a.act == MDT_ACT_GELU) MDT_TALL_EPI(MDT_ACT_GELU, 0)
+        else if (a.aux_mode == 1 && a.act == MDT_ACT_GELU) MDT_TALL_EPI(MDT_ACT_GELU, 1)
+        else if (a.aux_mode == 2 && a.act == MDT_ACT_GELU) MDT_TALL_EPI(MDT_ACT_GELU, 2)
+        else epilogue(integral_constant<int, -1>(), integral_constant<int, -1>(), F_());
+    }
+#undef MDT_TALL_EPI
+    MDT_TS(4)
 }

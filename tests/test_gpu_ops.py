@@ -118,7 +118,7 @@ def test_gemm_every_geometry(lib, geo, M, N, K, ln):
     assert_close(heur, ref, rtol=1e-5, atol=1e-5, what="heuristic choice vs tiled")
 
 
-TALL_GEOS = [10, 11, 12, 13, 14, 15, 16, 20, 21, 22, 23, 24, 26]
+TALL_GEOS = [10, 12, 16, 23]
 
 
 @pytest.mark.parametrize("geo", TALL_GEOS)
@@ -143,7 +143,7 @@ def test_gemm_tall_body_bit_equals_the_row_tile_body(lib, geo, M, N, K):
     assert torch.equal(got, ref), "tall body and row-tile body disagree bitwise"
 
 
-@pytest.mark.parametrize("geo", [10, 11, 13])
+@pytest.mark.parametrize("geo", [10, 12, 23])
 def test_gemm_tall_body_epilogues(lib, geo):
     """Every epilogue the tall body carries, against the row-tile body (bitwise) and float64: bias + GELU, per-sample gate +
     residual, token-row remap + row vector, and the two training hooks (aux_mode 1: pre-activation kept; 2: act'(aux))."""
@@ -665,7 +665,11 @@ def test_cross_attention_inside_the_linear_that_follows_it(lib, D, H, Te, Ta, B,
     lib.check(lib.load().mdt_op_xattn_gemm(C.byref(x), C.byref(a), stream()))
     x2, a2 = args(y2, o2)
     lib.check(lib.load().mdt_op_xattn_apply(C.byref(x2), stream()))
-    lib.check(lib.load().mdt_op_gemm(C.byref(a2), stream()))
+    try:  # the two-launch reference on the split-K kernel the fused launch is built from (the dispatcher may prefer tiles here)
+        lib.load().mdt_op_set_gemm_geometry(-1)
+        lib.check(lib.load().mdt_op_gemm(C.byref(a2), stream()))
+    finally:
+        lib.load().mdt_op_set_gemm_geometry(0)
     torch.cuda.synchronize()
     assert torch.equal(y1.cpu(), y0), "the input rows must stay as they are"
     assert torch.equal(y1n, y2) and torch.equal(o1, o2), "the one-launch form differs from xattn_apply + gemm"

@@ -243,8 +243,9 @@ def test_denoiser_forward_with_per_sample_sigma_in_the_mid_batch_regimes(B):
 
 def test_full_size_properties():
     """Size-independent properties at B=256: determinism and batch independence (a sample's actions do not
-    depend on what else is in the batch).  Bit-exact between batches served by the same GEMM kernel (the k-order of
-    every dot product is fixed); across the small-M / tiled kernel switch (M = 192 rows) equal to rounding."""
+    depend on what else is in the batch).  Bit-exact between batches served by the same GEMM kernels (the k-order of
+    every dot product is fixed); where the dispatcher picks the split-K small-M kernel for one batch size and tiles for the
+    other, equal to rounding."""
     meta, _ = load_fixture("g3_b256_lang.npz")
     model = build(meta)
     state, goal, noise = gpu_inputs(meta)
@@ -253,7 +254,7 @@ def test_full_size_properties():
         a = sampling().sample_ddim(model, state, noise * 80.0, goal, sig)
         b = sampling().sample_ddim(model, state, noise * 80.0, goal, sig)
         assert torch.equal(a, b), "non-deterministic"
-        for sub, exact in ((slice(20, 220), True), (slice(100, 117), False)):
+        for sub, exact in ((slice(10, 250), True), (slice(100, 117), False)):  # 240 / 17 samples (the dispatcher's kernel choice per product is the same at 240 and 256)
             st = {"state_images": state["state_images"][sub].contiguous(), "modality": state["modality"]}
             c = sampling().sample_ddim(model, st, noise[sub] * 80.0, goal[sub], sig)
             if exact:
