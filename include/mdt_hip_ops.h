@@ -109,6 +109,14 @@ mdt_status mdt_op_mlp(const mdt_gemm_args *fc, const mdt_gemm_args *proj, float 
 /* Tuning / test hook: the model-level entry points run the MLP sublayer through mdt_op_mlp from `rows` rows (B * horizon)
  * on; 0 = never (the two-GEMM sequence), -1 = default (1401, or MDT_HIP_MLP_FUSE_MIN from the environment). */
 void mdt_op_set_mlp_fuse_min(int32_t rows);
+/* Measurement hook: bracket every fused-MLP launch of the model-level calls that follow (mdt_sample_ddim, mdt_forward, ...)
+ * with a pair of HIP events on its stream; mdt_op_trace_mlp_read waits for them, writes up to `cap` durations in
+ * MICROSECONDS (launch order) to `us`, releases the events and returns how many it wrote.  The duration of the dominant
+ * kernel inside its launch chain, as a kernel trace reports it (bench.py's roofline.dominant_kernel).  Process-wide; not
+ * for use under stream capture. */
+void mdt_op_trace_mlp(int32_t enable);
+int32_t mdt_op_trace_mlp_read(float *us, int32_t cap);
+
 /* Tuning / test hook: wave schedule inside mdt_op_mlp's kernel.  Low byte = number of k-steps the second wave of every
  * SIMD starts behind the first (0 = lockstep with a workgroup barrier between the two products), | 256 = MFMA loops at
  * raised issue priority; -1 = default (18 | 256, or MDT_HIP_MLP_SKEW from the environment).  Every setting produces the

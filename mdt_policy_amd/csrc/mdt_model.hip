@@ -760,6 +760,26 @@ static int g_mlp_fuse_min_rows() {
 }
 extern "C" void mdt_op_set_mlp_fuse_min(int32_t rows) { g_mlp_fuse_override = rows; }
 
+// mdt_op_trace_mlp: every fused-MLP launch (k_mlp, the dominant kernel of the B = 256 sampler call) of the model-level calls
+// that follow is bracketed by a pair of HIP events on its stream -- the kernel's duration INSIDE the launch chain (the
+// preceding kernel's tail and the launch gap included, like a kernel-trace row), which 200 back-to-back launches of the
+// kernel alone do not give (bench.py).  mdt_op_trace_mlp_read synchronises the events, returns the
+// durations in microseconds (at most `cap`) and releases them.
+static bool g_trace_mlp = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_trace_mlp_events;
+extern "C" void mdt_op_trace_mlp(int32_t enable) { g_trace_mlp = enable != 0; }
+extern "C" int32_t mdt_op_trace_mlp_read(float* us, int32_t cap) {
+    int32_t n = 0;
+    for (auto& ev : g_trace_mlp_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess && us && n < cap)
+            us[n++] = ms * 1e3f;
+        (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+    }
+    g_trace_mlp_events.clear();
+    return n;
+}
+
 // `out` (optional): when given and the fused launch applies, the sublayer's output is left as slabs in V.hid (described in
 // *out) and V.y is NOT updated -- the caller hands *out to the next reader; otherwise V.y is updated in place.
 // `pre_x` (optional; rollout batches): the collapsed cross-attention that is still to run on these rows -- it goes into the
@@ -781,6 +801,14 @@ static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_
         // the hidden buffer (M x 4D) is free in this form: it holds the S <= 4 slabs of (M x D)
         p.ldo = D;
         const int64_t stride = (int64_t)M * D;
+        if (g_trace_mlp) {  // measurement hook (mdt_op_trace_mlp): this launch between its own pair of HIP events, inside the chain
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventRecord(e0, s));
+            LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
+            HIP_TRY(hipEventRecord(e1, s));
+            g_trace_mlp_events.emplace_back(e0, e1);
+        } else
         LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
         out->base = V.hid; out->parts = mdt_mlp_slices(D); out->stride = stride;
         return MDT_OK;

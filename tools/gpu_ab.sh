@@ -8,6 +8,6 @@ for rep in $(seq ${REPS:-3}); do for name in "$@"; do
   lib=$R/mdt_policy_amd/csrc/libmdt_hip_$name.so; [ "$name" = base ] && lib=$R/mdt_policy_amd/csrc/libmdt_hip.so
   echo -n "$name: "; MDT_HIP_LIB=$lib timeout 200 python -c "
 import torch, bench
-d = torch.device('cuda'); r = bench.time_dominant_kernel(d, 2560); print('k_mlp %.2f us' % r['avg_us'], end='   ')" 2>&1 | tail -1
+d = torch.device('cuda'); r = bench.time_dominant_kernel(d, 2560); print('k_mlp alone %.2f us' % r['alone']['avg_us'], end='   ')" 2>&1 | tail -1
   MDT_HIP_LIB=$lib timeout 300 python tools/latency.py $BATCHES 2>&1 | grep "B=" | tr '\n' ' '; echo
 done; done | tee $OUT/ab.txt

@@ -30,9 +30,13 @@ def write(name, text):
 bench = read("bench.json").strip().splitlines()[-1]
 write("bench.json", bench + "\n")
 stats = read("bench_kernel_stats.txt").splitlines(True)
+# sampler calls of the profiled command = launches of the once-per-call fold kernel (2 warm-up + 5 timed + 50 spread + 2 of the
+# in-chain dominant-kernel leg)
+calls = next((l.split("|")[1].strip() for l in stats if "k_xattn_fold" in l), "?")
 write("bench_kernel_stats.txt",
       head + "rocprofv3 --kernel-trace --stats of 'python bench.py --steps 5 --warmup 2 --no-cpu-baseline' (MI355X, 1 GPU), "
-      "tools/gpu_final.sh\n# 7 sampler calls x (encoder + fold + 10 decoder steps) + the 210-launch dominant-kernel timing leg; bench "
+      f"tools/gpu_final.sh\n# {calls} sampler calls x (encoder + fold + 10 decoder steps) (warm-up, timed, the 50-call spread leg, the "
+      "traced call) + the 210-launch dominant-kernel-alone leg; bench "
       f"line of the same build and box: profiles/{pre}bench.json\n" + "".join(stats[:32]))
 write("bench_pmc.txt",
       head + "rocprofv3 --kernel-trace --pmc (two separate passes) of 'python bench.py --steps 3 --warmup 1 --no-cpu-baseline', "
@@ -64,6 +68,7 @@ for l in read("bench_pmc.txt").splitlines():
         rd, wr = float(f[6]), float(f[7])
         M, D, N, S = 2560, 384, 1536, 3
         write("dominant_kernel_pmc.json", json.dumps({
+            "commit": commit,
             "kernel": f"{f[0]} (LN + modulate -> c_fc -> GELU -> c_proj -> gate, {M} rows, d = {D}, hidden {N}; B = 256)",
             "source": f"rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum of the bench command "
                       f"itself (own pass, tools/gpu_final.sh; table profiles/{pre}bench_pmc.txt), per launch, {f[2]} dispatches",
@@ -71,8 +76,9 @@ for l in read("bench_pmc.txt").splitlines():
             "l2_hit": float(f[8]), "mfma_busy_frac_at_2.4GHz": float(f[5]), "avg_us_under_pmc": float(f[3]),
             "units": "guide MI355X_MICROARCH.md 'HBM': EA read requests are 128-B requests on gfx950 (FETCH_SIZE = RDREQ x 64 B reports "
                      "half) -> x128 B; write requests x64 B (calibrated in round 1 on a GEMM whose output size is exact)",
-            "algorithmic_bytes_per_launch": 4 * (M * D + 2 * N * D + S * M * D),
-            "note": "reads exceed the algorithmic 13.4 MB because each of the 8 XCD L2s fetches both 2.36 MB weight images once (served "
+            "algorithmic_bytes_per_launch": 4 * (M * D + 2 * N * D + M * D),
+            "algorithmic_bytes_per_launch_with_slabs": 4 * (M * D + 2 * N * D + S * M * D),
+            "note": "reads exceed the truly algorithmic 12.6 MB (3.9 MB of rows + 4.7 MB of weights read once, 3.9 MB written) because each of the 8 XCD L2s fetches both 2.36 MB weight images once (served "
                     "by the 256 MB Infinity Cache, which these memory-side counters include): 8 x 4.7 + 3.9 MB of rows; the writes are "
                     "exactly the three partial slabs (3 x 3.9 MB).  The hidden layer (15.7 MB per launch in round 2) never leaves the CU."
         }, indent=2) + "\n")
