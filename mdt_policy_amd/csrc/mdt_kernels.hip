@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
         }
     };
 
-    const float* wp[NTW];
+    WStream wp[NTW];
     f32x4 ring[R][NTW];
     f32x4 acc[MTILES][NTW];
     const int nq = 4 * (lane >> 4);
@@ -235,12 +235,12 @@ __global__ __launch_bounds__(64 * (NWAVES + LW)) void k_gemm_pipe(mdt_gemm_args 
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int nt = min(nt0 + j, N16 - 1);
-            wp[j] = a.Wp + (int64_t)nt * K16 * 256 + lane * 4;
+            wp[j] = wstream(a.Wp, (int64_t)nt * K16 * 256 + lane * 4);
         }
 #pragma unroll
         for (int u = 0; u < R - 1; ++u)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
+            for (int j = 0; j < NTW; ++j) ring[u][j] = wld4(wp[j] + min(u, K16 - 1) * 256);
 #pragma unroll
         for (int i = 0; i < MTILES; ++i)
 #pragma unroll
@@ -755,6 +755,16 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         static int g9 = -1;
         if (g9 < 0) { const char* e = getenv("MDT_HIP_GEO_TRAIN"); g9 = e ? atoi(e) : 9; }
         if (g9 && !a.ln && a.M >= 4096 && a.N % 192 == 0 && a.N != 384 && a.batch <= 1) geo = g9;
+    }
+    // ... and from 8192 rows on the TALL body (mdt_tall.h: 128-row tiles, both operands staged in LDS by LDS-DMA, each staged
+    // element used by 2-4 waves) where the column count is a multiple of its 64-wide tiles: the forward / input-gradient
+    // products of a B = 1024 training step and the masked-image head's 104 k rows (tools/gemm_train_shapes.py,
+    // profiles/r04_gemm_train_shapes.txt: 104448 x 576 x 192 249 -> 213-231 us, 104448 x 192 x 768 290 -> 263-270,
+    // 10240 x 384 x 1536 124 -> 105-112, 10240 x 1152 x 384 94 -> 88-92; 10240 x 384 x 384 unchanged, 4096 rows lose)
+    {
+        static int gt = -1;
+        if (gt < 0) { const char* e = getenv("MDT_HIP_GEO_TALL"); gt = e ? atoi(e) : 23; }
+        if (gt && a.M >= 8192 && a.N % 64 == 0 && (a.N > 384 || a.K > 384) && a.batch <= 1 && mdt_gemm_tall_supported(a)) geo = gt;
     }
     if (a.batch > 1) {  // split-K partial products (deep reductions): geometry chosen for those, env override for A/B runs
         static int bgeo = -1;

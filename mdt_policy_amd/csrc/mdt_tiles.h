@@ -68,6 +68,37 @@ struct ActLd<true> {
     }
 };
 
+// ---- weight-fragment stream ----
+// A wave's handle on one column tile of a packed weight image: fragment k16 sits 256 floats behind fragment k16 - 1, lane l's
+// 16 bytes at l * 4 floats.  Fetched with BUFFER loads (resource = the image, 32-bit per-lane byte offset): a global_load
+// sends 64 lanes x 8 bytes of address through the SIMD's register read path before its 1 KiB of data comes back, and while
+// either moves the SIMD issues no MFMA -- tools/micro/wstream_probe.hip: 33 cycles of matrix-pipe time per global_load_dwordx4
+// against 17.7 per buffer_load_dwordx4 ... offen (17.3 with no address register at all: what is left is the data's way into the
+// registers), i.e. 113 -> 101 us for the k-loop of the fused MLP's first product alone.  (Round 3 measured buffer loads 7 %
+// SLOWER in mlp_tile: that form kept the tile base in the scalar offset behind a v_readfirstlane per request.)
+// -DMDT_W_GLOBAL: A/B build with the 64-bit global loads.  Offsets are bytes: an image (and every batched slice of one,
+// mdt_gemm_args.bs_w) stays below 4 GiB.
+#ifdef MDT_W_GLOBAL
+struct WStream {
+    const float* p;
+    __device__ __forceinline__ WStream operator+(int floats) const { return WStream{p + floats}; }
+};
+__device__ __forceinline__ WStream wstream(const float* image, int64_t float_off) { return WStream{image + float_off}; }
+__device__ __forceinline__ f32x4 wld4(const WStream& w) { return ldg4(w.p); }
+#else
+struct WStream {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned off;  // bytes
+    __device__ __forceinline__ WStream operator+(int floats) const { return WStream{rs, off + 4u * (unsigned)floats}; }
+};
+__device__ __forceinline__ WStream wstream(const float* image, int64_t float_off) {
+    return WStream{__builtin_amdgcn_make_buffer_rsrc((void*)image, 0, 0xffffffffu, 0x00020000), (unsigned)(float_off << 2)};
+}
+__device__ __forceinline__ f32x4 wld4(const WStream& w) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.off, 0, 0));
+}
+#endif
+
 // prologue kinds: plain copy | LayerNorm | LayerNorm + modulate with ONE broadcast row (sampler: one sigma per
 // step) | LayerNorm + modulate with a per-sample row (GCDenoiser.forward / loss with per-sample sigma)
 enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_LN_MOD_BCAST = 2, PRO_LN_MOD_ROWS = 3,
@@ -149,7 +180,7 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 #ifdef MDT_EXP_NOLOAD
 #define MDT_EXP_LDG(p, old) (old)
 #else
-#define MDT_EXP_LDG(p, old) ldg4(p)
+#define MDT_EXP_LDG(p, old) wld4(p)
 #endif
 #ifdef MDT_EXP_NOLDS
 #define MDT_EXP_LDS(x, old) (old)
@@ -619,17 +650,17 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
     const ActLd<COH> LO(a.out);
 
     // ---- weight stream: one continuous k16 index over the whole K, independent of the LDS chunking ----
-    const float* wp[NTW];
+    WStream wp[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int nt = min(nt0 + j, N16 - 1);  // clamp: a partial last wave re-reads a valid tile
-        wp[j] = a.Wp + (int64_t)nt * K16 * 256 + lane * 4;
+        wp[j] = wstream(a.Wp, (int64_t)nt * K16 * 256 + lane * 4);
     }
     f32x4 ring[R][NTW];
 #pragma unroll
     for (int u = 0; u < R - 1; ++u)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
+        for (int j = 0; j < NTW; ++j) ring[u][j] = wld4(wp[j] + min(u, K16 - 1) * 256);
 
     f32x4 acc[MTILES][NTW];
 #pragma unroll
@@ -843,14 +874,14 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
     // ---- phase 1 operands: weight ring of W1 rows [512 s + 64 wave, + 64), bias ----
     const int K16a = D >> 4;
     const int nt1 = (s * NWAVES + wave) * NTW1;
-    const float* wp1[NTW1];
+    WStream wp1[NTW1];
     f32x4 ring1[R1][NTW1], acc1[MTILES][NTW1], b1[NTW1];
 #pragma unroll
-    for (int j = 0; j < NTW1; ++j) wp1[j] = f.Wp + (int64_t)(nt1 + j) * K16a * 256 + lane * 4;
+    for (int j = 0; j < NTW1; ++j) wp1[j] = wstream(f.Wp, (int64_t)(nt1 + j) * K16a * 256 + lane * 4);
 #pragma unroll
     for (int u = 0; u < R1 - 1; ++u)
 #pragma unroll
-        for (int j = 0; j < NTW1; ++j) ring1[u][j] = ldg4(wp1[j] + min(u, K16a - 1) * 256);
+        for (int j = 0; j < NTW1; ++j) ring1[u][j] = wld4(wp1[j] + min(u, K16a - 1) * 256);
     {
         const float* bp = f.bias != nullptr ? f.bias : zeros;
 #pragma unroll
@@ -867,7 +898,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
     {
         constexpr int NTW = NTW1, R = R1;
         const int K16 = K16a, nk = K16a, stride = stride1, kg = 0;
-        const float* (&wp)[NTW] = wp1;
+        WStream (&wp)[NTW] = wp1;
         f32x4 (&ring)[R][NTW] = ring1;
         f32x4 (&acc)[MTILES][NTW] = acc1;
         const float* ap = xn + (lane & 15) * stride + 4 * (lane >> 4);
@@ -901,19 +932,19 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
     // ---- phase 2 operands, requested before the activation epilogue so that they travel while it runs: the first
     //      fragments of W2's K-slice [512 s, 512 s + 512), then bias / gate / residual rows of the output tile ----
     const int K16b = HS >> 4;  // k16 steps of the slice
-    const float* wp2[NTW2];
+    WStream wp2[NTW2];
     f32x4 ring2[R2][NTW2], acc2[MTILES][NTW2], b2[NTW2], gate_v[MTILES][NTW2], res_v[MTILES][NTW2];
     int ncol[NTW2];
 #pragma unroll
     for (int j = 0; j < NTW2; ++j) {
         const int nt = wave * NTW2 + j;
-        wp2[j] = p.Wp + ((int64_t)nt * (p.K >> 4) + (int64_t)s * K16b) * 256 + lane * 4;
+        wp2[j] = wstream(p.Wp, ((int64_t)nt * (p.K >> 4) + (int64_t)s * K16b) * 256 + lane * 4);
         ncol[j] = nt * 16 + nq;
     }
 #pragma unroll
     for (int u = 0; u < R2 - 1; ++u)
 #pragma unroll
-        for (int j = 0; j < NTW2; ++j) ring2[u][j] = ldg4(wp2[j] + u * 256);
+        for (int j = 0; j < NTW2; ++j) ring2[u][j] = wld4(wp2[j] + u * 256);
     const bool gated = p.mod != nullptr && p.gate_off >= 0;
     {
         const float* bp = (s == 0 && p.bias != nullptr) ? p.bias : zeros;
@@ -951,7 +982,7 @@ __device__ __forceinline__ void mlp_tile(const mdt_gemm_args& f, const mdt_gemm_
     {
         constexpr int NTW = NTW2, R = R2;
         const int K16 = K16b, nk = K16b, stride = HSTR, kg = 0;
-        const float* (&wp)[NTW] = wp2;
+        WStream (&wp)[NTW] = wp2;
         f32x4 (&ring)[R][NTW] = ring2;
         f32x4 (&acc)[MTILES][NTW] = acc2;
         const float* ap = hs + (lane & 15) * stride + 4 * (lane >> 4);
@@ -1775,9 +1806,9 @@ __device__ __forceinline__ void attn_xattn_tile(const mdt_gemm_args& a, const md
     float* xscr = scr + 16 * stride;
 
     const int nt0 = wave * NTW;
-    const float* wp[NTW];
+    WStream wp[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) wp[j] = a.Wp + (int64_t)(nt0 + j) * K16 * 256 + lane * 4;
+    for (int j = 0; j < NTW; ++j) wp[j] = wstream(a.Wp, (int64_t)(nt0 + j) * K16 * 256 + lane * 4);
     f32x4 ring[R][NTW];
     f32x4 acc[MTILES][NTW];
 #pragma unroll
@@ -1794,7 +1825,7 @@ __device__ __forceinline__ void attn_xattn_tile(const mdt_gemm_args& a, const md
 #pragma unroll
         for (int u = 0; u < R - 1; ++u)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) ring[u][j] = ldg4(wp[j] + min(u, K16 - 1) * 256);
+            for (int j = 0; j < NTW; ++j) ring[u][j] = wld4(wp[j] + min(u, K16 - 1) * 256);
         const float* biasp = a.bias != nullptr ? a.bias : zeros;
         const int m = min(m0 + min(lane & 15, T - 1), a.M - 1);
         const float* gp = zeros;
