@@ -462,6 +462,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void k_gemm_tall(mdt_gemm_args
 }
 extern "C" void mdt_op_set_tall_stagger(int32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tall_stagger), &v, sizeof(v)); }
 bool mdt_gemm_tall_supported(const mdt_gemm_args& a) {
+    // (32-bit byte offsets from the operand bases: the activation block and the weight image each below 4 GiB)
+    if ((int64_t)a.M * a.lda >= ((int64_t)1 << 30) || (int64_t)a.N * a.K >= ((int64_t)1 << 30)) return false;
     return !a.ln && a.a_parts <= 1 && a.batch <= 1 && a.K % MDT_TALL_BK == 0 && (a.N & 15) == 0 && a.M >= 1 && (a.lda & 3) == 0 &&
            (a.aux_mode == 0 || ((a.aux_mode == 1 || a.aux_mode == 2) && !a.residual));
 }
@@ -669,6 +671,8 @@ hipError_t mdt_launch_attn_xattn(const mdt_gemm_args& p, const float* qkv, int64
 
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
+    // the weight stream is addressed with 32-bit byte offsets from the image's base (buffer loads, mdt_tiles.h: WStream)
+    if ((int64_t)a.N * a.K >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
     hipError_t ze = ensure_zeros();
     if (ze != hipSuccess) return ze;
     if (g_mdt_smallm_max < 0) {

@@ -42,9 +42,12 @@
 typedef __attribute__((address_space(3))) void mdt_lds_void;
 typedef __attribute__((address_space(1))) const void mdt_glb_cvoid;
 
-__device__ __forceinline__ void tall_dma16(const float* g, float* lds_wave_base) {
-    // 64 lanes x 16 bytes: global (per lane) -> LDS (wave-uniform base + lane * 16)
-    __builtin_amdgcn_global_load_lds((mdt_glb_cvoid*)g, (mdt_lds_void*)lds_wave_base, 16, 0, 0);
+// 64 lanes x 16 bytes: global (per lane: resource base + 32-bit byte offset) -> LDS (wave-uniform base + lane * 16).  The
+// BUFFER form: a global_load_lds sends 64 x 8 bytes of address through the SIMD's register read path (tools/micro/
+// wstream_probe.hip: 40.7 cycles of matrix-pipe time per global_load_lds_dwordx4; the VGPR loads went 33 -> 17.7 with 32-bit
+// offsets).  Operand images stay below 4 GiB from their base (checked by mdt_gemm_tall_supported).
+__device__ __forceinline__ void tall_dma16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (mdt_lds_void*)lds_wave_base, 16, byte_off, 0, 0, 0);
 }
 
 template <int N>
@@ -77,9 +80,12 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
     const int N16 = a.N >> 4, K16 = a.K >> 4, KT = a.K / BK;
 
     // ---- DMA assignments of a loading wave (the same for every stage): instruction q = lw + NLOAD * u ----
-    const float* dsrc[DMA_PER_WAVE];   // per-lane global address of the next stage to request
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.Wp, 0, 0xffffffffu, 0x00020000);
+    unsigned dsrc[DMA_PER_WAVE];       // per-lane byte offset (from a.A / a.Wp) of the next stage to request
     int ddst[DMA_PER_WAVE];            // wave-uniform LDS float offset inside a stage
-    int dstep[DMA_PER_WAVE];           // floats per stage
+    int dstep[DMA_PER_WAVE];           // bytes per stage
+    bool disA[DMA_PER_WAVE];
     if (loader) {
         const int lw = LW ? 0 : wave;
 #pragma unroll
@@ -88,15 +94,17 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
             if (q < A_DMA) {               // rows 8 q .. 8 q + 7, the stage's 128 bytes of each
                 const int r = 8 * q + (lane >> 3), p = lane & 7, c = p ^ ((r >> 1) & 7);
                 const int64_t m = min(m0 + r, a.M - 1);   // rows past M re-read the last row (masked in the epilogue)
-                dsrc[u] = a.A + m * a.lda + 4 * c;
+                dsrc[u] = (unsigned)((m * a.lda + 4 * c) << 2);
                 ddst[u] = 256 * q;
-                dstep[u] = BK;
+                dstep[u] = BK * 4;
+                disA[u] = true;
             } else {                       // fragment (column tile t, k16 step s) of the packed weight image
                 const int f = q - A_DMA, t = f >> 1, s = f & 1;
                 const int nt = min(n0t + t, N16 - 1);     // a partial last tile re-reads a valid fragment
-                dsrc[u] = a.Wp + ((int64_t)nt * K16 + s) * 256 + lane * 4;
+                dsrc[u] = (unsigned)((((int64_t)nt * K16 + s) * 256 + lane * 4) << 2);
                 ddst[u] = A_FLOATS + 256 * f;
-                dstep[u] = 2 * 256;
+                dstep[u] = 2 * 1024;
+                disA[u] = false;
             }
         }
     }
@@ -104,7 +112,7 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
         float* base = lds + (kt % NS) * STAGE;
 #pragma unroll
         for (int u = 0; u < DMA_PER_WAVE; ++u) {
-            tall_dma16(dsrc[u], base + ddst[u]);
+            tall_dma16(disA[u] ? rsA : rsW, dsrc[u], base + ddst[u]);
             dsrc[u] += dstep[u];
         }
     };

@@ -1250,7 +1250,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int i = tid + 256 * u; yr[u] = i >> 4; yc[u] = (i & 15) * 4; }
     f32x4 xv[XU], yv[2];
+    // buffer loads with 32-bit byte offsets where the operands allow it (both blocks below 4 GiB: always, for the shapes of
+    // this model): a global load's 64-bit addresses cost the SIMD as much matrix-pipe time as its data (mdt_tiles.h: WStream)
+    const bool small = (int64_t)M * ldx < ((int64_t)1 << 30) && (int64_t)M * ldy < ((int64_t)1 << 30);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, 0xffffffffu, 0x00020000);
     auto fetch = [&](int mb) {
+        if (small) {
+#pragma unroll
+            for (int u = 0; u < XU; ++u) {
+                const unsigned m = (unsigned)min(mb + xr[u], m_hi - 1);
+                xv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (m * (unsigned)ldx + (unsigned)min(k0 + xc[u], K - 4)) << 2, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned m = (unsigned)min(mb + yr[u], m_hi - 1);
+                yv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (m * (unsigned)ldy + (unsigned)min(n0 + yc[u], N - 4)) << 2, 0, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const int64_t m = min(mb + xr[u], m_hi - 1);
