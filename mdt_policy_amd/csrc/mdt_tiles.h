@@ -795,7 +795,11 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
                     v = apply_act(v, a.act);
                 }
                 if constexpr (RES) v = res_v[i][j] + (gated ? gate_v[i][j] * v : v);
+#if defined(MDT_GEMM_OUT_PLAIN)   // A/B build: the GEMM's output tile stays in the XCD's L2 (plain store) for a same-XCD reader -- round 4: 4.50 vs 4.445 ms per B = 256 call, write-through stays
+                if (ok) *(f32x4*)(a.out + ooff[i] + ncol[j]) = v;
+#else
                 if (ok) st4(a.out + ooff[i] + ncol[j], v);
+#endif
             }
         }
     }
