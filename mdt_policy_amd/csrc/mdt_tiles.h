@@ -358,7 +358,9 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
                 red[r] += hsum4(v[r][p]);
             }
         }
+#ifndef MDT_EXP_NOLN   // timing experiment only (WRONG results): the prologue without its two wave reductions
         wave_sum_n<RPW>(red);
+#endif
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const float mean = red[r] * inv_k;
@@ -369,7 +371,9 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
                 red[r] += hsq4(v[r][p]);
             }
         }
+#ifndef MDT_EXP_NOLN
         wave_sum_n<RPW>(red);
+#endif
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int m = m0 + r0 + r;

@@ -22,6 +22,16 @@ __global__ __launch_bounds__(256) void touch(const float* __restrict__ X, float*
     out[blockIdx.x * 256 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
     if (threadIdx.x == 0) ts[blockIdx.x] = t1 - t0;
 }
+// producer kernel: workgroup b WRITES slice b (plain stores, or write-through sc0 sc1 stores)
+template <bool WT>
+__global__ __launch_bounds__(256) void fill(float* __restrict__ X, int slice_floats, float val) {
+    float* p = X + (size_t)blockIdx.x * slice_floats;
+    for (int i = threadIdx.x * 4; i < slice_floats; i += 256 * 4) {
+        const f32x4 v = (f32x4){val, val + 1.f, val + 2.f, val + 3.f};
+        if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p + i), "v"(v) : "memory");
+        else *(f32x4*)(p + i) = v;
+    }
+}
 int main() {
     const int wgs = 256, slice = 64 * 1024 / 4;   // 64 KiB per workgroup, 16 MiB per buffer (2 MiB per XCD L2)
     float *X, *Y, *Z, *out; unsigned long long* ts;
@@ -50,6 +60,16 @@ int main() {
         hipLaunchKernelGGL(touch, dim3(wgs), dim3(256), 0, 0, X, out, ts, slice);
         (void)hipDeviceSynchronize(); const double mall = mean();
         printf("   the same slice after 64 MB of other traffic (Infinity Cache hit, L2 miss): %7.0f clk\n", mall);
+        // the producer / consumer case of the decoder's launch chain: kernel A WRITES slice b on XCD b % 8, kernel B reads it there
+        double wr[2];
+        for (int wt = 0; wt < 2; ++wt) {
+            hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, 0, Z, out, ts, (512 << 20) / 4 / 2048);
+            if (wt) hipLaunchKernelGGL(fill<true>, dim3(wgs), dim3(256), 0, 0, X, slice, (float)rep);
+            else hipLaunchKernelGGL(fill<false>, dim3(wgs), dim3(256), 0, 0, X, slice, (float)rep);
+            hipLaunchKernelGGL(touch, dim3(wgs), dim3(256), 0, 0, X, out, ts, slice);
+            (void)hipDeviceSynchronize(); wr[wt] = mean();
+        }
+        printf("   slice WRITTEN by the previous kernel's workgroup b, read by workgroup b: plain stores %7.0f clk | write-through (sc0 sc1) stores %7.0f clk\n", wr[0], wr[1]);
         printf("64 KiB per workgroup: first read (HBM) %7.0f clk | same slice, next kernel %7.0f clk (back to back on the stream: %7.0f) | untouched buffer %7.0f clk\n", cold, again, b2b, coldy);
     }
     return 0;
