@@ -444,23 +444,15 @@ static hipError_t launch_gemm_pipe_r(const mdt_gemm_args& a, int kchunk, hipStre
 // ------------------------------------------------------------------------------------------------
 // k_gemm_tall: 128-row tiles, both operands through LDS by LDS-DMA (body: mdt_tall.h).  Plain prologue, K % 32 == 0.
 // ------------------------------------------------------------------------------------------------
-__constant__ int g_tall_stagger = 0;
 template <int WM, int WN, int NT, int NS, bool RES, int LW>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void k_gemm_tall(mdt_gemm_args a, int grid_n, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int by = logical / grid_n, bx = logical - by * grid_n;
-    // Workgroups that share a CU must not walk their stages in lockstep (the first round of a launch is dispatched all at once:
-    // every co-resident pair would sit at its barrier / wait for its fragments at the same moment, with nobody multiplying).
-    // The dispatcher fills the CUs round-robin, so workgroup b and b + 256 are (as a rule) neighbours on a CU: the later ones
-    // start a fraction of a stage behind.  Speed only.
-    if (g_tall_stagger > 0) {
-        const int slot = (blockIdx.x >> 8) % 3;
-        for (int i = 0; i < slot * g_tall_stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 clocks each
-    }
+    // (staggering the start of the workgroups that share a CU -- b and b + 256 by the dispatcher's round-robin -- by fractions of
+    //  a stage changed nothing: profiles/r04_gemm_train_shapes.txt)
     gemm_tall_tile<WM, WN, NT, NS, RES, LW>(a, by, bx, lds, zeros, threadIdx.x);
 }
-extern "C" void mdt_op_set_tall_stagger(int32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tall_stagger), &v, sizeof(v)); }
 bool mdt_gemm_tall_supported(const mdt_gemm_args& a) {
     // (32-bit byte offsets from the operand bases: the activation block and the weight image each below 4 GiB)
     if ((int64_t)a.M * a.lda >= ((int64_t)1 << 30) || (int64_t)a.N * a.K >= ((int64_t)1 << 30)) return false;

@@ -28,7 +28,6 @@ def run(M, N, K, geos):
     lib.mdt_op_set_gemm_geometry(0)
     print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(res), flush=True)
 geos = [int(x) for x in os.environ.get("GEOS", "0,1,2,3,5,7,8,9").split(",")]
-if os.environ.get("STAGGER"): lib.mdt_op_set_tall_stagger.argtypes = [C.c_int]; lib.mdt_op_set_tall_stagger(int(os.environ["STAGGER"])); print("stagger", os.environ["STAGGER"])
 shapes = [(10240, 384, 384), (10240, 1152, 384), (10240, 1536, 384), (10240, 384, 1536), (104448, 576, 192), (104448, 192, 768)] if os.environ.get("SHORT") else None
 for (M, N, K) in shapes or [(10240, 384, 384), (10240, 1152, 384), (10240, 1536, 384), (10240, 384, 1536), (4096, 384, 384), (4096, 1152, 384), (4096, 1536, 384), (4096, 384, 1536),
                   (104448, 192, 192), (104448, 576, 192), (104448, 1536, 192), (104448, 192, 768), (104448, 192, 576), (104448, 192, 1536)]:
