@@ -27,6 +27,7 @@ def _restore_switch(monkeypatch):
     monkeypatch.setattr(gs, "_GRAPH_MODE", "0")
     yield
     _lib().mdt_op_set_persist(-1)
+    _lib().mdt_op_set_gemm_geometry(0)
     _lib().mdt_op_set_mlp_fuse_min(-1)
     _lib().mdt_op_set_attn_wide_min(-1)
 
@@ -53,6 +54,9 @@ def _sample(model, state, x_T, goal, sig, persist):
     # adds the partial products in another order -- compare like with like
     _lib().mdt_op_set_mlp_fuse_min(-1 if persist else 0)
     _lib().mdt_op_set_attn_wide_min(-1 if persist else 0)  # likewise: attention in the projection's prologue sums in another order
+    # ... and its small-batch geometry runs EVERY product on the split-K tiles, where the dispatcher now picks half-height tiles
+    # for the wide ones: the launch path is held to the split-K kernel for the comparison
+    _lib().mdt_op_set_gemm_geometry(-1 if (not persist and x_T.shape[0] <= 8) else 0)
     eng = _engine(model)
     n0 = eng.persist_launches()
     with torch.no_grad():
