@@ -121,7 +121,7 @@ static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
     return scratch_leave(m, s);
 }
 
-static const int NARROW_SLICES = 128;  // row slices of the narrow (A x D) weight gradients: 128 x 2 workgroups
+static const int NARROW_SLICES = 512;  // row slices of the narrow (A x D) weight gradients: 512 x 2 workgroups of 20 rows at B = 1024 (128 slices: 80 dependent row trips per thread, 42 us per launch)
 
 // ------------------------------------------------------------------------------------------------
 // setup
