@@ -692,7 +692,10 @@ extern "C" void mdt_op_set_attn_wide_min(int32_t rows) { g_attn_wide_override = 
 // mdt_op_set_attn_wide_min(0) switches it off too
 static int g_attn_xattn_min_rows() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_XATTN_MIN"); v = e ? atoi(e) : 1401; if (v == 0) v = 1 << 30; }
+    // (round 3 started it where the fused MLP launch starts, 1401 rows; measured down the batch sizes in round 4 -- tools/latency.py,
+    //  profiles/r04_lowbatch.txt -- it beats k_attn + projection + k_xattn_apply from 200 rows on: B = 20 2.03 -> 1.99 ms, 32 2.13 -> 2.09,
+    //  40 2.48 -> 2.35, 80 3.12 -> 3.03, 100 3.26 -> 3.17, 128 3.62 -> 3.52, 140 4.33 -> 4.14; at 160 rows it loses, 1.71 -> 1.75)
+    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_XATTN_MIN"); v = e ? atoi(e) : 200; if (v == 0) v = 1 << 30; }
     return g_attn_wide_override == 0 ? 1 << 30 : v;
 }
 static int g_attn_xattn_max_batch() {
