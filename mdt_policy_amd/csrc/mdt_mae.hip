@@ -20,8 +20,18 @@ constexpr int TMAX = 128;
 // tuning-only build: thread 0 of workgroup (0, 0) stamps the shader clock at its phase boundaries (mdt_mae_debug_ts)
 __device__ unsigned long long g_mae_ts[16];
 #define MAE_TS(i) if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_mae_ts[i] = __builtin_readcyclecounter();
+// ... and thread 0 of EVERY workgroup (the first 8192) stamps the constant-rate 100 MHz clock at its start and end, with the
+// hardware id of where it ran (mdt_mae_debug_wg): the residency picture of a launch
+__device__ unsigned long long g_mae_wg[3 * 8192];
+#define MAE_WG(e)                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 8192) {                            \
+        const unsigned w_ = blockIdx.x + gridDim.x * blockIdx.y;                                     \
+        g_mae_wg[3 * w_ + e] = __builtin_amdgcn_s_memrealtime();                                     \
+        if (e == 0) g_mae_wg[3 * w_ + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+    }
 #else
 #define MAE_TS(i)
+#define MAE_WG(e)
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -351,6 +361,200 @@ __global__ __launch_bounds__(256) void k_attn_mid_fwd(const float* __restrict__ 
     MAE_TS(4)
 }
 
+// Forward, second form (round 4; default for head dims <= 32): the scores are computed TRANSPOSED -- keys as the MFMA's row
+// operand, queries as its column operand -- so that the accumulator of key tile tj, acc[tj][r] = S[query 16 ti + m][key 16 tj +
+// 4 g + r], is lane for lane the A-operand fragment of the P V product that follows (row = query m, reduction index = key
+// 4 g + e): the probabilities never leave the registers.  The first form passed them through a wave-private 16 x T16 LDS tile
+// with 28 four-byte stores and as many fragment reads per query tile, and that tile was 30 KB of the workgroup's 67 KB of
+// LDS.  V is kept transposed in LDS ([d][key], one 16-byte read per fragment); a query's max and sum are spread over the four
+// lane groups g that hold its keys: two cross-row exchanges each.  40 KB of LDS at T = 102, hd = 24.
+// Measured at B = 1024, H = 8, hd = 24, T = 102 (8192 (sample, head) units; 73 us of MFMA time at 2.4 GHz): 220 us first form,
+// 156 us this one.  What did NOT move it further (profiles/r04_mae_attn.txt): heads per workgroup 1 / 2 / 4 / 8 (+-3 %), six
+// instead of four waves per SIMD (160), stores delayed past the next head's rows (0).  Per query tile a wave issues 98 MFMAs
+// (3136 clocks of the matrix pipe) and ~260 other instructions; the sum of BOTH over a SIMD's waves, not the larger, is what
+// the kernel takes -- the same additive behaviour the GEMM loops show.
+// gfx950's lane-swap instructions: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the
+// second, v_permlane32_swap the upper half of the first with the lower half of the second; fed the same value twice they
+// return (x0 x0 x2 x2 | x1 x1 x3 x3) and (lo lo | hi hi) -- both partners of the xor-16 / xor-32 exchange in two VALU
+// registers, without the LDS round trip of a ds_bpermute (four of those sat between the score and the P V products).
+__device__ __forceinline__ float xrow_max(float v) {   // over the four 16-lane rows of the wave (same column m)
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned w = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ float xrow_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned w = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+}
+size_t attn_mid_lds_fwd2(int hd, int T) {
+    const int T16 = (T + 15) & ~15, hdp = (hd + 15) & ~15;
+    return ((size_t)2 * T16 * (hd + 4) + (size_t)hdp * (T16 + 4)) * sizeof(float);
+}
+// N = key (and query) tiles of 16, a compile-time count: the N score chains of a query tile are then one straight-line block
+// the compiler interleaves (as branches on a run-time count they ran one after the other, each waiting out its MFMA latency).
+template <int HD, int N>
+__global__ __launch_bounds__(N > 4 ? 512 : 256, 4) void k_attn_mid_fwd2(const float* __restrict__ qkv, int64_t ld, float* __restrict__ out, int64_t ldo,
+                                                       int H, int T, float scale, int hpw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = N > 4 ? 512 : 256, NW = NT / 64, ST = HD + 4, NC = (HD + 15) / 16, H4 = HD / 4;
+    constexpr int C16 = HD / 16, REM8 = (HD % 16) == 8, T16 = 16 * N, VS = T16 + 4, n16 = T16 * H4,
+                  U = (n16 + NT - 1) / NT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x, h0 = blockIdx.y * hpw, D = H * HD;
+    const int m = lane & 15, g = lane >> 4;
+    float* qs = lds;                  // [T16][ST], scaled by scale * log2 e
+    float* ks = qs + T16 * ST;        // [T16][ST]
+    float* vt = ks + T16 * ST;        // [HDP][VS]: V transposed (rows d >= HD are never written: they feed output columns nobody stores)
+    const float sl2 = scale * 1.44269504088896341f;  // softmax in base 2
+    // One workgroup walks hpw heads of one sample; the rows of head h + 1 are fetched into registers BEFORE the products of
+    // head h and written to LDS after them (the two workgroups of a CU start together: without this they wait for memory at
+    // the same time).
+    f32x4 rq[U], rk[U], rv[U];
+    // buffer loads: one 32-bit row offset per slot for all three matrices and all heads (the head is the scalar offset, k and v
+    // are immediates) -- the 64-bit pointers of plain loads cost more registers than the rows they fetch
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (int64_t)b * T * ld), 0, 0xffffffffu, 0x00020000);
+    unsigned roff[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = tid + u * NT, t = i / H4, c = i - t * H4;
+        roff[u] = ((unsigned)min(t, T - 1) * (unsigned)ld + 4u * c) << 2;
+    }
+    auto fetch = [&](int h) {
+        const unsigned so = (unsigned)(h * HD) << 2;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rq[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, roff[u], so, 0));
+            rk[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, roff[u] + 4u * D, so, 0));
+            rv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, roff[u] + 8u * D, so, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * NT, t = i / H4, c = i - t * H4;
+            if (i < n16) {   // rows / key columns T .. T16-1: zero (their probabilities are zero; the products must not see NaNs)
+                const bool live = t < T;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)(qs + t * ST + 4 * c) = live ? rq[u] * sl2 : z;
+                *(f32x4*)(ks + t * ST + 4 * c) = live ? rk[u] : z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vt[(4 * c + e) * VS + t] = live ? rv[u][e] : 0.f;
+            }
+        }
+    };
+    MAE_TS(0)
+    MAE_WG(0)
+    fetch(h0);
+    // a wave has at most ONE query tile per head (N <= NW); its output waits in registers until the next head's rows are in LDS
+    // (the wait for those rows is a wait for every earlier memory operation of the wave, these stores included)
+    static_assert(N <= NW, "one query tile per wave and head");
+    f32x4 oacc[NC];
+    int tq = -1;   // the held tile
+    auto store_tile = [&](int h) {
+        if (tq < 0) return;
+        float* o = out + (int64_t)b * T * ldo + h * HD;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 16 * tq + 4 * g + r;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int d = 16 * c + m;
+                if (d < HD && q < T) o[(int64_t)q * ldo + d] = oacc[c][r];
+            }
+        }
+    };
+    for (int hh = 0; hh < hpw; ++hh) {
+        if (hh) __syncthreads();   // every wave is done with the previous head's rows
+        commit();
+        if (hh) store_tile(h0 + hh - 1);
+        tq = -1;
+        __syncthreads();
+                if (hh + 1 < hpw) fetch(h0 + hh + 1);
+        if (hh == 0) { MAE_TS(1) }
+        // e.g. 7 query tiles over 8 waves: which wave (= which SIMD) idles rotates with the sample and the head (b >> 8: the two workgroups
+        // of a CU are 256 apart)
+        const int ti = (wave + b + (b >> 8) + hh) & (NW - 1);
+        if (ti < N) {
+            tq = ti;
+            // the query tile as the COLUMN operand: lane = (query m, d = 4 g + e)
+            const float* qp = qs + (16 * ti + m) * ST;
+            f32x4 qv[C16 + 1];
+#pragma unroll
+            for (int c = 0; c < C16; ++c) qv[c] = *(const f32x4*)(qp + 16 * c + 4 * g);
+            f32x2 q2 = {0.f, 0.f};
+            if (REM8) q2 = *(const f32x2*)(qp + 16 * C16 + 2 * g);
+            f32x4 acc[N];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tj = 0; tj < N; ++tj) {
+                acc[tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                {
+                    const float* kp = ks + (16 * tj + m) * ST;   // the key tile as the ROW operand: lane = (key m, d = 4 g + e)
+#pragma unroll
+                    for (int c = 0; c < C16; ++c) {
+                        const f32x4 kv = *(const f32x4*)(kp + 16 * c + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[e], qv[c][e], acc[tj], 0, 0, 0);
+                    }
+                    if (REM8) {
+                        const f32x2 k2 = *(const f32x2*)(kp + 16 * C16 + 2 * g);
+                        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k2.x, q2.x, acc[tj], 0, 0, 0);
+                        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k2.y, q2.y, acc[tj], 0, 0, 0);
+                    }
+                    // acc[tj][r] = log2 e * scale * q_{16 ti + m} . k_{16 tj + 4 g + r}
+                    if (tj == N - 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * tj + 4 * g + r >= T) acc[tj][r] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[tj][r]);
+                }
+            }
+            mx = xrow_max(mx);   // key 0 is always live: finite
+            float sum = 0.f;
+#pragma unroll
+            for (int tj = 0; tj < N; ++tj) {
+                {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[tj][r] = __builtin_amdgcn_exp2f(acc[tj][r] - mx);   // 2^(-inf) = 0 for the padding
+                        sum += acc[tj][r];
+                    }
+                }
+            }
+            const float inv = 1.0f / xrow_sum(sum);   // of query m, in every lane of column m
+            // O[query 4 g + r][d = 16 c + m] = sum_key P[query][key] V[key][d]: the accumulators ARE the A fragments
+#pragma unroll
+            for (int c = 0; c < NC; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tj = 0; tj < N; ++tj) {
+                {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const f32x4 vv = *(const f32x4*)(vt + (16 * c + m) * VS + 16 * tj + 4 * g);   // lane = (d, keys 4 g .. + 3)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[tj][e], vv[e], oacc[c], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ir = __shfl(inv, 4 * g + r, 64);   // the normaliser of output row 4 g + r lives in column 4 g + r
+#pragma unroll
+                for (int c = 0; c < NC; ++c) oacc[c][r] *= ir;
+            }
+        }
+    }
+    store_tile(h0 + hpw - 1);
+    MAE_TS(4)
+    MAE_WG(1)
+}
+
 // Backward.  The forward output O arrives from the caller (autograd keeps it: it is the input of the projection that
 // follows), so sum_j P_ij dP_ij = dO_i . O_i needs no second P V product here.
 template <int HD>
@@ -584,6 +788,31 @@ size_t attn_mid_lds(int hd, int T, bool bwd) {
 
 template <int HD>
 hipError_t launch_fwd(const float* qkv, int64_t ld, float* out, int64_t ldo, int64_t B, int H, int T, float scale, hipStream_t s) {
+    static int form = -1;  // MDT_HIP_ATTN_FWD=1: the first form (probabilities through a wave-private LDS tile), for A/B runs
+    if (form < 0) { const char* e = getenv("MDT_HIP_ATTN_FWD"); form = e ? atoi(e) : 2; }
+    if (form == 2 && HD <= 32) {
+        const size_t lds2 = attn_mid_lds_fwd2(HD, T);
+        // heads per workgroup: all of them once that still leaves four waves per SIMD on every CU, else the largest divisor of H
+        // that does
+        static int hpw_env = -1;
+        if (hpw_env < 0) { const char* e = getenv("MDT_HIP_ATTN_HPW"); hpw_env = e ? atoi(e) : 0; }
+        const int n = (T + 15) >> 4, per_cu = n > 4 ? 2 : 4;
+        int hpw = H;
+        while (hpw > 1 && (B * (H / hpw) < 256 * per_cu || H % hpw)) --hpw;
+        if (hpw_env > 0 && H % hpw_env == 0) hpw = hpw_env;
+        const dim3 grid((unsigned)B, H / hpw);
+#define MDT_FWD2(N_)                                                                                                              \
+    case N_: {                                                                                                                    \
+        hipError_t e2 = hipFuncSetAttribute((const void*)k_attn_mid_fwd2<HD, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        if (e2 != hipSuccess) return e2;                                                                                          \
+        hipLaunchKernelGGL((k_attn_mid_fwd2<HD, N_>), grid, dim3(N_ > 4 ? 512 : 256), lds2, s, qkv, ld, out, ldo, H, T, scale, hpw); \
+        return hipGetLastError();                                                                                                 \
+    }
+        switch (n) {
+            MDT_FWD2(1) MDT_FWD2(2) MDT_FWD2(3) MDT_FWD2(4) MDT_FWD2(5) MDT_FWD2(6) MDT_FWD2(7) MDT_FWD2(8)
+        }
+#undef MDT_FWD2
+    }
     const size_t lds = attn_mid_lds(HD, T, false);
     hipError_t e = hipFuncSetAttribute((const void*)k_attn_mid_fwd<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -655,6 +884,9 @@ __global__ __launch_bounds__(256) void k_scale_residual_bwd(const float* __restr
 #ifdef MDT_DEBUG_TIMING
 extern "C" int mdt_mae_debug_ts(unsigned long long* out16) {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mae_ts), 16 * sizeof(unsigned long long));
+}
+extern "C" int mdt_mae_debug_wg(unsigned long long* out, int n_wg) {   // (start, end, hw id) per workgroup, 100 MHz ticks
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mae_wg), (size_t)3 * (n_wg < 8192 ? n_wg : 8192) * sizeof(unsigned long long));
 }
 #endif
 
