@@ -105,6 +105,29 @@ def test_attention_mid_forward_and_backward(B, H, hd, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,hd,T", [(256, 8, 24, 102), (1024, 8, 24, 102), (600, 6, 24, 70), (1100, 4, 32, 90), (520, 3, 16, 51), (64, 8, 24, 102)])
+def test_attention_mid_forward_head_walk_regimes(B, H, hd, T):
+    """Batch sizes at which one workgroup of the forward walks several heads of a sample (all of them from B * H / hpw >= 512
+    workgroups on: hpw = 4, 8, 3, 2, 3, 1 here), every tile count 4 .. 7, against float64 attention on the GPU."""
+    L, lib = _lib()
+    D = H * hd
+    g = torch.Generator(device="cuda").manual_seed(1234 + B)
+    qkv = torch.randn(B, T, 3 * D, device="cuda", generator=g) * 1.5
+    q, k, v = (t.reshape(B, T, H, hd).transpose(1, 2) for t in qkv.double().split(D, dim=-1))
+    ref = ((q @ k.transpose(-1, -2) * hd ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(B, T, D)
+    out = torch.full((B, T, D), float("nan"), device="cuda")
+    L.check(lib.mdt_op_attn_mid_fwd(qkv.data_ptr(), 3 * D, out.data_ptr(), D, B, H, hd, T, hd ** -0.5, _s()))
+    assert_close(out.cpu(), ref.cpu(), what="attention output")
+    # strided views (the model passes the qkv projection's output and writes into a wider buffer)
+    wide_in = torch.randn(B, T, 3 * D + 8, device="cuda", generator=g)
+    wide_in[..., :3 * D] = qkv
+    wide_out = torch.full((B, T, D + 4), float("nan"), device="cuda")
+    L.check(lib.mdt_op_attn_mid_fwd(wide_in.data_ptr(), 3 * D + 8, wide_out.data_ptr(), D + 4, B, H, hd, T, hd ** -0.5, _s()))
+    assert torch.equal(wide_out[..., :D], out)
+    assert torch.isnan(wide_out[..., D:]).all()
+
+
+@pytest.mark.gpu
 def test_attention_mid_rejects_what_it_cannot_run():
     L, lib = _lib()
     x = torch.zeros(1, 129, 3 * 48, device="cuda")
