@@ -608,12 +608,14 @@ __global__ __launch_bounds__(512) void k_attn_mid_bwd(const float* __restrict__ 
     MAE_TS(12)
 }
 
-// acc[kt][q] += sum over the 16 rows i of a wave-private tile  W[i][16 kt + .] * x[i][16 q + .]   (kt < n key tiles, q < NC
-// feature tiles): the contribution of ONE query tile to dV = P^T dO or dK = dS^T Q.  W: 16 x ss tile in LDS (row i, key
-// column), read transposed (lane: key 16 kt + m, the four rows 4 g + e); x: the tile's 16 rows of dO / Q (stride HD + 4).
+// acc[kt][q] += sum over the 16 rows i of one query tile  W[i][16 kt + .] * x[i][16 q + .]   (kt < n key tiles, q < NC feature
+// tiles): the tile's contribution to dV = P^T dO or dK = dS^T Q.  W never touches LDS: a score-row accumulator from
+// score_row_tile, w[kt][r] = W[row 4 g + r][key 16 kt + m], is lane for lane the transposed operand (row of the product = key
+// m, reduction index = query row 4 g + e).  x: the tile's 16 rows of dO / Q in LDS (stride HD + 4).  (Until round 4 P and dS
+// both passed through the wave's LDS tile for this: 28 four-byte stores and 28 four-byte reads per product and query tile.)
 template <int HD, int NTJ>
-__device__ __forceinline__ void mma_acc_trans(const float* W, int ss, const float* xrows, int n, int lane,
-                                              f32x4 (&acc)[NTJ][(HD + 15) / 16]) {
+__device__ __forceinline__ void mma_acc_trans_reg(const f32x4 (&w)[NTJ], const float* xrows, int n, int lane,
+                                                  f32x4 (&acc)[NTJ][(HD + 15) / 16]) {
     constexpr int ST = HD + 4, NC = (HD + 15) / 16;
     const int m = lane & 15, g = lane >> 4;
     const float* xp = xrows + (4 * g) * ST + m;
@@ -623,25 +625,22 @@ __device__ __forceinline__ void mma_acc_trans(const float* W, int ss, const floa
         const float* r = xp + 16 * q;
         xv[q] = (f32x4){r[0], r[ST], r[2 * ST], r[3 * ST]};
     }
-    const float* wp = W + (4 * g) * ss + m;
 #pragma unroll
     for (int kt = 0; kt < NTJ; ++kt) {
         if (kt < n) {
-            const float* w = wp + 16 * kt;
-            const f32x4 wv = (f32x4){w[0], w[ss], w[2 * ss], w[3 * ss]};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int q = 0; q < NC; ++q) acc[kt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xv[q][e], acc[kt][q], 0, 0, 0);
+                for (int q = 0; q < NC; ++q) acc[kt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt][e], xv[q][e], acc[kt][q], 0, 0, 0);
         }
     }
 }
 
 // Backward, second form (default): like the forward, every wave owns whole QUERY tiles and keeps their score rows in the MFMA
 // accumulators -- P (recomputed, softmax in registers), dP = dO V^T and dS = P (dP - dO.O) never exist as a T x T matrix.  Per
-// query tile the wave passes P, then dS, through ONE wave-private 16 x T16 LDS tile (accumulator -> operand layout): dQ rows
-// go straight to memory, the tile's contributions to dV = P^T dO and dK = dS^T Q accumulate in registers (T16 x hd each) across
-// the wave's tiles.  One workgroup barrier after the loads, none inside; the four waves' dK / dV partials then meet in the
+// query tile the wave passes dS through ONE wave-private 16 x T16 LDS tile (accumulator -> row-operand layout) for dQ = dS K,
+// whose rows go straight to memory; the tile's contributions to dV = P^T dO and dK = dS^T Q take P and dS from the
+// accumulators as they are (mma_acc_trans_reg) and accumulate in registers (T16 x hd each) across the wave's tiles.  One workgroup barrier after the loads, none inside; the four waves' dK / dV partials then meet in the
 // (now free) q / k / v / dO buffers in a fixed order.  80 KB of LDS at T = 102, hd = 24 (the first form: 115 KB, five
 // barrier-separated phases): two workgroups per CU, one loading or reducing while the other multiplies.
 template <int HD>
@@ -661,6 +660,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
     const float* base = qkv + (int64_t)b * T * ld + h * HD;
     const float* dob = d_out + (int64_t)b * T * ldd + h * HD;
     const float* fob = fwd_out + (int64_t)b * T * ldf + h * HD;
+    MAE_TS(5)
+    MAE_WG(0)
     {
         const float* const src[4] = {base, base + D, base + 2 * D, dob};
         const int64_t lds_[4] = {ld, ld, ld, ldd};
@@ -677,6 +678,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
         rowdot[i] = i < T ? acc : 0.f;
     }
     __syncthreads();
+    MAE_TS(6)
     float* gq = d_qkv + (int64_t)b * T * ldg + h * HD;
     const float sl2 = scale * 1.44269504088896341f;    // softmax in base 2
     f32x4 dK[NTJ][NC], dV[NTJ][NC];
@@ -684,7 +686,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
     for (int kt = 0; kt < NTJ; ++kt)
 #pragma unroll
         for (int q = 0; q < NC; ++q) { dK[kt][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[kt][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int ti = wave; ti < n; ti += NW) {
+    // n tiles over 4 waves (7: 2 2 2 1): which wave (= which SIMD) gets the light share rotates with the sample and the head
+    for (int ti = (wave + b + (b >> 8) + h) & (NW - 1); ti < n; ti += NW) {
         f32x4 acc[NTJ], dp[NTJ];
         score_row_tile<HD, NTJ>(qs + 16 * ti * ST, ks, n, lane, acc);
         score_row_tile<HD, NTJ>(dos + 16 * ti * ST, vs, n, lane, dp);   // dP rows = dO rows . V rows
@@ -716,29 +719,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum[r] = 1.0f / group_sum(sum[r]);
-        // P -> tile; dS = scale * P * (dP - rowdot) stays in `dp`
+        // P stays in `acc`, dS = scale * P * (dP - rowdot) in `dp`; only dS passes through the tile (dQ wants it by rows)
 #pragma unroll
         for (int tj = 0; tj < NTJ; ++tj) {
             if (tj < n) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pv = acc[tj][r] * sum[r];
-                    ptile[(4 * g + r) * ss + 16 * tj + m] = pv;
+                    acc[tj][r] = pv;
                     dp[tj][r] = pv * (dp[tj][r] - rd[r]) * scale;
+                    ptile[(4 * g + r) * ss + 16 * tj + m] = dp[tj][r];
                 }
             }
         }
-        mma_acc_trans<HD, NTJ>(ptile, ss, dos + 16 * ti * ST, n, lane, dV);   // dV += P_tile^T dO_tile
-#pragma unroll
-        for (int tj = 0; tj < NTJ; ++tj) {
-            if (tj < n) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ptile[(4 * g + r) * ss + 16 * tj + m] = dp[tj][r];
-            }
-        }
+        mma_acc_trans_reg<HD, NTJ>(acc, dos + 16 * ti * ST, n, lane, dV);   // dV += P_tile^T dO_tile
+        mma_acc_trans_reg<HD, NTJ>(dp, qs + 16 * ti * ST, n, lane, dK);     // dK += dS_tile^T Q_tile
         mma_rows_tile<HD, false>(ptile - 16 * ti * ss, ss, ks, gq, ldg, T, ti, lane);   // dQ rows of this tile = dS K
-        mma_acc_trans<HD, NTJ>(ptile, ss, qs + 16 * ti * ST, n, lane, dK);     // dK += dS_tile^T Q_tile
     }
+    MAE_TS(7)
     __syncthreads();   // everyone is done with q / k / v / dO: the four buffers now take the partial sums
     // waves 0, 1 store their partials (dK -> buffers 0 / 1, dV -> 2 / 3), waves 2, 3 add theirs to them, then everybody adds
     // the two halves and writes the rows out: ((w0 + w2) + (w1 + w3)), a fixed order
@@ -767,12 +765,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
         }
         __syncthreads();
     }
+    MAE_TS(8)
     for (int i = tid; i < T * H4; i += NT) {
         const int t = i / H4, c = i - t * H4;
         const int o = t * ST + 4 * c;
         *(f32x4*)(gq + D + (int64_t)t * ldg + 4 * c) = *(const f32x4*)(lds + o) + *(const f32x4*)(lds + T16 * ST + o);
         *(f32x4*)(gq + 2 * D + (int64_t)t * ldg + 4 * c) = *(const f32x4*)(lds + 2 * T16 * ST + o) + *(const f32x4*)(lds + 3 * T16 * ST + o);
     }
+    MAE_TS(9)
+    MAE_WG(1)
 }
 
 size_t attn_mid_lds2(int hd, int T) {

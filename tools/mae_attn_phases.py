@@ -34,12 +34,12 @@ assert lib.mdt_mae_debug_ts(ts) == 0
 t = list(ts)
 names_f = ["load q k v", "row tiles of wave 0 (scores, softmax, P V)"]
 t[2] = t[4]
-names_b = ["zero S + load q k v dO O", "rowdot + scores", "softmax", "dV", "-", "dS", "dQ and dK"]
+names_b = ["load q k v dO, rowdot", "query tiles of wave 0", "barrier + partial dK / dV sums (LDS)", "write dK dV"]
 print("forward, workgroup (0,0), shader clocks:")
 for i, n in enumerate(names_f):
     print(f"  {n:44s} {t[i + 1] - t[i]:8d}")
 print(f"  {'total':26s} {t[4] - t[0]:8d}")
 print("backward:")
 for i, n in enumerate(names_b):
-    print(f"  {n:26s} {t[6 + i] - t[5 + i]:8d}")
-print(f"  {'total':26s} {t[12] - t[5]:8d}")
+    print(f"  {n:36s} {t[6 + i] - t[5 + i]:8d}")
+print(f"  {'total':36s} {t[9] - t[5]:8d}")

@@ -1,5 +1,5 @@
 """Residency picture of the masked-image head's attention forward: start / end of every workgroup on the constant 100 MHz
-clock and where it ran (-DMDT_DEBUG_TIMING build).   usage: MDT_HIP_LIB=<debug .so> python tools/mae_attn_residency.py [B H hd T]"""
+clock and where it ran (-DMDT_DEBUG_TIMING build).   usage: MDT_HIP_LIB=<debug .so> python tools/mae_attn_residency.py [B H hd T [bwd]]"""
 import ctypes as C
 import os
 import sys
@@ -18,8 +18,14 @@ D = H * hd
 qkv = torch.randn(B, T, 3 * D, device="cuda")
 out = torch.empty(B, T, D, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
+bwd = len(sys.argv) > 5 and sys.argv[5] == "bwd"
+do = torch.randn(B, T, D, device="cuda")
+dqkv = torch.empty_like(qkv)
 for _ in range(3):
     _lib.check(lib.mdt_op_attn_mid_fwd(qkv.data_ptr(), 3 * D, out.data_ptr(), D, B, H, hd, T, hd ** -0.5, s))
+if bwd:
+    for _ in range(3):
+        _lib.check(lib.mdt_op_attn_mid_bwd(qkv.data_ptr(), 3 * D, out.data_ptr(), D, do.data_ptr(), D, dqkv.data_ptr(), 3 * D, B, H, hd, T, hd ** -0.5, s))
 torch.cuda.synchronize()
 n = min(8192, B * H)
 buf = np.zeros(3 * n, dtype=np.uint64)
@@ -31,7 +37,7 @@ st, en = (w[:, 0] - t0).astype(np.int64), (w[:, 1] - t0).astype(np.int64)
 xcc = (w[:, 2] >> np.uint64(32)) & np.uint64(0xf)
 hw = w[:, 2] & np.uint64(0xffffffff)
 cu = ((hw >> np.uint64(8)) & np.uint64(0xf)) | (((hw >> np.uint64(13)) & np.uint64(0x7)) << np.uint64(4)) | (xcc << np.uint64(8))
-print(f"B={B} H={H} hd={hd} T={T}: {len(w)} workgroups stamped; span {en.max() / 100:.1f} us; lifetime mean {np.mean(en - st) / 100:.1f} us "
+print(f"{'backward' if bwd else 'forward'} B={B} H={H} hd={hd} T={T}: {len(w)} workgroups stamped; span {en.max() / 100:.1f} us; lifetime mean {np.mean(en - st) / 100:.1f} us "
       f"(min {np.min(en - st) / 100:.1f}, max {np.max(en - st) / 100:.1f})")
 print(f"distinct (xcc, se, cu) = {len(set(cu.tolist()))}; workgroups per XCC: {np.bincount(xcc.astype(np.int64)).tolist()}")
 for q in (0.1, 0.25, 0.5, 0.75, 0.9):
