@@ -30,6 +30,11 @@ mdt_status mdt_op_rms_fwd(const float *x, const float *g, float *out, int64_t M,
 int64_t mdt_op_rms_bwd_scratch(int64_t M, int32_t D);
 mdt_status mdt_op_rms_bwd(const float *x, const float *g, const float *dy, float *dx, int32_t accumulate_dx, float *dg,
                           int32_t accumulate_dg, int64_t M, int32_t D, float eps, float *scratch, void *stream);
+/* The norm at the head of a residual branch (x feeds the norm AND the residual sum, masked_transformer_decoder.py:110-121 /
+ * voltron Block): dx = d_res + backward of the norm, d_res = the gradient arriving on the residual path -- the sum autograd
+ * would form with a separate elementwise launch. */
+mdt_status mdt_op_rms_bwd_res(const float *x, const float *g, const float *dy, const float *d_res, float *dx, float *dg,
+                              int32_t accumulate_dg, int64_t M, int32_t D, float eps, float *scratch, void *stream);
 
 /* voltron SwishGLU (transformer_blocks.py:55-62): u = [projected | gate] (M, 2 H) -> projected * silu(gate) (M, H) */
 mdt_status mdt_op_swiglu_fwd(const float *u, float *out, int64_t M, int32_t H, void *stream);

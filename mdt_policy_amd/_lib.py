@@ -260,6 +260,7 @@ SYMBOLS = [
     ("mdt_op_rms_fwd", _I32, [_VP, _VP, _VP, _I64, _I32, _F, _VP]),
     ("mdt_op_rms_bwd_scratch", _I64, [_I64, _I32]),
     ("mdt_op_rms_bwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _I32, _I64, _I32, _F, _VP, _VP]),
+    ("mdt_op_rms_bwd_res", _I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I64, _I32, _F, _VP, _VP]),
     ("mdt_op_scale_residual_fwd", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_scale_residual_bwd_scratch", _I64, [_I64, _I32]),
     ("mdt_op_scale_residual_bwd", _I32, [_VP, _VP, _VP, _VP, _VP, _I64, _I32, _VP, _VP]),

@@ -204,7 +204,7 @@ hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks,
 // RMSNorm / SwishGLU row kernels (mdt_map_pool.hip), shared with the masked-image decoder's ops (mdt_mae.hip)
 hipError_t mdt_launch_rms_fwd(const float* x, const float* g, float* out, int64_t M, int D, float eps, hipStream_t s);
 hipError_t mdt_launch_rms_bwd(const float* x, const float* g, const float* dy, float* dx, int accumulate, float* pg, int64_t M,
-                              int D, float eps, hipStream_t s);
+                              int D, float eps, hipStream_t s, const float* res = nullptr);
 hipError_t mdt_launch_swiglu_fwd(const float* u, float* out, int64_t M, int Hm, hipStream_t s);
 hipError_t mdt_launch_swiglu_bwd(const float* u, const float* d_out, float* du, int64_t M, int Hm, hipStream_t s);
 struct mdt_model;

@@ -791,7 +791,8 @@ template <int HD>
 hipError_t launch_fwd(const float* qkv, int64_t ld, float* out, int64_t ldo, int64_t B, int H, int T, float scale, hipStream_t s) {
     static int form = -1;  // MDT_HIP_ATTN_FWD=1: the first form (probabilities through a wave-private LDS tile), for A/B runs
     if (form < 0) { const char* e = getenv("MDT_HIP_ATTN_FWD"); form = e ? atoi(e) : 2; }
-    if (form == 2 && HD <= 32) {
+    // (the second form addresses a sample's rows with 32-bit byte offsets: a sample must span less than 2 GiB)
+    if (form == 2 && HD <= 32 && (int64_t)T * ld + 3ll * H * HD < (1ll << 29)) {
         const size_t lds2 = attn_mid_lds_fwd2(HD, T);
         // heads per workgroup: all of them once that still leaves four waves per SIMD on every CU, else the largest divisor of H
         // that does
@@ -946,6 +947,16 @@ extern "C" mdt_status mdt_op_rms_bwd(const float* x, const float* g, const float
         return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_rms_bwd: bad argument (D <= 512)");
     hipStream_t s = (hipStream_t)stream;
     LAUNCH(mdt_launch_rms_bwd(x, g, dy, dx, accumulate_dx, scratch, M, D, eps, s));
+    if (dg) LAUNCH(mdt_launch_colsum(scratch, D, (int)((M + 3) / 4), D, dg, accumulate_dg, s));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_rms_bwd_res(const float* x, const float* g, const float* dy, const float* d_res, float* dx, float* dg,
+                                         int32_t accumulate_dg, int64_t M, int32_t D, float eps, float* scratch, void* stream) {
+    if (!x || !g || !dy || !d_res || !dx || !scratch || M < 1 || D < 1 || D > 512)
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_rms_bwd_res: bad argument (D <= 512)");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(mdt_launch_rms_bwd(x, g, dy, dx, 0, scratch, M, D, eps, s, d_res));
     if (dg) LAUNCH(mdt_launch_colsum(scratch, D, (int)((M + 3) / 4), D, dg, accumulate_dg, s));
     return MDT_OK;
 }

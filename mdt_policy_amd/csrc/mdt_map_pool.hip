@@ -143,22 +143,24 @@ __global__ __launch_bounds__(256) void k_rms_fwd(const float* __restrict__ x, co
 }
 
 // dx (+)= g dy / n - x * (sum_j g_j dy_j x_j) / (D n^3)   (clamped rows: dx = g dy / eps);  pg: per-workgroup partial
-// (4 rows) of dg = sum_rows dy x / n, reduced by k_colsum afterwards
+// (4 rows) of dg = sum_rows dy x / n, reduced by k_colsum afterwards.  res != nullptr: dx = res + that (the gradient that
+// reaches x past the norm, on the residual path: autograd's separate add of the two becomes one more read here)
 __global__ __launch_bounds__(256) void k_rms_bwd(const float* __restrict__ x, const float* __restrict__ g,
-                                                 const float* __restrict__ dy, float* __restrict__ dx, int accumulate,
-                                                 float* __restrict__ pg, int M, int D, float eps) {
+                                                 const float* __restrict__ dy, const float* __restrict__ res, float* __restrict__ dx,
+                                                 int accumulate, float* __restrict__ pg, int M, int D, float eps) {
     __shared__ float red[4][64 * RMS_MAXC];
     const int wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
     float dgv[RMS_MAXC];
 #pragma unroll
     for (int i = 0; i < RMS_MAXC; ++i) dgv[i] = 0.f;
     if (row < M) {
-        float xv[RMS_MAXC], gd[RMS_MAXC];
+        float xv[RMS_MAXC], gd[RMS_MAXC], rv[RMS_MAXC];
         float ss = 0.f, dot = 0.f;
 #pragma unroll
         for (int i = 0; i < RMS_MAXC; ++i) {
             const int c = lane + 64 * i;
             xv[i] = c < D ? x[(int64_t)row * D + c] : 0.f;
+            rv[i] = (res != nullptr && c < D) ? res[(int64_t)row * D + c] : 0.f;
             const float d = c < D ? dy[(int64_t)row * D + c] : 0.f;
             gd[i] = c < D ? g[c] * d : 0.f;
             ss = fmaf(xv[i], xv[i], ss);
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void k_rms_bwd(const float* __restrict__ x, co
         for (int i = 0; i < RMS_MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < D) {
-                const float v = gd[i] / n - xv[i] * k;
+                const float v = gd[i] / n - xv[i] * k + rv[i];
                 float* p = dx + (int64_t)row * D + c;
                 *p = accumulate ? *p + v : v;
             }
@@ -215,9 +217,9 @@ hipError_t mdt_launch_rms_fwd(const float* x, const float* g, float* out, int64_
 }
 // pg: ceil(M / 4) x D floats of scratch (per-workgroup partials of dg; reduce with mdt_launch_colsum)
 hipError_t mdt_launch_rms_bwd(const float* x, const float* g, const float* dy, float* dx, int accumulate, float* pg, int64_t M,
-                              int D, float eps, hipStream_t s) {
+                              int D, float eps, hipStream_t s, const float* res) {
     if (D > 64 * RMS_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_rms_bwd, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, g, dy, dx, accumulate, pg, (int)M, D, eps);
+    hipLaunchKernelGGL(k_rms_bwd, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, g, dy, res, dx, accumulate, pg, (int)M, D, eps);
     return hipGetLastError();
 }
 hipError_t mdt_launch_swiglu_fwd(const float* u, float* out, int64_t M, int Hm, hipStream_t s) {
@@ -599,7 +601,7 @@ static mdt_status m_lin_bwd(mdt_map_pool* p, float* grads, const Lin& l, const f
 static mdt_status m_rms_bwd(mdt_map_pool* p, float* grads, const float* x, const float* g, const float* dy, float* dx, int acc,
                             int64_t M, hipStream_t s) {
     const int blocks = (int)((M + 3) / 4);
-    hipLaunchKernelGGL(k_rms_bwd, dim3(blocks), dim3(256), 0, s, x, g, dy, dx, acc, p->g_pg, (int)M, p->D, RMS_EPS);
+    hipLaunchKernelGGL(k_rms_bwd, dim3(blocks), dim3(256), 0, s, x, g, dy, (const float*)nullptr, dx, acc, p->g_pg, (int)M, p->D, RMS_EPS);
     LAUNCH(hipGetLastError());
     LAUNCH(mdt_launch_colsum(p->g_pg, p->D, blocks, p->D, grad_of(p, grads, g), 1, s));
     return MDT_OK;

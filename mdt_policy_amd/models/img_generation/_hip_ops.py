@@ -261,6 +261,45 @@ class HipRMSNorm(torch.autograd.Function):
         return dx.reshape(ctx.xshape), dg
 
 
+class HipRMSNormBranch(torch.autograd.Function):
+    """The norm at the head of a residual branch: returns (x, RMSNorm(x)) -- x for the residual sum, the normed rows for
+    the branch -- so that ONE backward sees both gradients that reach x and the norm's backward kernel adds them on its way
+    out (`mdt_op_rms_bwd_res`).  With `HipRMSNorm` autograd forms that sum itself: one elementwise launch over the
+    (B, T, D) gradient per branch, twelve per step of the six-block decoder."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        lib = _lib.load()
+        D = x.shape[-1]
+        x2 = _c(x).reshape(-1, D)
+        gg = _c(g)
+        out = torch.empty_like(x2)
+        _lib.check(lib.mdt_op_rms_fwd(x2.data_ptr(), gg.data_ptr(), out.data_ptr(), x2.shape[0], D, RMS_EPS, _stream(x2)))
+        ctx.save_for_backward(x2, gg)
+        ctx.xshape = x.shape
+        return x.view_as(x), out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, d_res, dy):
+        lib = _lib.load()
+        x2, g = ctx.saved_tensors
+        M, D = x2.shape
+        if dy is None:
+            return d_res, None
+        d = _c(dy).reshape(M, D)
+        dx = torch.empty_like(x2)
+        dg = torch.empty_like(g)
+        scratch = torch.empty(lib.mdt_op_rms_bwd_scratch(M, D), device=d.device, dtype=torch.float32)
+        if d_res is None:
+            _lib.check(lib.mdt_op_rms_bwd(x2.data_ptr(), g.data_ptr(), d.data_ptr(), dx.data_ptr(), 0, dg.data_ptr(), 0, M, D, RMS_EPS,
+                                          scratch.data_ptr(), _stream(d)))
+        else:
+            r = _c(d_res).reshape(M, D)
+            _lib.check(lib.mdt_op_rms_bwd_res(x2.data_ptr(), g.data_ptr(), d.data_ptr(), r.data_ptr(), dx.data_ptr(), dg.data_ptr(), 0,
+                                              M, D, RMS_EPS, scratch.data_ptr(), _stream(d)))
+        return dx.reshape(ctx.xshape), dg
+
+
 class HipSwishGLU(torch.autograd.Function):
     """u = [projected | gate] (..., 2H) -> projected * silu(gate)."""
 

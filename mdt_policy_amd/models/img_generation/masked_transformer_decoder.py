@@ -256,11 +256,13 @@ class MaskedTransformerImgDecoder(nn.Module):
         tokens = tokens + pe[None] + self.ctx_dec_pe[:, :2]      # position embedding a second time, as the reference (:268-271)
         x = torch.cat([emb_context, tokens.reshape(B, X * n, d)], dim=1)
         for blk in self.decoder_blocks:
-            qkv = self._linear(ops.HipRMSNorm.apply(x, blk.pre_norm_attn.g), blk.attn.qkv)
-            att = ops.HipSelfAttention.apply(qkv, blk.attn.n_heads, blk.attn.scale)
+            # (x feeds the norm and the residual sum: HipRMSNormBranch hands both uses out so its backward adds their gradients)
+            x, h = ops.HipRMSNormBranch.apply(x, blk.pre_norm_attn.g)
+            att = ops.HipSelfAttention.apply(self._linear(h, blk.attn.qkv), blk.attn.n_heads, blk.attn.scale)
             x = ops.HipScaleResidual.apply(x, self._linear(att, blk.attn.proj), blk.layer_scale_attn.gamma)
-            z = ops.HipSwiGLUMLP.apply(ops.HipRMSNorm.apply(x, blk.pre_norm_mlp.g), blk.mlp[0].project.weight, blk.mlp[0].project.bias,
-                                       blk.mlp[1].weight, blk.mlp[1].bias, self._packs)
+            x, h = ops.HipRMSNormBranch.apply(x, blk.pre_norm_mlp.g)
+            z = ops.HipSwiGLUMLP.apply(h, blk.mlp[0].project.weight, blk.mlp[0].project.bias, blk.mlp[1].weight, blk.mlp[1].bias,
+                                       self._packs)
             x = ops.HipScaleResidual.apply(x, z, blk.layer_scale_mlp.gamma)
         x = ops.HipRMSNorm.apply(x, self.decoder_norm.g)
         rec = self._linear(x[:, context.shape[1]:], self.decoder_patch_prediction).reshape(B, X, n, -1)

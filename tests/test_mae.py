@@ -155,6 +155,12 @@ def test_rmsnorm_and_swiglu_ops(M, D):
     assert_close(out.cpu(), ref.detach(), what="rmsnorm")
     assert_close(dx.cpu(), x64.grad, what="rmsnorm dx")
     assert_close(dg.cpu(), g64.grad, rtol=1e-3, atol=1e-4 * max(1.0, (M / 64) ** 0.5), what="rmsnorm dg")
+    # the norm at the head of a residual branch: dx = d_res + the above, bit for bit the separate sum
+    d_res = torch.from_numpy(synthetic.normal("d_res", (M, D), 166)).cuda()
+    dx2, dg2 = torch.full_like(xd, float("nan")), torch.empty_like(gd)
+    L.check(lib.mdt_op_rms_bwd_res(xd.data_ptr(), gd.data_ptr(), dyd.data_ptr(), d_res.data_ptr(), dx2.data_ptr(), dg2.data_ptr(), 0, M,
+                                   D, 1e-8, scratch.data_ptr(), _s()))
+    assert torch.equal(dx2, dx + d_res) and torch.equal(dg2, dg)
     H = D // 2
     u64 = x.double().requires_grad_()
     a, b = u64.tensor_split(2, dim=-1)
