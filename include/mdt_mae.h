@@ -49,6 +49,19 @@ int64_t mdt_op_scale_residual_bwd_scratch(int64_t M, int32_t D);
 mdt_status mdt_op_scale_residual_bwd(const float *g, const float *z, const float *gamma, float *dz, float *dgamma, int64_t M,
                                      int32_t D, float *scratch, void *stream);
 
+/* The same LayerScale + residual AND the RMSNorm at the head of the next branch, one pass each way (the voltron Block the
+ * reference builds its decoder from, masked_transformer_decoder.py:110-121: x = x + ls(branch(norm(x))) twice per block):
+ *   x_new = x + gamma * z ;  h = RMSNorm(x_new; g_norm)
+ * backward: d_res = gradient arriving at x_new on the residual path (NULL: none), d_h = gradient of h;
+ *   d_x = d_res + RMSNorm'(d_h) ;  d_z = gamma * d_x ;  d_gamma = sum_rows d_x * z ;  d_gnorm = sum_rows d_h x_new / n
+ * scratch: mdt_op_scale_residual_rms_bwd_scratch(M, D) floats.  D a multiple of 4, <= 512; pointers 16-byte aligned. */
+mdt_status mdt_op_scale_residual_rms_fwd(const float *x, const float *z, const float *gamma, const float *g_norm, float *x_new,
+                                         float *h, int64_t M, int32_t D, float eps, void *stream);
+int64_t mdt_op_scale_residual_rms_bwd_scratch(int64_t M, int32_t D);
+mdt_status mdt_op_scale_residual_rms_bwd(const float *x_new, const float *g_norm, const float *d_h, const float *d_res,
+                                         const float *z, const float *gamma, float *d_x, float *d_z, float *d_gamma,
+                                         float *d_gnorm, int64_t M, int32_t D, float eps, float *scratch, void *stream);
+
 /* Unmasked multi-head self-attention over T <= 128 tokens (voltron Attention.forward):
  *   qkv (B*T, 3*H*hd) = q | k | v column blocks (row stride ld_qkv), head h at columns h*hd;
  *   out (B*T, H*hd) = softmax(q k^T * scale) v.   hd in {16, 24, 32, 48, 64}.  One workgroup per (sample, head). */

@@ -264,6 +264,9 @@ SYMBOLS = [
     ("mdt_op_scale_residual_fwd", _I32, [_VP, _VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_scale_residual_bwd_scratch", _I64, [_I64, _I32]),
     ("mdt_op_scale_residual_bwd", _I32, [_VP, _VP, _VP, _VP, _VP, _I64, _I32, _VP, _VP]),
+    ("mdt_op_scale_residual_rms_fwd", _I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _I32, _F, _VP]),
+    ("mdt_op_scale_residual_rms_bwd_scratch", _I64, [_I64, _I32]),
+    ("mdt_op_scale_residual_rms_bwd", _I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I32, _F, _VP, _VP]),
     ("mdt_op_swiglu_fwd", _I32, [_VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_swiglu_bwd", _I32, [_VP, _VP, _VP, _I64, _I32, _VP]),
     ("mdt_op_attn_mid_fwd", _I32, [_VP, _I64, _VP, _I64, _I64, _I32, _I32, _I32, _F, _VP]),

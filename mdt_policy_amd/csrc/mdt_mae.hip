@@ -881,6 +881,101 @@ __global__ __launch_bounds__(256) void k_scale_residual_bwd(const float* __restr
     }
 }
 
+// LayerScale + residual AND the RMSNorm at the head of the NEXT branch in one pass each way (round 4): the block's
+//   x' = x + gamma z ;  h = x' / max(||x'|| D^-1/2, eps) * gn
+// read x and z once and write x' and h (the two stand-alone kernels read x' again); backward, with G the whole gradient at x'
+// (d_res, what arrives on the residual path, + the norm's backward of d_h):
+//   G = d_res + gn d_h / n - x' (sum_j gn_j d_h_j x'_j) / (D n^3) ;  dz = gamma G ;  dgamma = sum_rows G z ;  dgn = sum_rows d_h x' / n
+// one wave per row, 64 rows per workgroup (16 per wave), the two parameter gradients as per-workgroup partials (k_colsum).
+constexpr int SRN_C4 = 2, SRN_ROWS = 64;   // 16-byte column groups per lane (D <= 512, D % 4 == 0); rows per workgroup (backward)
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+__global__ __launch_bounds__(256) void k_sr_rms_fwd(const float* __restrict__ x, const float* __restrict__ z,
+                                                    const float* __restrict__ gamma, const float* __restrict__ gn,
+                                                    float* __restrict__ xn, float* __restrict__ h, int M, int D4, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[SRN_C4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < SRN_C4; ++i) {
+        const int c = lane + 64 * i;
+        const int64_t o = (int64_t)row * D4 + c;
+        v[i] = c < D4 ? ((const f32x4*)x)[o] + ((const f32x4*)gamma)[c] * ((const f32x4*)z)[o] : zero4;
+        if (c < D4) ((f32x4*)xn)[o] = v[i];
+        ss += dot4(v[i], v[i]);
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)) * rsqrtf((float)(4 * D4)), eps);
+#pragma unroll
+    for (int i = 0; i < SRN_C4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) ((f32x4*)h)[(int64_t)row * D4 + c] = v[i] * inv * ((const f32x4*)gn)[c];
+    }
+}
+__global__ __launch_bounds__(256) void k_sr_rms_bwd(const float* __restrict__ xn, const float* __restrict__ gn,
+                                                    const float* __restrict__ dh, const float* __restrict__ res,
+                                                    const float* __restrict__ z, const float* __restrict__ gamma,
+                                                    float* __restrict__ G, float* __restrict__ dz, float* __restrict__ pgn,
+                                                    float* __restrict__ pgam, int M, int D4, float eps) {
+    __shared__ f32x4 red[2][4][64 * SRN_C4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * SRN_ROWS, r1 = min(r0 + SRN_ROWS, M);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float Df = (float)(4 * D4);
+    f32x4 gnv[SRN_C4], gmv[SRN_C4], dgn[SRN_C4], dgm[SRN_C4];
+#pragma unroll
+    for (int i = 0; i < SRN_C4; ++i) {
+        const int c = lane + 64 * i;
+        gnv[i] = c < D4 ? ((const f32x4*)gn)[c] : zero4;
+        gmv[i] = c < D4 ? ((const f32x4*)gamma)[c] : zero4;
+        dgn[i] = zero4;
+        dgm[i] = zero4;
+    }
+    for (int row = r0 + wv; row < r1; row += 4) {
+        f32x4 xv[SRN_C4], d[SRN_C4], rv[SRN_C4], zv[SRN_C4];
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < SRN_C4; ++i) {
+            const int c = lane + 64 * i;
+            const int64_t o = (int64_t)row * D4 + c;
+            xv[i] = c < D4 ? ((const f32x4*)xn)[o] : zero4;
+            d[i] = c < D4 ? ((const f32x4*)dh)[o] : zero4;
+            rv[i] = (res != nullptr && c < D4) ? ((const f32x4*)res)[o] : zero4;
+            zv[i] = c < D4 ? ((const f32x4*)z)[o] : zero4;
+            ss += dot4(xv[i], xv[i]);
+            dot += dot4(gnv[i] * d[i], xv[i]);
+        }
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float raw = sqrtf(ss) * rsqrtf(Df);
+        const bool clamped = raw < eps;
+        const float n = clamped ? eps : raw, inv = 1.0f / n;
+        const float k = clamped ? 0.f : dot / (Df * n * n * n);
+#pragma unroll
+        for (int i = 0; i < SRN_C4; ++i) {
+            const int c = lane + 64 * i;
+            const f32x4 v = gnv[i] * d[i] * inv - xv[i] * k + rv[i];
+            if (c < D4) {
+                const int64_t o = (int64_t)row * D4 + c;
+                ((f32x4*)G)[o] = v;
+                ((f32x4*)dz)[o] = gmv[i] * v;
+            }
+            dgn[i] += d[i] * xv[i] * inv;
+            dgm[i] += v * zv[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SRN_C4; ++i) {
+        red[0][wv][lane + 64 * i] = dgn[i];
+        red[1][wv][lane + 64 * i] = dgm[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D4; c += 256) {
+        ((f32x4*)pgn)[(int64_t)blockIdx.x * D4 + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        ((f32x4*)pgam)[(int64_t)blockIdx.x * D4 + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
 }  // namespace
 
 #ifdef MDT_DEBUG_TIMING
@@ -971,6 +1066,41 @@ extern "C" mdt_status mdt_op_scale_residual_fwd(const float* x, const float* z, 
     hipLaunchKernelGGL(k_scale_residual_fwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, z, gamma, out,
                        n4, D / 4);
     LAUNCH(hipGetLastError());
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_scale_residual_rms_fwd(const float* x, const float* z, const float* gamma, const float* g_norm, float* x_new,
+                                                    float* h, int64_t M, int32_t D, float eps, void* stream) {
+    if (!x || !z || !gamma || !g_norm || !x_new || !h || M < 1 || D < 4 || D % 4 || D > 256 * SRN_C4)
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_rms_fwd: bad argument (D a multiple of 4, <= 512)");
+    if (!aligned16(x) || !aligned16(z) || !aligned16(gamma) || !aligned16(g_norm) || !aligned16(x_new) || !aligned16(h))
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_rms_fwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_sr_rms_fwd, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, z, gamma, g_norm, x_new, h, (int)M,
+                       D / 4, eps);
+    LAUNCH(hipGetLastError());
+    return MDT_OK;
+}
+
+extern "C" int64_t mdt_op_scale_residual_rms_bwd_scratch(int64_t M, int32_t D) { return 2 * ((M + SRN_ROWS - 1) / SRN_ROWS) * (int64_t)D; }
+
+extern "C" mdt_status mdt_op_scale_residual_rms_bwd(const float* x_new, const float* g_norm, const float* d_h, const float* d_res,
+                                                    const float* z, const float* gamma, float* d_x, float* d_z, float* d_gamma,
+                                                    float* d_gnorm, int64_t M, int32_t D, float eps, float* scratch, void* stream) {
+    if (!x_new || !g_norm || !d_h || !z || !gamma || !d_x || !d_z || !d_gamma || !d_gnorm || !scratch || M < 1 || D < 4 || D % 4 ||
+        D > 256 * SRN_C4)
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_rms_bwd: bad argument (D a multiple of 4, <= 512; d_res alone may be NULL)");
+    if (!aligned16(x_new) || !aligned16(g_norm) || !aligned16(d_h) || !aligned16(d_res) || !aligned16(z) || !aligned16(gamma) ||
+        !aligned16(d_x) || !aligned16(d_z) || !aligned16(scratch))
+        return mdt_fail(MDT_ERR_INVALID_ARG, "mdt_op_scale_residual_rms_bwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t slices = (M + SRN_ROWS - 1) / SRN_ROWS;
+    float* pgn = scratch;
+    float* pgam = scratch + slices * D;
+    hipLaunchKernelGGL(k_sr_rms_bwd, dim3((unsigned)slices), dim3(256), 0, s, x_new, g_norm, d_h, d_res, z, gamma, d_x, d_z, pgn, pgam,
+                       (int)M, D / 4, eps);
+    LAUNCH(hipGetLastError());
+    LAUNCH(mdt_launch_colsum(pgn, D, (int)slices, D, d_gnorm, 0, s));
+    LAUNCH(mdt_launch_colsum(pgam, D, (int)slices, D, d_gamma, 0, s));
     return MDT_OK;
 }
 

@@ -342,17 +342,60 @@ class HipScaleResidual(torch.autograd.Function):
         return out.reshape(x.shape)
 
     @staticmethod
-    def backward(ctx, g):
+    def _bwd(g2, z2, gm):
         lib = _lib.load()
-        z2, gm = ctx.saved_tensors
         M, D = z2.shape
-        g2 = _c(g).reshape(M, D)
         dz = torch.empty_like(z2)
         dgamma = torch.empty_like(gm)
         scratch = torch.empty(lib.mdt_op_scale_residual_bwd_scratch(M, D), device=g2.device, dtype=torch.float32)
         _lib.check(lib.mdt_op_scale_residual_bwd(g2.data_ptr(), z2.data_ptr(), gm.data_ptr(), dz.data_ptr(), dgamma.data_ptr(), M, D,
                                                  scratch.data_ptr(), _stream(g2)))
+        return g2, dz, dgamma
+
+    @staticmethod
+    def backward(ctx, g):
+        z2, gm = ctx.saved_tensors
+        _, dz, dgamma = HipScaleResidual._bwd(_c(g).reshape(z2.shape), z2, gm)
         return g, dz.reshape(ctx.xshape), dgamma
+
+
+class HipScaleResidualNorm(torch.autograd.Function):
+    """x' = x + gamma * z and h = RMSNorm(x'; g_norm), the residual sum of one branch and the norm at the head of the next,
+    in one pass each way (`mdt_op_scale_residual_rms_fwd / _bwd`).  Returns (x', h); the backward receives the gradient that
+    reaches x' on the residual path (None when nothing else uses x': the decoder's last norm) and h's."""
+
+    @staticmethod
+    def forward(ctx, x, z, gamma, g_norm):
+        lib = _lib.load()
+        D = x.shape[-1]
+        x2, z2, gm, gn = _c(x).reshape(-1, D), _c(z).reshape(-1, D), _c(gamma), _c(g_norm)
+        xn, h = torch.empty_like(x2), torch.empty_like(x2)
+        _lib.check(lib.mdt_op_scale_residual_rms_fwd(x2.data_ptr(), z2.data_ptr(), gm.data_ptr(), gn.data_ptr(), xn.data_ptr(),
+                                                     h.data_ptr(), x2.shape[0], D, RMS_EPS, _stream(x2)))
+        ctx.save_for_backward(xn, z2, gm, gn)
+        ctx.xshape = x.shape
+        ctx.set_materialize_grads(False)
+        return xn.reshape(x.shape), h.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, d_res, d_h):
+        lib = _lib.load()
+        xn, z2, gm, gn = ctx.saved_tensors
+        M, D = xn.shape
+        if d_h is None:   # only the residual sum was used
+            if d_res is None:
+                return None, None, None, None
+            dx, dz, dgamma = HipScaleResidual._bwd(_c(d_res).reshape(M, D), z2, gm)
+            return dx.reshape(ctx.xshape), dz.reshape(ctx.xshape), dgamma, None
+        d = _c(d_h).reshape(M, D)
+        r = None if d_res is None else _c(d_res).reshape(M, D)
+        dx, dz = torch.empty_like(xn), torch.empty_like(xn)
+        dgamma, dgn = torch.empty_like(gm), torch.empty_like(gn)
+        scratch = torch.empty(lib.mdt_op_scale_residual_rms_bwd_scratch(M, D), device=d.device, dtype=torch.float32)
+        _lib.check(lib.mdt_op_scale_residual_rms_bwd(xn.data_ptr(), gn.data_ptr(), d.data_ptr(), None if r is None else r.data_ptr(),
+                                                     z2.data_ptr(), gm.data_ptr(), dx.data_ptr(), dz.data_ptr(), dgamma.data_ptr(),
+                                                     dgn.data_ptr(), M, D, RMS_EPS, scratch.data_ptr(), _stream(d)))
+        return dx.reshape(ctx.xshape), dz.reshape(ctx.xshape), dgamma, dgn
 
 
 class HipPatchMSE(torch.autograd.Function):

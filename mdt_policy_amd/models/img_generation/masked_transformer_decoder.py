@@ -255,16 +255,22 @@ class MaskedTransformerImgDecoder(nn.Module):
             tokens = torch.gather(slots, 2, restore[..., None].expand(B, X, n, d))
         tokens = tokens + pe[None] + self.ctx_dec_pe[:, :2]      # position embedding a second time, as the reference (:268-271)
         x = torch.cat([emb_context, tokens.reshape(B, X * n, d)], dim=1)
-        for blk in self.decoder_blocks:
-            # (x feeds the norm and the residual sum: HipRMSNormBranch hands both uses out so its backward adds their gradients)
-            x, h = ops.HipRMSNormBranch.apply(x, blk.pre_norm_attn.g)
-            att = ops.HipSelfAttention.apply(self._linear(h, blk.attn.qkv), blk.attn.n_heads, blk.attn.scale)
-            x = ops.HipScaleResidual.apply(x, self._linear(att, blk.attn.proj), blk.layer_scale_attn.gamma)
-            x, h = ops.HipRMSNormBranch.apply(x, blk.pre_norm_mlp.g)
-            z = ops.HipSwiGLUMLP.apply(h, blk.mlp[0].project.weight, blk.mlp[0].project.bias, blk.mlp[1].weight, blk.mlp[1].bias,
-                                       self._packs)
-            x = ops.HipScaleResidual.apply(x, z, blk.layer_scale_mlp.gamma)
-        x = ops.HipRMSNorm.apply(x, self.decoder_norm.g)
+        # Per block (voltron Block): x = x + ls(attn(norm(x))); x = x + ls(mlp(norm(x))).  Every residual sum runs in one launch
+        # with the norm that follows it (the next branch's, at the end the decoder's own), and that launch's backward also adds
+        # the two gradients that reach the summed rows (HipScaleResidualNorm); the first norm hands out both uses of its input.
+        blocks = list(self.decoder_blocks)
+        if blocks:
+            x, h = ops.HipRMSNormBranch.apply(x, blocks[0].pre_norm_attn.g)
+            for i, blk in enumerate(blocks):
+                att = ops.HipSelfAttention.apply(self._linear(h, blk.attn.qkv), blk.attn.n_heads, blk.attn.scale)
+                x, h = ops.HipScaleResidualNorm.apply(x, self._linear(att, blk.attn.proj), blk.layer_scale_attn.gamma, blk.pre_norm_mlp.g)
+                z = ops.HipSwiGLUMLP.apply(h, blk.mlp[0].project.weight, blk.mlp[0].project.bias, blk.mlp[1].weight, blk.mlp[1].bias,
+                                           self._packs)
+                g_next = blocks[i + 1].pre_norm_attn.g if i + 1 < len(blocks) else self.decoder_norm.g
+                x, h = ops.HipScaleResidualNorm.apply(x, z, blk.layer_scale_mlp.gamma, g_next)
+            x = h
+        else:
+            x = ops.HipRMSNorm.apply(x, self.decoder_norm.g)
         rec = self._linear(x[:, context.shape[1]:], self.decoder_patch_prediction).reshape(B, X, n, -1)
         return rec, m, restore, vis.reshape(B, X * n_keep, d)
 

@@ -261,6 +261,50 @@ def test_scale_residual_op(M, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,D", [(306, 192), (5, 64), (4133, 384), (130, 500)])
+def test_scale_residual_with_the_next_norm(M, D):
+    """x' = x + gamma z, h = RMSNorm(x') in one launch each way, against float64 autograd; with and without a gradient on the
+    residual path; the the residual sum bit-equal to the stand-alone op."""
+    L, lib = _lib()
+    x = torch.from_numpy(synthetic.normal("x", (M, D), 171))
+    z = torch.from_numpy(synthetic.normal("z", (M, D), 172))
+    gamma = torch.from_numpy(synthetic.normal("gamma", (D,), 173, std=0.3))
+    gn = torch.from_numpy(synthetic.normal("gn", (D,), 174, std=0.1, mean=1.0))
+    d_h = torch.from_numpy(synthetic.normal("d_h", (M, D), 175))
+    d_res = torch.from_numpy(synthetic.normal("d_res", (M, D), 176))
+    xd, zd, gd, gnd, dhd, drd = (t.cuda() for t in (x, z, gamma, gn, d_h, d_res))
+    xn, h = torch.empty_like(xd), torch.empty_like(xd)
+    L.check(lib.mdt_op_scale_residual_rms_fwd(xd.data_ptr(), zd.data_ptr(), gd.data_ptr(), gnd.data_ptr(), xn.data_ptr(), h.data_ptr(),
+                                              M, D, 1e-8, _s()))
+    xn2, h2 = torch.empty_like(xd), torch.empty_like(xd)
+    L.check(lib.mdt_op_scale_residual_fwd(xd.data_ptr(), zd.data_ptr(), gd.data_ptr(), xn2.data_ptr(), M, D, _s()))
+    L.check(lib.mdt_op_rms_fwd(xn2.data_ptr(), gnd.data_ptr(), h2.data_ptr(), M, D, 1e-8, _s()))
+    assert torch.equal(xn, xn2)
+    assert_close(h.cpu(), h2.cpu().double(), rtol=1e-5, atol=1e-6, what="h against the stand-alone norm")
+    for with_res in (True, False):
+        v = [t.double().requires_grad_() for t in (x, z, gamma, gn)]
+        xr = v[0] + v[2] * v[1]
+        hr = O.rms_norm(xr, v[3])
+        (hr * d_h.double()).sum().backward(retain_graph=with_res)
+        if with_res:
+            (xr * d_res.double()).sum().backward()
+        dx, dz = torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan"))
+        dgam, dgn = torch.empty_like(gd), torch.empty_like(gnd)
+        scratch = torch.empty(lib.mdt_op_scale_residual_rms_bwd_scratch(M, D), device="cuda")
+        L.check(lib.mdt_op_scale_residual_rms_bwd(xn.data_ptr(), gnd.data_ptr(), dhd.data_ptr(), drd.data_ptr() if with_res else None,
+                                                  zd.data_ptr(), gd.data_ptr(), dx.data_ptr(), dz.data_ptr(), dgam.data_ptr(),
+                                                  dgn.data_ptr(), M, D, 1e-8, scratch.data_ptr(), _s()))
+        tol = dict(rtol=1e-3, atol=1e-4 * max(1.0, (M / 64) ** 0.5))
+        assert_close(dx.cpu(), v[0].grad, what="d_x")
+        assert_close(dz.cpu(), v[1].grad, what="d_z")
+        assert_close(dgam.cpu(), v[2].grad, what="d_gamma", **tol)
+        assert_close(dgn.cpu(), v[3].grad, what="d_gnorm", **tol)
+    for bad_d in (516, 190):
+        assert lib.mdt_op_scale_residual_rms_fwd(xd.data_ptr(), zd.data_ptr(), gd.data_ptr(), gnd.data_ptr(), xn.data_ptr(), h.data_ptr(),
+                                                 M, bad_d, 1e-8, _s()) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,H", [(306, 192, 768), (37, 64, 48), (4100, 192, 768), (64, 128, 128)])
 def test_swiglu_on_the_gemm_epilogues(M, K, H):
     """SwishGLU riding on the GEMMs around it: forward on the project product (aux_mode 3: interleaved weight image, u and
