@@ -748,6 +748,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
 #pragma unroll
             for (int kt = 0; kt < NTJ; ++kt) {
                 if (kt < n) {
+                    // (the adding pass reads a key tile's 16 values per lane in one batch, then stores: written as one
+                    // read-add-write statement per value, every read waited for the store before it -- the two may alias as far
+                    // as the compiler knows -- and this phase took 15 k clocks of a workgroup's 70 k)
+                    f32x4 tK[NC], tV[NC];
+                    if (pass) {
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const int col = min(16 * q + m, HD - 1);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int o = (16 * kt + 4 * g + r) * ST + col;
+                                tK[q][r] = bK[o];
+                                tV[q][r] = bV[o];
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
                         const int col = 16 * q + m;
@@ -755,8 +771,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int o = (16 * kt + 4 * g + r) * ST + col;
-                                bK[o] = pass ? bK[o] + dK[kt][q][r] : dK[kt][q][r];
-                                bV[o] = pass ? bV[o] + dV[kt][q][r] : dV[kt][q][r];
+                                bK[o] = pass ? tK[q][r] + dK[kt][q][r] : dK[kt][q][r];
+                                bV[o] = pass ? tV[q][r] + dV[kt][q][r] : dV[kt][q][r];
                             }
                         }
                     }
