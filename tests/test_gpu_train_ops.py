@@ -217,6 +217,36 @@ def test_merge_gate_backward_and_colsum(lib):
         assert_close(o.cpu() - out0, X[:, :N].double().sum(0), rtol=1e-4, atol=1e-4, what=f"colsum {M}x{N}")
 
 
+@pytest.mark.parametrize("B,rps,D", [(3, 10, 384), (2, 401, 384), (5, 7, 64), (2, 3, 1024), (4, 1, 192), (3, 5, 30), (2, 19, 96)])
+def test_merge_vector_kernels_equal_the_scalar_ones(lib, B, rps, D):
+    """The 16-byte kernels (every load of a thread in flight before its first store) against the one-column-per-thread kernels
+    they replaced: the latter still take whatever is not 16-byte aligned, so a copy of the operands shifted by one float selects
+    them.  Same mask, same arithmetic per element: forward and d_a bit for bit, d_gate to rounding (other summation order)."""
+    p, seed, site = 0.1, 987654321, 3
+    x, a, gate, dx = rnd(B * rps, D, seed=41), rnd(B * rps, D, seed=42), rnd(B, D, seed=43), rnd(B * rps, D, seed=44)
+
+    def shifted(t):   # the same values at an address that is 4 (mod 16)
+        buf = torch.empty(t.numel() + 4, device="cuda")
+        v = buf[1:1 + t.numel()].view(t.shape)
+        v.copy_(t)
+        return v
+
+    res = []
+    for mk in (dev, lambda t: shifted(dev(t))):
+        xd, ad, gd, dxd = mk(x), mk(a), mk(gate), mk(dx)
+        out, da, dg = mk(torch.zeros_like(x)), mk(torch.zeros_like(x)), mk(torch.zeros_like(gate))
+        merge(lib, "mdt_op_merge_fwd", xd, ad, gd, out, None, B, rps, D, p=p, site=site, seed=seed, ld=D)
+        merge(lib, "mdt_op_merge_bwd", dxd, ad, gd, da, dg, B, rps, D, p=p, site=site, seed=seed, ld=D)
+        res.append((out.clone(), da.clone(), dg.clone()))
+    (o1, a1, g1), (o2, a2, g2) = res
+    assert torch.equal(o1, o2) and torch.equal(a1, a2)
+    assert_close(g1.cpu(), g2.cpu().double(), rtol=1e-5, atol=1e-5, what="d_gate")
+    keep = (o1 != dev(x)).float().mean().item()      # x + g * drop(a) differs from x exactly where the mask kept a
+    assert abs(keep - (1 - p)) < 0.05
+    mask = ((o1 - dev(x)) != 0).float() / (1 - p)
+    assert_close(a1.cpu(), (dev(dx) * dev(gate).repeat_interleave(rps, 0) * mask).cpu().double(), what="d_a", **G_TOL)
+
+
 def test_merge_dropout_mask_statistics_and_backward(lib):
     B, rps, D, p, seed = 64, 10, 384, 0.1, 123456789
     zeros, ones = torch.zeros(B * rps, D, device="cuda"), torch.ones(B * rps, D, device="cuda")
