@@ -95,8 +95,9 @@ hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t s
 hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s);
 hipError_t mdt_launch_noise_input(const float* act, const float* noise, const float* sigma, float* noised, int64_t n,
                                   int per_sample, hipStream_t s);
+constexpr int MDT_LOSS_PARTS = 1024;   // floats of scratch mdt_launch_loss_reduce wants (`part`)
 hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float* noised, const float* sigma, float sd,
-                                  int64_t n, int per_sample, float* loss, hipStream_t s);
+                                  int64_t n, int per_sample, float* loss, float* part, hipStream_t s);
 hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* packed, int n_off, hipStream_t s);
 hipError_t mdt_launch_pack_weight_glu(const float* w, int H, int K, float* packed, hipStream_t s);
 // one move of a batched parameter upload (k_multi_load): src is (rows, K) row-major on the device

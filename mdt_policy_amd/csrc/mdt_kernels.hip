@@ -1345,46 +1345,46 @@ __global__ void k_noise_input(const float* __restrict__ act, const float* __rest
     noised[i] = noise ? act[i] + noise[i] * sigma[i / per_sample] : act[i];  // noise == nullptr: the rows are given noisy
 }
 
-// single-workgroup deterministic reduction: loss = mean_i (F_i - (a_i - c_skip*noised_i)/c_out)^2
-// A thread walks whole SAMPLES (tid, tid + 1024, ...): the preconditioning scalars once per sample, no index division per
-// element, and a sample's loads are independent of each other (the element-strided form was 70 dependent trips of three loads,
-// a division and a square root per thread at B = 1024: 51 us of a 10 ms training step).  Fixed summation order.
-__global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ F, const float* __restrict__ act,
-                                                      const float* __restrict__ noised,
-                                                      const float* __restrict__ sigma, float sd, int64_t n,
-                                                      int per_sample, float* __restrict__ loss) {
-    __shared__ float part[16];
+// deterministic two-stage reduction: loss = mean_i (F_i - (a_i - c_skip*noised_i)/c_out)^2
+// Stage 1: up to MDT_LOSS_PARTS workgroups, each over a contiguous slice, element-strided (coalesced) with four elements of a
+// thread in flight; stage 2: one workgroup adds the partials in a fixed order.  (One 1024-thread workgroup over everything
+// took 51 us at B = 1024 walking elements and 104 us walking whole samples per thread -- one CU's worth of memory requests
+// in flight either way -- of a 10 ms training step.)
+__global__ __launch_bounds__(256) void k_loss_partial(const float* __restrict__ F, const float* __restrict__ act,
+                                                      const float* __restrict__ noised, const float* __restrict__ sigma, float sd,
+                                                      int n, int per_sample, int chunk, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const float sd2 = sd * sd;
     float s = 0.f;
-    const int64_t ns = n / per_sample;
-    for (int64_t b = threadIdx.x; b < ns; b += 1024) {
-        const float sg = sigma[b];
-        const float den2 = sg * sg + sd * sd;
-        const float c_skip = sd * sd / den2, inv_c_out = sqrtf(den2) / (sg * sd);
-        const float* f = F + b * per_sample;
-        const float* a = act + b * per_sample;
-        const float* x = noised + b * per_sample;
-        float s0 = 0.f, s1 = 0.f;
-        int i = 0;
-        for (; i + 2 <= per_sample; i += 2) {
-            const float d0 = f[i] - (a[i] - c_skip * x[i]) * inv_c_out;
-            const float d1 = f[i + 1] - (a[i + 1] - c_skip * x[i + 1]) * inv_c_out;
-            s0 = fmaf(d0, d0, s0);
-            s1 = fmaf(d1, d1, s1);
+    for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 1024) {
+        float f[4], a[4], x[4], sg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + 256 * u, hi - 1);
+            f[u] = F[i]; a[u] = act[i]; x[u] = noised[i]; sg[u] = sigma[i / per_sample];
         }
-        if (i < per_sample) {
-            const float d0 = f[i] - (a[i] - c_skip * x[i]) * inv_c_out;
-            s0 = fmaf(d0, d0, s0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float den2 = sg[u] * sg[u] + sd2;
+            const float c_skip = sd2 / den2, inv_c_out = sqrtf(den2) / (sg[u] * sd);
+            const float d = f[u] - (a[u] - c_skip * x[u]) * inv_c_out;
+            if (i0 + 256 * u < hi) s = fmaf(d, d, s);
         }
-        s += s0 + s1;
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += part[w];
-        *loss = t / (float)n;
-    }
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_loss_final(const float* __restrict__ part, int nparts, float inv_n, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
 }
 
 hipError_t mdt_launch_noise_input(const float* act, const float* noise, const float* sigma, float* noised, int64_t n,
@@ -1395,8 +1395,12 @@ hipError_t mdt_launch_noise_input(const float* act, const float* noise, const fl
 }
 
 hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float* noised, const float* sigma, float sd,
-                                  int64_t n, int per_sample, float* loss, hipStream_t s) {
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, F, act, noised, sigma, sd, n, per_sample, loss);
+                                  int64_t n, int per_sample, float* loss, float* part, hipStream_t s) {
+    if (n < 1 || n > 0x7fffffff || !part) return hipErrorInvalidValue;
+    const int chunk = (int)std::max<int64_t>(1024, ((n + MDT_LOSS_PARTS - 1) / MDT_LOSS_PARTS + 255) / 256 * 256);
+    const int nparts = (int)((n + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_loss_partial, dim3(nparts), dim3(256), 0, s, F, act, noised, sigma, sd, (int)n, per_sample, chunk, part);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, s, part, nparts, 1.0f / (float)n, loss);
     return hipGetLastError();
 }
 

@@ -615,6 +615,7 @@ static void carve_ws(mdt_model* m, Bump& b, int64_t B) {
     m->Fbuf = b.take(Ra * m->A);
     m->steps = b.take(MAX_STEPS * 4);
     m->sigs = b.take(MAX_STEPS + 1);
+    m->loss_part = b.take(MDT_LOSS_PARTS);
     if (m->xfold) {
         const int64_t np = (int64_t)4 * m->H;  // every head padded to 4 context tokens (fragment order, k_xattn_fold)
         m->xU = b.take((size_t)m->Ld * B * np * D);
@@ -1214,7 +1215,7 @@ extern "C" mdt_status mdt_loss_fwd(mdt_model* m, const float* tokens, const floa
     LAUNCH(mdt_launch_noise_input(action, noise, sigma, m->noised, n, per, s));
     float* F = model_output ? model_output : m->Fbuf;
     MDT_TRY(mdt_denoise_cached(m, m->noised, sigma, batch, MDT_RAW_OUTPUT, F, stream));
-    LAUNCH(mdt_launch_loss_reduce(F, action, m->noised, sigma, m->cfg.sigma_data, n, per, loss_out, s));
+    LAUNCH(mdt_launch_loss_reduce(F, action, m->noised, sigma, m->cfg.sigma_data, n, per, loss_out, m->loss_part, s));
     return MDT_OK;
 }
 

@@ -100,7 +100,7 @@ struct mdt_model {
     float* ws = nullptr;
     int64_t cap = 0;
     int64_t ws_generation = 0;  // bumped whenever the workspace is (re)allocated: captured HIP graphs hold its addresses
-    float *h_enc, *qkv, *att, *hid, *ctx, *kvx, *y, *qx, *sig_e, *sig_t, *sig_c, *mod, *xbuf, *noised, *Fbuf, *steps, *sigs;
+    float *h_enc, *qkv, *att, *hid, *ctx, *kvx, *y, *qx, *sig_e, *sig_t, *sig_c, *mod, *xbuf, *noised, *Fbuf, *steps, *sigs, *loss_part;
     float* cmod = nullptr;  // COND_NOISE: rows of [c | ones(D)], read as (shift, scale) by the LayerNorm prologue
     int64_t cached_batch = 0;  // batch of the context currently cached by mdt_encode (0 = none)
     // sampler pipelining: the batch is cut into `ways` sample-aligned slices whose launch chains run on separate

@@ -45,7 +45,7 @@ struct Tape {
     hipEvent_t freed = nullptr;
     bool freed_pending = false;
     // inputs
-    float *tokens, *tokens2, *goal, *action, *noised, *sigma;
+    float *tokens, *tokens2, *goal, *action, *noised, *sigma, *loss_part;
     float *p_pre = nullptr, *p_h = nullptr;  // proprio_emb: pre-activation and Mish output of its first layer (B, 2D)
     // encoder
     float *g_pre, *g_h;
@@ -214,7 +214,7 @@ static void carve_tape(const mdt_model* m, Bump& b, Tape& t, int64_t B) {
     t.tokens2 = b.take(m->cfg.arch == MDT_ARCH_MDT ? B * m->O : B * m->Pd);  // MDT-V: state_obs (B, Pd) when use_proprio
     t.p_pre = b.take(m->p_row >= 0 ? B * 2 * D : 0); t.p_h = b.take(m->p_row >= 0 ? B * 2 * D : 0);
     t.goal = b.take(B * m->G);
-    t.action = b.take(Ma * m->A); t.noised = b.take(Ma * m->A); t.sigma = b.take(B);
+    t.action = b.take(Ma * m->A); t.noised = b.take(Ma * m->A); t.sigma = b.take(B); t.loss_part = b.take(MDT_LOSS_PARTS);
     t.g_pre = b.take(B * 2 * D); t.g_h = b.take(B * 2 * D);
     t.enc.resize(m->Le);
     for (int l = 0; l < m->Le; ++l) carve_block(m, b, t.enc[l], Me, false);
@@ -567,7 +567,7 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     }
     LAUNCH(mdt_launch_head(h, s));
     if (model_output) HIP_TRY(hipMemcpyAsync(model_output, t.F, (size_t)Ma * A * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (loss_out) LAUNCH(mdt_launch_loss_reduce(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, loss_out, s));
+    if (loss_out) LAUNCH(mdt_launch_loss_reduce(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, loss_out, t.loss_part, s));
     t.has_decoder = true;
     return MDT_OK;
 }
