@@ -540,7 +540,40 @@ static float* colsum_scratch(hipStream_t s) {
     return p;
 }
 
+// very many columns (the S slices of a weight gradient, N = the flattened matrix): the kernel above with 16-byte column groups --
+// 256 columns per workgroup instead of 64, four loads of a thread in flight (c_fc's gradient: 9216 workgroups of 5 KB each,
+// 12 us a launch, 41 such launches a training step).  Same order of the additions as k_colsum.
+__global__ __launch_bounds__(256) void k_colsum_wide4(const float* __restrict__ X, int64_t ldx4, int M, int N4,
+                                                      float* __restrict__ out, int accumulate) {
+    __shared__ f32x4 part[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + cl;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = zero4, acc1 = zero4, acc2 = zero4, acc3 = zero4;
+    if (c4 < N4) {
+        const f32x4* __restrict__ X4 = (const f32x4*)X + c4;
+        int m = rg;
+        for (; m + 12 < M; m += 16) {
+            const f32x4 v0 = X4[(int64_t)m * ldx4], v1 = X4[(int64_t)(m + 4) * ldx4], v2 = X4[(int64_t)(m + 8) * ldx4],
+                        v3 = X4[(int64_t)(m + 12) * ldx4];
+            acc0 += v0; acc1 += v1; acc2 += v2; acc3 += v3;
+        }
+        for (; m < M; m += 4) acc0 += X4[(int64_t)m * ldx4];
+    }
+    part[rg][cl] = (acc0 + acc1) + (acc2 + acc3);
+    __syncthreads();
+    if (rg == 0 && c4 < N4) {
+        const f32x4 t = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        f32x4* o = (f32x4*)out + c4;
+        *o = accumulate ? *o + t : t;
+    }
+}
+
 hipError_t mdt_launch_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, hipStream_t s) {
+    if (N >= 16384 && N % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(k_colsum_wide4, dim3((N / 4 + 63) / 64), dim3(256), 0, s, X, ldx / 4, M, N / 4, out, accumulate);
+        return hipGetLastError();
+    }
     if (M >= 512 && N <= CS_MAXN) {  // 64 row slices in parallel, then their sum (a single stage runs on N / 64 workgroups)
         float* scratch = colsum_scratch(s);
         if (!scratch) return hipErrorOutOfMemory;

@@ -215,6 +215,14 @@ def test_merge_gate_backward_and_colsum(lib):
         o = dev(out0).clone()
         lib.check(L.mdt_op_colsum(dev(X).data_ptr(), N + 3, M, N, o.data_ptr(), 1, stream()))
         assert_close(o.cpu() - out0, X[:, :N].double().sum(0), rtol=1e-4, atol=1e-4, what=f"colsum {M}x{N}")
+    # few rows, very many columns (the slices of a weight gradient): the 16-byte kernel; odd strides keep the general one
+    for M, N, pad in [(16, 589824, 0), (5, 20000, 4), (9, 16384, 0), (1, 65536, 8), (256, 16388, 0), (13, 16384, 3)]:
+        X = rnd(M, N + pad, seed=M + N)
+        out0 = rnd(N, seed=N + 1)
+        for acc in (1, 0):
+            o = dev(out0).clone()
+            lib.check(L.mdt_op_colsum(dev(X).data_ptr(), N + pad, M, N, o.data_ptr(), acc, stream()))
+            assert_close(o.cpu() - (out0 if acc else 0), X[:, :N].double().sum(0), rtol=1e-4, atol=1e-4, what=f"wide colsum {M}x{N}")
 
 
 @pytest.mark.parametrize("B,rps,D", [(3, 10, 384), (2, 401, 384), (5, 7, 64), (2, 3, 1024), (4, 1, 192), (3, 5, 30), (2, 19, 96)])
