@@ -169,8 +169,62 @@ __global__ __launch_bounds__(256) void k_ln_fwd_train(const float* __restrict__ 
     if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
+// the same with 16-byte column groups (D % 4 == 0, aligned operands): 96 lanes' worth of requests per row of 384 instead of
+// 6 x 64 four-byte ones (13.4 us for 31 MB at M = 10240: 2.3 TB/s)
+__global__ __launch_bounds__(256) void k_ln_fwd_train4(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, const float* __restrict__ mod,
+                                                       int64_t mod_stride, int shift_off, int scale_off, int rps,
+                                                       float* __restrict__ out, float* __restrict__ stats, int M, int D4) {
+    constexpr int C4 = LN_MAXC / 4;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    const f32x4* xr = (const f32x4*)x + (int64_t)row * D4;
+    const float Df = (float)(4 * D4);
+    f32x4 v[C4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D4 ? xr[c] : zero4;
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / Df;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int c = lane + 64 * i;
+        const f32x4 d = c < D4 ? v[i] - mean : zero4;
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / Df + 1e-5f);
+    const float* mr = mod ? mod + (int64_t)(row / rps) * mod_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+            f32x4 n = (v[i] - mean) * rstd * ((const f32x4*)w)[c] + (b ? ((const f32x4*)b)[c] : zero4);
+            if (mr) {
+                const f32x4 sc = scale_off >= 0 ? *(const f32x4*)(mr + scale_off + 4 * c) : one4;
+                const f32x4 sh = shift_off >= 0 ? *(const f32x4*)(mr + shift_off + 4 * c) : zero4;
+                n = (f32x4){fmaf(n.x, sc.x, sh.x), fmaf(n.y, sc.y, sh.y), fmaf(n.z, sc.z, sh.z), fmaf(n.w, sc.w, sh.w)};
+            }
+            ((f32x4*)out)[(int64_t)row * D4 + c] = n;
+        }
+    }
+    if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s) {
     if (a.D > 64 * LN_MAXC || a.D < 1) return hipErrorInvalidValue;
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (a.D % 4 == 0 && al(a.x) && al(a.w) && al(a.b) && al(a.out) &&
+        (!a.mod || (al(a.mod) && a.mod_stride % 4 == 0 && (a.shift_off < 0 || a.shift_off % 4 == 0) &&
+                    (a.scale_off < 0 || a.scale_off % 4 == 0)))) {
+        hipLaunchKernelGGL(k_ln_fwd_train4, dim3((a.M + 3) / 4), dim3(256), 0, s, a.x, a.w, a.b, a.mod, a.mod_stride, a.shift_off,
+                           a.scale_off, a.rows_per_sample > 0 ? a.rows_per_sample : 1, a.out, a.stats, a.M, a.D / 4);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_ln_fwd_train, dim3((a.M + 3) / 4), dim3(256), 0, s, a.x, a.w, a.b, a.mod, a.mod_stride,
                        a.shift_off, a.scale_off, a.rows_per_sample > 0 ? a.rows_per_sample : 1, a.out, a.stats, a.M, a.D);
     return hipGetLastError();
