@@ -315,10 +315,94 @@ __global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
     }
 }
 
+// the same with 16-byte column groups; the row of dx an accumulating call adds to is requested with x and dh, not after the
+// row's two reductions
+__global__ __launch_bounds__(256) void k_ln_bwd4(mdt_ln_bwd_args a) {
+    extern __shared__ float red[];  // [4 waves][4 kinds][D]
+    constexpr int C4 = LN_MAXC / 4;
+    const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D = a.D, D4 = D >> 2, rps = a.rows_per_sample;
+    const int per = (rps + gridDim.y - 1) / gridDim.y, r_lo = blockIdx.y * per, r_hi = min(rps, r_lo + per);
+    const int prow = b * gridDim.y + blockIdx.y;
+    const float* mr = a.mod ? a.mod + (int64_t)b * a.mod_stride : nullptr;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    const float Df = (float)D;
+    f32x4 wgt[C4], bia[C4], sc[C4], a_sh[C4], a_sc[C4], a_w[C4], a_b[C4];
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int c = lane + 64 * i;
+        wgt[i] = c < D4 ? ((const f32x4*)a.w)[c] : zero4;
+        bia[i] = (c < D4 && a.b) ? ((const f32x4*)a.b)[c] : zero4;
+        sc[i] = c < D4 ? ((mr && a.scale_off >= 0) ? *(const f32x4*)(mr + a.scale_off + 4 * c) : one4) : zero4;
+        a_sh[i] = a_sc[i] = a_w[i] = a_b[i] = zero4;
+    }
+    const int64_t ld4 = a.ld_dh >> 2;
+    for (int r = r_lo + wv; r < r_hi; r += 4) {
+        const int64_t row = (int64_t)b * rps + r;
+        const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
+        f32x4 xh[C4], dxh[C4], old[C4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int c = lane + 64 * i;
+            const f32x4 xv = c < D4 ? ((const f32x4*)a.x)[row * D4 + c] : zero4;
+            const f32x4 dh = c < D4 ? ((const f32x4*)a.dh)[row * ld4 + c] : zero4;
+            old[i] = (a.accumulate && c < D4) ? ((const f32x4*)a.dx)[row * D4 + c] : zero4;
+            xh[i] = c < D4 ? (xv - mean) * rstd : zero4;
+            const f32x4 n = xh[i] * wgt[i] + bia[i];
+            const f32x4 dn = dh * sc[i];
+            a_sh[i] += dh;
+            a_sc[i] += dh * n;
+            a_w[i] += dn * xh[i];
+            a_b[i] += dn;
+            dxh[i] = dn * wgt[i];
+            s1 += (dxh[i].x + dxh[i].y) + (dxh[i].z + dxh[i].w);
+            const f32x4 t = dxh[i] * xh[i];
+            s2 += (t.x + t.y) + (t.z + t.w);
+        }
+        const float c1 = wave_sum(s1) / Df, c2 = wave_sum(s2) / Df;
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D4) ((f32x4*)a.dx)[row * D4 + c] = old[i] + (dxh[i] - c1 - xh[i] * c2) * rstd;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+            *(f32x4*)(red + (wv * 4 + 0) * D + 4 * c) = a_sh[i];
+            *(f32x4*)(red + (wv * 4 + 1) * D + 4 * c) = a_sc[i];
+            *(f32x4*)(red + (wv * 4 + 2) * D + 4 * c) = a_w[i];
+            *(f32x4*)(red + (wv * 4 + 3) * D + 4 * c) = a_b[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = red[(0 * 4 + k) * D + c] + red[(1 * 4 + k) * D + c] + red[(2 * 4 + k) * D + c] +
+                                           red[(3 * 4 + k) * D + c];
+        if (a.d_mod) {
+            float* dm = a.d_mod + (int64_t)b * a.d_mod_stride;
+            if (a.shift_off >= 0) dm[a.shift_off + c] = a.accumulate_dmod ? dm[a.shift_off + c] + t[0] : t[0];
+            if (a.scale_off >= 0) dm[a.scale_off + c] = a.accumulate_dmod ? dm[a.scale_off + c] + t[1] : t[1];
+        }
+        a.pw[(int64_t)prow * D + c] = t[2];
+        if (a.pb) a.pb[(int64_t)prow * D + c] = t[3];
+    }
+}
+
 hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s) {
     if (a.D > 64 * LN_MAXC || a.D < 1 || a.rows_per_sample < 1) return hipErrorInvalidValue;
     const int chunks = a.row_chunks > 1 ? a.row_chunks : 1;
     if (chunks > 1 && (a.d_mod || chunks > a.rows_per_sample)) return hipErrorInvalidValue;
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (a.D % 4 == 0 && a.ld_dh % 4 == 0 && al(a.x) && al(a.dh) && al(a.dx) && al(a.w) && al(a.b) &&
+        (!a.mod || (al(a.mod) && a.mod_stride % 4 == 0 && (a.scale_off < 0 || a.scale_off % 4 == 0)))) {
+        hipLaunchKernelGGL(k_ln_bwd4, dim3(a.B, chunks), dim3(256), (size_t)16 * a.D * sizeof(float), s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_ln_bwd, dim3(a.B, chunks), dim3(256), (size_t)16 * a.D * sizeof(float), s, a);
     return hipGetLastError();
 }
