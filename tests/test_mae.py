@@ -305,6 +305,32 @@ def test_scale_residual_with_the_next_norm(M, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,X,C_,R,P", [(3, 2, 3, 112, 16), (2, 1, 1, 32, 8), (1, 2, 3, 224, 16), (5, 2, 3, 48, 16), (2, 3, 4, 64, 4)])
+def test_patch_loss_op(B, X, C_, R, P):
+    """Masked per-patch MSE straight from the image planes (one workgroup per row of patches) against the patchified form in
+    float64 (reference compute_loss :228-262: element order inside a patch is (row, column, channel)), value and gradient."""
+    from mdt_policy_amd.models.img_generation import _hip_ops as ops
+    g_ = R // P
+    n, E = g_ * g_, P * P * C_
+    gen = torch.Generator().manual_seed(7 * B + R)
+    rec = torch.randn(B, X, n, E, generator=gen)
+    imgs = torch.randn(B, X, C_, R, R, generator=gen)
+    mask = (torch.rand(B, n, generator=gen) < 0.75).float()
+    mask[0, 0] = 1.0
+    patches = imgs.double().reshape(B, X, C_, g_, P, g_, P).permute(0, 1, 3, 5, 4, 6, 2).reshape(B, X, n, E)
+    r64 = rec.double().requires_grad_()
+    per_patch = ((r64 - patches) ** 2).mean(-1)                       # (B, X, n)
+    ref = sum((per_patch[:, x] * mask.double()).sum() / mask.double().sum() for x in range(X)) / X
+    ref.backward()
+    rd = rec.cuda().requires_grad_()
+    loss = ops.HipPatchMSE.apply(rd, imgs.cuda(), mask.cuda(), P)
+    loss.backward()
+    assert_close(loss.detach().cpu().reshape(()), ref.detach().reshape(()), rtol=1e-5, atol=1e-6, what="loss")
+    assert_close(rd.grad.cpu(), r64.grad, rtol=1e-4, atol=1e-8, what="d_rec")
+    assert (rd.grad.cpu()[mask[:, None, :, None].expand(B, X, n, E) == 0] == 0).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,H", [(306, 192, 768), (37, 64, 48), (4100, 192, 768), (64, 128, 128)])
 def test_swiglu_on_the_gemm_epilogues(M, K, H):
     """SwishGLU riding on the GEMMs around it: forward on the project product (aux_mode 3: interleaved weight image, u and
