@@ -142,6 +142,7 @@ int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K);
 hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
                               int K, int S, int L, int accumulate, float* bpart, hipStream_t s);
 int mdt_gemm_tn_ktile(int K);  // 128 or 192: the k-tile width k_gemm_tn picks for K columns
+void mdt_gemm_tn_tile(int64_t M, int N, int K, int* tn, int* tk);  // its (n, k) tile for an M-deep product: n 64 / 128 / 192 (4 / 8 / 12 waves)
 hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int M, int N, float* out0, float* out1,
                               int accumulate, hipStream_t s);
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);

@@ -1485,15 +1485,20 @@ hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks,
 // ------------------------------------------------------------------------------------------------
 // KT = 16-wide k-tiles per wave: 2 (tile 64 x 128) or 3 (64 x 192, for K = 192 / 576 / ... where 128-wide tiles would leave
 // a quarter of the last one empty: the masked-image head's d = 192 layers).
-template <int KT>
-__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
+// WN = 64-column halves of the n-tile (1: 4 waves, 64 x TK; 2: 8 waves, 128 x TK -- wave = (n half, k quarter)).  The wide tile
+// reads every X row half as often: a 64 x 192 tile at full MFMA rate wants 10.4 bytes per clock and CU from L2 / Infinity Cache
+// (32 KB per 32-row chunk and 96 MFMAs per wave), about what a CU gets; the 128-wide one 6.5.
+template <int KT, int WN>
+__global__ __launch_bounds__(256 * WN) void k_gemm_tn(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
                                                  float* __restrict__ out, int64_t slice_stride, int M, int N, int K, int L,
                                                  int accumulate, float* __restrict__ bpart) {
-    constexpr int CM = 32, TN_ = 64, TK = 64 * KT, SY = TN_ + 4, SX = TK + 4, XU = TK / 32, X4 = TK / 4;
+    constexpr int CM = 32, TN_ = 64 * WN, TK = 64 * KT, SY = TN_ + 4, SX = TK + 4, NTHR = 256 * WN, X4 = TK / 4, Y4 = TN_ / 4,
+                  XU = CM * X4 / NTHR, YU = CM * Y4 / NTHR;
+    static_assert(CM * X4 % NTHR == 0 && CM * Y4 % NTHR == 0, "staging does not split evenly");
     extern __shared__ __attribute__((aligned(16))) float tn_lds[];  // ys[2][CM * SY] | xs[2][CM * SX]  (51 / 68 KB)
     float (*ys)[CM * SY] = (float (*)[CM * SY])tn_lds;
     float (*xs)[CM * SX] = (float (*)[CM * SX])(tn_lds + 2 * CM * SY);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave & 3, wn = wave >> 2;
     const int gk = (K + TK - 1) / TK;
     const int bn = blockIdx.x / gk, bk = blockIdx.x - bn * gk;
     const int n0 = bn * TN_, k0 = bk * TK;
@@ -1502,12 +1507,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
     out += (int64_t)z * slice_stride;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     // staging assignment: X chunk = 32 rows x TK/4 float4 (4 or 6 per thread), dY chunk = 32 rows x 16 float4 (2 per thread)
-    int xr[XU], xc[XU], yr[2], yc[2];
+    int xr[XU], xc[XU], yr[YU], yc[YU];
 #pragma unroll
-    for (int u = 0; u < XU; ++u) { const int i = tid + 256 * u; xr[u] = i / X4; xc[u] = (i - xr[u] * X4) * 4; }
+    for (int u = 0; u < XU; ++u) { const int i = tid + NTHR * u; xr[u] = i / X4; xc[u] = (i - xr[u] * X4) * 4; }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { const int i = tid + 256 * u; yr[u] = i >> 4; yc[u] = (i & 15) * 4; }
-    f32x4 xv[XU], yv[2];
+    for (int u = 0; u < YU; ++u) { const int i = tid + NTHR * u; yr[u] = i / Y4; yc[u] = (i - yr[u] * Y4) * 4; }
+    f32x4 xv[XU], yv[YU];
     // buffer loads with 32-bit byte offsets where the operands allow it (both blocks below 4 GiB: always, for the shapes of
     // this model): a global load's 64-bit addresses cost the SIMD as much matrix-pipe time as its data (mdt_tiles.h: WStream)
     const bool small = (int64_t)M * ldx < ((int64_t)1 << 30) && (int64_t)M * ldy < ((int64_t)1 << 30);
@@ -1521,7 +1526,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
                 xv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (m * (unsigned)ldx + (unsigned)min(k0 + xc[u], K - 4)) << 2, 0, 0));
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < YU; ++u) {
                 const unsigned m = (unsigned)min(mb + yr[u], m_hi - 1);
                 yv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (m * (unsigned)ldy + (unsigned)min(n0 + yc[u], N - 4)) << 2, 0, 0));
             }
@@ -1533,7 +1538,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
             xv[u] = ldg4(X + m * ldx + min(k0 + xc[u], K - 4));
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < YU; ++u) {
             const int64_t m = min(mb + yr[u], m_hi - 1);
             yv[u] = ldg4(dY + m * ldy + min(n0 + yc[u], N - 4));
         }
@@ -1543,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
         for (int u = 0; u < XU; ++u)
             *(f32x4*)(&xs[buf][xr[u] * SX + xc[u]]) = (mb + xr[u] < m_hi && k0 + xc[u] < K) ? xv[u] : zero4;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < YU; ++u)
             *(f32x4*)(&ys[buf][yr[u] * SY + yc[u]]) = (mb + yr[u] < m_hi && n0 + yc[u] < N) ? yv[u] : zero4;
     };
     f32x4 acc[4][KT];
@@ -1572,9 +1577,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
                 const int row = 16 * s + 4 * h + e;
                 float a[KT], b[4];
 #pragma unroll
-                for (int j = 0; j < KT; ++j) a[j] = xb[row * SX + (KT * wave + j) * 16 + l16];
+                for (int j = 0; j < KT; ++j) a[j] = xb[row * SX + (KT * wk + j) * 16 + l16];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[i] = yb[row * SY + i * 16 + l16];
+                for (int i = 0; i < 4; ++i) b[i] = yb[row * SY + (4 * wn + i) * 16 + l16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1588,13 +1593,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
         if (c + 1 < nchunks) stash(buf ^ 1, m_lo + (c + 1) * CM);
         __syncthreads();
     }
-    // lane holds out[n0 + 16 i + l16][k0 + 16 (KT wave + j) + 4 h .. + 3]
+    // lane holds out[n0 + 16 (4 wn + i) + l16][k0 + 16 (KT wk + j) + 4 h .. + 3]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = n0 + 16 * i + l16;
+        const int n = n0 + 16 * (4 * wn + i) + l16;
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-            const int k = k0 + 16 * (KT * wave + j) + 4 * h;
+            const int k = k0 + 16 * (KT * wk + j) + 4 * h;
             if (n < N && k < K) {
                 float* p = out + (int64_t)n * K + k;
                 f32x4 v = acc[i][j];
@@ -1608,25 +1613,48 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dY, i
 
 // dW partials of S row slices of L rows: out + z * slice_stride is slice z's (N, K) product; N, K multiples of 16
 // (16-byte aligned rows).  bpart: nullptr or (S, N) per-slice column sums of dY.
+// (KT, WN) instantiation behind a shape.  n-tile: 192 wide (12 waves, needs N and K multiples of 192: every Linear of this model)
+// for the deepest reductions over large matrices, else 128 wide where N is a multiple of 128 and the reduction has 8192 rows,
+// else 64; k-tile: 192 with the 192-wide n-tile, else the one that pads K less.  MDT_HIP_TN_WIDE = 0 / 1 / 2 forces 64 / 128 / 192 where the shape allows (A/B runs).
+void mdt_gemm_tn_tile(int64_t M, int N, int K, int* tn, int* tk) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("MDT_HIP_TN_WIDE"); force = e ? atoi(e) + 1 : 0; }
+    const bool ok192 = N % 192 == 0 && K % 192 == 0, ok128 = N % 128 == 0;
+    // measured, product + sum of its slices (tools/dw_bench.py, us at 64 / 128 / 192): M = 104448: 1536 x 192 712 / 689 / 628,
+    // 192 x 768 357 / - / 307, 576 x 192 288 / - / 285, 192 x 192 115 / - / 139;  M = 10240: 1536 x 384 137 / 130 / 130,
+    // 384 x 1536 134 / 128 / 128, 1152 x 384 108 / 98 / 108, 384 x 384 51 / 48 / 63;  M = 4096: 64 wide or a tie
+    int w = ok192 && M >= 32768 && (int64_t)N * K >= 192 * 768 ? 192 : (ok128 && M >= 8192 ? 128 : 64);
+    if (force == 1) w = 64;
+    if (force == 2) w = ok128 ? 128 : 64;
+    if (force == 3) w = ok192 ? 192 : (ok128 ? 128 : 64);
+    *tn = w;
+    *tk = w == 192 ? 192 : mdt_gemm_tn_ktile(K);
+}
+template <int KT, int WN>
+static hipError_t launch_gemm_tn_t(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M,
+                                   int N, int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
+    constexpr int TN_ = 64 * WN, TK = 64 * KT;
+    constexpr size_t lds = (size_t)2 * 32 * ((TN_ + 4) + (TK + 4)) * sizeof(float);
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn<KT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_gemm_tn<KT, WN>), dim3(((N + TN_ - 1) / TN_) * ((K + TK - 1) / TK), 1, S), dim3(256 * WN), lds, s, dY, ldy, X, ldx,
+                       out, slice_stride, M, N, K, L, accumulate, bpart);
+    return hipGetLastError();
+}
 hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
                               int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
     if (M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || S < 1) return hipErrorInvalidValue;
-    const int gn = (N + 63) / 64;
-    constexpr size_t lds2 = (size_t)2 * 32 * (68 + 132) * sizeof(float), lds3 = (size_t)2 * 32 * (68 + 196) * sizeof(float);
-    if (mdt_gemm_tn_ktile(K) == 192) {
-        static bool attr = false;  // 67.6 KB: above the default dynamic-LDS limit
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
-        hipLaunchKernelGGL(k_gemm_tn<3>, dim3(gn * ((K + 191) / 192), 1, S), dim3(256), lds3, s, dY, ldy, X, ldx, out, slice_stride, M, N,
-                           K, L, accumulate, bpart);
-    } else {
-        hipLaunchKernelGGL(k_gemm_tn<2>, dim3(gn * ((K + 127) / 128), 1, S), dim3(256), lds2, s, dY, ldy, X, ldx, out, slice_stride, M, N,
-                           K, L, accumulate, bpart);
-    }
-    return hipGetLastError();
+    int tn, tk;
+    mdt_gemm_tn_tile(M, N, K, &tn, &tk);
+#define TN_ARGS dY, ldy, X, ldx, out, slice_stride, M, N, K, S, L, accumulate, bpart, s
+    if (tn == 192) return launch_gemm_tn_t<3, 3>(TN_ARGS);
+    if (tk == 192) return tn == 128 ? launch_gemm_tn_t<3, 2>(TN_ARGS) : launch_gemm_tn_t<3, 1>(TN_ARGS);
+    return tn == 128 ? launch_gemm_tn_t<2, 2>(TN_ARGS) : launch_gemm_tn_t<2, 1>(TN_ARGS);
+#undef TN_ARGS
 }
 // k-tile width k_gemm_tn uses for a K-column product: the one that pads K less (128 on a tie)
 int mdt_gemm_tn_ktile(int K) {

@@ -42,7 +42,9 @@ static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
 // The same for k_gemm_tn (64 x 128 tiles, no transposed / packed copies to amortise): ~6 workgroups per CU queued (3 resident), slices of at
 // least 128 rows -- small batches (B = 128: 1280 rows) need the split even more than large ones.
 static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
-    const int tk = mdt_gemm_tn_ktile((int)K);
+    int tn, tk;
+    mdt_gemm_tn_tile(M, (int)N, (int)K, &tn, &tk);
+    // in units of 64-column tiles whatever the n-tile: a 128- / 192-wide workgroup counts two / three times (it has as many waves)
     const int64_t tiles = ((N + 63) / 64) * ((K + tk - 1) / tk);
     static int64_t target = -1;
     if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 1536; }  // measured at B = 1024: 768 -> 11.27 ms step / 42.1 ms head, 1536 -> 11.18 / 41.4, 2304 -> 11.22 / 41.4

@@ -340,6 +340,26 @@ def test_attention_dropout_forward_and_backward(lib, hd, H, Tq, Tk, causal, rope
     assert_close(dkv[:, Dm:].cpu(), v64.grad, what="dv", **G_TOL)
 
 
+@pytest.mark.parametrize("M,N,K", [(8200, 384, 384), (8192, 1152, 384), (10240, 640, 128), (33000, 192, 768), (32768, 384, 384),
+                                   (40000, 1536, 192), (33000, 576, 192), (32800, 256, 64)])
+def test_weight_gradient_wide_tiles(lib, M, N, K):
+    """The 128- and 192-column tiles of the weight-gradient product (8 / 12 waves per workgroup; from 8192 / 32768 reduction rows
+    on, mdt_gemm_tn_tile) against float64 on the GPU, bias gradient included, ragged last slices."""
+    L = lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    X = torch.randn(M, K, device="cuda", generator=g)
+    dY = torch.randn(M, N, device="cuda", generator=g)
+    dW0 = torch.randn(N, K, device="cuda", generator=g)
+    dW, db = dW0.clone(), torch.zeros(N, device="cuda")
+    scratch = torch.empty(L.mdt_op_linear_bwd_scratch(M, N, K), device="cuda")
+    a = lib.LinearBwdArgs(X=X.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None, dW=dW.data_ptr(), dbias=db.data_ptr(), dX=None,
+                          ldxo=K, accumulate_dw=1, accumulate_dx=0, M=M, N=N, K=K, scratch=scratch.data_ptr())
+    lib.check(L.mdt_op_linear_bwd(C.byref(a), stream()))
+    tol = dict(rtol=1e-3, atol=1e-4 * (M / 64) ** 0.5)
+    assert_close((dW - dW0).cpu(), (dY.double().T @ X.double()).cpu(), what="dW", **tol)
+    assert_close(db.cpu(), dY.double().sum(0).cpu(), what="dbias", **tol)
+
+
 @pytest.mark.parametrize("M,N,K", [(2560, 1536, 384), (1280, 384, 1536), (1024, 1152, 384), (250, 384, 384), (37, 768, 512),
                                    (3, 64, 128), (128, 9216, 384)])
 def test_linear_backward_through_the_forward_gemm(lib, M, N, K):
