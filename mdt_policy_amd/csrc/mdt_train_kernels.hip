@@ -1623,7 +1623,8 @@ void mdt_gemm_tn_tile(int64_t M, int N, int K, int* tn, int* tk) {
     // measured, product + sum of its slices (tools/dw_bench.py, us at 64 / 128 / 192): M = 104448: 1536 x 192 712 / 689 / 628,
     // 192 x 768 357 / - / 307, 576 x 192 288 / - / 285, 192 x 192 115 / - / 139;  M = 10240: 1536 x 384 137 / 130 / 130,
     // 384 x 1536 134 / 128 / 128, 1152 x 384 108 / 98 / 108, 384 x 384 51 / 48 / 63;  M = 4096: 64 wide or a tie
-    int w = ok192 && M >= 32768 && (int64_t)N * K >= 192 * 768 ? 192 : (ok128 && M >= 8192 ? 128 : 64);
+    // (192 wide with ONE round of workgroups, split_rows_tn: 1536 x 192 597, 192 x 768 280, 576 x 192 263)
+    int w = ok192 && M >= 32768 && (int64_t)N * K >= 576 * 192 ? 192 : (ok128 && M >= 8192 ? 128 : 64);
     if (force == 1) w = 64;
     if (force == 2) w = ok128 ? 128 : 64;
     if (force == 3) w = ok192 ? 192 : (ok128 ? 128 : 64);

@@ -49,6 +49,12 @@ static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     static int64_t target = -1;
     if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 1536; }  // measured at B = 1024: 768 -> 11.27 ms step / 42.1 ms head, 1536 -> 11.18 / 41.4, 2304 -> 11.22 / 41.4
     int64_t s = std::max<int64_t>(1, std::min<int64_t>((target + tiles - 1) / tiles, M / 128));
+    if (tn == 192) {
+        // twelve-wave workgroups, one per CU: ONE round of them (tools/dw_bench.py at M = 104448, us at 32 / 64 / 128 slices:
+        // 1536 x 192 (8 tiles) 597 / 624 / 616, 192 x 768 (4) 495 / 280 / 302, 576 x 192 (3) 483 / 263 / 281)
+        const int64_t tiles192 = (N / 192) * (K / 192);
+        s = std::max<int64_t>(1, std::min<int64_t>((256 + tiles192 / 2) / tiles192, M / 128));
+    }
     static int64_t cap = -1;
     if (cap < 0) { const char* e = getenv("MDT_HIP_TN_SLICES"); cap = e ? atoll(e) : 128; }  // measured: masked-image head 37.7 ms (64) -> 37.2 (128) = (192, 256); denoiser step unchanged
     s = std::min<int64_t>(s, cap);
