@@ -1614,8 +1614,8 @@ __global__ __launch_bounds__(256 * WN) void k_gemm_tn(const float* __restrict__ 
 // dW partials of S row slices of L rows: out + z * slice_stride is slice z's (N, K) product; N, K multiples of 16
 // (16-byte aligned rows).  bpart: nullptr or (S, N) per-slice column sums of dY.
 // (KT, WN) instantiation behind a shape.  n-tile: 192 wide (12 waves, needs N and K multiples of 192: every Linear of this model)
-// for the deepest reductions over large matrices, else 128 wide where N is a multiple of 128 and the reduction has 8192 rows,
-// else 64; k-tile: 192 with the 192-wide n-tile, else the one that pads K less.  MDT_HIP_TN_WIDE = 0 / 1 / 2 forces 64 / 128 / 192 where the shape allows (A/B runs).
+// from 8192 reduction rows on for matrices of at least 576 x 192, else 128 wide where N is a multiple of 128, else 64; k-tile:
+// 192 with the 192-wide n-tile, else the one that pads K less.  MDT_HIP_TN_WIDE = 0 / 1 / 2 forces 64 / 128 / 192 where the shape allows (A/B runs).
 void mdt_gemm_tn_tile(int64_t M, int N, int K, int* tn, int* tk) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("MDT_HIP_TN_WIDE"); force = e ? atoi(e) + 1 : 0; }
@@ -1624,7 +1624,8 @@ void mdt_gemm_tn_tile(int64_t M, int N, int K, int* tn, int* tk) {
     // 192 x 768 357 / - / 307, 576 x 192 288 / - / 285, 192 x 192 115 / - / 139;  M = 10240: 1536 x 384 137 / 130 / 130,
     // 384 x 1536 134 / 128 / 128, 1152 x 384 108 / 98 / 108, 384 x 384 51 / 48 / 63;  M = 4096: 64 wide or a tie
     // (192 wide with ONE round of workgroups, split_rows_tn: 1536 x 192 597, 192 x 768 280, 576 x 192 263)
-    int w = ok192 && M >= 32768 && (int64_t)N * K >= 576 * 192 ? 192 : (ok128 && M >= 8192 ? 128 : 64);
+    // M = 10240 with that slicing: 1536 x 384 119, 384 x 1536 118, 1152 x 384 97, 384 x 384 45 -- 192 wide everywhere it fits
+    int w = ok192 && M >= 8192 && (int64_t)N * K >= 576 * 192 ? 192 : (ok128 && M >= 8192 ? 128 : 64);
     if (force == 1) w = 64;
     if (force == 2) w = ok128 ? 128 : 64;
     if (force == 3) w = ok192 ? 192 : (ok128 ? 128 : 64);
