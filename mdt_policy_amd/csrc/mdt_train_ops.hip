@@ -58,6 +58,15 @@ static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     static int64_t cap = -1;
     if (cap < 0) { const char* e = getenv("MDT_HIP_TN_SLICES"); cap = e ? atoll(e) : 128; }  // measured: masked-image head 37.7 ms (64) -> 37.2 (128) = (192, 256); denoiser step unchanged
     s = std::min<int64_t>(s, cap);
+    if (tn != 192) {
+        // whole rounds of workgroups here too where that is within a factor 1.5 of the above (192 x 192 at M = 104448, three
+        // 64 x 192 tiles: 128 slices = 384 workgroups 118 us, 170 = 510 of the 512 that are resident at once 99 us, 256 108 us)
+        const int64_t tiles_wg = ((N + tn - 1) / tn) * ((K + tk - 1) / tk);
+        const int64_t slots = 256 * (tn == 64 ? (tk == 192 ? 2 : 3) : (tk == 192 ? 1 : 2));   // resident workgroups: LDS 51 / 68 / 68 / 84 KB
+        const int64_t rounds = std::max<int64_t>(1, (tiles_wg * s + slots / 2) / slots);
+        const int64_t s2 = std::min<int64_t>((rounds * slots) / tiles_wg, M / 128);
+        if (s2 >= 1 && 2 * s2 <= 3 * s && 3 * s2 >= 2 * s) s = s2;
+    }
     if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
     const int64_t l = ((M + s - 1) / s + 31) / 32 * 32;
     *S = (int)((M + l - 1) / l);
