@@ -439,11 +439,21 @@ def main():
     eng = model.inner_model.hip_engine(0.5)
     eng.reserve(B)
 
+    gather_evs = []  # N > 1: a pair of HIP events around the collective of every TIMED step (recorded on the launch stream:
+    #                  what they bracket is the gather as the stream sees it, waiting for the slowest peer included)
+    timing_gather = [False]
+
     def step():
         with torch.no_grad():
             act = gs.sample_ddim(model, state, x_T, goal, sigmas)
         if world > 1:
+            if timing_gather[0]:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
             act = sharding.all_gather_actions(act, B * world)  # ONE collective per sample call
+            if timing_gather[0]:
+                g1.record()
+                gather_evs.append((g0, g1))
         return act
 
     log(f"model ready on {device}; warm-up x{args.warmup}")
@@ -453,17 +463,28 @@ def main():
     if dist is not None:
         dist.barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timing_gather[0] = True
     t0 = time.perf_counter()
     e0.record()
     for _ in range(args.steps):
         out = step()
     e1.record()
     torch.cuda.synchronize(device)
+    own_wall = time.perf_counter() - t0  # this rank's own clock, before it waits for the others
     if dist is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
+    timing_gather[0] = False
     gpu_s = e0.elapsed_time(e1) * 1e-3
+    per_rank = None
     if dist is not None:
+        # what a shortfall at N > 1 is made of: every rank's own step time, its GPU time, and the collective as its stream saw it
+        g_us = sorted(a.elapsed_time(b) * 1e3 for a, b in gather_evs)
+        mine = torch.tensor([own_wall / args.steps * 1e3, gpu_s / args.steps * 1e3, g_us[len(g_us) // 2], g_us[-1]],
+                            device=device, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu()
         t = torch.tensor([wall, gpu_s], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, gpu_s = t[0].item(), t[1].item()
@@ -529,7 +550,18 @@ def main():
                        "weights": "random init N(0,0.02) (reference _init_weights distributions), seed 0"},
             "collective": ({"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                             "ranks": dist.get_world_size(), "per_step": "one all_gather_into_tensor of (B, 10, 7) fp32",
-                            "gather_verified": gather_ok}
+                            "gather_verified": gather_ok,
+                            "bytes_per_rank": int(B * out.shape[1] * out.shape[2] * 4),
+                            # median over the timed steps of the HIP-event time around all_gather_actions, per rank; the figure of
+                            # the slowest rank is the one quoted (a fast rank's gather also contains its wait for the slowest)
+                            "gather_us": round(float(per_rank[:, 2].min()), 1),
+                            "gather_us_per_rank": [round(float(v), 1) for v in per_rank[:, 2]],
+                            "gather_us_max_per_rank": [round(float(v), 1) for v in per_rank[:, 3]],
+                            "gather_what": "HIP events on the launch stream around the collective of every timed step: median per rank; "
+                                           "`gather_us` = the smallest median = the rank that arrives last and waits for nobody",
+                            "per_rank_ms": [round(float(v), 4) for v in per_rank[:, 0]],
+                            "per_rank_gpu_ms": [round(float(v), 4) for v in per_rank[:, 1]],
+                            "slowest_rank": int(per_rank[:, 0].argmax())}
                            if dist is not None else None),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,

@@ -225,6 +225,7 @@ SYMBOLS = [
     ("mdt_op_colsum", _I32, [_VP, _I64, _I64, _I64, _VP, _I32, _VP]),
     ("mdt_op_linear_bwd", _I32, [C.POINTER(LinearBwdArgs), _VP]),
     ("mdt_op_linear_bwd_scratch", _I64, [_I64, _I64, _I64]),
+    ("mdt_op_linear_bwd_scratch_exact", _I64, [_I64, _I64, _I64]),
     ("mdt_op_multi_adamw", _I32, [C.POINTER(OptTensor), _I32, _F, _F, _F, _F, _F, _I64, _VP]),
     ("mdt_op_multi_ema", _I32, [C.POINTER(OptTensor), _I32, _F, _VP]),
     # include/mdt_resampler.h

@@ -554,8 +554,12 @@ static bool attn_proj_disabled() {  // MDT_HIP_NO_ATTN_PROJ=1: the separate atte
     return off != 0;
 }
 
+// WStream (mdt_tiles.h) addresses a weight image with 32-bit byte offsets from its base: every launcher that feeds one checks
+// the image size (mdt_launch_gemm does for the GEMMs; the fused MLP and attn_xattn tiles bound N and K by their shape rules)
+static bool w_image_ok(int64_t N, int64_t K) { return N * K < ((int64_t)1 << 30); }
+
 bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope) {
-    return H == 8 && (hd == 16 || hd == 32 || hd == 48 || hd == 64) && p.K == H * hd && T >= 1 && T <= 16 && p.M >= T &&
+    return w_image_ok(p.N, p.K) && H == 8 && (hd == 16 || hd == 32 || hd == 48 || hd == 64) && p.K == H * hd && T >= 1 && T <= 16 && p.M >= T &&
            p.M % T == 0 && p.M / T <= 64 && (p.rows_per_sample == T || p.M == T) && !rope &&
            !(p.N & 15) && p.gin == 1 && p.gout == 1 && p.goff == 0 && !p.ln && p.act == MDT_ACT_NONE && p.rowvec == nullptr &&
            p.batch <= 1 && !attn_proj_disabled();
@@ -592,7 +596,7 @@ hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_
 static hipError_t launch_gemm_merge(const mdt_gemm_args& a, hipStream_t s);
 
 bool mdt_attn_proj_wide_supported(const mdt_gemm_args& p, int H, int hd, int T, int causal, int rope) {
-    return H == 8 && (hd == 16 || hd == 32 || hd == 48) && p.K == H * hd && T >= 1 && T <= 16 && causal && !rope && p.residual &&
+    return w_image_ok(p.N, p.K) && H == 8 && (hd == 16 || hd == 32 || hd == 48) && p.K == H * hd && T >= 1 && T <= 16 && causal && !rope && p.residual &&
            p.M >= T && p.M % T == 0 && p.rows_per_sample == T && !(p.N & 15) && p.gin == 1 && p.gout == 1 && p.goff == 0 && !p.ln &&
            p.act == MDT_ACT_NONE && p.rowvec == nullptr && p.batch <= 1 && !p.aux_mode;
 }
@@ -1300,7 +1304,7 @@ size_t mdt_xattn_lds_floats(int D, int H) {
 // output array (x.y_out != x.y: the workgroups that repeat a sample's cross-attention read x.y while one of them writes), `g` =
 // the Linear on the same rows (g.A == x.y, LayerNorm prologue, K = x.D, M = x.B * x.Ta, no residual, plain row mapping).
 bool mdt_xattn_gemm_supported(const mdt_xapply_args& x, const mdt_gemm_args& g) {
-    return mdt_xattn_apply_supported(x.D, x.H, x.Te, x.Ta) && x.y_out != nullptr && x.y_out != x.y && g.ln && g.K == x.D && g.A == x.y &&
+    return w_image_ok(g.N, g.K) && mdt_xattn_apply_supported(x.D, x.H, x.Te, x.Ta) && x.y_out != nullptr && x.y_out != x.y && g.ln && g.K == x.D && g.A == x.y &&
            g.lda == x.D &&
            g.M == x.B * x.Ta && !(g.N & 15) && !g.residual && g.batch <= 1 && !g.aux_mode && g.a_parts <= 1 && g.gin == 1 &&
            g.gout == 1 && g.goff == 0 && g.rows_per_sample == x.Ta;

@@ -1,7 +1,7 @@
 // mdt_tall.h -- the TALL GEMM body (round 4): 128-row tiles, BOTH operands staged through LDS by LDS-DMA
 // (global_load_lds_dwordx4), every staged element reused by 2-4 waves.
 //
-// Why a second body (tools/micro/wstream_probe.hip, profiles/r04_wstream_probe.txt): gemm_tile (mdt_tiles.h) hands every wave
+// Why a second body (tools/micro/wstream_probe.hip, profiles/r04_probes.txt (1)): gemm_tile (mdt_tiles.h) hands every wave
 // its own weight fragments straight from L2 into VGPRs -- ideal for ONE 32-row tile per CU (the B = 256 sampler: 80 row tiles),
 // where no operand is shared between waves anyway -- but it pulls 128 B through the CU's vector-memory path per MFMA, and a
 // wave that issues those requests is a wave that is not issuing MFMAs.  Where there are THOUSANDS of tiles (the training step:
@@ -201,7 +201,7 @@ __device__ __forceinline__ void gemm_tall_tile(const mdt_gemm_args& a, int by, i
     // The common cases are their own straight-line instantiations (ACT / AUX fixed, FULL: no row or column of the tile is
     // outside the matrix, so no store carries a predicate).  With everything decided per value at run time -- activation
     // switch, training hooks, `ok` masks as exec-mask branches -- the epilogue was ~140 instructions per 16 x 16 tile: 9.3 k
-    // cycles for a 128 x 128 tile alone on its CU against 49 k of MFMA issue (profiles/r04_tall_phases.txt).
+    // cycles for a 128 x 128 tile alone on its CU against 49 k of MFMA issue (profiles/r04_gemm_train_shapes.txt, "Where the time of a 128 x 128 tile goes").
     const int nq = 4 * (lane >> 4);
     const float* biasp = a.bias != nullptr ? a.bias : zeros;
     const float* rvp = a.rowvec != nullptr ? a.rowvec : zeros;

@@ -472,16 +472,16 @@ __global__ __launch_bounds__(256) void k_merge_fwd4(mdt_merge_args a) {
     const int b = blockIdx.x, D4 = a.D >> 2, rps = a.rows_per_sample, RL = 256 / D4;
     const int c4 = threadIdx.x % D4, rl = threadIdx.x / D4;
     if (rl >= RL) return;
-    const f32x4* __restrict__ A = (const f32x4*)a.a;
-    const f32x4* __restrict__ X = (const f32x4*)a.x;
-    f32x4* __restrict__ O = (f32x4*)a.out;
+    const f32x4* A = (const f32x4*)a.a;  // no __restrict__: `out` may be `a` or `x` (in-place merges); the batches below
+    const f32x4* X = (const f32x4*)a.x;  // already request every row of a thread before its first store
+    f32x4* O = (f32x4*)a.out;
     const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
     const f32x4 g = a.gate ? *(const f32x4*)(a.gate + (int64_t)b * a.gate_stride + 4 * c4) : one4;
     for (int r0 = rl; r0 < rps; r0 += RL * MERGE_U) {
         f32x4 av[MERGE_U], xv[MERGE_U];
 #pragma unroll
         for (int u = 0; u < MERGE_U; ++u) {
-            const int r = min(r0 + u * RL, rps - 1);
+            const int r = r0 + u * RL < rps ? r0 + u * RL : r0;  // past the end: the thread's own first row again (never a row another thread stores)
             const int64_t i = ((int64_t)b * rps + r) * D4 + c4;
             av[u] = A[i];
             xv[u] = X[i];
@@ -501,9 +501,9 @@ __global__ __launch_bounds__(256) void k_merge_bwd4(mdt_merge_args a) {
     __shared__ f32x4 red[256];
     const int b = blockIdx.x, D4 = a.D >> 2, rps = a.rows_per_sample, RL = 256 / D4;
     const int c4 = threadIdx.x % D4, rl = threadIdx.x / D4;
-    const f32x4* __restrict__ A = (const f32x4*)a.a;
-    const f32x4* __restrict__ X = (const f32x4*)a.x;
-    f32x4* __restrict__ O = (f32x4*)a.out;
+    const f32x4* A = (const f32x4*)a.a;  // no __restrict__: `out` may be `a` or `x` (in-place merges); the batches below
+    const f32x4* X = (const f32x4*)a.x;  // already request every row of a thread before its first store
+    f32x4* O = (f32x4*)a.out;
     const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (rl < RL) {
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_merge_bwd4(mdt_merge_args a) {
             f32x4 av[MERGE_U], dv[MERGE_U];
 #pragma unroll
             for (int u = 0; u < MERGE_U; ++u) {
-                const int r = min(r0 + u * RL, rps - 1);
+                const int r = r0 + u * RL < rps ? r0 + u * RL : r0;  // past the end: the thread's own first row again (never a row another thread stores)
                 const int64_t i = ((int64_t)b * rps + r) * D4 + c4;
                 av[u] = A[i];
                 dv[u] = X[i];
@@ -1637,11 +1637,13 @@ static hipError_t launch_gemm_tn_t(const float* dY, int64_t ldy, const float* X,
                                    int N, int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
     constexpr int TN_ = 64 * WN, TK = 64 * KT;
     constexpr size_t lds = (size_t)2 * 32 * ((TN_ + 4) + (TK + 4)) * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
+    static bool attr_dev[32] = {false};  // per instantiation AND per device: function attributes are per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (!attr_dev[dev] && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn<KT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr_dev[dev] = true;
     }
     hipLaunchKernelGGL((k_gemm_tn<KT, WN>), dim3(((N + TN_ - 1) / TN_) * ((K + TK - 1) / TK), 1, S), dim3(256 * WN), lds, s, dY, ldy, X, ldx,
                        out, slice_stride, M, N, K, L, accumulate, bpart);

@@ -21,6 +21,11 @@
 // fills the chip with WIDE tiles however small N x K is: slice s multiplies its own (N, L) piece of dY^T with its own
 // packed (K, L) piece of X^T in ONE batched launch (grid.z = S), and the S partial (N, K) products are summed in a
 // fixed order by a column sum -- deterministic, unlike atomics.  Only worth it for deep reductions.
+static bool no_splitk() {
+    static int v = -1;
+    if (v < 0) v = getenv("MDT_HIP_NO_SPLITK") ? 1 : 0;
+    return v == 1;
+}
 static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     const int64_t tiles = ((N + 31) / 32) * ((K + 127) / 128);   // 32 x 128 tiles of one product
     static int64_t target = -1, min_depth = -1;  // tuning knobs (A/B runs): workgroups aimed for, least slice depth
@@ -32,7 +37,7 @@ static void split_rows(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     const int64_t depth = M >= 4096 ? min_depth : std::max<int64_t>(min_depth, 1024);
     int64_t s = std::max<int64_t>(1, std::min<int64_t>((target + tiles - 1) / tiles, M / depth));
     s = std::min<int64_t>(s, 32);
-    if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
+    if (no_splitk()) s = 1;
     int64_t l = ((M + s - 1) / s + 31) / 32 * 32;                // equal slices: at most 31 pad rows each
     while (l > 16384) { ++s; l = ((M + s - 1) / s + 31) / 32 * 32; }  // keeps the GEMM's K' well inside its limit
     *S = (int)((M + l - 1) / l);
@@ -67,18 +72,51 @@ static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
         const int64_t s2 = std::min<int64_t>((rounds * slots) / tiles_wg, M / 128);
         if (s2 >= 1 && 2 * s2 <= 3 * s && 3 * s2 >= 2 * s) s = s2;
     }
-    if (getenv("MDT_HIP_NO_SPLITK")) s = 1;
+    if (no_splitk()) s = 1;
     const int64_t l = ((M + s - 1) / s + 31) / 32 * 32;
     *S = (int)((M + l - 1) / l);
     *L = (int)l;
 }
 
-int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K) {
+// Floats of scratch ONE product of exactly M rows needs (what mdt_linear_bwd carves out of `scratch` for it).
+static int64_t linear_bwd_scratch_exact(int64_t M, int64_t N, int64_t K) {
     int S, L, St, Lt;
     split_rows(M, N, K, &S, &L);
     split_rows_tn(M, N, K, &St, &Lt);
     const int64_t Mp = (int64_t)S * L;
     return std::max<int64_t>((N + K) * Mp + (int64_t)S * N * K + N * (Mp / 32 + 2), (int64_t)St * N * K + (int64_t)St * N + 64);
+}
+
+// Floats of scratch that serve EVERY row count up to M.  The callers size their scratch once, for the largest batch seen, and
+// reuse it for every smaller one -- and the slice count is not monotone in M (the n-tile changes at 8192 rows, the 192-wide tile
+// wants one round of workgroups, the narrower ones whole rounds of the resident workgroups: a smaller batch can be cut into MORE
+// slices than the capacity batch), so the exact figure at M is not enough.  Closed-form bounds of both paths:
+//   k_gemm_tn: S <= M / 128 always; S <= 3/2 x min(ceil(target / tiles), cap) for the 64- / 128-wide tiles (`tiles` counted with
+//              the k-tile that gives fewer of them), S <= (256 + t / 2) / t one-round slices for the 192-wide one;
+//   transposed-copy path (MDT_HIP_DW_TN=0 or odd shapes): its slice count s only grows with M and Mp = S L <= M + 32 s.
+// tests/test_cpu_abi.py sweeps the exact need of every row count below a capacity against this bound.
+int64_t mdt_linear_bwd_scratch(int64_t M, int64_t N, int64_t K) {
+    if (M < 1) M = 1;
+    // k_gemm_tn
+    static int64_t target = -1, cap = -1;
+    if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 1536; }
+    if (cap < 0) { const char* e = getenv("MDT_HIP_TN_SLICES"); cap = e ? atoll(e) : 128; }
+    const int64_t tiles_min = ((N + 63) / 64) * ((K + 191) / 192);
+    int64_t s_tn = (3 * std::min<int64_t>((target + tiles_min - 1) / tiles_min, cap) + 1) / 2;
+    if (N % 192 == 0 && K % 192 == 0) {
+        const int64_t t192 = (N / 192) * (K / 192);
+        s_tn = std::max<int64_t>(s_tn, (256 + t192 / 2) / t192);
+    }
+    s_tn = std::max<int64_t>(1, std::min<int64_t>(s_tn, M / 128));
+    const int64_t need_tn = s_tn * N * K + s_tn * N + 64;
+    // transposed-copy path: split_rows' slice count before it is rounded to whole slices -- non-decreasing in M
+    int S, L;
+    split_rows(M, N, K, &S, &L);
+    int64_t s_old = std::max<int64_t>(S, std::min<int64_t>(32, std::max<int64_t>(1, M / 512)));
+    while ((M + s_old - 1) / s_old > 16384) ++s_old;
+    const int64_t Mp = M + 32 * s_old;
+    const int64_t need_old = (N + K) * Mp + s_old * N * K + N * (Mp / 32 + 2);
+    return std::max(std::max(need_tn, need_old), linear_bwd_scratch_exact(M, N, K));
 }
 
 mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsum_entry* defer_bias, float* bias_space) {
@@ -151,6 +189,7 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsu
 }
 
 extern "C" int64_t mdt_op_linear_bwd_scratch(int64_t M, int64_t N, int64_t K) { return mdt_linear_bwd_scratch(M, N, K); }
+extern "C" int64_t mdt_op_linear_bwd_scratch_exact(int64_t M, int64_t N, int64_t K) { return linear_bwd_scratch_exact(M, N, K); }
 
 extern "C" mdt_status mdt_op_linear_bwd(const mdt_linear_bwd_args* a, void* stream) {
     if (!a || !a->X || !a->dY || !a->scratch) return fail(MDT_ERR_INVALID_ARG, "mdt_op_linear_bwd: null argument");

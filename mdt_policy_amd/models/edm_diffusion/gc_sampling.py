@@ -189,9 +189,11 @@ def _graphed(model, state, action, goal, sigmas):
 def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
                 eta=1.):
     """DPM-Solver-1 / DDIM (reference gc_sampling.py:922-951):
-    x <- (sigma_{i+1}/sigma_i) x - expm1(-(t_{i+1} - t_i)) D(x; sigma_i),  t = -ln sigma."""
+    x <- (sigma_{i+1}/sigma_i) x - expm1(-(t_{i+1} - t_i)) D(x; sigma_i),  t = -ln sigma.
+    `scaler` is accepted and never read, exactly as in the reference (its DDIM has no `clip_output` call), so a harness run
+    with `use_scaler` (mdtv_agent.py:606-614) keeps the fused native loop; only `callback` / `extra_args` need the step loop."""
     extra_args = {} if extra_args is None else extra_args
-    if isinstance(model, GCDenoiser) and scaler is None and callback is None and not extra_args:
+    if isinstance(model, GCDenoiser) and callback is None and not extra_args:
         if _graph_wanted(model, state, action, goal, sigmas):
             if _GRAPH_SAMPLER:
                 return _graphed(model, state, action, goal, sigmas)  # the same launches, replayed as a HIP graph

@@ -277,6 +277,7 @@ class HipRMSNormBranch(torch.autograd.Function):
         _lib.check(lib.mdt_op_rms_fwd(x2.data_ptr(), gg.data_ptr(), out.data_ptr(), x2.shape[0], D, RMS_EPS, _stream(x2)))
         ctx.save_for_backward(x2, gg)
         ctx.xshape = x.shape
+        ctx.set_materialize_grads(False)  # an unused output arrives as None, not as a dense zero tensor: the branches below are live
         return x.view_as(x), out.reshape(x.shape)
 
     @staticmethod

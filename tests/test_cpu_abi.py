@@ -410,3 +410,26 @@ def test_copies_of_the_facade_modules_are_tracked_by_the_optimizer_hook():
             p.grad = torch.zeros_like(p)
             torch.optim.SGD([p], lr=0.1).step()
             assert marks, f"{type(m).__name__}: the optimizer hook did not reach the copy"
+
+
+@pytest.mark.parametrize("N,K", [(1536, 384), (384, 1536), (1152, 384), (384, 384), (9216, 384), (256, 256), (1024, 256), (192, 192),
+                                 (576, 192), (1536, 192), (192, 768), (768, 192), (512, 128), (112, 384), (1024, 384)])
+def test_linear_backward_scratch_bound_serves_every_smaller_row_count(N, K):
+    """The training handles size `lin_scratch` ONCE, for the largest batch seen, and reuse it for every smaller batch; the slice
+    count of the weight-gradient product is not monotone in the row count (n-tile switch at 8192 rows, whole rounds of resident
+    workgroups), so mdt_op_linear_bwd_scratch(M) must cover the exact need of every M' <= M (with D = 256, Ta = 11 a
+    batch of 219 needed 789 504 floats more than the capacity batch of 256 had been given)."""
+    lib = _lib.load()
+    caps = [128 * 10, 256 * 11, 128 * 16, 1024 * 10, 8191, 8192, 1024 * 102, 50176]
+    for cap in caps:
+        bound = lib.mdt_op_linear_bwd_scratch(cap, N, K)
+        rows = set(range(1, min(cap, 4096) + 1)) | set(range(4096, cap + 1, 7)) | {cap}
+        rows |= {m for b in (8191, 8192, 8193) for m in (b,) if m <= cap}
+        worst = max(lib.mdt_op_linear_bwd_scratch_exact(m, N, K) for m in rows)
+        assert worst <= bound, f"cap {cap} rows: a smaller batch needs {worst} floats, the bound is {bound}"
+    # ... and the bound itself never shrinks as the capacity grows
+    prev = 0
+    for cap in sorted(set(caps) | {1, 10, 127, 128, 129, 4095, 4096}):
+        b = lib.mdt_op_linear_bwd_scratch(cap, N, K)
+        assert b >= prev, (cap, b, prev)
+        prev = b

@@ -34,6 +34,7 @@ def test_bench_two_ranks_over_rccl():
     assert j["collective"]["backend"] == "nccl" and j["collective"]["rccl_ranks"] == 2
     assert j["collective"]["gather_verified"] is True  # shape (2 B, 10, 7), rank-ordered blocks equal to each rank's own output
     assert j["value"] > 0
+    assert len(j["collective"]["per_rank_ms"]) == 2 and j["collective"]["gather_us"] > 0
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
@@ -55,6 +56,13 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     assert j["collective"]["backend"] == "gloo" and j["collective"]["ranks"] == 2 and j["collective"]["rccl_ranks"] == 0
     assert j["collective"]["gather_verified"] is True
     assert j["value"] > 0 and abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
+    # the N > 1 line says where a shortfall comes from: the collective's time on every rank's stream, every rank's own step time
+    c = j["collective"]
+    assert c["bytes_per_rank"] == 32 * 10 * 7 * 4
+    assert len(c["per_rank_ms"]) == len(c["per_rank_gpu_ms"]) == len(c["gather_us_per_rank"]) == len(c["gather_us_max_per_rank"]) == 2
+    assert all(v > 0 for v in c["per_rank_ms"] + c["per_rank_gpu_ms"] + c["gather_us_per_rank"])
+    assert c["gather_us"] == min(c["gather_us_per_rank"]) and c["slowest_rank"] in (0, 1)
+    assert max(c["per_rank_ms"]) <= j["ms_per_step"] * 1.001  # the quoted step time is the slowest rank's, barrier included
 
 
 _RAGGED_WORKER = r'''

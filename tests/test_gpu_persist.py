@@ -238,3 +238,34 @@ def test_rollout_sized_calls_switch_to_graph_replay_by_themselves(monkeypatch):
         for _ in range(4):
             gs.sample_ddim(model, *inputs(9, 64), sig)
     assert len(model._graphed_samplers) == 1
+
+
+def test_a_scaler_argument_keeps_the_fused_loop(monkeypatch):
+    """The reference's DDIM accepts `scaler` and never reads it (gc_sampling.py:922-951), so a harness run with `use_scaler`
+    (mdtv_agent.py:606-614) must get the same ONE native call -- not the per-step Python loop -- and the same bits."""
+    meta, fx = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    gs = sampling()
+    sig = gs.get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    x_T = noise * meta["sigma_max"]
+    fused, stepped = [], []
+    native, fwd = model.sample_ddim, type(model).forward
+    monkeypatch.setattr(model, "sample_ddim", lambda *a, **k: (fused.append(1), native(*a, **k))[1])
+    monkeypatch.setattr(type(model), "forward", lambda self, *a, **k: (stepped.append(1), fwd(self, *a, **k))[1])
+
+    class Scaler:  # any object: reading an attribute of it would raise
+        def __getattr__(self, name):
+            raise AssertionError(f"sample_ddim read scaler.{name}")
+
+    with torch.no_grad():
+        plain = gs.sample_ddim(model, state, x_T, goal, sig)
+        scaled = gs.sample_ddim(model, state, x_T, goal, sig, scaler=Scaler())
+    torch.cuda.synchronize()
+    assert len(fused) == 2 and not stepped, f"native calls {len(fused)}, per-step denoiser calls {len(stepped)}"
+    assert torch.equal(plain, scaled)
+    assert_close(scaled.cpu(), fx["actions"], what="scaler passed vs reference")
+    with torch.no_grad():  # a callback still needs the step loop, and gets every step
+        seen = []
+        gs.sample_ddim(model, state, x_T, goal, sig, scaler=Scaler(), callback=lambda d: seen.append(d["i"]))
+    assert seen == list(range(meta["n_steps"])) and len(stepped) == meta["n_steps"]
