@@ -4,6 +4,8 @@ MFMA issue slots (the clock behind the 157.3 TFLOP/s figure) the kernel used; du
 of the same (profiled) run.  GRBM_GUI_ACTIVE is not used: it is not a per-dispatch cycle count in this rocprofv3."""
 import collections, csv, glob, os, sys
 root = sys.argv[1]
+WHAT = sys.argv[2] if len(sys.argv) > 2 else "'bench.py --steps 3 --warmup 1' (4 sampler calls + the 210-launch dominant-kernel leg)"
+NROWS = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 CLK = 2.4e9
 val = collections.defaultdict(lambda: collections.defaultdict(float))   # kernel -> counter -> sum
 num = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -13,16 +15,16 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.cs
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if name.startswith("at::") or "rocclr" in name or name.startswith("k_pack") or "elementwise" in name:
             name = "(other)"
-        k = (name, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+        k = (name, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))  # rocprofv3's Grid_Size / Workgroup_Size are the products over x, y, z
         c = r["Counter_Name"]
         val[k][c] += float(r["Counter_Value"]); num[k][c] += 1
         if c == "SQ_VALU_MFMA_BUSY_CYCLES":
             dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
 rows = sorted(val.items(), key=lambda kv: -dur[kv[0]])
-print("# sums over all dispatches of 'bench.py --steps 3 --warmup 1' (4 sampler calls + the 210-launch dominant-kernel leg), profiled run")
-print("kernel | workgroups | dispatches | avg us | MFMA-busy cycles/SIMD/launch | MFMA-busy frac @2.4GHz | HBM-side read MB/launch | write MB/launch | L2 hit")
+print(f"# sums over all dispatches of {WHAT}, profiled run")
+print("kernel | workgroups | dispatches | avg us | MFMA-busy cycles/SIMD/launch | MFMA-busy frac @2.4GHz | HBM-side read MB/launch | write MB/launch | L2 hit | HBM-side TB/s | share of kernel time")
 tb = td = 0.0
-for k, d in rows[:14]:
+for k, d in rows[:NROWS]:
     n = max(1, num[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))
     busy = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024
     frac = busy / (dur[k] * CLK) if dur[k] else 0.0
@@ -30,7 +32,8 @@ for k, d in rows[:14]:
     rd = d.get("TCC_EA0_RDREQ_sum", 0.0) * 128 / 1e6 / max(1, num[k].get("TCC_EA0_RDREQ_sum", 1))
     wr = d.get("TCC_EA0_WRREQ_sum", 0.0) * 64 / 1e6 / max(1, num[k].get("TCC_EA0_WRREQ_sum", 1))
     hit = d.get("TCC_HIT_sum", 0.0) / max(1.0, d.get("TCC_HIT_sum", 0.0) + d.get("TCC_MISS_sum", 0.0))
-    print(f"{k[0][:44]} | {k[1]} | {n} | {dur[k] / n * 1e6:.2f} | {busy / n:.0f} | {frac:.3f} | {rd:.1f} | {wr:.1f} | {hit:.2f}")
+    tbs = (rd + wr) * 1e6 / (dur[k] / n) / 1e12 if dur[k] else 0.0
+    print(f"{k[0][:44]} | {k[1]} | {n} | {dur[k] / n * 1e6:.2f} | {busy / n:.0f} | {frac:.3f} | {rd:.1f} | {wr:.1f} | {hit:.2f} | {tbs:.2f} | {100 * dur[k] / max(1e-12, sum(dur.values())):.1f}%")
 allb = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for d in val.values()) / 1024
 alld = sum(dur.values())
 rd = sum(d.get("TCC_EA0_RDREQ_sum", 0.0) for d in val.values()) * 128 / 1e9
