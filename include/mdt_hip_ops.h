@@ -193,9 +193,9 @@ mdt_status mdt_op_head(const mdt_head_args *args, void *stream);
  * output projections once per sampler call ... */
 typedef struct {
     const float *kv; int64_t ldkv; /* (B*Te, ...) rows holding K at column 0 and V at column D of this block   */
-    const float *Wq;               /* cross_att.query.weight (D, D) row-major (reference layout)               */
+    const float *WqT_p;            /* fragment image of cross_att.query.weight TRANSPOSED: mdt_op_pack_weight_t(Wq, D, D, D, .., 0, D / 16) */
     const float *bq;               /* cross_att.query.bias (D)                                                 */
-    const float *WoT;              /* cross_att.c_proj.weight TRANSPOSED: WoT[d][n] = Wo[n][d]                 */
+    const float *Wo_p;             /* fragment image of cross_att.c_proj.weight: mdt_op_pack_weight(Wo, D, D, .., 0)               */
     float *U, *Wf;                 /* out: B images of 4 H * D floats each, opaque: MFMA weight-fragment order, every head */
                                    /* padded to 4 context tokens (row p = 4 h + j; mdt_kernels.hip "Collapsed ...")        */
     float *c;                      /* out: (B, 4 H)                                                                        */

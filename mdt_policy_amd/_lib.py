@@ -49,7 +49,7 @@ class AttnArgs(C.Structure):
 
 
 class XFoldArgs(C.Structure):
-    _fields_ = [("kv", C.c_void_p), ("ldkv", C.c_int64), ("Wq", C.c_void_p), ("bq", C.c_void_p), ("WoT", C.c_void_p),
+    _fields_ = [("kv", C.c_void_p), ("ldkv", C.c_int64), ("WqT_p", C.c_void_p), ("bq", C.c_void_p), ("Wo_p", C.c_void_p),
                 ("U", C.c_void_p), ("Wf", C.c_void_p), ("c", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32),
                 ("hd", C.c_int32), ("D", C.c_int32), ("Te", C.c_int32)]
 

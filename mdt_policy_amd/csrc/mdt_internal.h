@@ -86,10 +86,17 @@ bool mdt_attn_xattn_supported(const mdt_gemm_args& p, const mdt_xapply_args& x, 
 hipError_t mdt_launch_attn_xattn(const mdt_gemm_args& p, const float* qkv, int64_t ldq, const mdt_xapply_args& x, int H, int hd,
                                  int T, hipStream_t s);
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
-                                hipStream_t s);
+                                hipStream_t s, float* out2 = nullptr);
 hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,
                                 hipStream_t s);
 hipError_t mdt_launch_ddim_steps(const float* sigmas_dev, int n, float* steps, hipStream_t s);
+// the DDIM sampler's once-per-call scalar work in one launch: per-step scalars, the sigma embeddings of all steps, the first
+// action embedding (mdt_kernels.hip: k_sample_prep); the schedule from device memory or, by value, from the host
+constexpr int MDT_SCHED_MAX = 64;
+struct mdt_sched_arg { float s[MDT_SCHED_MAX + 1]; };
+hipError_t mdt_launch_sample_prep(const float* sigmas_dev, const float* sigmas_host, int n_steps, float* steps, const float* freqs,
+                                  float* sig_e, int D, const float* x, float sd, const float* Wa, const float* ba, float* y, int M,
+                                  int A, hipStream_t s);
 hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t sstride, float sd, const float* Wa,
                                    const float* ba, float* y, int M, int A, int D, int rps, hipStream_t s);
 hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s);

@@ -987,7 +987,8 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ in, int n4, int
 }
 
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ w,
-                                                   const float* __restrict__ b, float* __restrict__ out, int M, int D) {
+                                                   const float* __restrict__ b, float* __restrict__ out, float* __restrict__ out2,
+                                                   int M, int D) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -1002,13 +1003,16 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
             f32x4 y = v[p] * rstd * *(const f32x4*)(w + 4 * c4);
             if (b != nullptr) y += *(const f32x4*)(b + 4 * c4);
             *(f32x4*)(out + (int64_t)m * D + 4 * c4) = y;
+            if (out2 != nullptr) *(f32x4*)(out2 + (int64_t)m * D + 4 * c4) = y;
         }
     }
 }
 
+// out2 (optional): a second copy of the rows (the encoder's final norm leaves the context in the workspace AND in the caller's
+// latent_encoder_emb buffer: no device-to-device copy launch behind it)
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, in, w, b, out, M, D);
+                                hipStream_t s, float* out2) {
+    hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, in, w, b, out, out2, M, D);
     return hipGetLastError();
 }
 
@@ -1122,6 +1126,71 @@ hipError_t mdt_launch_action_embed(const float* x, const float* sigma, int64_t s
 }
 
 // ------------------------------------------------------------------------------------------------
+// The once-per-call scalar work of the DDIM sampler as ONE launch (round 5; it was a host-to-device copy of the schedule +
+// k_ddim_steps + k_sigma_emb + k_action_embed: four dependent ~4.5 us launches in front of every sampler call, a tenth of a
+// rollout-sized call).  A host schedule travels in the kernel arguments; a device schedule is read in place.  Blocks
+// [0, n_act) embed the first noisy actions (k_action_embed's arithmetic with c_in(sigma_0)), blocks [n_act, n_act + n_emb) write
+// the sinusoidal sigma embeddings of all steps (k_sigma_emb's), the last block the per-step DDIM scalars (k_ddim_steps's) --
+// each from the schedule itself, so nothing in the launch depends on anything else in it, and every value has the bits the
+// separate kernels gave.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_prep(const float* __restrict__ sig_dev, mdt_sched_arg sv, int n_steps,
+                                                     float* __restrict__ steps, const float* __restrict__ freqs,
+                                                     float* __restrict__ sig_e, int D, const float* __restrict__ x, float sd,
+                                                     const float* __restrict__ WaT, const float* __restrict__ ba,
+                                                     float* __restrict__ y, int M, int A, int n_act, int n_emb) {
+    const int b = blockIdx.x;
+    if (b < n_act) {
+        const int n4 = D >> 2;
+        const int64_t idx = (int64_t)b * 256 + threadIdx.x;
+        if (idx >= (int64_t)M * n4) return;
+        const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+        const float cin = edm_c_in(sig_dev ? sig_dev[0] : sv.s[0], sd);
+        f32x4 acc = *(const f32x4*)(ba + n);
+        for (int c = 0; c < A; ++c) {
+            const float xv = x[(int64_t)m * A + c] * cin;
+            const f32x4 w = *(const f32x4*)(WaT + (int64_t)c * D + n);
+            acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y);
+            acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+        }
+        *(f32x4*)(y + (int64_t)m * D + n) = acc;
+    } else if (b < n_act + n_emb) {
+        const int half = D >> 1;
+        const int idx = (b - n_act) * 256 + threadIdx.x;
+        if (idx >= n_steps * half) return;
+        const int r = idx / half, j = idx % half;
+        const float sg = sig_dev ? sig_dev[r] : sv.s[r];
+        const float ang = (logf(sg) / 4.0f) * freqs[j];
+        sig_e[(int64_t)r * D + j] = sinf(ang);
+        sig_e[(int64_t)r * D + half + j] = cosf(ang);
+    } else {
+        const int i = threadIdx.x;
+        if (i >= n_steps) return;
+        const float s0 = sig_dev ? sig_dev[i] : sv.s[i], s1 = sig_dev ? sig_dev[i + 1] : sv.s[i + 1];
+        const float t = -logf(s0), tn = -logf(s1);
+        const float h = tn - t;
+        steps[4 * i + 0] = expf(-tn) / expf(-t);
+        steps[4 * i + 1] = -expm1f(-h);
+        steps[4 * i + 2] = s1;
+        steps[4 * i + 3] = s0;
+    }
+}
+// sigmas_dev or sigmas_host (exactly one non-null): n_steps + 1 levels, n_steps <= MDT_SCHED_MAX; sig_e == nullptr: no embeddings
+hipError_t mdt_launch_sample_prep(const float* sigmas_dev, const float* sigmas_host, int n_steps, float* steps, const float* freqs,
+                                  float* sig_e, int D, const float* x, float sd, const float* Wa, const float* ba, float* y, int M,
+                                  int A, hipStream_t s) {
+    if (n_steps < 1 || n_steps > MDT_SCHED_MAX || (!sigmas_dev) == (!sigmas_host) || (D & 3)) return hipErrorInvalidValue;
+    mdt_sched_arg sv;
+    memset(&sv, 0, sizeof sv);
+    if (sigmas_host) memcpy(sv.s, sigmas_host, (size_t)(n_steps + 1) * sizeof(float));
+    const int n_act = (int)(((int64_t)M * (D / 4) + 255) / 256);
+    const int n_emb = sig_e ? (n_steps * (D / 2) + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_sample_prep, dim3(n_act + n_emb + 1), dim3(256), 0, s, sigmas_dev, sv, n_steps, steps, freqs, sig_e, D, x, sd,
+                       Wa, ba, y, M, A, n_act, n_emb);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // action head: decoder LN -> action_pred -> EDM combine -> (DDIM update) -> (next step's embedding)
 // one wave per action-token row; A <= 16
 // ------------------------------------------------------------------------------------------------
@@ -1171,20 +1240,27 @@ hipError_t mdt_launch_head(const mdt_head_args& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // the folds of ALL decoder blocks of one sampler call are one launch: blockIdx.z picks the block's argument set
 struct mdt_xfold_table { mdt_xfold_args a[8]; };
-// One workgroup = (8 samples, head h, decoder block): both folds as MFMA products with K = hd.  The 32 activation rows are
-// (sample, token) pairs -- 4 rows per sample, rows of absent tokens zero, which also zeroes their rows of the images --
-//   U : transposed form, A = Wq^T fragment (4 dwords per lane from 4 rows of query.weight), B = K rows: the lane ends with 4
+// One workgroup = (8 samples, a group of 4 heads = one 16-row block of the images, decoder block, feature part): both folds as
+// MFMA products with K = hd.  The 32 activation rows are (sample, token) pairs -- 4 rows per sample, rows of absent tokens zero,
+// which also zeroes their rows of the images --
+//   U : transposed form, A = fragment of the packed image of Wq^T (features x head dims), B = K rows: the lane ends with 4
 //       consecutive features of one (sample, token) = one 16-byte slot of the U image
-//   Wf: plain form, A = V rows, B = c_proj.weight^T fragment: the lane ends with the 4 tokens of one (sample, feature) = one
-//       16-byte slot of the Wf image
-// wave w owns the feature tiles w, w + 8, ...  (The first form: one thread per feature, K / V as scalar operands of 1500 FMAs
-// per thread -- a third of the VALU rate, 93 us per sampler call at B = 256.)
+//   Wf: plain form, A = V rows, B = fragment of the packed image of c_proj.weight: the lane ends with the 4 tokens of one
+//       (sample, feature) = one 16-byte slot of the Wf image
+// wave w owns head 4 hg + w % 4 and the feature tiles part, part + P, ... (part = 2 fs + w / 4 of P = 2 FS parts).
+// Round 5: both weight operands are MFMA fragment images, one coalesced 16-byte load per lane and k-block (round 3-4 read query.weight
+// and the transposed c_proj.weight element by element: 24 four-byte loads per lane and feature tile, 63 us per call at B = 256 with
+// the matrix pipe busy for 14 of them, 15 us at B = 1); the next tile's fragments are requested before the current tile's MFMAs; the
+// four heads of a workgroup write whole 256-byte / 1-KiB runs of the images; small batches spread the feature tiles over more
+// workgroups (FS).  Same products in the same order: the images have the bits the earlier kernel wrote.
+// (The first form of all: one thread per feature, K / V as scalar operands of 1500 FMAs per thread, 93 us.)
 template <int TE>
-__global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
+__global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab, int FS) {
     constexpr int SB = 8, K16MAX = 4;     // samples per workgroup; hd <= 64
     const mdt_xfold_args& a = tab.a[blockIdx.z];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = blockIdx.y;
+    const int hg = blockIdx.y / FS, fs = blockIdx.y - hg * FS;
+    const int h = 4 * hg + (wave & 3);
     const int bg = blockIdx.x * SB;       // first sample of the group
     const int HD = a.hd, D = a.D, NPP = 4 * a.H, K16 = D >> 4, KP16 = NPP >> 4, KH = HD >> 4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1204,17 +1280,23 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
             vf[mt][kc] = sel4(live, ldg4(row + D + ko), zero4);
         }
     }
-    for (int nt = wave; nt < K16; nt += 8) {
-        // weight fragments of feature tile nt: element e of k-block kc = weight row h hd + 16 kc + 4 (lane / 16) + e, column 16 nt + lane % 16
-        float wq[K16MAX][4], wo[K16MAX][4];
+    // ---- weight fragments: block (feature tile nt, k-block kb0 + kc) of either image, 1 KiB in lane order ----
+    const int P = 2 * FS, part = 2 * fs + (wave >> 2);
+    const int kb0 = (h * HD) >> 4;
+    f32x4 wq[K16MAX], wo[K16MAX];
+    auto request = [&](int nt, f32x4* q, f32x4* o) {
+        const int ntc = min(nt, K16 - 1);
 #pragma unroll
-        for (int kc = 0; kc < K16MAX; ++kc)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t o = (int64_t)(h * HD + min(kc, KH - 1) * 16 + kq + e) * D + nt * 16 + (lane & 15);
-                wq[kc][e] = a.Wq[o];
-                wo[kc][e] = a.WoT[o];
-            }
+        for (int kc = 0; kc < K16MAX; ++kc) {
+            const int64_t off = (((int64_t)ntc * K16 + kb0 + min(kc, KH - 1)) * 64 + lane) * 4;
+            q[kc] = ldg4(a.WqT_p + off);
+            o[kc] = ldg4(a.Wo_p + off);
+        }
+    };
+    request(part, wq, wo);
+    for (int nt = part; nt < K16; nt += P) {
+        f32x4 wqn[K16MAX], won[K16MAX];
+        request(nt + P, wqn, won);  // (clamped past the end: an L2 hit nobody uses)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4 accU = zero4, accW = zero4;
@@ -1240,16 +1322,18 @@ __global__ __launch_bounds__(512) void k_xattn_fold(mdt_xfold_table tab) {
                     *(f32x4*)(a.Wf + (int64_t)smp * NPP * D + (((int64_t)nt * KP16 + (h >> 2)) * 64 + (lane & 15) + 16 * (h & 3)) * 4) = accW;
             }
         }
+#pragma unroll
+        for (int kc = 0; kc < K16MAX; ++kc) { wq[kc] = wqn[kc]; wo[kc] = won[kc]; }
     }
-    if (threadIdx.x < SB * 4) {
-        const int sb = threadIdx.x >> 2, j = threadIdx.x & 3;
+    if (fs == 0 && threadIdx.x < SB * 16) {   // c[b][h][j] for the group's four heads
+        const int hh = 4 * hg + (threadIdx.x >> 5), sb = (threadIdx.x >> 2) & 7, j = threadIdx.x & 3;
         if (bg + sb < a.B) {
             float acc = 0.f;
             if (j < TE) {
-                const float* kr = a.kv + (int64_t)((bg + sb) * TE + j) * a.ldkv + h * HD;
-                for (int d = 0; d < HD; ++d) acc = fmaf(a.bq[h * HD + d], kr[d], acc);
+                const float* kr = a.kv + (int64_t)((bg + sb) * TE + j) * a.ldkv + hh * HD;
+                for (int d = 0; d < HD; ++d) acc = fmaf(a.bq[hh * HD + d], kr[d], acc);
             }
-            a.c[(int64_t)(bg + sb) * NPP + h * 4 + j] = acc * scale;
+            a.c[(int64_t)(bg + sb) * NPP + hh * 4 + j] = acc * scale;
         }
     }
 }
@@ -1260,7 +1344,8 @@ hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_
     constexpr int SB = 8;
     if (n < 1) return hipErrorInvalidValue;
     const mdt_xfold_args& a = sets[0];
-    if (a.D > 512 || a.D % 128 || a.Te < 1 || a.Te > 4 || (a.H != 4 && a.H != 8) || a.hd % 16 || a.hd > 64 || (a.ldkv & 3))
+    if (a.D > 512 || a.D % 128 || a.Te < 1 || a.Te > 4 || (a.H != 4 && a.H != 8) || a.hd % 16 || a.hd > 64 || (a.ldkv & 3) ||
+        a.H * a.hd != a.D)
         return hipErrorInvalidValue;
     for (int i = 1; i < n; ++i)
         if (sets[i].B != a.B || sets[i].H != a.H || sets[i].hd != a.hd || sets[i].D != a.D || sets[i].Te != a.Te)
@@ -1269,12 +1354,15 @@ hipError_t mdt_launch_xattn_fold_n(const mdt_xfold_args* sets, int n, hipStream_
         mdt_xfold_table tab;
         const int cnt = n - i0 < 8 ? n - i0 : 8;
         for (int i = 0; i < 8; ++i) tab.a[i] = sets[i0 + (i < cnt ? i : 0)];
-        const dim3 grid((a.B + SB - 1) / SB, a.H, cnt);
+        // feature parts: enough workgroups to fill the chip when the batch alone does not (a rollout call: 1 sample group)
+        const int groups = (a.B + SB - 1) / SB, base = groups * (a.H / 4) * cnt;
+        const int FS = std::max(1, std::min((256 + base - 1) / base, (a.D >> 4) / 2));
+        const dim3 grid(groups, (a.H / 4) * FS, cnt);
         switch (a.Te) {
-            case 1: hipLaunchKernelGGL((k_xattn_fold<1>), grid, dim3(512), 0, s, tab); break;
-            case 2: hipLaunchKernelGGL((k_xattn_fold<2>), grid, dim3(512), 0, s, tab); break;
-            case 3: hipLaunchKernelGGL((k_xattn_fold<3>), grid, dim3(512), 0, s, tab); break;
-            default: hipLaunchKernelGGL((k_xattn_fold<4>), grid, dim3(512), 0, s, tab); break;
+            case 1: hipLaunchKernelGGL((k_xattn_fold<1>), grid, dim3(512), 0, s, tab, FS); break;
+            case 2: hipLaunchKernelGGL((k_xattn_fold<2>), grid, dim3(512), 0, s, tab, FS); break;
+            case 3: hipLaunchKernelGGL((k_xattn_fold<3>), grid, dim3(512), 0, s, tab, FS); break;
+            default: hipLaunchKernelGGL((k_xattn_fold<4>), grid, dim3(512), 0, s, tab, FS); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

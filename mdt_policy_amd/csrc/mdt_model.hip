@@ -138,7 +138,7 @@ static View encoder_view(const mdt_model* m) {
     return v;
 }
 
-static const int MAX_STEPS = 64;
+static const int MAX_STEPS = MDT_SCHED_MAX;  // (a host schedule travels in k_sample_prep's kernel arguments)
 
 // Parameter map: called twice (count pass with base == nullptr, then with the allocated arena).
 static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
@@ -242,13 +242,11 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         lin_part(m->kv_all, pre + ".cross_att.key", D, l * 2 * D, true);
         lin_begin(d.xq, D, D, true);
         lin_part(d.xq, pre + ".cross_att.query", D, 0, true);
-        d.xq_raw = b.take((size_t)D * D);
-        add_extra(pre + ".cross_att.query.weight", (int64_t)D * D, SLOT_RAW, d.xq_raw, 0, 0);
+        d.xq_pT = b.take((size_t)D * D);
+        add_extra(pre + ".cross_att.query.weight", (int64_t)D * D, SLOT_PACK_T, d.xq_pT, D, D);
         lin_part(m->kv_all, pre + ".cross_att.value", D, l * 2 * D + D, true);
         lin_begin(d.xproj, D, D, xb);
         lin_part(d.xproj, pre + ".cross_att.c_proj", D, 0, xb);
-        d.xo_T = b.take((size_t)D * D);
-        add_extra(pre + ".cross_att.c_proj.weight", (int64_t)D * D, SLOT_TRANSPOSE, d.xo_T, D, D);
         raw(d.ln3_w, pre + ".ln3.weight", D);
         raw(d.ln3_b, pre + ".ln3.bias", D);
         block_common_b(d, pre);
@@ -478,6 +476,7 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
             }
         }
         if (t->kind == SLOT_TRANSPOSE) HIP_TRY(mdt_launch_transpose(dev_src, t->dst, t->rows, t->K, s));
+        else if (t->kind == SLOT_PACK_T) HIP_TRY(mdt_launch_pack_weight_t(dev_src, t->rows, t->K, t->K, t->dst, 0, t->rows / 16, s));  // image of the transpose
         else HIP_TRY(mdt_launch_pack_weight(dev_src, t->rows, t->K, t->dst, t->n_off, s));
         if (t->kind == SLOT_PACK && t->lin && t->lin->wt)  // training: image of W^T for dX = dY W
             HIP_TRY(mdt_launch_pack_weight_t(dev_src, t->rows, t->K, t->K, t->lin->wt, t->n_off, t->lin->N / 16, s));
@@ -535,6 +534,7 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
             if (t->kind == SLOT_RAW) add(srcs[i], t->dst, MDT_LOAD_RAW, 1, (int)numels[i], 0, 0);
             else if (t->kind == SLOT_PAD_COLS) add(srcs[i], t->dst, MDT_LOAD_PAD_COLS, t->rows, t->K, t->n_off, 0);
             else if (t->kind == SLOT_TRANSPOSE) add(srcs[i], t->dst, MDT_LOAD_TRANSPOSE, t->rows, t->K, 0, 0);
+            else if (t->kind == SLOT_PACK_T) add(srcs[i], t->dst, MDT_LOAD_PACK_T, t->rows, t->K, 0, t->rows / 16);
             else {
                 add(srcs[i], t->dst, MDT_LOAD_PACK, t->rows, t->K, t->n_off, 0);
                 if (t->lin && t->lin->wt) add(srcs[i], t->lin->wt, MDT_LOAD_PACK_T, t->rows, t->K, t->n_off, t->lin->N / 16);
@@ -833,10 +833,11 @@ static int g_xattn_fc_max_batch() {
 
 // sigma_emb: sinusoidal(ln(sigma)/4) -> Linear -> Mish -> Linear for R sigmas (mdtv_transformer.py:105-110,282-288);
 // the second Linear's output rows go to out (leading dimension ldo, row r -> row r*gout) after `act`.
+// emb_done: m->sig_e already holds the R embeddings (the sampler's one-launch preparation wrote them)
 static mdt_status run_sigma_mlp(mdt_model* m, const float* sigma, int64_t sstride, int R, float* out, int64_t ldo,
-                                int gout, int act, hipStream_t s) {
+                                int gout, int act, hipStream_t s, bool emb_done = false) {
     const int D = m->D;
-    LAUNCH(mdt_launch_sigma_emb(sigma, sstride, m->freqs, m->sig_e, R, D, s));
+    if (!emb_done) LAUNCH(mdt_launch_sigma_emb(sigma, sstride, m->freqs, m->sig_e, R, D, s));
     mdt_gemm_args a = gemm_args(m->sig_e, D, m->sig1, m->sig_t, 2 * D, R);
     a.act = MDT_ACT_MISH;
     LAUNCH(mdt_launch_gemm(a, s));
@@ -910,8 +911,7 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
         MDT_TRY(run_self_attn(m, m->enc[l], encoder_view(m), B, Te, false, ModRef(), s));
         MDT_TRY(run_mlp(m, m->enc[l], encoder_view(m), B, Te, ModRef(), s));
     }
-    LAUNCH(mdt_launch_layernorm(m->h_enc, m->enc_ln_w, m->enc_ln_b, m->ctx, (int)(B * Te), D, s));
-    if (ctx_out) HIP_TRY(hipMemcpyAsync(ctx_out, m->ctx, (size_t)B * Te * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    LAUNCH(mdt_launch_layernorm(m->h_enc, m->enc_ln_w, m->enc_ln_b, m->ctx, (int)(B * Te), D, s, ctx_out));  // both copies in one launch
     // cross-attention K|V of all decoder blocks in one GEMM (sigma independent: hoisted out of the step loop)
     {
         mdt_gemm_args a = gemm_args(m->ctx, D, m->kv_all, m->kvx, (int64_t)m->Ld * 2 * D, (int)(B * Te));
@@ -924,7 +924,7 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
             mdt_xfold_args& f = sets[l];
             memset(&f, 0, sizeof f);
             f.kv = m->kvx + (int64_t)l * 2 * D; f.ldkv = (int64_t)m->Ld * 2 * D;
-            f.Wq = m->dec[l].xq_raw; f.bq = m->dec[l].xq.bias; f.WoT = m->dec[l].xo_T;
+            f.WqT_p = m->dec[l].xq_pT; f.bq = m->dec[l].xq.bias; f.Wo_p = m->dec[l].xproj.wp;
             f.U = m->xU + (int64_t)l * m->cap * np * D; f.Wf = m->xW + (int64_t)l * m->cap * np * D;
             f.c = m->xc + (int64_t)l * m->cap * np;
             f.B = (int)B; f.H = m->H; f.hd = m->hd; f.D = D; f.Te = Te;
@@ -939,12 +939,12 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
 //   COND_ADALN: mod (R, Ld*6D) = adaLN_zero Linear(SiLU(c)) of every block, one stacked GEMM
 //   COND_NOISE: cmod (R, 2D)   = [c | ones]
 //   COND_TOKEN: nothing (sigma lives in the context)
-static mdt_status run_modulation(mdt_model* m, const float* sigma, int64_t sstride, int R, hipStream_t s) {
+static mdt_status run_modulation(mdt_model* m, const float* sigma, int64_t sstride, int R, hipStream_t s, bool emb_done = false) {
     const int D = m->D;
     if (m->cond == COND_TOKEN) return MDT_OK;
-    if (m->cond == COND_NOISE) return run_sigma_mlp(m, sigma, sstride, R, m->cmod, 2 * D, 1, MDT_ACT_NONE, s);
+    if (m->cond == COND_NOISE) return run_sigma_mlp(m, sigma, sstride, R, m->cmod, 2 * D, 1, MDT_ACT_NONE, s, emb_done);
     // AdaLNZero applies SiLU to c before its Linear; c itself is used nowhere else
-    MDT_TRY(run_sigma_mlp(m, sigma, sstride, R, m->sig_c, D, 1, MDT_ACT_SILU, s));
+    MDT_TRY(run_sigma_mlp(m, sigma, sstride, R, m->sig_c, D, 1, MDT_ACT_SILU, s, emb_done));
     mdt_gemm_args c = gemm_args(m->sig_c, D, m->mod_all, m->mod, (int64_t)m->Ld * 6 * D, R);
     LAUNCH(mdt_launch_gemm(c, s));
     return MDT_OK;
@@ -1127,15 +1127,24 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
     // whether the schedule arrives in host memory (the reference's CPU default) or on the device (mdtv_agent.py:660-667: no
     // copy, no synchronisation then), so that the eager call, the call with device sigmas and the graph replay of either give
     // the same bits (host libm and the device's expf / logf differ in the last place)
-    if (!sigmas_dev) {
-        HIP_TRY(hipMemcpyAsync(m->sigs, sigmas, (size_t)(n_steps + 1) * sizeof(float), hipMemcpyHostToDevice, s));
-        sigmas_dev = m->sigs;
-    }
-    LAUNCH(mdt_launch_ddim_steps(sigmas_dev, n_steps, m->steps, s));
-    MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));  // one row of conditioning vectors per step
     // ---- cut the batch into sample-aligned slices (multiples of 16 samples = 5 row tiles) on separate streams ----
     int ways = per_step_ctx ? 1 : m->ways;  // the encoder works on whole-batch buffers
     while (ways > 1 && batch / ways < 32) --ways;
+    if (ways == 1) {
+        // ONE launch: per-step scalars, the sigma embeddings of all steps, the first action embedding (k_sample_prep); a host
+        // schedule rides in the kernel arguments (no copy launch in front of it)
+        LAUNCH(mdt_launch_sample_prep(sigmas_dev, sigmas_dev ? nullptr : sigmas, n_steps, m->steps, m->freqs,
+                                      m->cond == COND_TOKEN ? nullptr : m->sig_e, m->D, x_T, m->cfg.sigma_data, m->Wa, m->ba,
+                                      decoder_view(m, 0).y, (int)(batch * m->Ta), m->A, s));
+        MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s, true));  // one row of conditioning vectors per step
+    } else {
+        if (!sigmas_dev) {
+            HIP_TRY(hipMemcpyAsync(m->sigs, sigmas, (size_t)(n_steps + 1) * sizeof(float), hipMemcpyHostToDevice, s));
+            sigmas_dev = m->sigs;
+        }
+        LAUNCH(mdt_launch_ddim_steps(sigmas_dev, n_steps, m->steps, s));
+        MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s));
+    }
     int64_t b0[MAX_WAYS + 1];
     b0[0] = 0;
     for (int w = 0; w < ways; ++w) {
@@ -1153,7 +1162,7 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
         }
     }
     const int64_t xs = (int64_t)m->Ta * m->A;  // floats of x per sample
-    for (int w = 0; w < ways; ++w) {
+    for (int w = 0; ways > 1 && w < ways; ++w) {
         const int64_t nb = b0[w + 1] - b0[w];
         const View V = decoder_view(m, b0[w]);
         LAUNCH(mdt_launch_action_embed(x_T + b0[w] * xs, m->steps + 3, 0, m->cfg.sigma_data, m->Wa, m->ba, V.y,
@@ -1312,7 +1321,7 @@ extern "C" mdt_status mdt_op_attention(const mdt_attn_args* a, void* stream) {
 }
 
 extern "C" mdt_status mdt_op_xattn_fold(const mdt_xfold_args* a, void* stream) {
-    if (!a || !a->kv || !a->Wq || !a->bq || !a->WoT || !a->U || !a->Wf || !a->c)
+    if (!a || !a->kv || !a->WqT_p || !a->bq || !a->Wo_p || !a->U || !a->Wf || !a->c)
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_xattn_fold: null pointer");
     if (a->H * a->hd != a->D || a->Te < 1 || a->Te > 4 || a->D > 512 || a->D % 128 || (a->H != 4 && a->H != 8) || a->hd % 16)
         return fail(MDT_ERR_UNSUPPORTED, "mdt_op_xattn_fold: need 4 or 8 heads of 16 / 32 / 48 / 64, H*hd == D <= 512 a multiple of 128 "

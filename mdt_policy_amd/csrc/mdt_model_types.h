@@ -10,7 +10,7 @@
 // model description
 // ------------------------------------------------------------------------------------------------
 // TRANSPOSE: (rows, K) -> (K, rows);  PAD_COLS: (rows, K) -> (rows, n_off) row-major, columns K.. stay zero
-enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2, SLOT_PAD_COLS = 3 };
+enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2, SLOT_PAD_COLS = 3, SLOT_PACK_T = 4 };  // PACK_T: fragment image of the TRANSPOSE of a (rows, K) matrix
 
 struct Slot {
     std::string name;
@@ -39,8 +39,8 @@ struct EncBlock {
 struct DecBlock : EncBlock {
     float *ln3_w = nullptr, *ln3_b = nullptr;
     Lin xq, xproj;
-    float *xq_raw = nullptr;  // cross_att.query.weight, reference layout (collapsed cross-attention fold)
-    float *xo_T = nullptr;    // cross_att.c_proj.weight transposed
+    float *xq_pT = nullptr;   // fragment image of cross_att.query.weight TRANSPOSED (collapsed cross-attention fold; its other
+                              // weight operand is xproj.wp, the forward image of cross_att.c_proj.weight)
 };
 
 // how sigma conditions the decoder (reference constructor flags use_ada_conditioning / use_noise_encoder)

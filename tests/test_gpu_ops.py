@@ -36,6 +36,15 @@ def pack(lib, W):
     return P
 
 
+def pack_t(lib, W):
+    """Fragment image of W^T through the library's transposed packer (what the model keeps of cross_att.query.weight)."""
+    R, Cc = W.shape
+    Wd = dev(W)
+    P = torch.zeros(R * Cc, device="cuda")
+    lib.check(lib.load().mdt_op_pack_weight_t(Wd.data_ptr(), R, Cc, Cc, P.data_ptr(), 0, R, stream()))
+    return P
+
+
 def expected_pack(W):
     """Fragment-major image: block (nt, kc) = 64 lanes x 4 floats; lane l = n%16 + 16*((k%16)//4), j = k%4."""
     N, K = W.shape
@@ -525,13 +534,15 @@ def test_collapsed_cross_attention(lib, D, H, Te, Ta, bias):
     Wq, bq = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
     Wo, bo = torch.randn(D, D, generator=g) / math.sqrt(D), torch.randn(D, generator=g) * 0.3
     lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
-    t = {k: dev(v) for k, v in dict(y=y, kv=kv, Wq=Wq, bq=bq, WoT=Wo.T, bo=bo, lw=lw, lb=lb).items()}
+    t = {k: dev(v) for k, v in dict(y=y, kv=kv, bq=bq, bo=bo, lw=lw, lb=lb).items()}
+    t["WqT_p"], t["Wo_p"] = pack_t(lib, Wq), pack(lib, Wo)  # the fold reads both weights as MFMA fragment images
+    assert torch.equal(t["WqT_p"], pack(lib, Wq.T.contiguous()))
     NP = 4 * H  # rows of the folded images: every head padded to 4 context tokens
     U = torch.full((B * NP * D,), float("nan"), device="cuda")
     Wf = torch.full((B * NP * D,), float("nan"), device="cuda")
     c = torch.full((B * NP,), float("nan"), device="cuda")
     f = lib.XFoldArgs()
-    f.kv, f.ldkv, f.Wq, f.bq, f.WoT = t["kv"].data_ptr(), kv.shape[1], t["Wq"].data_ptr(), t["bq"].data_ptr(), t["WoT"].data_ptr()
+    f.kv, f.ldkv, f.WqT_p, f.bq, f.Wo_p = t["kv"].data_ptr(), kv.shape[1], t["WqT_p"].data_ptr(), t["bq"].data_ptr(), t["Wo_p"].data_ptr()
     f.U, f.Wf, f.c, f.B, f.H, f.hd, f.D, f.Te = U.data_ptr(), Wf.data_ptr(), c.data_ptr(), B, H, hd, D, Te
     lib.check(lib.load().mdt_op_xattn_fold(C.byref(f), stream()))
     a = lib.XApplyArgs()
@@ -583,12 +594,13 @@ def test_one_sample_per_workgroup_through_attention_projection_and_cross_attenti
     o = (sc.softmax(-1) @ vh).transpose(1, 2).reshape(B, T, D) @ Wo.double().T + (bo.double() if bias else 0)
     want = (y1 + o).reshape(B * T, D).float()
     # device operands
-    t = {k: dev(v) for k, v in dict(kv=kv, Wq=Wq, bq=bq, WoT=Wo.T, bo=bo, lw=lw, lb=lb, b=b, gate=gate, qkv=qkv).items()}
+    t = {k: dev(v) for k, v in dict(kv=kv, bq=bq, bo=bo, lw=lw, lb=lb, b=b, gate=gate, qkv=qkv).items()}
+    t["WqT_p"], t["Wo_p"] = pack_t(lib, Wq), pack(lib, Wo)
     Pd = pack(lib, W)
     NP = 4 * H  # rows of the folded images: every head padded to 4 context tokens
     U, Wf, c = (torch.empty(n, device="cuda") for n in (B * NP * D, B * NP * D, B * NP))
     f = lib.XFoldArgs()
-    f.kv, f.ldkv, f.Wq, f.bq, f.WoT = t["kv"].data_ptr(), 2 * D, t["Wq"].data_ptr(), t["bq"].data_ptr(), t["WoT"].data_ptr()
+    f.kv, f.ldkv, f.WqT_p, f.bq, f.Wo_p = t["kv"].data_ptr(), 2 * D, t["WqT_p"].data_ptr(), t["bq"].data_ptr(), t["Wo_p"].data_ptr()
     f.U, f.Wf, f.c, f.B, f.H, f.hd, f.D, f.Te = U.data_ptr(), Wf.data_ptr(), c.data_ptr(), B, H, hd, D, Te
     lib.check(lib.load().mdt_op_xattn_fold(C.byref(f), stream()))
 
@@ -635,11 +647,12 @@ def test_cross_attention_inside_the_linear_that_follows_it(lib, D, H, Te, Ta, B,
     lw2, lb2 = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
     W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g) * 0.1
     modv = torch.randn(6 * D, generator=g) * 0.5
-    t = {k: dev(v) for k, v in dict(kv=kv, Wq=Wq, bq=bq, WoT=Wo.T, bo=bo, lw3=lw3, lb3=lb3, lw2=lw2, lb2=lb2, b=b, mod=modv).items()}
+    t = {k: dev(v) for k, v in dict(kv=kv, bq=bq, bo=bo, lw3=lw3, lb3=lb3, lw2=lw2, lb2=lb2, b=b, mod=modv).items()}
+    t["WqT_p"], t["Wo_p"] = pack_t(lib, Wq), pack(lib, Wo)
     Pd = pack(lib, W)
     U, Wf, c = (torch.empty(n, device="cuda") for n in (B * NP * D, B * NP * D, B * NP))
     f = lib.XFoldArgs()
-    f.kv, f.ldkv, f.Wq, f.bq, f.WoT = t["kv"].data_ptr(), 2 * D, t["Wq"].data_ptr(), t["bq"].data_ptr(), t["WoT"].data_ptr()
+    f.kv, f.ldkv, f.WqT_p, f.bq, f.Wo_p = t["kv"].data_ptr(), 2 * D, t["WqT_p"].data_ptr(), t["bq"].data_ptr(), t["Wo_p"].data_ptr()
     f.U, f.Wf, f.c, f.B, f.H, f.hd, f.D, f.Te = U.data_ptr(), Wf.data_ptr(), c.data_ptr(), B, H, hd, D, Te
     lib.check(lib.load().mdt_op_xattn_fold(C.byref(f), stream()))
 
