@@ -28,7 +28,8 @@
 
 #define MDT_TILES_TIMING_OWNER  // this translation unit owns the -DMDT_DEBUG_TIMING stamp buffer
 #include "mdt_tiles.h"  // the tile bodies (shared with the persistent decoder kernel, mdt_persist.hip)
-#include "mdt_tall.h"   // the tall LDS-staged GEMM body (round 4)
+#include "mdt_tall.h"
+#include "mdt_ws.h"   // the tall LDS-staged GEMM body (round 4)
 
 // ------------------------------------------------------------------------------------------------
 // weight packing
@@ -479,6 +480,50 @@ static hipError_t launch_gemm_tall(const mdt_gemm_args& a, hipStream_t s) {
     return a.residual ? launch_gemm_tall_r<WM, WN, NT, NS, true, LW>(a, s) : launch_gemm_tall_r<WM, WN, NT, NS, false, LW>(a, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gemm_ws: shallow products over very many rows with the weights held in registers for the workgroup's whole life
+// (body: mdt_ws.h).  Block b runs on XCD b % 8: the `panels` column panels of one row chunk are consecutive blocks of ONE XCD.
+// ------------------------------------------------------------------------------------------------
+template <int K16, int NTW, int NWAVES, int GLU>
+__global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws(mdt_gemm_args a, int tiles, int panels, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+    const int panel = i % panels, chunk = (i / panels) * 8 + xcd;
+    gemm_ws_tile<K16, NTW, NWAVES, GLU>(a, panel, chunk, tiles, lds, zeros, threadIdx.x);
+}
+// Workgroup = 8 waves x 2 column tiles (256-column panels), one per CU.  Measured and dropped (profiles/r05_ws_ab.txt): 4 waves x 2
+// tiles as two independent workgroups per CU (27.6 vs 27.5 ms per head step), 4 waves x 3 tiles for the N = 576 / 192 products
+// (272 VGPRs: qkv 225 -> 215 us against the tall body, c_proj 81.6 -> 81.0 against the row tiles: not worth a shape).
+static int ws_shape(const mdt_gemm_args& a) { return a.N % 256 == 0 ? 8 : 0; }
+bool mdt_gemm_ws_supported(const mdt_gemm_args& a) {
+    const bool mode_ok = a.aux_mode == 0 || ((a.aux_mode == 3 || a.aux_mode == 4) && a.aux != nullptr);
+    return !a.ln && a.a_parts <= 1 && a.batch <= 1 && a.K == 192 && ws_shape(a) != 0 && a.M >= 32 &&
+           (a.lda & 3) == 0 && (a.ldo & 3) == 0 && !a.residual && a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr &&
+           a.act == MDT_ACT_NONE && mode_ok && (int64_t)a.N * a.K < ((int64_t)1 << 30);
+}
+template <int K16, int GLU, int NW, int NTW>
+static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
+    const int panels = a.N / (NW * NTW * 16), ntiles = (a.M + 31) / 32;
+    // one round of one workgroup per CU: 8 x panels x groups blocks
+    const int groups = std::max(1, std::min(256 / (8 * panels), (ntiles + 7) / 8));
+    const int chunks = 8 * groups, tiles = (ntiles + chunks - 1) / chunks;
+    const size_t lds = (size_t)2 * 32 * (K16 * 16 + 4) * sizeof(float);
+    static bool attr_dev[MAX_DEVICES] = {false};
+    bool& done = attr_dev[current_device()];
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_ws<K16, NTW, NW, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL((k_gemm_ws<K16, NTW, NW, GLU>), dim3(chunks * panels), dim3(64 * NW), lds, s, a, tiles, panels, g_zeros);
+    return hipGetLastError();
+}
+static hipError_t launch_gemm_ws(const mdt_gemm_args& a, hipStream_t s) {
+    if (a.aux_mode == 3) return launch_gemm_ws_t<12, 3, 8, 2>(a, s);
+    if (a.aux_mode == 4) return launch_gemm_ws_t<12, 4, 8, 2>(a, s);
+    return launch_gemm_ws_t<12, 0, 8, 2>(a, s);
+}
+
 template <int MTILES, int NTW, int NWAVES, int PRO>
 static hipError_t launch_gemm_t(const mdt_gemm_args& a, int kchunk, hipStream_t s) {
     return a.residual ? launch_gemm_r<MTILES, NTW, NWAVES, PRO, true>(a, kchunk, s)
@@ -688,6 +733,11 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.aux_mode == 3 || a.aux_mode == 4) {  // SwishGLU on the epilogue: own kernels (4 waves; forward: pairs of column tiles per wave)
         if ((a.N & (a.aux_mode == 3 ? 31 : 15)) || a.gin != 1 || a.gout != 1 || a.goff != 0 || a.act != MDT_ACT_NONE)
             return hipErrorInvalidValue;
+        // from 8192 rows on, K = 192: the weight-stationary body (mdt_ws.h) with the same epilogues -- round 5; MDT_HIP_WS=0: the 32-row
+        // tiles (A/B runs).  The masked-image head's two SwishGLU products at B = 1024 (104448 rows).
+        static int ws = -1;
+        if (ws < 0) { const char* e = getenv("MDT_HIP_WS"); ws = e ? atoi(e) : 1; }
+        if (ws && a.M >= 8192 && g_mdt_gemm_force <= 0 && mdt_gemm_ws_supported(a)) return launch_gemm_ws(a, s);
         const int kc = mdt_gemm_kchunk(a.K, 0, 384);
         if (a.aux_mode == 3)
             return (a.N % 256 == 0) ? launch_gemm_glu<2, 4, 4, 3>(a, kc, s) : launch_gemm_glu<2, 2, 4, 3>(a, kc, s);
@@ -761,6 +811,13 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     // products of a B = 1024 training step and the masked-image head's 104 k rows (tools/gemm_train_shapes.py,
     // profiles/r04_gemm_train_shapes.txt: 104448 x 576 x 192 249 -> 213-231 us, 104448 x 192 x 768 290 -> 263-270,
     // 10240 x 384 x 1536 124 -> 105-112, 10240 x 1152 x 384 94 -> 88-92; 10240 x 384 x 384 unchanged, 4096 rows lose)
+    // ... and the K = 192 products among them whose column count is a multiple of 256 on the weight-stationary body (mdt_ws.h);
+    // MDT_HIP_WS=0: A/B runs
+    {
+        static int ws = -1;
+        if (ws < 0) { const char* e = getenv("MDT_HIP_WS"); ws = e ? atoi(e) : 1; }
+        if (ws && a.M >= 8192 && a.aux_mode == 0 && g_mdt_gemm_force <= 0 && mdt_gemm_ws_supported(a)) return launch_gemm_ws(a, s);
+    }
     {
         static int gt = -1;
         if (gt < 0) { const char* e = getenv("MDT_HIP_GEO_TALL"); gt = e ? atoi(e) : 23; }
@@ -779,6 +836,10 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
             if (a.N >= 1024 && gw) geo = gw;
             if (a.N < 1024 && gn) geo = gn;
         }
+    }
+    if (geo == 30) {  // forced: the weight-stationary body (tests pin it against the other bodies)
+        if (mdt_gemm_ws_supported(a)) return launch_gemm_ws(a, s);
+        geo = 0;
     }
     if (geo >= 10 && !mdt_gemm_tall_supported(a)) geo = 0;  // (forced geometry on a product the tall body does not take)
     switch (geo) {

@@ -770,9 +770,9 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
                     const f32x4 pj = *(const f32x4*)(a.aux + ooff[i] + ncol[j]);  // rows clamped above: in bounds
                     const f32x4 gt = *(const f32x4*)(a.aux + ooff[i] + a.N + ncol[j]);
                     f32x4 dg;
-                    dg.x = v.x * pj.x * act_silu_grad(gt.x); dg.y = v.y * pj.y * act_silu_grad(gt.y);
-                    dg.z = v.z * pj.z * act_silu_grad(gt.z); dg.w = v.w * pj.w * act_silu_grad(gt.w);
-                    v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
+                    dg.x = v.x * pj.x * glu_silu_grad(gt.x); dg.y = v.y * pj.y * glu_silu_grad(gt.y);
+                    dg.z = v.z * pj.z * glu_silu_grad(gt.z); dg.w = v.w * pj.w * glu_silu_grad(gt.w);
+                    v.x *= glu_silu(gt.x); v.y *= glu_silu(gt.y); v.z *= glu_silu(gt.z); v.w *= glu_silu(gt.w);
                     if (ok) st4(a.out + ooff[i] + a.N + ncol[j], dg);
                 } else if constexpr (GLU == 3 && NTW % 2 == 0) {
                     // even tile: projected, odd tile: its gate (same lane, same columns): u -> aux (row stride 2 ldo),
@@ -780,7 +780,7 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
                     if (ok) st4(const_cast<float*>(a.aux) + 2 * ooff[i] + ncol[j], v);
                     if ((j & 1) == 0) {
                         const f32x4 gt = acc[i][(j + 1) % NTW] + bias_v[(j + 1) % NTW];
-                        v.x *= act_silu(gt.x); v.y *= act_silu(gt.y); v.z *= act_silu(gt.z); v.w *= act_silu(gt.w);
+                        v.x *= glu_silu(gt.x); v.y *= glu_silu(gt.y); v.z *= glu_silu(gt.z); v.w *= glu_silu(gt.w);
                     } else {
                         continue;  // the gate tile has no column of its own in `out`
                     }

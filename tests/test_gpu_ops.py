@@ -152,6 +152,26 @@ def test_gemm_tall_body_bit_equals_the_row_tile_body(lib, geo, M, N, K):
     assert torch.equal(got, ref), "tall body and row-tile body disagree bitwise"
 
 
+@pytest.mark.parametrize("M,N", [(32, 256), (33, 256), (1000, 512), (8192 + 45, 1536), (70, 768), (2600, 256), (9000, 1024)])
+def test_gemm_weight_stationary_body_bit_equals_the_row_tile_body(lib, M, N):
+    """The weight-stationary body (mdt_ws.h: a wave keeps its 2 x 12 weight fragments in
+    registers and walks 32-row tiles of A through two LDS buffers) multiplies in the same K order as gemm_tile: same BITS for full and ragged last tiles, one tile per
+    workgroup and many, a row count that leaves some workgroups without a tile -- and the right values against float64."""
+    K = 192
+    g = torch.Generator().manual_seed(M + N)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    want = (A.double() @ W.double().T + b.double()).float()
+    try:
+        lib.load().mdt_op_set_gemm_geometry(1)
+        ref = run_gemm(lib, A, W, bias=b)
+        lib.load().mdt_op_set_gemm_geometry(30)
+        got = run_gemm(lib, A, W, bias=b)
+    finally:
+        lib.load().mdt_op_set_gemm_geometry(0)
+    assert_close(got, want, rtol=1e-4, atol=1e-4, what="weight-stationary body")
+    assert torch.equal(got, ref), "weight-stationary body and row-tile body disagree bitwise"
+
+
 @pytest.mark.parametrize("geo", [10, 12, 23])
 def test_gemm_tall_body_epilogues(lib, geo):
     """Every epilogue the tall body carries, against the row-tile body (bitwise) and float64: bias + GELU, per-sample gate +

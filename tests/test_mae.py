@@ -331,7 +331,8 @@ def test_patch_loss_op(B, X, C_, R, P):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,H", [(306, 192, 768), (37, 64, 48), (4100, 192, 768), (64, 128, 128)])
+@pytest.mark.parametrize("M,K,H", [(306, 192, 768), (37, 64, 48), (4100, 192, 768), (64, 128, 128), (8192 + 77, 192, 768),
+                                   (9000, 64, 96)])
 def test_swiglu_on_the_gemm_epilogues(M, K, H):
     """SwishGLU riding on the GEMMs around it: forward on the project product (aux_mode 3: interleaved weight image, u and
     projected * silu(gate) from one launch), backward on mlp.1's input-gradient product (dx_act = SWIGLU), through the fused
@@ -356,3 +357,18 @@ def test_swiglu_on_the_gemm_epilogues(M, K, H):
     for name, got, want in zip(("dx", "dW0", "db0", "dW1", "db1"), (x, w0, b0, w1, b1), r):
         sc = float(want.grad.abs().max())
         assert_close(got.grad.cpu(), want.grad, rtol=2e-3, atol=2e-3 * sc, what=name)
+    if M >= 8192:
+        # from 8192 rows on the K = 192 SwishGLU products run on the weight-stationary body (mdt_ws.h; the last 32-row tile here is
+        # ragged): same MFMA form and K order as the 32-row tiles, so the geometry hook that forces those must give the same bits
+        from mdt_policy_amd import _lib
+        lib = _lib.load()
+        x2, w02, b02, w12, b12 = (t.detach().clone().requires_grad_() for t in (x, w0, b0, w1, b1))
+        lib.mdt_op_set_gemm_geometry(9)
+        try:
+            y2 = ops.HipSwiGLUMLP.apply(x2, w02, b02, w12, b12, ops.PackedWeights())
+            (y2 * wy.cuda()).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            lib.mdt_op_set_gemm_geometry(0)
+        assert torch.equal(y2, y), "weight-stationary SwishGLU forward differs from the 32-row tiles"
+        assert torch.equal(x2.grad, x.grad), "weight-stationary SwishGLU backward (dx) differs from the 32-row tiles"
