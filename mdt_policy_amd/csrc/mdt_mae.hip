@@ -739,41 +739,39 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
     MAE_TS(7)
     __syncthreads();   // everyone is done with q / k / v / dO: the four buffers now take the partial sums
     // waves 0, 1 store their partials (dK -> buffers 0 / 1, dV -> 2 / 3), waves 2, 3 add theirs to them, then everybody adds
-    // the two halves and writes the rows out: ((w0 + w2) + (w1 + w3)), a fixed order
-    float* bK = lds + (wave & 1) * T16 * ST;
-    float* bV = lds + (2 + (wave & 1)) * T16 * ST;
+    // the two halves and writes the rows out: ((w0 + w2) + (w1 + w3)), a fixed order.
+    // The buffers hold the partials TRANSPOSED, [column][key] with row stride KS: an accumulator register quad is four
+    // consecutive KEYS of one column, so a lane moves a quad with ONE 16-byte LDS instruction (round 5; as [key][column] rows it
+    // took four 4-byte ones: 112 stores + 112 loads per lane and pass, most of the 15 k clocks this phase took of a workgroup's 70 k).
+    // (short sequences: a transposed buffer, HD x KS floats, can be larger than a T16 x ST one; the four of them then reach into the
+    //  score-tile area behind, which is free as well by now -- 4 HD KS <= 4 T16 ST + T16 + 64 (T16 + 4) for every HD <= 32)
+    const int KS = T16 + 4, SLOT = max(T16 * ST, HD * KS);
+    float* bK = lds + (wave & 1) * SLOT;
+    float* bV = lds + (2 + (wave & 1)) * SLOT;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if ((wave >> 1) == pass) {
 #pragma unroll
             for (int kt = 0; kt < NTJ; ++kt) {
                 if (kt < n) {
-                    // (the adding pass reads a key tile's 16 values per lane in one batch, then stores: written as one
-                    // read-add-write statement per value, every read waited for the store before it -- the two may alias as far
-                    // as the compiler knows -- and this phase took 15 k clocks of a workgroup's 70 k)
+                    // (the adding pass reads a key tile's quads in one batch, then stores: a read behind a store that may alias
+                    //  it as far as the compiler knows would wait for that store)
                     f32x4 tK[NC], tV[NC];
                     if (pass) {
 #pragma unroll
                         for (int q = 0; q < NC; ++q) {
-                            const int col = min(16 * q + m, HD - 1);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int o = (16 * kt + 4 * g + r) * ST + col;
-                                tK[q][r] = bK[o];
-                                tV[q][r] = bV[o];
-                            }
+                            const int o = min(16 * q + m, HD - 1) * KS + 16 * kt + 4 * g;
+                            tK[q] = *(const f32x4*)(bK + o);
+                            tV[q] = *(const f32x4*)(bV + o);
                         }
                     }
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
                         const int col = 16 * q + m;
                         if (col < HD) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int o = (16 * kt + 4 * g + r) * ST + col;
-                                bK[o] = pass ? tK[q][r] + dK[kt][q][r] : dK[kt][q][r];
-                                bV[o] = pass ? tV[q][r] + dV[kt][q][r] : dV[kt][q][r];
-                            }
+                            const int o = col * KS + 16 * kt + 4 * g;
+                            *(f32x4*)(bK + o) = pass ? tK[q] + dK[kt][q] : dK[kt][q];
+                            *(f32x4*)(bV + o) = pass ? tV[q] + dV[kt][q] : dV[kt][q];
                         }
                     }
                 }
@@ -784,9 +782,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
     MAE_TS(8)
     for (int i = tid; i < T * H4; i += NT) {
         const int t = i / H4, c = i - t * H4;
-        const int o = t * ST + 4 * c;
-        *(f32x4*)(gq + D + (int64_t)t * ldg + 4 * c) = *(const f32x4*)(lds + o) + *(const f32x4*)(lds + T16 * ST + o);
-        *(f32x4*)(gq + 2 * D + (int64_t)t * ldg + 4 * c) = *(const f32x4*)(lds + 2 * T16 * ST + o) + *(const f32x4*)(lds + 3 * T16 * ST + o);
+        f32x4 k4, v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = (4 * c + e) * KS + t;
+            k4[e] = lds[o] + lds[SLOT + o];
+            v4[e] = lds[2 * SLOT + o] + lds[3 * SLOT + o];
+        }
+        *(f32x4*)(gq + D + (int64_t)t * ldg + 4 * c) = k4;
+        *(f32x4*)(gq + 2 * D + (int64_t)t * ldg + 4 * c) = v4;
     }
     MAE_TS(9)
     MAE_WG(1)
