@@ -227,7 +227,8 @@ mdt_status mdt_op_xattn_gemm(const mdt_xapply_args *x, const mdt_gemm_args *g, v
  * (k_attn_xattn): mdt_op_attn_proj's contract (causal self-attention of the sample's T rows -> c_proj + gate + residual,
  * transformer_blocks.py:296-300) followed by mdt_op_xattn_apply's on the same rows (:301-305); the rows between the two
  * sublayers stay in the workgroup's LDS and x->y == proj->out is written once.  8 heads of 48 (K = N = ldo = 384, ldq = 3 K),
- * T = x->Ta <= 16, proj->M = x->B * T; results equal the two launches bit for bit.  The model-level entry points use it
+ * T = x->Ta <= 16, proj->M = x->B * T; results equal the two launches up to the summation order of the self-attention
+ * (this form runs q k^T and P v on the MFMA pipe, one wave per head).  The model-level entry points use it
  * from 1401 rows up to 512 samples (MDT_HIP_ATTN_XATTN_MIN / MDT_HIP_ATTN_XATTN_MAX_B; mdt_op_set_attn_wide_min(0) switches
  * it off together with the tiled form). */
 mdt_status mdt_op_attn_xattn(const mdt_gemm_args *proj, const float *qkv, int64_t ldq, const mdt_xapply_args *x, int32_t hd,

@@ -215,6 +215,23 @@ __device__ __forceinline__ float apply_act_grad1(float v, int act) {
                                  : 1.0f;
 }
 
+// reductions over the four 16-lane rows of a wave, same column (lane % 16), through gfx950's v_permlane16_swap /
+// v_permlane32_swap (VALU, no LDS round trip): every lane ends with the result
+__device__ __forceinline__ float xrow_max(float v) {   // over the four 16-lane rows of the wave (same column m)
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned w = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ float xrow_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned w = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // counter-based dropout masks (training): Philox4x32-10 keyed by the call's 64-bit seed, counter =
 // (element index, site id).  The backward regenerates the mask from the same (seed, site, index), so no mask is

@@ -377,20 +377,7 @@ __global__ __launch_bounds__(256) void k_attn_mid_fwd(const float* __restrict__ 
 // second, v_permlane32_swap the upper half of the first with the lower half of the second; fed the same value twice they
 // return (x0 x0 x2 x2 | x1 x1 x3 x3) and (lo lo | hi hi) -- both partners of the xor-16 / xor-32 exchange in two VALU
 // registers, without the LDS round trip of a ds_bpermute (four of those sat between the score and the P V products).
-__device__ __forceinline__ float xrow_max(float v) {   // over the four 16-lane rows of the wave (same column m)
-    const unsigned u = __float_as_uint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const unsigned w = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
-    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
-}
-__device__ __forceinline__ float xrow_sum(float v) {
-    const unsigned u = __float_as_uint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const unsigned w = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
-    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
-}
+// (xrow_max / xrow_sum live in mdt_device.h: the sampler's per-sample attention uses them too)
 size_t attn_mid_lds_fwd2(int hd, int T) {
     const int T16 = (T + 15) & ~15, hdp = (hd + 15) & ~15;
     return ((size_t)2 * T16 * (hd + 4) + (size_t)hdp * (T16 + 4)) * sizeof(float);

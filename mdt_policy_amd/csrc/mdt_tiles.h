@@ -548,13 +548,13 @@ __device__ __forceinline__ void attn_stage_tile(const mdt_gemm_args& a, const md
 // floats: thread t requests float4 items t, t + 512, ... of it and puts them at the same (row, column) in LDS -- no division,
 // no 64-bit arithmetic per request (the general stage above spends ~1100 integer instructions per thread on its 9 + 28
 // addresses: 9.5 k cycles from entry until the rows are in LDS even on an idle chip, all VALU issue).  Row stride 3 D + 16 =
-// 16 (mod 64) floats: same bank behaviour as above.  Thread = (head, row, quarter of the head dimension).  512 threads.
+// 16 (mod 64) floats.  Wave = head: both attention products on the MFMA pipe (below).  512 threads = 8 heads.
 //   scratch: 16 * (3 D + 16) floats.  `after_loads`: see attn_stage_tile.
 // ------------------------------------------------------------------------------------------------
 template <int HD, int TKC, class F>
 __device__ __forceinline__ void attn_sample_tile(const mdt_attn_pro& ap, float* xa, int stride, int m0, float* scratch, int tid,
                                                  F after_loads) {
-    constexpr int D = 8 * HD, R4 = 3 * D / 4, ST3 = 3 * D + 16, DS = HD / 4;
+    constexpr int D = 8 * HD, R4 = 3 * D / 4, ST3 = 3 * D + 16;
     constexpr int NL = (TKC * R4 + 511) / 512;          // 6 float4 per thread for 10 rows of d = 384, 9 for 16
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int T = ap.T, total = T * R4;
@@ -563,10 +563,6 @@ __device__ __forceinline__ void attn_sample_tile(const mdt_attn_pro& ap, float* 
 #pragma unroll
     for (int u = 0; u < NL; ++u) t[u] = src[min(tid + 512 * u, total - 1)];
     after_loads();
-    const int lp = tid & 3, pr = tid >> 2, r = pr & 15, hl = pr >> 4;   // 128 pairs = 8 heads x 16 rows
-    const bool valid = r < T;
-    const int tq = min(r, T - 1);                        // keys 0 .. tq
-    const int d0 = hl * HD + lp * DS;
     {
         int rr = tid / R4, c = tid - rr * R4;            // item tid + 512 u sits at (row rr, float4 column c)
 #pragma unroll
@@ -580,47 +576,62 @@ __device__ __forceinline__ void attn_sample_tile(const mdt_attn_pro& ap, float* 
 #ifdef MDT_TS_ROWS_LANDED
     MDT_TS(7)
 #endif
-    float q[DS];
+    // ---- wave h = head h, both products on the MFMA pipe (round 5; rounds 3-4: thread = (head, row, quarter of the head
+    //      dimension), ~60 LDS reads and ~250 FMAs per thread with 6 of the 16 row slots idle: 4 k of the kernel's 42 k clocks).
+    //      Scores with TRANSPOSED operand roles: A = the head's key rows, B = its query rows -> the lane ends with
+    //      S[query lane % 16][keys 4 g .. 4 g + 3], g = lane / 16; the masked softmax of a query runs over the lane's four values
+    //      and the four 16-lane rows of the wave (xrow_max / xrow_sum: v_permlane swaps, no LDS); the probabilities, still in
+    //      those registers, are the B operand of O^T = V^T P^T (k = key 4 g + e), whose A operand is read from the v rows
+    //      as scalars; the lane ends with 4 consecutive features of its query's output: one 16-byte store into xa.
+    //      Rows past T are never read (indices clamped to T - 1: a masked key's probability is an exact 0, times a finite v). ----
+    constexpr int KH = HD / 16;
+    const int lane = tid & 63, h = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int rc = min(m, T - 1);
+    f32x4 sc = zero4;
+    {
+        const float* qp = scratch + rc * ST3 + h * HD + 4 * g;
+        const float* kp = qp + D;
+        f32x4 kf[KH], qf[KH];
 #pragma unroll
-    for (int d = 0; d < DS; d += 4) {
-        const f32x4 x = *(const f32x4*)(scratch + r * ST3 + d0 + d);
-        q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w;
+        for (int kc = 0; kc < KH; ++kc) { kf[kc] = *(const f32x4*)(kp + 16 * kc); qf[kc] = *(const f32x4*)(qp + 16 * kc); }
+#pragma unroll
+        for (int kc = 0; kc < KH; ++kc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kc][e], qf[kc][e], sc, 0, 0, 0);
     }
-    float sc[TKC];
-    float mx = -INFINITY;
+    // V^T fragments (scalars: feature 16 nt + m of key row 4 g + e) are requested before the softmax arithmetic
+    float vt[KH][4];
 #pragma unroll
-    for (int j = 0; j < TKC; ++j) {
-        const float* kp = scratch + min(j, tq) * ST3 + D + d0;   // clamped: masked keys re-read a visible one
-        float dot = 0.f;
+    for (int e = 0; e < 4; ++e) {
+        const float* vp = scratch + min(4 * g + e, T - 1) * ST3 + 2 * D + h * HD + m;
 #pragma unroll
-        for (int d = 0; d < DS; d += 4) {
-            const f32x4 x = *(const f32x4*)(kp + d);
-            dot = fmaf(q[d], x.x, dot); dot = fmaf(q[d + 1], x.y, dot); dot = fmaf(q[d + 2], x.z, dot); dot = fmaf(q[d + 3], x.w, dot);
+        for (int nt = 0; nt < KH; ++nt) vt[nt][e] = vp[16 * nt];
+    }
+    f32x4 pr;
+    {
+        float mx = -INFINITY;
+        bool vis[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vis[e] = 4 * g + e <= rc;                    // causal inside the sample; rc < T
+            sc[e] = vis[e] ? sc[e] * ap.scale : -INFINITY;
+            mx = fmaxf(mx, sc[e]);
         }
-        dot = quad_sum(dot);                             // the four quarters of the head dimension
-        sc[j] = j <= tq ? dot * ap.scale : -INFINITY;
-        mx = fmaxf(mx, sc[j]);
+        mx = xrow_max(mx);                               // key 0 is always visible: finite
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pr[e] = vis[e] ? expf(sc[e] - mx) : 0.f; sum += pr[e]; }
+        const float inv = 1.0f / xrow_sum(sum);
+        pr = pr * inv;
     }
-    float sum = 0.f;
+    const bool valid = m < T;
 #pragma unroll
-    for (int j = 0; j < TKC; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }   // key 0 is always visible: mx is finite
-    const float inv = 1.0f / sum;
-    float o[DS];
+    for (int nt = 0; nt < KH; ++nt) {
+        f32x4 o = zero4;
 #pragma unroll
-    for (int d = 0; d < DS; ++d) o[d] = 0.f;
-#pragma unroll
-    for (int j = 0; j < TKC; ++j) {
-        const float pj = sc[j] * inv;
-        const float* vp = scratch + min(j, tq) * ST3 + 2 * D + d0;
-#pragma unroll
-        for (int d = 0; d < DS; d += 4) {
-            const f32x4 x = *(const f32x4*)(vp + d);
-            o[d] = fmaf(pj, x.x, o[d]); o[d + 1] = fmaf(pj, x.y, o[d + 1]); o[d + 2] = fmaf(pj, x.z, o[d + 2]); o[d + 3] = fmaf(pj, x.w, o[d + 3]);
-        }
+        for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[nt][e], pr[e], o, 0, 0, 0);
+        *(f32x4*)(xa + m * stride + h * HD + 16 * nt + 4 * g) = valid ? o : zero4;
     }
-#pragma unroll
-    for (int d = 0; d < DS; d += 4)
-        *(f32x4*)(xa + r * stride + d0 + d) = valid ? (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]} : zero4;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -645,7 +645,9 @@ def test_one_sample_per_workgroup_through_attention_projection_and_cross_attenti
     lib.check(lib.load().mdt_op_xattn_apply(C.byref(x2), stream()))
     torch.cuda.synchronize()
     assert_close(one.cpu(), want, rtol=2e-4, atol=2e-4, what="attention + projection + cross-attention, one launch")
-    assert torch.equal(one, two), "the one-launch form differs from attn_proj + xattn_apply"
+    # (round 5: the one-launch form runs the self-attention's two products on the MFMA pipe, the two-launch form in vector FMAs:
+    #  same arithmetic, another summation order)
+    assert_close(one.cpu(), two.cpu(), rtol=2e-5, atol=2e-5, what="the one-launch form vs attn_proj + xattn_apply")
     # what it refuses: other head dimensions, a cross-attention on other rows
     x.y = two.data_ptr()
     assert lib.load().mdt_op_attn_xattn(C.byref(a), t["qkv"].data_ptr(), 3 * D, C.byref(x), hd, T, stream()) == 2
