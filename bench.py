@@ -134,11 +134,19 @@ def time_dominant_kernel_in_chain(step, device):
         lib.mdt_op_trace_mlp(0)
     buf = (C.c_float * 4096)()
     n = lib.mdt_op_trace_mlp_read(buf, 4096)
-    us = sorted(buf[i] for i in range(n))
-    if not us:
+    raw = [buf[i] for i in range(n)]
+    if not raw:
         return None
+    ebuf = (C.c_float * 4096)()
+    ne = lib.mdt_op_trace_mlp_read_empty(ebuf, 4096)
+    empty = sorted(ebuf[i] for i in range(ne))
+    # an event pair on the stream costs something by itself (the record packets and the boundary between them): behind every
+    # traced launch the hook brackets NOTHING with a second pair; their median is subtracted from every launch bracket
+    e_med = empty[len(empty) // 2] if empty else 0.0
+    us = sorted(max(0.0, v - e_med) for v in raw)
     return {"launches": n, "avg_us": round(sum(us) / n, 2), "median_us": round(us[n // 2], 2), "min_us": round(us[0], 2),
-            "max_us": round(us[-1], 2)}
+            "max_us": round(us[-1], 2), "avg_us_bracket": round(sum(raw) / n, 2), "empty_bracket_us": round(e_med, 2),
+            "what": "launch bracket minus the median EMPTY bracket recorded behind each launch (mdt_op_trace_mlp_read_empty)"}
 
 
 def other_configs(device):
@@ -577,7 +585,9 @@ def main():
                 dk.update({"avg_us": chain["avg_us"], "achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                            "in_chain": chain,
                            "what": f"mean over the {chain['launches']} launches of ONE sampler call, each between its own pair of HIP "
-                                   "events on the launch stream (mdt_op_trace_mlp): the kernel as a kernel trace of the call sees it"})
+                                   "events on the launch stream (mdt_op_trace_mlp), minus the cost of an empty event bracket measured "
+                                   f"in the same call ({chain['empty_bracket_us']} us; the raw brackets average {chain['avg_us_bracket']} us): "
+                                   "the kernel as a kernel trace of the call sees it"})
             else:
                 dk.update({k: dk["alone"][k] for k in ("avg_us", "achieved", "frac")})
             res["roofline"]["dominant_kernel"] = dk
@@ -591,6 +601,16 @@ def main():
                 with open(os.path.join(here, cands[-1])) as f:
                     j = json.load(f)
                 res["roofline"]["traffic"] = j["hbm_side_bytes_per_launch"]
+                # the EXECUTED share of the matrix pipe, beside the algorithmic fraction above (which credits the folded cross-
+                # attention projections and the per-step conditioning at the reference's FLOP count): whole-run MFMA-busy of the
+                # same committed PMC pass (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / kernel time at 2.4 GHz)
+                if "whole_run_mfma_busy" in j:
+                    res["roofline"]["mfma_busy"] = j["whole_run_mfma_busy"]
+                    res["roofline"]["mfma_busy_scope"] = (
+                        f"NOT measured by this run: whole-run MFMA-busy fraction of the committed PMC pass profiles/{cands[-1]} "
+                        "(executed MFMA issue slots / peak slots at 2.4 GHz over all kernels of the bench command); `frac` above counts "
+                        "the reference's algorithmic FLOPs, of which the folded cross-attention projections and the per-sample sigma / adaLN "
+                        "products are not executed")
                 res["roofline"]["traffic_scope"] = (
                     f"NOT measured by this run: committed PMC pass profiles/{cands[-1]} (commit {j.get('commit', 'see its header')}), HBM-side "
                     "bytes per launch of the dominant kernel (TCC_EA0 read x128 B + write x64 B); true algorithmic bytes "

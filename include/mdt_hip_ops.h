@@ -116,6 +116,10 @@ void mdt_op_set_mlp_fuse_min(int32_t rows);
  * for use under stream capture. */
 void mdt_op_trace_mlp(int32_t enable);
 int32_t mdt_op_trace_mlp_read(float *us, int32_t cap);
+/* Behind every traced launch the hook also brackets NOTHING with a second pair of events: mdt_op_trace_mlp_read_empty returns
+ * those empty brackets (microseconds; same order and count as the last mdt_op_trace_mlp_read) -- what the bracket itself costs
+ * on the stream.  Launch bracket minus empty bracket = the kernel as a kernel trace's row reports it. */
+int32_t mdt_op_trace_mlp_read_empty(float *us, int32_t cap);
 
 /* Tuning / test hook: wave schedule inside mdt_op_mlp's kernel.  Low byte = number of k-steps the second wave of every
  * SIMD starts behind the first (0 = lockstep with a workgroup barrier between the two products), | 256 = MFMA loops at

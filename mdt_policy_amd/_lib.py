@@ -177,6 +177,7 @@ SYMBOLS = [
     ("mdt_persist_built", _I32, []),
     ("mdt_op_trace_mlp", None, [_I32]),
     ("mdt_op_trace_mlp_read", _I32, [_VP, _I32]),
+    ("mdt_op_trace_mlp_read_empty", _I32, [_VP, _I32]),
     ("mdt_op_set_persist", None, [_I32]),
     ("mdt_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     ("mdt_flops_per_chunk", C.c_double, [_VP, _I32]),

@@ -770,17 +770,31 @@ extern "C" void mdt_op_set_mlp_fuse_min(int32_t rows) { g_mlp_fuse_override = ro
 // kernel alone do not give (bench.py).  mdt_op_trace_mlp_read synchronises the events, returns the
 // durations in microseconds (at most `cap`) and releases them.
 static bool g_trace_mlp = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_trace_mlp_events;
+struct TraceEv { hipEvent_t e0, e1, e2; };   // e0 .. e1 bracket the launch; e1 .. e2 bracket NOTHING (the cost of a bracket itself)
+static std::vector<TraceEv> g_trace_mlp_events;
+static std::vector<float> g_trace_mlp_empty;
 extern "C" void mdt_op_trace_mlp(int32_t enable) { g_trace_mlp = enable != 0; }
 extern "C" int32_t mdt_op_trace_mlp_read(float* us, int32_t cap) {
     int32_t n = 0;
+    g_trace_mlp_empty.clear();
     for (auto& ev : g_trace_mlp_events) {
-        float ms = 0.f;
-        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess && us && n < cap)
+        float ms = 0.f, ms0 = 0.f;
+        if (hipEventSynchronize(ev.e2) == hipSuccess && hipEventElapsedTime(&ms, ev.e0, ev.e1) == hipSuccess &&
+            hipEventElapsedTime(&ms0, ev.e1, ev.e2) == hipSuccess && us && n < cap) {
             us[n++] = ms * 1e3f;
-        (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+            g_trace_mlp_empty.push_back(ms0 * 1e3f);
+        }
+        (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2);
     }
     g_trace_mlp_events.clear();
+    return n;
+}
+// the EMPTY brackets recorded behind each traced launch (same order, same count as the last mdt_op_trace_mlp_read): what a pair
+// of events costs on the stream with nothing in between -- subtracted, the bracketed time is the kernel's own (a kernel trace's row)
+extern "C" int32_t mdt_op_trace_mlp_read_empty(float* us, int32_t cap) {
+    int32_t n = 0;
+    for (float v : g_trace_mlp_empty)
+        if (us && n < cap) us[n++] = v;
     return n;
 }
 
@@ -806,12 +820,13 @@ static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_
         p.ldo = D;
         const int64_t stride = (int64_t)M * D;
         if (g_trace_mlp) {  // measurement hook (mdt_op_trace_mlp): this launch between its own pair of HIP events, inside the chain
-            hipEvent_t e0, e1;
-            HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, s));
+            TraceEv ev;
+            HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1)); HIP_TRY(hipEventCreate(&ev.e2));
+            HIP_TRY(hipEventRecord(ev.e0, s));
             LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
-            HIP_TRY(hipEventRecord(e1, s));
-            g_trace_mlp_events.emplace_back(e0, e1);
+            HIP_TRY(hipEventRecord(ev.e1, s));
+            HIP_TRY(hipEventRecord(ev.e2, s));
+            g_trace_mlp_events.push_back(ev);
         } else
         LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
         out->base = V.hid; out->parts = mdt_mlp_slices(D); out->stride = stride;

@@ -62,6 +62,8 @@ write("mae_kernel_stats.txt",
 # the dominant kernel's HBM-side traffic per launch, for bench.py's roofline.traffic (PMC counters cannot be read from inside
 # the bench process): the fused MLP launch's row of the PMC table above
 import json
+import re
+whole = re.search(r"whole run: MFMA busy ([0-9.]+)", read("bench_pmc.txt"))
 for l in read("bench_pmc.txt").splitlines():
     if l.startswith("k_mlp<"):
         f = [x.strip() for x in l.split("|")]
@@ -74,6 +76,7 @@ for l in read("bench_pmc.txt").splitlines():
                       f"itself (own pass, tools/gpu_final.sh; table profiles/{pre}bench_pmc.txt), per launch, {f[2]} dispatches",
             "read_bytes": int(rd * 1e6), "write_bytes": int(wr * 1e6), "hbm_side_bytes_per_launch": int((rd + wr) * 1e6),
             "l2_hit": float(f[8]), "mfma_busy_frac_at_2.4GHz": float(f[5]), "avg_us_under_pmc": float(f[3]),
+            "whole_run_mfma_busy": float(whole.group(1)) if whole else None,
             "units": "guide MI355X_MICROARCH.md 'HBM': EA read requests are 128-B requests on gfx950 (FETCH_SIZE = RDREQ x 64 B reports "
                      "half) -> x128 B; write requests x64 B (calibrated in round 1 on a GEMM whose output size is exact)",
             "algorithmic_bytes_per_launch": 4 * (M * D + 2 * N * D + M * D),
