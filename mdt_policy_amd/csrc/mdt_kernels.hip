@@ -841,13 +841,11 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
         if (mdt_gemm_ws_supported(a)) return launch_gemm_ws(a, s);
         geo = 0;
     }
-    if (geo >= 10 && !mdt_gemm_tall_supported(a)) geo = 0;  // (forced geometry on a product the tall body does not take)
+    if (geo >= 10 && (geo != 23 || !mdt_gemm_tall_supported(a))) geo = 0;  // (forced geometry on a product the tall body does not take)
     switch (geo) {
-        // the tall body (mdt_tall.h): 128-row tiles, operands by LDS-DMA
-        case 10: return launch_gemm_tall<2, 2, 4, 2>(a, s);  // 4 waves 128 x 128, 2 stages (64 KiB: two workgroups per CU)
-        case 12: return launch_gemm_tall<2, 2, 2, 2>(a, s);  // 4 waves 128 x 64,  2 stages (48 KiB: three per CU)
-        case 16: return launch_gemm_tall<2, 2, 3, 2>(a, s);  // 4 waves 128 x 96,  2 stages (56 KiB: two per CU)
-        // ... with ONE loader wave issuing every DMA request of the workgroup
+        // the tall body (mdt_tall.h): 128-row tiles, operands by LDS-DMA, ONE loader wave issuing every DMA request of the workgroup.
+        // (Round 4 also carried 128 x 128 / 128 x 64 / 128 x 96 tiles without the loader wave -- geometries 10 / 12 / 16 -- which no
+        //  dispatcher rule reached after tools/gemm_train_shapes.py had measured them: pruned in round 5.)
         case 23: return launch_gemm_tall<2, 2, 2, 3, 1>(a, s);  // 4 + 1 waves 128 x 64,  3 stages (72 KiB: two per CU)
         case 1: return launch_gemm_pro<2, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
         case 2:

@@ -127,7 +127,7 @@ def test_gemm_every_geometry(lib, geo, M, N, K, ln):
     assert_close(heur, ref, rtol=1e-5, atol=1e-5, what="heuristic choice vs tiled")
 
 
-TALL_GEOS = [10, 12, 16, 23]
+TALL_GEOS = [23]
 
 
 @pytest.mark.parametrize("geo", TALL_GEOS)
@@ -172,7 +172,7 @@ def test_gemm_weight_stationary_body_bit_equals_the_row_tile_body(lib, M, N):
     assert torch.equal(got, ref), "weight-stationary body and row-tile body disagree bitwise"
 
 
-@pytest.mark.parametrize("geo", [10, 12, 23])
+@pytest.mark.parametrize("geo", [23])
 def test_gemm_tall_body_epilogues(lib, geo):
     """Every epilogue the tall body carries, against the row-tile body (bitwise) and float64: bias + GELU, per-sample gate +
     residual, token-row remap + row vector, and the two training hooks (aux_mode 1: pre-activation kept; 2: act'(aux))."""

@@ -1,5 +1,5 @@
 """Per-workgroup phase timing of the tall GEMM body (needs the -DMDT_DEBUG_TIMING build: MDT_HIP_LIB=.../libmdt_hip_dbg.so).
-usage: GEOS=10,12,16 python tools/tall_phases.py [M N K]"""
+usage: GEOS=23 python tools/tall_phases.py [M N K]   (round 5 pruned geometries 10 / 12 / 16)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,7 +15,7 @@ A = torch.randn(M, K, generator=g).to(dev); out = torch.empty(M, N, device=dev)
 a = _lib.GemmArgs(); a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = A.data_ptr(), K, P.data_ptr(), out.data_ptr(), N, M, N, K
 a.shift_off = a.scale_off = a.gate_off = -1; a.rows_per_sample = 1; a.gin = a.gout = 1
 buf = torch.zeros(16384 * 8, dtype=torch.int64, device=dev)
-for geo in [int(x) for x in os.environ.get("GEOS", "10,12,16").split(",")]:
+for geo in [int(x) for x in os.environ.get("GEOS", "23").split(",")]:
     lib.mdt_op_set_gemm_geometry(geo)
     for _ in range(3): _lib.check(lib.mdt_op_gemm(C.byref(a), s))
     torch.cuda.synchronize(); buf.zero_(); torch.cuda.synchronize()
