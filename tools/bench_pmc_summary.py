@@ -12,7 +12,7 @@ num = collections.defaultdict(lambda: collections.defaultdict(int))
 dur = collections.defaultdict(float)                                   # kernel -> summed duration (s), pass 1 only
 for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if name.startswith("at::") or "rocclr" in name or name.startswith("k_pack") or "elementwise" in name:
             name = "(other)"
         k = (name, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))  # rocprofv3's Grid_Size / Workgroup_Size are the products over x, y, z

@@ -24,4 +24,6 @@ echo "== MGF head"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/mae -o mae -- python $R/tools/mae_bench.py 1024 > $OUT/mae_run.txt 2> $OUT/mae.err )
 DB=$(find $OUT/mae -name "*.db" | head -1); python tools/prof_summary.py $DB > $OUT/mae_kernel_stats.txt
 timeout 200 python tools/mae_bench.py 128 1024 2>&1 | grep "B=" | tee $OUT/mae_bench.txt
+echo "== PMC passes of the training step and the masked-image head (tools/gpu_train_pmc.sh)"
+bash tools/gpu_train_pmc.sh $TAG/trainpmc > $OUT/trainpmc.log 2>&1; tail -2 $OUT/trainpmc/train_pmc.txt | cut -c1-200; tail -1 $OUT/trainpmc/mae_pmc.txt | cut -c1-200
 find $OUT -type f -size +20M -delete

@@ -59,6 +59,15 @@ mae = read("mae_kernel_stats.txt").splitlines(True)
 write("mae_kernel_stats.txt",
       head + "masked generative foresight head: rocprofv3 --kernel-trace --stats of 'python tools/mae_bench.py 1024' (forward + "
       "backward, B = 1024), MI355X\n# without the profiler (same box):\n" + read("mae_bench.txt") + "".join(mae[:34]))
+# PMC passes of the training step and of the masked-image head (tools/gpu_train_pmc.sh: MFMA-busy | HBM-side requests + L2 hit)
+for name, what in (("train", "MDT_TRAIN_BENCH_MODES=train python tools/train_bench.py 1024' (denoiser training step, B = 1024, train mode, torch fused AdamW"),
+                   ("mae", "python tools/mae_bench.py 1024' (masked-image head, forward + backward, B = 1024: 104448 decoder rows")):
+    fn = os.path.join("trainpmc", f"{name}_pmc.txt")
+    if os.path.exists(os.path.join(src, fn)):
+        write(f"{'train_step' if name == 'train' else 'mae'}_pmc.txt",
+              head + f"rocprofv3 --pmc over '{what}), two separate passes with kernel-trace only (tools/gpu_train_pmc.sh):\n"
+              "# SQ_VALU_MFMA_BUSY_CYCLES | TCC_EA0_RDREQ / WRREQ + TCC_HIT / MISS; HBM-side MB = RDREQ x 128 B / WRREQ x 64 B per launch "
+              "(MI355X_MICROARCH.md, gfx950 corrections).  Reading and algorithmic bytes: DESIGN.md section 5e.\n" + read(fn))
 # the dominant kernel's HBM-side traffic per launch, for bench.py's roofline.traffic (PMC counters cannot be read from inside
 # the bench process): the fused MLP launch's row of the PMC table above
 import json
