@@ -494,7 +494,15 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws(mdt_gemm_args a, int ti
 // Workgroup = 8 waves x 2 column tiles (256-column panels), one per CU.  Measured and dropped (profiles/r05_ws_ab.txt): 4 waves x 2
 // tiles as two independent workgroups per CU (27.6 vs 27.5 ms per head step), 4 waves x 3 tiles for the N = 576 / 192 products
 // (272 VGPRs: qkv 225 -> 215 us against the tall body, c_proj 81.6 -> 81.0 against the row tiles: not worth a shape).
-static int ws_shape(const mdt_gemm_args& a) { return a.N % 256 == 0 ? 8 : 0; }
+static int ws_shape(const mdt_gemm_args& a) {
+    static int w12 = -1;  // MDT_HIP_WS_WAVES=8: the 8-wave shape everywhere (A/B runs)
+    if (w12 < 0) { const char* e = getenv("MDT_HIP_WS_WAVES"); w12 = e && atoi(e) == 8 ? 0 : 1; }
+    // 384-column panels, three waves per SIMD, 4 / 2 panels x 64 / 128 row chunks = 256 workgroups: the per-tile epilogue + barrier is
+    // amortised over 18.4 k instead of 12.3 k clocks of MFMA issue and all 256 CUs work (SwishGLU forward 601 -> 544 us, plain 272 -> 248).
+    // Not for the SwishGLU backward epilogue: at 168 VGPRs its u operands cannot be requested a tile ahead (348 -> 448 us)
+    if (w12 && a.N % 384 == 0 && a.aux_mode != 4) return 12;
+    return a.N % 256 == 0 ? 8 : 0;
+}
 bool mdt_gemm_ws_supported(const mdt_gemm_args& a) {
     const bool mode_ok = a.aux_mode == 0 || ((a.aux_mode == 3 || a.aux_mode == 4) && a.aux != nullptr);
     return !a.ln && a.a_parts <= 1 && a.batch <= 1 && a.K == 192 && ws_shape(a) != 0 && a.M >= 32 &&
@@ -519,6 +527,7 @@ static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
     return hipGetLastError();
 }
 static hipError_t launch_gemm_ws(const mdt_gemm_args& a, hipStream_t s) {
+    if (ws_shape(a) == 12) return a.aux_mode == 3 ? launch_gemm_ws_t<12, 3, 12, 2>(a, s) : launch_gemm_ws_t<12, 0, 12, 2>(a, s);
     if (a.aux_mode == 3) return launch_gemm_ws_t<12, 3, 8, 2>(a, s);
     if (a.aux_mode == 4) return launch_gemm_ws_t<12, 4, 8, 2>(a, s);
     return launch_gemm_ws_t<12, 0, 8, 2>(a, s);

@@ -14,6 +14,8 @@
 // barrier per tile), and tile t's epilogue stores drain under tile t + 1's MFMAs.  Per MFMA: 16 bytes of A through LDS, nothing
 // else.  (The k-steps are pinned like gemm_tile's, and the SwishGLU epilogues use the hardware exp2 / reciprocal: 688 -> 601 us forward,
 // 479 -> 348 us backward per block of the head at B = 1024, 28.65 -> 27.5 ms per head step; profiles/r05_ws_ab.txt.)
+// Shapes: 12 waves (384-column panels: three waves per SIMD, 256 workgroups) where N allows and the epilogue has no prefetched operands,
+// else 8 waves (256-column panels, 240 workgroups).
 // Grid = column panels x row chunks, sized to one round of one workgroup per CU; the panels of one row chunk run on the
 // SAME XCD (block b -> XCD b % 8), so an A tile comes from HBM once and from that XCD's L2 for the other panels.
 //
@@ -102,8 +104,11 @@ __device__ __forceinline__ void gemm_ws_tile(const mdt_gemm_args& a, int panel, 
             okr[i] = mr < a.M;
             oo[i] = (int64_t)min(mr, a.M - 1) * a.ldo;
         }
-        f32x4 pj[GLU == 4 ? 2 : 1][GLU == 4 ? NTW : 1], gt[GLU == 4 ? 2 : 1][GLU == 4 ? NTW : 1];
-        if constexpr (GLU == 4) {
+        // (a twelve-wave instantiation would have to do without: 168 VGPRs have no room for the prefetch -- measured 448 us against 348,
+        //  so the dispatcher keeps the backward product on the 8-wave shape)
+        constexpr bool AUX_EARLY = GLU == 4 && NWAVES < 12;
+        f32x4 pj[AUX_EARLY ? 2 : 1][AUX_EARLY ? NTW : 1], gt[AUX_EARLY ? 2 : 1][AUX_EARLY ? NTW : 1];
+        if constexpr (AUX_EARLY) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -169,7 +174,9 @@ __device__ __forceinline__ void gemm_ws_tile(const mdt_gemm_args& a, int panel, 
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     f32x4 v = acc[i][j] + bias_v[j];
-                    const f32x4 g = gt[i][j], pv = pj[i][j];
+                    f32x4 g, pv;
+                    if constexpr (AUX_EARLY) { g = gt[i][j]; pv = pj[i][j]; }
+                    else { pv = ldg4(a.aux + oo[i] + ncol[j]); g = ldg4(a.aux + oo[i] + a.N + ncol[j]); }
                     f32x4 dg;
                     dg.x = v.x * pv.x * glu_silu_grad(g.x); dg.y = v.y * pv.y * glu_silu_grad(g.y);
                     dg.z = v.z * pv.z * glu_silu_grad(g.z); dg.w = v.w * pv.w * glu_silu_grad(g.w);
