@@ -143,11 +143,12 @@ __device__ __forceinline__ void mma_scores(const float* a, const float* b, float
 // The reduction runs over T16 = ceil16(T) indices: S is zero there (rows AND columns) and the rows of x are zero padded.
 // The W fragment of a 16-index chunk is read once and feeds NC independent accumulator chains; the next chunk's fragments
 // are requested before the current chunk's MFMAs issue.  dst: LDS (stride HD + 4) or global (stride ldd).
-template <int HD, bool TRANS>
+// NFIX > 0: the number of 16-index chunks is that compile-time constant (the chunk loop unrolls)
+template <int HD, bool TRANS, int NFIX = 0>
 __device__ __forceinline__ void mma_rows_tile(const float* S, int ss, const float* x, float* dst, int64_t ldd, int T, int ti,
                                               int lane) {
     constexpr int ST = HD + 4, NC = (HD + 15) / 16;
-    const int n = (T + 15) >> 4, m = lane & 15, g = lane >> 4;
+    const int n = NFIX > 0 ? NFIX : (T + 15) >> 4, m = lane & 15, g = lane >> 4;
     f32x4 acc[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -164,6 +165,7 @@ __device__ __forceinline__ void mma_rows_tile(const float* S, int ss, const floa
     f32x4 w = load_w(0), xv[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) xv[q] = load_x(0, q);
+#pragma unroll
     for (int c = 0; c < n; ++c) {
         const int cn = min(c + 1, n - 1);
         const f32x4 wn = load_w(cn);
@@ -630,14 +632,18 @@ __device__ __forceinline__ void mma_acc_trans_reg(const f32x4 (&w)[NTJ], const f
 // accumulators as they are (mma_acc_trans_reg) and accumulate in registers (T16 x hd each) across the wave's tiles.  One workgroup barrier after the loads, none inside; the four waves' dK / dV partials then meet in the
 // (now free) q / k / v / dO buffers in a fixed order.  80 KB of LDS at T = 102, hd = 24 (the first form: 115 KB, five
 // barrier-separated phases): two workgroups per CU, one loading or reducing while the other multiplies.
-template <int HD>
+// N = key (and query) tiles of 16, a compile-time count like the forward's (round 5): with a run-time count every key tile's MFMA
+// chain sat behind its own branch and waited out its LDS reads and its MFMA latency alone (the ISA: `s_cbranch_vccnz` + `lgkmcnt(0)`
+// per key tile in the score rows, the softmax and the two transposed products); as straight-line code the N chains interleave.
+template <int HD, int N>
 __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ fwd_out,
                                                        int64_t ldf, const float* __restrict__ d_out, int64_t ldd,
                                                        float* __restrict__ d_qkv, int64_t ldg, int H, int T, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NT = 256, NW = NT / 64, ST = HD + 4, NTJ = TMAX / 16, NC = (HD + 15) / 16, H4 = HD / 4;
+    constexpr int NT = 256, NW = NT / 64, ST = HD + 4, NTJ = N, NC = (HD + 15) / 16, H4 = HD / 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x, h = blockIdx.y, D = H * HD;
-    const int T16 = (T + 15) & ~15, n = T16 >> 4, ss = score_stride(T), m = lane & 15, g = lane >> 4;
+    constexpr int T16 = 16 * N, n = N;
+    const int ss = score_stride(T), m = lane & 15, g = lane >> 4;
     float* qs = lds;
     float* ks = qs + T16 * ST;
     float* vs = ks + T16 * ST;
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_mid_bwd2(const float* __restric
         }
         mma_acc_trans_reg<HD, NTJ>(acc, dos + 16 * ti * ST, n, lane, dV);   // dV += P_tile^T dO_tile
         mma_acc_trans_reg<HD, NTJ>(dp, qs + 16 * ti * ST, n, lane, dK);     // dK += dS_tile^T Q_tile
-        mma_rows_tile<HD, false>(ptile - 16 * ti * ss, ss, ks, gq, ldg, T, ti, lane);   // dQ rows of this tile = dS K
+        mma_rows_tile<HD, false, N>(ptile - 16 * ti * ss, ss, ks, gq, ldg, T, ti, lane);   // dQ rows of this tile = dS K
     }
     MAE_TS(7)
     __syncthreads();   // everyone is done with q / k / v / dO: the four buffers now take the partial sums
@@ -833,13 +839,22 @@ hipError_t launch_bwd(const float* qkv, int64_t ld, const float* fo, int64_t ldf
                       int64_t ldg, int64_t B, int H, int T, float scale, hipStream_t s) {
     static int form = -1;  // MDT_HIP_ATTN_BWD=1: the first form (T x T matrices in LDS, five phases), for A/B runs
     if (form < 0) { const char* e = getenv("MDT_HIP_ATTN_BWD"); form = e ? atoi(e) : 2; }
-    if (form == 2 && HD <= 32) {  // (hd 48 / 64: the T16 x hd accumulators of dK and dV no longer fit the registers)
-        const size_t lds2 = attn_mid_lds2(HD, T);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_attn_mid_bwd2<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL((k_attn_mid_bwd2<HD>), dim3((unsigned)B, H), dim3(256), lds2, s, qkv, ld, fo, ldf, d_out, ldd, d_qkv, ldg, H,
-                           T, scale);
-        return hipGetLastError();
+    if constexpr (HD <= 32) {  // (hd 48 / 64: the T16 x hd accumulators of dK and dV no longer fit the registers)
+        if (form == 2) {
+            const size_t lds2 = attn_mid_lds2(HD, T);
+#define MDT_BWD2(N_)                                                                                                              \
+    case N_: {                                                                                                                    \
+        hipError_t e2 = hipFuncSetAttribute((const void*)k_attn_mid_bwd2<HD, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        if (e2 != hipSuccess) return e2;                                                                                          \
+        hipLaunchKernelGGL((k_attn_mid_bwd2<HD, N_>), dim3((unsigned)B, H), dim3(256), lds2, s, qkv, ld, fo, ldf, d_out, ldd, d_qkv, ldg, \
+                           H, T, scale);                                                                                          \
+        return hipGetLastError();                                                                                                 \
+    }
+            switch ((T + 15) >> 4) {
+                MDT_BWD2(1) MDT_BWD2(2) MDT_BWD2(3) MDT_BWD2(4) MDT_BWD2(5) MDT_BWD2(6) MDT_BWD2(7) MDT_BWD2(8)
+            }
+#undef MDT_BWD2
+        }
     }
     const size_t lds = attn_mid_lds(HD, T, true);
     hipError_t e = hipFuncSetAttribute((const void*)k_attn_mid_bwd<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
