@@ -1570,20 +1570,33 @@ __global__ __launch_bounds__(256 * WN) void k_gemm_tn(const float* __restrict__ 
         if (c + 1 < nchunks) fetch(m_lo + (c + 1) * CM);
         const float* xb = xs[buf];
         const float* yb = ys[buf];
+        // 8 steps of 4 KT MFMAs per chunk; step t + 1's operands (KT + 4 LDS words per lane) are requested BEFORE step t's MFMAs and
+        // the order is pinned (round 5): as written before -- read, then multiply -- the compiler issued each step's reads in front of
+        // their first use and waited lgkmcnt(0) there, an LDS round trip per 12 MFMAs that three waves per SIMD only partly covered
+        auto operands = [&](int t, float (&a)[KT], float (&b)[4]) __attribute__((always_inline)) {
+            const int row = 16 * (t >> 2) + 4 * h + (t & 3);
 #pragma unroll
-        for (int s = 0; s < CM / 16; ++s) {
+            for (int j = 0; j < KT; ++j) a[j] = xb[row * SX + (KT * wk + j) * 16 + l16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = 16 * s + 4 * h + e;
-                float a[KT], b[4];
+            for (int i = 0; i < 4; ++i) b[i] = yb[row * SY + (4 * wn + i) * 16 + l16];
+        };
+        float a[KT], b[4];
+        operands(0, a, b);
 #pragma unroll
-                for (int j = 0; j < KT; ++j) a[j] = xb[row * SX + (KT * wk + j) * 16 + l16];
+        for (int t = 0; t < CM / 4; ++t) {
+            float an[KT], bn[4];
+            if (t + 1 < CM / 4) operands(t + 1, an, bn);
+            __builtin_amdgcn_sched_barrier(0x6);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[i] = yb[row * SY + (4 * wn + i) * 16 + l16];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x6);
+            if (t + 1 < CM / 4) {
 #pragma unroll
-                    for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < KT; ++j) a[j] = an[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = bn[i];
             }
         }
         if (do_bias) {
