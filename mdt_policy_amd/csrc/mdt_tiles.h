@@ -259,7 +259,8 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 // XP > 1 (LayerNorm prologues only): the rows are the sum of XP slabs a.A + x * a.a_part_stride (the partial outputs of
 // the fused MLP launch, mlp_tile below), added in slab order; `merge_out` (the column-0 workgroup of a row tile passes
 // a.a_merged, the others nullptr) also receives the summed rows.
-template <int MTILES, int NWAVES, int PRO, bool COH, int XP = 1>
+// XB (XP > 1): row batches the other slabs are requested in -- 1 where the registers allow it, else 2 (the caller knows its own load)
+template <int MTILES, int NWAVES, int PRO, bool COH, int XP = 1, int XB = 2>
 __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* lds, int stride, int m0, int k0, int klen,
                                                 const float* __restrict__ zeros, int tid, int lane, int wave,
                                                 float* merge_out = nullptr) {
@@ -288,10 +289,13 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
             for (int p = 0; p < 2; ++p) v[r][p] = LA.ld4(m * a.lda + cc[p]);
         }
         if constexpr (XP > 1) {
-            // the other slabs, summed in slab order -- in two batches of rows so that at most half of them are in flight
-            // (all at once the kernel spilled: 5 MB of scratch traffic per launch); the column-0 workgroup also leaves the sum
-            // in a.a_merged for the residual GEMM that follows
-            constexpr int HB = RPW / 2 > 0 ? RPW / 2 : 1;
+            // the other slabs, summed in slab order; the column-0 workgroup also leaves the sum in a.a_merged for the residual GEMM
+            // that follows.  ALL of a wave's slab rows are requested at once (round 5: 236 VGPRs, no spill).  Round 3 split them into
+            // two batches of rows because the kernel spilled then; the second batch was requested only after the first had
+            // arrived and been stored -- two serial round trips to the Infinity Cache in the prologue of every qkv launch
+            // (B = 256 sampler call 4.397 -> 4.377 ms in alternating runs).  The instantiations that would still spill -- four slabs
+            // (d = 512), four column tiles per wave -- keep the two batches (XB = 2).
+            constexpr int HB = XB == 1 || RPW < 2 ? RPW : RPW / 2;
 #pragma unroll
             for (int r0b = 0; r0b < RPW; r0b += HB) {
                 f32x4 vx[XP - 1][HB][2];
@@ -347,6 +351,10 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
                 sc[NC - 1][p] = ldg4(mhi + a.scale_off + cc[p]);
             }
         }
+        // (Round 5 measured pinning the prologue's requests to the order they are written in -- weight ring and epilogue operands in
+        //  front of the rows, the LayerNorm vectors in front of the reductions: 4.405 against 4.378 ms per B = 256 call.  The machine
+        //  scheduler's own order -- the rows, whose Infinity-Cache round trip is the longest, FIRST, everything L2-resident behind
+        //  them -- is the better one; nothing is pinned here.)
         const float inv_k = 1.0f / (float)klen;
         float red[RPW];
 #pragma unroll
@@ -730,7 +738,7 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
         if constexpr (PRO == PRO_ATTN)
             attn_stage_tile<AHD, ATKC>(a, *ap, lds, stride, m0, lds + MT * stride, tid);
         else
-            gemm_stage_tile<MTILES, NWAVES, PRO, COH, XP>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave,
+            gemm_stage_tile<MTILES, NWAVES, PRO, COH, XP, (NTW <= 3 && XP <= 3) ? 1 : 2>(a, lds, stride, m0, k0, klen, zeros, tid, lane, wave,
                                                           bx == 0 ? a.a_merged : nullptr);
         MDT_TS(1)
         __syncthreads();
