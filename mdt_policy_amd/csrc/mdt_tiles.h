@@ -732,8 +732,13 @@ __device__ __forceinline__ void gemm_tile(const mdt_gemm_args& a, int kchunk, in
     }
 
     int kg = 0;  // global k16 index of the weight stream
-    for (int k0 = 0; k0 < a.K; k0 += kchunk) {
-        const int klen = min(kchunk, a.K - k0);
+    // A LayerNorm / attention prologue stages whole rows: ONE chunk, and the compiler is told so (a loop with compile-time bounds
+    // 0 .. 1): as a run-time loop its header made the row requests wait for the weight ring and the epilogue operands requested
+    // above (`vmcnt(4)` in front of the first row load: an L2 round trip before the rows' Infinity-Cache one in every LayerNorm GEMM)
+    constexpr bool ONE_CHUNK = PRO != PRO_PLAIN;
+    const int k_end = ONE_CHUNK ? 1 : a.K, k_step = ONE_CHUNK ? 1 : kchunk;
+    for (int k0 = 0; k0 < k_end; k0 += k_step) {
+        const int klen = ONE_CHUNK ? a.K : min(kchunk, a.K - k0);
         if (k0 > 0) __syncthreads();  // everyone is done reading the previous chunk
         if constexpr (PRO == PRO_ATTN)
             attn_stage_tile<AHD, ATKC>(a, *ap, lds, stride, m0, lds + MT * stride, tid);
