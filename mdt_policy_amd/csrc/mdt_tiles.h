@@ -1091,17 +1091,38 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
     const f32x4 e_gate = ldg4(e_gated ? a.mod + a.gate_off + (a.mod_stride == 0 ? 0 : (e_mc / a.rows_per_sample) * a.mod_stride) + e_ncol
                                       : zeros + e_ncol);
     const f32x4 e_res = LO.ld4(a.residual ? e_oo : 0);
+    const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
+    // rollout batches (at most two samples' rows): the wave's first round of weight fragments is requested in front of the row
+    // statistics (round 5: B = 1 1.295 -> 1.286 ms, B = 2 1.339 -> 1.331; from B = 8 on it LOSES 1 %, the fragments of sixteen row
+    // tiles' workgroups then queue in front of each other's rows).  -DMDT_SMALLM_WF_LATE: A/B build
+#ifdef MDT_SMALLM_WF_LATE
+    const bool WF_EARLY = false;
+#else
+    const bool WF_EARLY = a.M <= 24;
+#endif
+    f32x4 wf0[4];
     if (a.ln) {  // row statistics: 32 threads per row, whole row in registers (K <= 512)
         const int r = tid >> 5, l32 = tid & 31;
         const int64_t m = min(m0 + r, a.M - 1);
         const int n4 = a.K >> 2;
         f32x4 v[4];
-        float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c4 = l32 + 32 * i;
             if constexpr (XL) v[i] = *(const f32x4*)(xl + min(r, rows - 1) * xls + 4 * min(c4, n4 - 1));
             else v[i] = LA.ld4(m * a.lda + 4 * min(c4, n4 - 1));
+        }
+        if (WF_EARLY) {
+            // the wave's first round of weight fragments (all of them for K <= 512), requested BEHIND the rows and in front of the
+            // statistics: the rows retire first (vmcnt is in order), the fragments travel under the statistics and the barrier
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wf0[u] = ldg4(wbase + min(wave + 8 * u, K16 - 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = l32 + 32 * i;
             v[i] = sel4(c4 < n4, v[i], zero4);
             sum += hsum4(v[i]);
         }
@@ -1125,7 +1146,6 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
     const int kq = 4 * (lane >> 4);
     const int64_t xoff = mc * a.lda + kq;
     const float* xlp = XL ? xl + min(lane & 15, rows - 1) * xls + kq : nullptr;
-    const float* wbase = a.Wp + (int64_t)n_tile * K16 * 256 + lane * 4;
     const bool modded = a.ln && a.mod != nullptr && a.shift_off >= 0;
     const float* mrw = modded ? a.mod + (a.mod_stride == 0 ? 0 : (mc / a.rows_per_sample) * a.mod_stride) : zeros;
     const float mean = a.ln ? s_mean[lane & 15] : 0.f, rstd = a.ln ? s_rstd[lane & 15] : 1.f;
@@ -1135,7 +1155,8 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int ks = min(ks0 + 8 * u, K16 - 1);
-            wf[u] = ldg4(wbase + ks * 256);
+            if (WF_EARLY && a.ln && ks0 == wave) wf[u] = wf0[u];
+            else wf[u] = ldg4(wbase + ks * 256);
             if constexpr (XL) xv[u] = *(const f32x4*)(xlp + ks * 16);
             else xv[u] = LA.ld4(xoff + ks * 16);
             if (a.ln) {
