@@ -85,6 +85,11 @@ hipError_t mdt_launch_attn_proj_wide(const mdt_gemm_args& p, const float* qkv, i
 bool mdt_attn_xattn_supported(const mdt_gemm_args& p, const mdt_xapply_args& x, int H, int hd, int T, int causal, int rope);
 hipError_t mdt_launch_attn_xattn(const mdt_gemm_args& p, const float* qkv, int64_t ldq, const mdt_xapply_args& x, int H, int hd,
                                  int T, hipStream_t s);
+// side jobs (mdt_kernels.hip): small-M products that ride in the launches of the small-M products that follow them
+hipError_t mdt_gemm_side_push(const mdt_gemm_args& a, hipStream_t s);
+hipError_t mdt_gemm_side_push_front(const mdt_gemm_args& a, hipStream_t s);
+hipError_t mdt_gemm_side_flush(hipStream_t s);
+void mdt_gemm_side_drop();
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
                                 hipStream_t s, float* out2 = nullptr);
 hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
 
 #include "mdt_internal.h"
 
@@ -28,8 +29,8 @@
 
 #define MDT_TILES_TIMING_OWNER  // this translation unit owns the -DMDT_DEBUG_TIMING stamp buffer
 #include "mdt_tiles.h"  // the tile bodies (shared with the persistent decoder kernel, mdt_persist.hip)
-#include "mdt_tall.h"
-#include "mdt_ws.h"   // the tall LDS-staged GEMM body (round 4)
+#include "mdt_tall.h"  // the tall LDS-staged GEMM body (round 4)
+#include "mdt_ws.h"    // the weight-stationary GEMM body (round 5)
 
 // ------------------------------------------------------------------------------------------------
 // weight packing
@@ -559,6 +560,21 @@ __global__ __launch_bounds__(512) void k_gemm_smallm(mdt_gemm_args a, const floa
     gemm_smallm_tile<false>(a, blockIdx.x, blockIdx.y * 16, s_stat, red, zeros, threadIdx.x);
 }
 
+// Two INDEPENDENT small products in one launch (round 5): blocks [0, nxa) x row tiles of `a`, then those of `b`.  A rollout-sized
+// sampler call is a chain of ~200 such ~5 us launches, and a handful of them do not depend on their neighbours (the sigma-MLP /
+// adaLN table chain beside the encoder chain, the token embedding beside the goal embedding): riding in a neighbour's launch they cost
+// nothing (mdt_gemm_side_*, below).
+__global__ __launch_bounds__(512) void k_gemm_smallm2(mdt_gemm_args a, mdt_gemm_args b, int nxa, int nya, const float* __restrict__ zeros) {
+    __shared__ float s_stat[32];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    const int na = nxa * nya;
+    if ((int)blockIdx.x < na) gemm_smallm_tile<false>(a, blockIdx.x % nxa, (blockIdx.x / nxa) * 16, s_stat, red, zeros, threadIdx.x);
+    else {
+        const int i = blockIdx.x - na, nxb = b.N >> 4;
+        gemm_smallm_tile<false>(b, i % nxb, (i / nxb) * 16, s_stat, red, zeros, threadIdx.x);
+    }
+}
+
 static int g_mdt_mid_max = 1400;    // rows up to which the 16 x 64 tiled geometry is used (env MDT_HIP_MID_MAX)
 // k_xattn_gemm_smallm: the collapsed cross-attention of sample b and, on its output rows, 16 columns (blockIdx.x) of the
 // LayerNorm + modulate -> Linear that follows (mlp.c_fc) -- rollout batches: the cross-attention launch (one workgroup, 6.5 us
@@ -719,6 +735,44 @@ hipError_t mdt_launch_attn_xattn(const mdt_gemm_args& p, const float* qkv, int64
     return T <= 10 ? launch_attn_xattn_t<48, 10>(p, at, x, s) : launch_attn_xattn_t<48, 16>(p, at, x, s);
 }
 
+// Side jobs: products that do not depend on the launches they are queued beside (and that nothing launched before
+// mdt_gemm_side_flush reads).  Each one rides in the launch of the NEXT product that goes to the split-K small-M kernel, in queue
+// order, one per launch (so a side job may depend on the side job before it); what is left is launched by mdt_gemm_side_flush.
+// Only small-M products are accepted (M <= 16 rows, the small-M kernel's own shape rules); anything else is launched at once.
+static thread_local std::vector<mdt_gemm_args> g_side_jobs;
+static thread_local size_t g_side_next = 0;
+static bool smallm_shape_ok(const mdt_gemm_args& a) {
+    return a.M >= 1 && a.M <= 15 && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode && a.a_parts <= 1 &&
+           a.N <= ZEROS_FLOATS && a.K <= ZEROS_FLOATS && !(a.N & 15) && (int64_t)a.N * a.K < ((int64_t)1 << 30);
+}
+static bool side_enabled() {
+    static int v = -1;  // MDT_HIP_SIDE_JOBS=0: every product its own launch (A/B runs)
+    if (v < 0) { const char* e = getenv("MDT_HIP_SIDE_JOBS"); v = e ? atoi(e) : 1; }
+    return v != 0 && g_mdt_gemm_force == 0;
+}
+hipError_t mdt_gemm_side_push(const mdt_gemm_args& a, hipStream_t s) {
+    if (!side_enabled() || !smallm_shape_ok(a)) return mdt_launch_gemm(a, s);
+    g_side_jobs.push_back(a);
+    return hipSuccess;
+}
+hipError_t mdt_gemm_side_push_front(const mdt_gemm_args& a, hipStream_t s) {   // rides in the NEXT small-M launch, ahead of the queue
+    if (!side_enabled() || !smallm_shape_ok(a)) return mdt_launch_gemm(a, s);
+    g_side_jobs.insert(g_side_jobs.begin() + g_side_next, a);
+    return hipSuccess;
+}
+void mdt_gemm_side_drop() { g_side_jobs.clear(); g_side_next = 0; }   // error paths: forget what was queued
+hipError_t mdt_gemm_side_flush(hipStream_t s) {
+    // the rest of the queue, each job as a launch of its own: the queue is emptied FIRST (a job launched from here must not take
+    // its successor -- which may depend on it -- along)
+    std::vector<mdt_gemm_args> rest(g_side_jobs.begin() + g_side_next, g_side_jobs.end());
+    mdt_gemm_side_drop();
+    for (const mdt_gemm_args& a : rest) {
+        hipError_t e = mdt_launch_gemm(a, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if (a.N > ZEROS_FLOATS || a.K > ZEROS_FLOATS) return hipErrorInvalidValue;
     // the weight stream is addressed with 32-bit byte offsets from the image's base (buffer loads, mdt_tiles.h: WStream)
@@ -763,6 +817,12 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
                            tiles6 < (g_mdt_smallm_tiles > 0 ? g_mdt_smallm_tiles : (a.ln ? 60 : (a.M <= 192 ? 100 : 160)));
     // (geometry hook -1: the split-K kernel wherever it applies -- tests that pin it against its fused variants)
     if ((a.M <= g_mdt_smallm_max || few_tiles || g_mdt_gemm_force < 0) && g_mdt_gemm_force <= 0 && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {
+        if (g_side_next < g_side_jobs.size() && a.batch <= 1 && a.M <= 16 * 64) {  // a queued side job rides in this launch
+            const mdt_gemm_args b = g_side_jobs[g_side_next++];
+            const int nxa = a.N >> 4, nya = (a.M + 15) >> 4;
+            hipLaunchKernelGGL(k_gemm_smallm2, dim3(nxa * nya + (b.N >> 4) * ((b.M + 15) >> 4)), dim3(512), 0, s, a, b, nxa, nya, g_zeros);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(k_gemm_smallm, dim3(a.N >> 4, (a.M + 15) >> 4, a.batch > 1 ? a.batch : 1), dim3(512), 0, s, a, g_zeros);
         return hipGetLastError();
     }

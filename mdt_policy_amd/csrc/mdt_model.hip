@@ -849,17 +849,19 @@ static int g_xattn_fc_max_batch() {
 // sigma_emb: sinusoidal(ln(sigma)/4) -> Linear -> Mish -> Linear for R sigmas (mdtv_transformer.py:105-110,282-288);
 // the second Linear's output rows go to out (leading dimension ldo, row r -> row r*gout) after `act`.
 // emb_done: m->sig_e already holds the R embeddings (the sampler's one-launch preparation wrote them)
+// side: the GEMMs are queued as side jobs (mdt_gemm_side_push: they ride in the launches of the small-M products that follow;
+// the caller flushes the queue before anything reads their outputs)
 static mdt_status run_sigma_mlp(mdt_model* m, const float* sigma, int64_t sstride, int R, float* out, int64_t ldo,
-                                int gout, int act, hipStream_t s, bool emb_done = false) {
+                                int gout, int act, hipStream_t s, bool emb_done = false, bool side = false) {
     const int D = m->D;
     if (!emb_done) LAUNCH(mdt_launch_sigma_emb(sigma, sstride, m->freqs, m->sig_e, R, D, s));
     mdt_gemm_args a = gemm_args(m->sig_e, D, m->sig1, m->sig_t, 2 * D, R);
     a.act = MDT_ACT_MISH;
-    LAUNCH(mdt_launch_gemm(a, s));
+    LAUNCH(side ? mdt_gemm_side_push(a, s) : mdt_launch_gemm(a, s));
     mdt_gemm_args b = gemm_args(m->sig_t, 2 * D, m->sig3, out, ldo, R);
     b.act = act;
     b.gin = 1; b.gout = gout; b.goff = 0;
-    LAUNCH(mdt_launch_gemm(b, s));
+    LAUNCH(side ? mdt_gemm_side_push(b, s) : mdt_launch_gemm(b, s));
     return MDT_OK;
 }
 
@@ -889,6 +891,14 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     const float* pos1 = pos0 ? m->pos_emb + (int64_t)c.goal_seq_len * D : nullptr;
     // sigma token -> row 0 of every sample's context           (concatenate_inputs, mdtv_transformer.py:296-297)
     if (t0) MDT_TRY(run_sigma_mlp(m, sigma, sstride, (int)B, m->h_enc, D, Te, MDT_ACT_NONE, s));
+    // rollout batches: the state-token embedding does not depend on the goal embedding -- it rides in the goal GEMM's launch
+    // (mdt_gemm_side_push_front; both are small-M products then, so the goal GEMM below takes it along)
+    const bool tok_side = c.arch == MDT_ARCH_MDTV && m->g_row >= 0 && B * m->n_tok <= 15;
+    if (tok_side) {
+        mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)(B * m->n_tok));
+        a.gin = m->n_tok; a.gout = Te; a.goff = m->tok_row;
+        LAUNCH(mdt_gemm_side_push_front(a, s));
+    }
     // goal token -> its row                                     (process_goal_embeddings, mdtv_transformer.py:268)
     if (m->g_row >= 0) {
         const float* gin = goal;
@@ -905,9 +915,11 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     }
     // state tokens -> the rows after it                         (process_state_embeddings, :260 / mdt :300)
     if (c.arch == MDT_ARCH_MDTV) {
-        mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)(B * m->n_tok));
-        a.gin = m->n_tok; a.gout = Te; a.goff = m->tok_row;
-        LAUNCH(mdt_launch_gemm(a, s));
+        if (!tok_side) {
+            mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)(B * m->n_tok));
+            a.gin = m->n_tok; a.gout = Te; a.goff = m->tok_row;
+            LAUNCH(mdt_launch_gemm(a, s));
+        }
     } else {
         mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)B);
         a.gin = 1; a.gout = Te; a.goff = m->tok_row; a.rowvec = pos1;
@@ -954,14 +966,15 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
 //   COND_ADALN: mod (R, Ld*6D) = adaLN_zero Linear(SiLU(c)) of every block, one stacked GEMM
 //   COND_NOISE: cmod (R, 2D)   = [c | ones]
 //   COND_TOKEN: nothing (sigma lives in the context)
-static mdt_status run_modulation(mdt_model* m, const float* sigma, int64_t sstride, int R, hipStream_t s, bool emb_done = false) {
+static mdt_status run_modulation(mdt_model* m, const float* sigma, int64_t sstride, int R, hipStream_t s, bool emb_done = false,
+                                 bool side = false) {
     const int D = m->D;
     if (m->cond == COND_TOKEN) return MDT_OK;
-    if (m->cond == COND_NOISE) return run_sigma_mlp(m, sigma, sstride, R, m->cmod, 2 * D, 1, MDT_ACT_NONE, s, emb_done);
+    if (m->cond == COND_NOISE) return run_sigma_mlp(m, sigma, sstride, R, m->cmod, 2 * D, 1, MDT_ACT_NONE, s, emb_done, side);
     // AdaLNZero applies SiLU to c before its Linear; c itself is used nowhere else
-    MDT_TRY(run_sigma_mlp(m, sigma, sstride, R, m->sig_c, D, 1, MDT_ACT_SILU, s, emb_done));
+    MDT_TRY(run_sigma_mlp(m, sigma, sstride, R, m->sig_c, D, 1, MDT_ACT_SILU, s, emb_done, side));
     mdt_gemm_args c = gemm_args(m->sig_c, D, m->mod_all, m->mod, (int64_t)m->Ld * 6 * D, R);
-    LAUNCH(mdt_launch_gemm(c, s));
+    LAUNCH(side ? mdt_gemm_side_push(c, s) : mdt_launch_gemm(c, s));
     return MDT_OK;
 }
 
@@ -1135,24 +1148,31 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
     hipStream_t s = (hipStream_t)stream;
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
     const bool per_step_ctx = m->cond == COND_TOKEN;  // sigma is a context token: the encoder cannot be hoisted
-    if (!per_step_ctx) MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, nullptr, 0, ctx_out, s));
-    else { MDT_TRY(check_loaded(m)); MDT_TRY(mdt_reserve(m, batch)); }
-    // per-step scalars, fp32 like the reference's 0-dim tensor math (gc_sampling.py:946-950):
-    // t = -ln(sigma); ratio = exp(-t_next)/exp(-t); coef = -expm1(-(t_next - t)) -- by ONE routine (k_ddim_steps, on the device)
-    // whether the schedule arrives in host memory (the reference's CPU default) or on the device (mdtv_agent.py:660-667: no
-    // copy, no synchronisation then), so that the eager call, the call with device sigmas and the graph replay of either give
-    // the same bits (host libm and the device's expf / logf differ in the last place)
     // ---- cut the batch into sample-aligned slices (multiples of 16 samples = 5 row tiles) on separate streams ----
     int ways = per_step_ctx ? 1 : m->ways;  // the encoder works on whole-batch buffers
     while (ways > 1 && batch / ways < 32) --ways;
+    MDT_TRY(check_loaded(m));
+    MDT_TRY(mdt_reserve(m, batch));
+    // per-step scalars, fp32 like the reference's 0-dim tensor math (gc_sampling.py:946-950):
+    // t = -ln(sigma); ratio = exp(-t_next)/exp(-t); coef = -expm1(-(t_next - t)) -- by ONE routine (on the device)
+    // whether the schedule arrives in host memory (the reference's CPU default) or on the device (mdtv_agent.py:660-667: no
+    // copy, no synchronisation then), so that the eager call, the call with device sigmas and the graph replay of either give
+    // the same bits (host libm and the device's expf / logf differ in the last place)
     if (ways == 1) {
         // ONE launch: per-step scalars, the sigma embeddings of all steps, the first action embedding (k_sample_prep); a host
-        // schedule rides in the kernel arguments (no copy launch in front of it)
+        // schedule rides in the kernel arguments (no copy launch in front of it).  It goes FIRST: the three GEMMs of the
+        // conditioning table (M = n_steps rows) depend on nothing else and are queued as side jobs -- they ride in the launches
+        // of the encoder's first small products (rollout batches; at large batches whatever the encoder did not take along is
+        // launched behind it)
         LAUNCH(mdt_launch_sample_prep(sigmas_dev, sigmas_dev ? nullptr : sigmas, n_steps, m->steps, m->freqs,
                                       m->cond == COND_TOKEN ? nullptr : m->sig_e, m->D, x_T, m->cfg.sigma_data, m->Wa, m->ba,
                                       decoder_view(m, 0).y, (int)(batch * m->Ta), m->A, s));
-        MDT_TRY(run_modulation(m, m->steps + 3, 4, n_steps, s, true));  // one row of conditioning vectors per step
+        mdt_status ms = run_modulation(m, m->steps + 3, 4, n_steps, s, true, !per_step_ctx);  // one row of conditioning vectors per step
+        if (ms == MDT_OK && !per_step_ctx) ms = run_encode(m, tokens, tokens2, goal, modality, honour, batch, nullptr, 0, ctx_out, s);
+        if (ms != MDT_OK) { mdt_gemm_side_drop(); return ms; }
+        LAUNCH(mdt_gemm_side_flush(s));
     } else {
+        MDT_TRY(run_encode(m, tokens, tokens2, goal, modality, honour, batch, nullptr, 0, ctx_out, s));
         if (!sigmas_dev) {
             HIP_TRY(hipMemcpyAsync(m->sigs, sigmas, (size_t)(n_steps + 1) * sizeof(float), hipMemcpyHostToDevice, s));
             sigmas_dev = m->sigs;
