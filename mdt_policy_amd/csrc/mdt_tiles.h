@@ -142,6 +142,11 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
     if ((threadIdx.x & 255) == 0 && g_dbg_ts != nullptr) {                               \
         g_dbg_ts[((size_t)blockIdx.x + (threadIdx.x >> 8) * gridDim.x) * 8 + (i)] = __builtin_readcyclecounter(); \
     }
+// a body that runs BEHIND another stamped body in one kernel (k_xattn_gemm_smallm) stamps into the rows behind the grid's
+#define MDT_TSO(off, i)                                                                   \
+    if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
+        g_dbg_ts[((size_t)blockIdx.x + (off)) * 8 + (i)] = __builtin_readcyclecounter();  \
+    }
 #define MDT_TS_HWID()                                                                     \
     if (threadIdx.x == 0 && g_dbg_ts != nullptr) {                                        \
         unsigned hw, xcc;                                                                 \
@@ -152,6 +157,7 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 #else
 #define MDT_TS(i)
 #define MDT_TS2(i)
+#define MDT_TSO(off, i)
 #define MDT_TS_HWID()
 #endif
 
@@ -1071,7 +1077,7 @@ template <bool COH, bool XL = false>
 __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_tile, int m0, float* s_stat, float* red,
                                                  const float* __restrict__ zeros, int tid, const float* xl = nullptr, int xls = 0,
                                                  int rows = 16) {
-    MDT_TS(0)
+    MDT_TSO(XL ? gridDim.x : 0, 0)
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int K16 = a.K >> 4;
@@ -1136,9 +1142,9 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
         }
         sq = half_wave_sum(sq);
         if (l32 == 0) { s_mean[r] = mean; s_rstd[r] = 1.0f / sqrtf(sq / (float)a.K + 1e-5f); }
-        MDT_TS(1)
+        MDT_TSO(XL ? gridDim.x : 0, 1)
         __syncthreads();
-        MDT_TS(2)
+        MDT_TSO(XL ? gridDim.x : 0, 2)
     }
     const int mrow = m0 + (lane & 15);
     const int64_t mc = min(mrow, a.M - 1);
@@ -1179,10 +1185,10 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
             }
         }
     }
-    MDT_TS(3)
+    MDT_TSO(XL ? gridDim.x : 0, 3)
     *(f32x4*)(red + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
-    MDT_TS(4)
+    MDT_TSO(XL ? gridDim.x : 0, 4)
     if (wave == 0) {
         f32x4 v = *(const f32x4*)(red + lane * 4);
 #pragma unroll
@@ -1192,7 +1198,7 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
         if (a.residual) v = e_res + (e_gated ? e_gate * v : v);
         if (mok) *(f32x4*)(a.out + e_oo) = v;  // (rollout-sized launches: plain stores, write-through costs them 0.8 %)
     }
-    MDT_TS(5)
+    MDT_TSO(XL ? gridDim.x : 0, 5)
 }
 
 // ------------------------------------------------------------------------------------------------
