@@ -109,6 +109,13 @@ mdt_status mdt_op_mlp(const mdt_gemm_args *fc, const mdt_gemm_args *proj, float 
 /* Tuning / test hook: the model-level entry points run the MLP sublayer through mdt_op_mlp from `rows` rows (B * horizon)
  * on; 0 = never (the two-GEMM sequence), -1 = default (1401, or MDT_HIP_MLP_FUSE_MIN from the environment). */
 void mdt_op_set_mlp_fuse_min(int32_t rows);
+/* Tuning / test hook (round 5): rollout-sized model-level calls queue the products that do not depend on their neighbours in the
+ * launch chain (the sigma-MLP / adaLN table of mdt_sample_ddim, the MDTV token embedding) and let each ride as extra workgroups in
+ * the next split-K small-M launch.  0 = every product its own launch, 1 = on, -1 = default (on, or MDT_HIP_SIDE_JOBS from the
+ * environment).  Same tiles, same order inside each product: results are bit-identical either way.
+ * mdt_op_side_jobs_paired: how many launches of this process have taken such a product along so far. */
+void mdt_op_set_side_jobs(int32_t on);
+int64_t mdt_op_side_jobs_paired(void);
 /* Measurement hook: bracket every fused-MLP launch of the model-level calls that follow (mdt_sample_ddim, mdt_forward, ...)
  * with a pair of HIP events on its stream; mdt_op_trace_mlp_read waits for them, writes up to `cap` durations in
  * MICROSECONDS (launch order) to `us`, releases the events and returns how many it wrote.  The duration of the dominant

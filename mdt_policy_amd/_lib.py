@@ -189,6 +189,8 @@ SYMBOLS = [
     ("mdt_op_mlp", _I32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _VP, _I64, C.POINTER(_I32), _VP]),
     ("mdt_op_set_gemm_geometry", None, [_I32]),
     ("mdt_op_set_mlp_fuse_min", None, [_I32]),
+    ("mdt_op_set_side_jobs", None, [_I32]),
+    ("mdt_op_side_jobs_paired", _I64, []),
     ("mdt_op_set_mlp_skew", None, [_I32]),
     ("mdt_op_set_attn_wide_min", None, [_I32]),
     ("mdt_op_attention", _I32, [C.POINTER(AttnArgs), _VP]),

@@ -745,11 +745,15 @@ static bool smallm_shape_ok(const mdt_gemm_args& a) {
     return a.M >= 1 && a.M <= 15 && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode && a.a_parts <= 1 &&
            a.N <= ZEROS_FLOATS && a.K <= ZEROS_FLOATS && !(a.N & 15) && (int64_t)a.N * a.K < ((int64_t)1 << 30);
 }
+static int g_side_override = -1;        // mdt_op_set_side_jobs (tests / A-B runs): 0 = off, 1 = on, -1 = the environment's choice
+static int64_t g_side_paired = 0;       // launches that took a side job along (mdt_op_side_jobs_paired)
 static bool side_enabled() {
     static int v = -1;  // MDT_HIP_SIDE_JOBS=0: every product its own launch (A/B runs)
     if (v < 0) { const char* e = getenv("MDT_HIP_SIDE_JOBS"); v = e ? atoi(e) : 1; }
-    return v != 0 && g_mdt_gemm_force == 0;
+    return (g_side_override >= 0 ? g_side_override != 0 : v != 0) && g_mdt_gemm_force == 0;
 }
+extern "C" void mdt_op_set_side_jobs(int32_t on) { g_side_override = on < 0 ? -1 : (on != 0); }
+extern "C" int64_t mdt_op_side_jobs_paired(void) { return g_side_paired; }
 hipError_t mdt_gemm_side_push(const mdt_gemm_args& a, hipStream_t s) {
     if (!side_enabled() || !smallm_shape_ok(a)) return mdt_launch_gemm(a, s);
     g_side_jobs.push_back(a);
@@ -819,6 +823,7 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     if ((a.M <= g_mdt_smallm_max || few_tiles || g_mdt_gemm_force < 0) && g_mdt_gemm_force <= 0 && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode) {
         if (g_side_next < g_side_jobs.size() && a.batch <= 1 && a.M <= 16 * 64) {  // a queued side job rides in this launch
             const mdt_gemm_args b = g_side_jobs[g_side_next++];
+            ++g_side_paired;
             const int nxa = a.N >> 4, nya = (a.M + 15) >> 4;
             hipLaunchKernelGGL(k_gemm_smallm2, dim3(nxa * nya + (b.N >> 4) * ((b.M + 15) >> 4)), dim3(512), 0, s, a, b, nxa, nya, g_zeros);
             return hipGetLastError();

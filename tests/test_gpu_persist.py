@@ -30,6 +30,7 @@ def _restore_switch(monkeypatch):
     _lib().mdt_op_set_gemm_geometry(0)
     _lib().mdt_op_set_mlp_fuse_min(-1)
     _lib().mdt_op_set_attn_wide_min(-1)
+    _lib().mdt_op_set_side_jobs(-1)
 
 
 def _engine(model):
@@ -269,3 +270,36 @@ def test_a_scaler_argument_keeps_the_fused_loop(monkeypatch):
         seen = []
         gs.sample_ddim(model, state, x_T, goal, sig, scaler=Scaler(), callback=lambda d: seen.append(d["i"]))
     assert seen == list(range(meta["n_steps"])) and len(stepped) == meta["n_steps"]
+
+
+@pytest.mark.parametrize("batch", [1, 3, 40])
+def test_side_jobs_ride_in_neighbouring_launches_and_change_no_bit(batch):
+    """Round 5: the products of a sampler call that do not depend on their neighbours in the launch chain (the sigma-MLP / adaLN
+    table, M = n_steps rows; the MDTV token embedding) ride as extra workgroups in the next split-K small-M launch
+    (mdt_gemm_side_*, k_gemm_smallm2).  Same tiles in the same order: the call's output is bit-identical with the switch off; at a
+    rollout batch some launches must actually have taken one along, at a batch whose encoder runs on the tiled kernels the queue is
+    simply launched behind it."""
+    meta, fx = load_fixture("g3_b256_lang.npz")
+    model = build(meta)
+    state, goal, noise = gpu_inputs(meta)
+    state = {k: (v[:batch] if torch.is_tensor(v) else v) for k, v in state.items()}
+    goal, x_T = goal[:batch], noise[:batch] * meta["sigma_max"]
+    gs = sampling()
+    sig = gs.get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    lib = _lib()
+    out = {}
+    paired = {}
+    with torch.no_grad():
+        for on in (0, 1, 0, 1):
+            lib.mdt_op_set_side_jobs(on)
+            before = lib.mdt_op_side_jobs_paired()
+            y = gs.sample_ddim(model, state, x_T, goal, sig)
+            torch.cuda.synchronize()
+            paired.setdefault(on, []).append(lib.mdt_op_side_jobs_paired() - before)
+            out.setdefault(on, []).append(y.clone())
+    assert paired[0] == [0, 0], paired
+    if batch <= 3:
+        assert paired[1][0] >= 3 and paired[1][0] == paired[1][1], paired   # the three table products at least
+    for a in out[0] + out[1]:
+        assert torch.equal(a, out[0][0]), "side jobs changed the result"
+    assert_close(out[1][0].cpu(), fx["actions"][:batch], what="side jobs on vs reference")
