@@ -1234,53 +1234,89 @@ __device__ __forceinline__ void attn_proj_tile(const mdt_gemm_args& a, const flo
     const bool e_gated = a.residual && a.gate_off >= 0;
     const f32x4 e_gate = ldg4(e_gated ? a.mod + a.gate_off + (int64_t)b * a.mod_stride + e_ncol : zeros + e_ncol);
     const f32x4 e_res = LO.ld4(a.residual ? e_oo : 0);
-    float* qs = lds + h * (3 * 16 * ST + 16 * 17);  // [16][ST] q, later the attention output
+    float* qs = lds + h * (3 * 16 * ST + 16 * 17);  // [16][ST] this head's q rows (the wave's own region: no workgroup barrier)
     float* ks = qs + 16 * ST;
     float* vs = ks + 16 * ST;
-    float* P = vs + 16 * ST;                         // [16][17]
-    for (int i = lane; i < T * H4; i += 64) {
+    // the head's q | k | v rows: ALL requests first, then the LDS stores (round 5: as a run-time loop of load -> store the second
+    // trip's requests went out only when the first trip's data had arrived -- a second memory round trip, ~1.4 us of a 6.6 us
+    // launch, in every decoder block of a rollout-sized call)
+    constexpr int NIT = (16 * H4 + 63) / 64;
+    const int nitems = T * H4;
+    f32x4 tq[NIT], tk[NIT], tv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(lane + 64 * it, nitems - 1);
         const int t = i / H4, c = i - t * H4;
         const int64_t row = qoff + (int64_t)t * ldq + h * HD + 4 * c;
-        *(f32x4*)(qs + t * ST + 4 * c) = LQ.ld4(row);
-        *(f32x4*)(ks + t * ST + 4 * c) = LQ.ld4(row + D);
-        *(f32x4*)(vs + t * ST + 4 * c) = LQ.ld4(row + 2 * D);
+        tq[it] = LQ.ld4(row);
+        tk[it] = LQ.ld4(row + D);
+        tv[it] = LQ.ld4(row + 2 * D);
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < T * T; e += 64) {
-        const int i = e / T, j = e - i * T;
-        float sacc = 0.f;
 #pragma unroll
-        for (int c = 0; c < H4; ++c) {
-            const f32x4 qv = *(const f32x4*)(qs + i * ST + 4 * c), kv = *(const f32x4*)(ks + j * ST + 4 * c);
-            sacc = fmaf(qv.x, kv.x, sacc); sacc = fmaf(qv.y, kv.y, sacc); sacc = fmaf(qv.z, kv.z, sacc); sacc = fmaf(qv.w, kv.w, sacc);
+    for (int it = 0; it < NIT; ++it) {
+        const int i = lane + 64 * it;
+        if (i < nitems) {
+            const int t = i / H4, c = i - t * H4;
+            *(f32x4*)(qs + t * ST + 4 * c) = tq[it];
+            *(f32x4*)(ks + t * ST + 4 * c) = tk[it];
+            *(f32x4*)(vs + t * ST + 4 * c) = tv[it];
         }
-        P[i * 17 + j] = (!causal || j <= i) ? sacc * scale : -INFINITY;
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane < T) {
-        float* row = P + lane * 17;
-        float mx = row[0];
-        for (int j = 1; j < T; ++j) mx = fmaxf(mx, row[j]);
+    // ---- both attention products on the MFMA pipe, as attn_sample_tile runs them (round 5; before: ~100 scores by vector FMAs,
+    //      a serial softmax on T lanes, the weighted values through LDS).  Scores with transposed operand roles (A = key rows, B =
+    //      query rows): the lane ends with S[query m = lane % 16][keys 4 g .. 4 g + 3], g = lane / 16; softmax over the lane's four
+    //      values and the four 16-lane rows of the wave (xrow_max / xrow_sum); the probabilities are the B operand of O^T = V^T P^T,
+    //      and the lane ends with O[query m][features 16 u + 4 g .. + 3] -- exactly the activation fragment of the projection's
+    //      k-step u: the attention output never leaves the registers.  Rows past T are never read (indices clamped to T - 1). ----
+    const int m = lane & 15, g = lane >> 4;
+    const int rc = min(m, T - 1);
+    f32x4 sc = zero4;
+    {
+        const float* qp = qs + rc * ST + 4 * g;
+        const float* kp = ks + rc * ST + 4 * g;
+        f32x4 kf[KS], qf[KS];
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) { kf[kc] = *(const f32x4*)(kp + 16 * kc); qf[kc] = *(const f32x4*)(qp + 16 * kc); }
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kc][e], qf[kc][e], sc, 0, 0, 0);
+    }
+    float vt[KS][4];   // V^T fragments: feature 16 nt + m of key row 4 g + e
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float* vp = vs + min(4 * g + e, T - 1) * ST + m;
+#pragma unroll
+        for (int nt = 0; nt < KS; ++nt) vt[nt][e] = vp[16 * nt];
+    }
+    f32x4 pr;
+    {
+        float mx = -INFINITY;
+        bool vis[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vis[e] = 4 * g + e < T && (!causal || 4 * g + e <= rc);   // key 0 is always visible
+            sc[e] = vis[e] ? sc[e] * scale : -INFINITY;
+            mx = fmaxf(mx, sc[e]);
+        }
+        mx = xrow_max(mx);
         float sum = 0.f;
-        for (int j = 0; j < T; ++j) { row[j] = expf(row[j] - mx); sum += row[j]; }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < T; ++j) row[j] *= inv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pr[e] = vis[e] ? expf(sc[e] - mx) : 0.f; sum += pr[e]; }
+        const float inv = 1.0f / xrow_sum(sum);
+        pr = pr * inv;
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < 16 * H4; i += 64) {  // rows T..15 of the activation tile are zero
-        const int t = i / H4, c = i - t * H4;
-        f32x4 o = zero4;
-        if (t < T)
-            for (int j = 0; j < T; ++j) o += P[t * 17 + j] * *(const f32x4*)(vs + j * ST + 4 * c);
-        *(f32x4*)(qs + t * ST + 4 * c) = o;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- this head's slice of the projection: lane holds row lane % 16, k = 16 u + 4 (lane / 16) .. + 3 ----
-    const int mrow = lane & 15, kq = 4 * (lane >> 4);
+    // ---- this head's slice of the projection: lane holds row m, k = 16 u + 4 g .. + 3 of the head's range ----
+    const int mrow = m;
+    const bool rok = m < T;
     f32x4 acc = zero4;
 #pragma unroll
     for (int u = 0; u < KS; ++u) {
-        const f32x4 x = *(const f32x4*)(qs + mrow * ST + 16 * u + kq);
+        f32x4 o = zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[u][e], pr[e], o, 0, 0, 0);
+        const f32x4 x = rok ? o : zero4;   // rows T .. 15 of the activation tile are zero
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][e], x[e], acc, 0, 0, 0);
     }
