@@ -931,7 +931,18 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
             return launch_gemm_pro<2, 1, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 3: return launch_gemm_pro<2, 3, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
         case 4: return launch_gemm_pro<2, 4, 8>(a, mdt_gemm_kchunk(a.K, a.ln, 768), s);
-        case 6: return launch_gemm_pro<1, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 16 x 64
+        case 6: {
+            // 4 waves 16 x 64.  Deep K (the encoder's / a mid batch's c_proj, K = 4d in four LDS chunks): with two LOADER waves that
+            // double-buffer the activation chunk -- as a single-buffer loop each chunk was a memory round trip of its own in front of
+            // its 24 k-steps, and half-height tiles have few workgroups per CU to hide it (MDT_HIP_PIPE6=0: A/B runs)
+            static int p6 = -1;
+            if (p6 < 0) { const char* e = getenv("MDT_HIP_PIPE6"); p6 = e ? atoi(e) : 1; }
+            if (p6 && !a.ln && a.K > 512 && !a.aux_mode && !g_mdt_gemm_nopipe) {
+                const int kc = mdt_gemm_kchunk(a.K, 0, 384);
+                return a.residual ? launch_gemm_pipe_r<1, 1, 4, 2, true>(a, kc, s) : launch_gemm_pipe_r<1, 1, 4, 2, false>(a, kc, s);
+            }
+            return launch_gemm_pro<1, 1, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);
+        }
         case 7: return launch_gemm_pro<4, 2, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 64 x 128 (deep-K products)
         case 8: return launch_gemm_pro<2, 4, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 32 x 256: two workgroups per CU
         case 9: return launch_gemm_pro<2, 3, 4>(a, mdt_gemm_kchunk(a.K, a.ln, 384), s);  // 4 waves 32 x 192
