@@ -937,7 +937,9 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
             // its 24 k-steps, and half-height tiles have few workgroups per CU to hide it (MDT_HIP_PIPE6=0: A/B runs)
             static int p6 = -1;
             if (p6 < 0) { const char* e = getenv("MDT_HIP_PIPE6"); p6 = e ? atoi(e) : 1; }
-            if (p6 && !a.ln && a.K > 512 && !a.aux_mode && !g_mdt_gemm_nopipe) {
+            // (up to one workgroup per CU: beyond that the co-resident workgroups hide each other's round trips -- the encoder's
+            //  1024-row c_proj, 384 workgroups, measured +0.1 % with the loader waves)
+            if (p6 && !a.ln && a.K > 512 && !a.aux_mode && !g_mdt_gemm_nopipe && (int64_t)((a.M + 15) / 16) * ((a.N + 63) / 64) <= 256) {
                 const int kc = mdt_gemm_kchunk(a.K, 0, 384);
                 return a.residual ? launch_gemm_pipe_r<1, 1, 4, 2, true>(a, kc, s) : launch_gemm_pipe_r<1, 1, 4, 2, false>(a, kc, s);
             }
