@@ -87,15 +87,32 @@ class GraphedDDIM:
         eng.sync_params()  # parameter updates go into the arena the graph reads (outside the graph)
         if int(eng.lib.mdt_ws_generation(eng.handle)) != self._gen:
             self._capture()  # the workspace moved: the old graph's addresses are dead
+        # the inputs into the graph's static buffers: ONE multi-tensor copy launch for everything that is already on the device
+        # (round 5: as one copy_ per tensor these were six dependent ~3 us launches with ~15 us of host cadence between them in front
+        # of a 1.19 ms replay)
+        dst, src = [], []
         for k, v in self._static_state.items():
             if torch.is_tensor(v):
-                v.copy_(state[k])
-        self._x.copy_(x_T)
-        self._goal.copy_(goal)
+                dst.append(v); src.append(state[k])
+        dst += [self._x, self._goal]; src += [x_T, goal]
         if sigmas is not None:
-            # n + 1 floats: always copied -- a caller may rewrite its schedule tensor in place (same object, new values), and
-            # an identity check would then replay the old noise levels without any error
-            self._sig.copy_(sigmas if torch.is_tensor(sigmas) else torch.as_tensor(sigmas, dtype=torch.float32))
+            # n + 1 floats: never skipped on identity -- a caller may rewrite its schedule tensor in place (same object, new values).
+            # A HOST schedule (the reference's CPU default) is compared by value with the last one copied: equal -> nothing to do
+            sg = sigmas if torch.is_tensor(sigmas) else torch.as_tensor(sigmas, dtype=torch.float32)
+            if sg.device.type == "cpu":
+                sg = sg.detach().to(torch.float32)
+                if self._last_sig is None or not torch.equal(sg, self._last_sig):
+                    self._sig.copy_(sg)
+                    self._last_sig = sg.clone()
+            else:
+                dst.append(self._sig); src.append(sg.detach())
+                self._last_sig = None
+        fast = all(torch.is_tensor(b) and b.device == a.device and b.dtype == a.dtype and b.shape == a.shape for a, b in zip(dst, src))
+        if fast:
+            torch._foreach_copy_(dst, src)
+        else:
+            for a, b in zip(dst, src):
+                a.copy_(b)
         self._graph.replay()
         eng.ctx_generation += 1
         self.model.inner_model.latent_encoder_emb = self._ctx

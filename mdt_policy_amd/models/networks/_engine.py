@@ -14,6 +14,7 @@ configuration raises.
 from __future__ import annotations
 
 import ctypes as C
+import operator
 from typing import Dict, Optional
 
 import torch
@@ -78,6 +79,7 @@ class HipEngine:
         updates the version counter does not see -- ``p.data.mul_()/copy_()``, apex / DeepSpeed multi-tensor kernels, any
         raw-pointer write other than this package's FusedAdamW / multi_tensor_ema (which bump the counter)."""
         self._uploaded.clear()
+        self._fast = None
 
     def sync_params(self) -> None:
         """Upload every parameter whose storage or version changed since the last upload.  MDT_HIP_PARAM_RESYNC=N
@@ -87,6 +89,12 @@ class HipEngine:
             self._calls = getattr(self, "_calls", 0) + 1
             if self._calls % _RESYNC_EVERY == 0:
                 self._uploaded.clear()
+        # fast path (a rollout calls this ~1000 times a second with nothing changed): three C-level sweeps over the cached lists --
+        # every parameter still the object its module holds, same version counters, same storage pointers -- instead of a Python
+        # loop body per parameter (73 -> ~45 us per call of a 1.2 ms rollout step)
+        fast = getattr(self, "_fast", None)
+        if fast is not None and not self._dirty_fast():
+            return
         seen = 0
         changed = []  # (key, source tensor, tag)
         # the parameters the library reads, resolved once per engine as (key, leaf name, owning module, parameter): walking the
@@ -127,6 +135,27 @@ class HipEngine:
         if seen != len(self.expected):
             have = {"inner_model." + n for n, _ in self.module.named_parameters()}
             raise RuntimeError(f"module lacks parameters the HIP path needs: {sorted(set(self.expected) - have)[:5]}")
+        params = [p for _, _, _, p in plist]
+        if all(self._uploaded.get(k) == (p.data_ptr(), p._version) for k, _, _, p in plist):
+            self._fast = ([o._parameters for _, _, o, _ in plist], [l for _, l, _, _ in plist], params,
+                          [p._version for p in params], [p.data_ptr() for p in params], plist)
+        else:
+            self._fast = None
+
+    def _dirty_fast(self) -> bool:
+        """True when the cached snapshot of sync_params no longer describes the module (or cannot tell)."""
+        dicts, leafs, params, vers, ptrs, plist = self._fast
+        if plist is not getattr(self, "_plist", None) or len(self._uploaded) < len(params):   # invalidate() / a re-resolved list
+            self._fast = None
+            return True
+        try:
+            same = all(map(operator.is_, [d[l] for d, l in zip(dicts, leafs)], params))
+        except KeyError:
+            same = False
+        if same and [p._version for p in params] == vers and [p.data_ptr() for p in params] == ptrs:
+            return False
+        self._fast = None
+        return True
 
     def _in(self, t: torch.Tensor, shape=None) -> torch.Tensor:
         if t.device != self.device:
