@@ -308,6 +308,13 @@ def load() -> C.CDLL:
                 raise RuntimeError(
                     "libmdt_hip.so is missing and could not be built; the MDT hot path has no CPU/eager "
                     f"fallback ({e})") from e
+        # torch FIRST: its wheels bundle their own libamdhip64 / HSA runtime.  If this library is loaded before torch (as
+        # __graft_entry__.build() followed by smoke() in ONE process did), the process ends up with two HIP runtimes and the one
+        # this library is bound to reports "no ROCm-capable device" at its first hipMalloc.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # a torch-free client of the C ABI (tests/c_client) has only one runtime anyway
+            pass
         lib = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
