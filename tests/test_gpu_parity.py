@@ -517,6 +517,41 @@ def test_mark_dirty_picks_up_writes_the_version_counter_misses():
     assert torch.equal(a, c)
 
 
+def test_unchanged_parameter_fast_path_still_sees_every_kind_of_change():
+    """Round 5: after a call that uploaded nothing, `sync_params` checks the parameters with three sweeps over cached lists (same
+    objects, same version counters, same storage pointers).  Every way a parameter can change must still leave that fast path: an
+    in-place update (version counter), `p.data = ...` (storage pointer, counter untouched), a Parameter REPLACED by assignment
+    (object identity), `mark_dirty()`."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx = load_fixture("g1_tiny_mdtv.npz")
+    model = GCDenoiser(cfg_of(meta), sigma_data=0.5)
+    model.load_state_dict(params_of(meta))
+    model = model.cuda().eval()
+    state, goal, noise = gpu_inputs(meta)
+    sig = sampling().get_sigmas_exponential(meta["n_steps"], meta["sigma_min"], meta["sigma_max"])
+    run = lambda: sampling().sample_ddim(model, state, noise * meta["sigma_max"], goal, sig).clone()
+    im = model.inner_model
+    eng = im.hip_engine(0.5, state)
+    with torch.no_grad():
+        a = run(); a2 = run(); a3 = run()
+        assert eng._fast is not None, "two unchanged calls must have armed the fast path"
+        assert torch.equal(a, a2) and torch.equal(a, a3)
+        im.action_pred.weight.mul_(0.5)                       # version counter
+        b = run()
+        assert eng._fast is not None
+        im.action_pred.weight.data = im.action_pred.weight.data.clone() * 2.0   # new storage, same counter
+        c = run()
+        old = im.action_pred.weight
+        im.action_pred.weight = torch.nn.Parameter(old.detach().clone() * 0.5)    # another Parameter object
+        d = run()
+        im.action_pred.weight.data.mul_(2.0)                  # invisible to every check ...
+        im.mark_dirty()                                       # ... hence the escape hatch
+        e = run()
+    assert_close(a.cpu(), fx["actions"], what="before")
+    assert (a - b).abs().max().item() > 1e-3 and torch.equal(b, d), "halved weights must change the actions, the same way both times"
+    assert torch.equal(a, c) and torch.equal(a, e)
+
+
 def test_cached_context_is_not_poisoned_by_an_interleaved_encode():
     """Inside ``cached_context`` a call with ANOTHER state / goal (classifier-free guidance's unconditional branch, a callback
     evaluating something else) re-encodes on the same handle; later calls with the original pair must not decode against
