@@ -637,7 +637,7 @@ bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int r
 
 template <int HD>
 static hipError_t launch_attn_proj_t(const mdt_gemm_args& p, const float* qkv, int64_t ldq, int T, int causal, hipStream_t s) {
-    const size_t lds = (size_t)8 * (3 * 16 * (HD + 4) + 16 * 17) * sizeof(float);
+    const size_t lds = (size_t)8 * 3 * T * (HD + 4) * sizeof(float);
     static size_t lds_attr_dev[MAX_DEVICES] = {0};
     size_t& lds_attr = lds_attr_dev[current_device()];
     if (lds > 48 * 1024 && lds > lds_attr) {

@@ -668,9 +668,10 @@ struct ModRef {
 static int64_t g_attn_proj_max_batch() {
     static int64_t v = -1;
     // (round 2, B = 2 / 4 / 8: 1.87 -> 1.71, 2.02 -> 1.85, 2.24 -> 2.07 ms; B = 16 lost then, 2.76 -> 2.83.  Round 5, with the fused
-    //  kernel's attention on the MFMA pipe and its rows requested in one batch: B = 12 1.653 -> 1.554, B = 16 1.649 -> 1.563; a limit
-    //  of 32 loses again, B = 24 / 32 2.007 / 2.015 -> 2.036 / 2.059)
-    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_PROJ_MAX"); v = e ? atoll(e) : 16; }
+    //  kernel's attention on the MFMA pipe, its rows requested in one batch and its LDS cut to the T real rows -- two workgroups
+    //  per CU: B = 12 / 16 / 20 / 24 / 32 1.653 / 1.649 / 1.918 / 2.006 / 2.017 -> 1.49 / 1.50 / 1.74 / 1.93 / 1.95 ms; B = 48 loses,
+    //  2.30 -> 2.42)
+    if (v < 0) { const char* e = getenv("MDT_HIP_ATTN_PROJ_MAX"); v = e ? atoll(e) : 32; }
     return v;
 }
 

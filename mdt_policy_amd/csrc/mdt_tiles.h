@@ -1209,7 +1209,8 @@ __device__ __forceinline__ void gemm_smallm_tile(const mdt_gemm_args& a, int n_t
 // and softmax by the wave alone, no workgroup barrier) and then feeds it to the MFMAs as the activation fragment.  Every
 // workgroup (16 output columns) repeats the T x T attention -- 19 kFLOP per head -- in exchange for one launch and one
 // round trip of the attention output per block.  The weight fragments are requested before the attention starts.
-// lds: 8 * (3*16*(HD+4) + 16*17) floats; red: 8*64*4 floats.  512 threads.
+// lds: 8 * 3 * T * (HD+4) floats (round 5: only the T real rows, no probability tile -- 50 KB at T = 10, d = 384, so that two
+// workgroups share a CU); red: 8*64*4 floats.  512 threads.
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool COH>
 __device__ __forceinline__ void attn_proj_tile(const mdt_gemm_args& a, const float* __restrict__ qkv_base, int64_t ldq, int T,
@@ -1234,9 +1235,9 @@ __device__ __forceinline__ void attn_proj_tile(const mdt_gemm_args& a, const flo
     const bool e_gated = a.residual && a.gate_off >= 0;
     const f32x4 e_gate = ldg4(e_gated ? a.mod + a.gate_off + (int64_t)b * a.mod_stride + e_ncol : zeros + e_ncol);
     const f32x4 e_res = LO.ld4(a.residual ? e_oo : 0);
-    float* qs = lds + h * (3 * 16 * ST + 16 * 17);  // [16][ST] this head's q rows (the wave's own region: no workgroup barrier)
-    float* ks = qs + 16 * ST;
-    float* vs = ks + 16 * ST;
+    float* qs = lds + h * (3 * T * ST);   // [T][ST] this head's q rows (the wave's own region of 3 T rows: no workgroup barrier)
+    float* ks = qs + T * ST;
+    float* vs = ks + T * ST;
     // the head's q | k | v rows: ALL requests first, then the LDS stores (round 5: as a run-time loop of load -> store the second
     // trip's requests went out only when the first trip's data had arrived -- a second memory round trip, ~1.4 us of a 6.6 us
     // launch, in every decoder block of a rollout-sized call)

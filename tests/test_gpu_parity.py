@@ -203,9 +203,9 @@ def test_against_oracle_random_batch_sizes():
 # geometry choice of mdt_launch_gemm): half-height 16 x 64 tiles (192 < M <= 1400 rows: B = 20 ... 140), the last batch before
 # / the first batch on the one-workgroup-per-sample middle + the fused MLP launch (1401 rows: B = 140 | 141), the second round
 # of per-sample workgroups (B = 257 ... 512), and the first batch beyond it (B = 513: k_attn + GEMM + k_xattn_apply again)
-# (round 5: B = 9 ... 16 run the self-attention inside its projection launch like the rollout batches -- B = 12, 16; B = 17 is the first
-#  batch back on k_attn + projection)
-REGIME_BATCHES = (12, 16, 17, 20, 64, 128, 140, 141, 257, 300, 512, 513)
+# (round 5: B = 9 ... 32 run the self-attention inside its projection launch like the rollout batches -- B = 12, 16, 20, 32; B = 33 is
+#  the first batch back on k_attn + projection)
+REGIME_BATCHES = (12, 16, 20, 32, 33, 64, 128, 140, 141, 257, 300, 512, 513)
 
 
 @pytest.mark.parametrize("B", REGIME_BATCHES)
