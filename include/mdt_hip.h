@@ -180,23 +180,6 @@ mdt_status mdt_sample_ddim_dev(mdt_model *m, const float *tokens, const float *t
                                int32_t modality, const float *x_T, const float *sigmas_dev, int32_t n_steps,
                                int64_t batch, float *out, float *ctx_out, void *stream);
 
-/* The step loop of mdt_sample_ddim[_dev] can run as ONE persistent kernel launch where the configuration allows it
- * (adaLN conditioning, collapsed cross-attention, linear head, no RoPE; batches <= 8 or >= 128).  OPT-IN
- * (an MDT_BUILD_PERSIST=1 build of the library, then MDT_HIP_PERSIST=1 or mdt_op_set_persist(1)): measured slower on MI355X
- * (DESIGN.md section 5b), so the launch sequence is the default.  Its inter-workgroup barriers are bounded: a launch that cannot complete (workgroups not spread
- * evenly over the XCDs, a barrier that times out) abandons itself and records a non-zero status in host-mapped memory.
- * mdt_persist_status reads that word without synchronising (0 = every launch so far completed; call it after the stream
- * has been synchronised to learn about the latest one); after a failure every further sampler call on the handle
- * returns MDT_ERR_HIP.  mdt_persist_launches: number of persistent launches enqueued on this handle so far. */
-int32_t mdt_persist_status(mdt_model *m);
-int64_t mdt_persist_launches(mdt_model *m);
-/* 1 if this build of the library carries the persistent kernel (MDT_BUILD_PERSIST=1 at build time, -DMDT_WITH_PERSIST), 0 if
- * the entry points around it are stubs: the switch below is then accepted and ignored, every call takes the launch sequence. */
-int32_t mdt_persist_built(void);
-/* Process-wide switch for A/B runs and tests: 0 = always the launch sequence, 1 = the persistent kernel where supported,
- * negative = follow the environment (MDT_HIP_PERSIST, default 0). */
-void mdt_op_set_persist(int32_t mode);
-
 /* GCDenoiser.loss(state, action, goal, noise, sigma) forward value, eval mode (reference
  * score_wrappers.py:45-63): noised = a + n*sigma; F = inner(noised*c_in); target = (a - c_skip*noised)/c_out;
  * loss = mean((F - target)^2) over all B*Ta*A elements.  loss_out: 1 float (device); model_output: (B,Ta,A). */

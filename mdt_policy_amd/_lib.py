@@ -172,13 +172,9 @@ SYMBOLS = [
     ("mdt_forward", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _I64, _VP, _VP, _VP]),
     ("mdt_sample_ddim", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, C.POINTER(C.c_float), _I32, _I64, _VP, _VP, _VP]),
     ("mdt_sample_ddim_dev", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _I32, _I64, _VP, _VP, _VP]),
-    ("mdt_persist_status", _I32, [_VP]),
-    ("mdt_persist_launches", _I64, [_VP]),
-    ("mdt_persist_built", _I32, []),
     ("mdt_op_trace_mlp", None, [_I32]),
     ("mdt_op_trace_mlp_read", _I32, [_VP, _I32]),
     ("mdt_op_trace_mlp_read_empty", _I32, [_VP, _I32]),
-    ("mdt_op_set_persist", None, [_I32]),
     ("mdt_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     ("mdt_flops_per_chunk", C.c_double, [_VP, _I32]),
     ("mdt_fnv1_32", C.c_uint32, [C.c_char_p, C.c_uint64, C.c_uint32]),
@@ -225,6 +221,8 @@ SYMBOLS = [
     ("mdt_op_attn_fwd_train", _I32, [C.POINTER(AttnTrainArgs), _VP]),
     ("mdt_op_merge_fwd", _I32, [C.POINTER(MergeArgs), _VP]),
     ("mdt_op_merge_bwd", _I32, [C.POINTER(MergeArgs), _VP]),
+    ("mdt_op_merge_ln_fwd", _I32, [C.POINTER(MergeArgs), C.POINTER(LnTrainArgs), _VP]),
+    ("mdt_op_ln_bwd_merge", _I32, [C.POINTER(LnBwdArgs), C.POINTER(MergeArgs), _VP]),
     ("mdt_op_colsum", _I32, [_VP, _I64, _I64, _I64, _VP, _I32, _VP]),
     ("mdt_op_linear_bwd", _I32, [C.POINTER(LinearBwdArgs), _VP]),
     ("mdt_op_linear_bwd_scratch", _I64, [_I64, _I64, _I64]),

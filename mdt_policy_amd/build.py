@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libmdt_hip.so")
-SOURCES = ["mdt_kernels.hip", "mdt_persist.hip", "mdt_model.hip", "mdt_resampler.hip", "mdt_map_pool.hip", "mdt_mae.hip", "mdt_infonce.hip", "mdt_train_kernels.hip", "mdt_train_ops.hip", "mdt_train.hip"]
+SOURCES = ["mdt_kernels.hip", "mdt_model.hip", "mdt_resampler.hip", "mdt_map_pool.hip", "mdt_mae.hip", "mdt_infonce.hip", "mdt_train_kernels.hip", "mdt_train_ops.hip", "mdt_train.hip"]
 ARCH = "gfx950"
 
 
@@ -29,13 +29,13 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_tall.h", "mdt_ws.h", "mdt_persist.h"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_tall.h", "mdt_ws.h"]]
     deps += [os.path.join(INCLUDE, f) for f in ("mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h")]
     deps.append(os.path.abspath(__file__))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-HEADERS = ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_tall.h", "mdt_ws.h", "mdt_persist.h"]
+HEADERS = ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_tall.h", "mdt_ws.h"]
 PUBLIC_HEADERS = ["mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h"]
 
 
@@ -63,8 +63,6 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, d
     if out is None and not force and not needs_build():
         return LIB
     out = out or LIB
-    if os.environ.get("MDT_BUILD_PERSIST", "0") not in ("", "0"):  # opt-in: the persistent decoder kernel (mdt_persist.hip)
-        defines = tuple(defines) + ("MDT_WITH_PERSIST",)
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     tag = hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:8] if defines else "default"

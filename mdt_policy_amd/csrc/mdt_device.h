@@ -237,8 +237,12 @@ __device__ __forceinline__ float xrow_sum(float v) {
 // (element index, site id).  The backward regenerates the mask from the same (seed, site, index), so no mask is
 // ever stored.  keep(element) <=> uniform >= p; kept values are scaled by 1 / (1 - p) (nn.Dropout / SDPA dropout_p).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint32_t site, uint64_t idx) {
-    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = site, c3 = 0x9e3779b9u;
+// One Philox4x32-10 block: the four 32-bit words of counter `ctr` under (seed, site).  Element idx of a site takes word
+// idx & 3 of block idx >> 2 (round 6; rounds 1-5 ran a whole block per element and kept one word: ~100 integer instructions per
+// dropped-out value, as much as the branch-merge kernels' memory time), so 16-byte accesses pay one block per four elements.
+struct philox4_t { uint32_t w[4]; };
+__device__ __forceinline__ philox4_t philox4(uint64_t seed, uint32_t site, uint64_t ctr) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = site, c3 = 0x9e3779b9u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -247,11 +251,21 @@ __device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint32_t site, uin
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    return philox4_t{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ float dropout_keep(uint32_t word, float p) {   // [0, 1) on a 24-bit grid against p
+    return (float)(word >> 8) * (1.0f / 16777216.0f) >= p ? 1.0f / (1.0f - p) : 0.f;
 }
 // multiplier of element idx: 0 (dropped) or 1 / (1 - p); p == 0 or seed == 0 -> 1
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t site, uint64_t idx, float p) {
     if (p <= 0.f || seed == 0) return 1.f;
-    const float u = (float)(philox_u32(seed, site, idx) >> 8) * (1.0f / 16777216.0f);  // [0, 1) on a 24-bit grid
-    return u >= p ? 1.0f / (1.0f - p) : 0.f;
+    const philox4_t r = philox4(seed, site, idx >> 2);
+    const unsigned e = (unsigned)idx & 3u;
+    return dropout_keep(e == 0 ? r.w[0] : (e == 1 ? r.w[1] : (e == 2 ? r.w[2] : r.w[3])), p);
+}
+// the multipliers of elements idx .. idx + 3, idx a multiple of 4: one block
+__device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, uint32_t site, uint64_t idx, float p) {
+    if (p <= 0.f || seed == 0) return (f32x4){1.f, 1.f, 1.f, 1.f};
+    const philox4_t r = philox4(seed, site, idx >> 2);
+    return (f32x4){dropout_keep(r.w[0], p), dropout_keep(r.w[1], p), dropout_keep(r.w[2], p), dropout_keep(r.w[3], p)};
 }

@@ -90,6 +90,8 @@ hipError_t mdt_gemm_side_push(const mdt_gemm_args& a, hipStream_t s);
 hipError_t mdt_gemm_side_push_front(const mdt_gemm_args& a, hipStream_t s);
 hipError_t mdt_gemm_side_flush(hipStream_t s);
 void mdt_gemm_side_drop();
+size_t mdt_gemm_side_pending();                       // jobs still queued on this host thread
+hipError_t mdt_gemm_side_launch_front(hipStream_t s);  // the head of the queue as a launch of its own
 hipError_t mdt_launch_layernorm(const float* in, const float* w, const float* b, float* out, int M, int D,
                                 hipStream_t s, float* out2 = nullptr);
 hipError_t mdt_launch_sigma_emb(const float* sigma, int64_t sstride, const float* freqs, float* out, int R, int D,
@@ -159,6 +161,9 @@ hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int
                               int accumulate, hipStream_t s);
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);
 hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s);
+// fused pairs of the training path (round 6): LayerNorm backward + the merge backward behind it; merge + the LayerNorm of its result
+hipError_t mdt_launch_ln_bwd_merge(const mdt_ln_bwd_args& a, const mdt_merge_args& g, hipStream_t s);
+hipError_t mdt_launch_merge_ln_fwd(const mdt_merge_args& g, const mdt_ln_train_args& l, hipStream_t s);
 hipError_t mdt_launch_act_fwd(const float* u, float* out, int64_t n, int act, hipStream_t s);
 hipError_t mdt_launch_act_bwd(const float* u, const float* dy, float* du, int64_t n, int act, hipStream_t s);
 hipError_t mdt_launch_merge_fwd(const mdt_merge_args& a, hipStream_t s);

@@ -17,6 +17,8 @@
 //     modulation fused into the staging pass and bias / GELU / Mish / SiLU / gate * residual fused into
 //     the epilogue.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -28,7 +30,7 @@
 #include "mdt_device.h"
 
 #define MDT_TILES_TIMING_OWNER  // this translation unit owns the -DMDT_DEBUG_TIMING stamp buffer
-#include "mdt_tiles.h"  // the tile bodies (shared with the persistent decoder kernel, mdt_persist.hip)
+#include "mdt_tiles.h"  // the tile bodies
 #include "mdt_tall.h"  // the tall LDS-staged GEMM body (round 4)
 #include "mdt_ws.h"    // the weight-stationary GEMM body (round 5)
 
@@ -498,6 +500,21 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws(mdt_gemm_args a, int ti
 static int ws_shape(const mdt_gemm_args& a) {
     static int w12 = -1;  // MDT_HIP_WS_WAVES=8: the 8-wave shape everywhere (A/B runs)
     if (w12 < 0) { const char* e = getenv("MDT_HIP_WS_WAVES"); w12 = e && atoi(e) == 8 ? 0 : 1; }
+    if (a.K == 384) {
+        // one column tile per wave: 128- (8 waves) or 192-column (12 waves) panels.  One round of one workgroup per CU either way;
+        // what differs is how evenly the row tiles divide: cost ~ tiles per workgroup x waves (a SIMD's waves share its matrix pipe).
+        // M = 10240: N = 384 -> 8 waves (3 panels x 80 chunks x 4 tiles), N = 1152 / 1536 -> 12 waves (6 x 40 x 8 / 8 x 32 x 10)
+        const int ntiles = (a.M + 31) / 32;
+        int best = 0, best_cost = 0;
+        for (int nw : {12, 8}) {
+            if ((nw == 12 && !w12) || a.N % (nw * 16)) continue;
+            const int panels = a.N / (nw * 16), groups = std::max(1, std::min(256 / (8 * panels), (ntiles + 7) / 8));
+            if (8 * panels > 256) continue;
+            const int tiles = (ntiles + 8 * groups - 1) / (8 * groups), cost = tiles * nw;
+            if (!best || cost < best_cost) { best = nw; best_cost = cost; }
+        }
+        return best;
+    }
     // 384-column panels, three waves per SIMD, 4 / 2 panels x 64 / 128 row chunks = 256 workgroups: the per-tile epilogue + barrier is
     // amortised over 18.4 k instead of 12.3 k clocks of MFMA issue and all 256 CUs work (SwishGLU forward 601 -> 544 us, plain 272 -> 248).
     // Not for the SwishGLU backward epilogue: at 168 VGPRs its u operands cannot be requested a tile ahead (348 -> 448 us)
@@ -505,10 +522,14 @@ static int ws_shape(const mdt_gemm_args& a) {
     return a.N % 256 == 0 ? 8 : 0;
 }
 bool mdt_gemm_ws_supported(const mdt_gemm_args& a) {
+    static int k384 = -1;  // MDT_HIP_WS384=0: the K = 384 products stay on the row tiles / the tall body (A/B runs)
+    if (k384 < 0) { const char* e = getenv("MDT_HIP_WS384"); k384 = e ? atoi(e) : 1; }
+    const bool common = !a.ln && a.a_parts <= 1 && a.batch <= 1 && a.M >= 32 && (a.lda & 3) == 0 && (a.ldo & 3) == 0 && !a.residual &&
+                        a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr && (int64_t)a.N * a.K < ((int64_t)1 << 30);
+    if (a.K == 384)   // plain rows, or an activation / the training hooks on the epilogue (GLU = 1 instantiation)
+        return k384 && common && (a.aux_mode == 0 || ((a.aux_mode == 1 || a.aux_mode == 2) && a.aux != nullptr)) && ws_shape(a) != 0;
     const bool mode_ok = a.aux_mode == 0 || ((a.aux_mode == 3 || a.aux_mode == 4) && a.aux != nullptr);
-    return !a.ln && a.a_parts <= 1 && a.batch <= 1 && a.K == 192 && ws_shape(a) != 0 && a.M >= 32 &&
-           (a.lda & 3) == 0 && (a.ldo & 3) == 0 && !a.residual && a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr &&
-           a.act == MDT_ACT_NONE && mode_ok && (int64_t)a.N * a.K < ((int64_t)1 << 30);
+    return common && a.K == 192 && ws_shape(a) != 0 && a.act == MDT_ACT_NONE && mode_ok;
 }
 template <int K16, int GLU, int NW, int NTW>
 static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
@@ -528,6 +549,11 @@ static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
     return hipGetLastError();
 }
 static hipError_t launch_gemm_ws(const mdt_gemm_args& a, hipStream_t s) {
+    if (a.K == 384) {
+        const bool hooks = a.aux_mode != 0 || a.act != MDT_ACT_NONE;
+        if (ws_shape(a) == 12) return hooks ? launch_gemm_ws_t<24, 1, 12, 1>(a, s) : launch_gemm_ws_t<24, 0, 12, 1>(a, s);
+        return hooks ? launch_gemm_ws_t<24, 1, 8, 1>(a, s) : launch_gemm_ws_t<24, 0, 8, 1>(a, s);
+    }
     if (ws_shape(a) == 12) return a.aux_mode == 3 ? launch_gemm_ws_t<12, 3, 12, 2>(a, s) : launch_gemm_ws_t<12, 0, 12, 2>(a, s);
     if (a.aux_mode == 3) return launch_gemm_ws_t<12, 3, 8, 2>(a, s);
     if (a.aux_mode == 4) return launch_gemm_ws_t<12, 4, 8, 2>(a, s);
@@ -745,15 +771,17 @@ static bool smallm_shape_ok(const mdt_gemm_args& a) {
     return a.M >= 1 && a.M <= 15 && (!a.ln || a.K <= 512) && a.batch <= 1 && a.K <= 4096 && !a.aux_mode && a.a_parts <= 1 &&
            a.N <= ZEROS_FLOATS && a.K <= ZEROS_FLOATS && !(a.N & 15) && (int64_t)a.N * a.K < ((int64_t)1 << 30);
 }
-static int g_side_override = -1;        // mdt_op_set_side_jobs (tests / A-B runs): 0 = off, 1 = on, -1 = the environment's choice
-static int64_t g_side_paired = 0;       // launches that took a side job along (mdt_op_side_jobs_paired)
+// process-wide (the queue itself is per host thread): atomics, host threads may drive different handles side by side
+static std::atomic<int> g_side_override{-1};     // mdt_op_set_side_jobs (tests / A-B runs): 0 = off, 1 = on, -1 = the environment's choice
+static std::atomic<int64_t> g_side_paired{0};    // launches that took a side job along (mdt_op_side_jobs_paired)
 static bool side_enabled() {
     static int v = -1;  // MDT_HIP_SIDE_JOBS=0: every product its own launch (A/B runs)
     if (v < 0) { const char* e = getenv("MDT_HIP_SIDE_JOBS"); v = e ? atoi(e) : 1; }
-    return (g_side_override >= 0 ? g_side_override != 0 : v != 0) && g_mdt_gemm_force == 0;
+    const int ov = g_side_override.load(std::memory_order_relaxed);
+    return (ov >= 0 ? ov != 0 : v != 0) && g_mdt_gemm_force == 0;
 }
-extern "C" void mdt_op_set_side_jobs(int32_t on) { g_side_override = on < 0 ? -1 : (on != 0); }
-extern "C" int64_t mdt_op_side_jobs_paired(void) { return g_side_paired; }
+extern "C" void mdt_op_set_side_jobs(int32_t on) { g_side_override.store(on < 0 ? -1 : (on != 0)); }
+extern "C" int64_t mdt_op_side_jobs_paired(void) { return g_side_paired.load(); }
 hipError_t mdt_gemm_side_push(const mdt_gemm_args& a, hipStream_t s) {
     if (!side_enabled() || !smallm_shape_ok(a)) return mdt_launch_gemm(a, s);
     g_side_jobs.push_back(a);
@@ -765,6 +793,20 @@ hipError_t mdt_gemm_side_push_front(const mdt_gemm_args& a, hipStream_t s) {   /
     return hipSuccess;
 }
 void mdt_gemm_side_drop() { g_side_jobs.clear(); g_side_next = 0; }   // error paths: forget what was queued
+size_t mdt_gemm_side_pending() { return g_side_jobs.size() - g_side_next; }
+hipError_t mdt_gemm_side_launch_front(hipStream_t s) {   // the head of the queue as a launch of its own, the rest stays queued
+    if (g_side_next >= g_side_jobs.size()) return hipSuccess;
+    const mdt_gemm_args a = g_side_jobs[g_side_next];
+    g_side_jobs.erase(g_side_jobs.begin() + g_side_next);
+    std::vector<mdt_gemm_args> keep;   // hidden while the job is launched: it must not take its successor along
+    keep.swap(g_side_jobs);
+    const size_t next = g_side_next;
+    g_side_next = 0;
+    const hipError_t e = mdt_launch_gemm(a, s);
+    g_side_jobs.swap(keep);
+    g_side_next = next;
+    return e;
+}
 hipError_t mdt_gemm_side_flush(hipStream_t s) {
     // the rest of the queue, each job as a launch of its own: the queue is emptied FIRST (a job launched from here must not take
     // its successor -- which may depend on it -- along)
@@ -890,7 +932,7 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
     {
         static int ws = -1;
         if (ws < 0) { const char* e = getenv("MDT_HIP_WS"); ws = e ? atoi(e) : 1; }
-        if (ws && a.M >= 8192 && a.aux_mode == 0 && g_mdt_gemm_force <= 0 && mdt_gemm_ws_supported(a)) return launch_gemm_ws(a, s);
+        if (ws && a.M >= 8192 && (a.aux_mode == 0 || a.K == 384) && g_mdt_gemm_force <= 0 && mdt_gemm_ws_supported(a)) return launch_gemm_ws(a, s);
     }
     {
         static int gt = -1;

@@ -108,7 +108,6 @@ hipError_t mdt_dev_free(void* p) {
 extern "C" const char* mdt_version(void) { return "mdt_hip 0.1 (gfx950, v_mfma_f32_16x16x4_f32)"; }
 
 #include "mdt_model_types.h"
-#include "mdt_persist.h"
 
 static const int MAX_WAYS = 4;
 
@@ -411,7 +410,6 @@ extern "C" mdt_status mdt_destroy(mdt_model* m) {
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     mdt_train_free(m);
-    mdt_persist_free(m);
     (void)hipFree(m->arena);
     (void)hipFree(m->staging);
     (void)mdt_dev_free(m->ws);
@@ -869,6 +867,19 @@ static mdt_status run_sigma_mlp(mdt_model* m, const float* sigma, int64_t sstrid
     return MDT_OK;
 }
 
+// argument checks of every entry point that encodes a context (also run by mdt_sample_ddim BEFORE it enqueues anything, so
+// that an invalid-argument return leaves no device work behind)
+static mdt_status check_encode_args(const mdt_model* m, const float* tokens, const float* tokens2, const float* goal,
+                                    const float* ctx_out) {
+    if (!tokens || !goal) return fail(MDT_ERR_INVALID_ARG, "encode: null tokens/goal");
+    if (m->cfg.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "encode: MDT needs the gripper tokens");
+    if (m->p_row >= 0 && !tokens2)
+        return fail(MDT_ERR_INVALID_ARG, "encode: this handle was created with use_proprio; state_obs (tokens2) is required");
+    if (misaligned(tokens) || misaligned(goal) || misaligned(tokens2) || misaligned(ctx_out))
+        return fail(MDT_ERR_INVALID_ARG, "encode: pointers must be 16-byte aligned");
+    return MDT_OK;
+}
+
 // sigma / sstride: only read when the context starts with the sigma token (COND_TOKEN); sstride 0 = one sigma for
 // the whole batch, 1 = one per sample.
 static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tokens2, const float* goal, int modality,
@@ -877,14 +888,9 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     const mdt_config& c = m->cfg;
     const int D = m->D, Te = m->Te;
     const int t0 = m->sig_tok;  // context row of the goal token
-    if (!tokens || !goal) return fail(MDT_ERR_INVALID_ARG, "encode: null tokens/goal");
     if (t0 && !sigma)
         return fail(MDT_ERR_INVALID_ARG, "encode: use_ada_conditioning=False puts sigma into the context; sigma is required");
-    if (c.arch == MDT_ARCH_MDT && !tokens2) return fail(MDT_ERR_INVALID_ARG, "encode: MDT needs the gripper tokens");
-    if (m->p_row >= 0 && !tokens2)
-        return fail(MDT_ERR_INVALID_ARG, "encode: this handle was created with use_proprio; state_obs (tokens2) is required");
-    if (misaligned(tokens) || misaligned(goal) || misaligned(tokens2) || misaligned(ctx_out))
-        return fail(MDT_ERR_INVALID_ARG, "encode: pointers must be 16-byte aligned");
+    MDT_TRY(check_encode_args(m, tokens, tokens2, goal, ctx_out));
     MDT_TRY(check_loaded(m));
     MDT_TRY(mdt_reserve(m, B));
     m->cached_batch = 0;
@@ -898,6 +904,7 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     // rollout batches: the state-token embedding does not depend on the goal embedding -- it rides in the goal GEMM's launch
     // (mdt_gemm_side_push_front; both are small-M products then, so the goal GEMM below takes it along)
     const bool tok_side = c.arch == MDT_ARCH_MDTV && m->g_row >= 0 && B * m->n_tok <= 15;
+    const size_t side_before = mdt_gemm_side_pending();
     if (tok_side) {
         mdt_gemm_args a = gemm_args(tokens, m->O, m->tok, m->h_enc, D, (int)(B * m->n_tok));
         a.gin = m->n_tok; a.gout = Te; a.goff = m->tok_row;
@@ -917,6 +924,10 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
         a.gin = 1; a.gout = Te; a.goff = m->g_row; a.rowvec = pos0;
         LAUNCH(mdt_launch_gemm(a, s));
     }
+    // The goal product above normally took the queued token embedding along.  Where it did not (a goal width or an override
+    // -- MDT_HIP_SMALLM_MAX / _ROWS / _TILES -- that routes it away from the small-M kernel), the job must not stay at the head of
+    // the queue: the next small-M launch would be the encoder's first LayerNorm product, which READS the rows the job writes.
+    if (tok_side && mdt_gemm_side_pending() > side_before) LAUNCH(mdt_gemm_side_launch_front(s));
     // state tokens -> the rows after it                         (process_state_embeddings, :260 / mdt :300)
     if (c.arch == MDT_ARCH_MDTV) {
         if (!tok_side) {
@@ -1155,6 +1166,7 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
     // ---- cut the batch into sample-aligned slices (multiples of 16 samples = 5 row tiles) on separate streams ----
     int ways = per_step_ctx ? 1 : m->ways;  // the encoder works on whole-batch buffers
     while (ways > 1 && batch / ways < 32) --ways;
+    MDT_TRY(check_encode_args(m, tokens, tokens2, goal, ctx_out));  // before anything is enqueued
     MDT_TRY(check_loaded(m));
     MDT_TRY(mdt_reserve(m, batch));
     // per-step scalars, fp32 like the reference's 0-dim tensor math (gc_sampling.py:946-950):
@@ -1207,8 +1219,6 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
         LAUNCH(mdt_launch_action_embed(x_T + b0[w] * xs, m->steps + 3, 0, m->cfg.sigma_data, m->Wa, m->ba, V.y,
                                        (int)(nb * m->Ta), m->A, m->D, m->Ta, st[w]));
     }
-    if (!per_step_ctx && ways == 1 && mdt_persist_supported(m, batch))  // the whole step loop as ONE launch (mdt_persist.hip)
-        return mdt_persist_sample(m, batch, n_steps, x_T, out, s);
     for (int i = 0; i < n_steps; ++i) {
         const bool last = i == n_steps - 1;
         if (per_step_ctx)  // the reference leaves the LAST step's context in latent_encoder_emb

@@ -110,7 +110,6 @@ struct mdt_model {
     bool xfold = false;
     float *xU = nullptr, *xW = nullptr, *xc = nullptr;  // [Ld][cap][4 H * D] weight images (fragment order), same, [Ld][cap][4 H]
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    void* persist = nullptr;  // mdt_persist_state (mdt_persist.hip): the persistent decoder kernel's buffers
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 

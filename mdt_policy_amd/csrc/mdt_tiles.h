@@ -1,14 +1,14 @@
-// mdt_tiles.h -- the per-workgroup TILE BODIES of the decoder's kernels, shared by
-//   * mdt_kernels.hip : one launch per operation (grid = tiles), and
-//   * mdt_persist.hip : the persistent decoder kernel (one launch per sampler call; every XCD owns a slice of the
-//                       batch and walks the phase list, its workgroups meeting at a fence-free per-XCD barrier).
-// A body is written once; the template flag COH selects how ACTIVATIONS (anything another workgroup of the same launch
-// may have written) are read:
-//   COH = false : plain global loads (between launches the kernel boundary makes everything visible)
+// mdt_tiles.h -- the per-workgroup TILE BODIES of the decoder's kernels; mdt_kernels.hip wraps each in a one-launch-per-
+// operation kernel (grid = tiles).
+// A body is written once; the template flag COH selects how ACTIVATIONS are read:
+//   COH = false : plain global loads (between launches the kernel boundary makes everything visible) -- every shipped kernel
 //   COH = true  : `buffer_load_dwordx4 ... sc1` -- bypasses the reading CU's vector L1, which is never refreshed by
 //                 another CU's stores; served by the XCD's L2, where the producer's plain stores live once its
 //                 `s_waitcnt vmcnt(0)` has retired (MI355X_MICROARCH.md "inter-workgroup visibility";
 //                 tools/micro/persist_probe.hip: 0 stale words in 1500 phases x 32 peers x 16 KiB under uneven load).
+//                 What a body needs when it reads rows another workgroup of the SAME launch wrote.  The persistent decoder
+//                 kernel of rounds 2-4 (one launch per sampler call, per-XCD barriers between phases) was its one user; it
+//                 never beat the launch sequence (profiles/r02_persist_*, docs/history/) and was removed in round 6.
 // Weights, LayerNorm vectors and the modulation table are written before the launch and always read with plain loads.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -57,8 +57,7 @@ struct ActLd<true> {
     __amdgpu_buffer_rsrc_t rsrc;
     __device__ __forceinline__ explicit ActLd(const float* p)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0xffffffffu, 0x00020000)) {}
-    // 16 bytes at float offset `off`; off * 4 must stay below 4 GiB (checked by the host before it picks the
-    // persistent kernel)
+    // 16 bytes at float offset `off`; off * 4 must stay below 4 GiB
     __device__ __forceinline__ f32x4 ld4(int64_t off) const {
         const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(off << 2), 0, 16 /* sc1 */);
         return __builtin_bit_cast(f32x4, r);
@@ -655,7 +654,7 @@ __device__ __forceinline__ void attn_sample_tile(const mdt_attn_pro& ap, float* 
 //   Memory-level parallelism rule for every phase: all global loads of a phase are issued back to back from
 //   clamped (always valid) addresses, consumed afterwards; validity is applied by selects / masked stores.  A
 //   branch around a load makes hipcc wait vmcnt(0) right behind it -- one full L2 round trip per load.
-// No thread leaves early (the persistent kernel follows the tile with a barrier).
+// No thread leaves early (a caller may follow the tile with a barrier).
 // ------------------------------------------------------------------------------------------------
 // GLU (compile time; 0 in every kernel but k_gemm_glu): 3 = SwishGLU forward on this product's epilogue, 4 = SwishGLU backward
 // (mdt_gemm_args.aux_mode 3 / 4) -- their own instantiations, so that the plain kernels carry none of their code
@@ -1495,7 +1494,7 @@ __device__ __forceinline__ float edm_c_in(float sigma, float sd) { return 1.0f /
 // twice); AMAX (8 or 16) bounds the action dimension at compile time so no load sits behind a branch.
 // The caller guarantees base < a.M (wave-uniform).
 // ------------------------------------------------------------------------------------------------
-// RW = rows per wave: 2 in the persistent kernel (the fragments of action_pred / action_emb it fetches are used twice), 1 in
+// RW = rows per wave: 2 when the fragments of action_pred / action_emb a wave fetches should be used twice, 1 in
 // k_head (twice the waves, half the dot products per wave: the launch is a latency chain -- B = 256 sampler call 4.712 -> 4.686 ms,
 // four rows per wave 4.705).
 template <int AMAX, bool COH, int XP = 1, int RW = 2>

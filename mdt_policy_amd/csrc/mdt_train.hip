@@ -80,7 +80,33 @@ struct mdt_train_state {
     hipEvent_t scratch_done = nullptr;
     bool scratch_pending = false;
     std::vector<mdt_colsum_entry> deferred;
+    // Weight gradients beside the chain (round 6, MDT_HIP_DW_STREAM): the dW products of the blocks are leaves of the backward --
+    // nothing reads them before the optimizer -- so they run on a second stream, each behind an event that says its dY exists,
+    // while the chain (dX products, LayerNorm / attention backward) goes on.  Their dY operands then must outlive the chain's reuse
+    // of its scratch: in this mode every dY of a block lives in its own piece of `dy_arena` (no reuse inside one backward;
+    // ~1 GB at B = 1024, of 288).  The side stream has its own partial-product scratch.
+    hipStream_t side = nullptr;
+    hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, side_done = nullptr;
+    int side_ev_next = 0;
+    bool side_used = false;
+    float *dy_arena = nullptr, *lin_scratch2 = nullptr;
+    int64_t dy_cap = 0, dy_off = 0;
 };
+
+static int dw_stream_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_DW_STREAM"); v = e ? atoi(e) : 0; }
+    return v;
+}
+// a dY buffer of n floats: its own piece of the arena when the weight gradients run beside the chain, else `shared`
+static float* dy_take(mdt_train_state* ts, int64_t n, float* shared) {
+    if (!ts->dy_arena) return shared;
+    n = (n + 63) & ~(int64_t)63;
+    if (ts->dy_off + n > ts->dy_cap) return shared;  // (sized for one whole backward: not reached)
+    float* p = ts->dy_arena + ts->dy_off;
+    ts->dy_off += n;
+    return p;
+}
 
 static float* defer_take(mdt_train_state* ts, int64_t n) {
     n = (n + 3) & ~(int64_t)3;
@@ -108,6 +134,12 @@ static mdt_status scratch_leave(mdt_model* m, hipStream_t s) {
 
 static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
     mdt_train_state* ts = m->train;
+    if (ts->side_used) {  // the weight gradients that ran beside the chain (and their bias partials) before anything reads them
+        if (!ts->side_done) HIP_TRY(hipEventCreateWithFlags(&ts->side_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ts->side_done, ts->side));
+        HIP_TRY(hipStreamWaitEvent(s, ts->side_done, 0));
+        ts->side_used = false;
+    }
     // entries of one launch run concurrently: two sums into the same gradient (a parameter read twice) go to successive launches
     std::vector<mdt_colsum_entry>& d = ts->deferred;
     size_t lo = 0;
@@ -174,6 +206,9 @@ void mdt_train_free(mdt_model* m) {
     }
     (void)mdt_dev_free(t->scratch);
     if (t->scratch_done) (void)hipEventDestroy(t->scratch_done);
+    for (hipEvent_t e : t->side_ev) if (e) (void)hipEventDestroy(e);
+    if (t->side_done) (void)hipEventDestroy(t->side_done);
+    if (t->side) (void)hipStreamDestroy(t->side);
     (void)hipFree(t->wt_arena);
     for (const LinPart& p : m->parts) p.lin->wt = nullptr;
     delete t;
@@ -309,6 +344,14 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
     need = std::max(need, mdt_linear_bwd_scratch(B * m->n_tok, D, m->O));
     if (m->HP) need = std::max(need, mdt_linear_bwd_scratch(Ma, m->HP, D));
     ts->lin_scratch = b.take(need);
+    if (dw_stream_mode()) {
+        ts->lin_scratch2 = b.take(need);
+        // every dY of every block once: (3 + dec) x (M, D) merged gradients / dq, (M, 4D), (M, 3D) per block
+        ts->dy_cap = (int64_t)m->Le * Me * (3 + 4 + 3) * D + (int64_t)m->Ld * Ma * (4 + 4 + 3) * D + 64 * (int64_t)(m->Le + m->Ld) * 8 + 1024;
+        ts->dy_arena = b.take(ts->dy_cap);
+    } else {
+        ts->lin_scratch2 = nullptr; ts->dy_arena = nullptr; ts->dy_cap = 0;
+    }
     ts->dF = b.take(Ma * m->A);
     ts->small = b.take(std::max<int64_t>({B * 2 * D, Mx * (int64_t)std::max(m->O, m->G), (int64_t)16 * m->HP}));
 }
@@ -389,43 +432,72 @@ static void ln_cond(mdt_ln_train_args& l, const float* mod, int64_t modw, int sh
     l.mod = mod; l.mod_stride = modw; l.shift_off = sh; l.scale_off = sc; l.rows_per_sample = T;
 }
 
+// MDT_HIP_TRAIN_FUSE (A/B runs; default 3): bit 0 = every branch merge of the forward in one launch with the LayerNorm that
+// reads its result (k_merge_ln_fwd4), bit 1 = every LayerNorm backward in one launch with the merge backward behind it
+// (k_ln_bwd4<true>).  0 restores the separate launches of rounds 1-5; both forms give the same bits except the gate gradient's
+// summation order over a sample's rows.
+static int train_fuse() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_TRAIN_FUSE"); v = e ? atoi(e) : 3; }
+    return v;
+}
+
+// the first LayerNorm of a block (ln_1 on its input, conditioned as the block is)
+static mdt_ln_train_args block_ln1_args(mdt_model* m, const EncBlock& e, BlockTape& t, int64_t B, int T, int cond, const float* mod,
+                                        int64_t modw) {
+    const CondLayout c = cond_layout(mod ? cond : COND_TOKEN, m->D);
+    mdt_ln_train_args l1 = ln_args(t.x_in, e.ln1_w, e.ln1_b, t.h1, t.st1, (int)(B * T), m->D);
+    ln_cond(l1, mod, modw, c.sh1, c.sc1, T);
+    return l1;
+}
+
+// merge g, then LayerNorm l on its result: one launch or two (train_fuse)
+static mdt_status merge_then_ln(const mdt_merge_args& g, const mdt_ln_train_args& l, hipStream_t s) {
+    if (train_fuse() & 1) { LAUNCH(mdt_launch_merge_ln_fwd(g, l, s)); return MDT_OK; }
+    LAUNCH(mdt_launch_merge_fwd(g, s));
+    LAUNCH(mdt_launch_ln_fwd_train(l, s));
+    return MDT_OK;
+}
+
 // one block forward; mod == nullptr: plain Block, else conditioned by the rows of `mod` (stride modw) as `cond` lays
 // them out.  `blk` numbers the block for the dropout sites (encoder blocks first, then decoder blocks).
+// ln1_done: the block's first LayerNorm already ran (in the launch of the previous block's last merge); tail_ln: the LayerNorm
+// that reads this block's output (the next block's ln_1 or the stack's final LayerNorm) -- it rides in the last merge's launch.
 static mdt_status block_fwd(mdt_model* m, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T, bool causal,
                             int cond, const float* mod, int64_t modw, const float* kv, const mdt_dropout& dr, int blk,
-                            hipStream_t s) {
+                            hipStream_t s, bool ln1_done = false, const mdt_ln_train_args* tail_ln = nullptr) {
     const int D = m->D, M = (int)(B * T);
     const CondLayout c = cond_layout(mod ? cond : COND_TOKEN, D);
-    mdt_ln_train_args l1 = ln_args(t.x_in, e.ln1_w, e.ln1_b, t.h1, t.st1, M, D);
-    ln_cond(l1, mod, modw, c.sh1, c.sc1, T);
-    LAUNCH(mdt_launch_ln_fwd_train(l1, s));
+    if (!ln1_done) LAUNCH(mdt_launch_ln_fwd_train(block_ln1_args(m, e, t, B, T, cond, mod, modw), s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.h1, D, e.qkv, t.qkv, 3 * D, M), s));
     MDT_TRY(attn_fwd(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, t.att, B, T, T, causal, dr, site_id(blk, SITE_ATTN), s));
     LAUNCH(mdt_launch_gemm(gemm_args(t.att, D, e.proj, t.a1, D, M), s));
-    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x_in, t.a1, c.g1 >= 0 ? mod + c.g1 : nullptr, modw, t.x1, B, T, D, dr.resid_p,
-                                           site_id(blk, SITE_RESID), dr.seed), s));
+    const mdt_merge_args g1 = merge_args(t.x_in, t.a1, c.g1 >= 0 ? mod + c.g1 : nullptr, modw, t.x1, B, T, D, dr.resid_p,
+                                         site_id(blk, SITE_RESID), dr.seed);
+    mdt_ln_train_args l2 = ln_args(t.x2, e.ln2_w, e.ln2_b, t.h2, t.st2, M, D);
+    ln_cond(l2, mod, modw, c.sh2, c.sc2, T);
     if (d) {
         mdt_ln_train_args l3 = ln_args(t.x1, d->ln3_w, d->ln3_b, t.h3, t.st3, M, D);
         ln_cond(l3, mod, modw, c.sh3, -1, T);
-        LAUNCH(mdt_launch_ln_fwd_train(l3, s));
+        MDT_TRY(merge_then_ln(g1, l3, s));
         LAUNCH(mdt_launch_gemm(gemm_args(t.h3, D, d->xq, t.q, D, M), s));
         // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
         MDT_TRY(attn_fwd(m, t.q, D, kv, kv + D, (int64_t)m->Ld * 2 * D, t.att2, B, T, m->Te, true, dr, site_id(blk, SITE_XATTN), s));
         LAUNCH(mdt_launch_gemm(gemm_args(t.att2, D, d->xproj, t.a2, D, M), s));
-        LAUNCH(mdt_launch_merge_fwd(merge_args(t.x1, t.a2, nullptr, 0, t.x2, B, T, D, dr.resid_p, site_id(blk, SITE_XRESID),
-                                               dr.seed), s));
+        MDT_TRY(merge_then_ln(merge_args(t.x1, t.a2, nullptr, 0, t.x2, B, T, D, dr.resid_p, site_id(blk, SITE_XRESID), dr.seed), l2, s));
+    } else {
+        MDT_TRY(merge_then_ln(g1, l2, s));  // t.x2 == t.x1 in an encoder block
     }
-    mdt_ln_train_args l2 = ln_args(t.x2, e.ln2_w, e.ln2_b, t.h2, t.st2, M, D);
-    ln_cond(l2, mod, modw, c.sh2, c.sc2, T);
-    LAUNCH(mdt_launch_ln_fwd_train(l2, s));
     {   // c_fc and its GELU in one launch: the epilogue leaves the pre-activation u (the backward's operand) beside gelu(u)
         mdt_gemm_args g = gemm_args(t.h2, D, e.fc, t.hid, 4 * D, M);
         g.act = MDT_ACT_GELU; g.aux = t.u; g.aux_mode = 1;
         LAUNCH(mdt_launch_gemm(g, s));
     }
     LAUNCH(mdt_launch_gemm(gemm_args(t.hid, 4 * D, e.proj2, t.mo, D, M), s));
-    LAUNCH(mdt_launch_merge_fwd(merge_args(t.x2, t.mo, c.g2 >= 0 ? mod + c.g2 : nullptr, modw, t.x3, B, T, D, dr.mlp_p,
-                                           site_id(blk, SITE_MLP), dr.seed), s));
+    const mdt_merge_args g2 = merge_args(t.x2, t.mo, c.g2 >= 0 ? mod + c.g2 : nullptr, modw, t.x3, B, T, D, dr.mlp_p,
+                                         site_id(blk, SITE_MLP), dr.seed);
+    if (tail_ln) MDT_TRY(merge_then_ln(g2, *tail_ln, s));
+    else LAUNCH(mdt_launch_merge_fwd(g2, s));
     return MDT_OK;
 }
 
@@ -513,12 +585,14 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
     if (drop_lo >= 0)
         LAUNCH(mdt_launch_dropout_rows(x0, B * Te, D, Te, drop_lo, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_CTX),
                                        t.drop.seed, s));
+    for (int l = 1; l < m->Le; ++l) t.enc[l].x_in = t.enc[l - 1].x3;  // chain: a block's input is its predecessor's output buffer
+    const mdt_ln_train_args lf = ln_args(enc_last_output(m, t), m->enc_ln_w, m->enc_ln_b, t.ctx, t.st_f, (int)(B * Te), D);
     for (int l = 0; l < m->Le; ++l) {
-        if (l > 0) t.enc[l].x_in = t.enc[l - 1].x3;  // chain: a block's input is its predecessor's output buffer
-        MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, 0, nullptr, t.drop, l, s));
+        // the LayerNorm behind this block (the next block's ln_1, at the end the encoder's final one) rides in its last merge
+        const mdt_ln_train_args tail = l + 1 < m->Le ? block_ln1_args(m, m->enc[l + 1], t.enc[l + 1], B, Te, COND_TOKEN, nullptr, 0) : lf;
+        MDT_TRY(block_fwd(m, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, 0, nullptr, t.drop, l, s, l > 0, &tail));
     }
-    mdt_ln_train_args lf = ln_args(enc_last_output(m, t), m->enc_ln_w, m->enc_ln_b, t.ctx, t.st_f, (int)(B * Te), D);
-    LAUNCH(mdt_launch_ln_fwd_train(lf, s));
+    if (m->Le == 0) LAUNCH(mdt_launch_ln_fwd_train(lf, s));
     if (ctx_out) HIP_TRY(hipMemcpyAsync(ctx_out, t.ctx, (size_t)B * Te * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     return MDT_OK;
 }
@@ -546,15 +620,15 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     LAUNCH(mdt_launch_scaled_input(t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, t.xin, s));
     LAUNCH(mdt_launch_action_embed(t.xin, nullptr, 0, m->cfg.sigma_data, m->Wa, m->ba, t.y0, (int)Ma, A, D, Ta, s));
     LAUNCH(mdt_launch_dropout_rows(t.y0, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed, s));
-    for (int l = 0; l < m->Ld; ++l) {
-        t.dec[l].x_in = l == 0 ? t.y0 : t.dec[l - 1].x3;
-        MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond,
-                          m->cond == COND_TOKEN ? nullptr : t.mod + l * mod_blk, modw, t.kvx + (int64_t)l * 2 * D, t.drop,
-                          m->Le + l, s));
-    }
+    for (int l = 0; l < m->Ld; ++l) t.dec[l].x_in = l == 0 ? t.y0 : t.dec[l - 1].x3;
     float* xl = t.dec[m->Ld - 1].x3;
-    mdt_ln_train_args lh = ln_args(xl, m->dec_ln_w, m->dec_ln_b, t.lnout, t.st_h, (int)Ma, D);
-    LAUNCH(mdt_launch_ln_fwd_train(lh, s));
+    const mdt_ln_train_args lh = ln_args(xl, m->dec_ln_w, m->dec_ln_b, t.lnout, t.st_h, (int)Ma, D);
+    auto mod_of = [&](int l) { return m->cond == COND_TOKEN ? (const float*)nullptr : t.mod + l * mod_blk; };
+    for (int l = 0; l < m->Ld; ++l) {
+        const mdt_ln_train_args tail = l + 1 < m->Ld ? block_ln1_args(m, m->dec[l + 1], t.dec[l + 1], B, Ta, m->cond, mod_of(l + 1), modw) : lh;
+        MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond, mod_of(l), modw, t.kvx + (int64_t)l * 2 * D,
+                          t.drop, m->Le + l, s, l > 0, &tail));
+    }
     mdt_head_args h;
     memset(&h, 0, sizeof h);
     h.y = xl; h.ln_w = m->dec_ln_w; h.ln_b = m->dec_ln_b; h.Wp = m->Wp; h.bp = m->bp;
@@ -632,8 +706,10 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
 // backward
 // ------------------------------------------------------------------------------------------------
 // gradient slots of a (possibly stacked) Linear: every reference Linear inside `l`
+// beside: this product's dY lives in the arena (dy_take) -- its weight gradient may run on the side stream
 static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float* X, int64_t ldx, const float* dY, int64_t ldy,
-                          int M, float* dX, int64_t ldxo, int acc_dx, hipStream_t s, const float* act_u = nullptr, int act = 0) {
+                          int M, float* dX, int64_t ldxo, int acc_dx, hipStream_t s, const float* act_u = nullptr, int act = 0,
+                          bool beside = false) {
     mdt_train_state* ts = m->train;
     const LinPart* first = nullptr;  // the part at row 0: the stack's gradient region starts at its slot
     for (const LinPart& p : m->parts)
@@ -651,6 +727,25 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     a.dx_act_u = act_u; a.dx_act = act;
     mdt_colsum_entry be;
     float* space = a.dbias ? defer_take(ts, (int64_t)256 * l.N) : nullptr;
+    if (beside && a.dW && ts->dy_arena) {
+        // dW (+ bias partials) on the side stream behind "dY exists"; dX stays in the chain
+        if (!ts->side) HIP_TRY(hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking));
+        hipEvent_t& ev = ts->side_ev[ts->side_ev_next++ & 7];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, s));
+        HIP_TRY(hipStreamWaitEvent(ts->side, ev, 0));
+        mdt_linear_bwd_args w = a;
+        w.dX = nullptr; w.scratch = ts->lin_scratch2;
+        MDT_TRY(mdt_linear_bwd(w, ts->side, space ? &be : nullptr, space));
+        if (space && be.src) ts->deferred.push_back(be);
+        ts->side_used = true;
+        if (a.dX) {
+            mdt_linear_bwd_args x = a;
+            x.dW = nullptr; x.dbias = nullptr;
+            MDT_TRY(mdt_linear_bwd(x, s));
+        }
+        return MDT_OK;
+    }
     MDT_TRY(mdt_linear_bwd(a, s, space ? &be : nullptr, space));
     if (space && be.src) ts->deferred.push_back(be);
     return MDT_OK;
@@ -668,9 +763,11 @@ static float* grad_of(mdt_model* m, float* grads, const float* param) {
 }
 
 // LayerNorm backward + reduction of the per-sample weight/bias partials into the gradient slots
+// mg: the backward of the branch merge that follows in the backward order, on the gradient this call leaves in dx (its
+// `x`): rides in the same launch (train_fuse bit 1) or runs behind it
 static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float* stats, const float* w, const float* b,
                          const float* mod, int64_t modw, int shift_off, int scale_off, const float* dh, float* dx, int acc,
-                         float* d_mod, int64_t B, int T, hipStream_t s, int acc_dmod = 0) {
+                         float* d_mod, int64_t B, int T, hipStream_t s, int acc_dmod = 0, const mdt_merge_args* mg = nullptr) {
     mdt_train_state* ts = m->train;
     mdt_ln_bwd_args a;
     memset(&a, 0, sizeof a);
@@ -684,7 +781,12 @@ static mdt_status ln_bwd(mdt_model* m, float* grads, const float* x, const float
     const bool deferred = pw && (!b || pb);
     a.pw = deferred ? pw : ts->pw; a.pb = b ? (deferred ? pb : ts->pb) : nullptr;
     a.B = (int)B; a.rows_per_sample = T; a.D = m->D;
-    LAUNCH(mdt_launch_ln_bwd(a, s));
+    if (mg && (train_fuse() & 2)) {
+        LAUNCH(mdt_launch_ln_bwd_merge(a, *mg, s));
+    } else {
+        LAUNCH(mdt_launch_ln_bwd(a, s));
+        if (mg) LAUNCH(mdt_launch_merge_bwd(*mg, s));
+    }
     if (!grads) return MDT_OK;
     if (deferred) {
         ts->deferred.push_back(mdt_colsum_entry{pw, grad_of(m, grads, w), (int64_t)m->D, (int)B, m->D, 1});
@@ -709,50 +811,66 @@ static mdt_attn_bwd_args attn_bwd_args(mdt_model* m, const float* q, int64_t ldq
     return a;
 }
 
+// backward of a block's LAST merge (the MLP branch): d_mo = mask/(1-p) * gate_mlp * dx -> ts->t_d2, d_gate_mlp -> d_mod
+static mdt_merge_args block_mlp_merge_bwd(mdt_model* m, BlockTape& t, int64_t B, int T, int cond, const float* mod, float* d_mod,
+                                          int64_t modw, float* dx, const mdt_dropout& dr, int blk) {
+    const CondLayout c = cond_layout(mod ? cond : COND_TOKEN, m->D);
+    mdt_merge_args g = merge_args(dx, t.mo, c.g2 >= 0 ? mod + c.g2 : nullptr, modw,
+                                  dy_take(m->train, B * T * m->D, m->train->t_d2), B, T, m->D, dr.mlp_p, site_id(blk, SITE_MLP), dr.seed);
+    if (c.g2 >= 0) { g.dgate = d_mod + c.g2; g.dgate_stride = modw; }
+    return g;
+}
+
 // dx: gradient wrt the block's output on entry, wrt its input on return (in place)
 // d_mod mirrors mod (same stride and offsets); NoiseBlock: every LayerNorm ADDS its d_shift into the one d_c row.
+// Buffers: every sublayer finds its merged branch gradient in a dY buffer (ts->t_d2, or its own piece of the arena when the
+// weight gradients run beside the chain) and leaves the gradient of its LayerNorm output in ts->t_d; the LayerNorm backward that
+// consumes it also runs the NEXT sublayer's merge backward.
+// gm: this block's MLP-merged gradient -- the caller's preceding LayerNorm backward ran block_mlp_merge_bwd into it;
+// tail_merge: the merge backward that follows this block in the backward order (the previous block's MLP merge).
 static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T,
                             bool causal, int cond, const float* mod, float* d_mod, int64_t modw, const float* kv, float* d_kv,
-                            float* dx, const mdt_dropout& dr, int blk, hipStream_t s) {
+                            float* dx, const mdt_dropout& dr, int blk, hipStream_t s, const float* gm,
+                            const mdt_merge_args* tail_merge = nullptr) {
     mdt_train_state* ts = m->train;
     const int D = m->D, M = (int)(B * T);
+    const int64_t MD = (int64_t)M * D;
     const CondLayout c = cond_layout(mod ? cond : COND_TOKEN, D);
     const int acc_dmod = cond == COND_NOISE;
+    const bool bs = true;  // dY buffers below come from dy_take
+    // the self-attention branch's merge: x1 = x_in + g1 * drop(a1)
+    float* g_self = dy_take(ts, MD, ts->t_d2);
+    mdt_merge_args gs = merge_args(dx, t.a1, c.g1 >= 0 ? mod + c.g1 : nullptr, modw, g_self, B, T, D, dr.resid_p,
+                                   site_id(blk, SITE_RESID), dr.seed);
+    if (c.g1 >= 0) { gs.dgate = d_mod + c.g1; gs.dgate_stride = modw; }
     // ---- MLP half: x3 = x2 + g2 * drop(c_proj(gelu(c_fc(h2))))
-    {
-        mdt_merge_args g = merge_args(dx, t.mo, c.g2 >= 0 ? mod + c.g2 : nullptr, modw, ts->t_d, B, T, D, dr.mlp_p,
-                                      site_id(blk, SITE_MLP), dr.seed);
-        if (c.g2 >= 0) { g.dgate = d_mod + c.g2; g.dgate_stride = modw; }
-        LAUNCH(mdt_launch_merge_bwd(g, s));
-    }
     // d_u = (d_mo W_proj) * gelu'(u): the GELU backward is the epilogue of c_proj's input-gradient product
-    MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, ts->t_d, D, M, ts->t_4d, 4 * D, 0, s, t.u, MDT_ACT_GELU));
-    MDT_TRY(lin_bwd(m, grads, e.fc, t.h2, D, ts->t_4d, 4 * D, M, ts->t_d2, D, 0, s));
-    MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, c.sh2, c.sc2, ts->t_d2, dx, 1, d_mod, B, T, s, acc_dmod));
+    float* d_u = dy_take(ts, 4 * MD, ts->t_4d);
+    MDT_TRY(lin_bwd(m, grads, e.proj2, t.hid, 4 * D, gm, D, M, d_u, 4 * D, 0, s, t.u, MDT_ACT_GELU, bs));
+    MDT_TRY(lin_bwd(m, grads, e.fc, t.h2, D, d_u, 4 * D, M, ts->t_d, D, 0, s, nullptr, 0, bs));
     if (d) {
         // ---- cross-attention half: x2 = x1 + drop(c_proj(attn(q(ln3(x1)), K, V)))
-        LAUNCH(mdt_launch_merge_bwd(merge_args(dx, t.a2, nullptr, 0, ts->t_d2, B, T, D, dr.resid_p, site_id(blk, SITE_XRESID),
-                                               dr.seed), s));
-        MDT_TRY(lin_bwd(m, grads, d->xproj, t.att2, D, ts->t_d2, D, M, ts->t_d, D, 0, s));
-        LAUNCH(mdt_launch_attn_bwd(attn_bwd_args(m, t.q, D, kv, kv + D, (int64_t)m->Ld * 2 * D, ts->t_d, ts->t_d2, D, d_kv,
+        float* g_x = dy_take(ts, MD, ts->t_d2);
+        const mdt_merge_args gx = merge_args(dx, t.a2, nullptr, 0, g_x, B, T, D, dr.resid_p, site_id(blk, SITE_XRESID), dr.seed);
+        MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, c.sh2, c.sc2, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod, &gx));
+        MDT_TRY(lin_bwd(m, grads, d->xproj, t.att2, D, g_x, D, M, ts->t_d, D, 0, s, nullptr, 0, bs));
+        float* d_q = dy_take(ts, MD, ts->t_d2);
+        LAUNCH(mdt_launch_attn_bwd(attn_bwd_args(m, t.q, D, kv, kv + D, (int64_t)m->Ld * 2 * D, ts->t_d, d_q, D, d_kv,
                                                  d_kv + D, (int64_t)m->Ld * 2 * D, B, T, m->Te, true, dr,
                                                  site_id(blk, SITE_XATTN)), s));
-        MDT_TRY(lin_bwd(m, grads, d->xq, t.h3, D, ts->t_d2, D, M, ts->t_d, D, 0, s));
-        MDT_TRY(ln_bwd(m, grads, t.x1, t.st3, d->ln3_w, d->ln3_b, mod, modw, c.sh3, -1, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod));
+        MDT_TRY(lin_bwd(m, grads, d->xq, t.h3, D, d_q, D, M, ts->t_d, D, 0, s, nullptr, 0, bs));
+        MDT_TRY(ln_bwd(m, grads, t.x1, t.st3, d->ln3_w, d->ln3_b, mod, modw, c.sh3, -1, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod, &gs));
+    } else {
+        MDT_TRY(ln_bwd(m, grads, t.x2, t.st2, e.ln2_w, e.ln2_b, mod, modw, c.sh2, c.sc2, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod, &gs));
     }
     // ---- self-attention half: x1 = x_in + g1 * drop(c_proj(attn(qkv(h1))))
-    {
-        mdt_merge_args g = merge_args(dx, t.a1, c.g1 >= 0 ? mod + c.g1 : nullptr, modw, ts->t_d, B, T, D, dr.resid_p,
-                                      site_id(blk, SITE_RESID), dr.seed);
-        if (c.g1 >= 0) { g.dgate = d_mod + c.g1; g.dgate_stride = modw; }
-        LAUNCH(mdt_launch_merge_bwd(g, s));
-    }
-    MDT_TRY(lin_bwd(m, grads, e.proj, t.att, D, ts->t_d, D, M, ts->t_d2, D, 0, s));
-    LAUNCH(mdt_launch_attn_bwd(attn_bwd_args(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, ts->t_d2, ts->t_3d, 3 * D,
-                                             ts->t_3d + D, ts->t_3d + 2 * D, 3 * D, B, T, T, causal, dr, site_id(blk, SITE_ATTN)),
+    MDT_TRY(lin_bwd(m, grads, e.proj, t.att, D, g_self, D, M, ts->t_d, D, 0, s, nullptr, 0, bs));
+    float* d_qkv = dy_take(ts, 3 * MD, ts->t_3d);
+    LAUNCH(mdt_launch_attn_bwd(attn_bwd_args(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, ts->t_d, d_qkv, 3 * D,
+                                             d_qkv + D, d_qkv + 2 * D, 3 * D, B, T, T, causal, dr, site_id(blk, SITE_ATTN)),
                                s));
-    MDT_TRY(lin_bwd(m, grads, e.qkv, t.h1, D, ts->t_3d, 3 * D, M, ts->t_d, D, 0, s));
-    MDT_TRY(ln_bwd(m, grads, t.x_in, t.st1, e.ln1_w, e.ln1_b, mod, modw, c.sh1, c.sc1, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod));
+    MDT_TRY(lin_bwd(m, grads, e.qkv, t.h1, D, d_qkv, 3 * D, M, ts->t_d, D, 0, s, nullptr, 0, bs));
+    MDT_TRY(ln_bwd(m, grads, t.x_in, t.st1, e.ln1_w, e.ln1_b, mod, modw, c.sh1, c.sc1, ts->t_d, dx, 1, d_mod, B, T, s, acc_dmod, tail_merge));
     return MDT_OK;
 }
 
@@ -776,11 +894,20 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
     const int64_t B = t.B, Me = B * Te;
     // final LayerNorm: ctx = ln(x_L)
     HIP_TRY(hipMemcpyAsync(ts->t_d, ts->dxe, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    MDT_TRY(ln_bwd(m, grads, enc_last_output(m, t), t.st_f, m->enc_ln_w, m->enc_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dxe, 0,
-                   nullptr, B, Te, s));
-    for (int l = m->Le - 1; l >= 0; --l)
+    auto enc_merge = [&](int l) { return block_mlp_merge_bwd(m, t.enc[l], B, Te, COND_TOKEN, nullptr, nullptr, 0, ts->dxe, t.drop, l); };
+    const float* gm = nullptr;  // the MLP-merged gradient of the block about to run
+    {
+        const mdt_merge_args g = m->Le > 0 ? enc_merge(m->Le - 1) : mdt_merge_args{};
+        MDT_TRY(ln_bwd(m, grads, enc_last_output(m, t), t.st_f, m->enc_ln_w, m->enc_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dxe, 0,
+                       nullptr, B, Te, s, 0, m->Le > 0 ? &g : nullptr));
+        gm = g.out;
+    }
+    for (int l = m->Le - 1; l >= 0; --l) {
+        const mdt_merge_args g = l > 0 ? enc_merge(l - 1) : mdt_merge_args{};
         MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, nullptr, 0, nullptr, nullptr,
-                          ts->dxe, t.drop, l, s));
+                          ts->dxe, t.drop, l, s, gm, l > 0 ? &g : nullptr));
+        gm = g.out;
+    }
     const int t0 = m->sig_tok;
     const int drop_lo = embed_drop_from(m);
     if (drop_lo >= 0)
@@ -846,7 +973,7 @@ extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const
     t->stream = s;
     MDT_TRY(scratch_enter(m, s));
     MDT_TRY(reserve_scratch(m, t->B));
-    m->train->deferred.clear(); m->train->defer_off = 0;
+    m->train->deferred.clear(); m->train->defer_off = 0; m->train->dy_off = 0;
     HIP_TRY(hipMemcpyAsync(m->train->dxe, g_ctx, (size_t)t->B * m->Te * m->D * sizeof(float), hipMemcpyDeviceToDevice, s));
     MDT_TRY(enc_bwd(m, *t, grads, d_tokens, d_tokens2, d_goal, s));
     return flush_deferred(m, s);
@@ -866,7 +993,7 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     mdt_train_state* ts = m->train;
     MDT_TRY(scratch_enter(m, s));
     MDT_TRY(reserve_scratch(m, t.B));
-    ts->deferred.clear(); ts->defer_off = 0;
+    ts->deferred.clear(); ts->defer_off = 0; ts->dy_off = 0;
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta, Me = B * m->Te;
     // ---- loss and action head: F = action_pred(ln(x_L))
@@ -907,15 +1034,28 @@ static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
         }
         LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_d, (int)Ma, A, D, s));
     }
-    MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
-                   B, Ta, s));
-    // ---- decoder blocks
     if (m->cond == COND_NOISE) HIP_TRY(hipMemsetAsync(ts->d_mod, 0, (size_t)B * D * sizeof(float), s));  // d_c accumulates
     const bool rows = m->cond != COND_TOKEN;
-    for (int l = m->Ld - 1; l >= 0; --l)
-        MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond, rows ? t.mod + l * mod_blk : nullptr,
-                          rows ? ts->d_mod + l * mod_blk : nullptr, modw, t.kvx + (int64_t)l * 2 * D,
-                          ts->d_kvx + (int64_t)l * 2 * D, ts->dx, t.drop, m->Le + l, s));
+    auto mod_of = [&](int l) { return rows ? (const float*)(t.mod + l * mod_blk) : (const float*)nullptr; };
+    auto dmod_of = [&](int l) { return rows ? ts->d_mod + l * mod_blk : (float*)nullptr; };
+    auto dec_merge = [&](int l) {
+        return block_mlp_merge_bwd(m, t.dec[l], B, Ta, m->cond, mod_of(l), dmod_of(l), modw, ts->dx, t.drop, m->Le + l);
+    };
+    const float* gm = nullptr;  // the MLP-merged gradient of the block about to run
+    {   // the final LayerNorm's backward also runs the last block's MLP merge backward
+        const mdt_merge_args g = dec_merge(m->Ld - 1);
+        MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
+                       B, Ta, s, 0, &g));
+        gm = g.out;
+    }
+    // ---- decoder blocks
+    for (int l = m->Ld - 1; l >= 0; --l) {
+        const mdt_merge_args g = l > 0 ? dec_merge(l - 1) : mdt_merge_args{};
+        MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond, mod_of(l), dmod_of(l), modw,
+                          t.kvx + (int64_t)l * 2 * D, ts->d_kvx + (int64_t)l * 2 * D, ts->dx, t.drop, m->Le + l, s, gm,
+                          l > 0 ? &g : nullptr));
+        gm = g.out;
+    }
     // ---- action embedding: y0 = drop(action_emb(xin)); no gradient flows to the noisy actions
     LAUNCH(mdt_launch_dropout_rows(ts->dx, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed,
                                    s));
@@ -954,6 +1094,7 @@ extern "C" mdt_status mdt_denoise_vjp(mdt_model* m, const float* tokens, const f
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;
     mdt_status st = scratch_enter(m, s);
     if (st == MDT_OK) st = reserve_scratch(m, batch);
+    if (st == MDT_OK) m->train->dy_off = 0;
     if (st == MDT_OK) st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, sigma, nullptr, s);
     // action := x, no noise: the tape's "noised" rows are x itself, F the raw network output
     if (st == MDT_OK) st = dec_fwd(m, t, x, nullptr, sigma, nullptr, nullptr, s);

@@ -8,6 +8,7 @@
 // Attention :119-158, MLP :161-180, ConditionedBlock :291-309) and mdt/models/edm_diffusion/score_wrappers.py:45-63.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <unordered_map>
@@ -215,6 +216,93 @@ __global__ __launch_bounds__(256) void k_ln_fwd_train4(const float* __restrict__
     if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
+// Branch merge + the LayerNorm that reads its result, one launch (round 6): every merge of the training forward --
+// x_out = x + gate * dropout(a), k_merge_fwd4 -- is followed by the LayerNorm(+modulate) of the next sublayer on the rows it has
+// just written.  One wave per row: the merged row is formed in registers, stored (the residual stream the backward needs), and
+// normalised on the spot.  Same arithmetic per element as the two kernels: bit-identical to k_merge_fwd4 + k_ln_fwd_train4.
+// l.x is ignored (it IS g.out); gate rows are indexed by row / g.rows_per_sample, modulation rows by row / rps.
+__global__ __launch_bounds__(256) void k_merge_ln_fwd4(mdt_merge_args g, const float* __restrict__ w, const float* __restrict__ b,
+                                                       const float* __restrict__ mod, int64_t mod_stride, int shift_off,
+                                                       int scale_off, int rps, float* __restrict__ out, float* __restrict__ stats,
+                                                       int M, int D4) {
+    constexpr int C4 = LN_MAXC / 4;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    const float Df = (float)(4 * D4);
+    const float* gr = g.gate ? g.gate + (int64_t)(row / g.rows_per_sample) * g.gate_stride : nullptr;
+    f32x4 v[C4];
+    float s = 0.f;
+    {
+        f32x4 av[C4], xv[C4], gv[C4];
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int c = lane + 64 * i;
+            av[i] = c < D4 ? ((const f32x4*)g.a)[(int64_t)row * D4 + c] : zero4;
+            xv[i] = c < D4 ? ((const f32x4*)g.x)[(int64_t)row * D4 + c] : zero4;
+            gv[i] = (c < D4 && gr) ? *(const f32x4*)(gr + 4 * c) : one4;
+        }
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int c = lane + 64 * i;
+            const int64_t e = (int64_t)row * D4 + c;
+            v[i] = zero4;
+            if (c < D4) {
+                const f32x4 ds = dropout_scale4(g.seed, g.site, (uint64_t)e * 4, g.p), t = av[i] * ds;
+                v[i] = (f32x4){fmaf(gv[i].x, t.x, xv[i].x), fmaf(gv[i].y, t.y, xv[i].y), fmaf(gv[i].z, t.z, xv[i].z), fmaf(gv[i].w, t.w, xv[i].w)};
+                ((f32x4*)g.out)[e] = v[i];
+            }
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / Df;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int c = lane + 64 * i;
+        const f32x4 d = c < D4 ? v[i] - mean : zero4;
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / Df + 1e-5f);
+    const float* mr = mod ? mod + (int64_t)(row / rps) * mod_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+            f32x4 n = (v[i] - mean) * rstd * ((const f32x4*)w)[c] + (b ? ((const f32x4*)b)[c] : zero4);
+            if (mr) {
+                const f32x4 sc = scale_off >= 0 ? *(const f32x4*)(mr + scale_off + 4 * c) : one4;
+                const f32x4 sh = shift_off >= 0 ? *(const f32x4*)(mr + shift_off + 4 * c) : zero4;
+                n = (f32x4){fmaf(n.x, sc.x, sh.x), fmaf(n.y, sc.y, sh.y), fmaf(n.z, sc.z, sh.z), fmaf(n.w, sc.w, sh.w)};
+            }
+            ((f32x4*)out)[(int64_t)row * D4 + c] = n;
+        }
+    }
+    if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+static bool ln_fwd_vec_ok(const mdt_ln_train_args& a) {
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    return a.D % 4 == 0 && al(a.x) && al(a.w) && al(a.b) && al(a.out) &&
+           (!a.mod || (al(a.mod) && a.mod_stride % 4 == 0 && (a.shift_off < 0 || a.shift_off % 4 == 0) &&
+                       (a.scale_off < 0 || a.scale_off % 4 == 0)));
+}
+static bool merge_vec_ok(const mdt_merge_args& a, bool bwd);
+hipError_t mdt_launch_merge_fwd(const mdt_merge_args& a, hipStream_t s);
+// the merge g, then the LayerNorm l of its result (l.x is ignored): one launch where both take 16-byte accesses
+hipError_t mdt_launch_merge_ln_fwd(const mdt_merge_args& g, const mdt_ln_train_args& l, hipStream_t s) {
+    mdt_ln_train_args ll = l;
+    ll.x = g.out;
+    if (ll.D > 64 * LN_MAXC || ll.D < 1) return hipErrorInvalidValue;
+    if (ln_fwd_vec_ok(ll) && merge_vec_ok(g, false) && g.D == ll.D && (int64_t)g.B * g.rows_per_sample == ll.M && g.out != g.a) {
+        hipLaunchKernelGGL(k_merge_ln_fwd4, dim3((ll.M + 3) / 4), dim3(256), 0, s, g, ll.w, ll.b, ll.mod, ll.mod_stride, ll.shift_off,
+                           ll.scale_off, ll.rows_per_sample > 0 ? ll.rows_per_sample : 1, ll.out, ll.stats, ll.M, ll.D / 4);
+        return hipGetLastError();
+    }
+    hipError_t e = mdt_launch_merge_fwd(g, s);
+    return e != hipSuccess ? e : mdt_launch_ln_fwd_train(ll, s);
+}
+
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s) {
     if (a.D > 64 * LN_MAXC || a.D < 1) return hipErrorInvalidValue;
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
@@ -316,10 +404,19 @@ __global__ __launch_bounds__(256) void k_ln_bwd(mdt_ln_bwd_args a) {
 }
 
 // the same with 16-byte column groups; the row of dx an accumulating call adds to is requested with x and dh, not after the
-// row's two reductions
-__global__ __launch_bounds__(256) void k_ln_bwd4(mdt_ln_bwd_args a) {
-    extern __shared__ float red[];  // [4 waves][4 kinds][D]
-    constexpr int C4 = LN_MAXC / 4;
+// row's two reductions.
+// MG (round 6): the branch merge that FOLLOWS this LayerNorm in the backward order rides along.  Every LayerNorm backward of a
+// block is followed by the backward of the merge in front of it -- d_a = mask/(1-p) * gate * d_x, d_gate = sum_rows d_x * drop(a)
+// (k_merge_bwd4) -- on exactly the rows this workgroup has just finished (one workgroup per sample in both), so the freshly
+// accumulated d_x row goes from registers into both: one launch and one read of d_x less per sublayer (20 a step).
+// g.x is ignored (it IS a.dx); g.out must not be a.dh's buffer unless it is the same rows (it is the same thread either way).
+// RB = rows a wave has in flight at once: a wave's rows wv, wv + 4, ... were one dependent memory round trip each (the store of a
+// row may alias the next row's loads for all the compiler knows, so nothing was requested ahead: three trips per launch at ten
+// rows per sample); now every operand of up to RB rows is requested before the first reduction and the first store.
+template <bool MG, int RB>
+__global__ __launch_bounds__(256) void k_ln_bwd4(mdt_ln_bwd_args a, mdt_merge_args g) {
+    extern __shared__ float red[];  // [4 waves][4 (+ 1) kinds][D]
+    constexpr int C4 = LN_MAXC / 4, NK = MG ? 5 : 4;
     const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int D = a.D, D4 = D >> 2, rps = a.rows_per_sample;
     const int per = (rps + gridDim.y - 1) / gridDim.y, r_lo = blockIdx.y * per, r_hi = min(rps, r_lo + per);
@@ -327,62 +424,92 @@ __global__ __launch_bounds__(256) void k_ln_bwd4(mdt_ln_bwd_args a) {
     const float* mr = a.mod ? a.mod + (int64_t)b * a.mod_stride : nullptr;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
     const float Df = (float)D;
-    f32x4 wgt[C4], bia[C4], sc[C4], a_sh[C4], a_sc[C4], a_w[C4], a_b[C4];
+    f32x4 wgt[C4], bia[C4], sc[C4], a_sh[C4], a_sc[C4], a_w[C4], a_b[C4], gt[C4], a_g[C4];
 #pragma unroll
     for (int i = 0; i < C4; ++i) {
         const int c = lane + 64 * i;
         wgt[i] = c < D4 ? ((const f32x4*)a.w)[c] : zero4;
         bia[i] = (c < D4 && a.b) ? ((const f32x4*)a.b)[c] : zero4;
         sc[i] = c < D4 ? ((mr && a.scale_off >= 0) ? *(const f32x4*)(mr + a.scale_off + 4 * c) : one4) : zero4;
-        a_sh[i] = a_sc[i] = a_w[i] = a_b[i] = zero4;
+        a_sh[i] = a_sc[i] = a_w[i] = a_b[i] = a_g[i] = zero4;
+        if constexpr (MG) gt[i] = (c < D4 && g.gate) ? *(const f32x4*)(g.gate + (int64_t)b * g.gate_stride + 4 * c) : one4;
     }
     const int64_t ld4 = a.ld_dh >> 2;
-    for (int r = r_lo + wv; r < r_hi; r += 4) {
-        const int64_t row = (int64_t)b * rps + r;
-        const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
-        f32x4 xh[C4], dxh[C4], old[C4];
-        float s1 = 0.f, s2 = 0.f;
+    for (int r0 = r_lo + wv; r0 < r_hi; r0 += 4 * RB) {
+        f32x4 xv[RB][C4], dhv[RB][C4], old[RB][C4], br[MG ? RB : 1][C4];
+        float mean[RB], rstd[RB];
+        // ---- every request of the batch (rows past the end: the wave's first row again, never stored) ----
 #pragma unroll
-        for (int i = 0; i < C4; ++i) {
-            const int c = lane + 64 * i;
-            const f32x4 xv = c < D4 ? ((const f32x4*)a.x)[row * D4 + c] : zero4;
-            const f32x4 dh = c < D4 ? ((const f32x4*)a.dh)[row * ld4 + c] : zero4;
-            old[i] = (a.accumulate && c < D4) ? ((const f32x4*)a.dx)[row * D4 + c] : zero4;
-            xh[i] = c < D4 ? (xv - mean) * rstd : zero4;
-            const f32x4 n = xh[i] * wgt[i] + bia[i];
-            const f32x4 dn = dh * sc[i];
-            a_sh[i] += dh;
-            a_sc[i] += dh * n;
-            a_w[i] += dn * xh[i];
-            a_b[i] += dn;
-            dxh[i] = dn * wgt[i];
-            s1 += (dxh[i].x + dxh[i].y) + (dxh[i].z + dxh[i].w);
-            const f32x4 t = dxh[i] * xh[i];
-            s2 += (t.x + t.y) + (t.z + t.w);
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + 4 * u < r_hi ? r0 + 4 * u : r0;
+            const int64_t row = (int64_t)b * rps + r;
+            mean[u] = a.stats[2 * row]; rstd[u] = a.stats[2 * row + 1];
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int c = min(lane + 64 * i, D4 - 1);
+                xv[u][i] = ((const f32x4*)a.x)[row * D4 + c];
+                dhv[u][i] = ((const f32x4*)a.dh)[row * ld4 + c];
+                old[u][i] = a.accumulate ? ((const f32x4*)a.dx)[row * D4 + c] : zero4;
+                if constexpr (MG) br[u][i] = ((const f32x4*)g.a)[row * D4 + c];
+            }
         }
-        const float c1 = wave_sum(s1) / Df, c2 = wave_sum(s2) / Df;
 #pragma unroll
-        for (int i = 0; i < C4; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D4) ((f32x4*)a.dx)[row * D4 + c] = old[i] + (dxh[i] - c1 - xh[i] * c2) * rstd;
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + 4 * u;
+            if (r >= r_hi) continue;  // wave-uniform
+            const int64_t row = (int64_t)b * rps + r;
+            f32x4 xh[C4], dxh[C4];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const bool in = lane + 64 * i < D4;
+                const f32x4 dh = in ? dhv[u][i] : zero4;
+                xh[i] = in ? (xv[u][i] - mean[u]) * rstd[u] : zero4;
+                const f32x4 n = xh[i] * wgt[i] + bia[i];
+                const f32x4 dn = dh * sc[i];
+                a_sh[i] += dh;
+                a_sc[i] += dh * n;
+                a_w[i] += dn * xh[i];
+                a_b[i] += dn;
+                dxh[i] = dn * wgt[i];
+                s1 += (dxh[i].x + dxh[i].y) + (dxh[i].z + dxh[i].w);
+                const f32x4 t = dxh[i] * xh[i];
+                s2 += (t.x + t.y) + (t.z + t.w);
+            }
+            const float c1 = wave_sum(s1) / Df, c2 = wave_sum(s2) / Df;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int c = lane + 64 * i;
+                if (c < D4) {
+                    const f32x4 d = old[u][i] + (dxh[i] - c1 - xh[i] * c2) * rstd[u];
+                    ((f32x4*)a.dx)[row * D4 + c] = d;
+                    if constexpr (MG) {  // k_merge_bwd4's arithmetic on the row just formed
+                        const int64_t e = row * D4 + c;
+                        const f32x4 ds = dropout_scale4(g.seed, g.site, (uint64_t)e * 4, g.p), t = br[u][i] * ds;
+                        a_g[i] = (f32x4){fmaf(d.x, t.x, a_g[i].x), fmaf(d.y, t.y, a_g[i].y), fmaf(d.z, t.z, a_g[i].z), fmaf(d.w, t.w, a_g[i].w)};
+                        ((f32x4*)g.out)[e] = gt[i] * d * ds;
+                    }
+                }
+            }
         }
     }
 #pragma unroll
     for (int i = 0; i < C4; ++i) {
         const int c = lane + 64 * i;
         if (c < D4) {
-            *(f32x4*)(red + (wv * 4 + 0) * D + 4 * c) = a_sh[i];
-            *(f32x4*)(red + (wv * 4 + 1) * D + 4 * c) = a_sc[i];
-            *(f32x4*)(red + (wv * 4 + 2) * D + 4 * c) = a_w[i];
-            *(f32x4*)(red + (wv * 4 + 3) * D + 4 * c) = a_b[i];
+            *(f32x4*)(red + (wv * NK + 0) * D + 4 * c) = a_sh[i];
+            *(f32x4*)(red + (wv * NK + 1) * D + 4 * c) = a_sc[i];
+            *(f32x4*)(red + (wv * NK + 2) * D + 4 * c) = a_w[i];
+            *(f32x4*)(red + (wv * NK + 3) * D + 4 * c) = a_b[i];
+            if constexpr (MG) *(f32x4*)(red + (wv * NK + 4) * D + 4 * c) = a_g[i];
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
-        float t[4];
+        float t[NK];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = red[(0 * 4 + k) * D + c] + red[(1 * 4 + k) * D + c] + red[(2 * 4 + k) * D + c] +
-                                           red[(3 * 4 + k) * D + c];
+        for (int k = 0; k < NK; ++k) t[k] = red[(0 * NK + k) * D + c] + red[(1 * NK + k) * D + c] + red[(2 * NK + k) * D + c] +
+                                            red[(3 * NK + k) * D + c];
         if (a.d_mod) {
             float* dm = a.d_mod + (int64_t)b * a.d_mod_stride;
             if (a.shift_off >= 0) dm[a.shift_off + c] = a.accumulate_dmod ? dm[a.shift_off + c] + t[0] : t[0];
@@ -390,21 +517,56 @@ __global__ __launch_bounds__(256) void k_ln_bwd4(mdt_ln_bwd_args a) {
         }
         a.pw[(int64_t)prow * D + c] = t[2];
         if (a.pb) a.pb[(int64_t)prow * D + c] = t[3];
+        if constexpr (MG) { if (g.dgate) g.dgate[(int64_t)b * g.dgate_stride + c] = t[NK - 1]; }
     }
 }
 
+template <bool MG>
+static void launch_ln_bwd4(const mdt_ln_bwd_args& a, const mdt_merge_args& g, int chunks, hipStream_t s) {
+    static int rb_force = -1;  // MDT_HIP_LNB_ROWS=1..3: rows a wave keeps in flight (A/B runs; default: all of them, up to 3)
+    if (rb_force < 0) { const char* e = getenv("MDT_HIP_LNB_ROWS"); rb_force = e ? atoi(e) : 0; }
+    const int per = (a.rows_per_sample + chunks - 1) / chunks;
+    int rb = per <= 4 ? 1 : (per <= 8 ? 2 : 3);
+    if (rb_force >= 1 && rb_force <= 3) rb = rb_force;
+    const size_t lds = (size_t)4 * (MG ? 5 : 4) * a.D * sizeof(float);
+    if (rb == 1) hipLaunchKernelGGL((k_ln_bwd4<MG, 1>), dim3(a.B, chunks), dim3(256), lds, s, a, g);
+    else if (rb == 2) hipLaunchKernelGGL((k_ln_bwd4<MG, 2>), dim3(a.B, chunks), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((k_ln_bwd4<MG, 3>), dim3(a.B, chunks), dim3(256), lds, s, a, g);
+}
+
+static bool ln_bwd_vec_ok(const mdt_ln_bwd_args& a) {
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    return a.D % 4 == 0 && a.ld_dh % 4 == 0 && al(a.x) && al(a.dh) && al(a.dx) && al(a.w) && al(a.b) &&
+           (!a.mod || (al(a.mod) && a.mod_stride % 4 == 0 && (a.scale_off < 0 || a.scale_off % 4 == 0)));
+}
 hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s) {
     if (a.D > 64 * LN_MAXC || a.D < 1 || a.rows_per_sample < 1) return hipErrorInvalidValue;
     const int chunks = a.row_chunks > 1 ? a.row_chunks : 1;
     if (chunks > 1 && (a.d_mod || chunks > a.rows_per_sample)) return hipErrorInvalidValue;
-    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (a.D % 4 == 0 && a.ld_dh % 4 == 0 && al(a.x) && al(a.dh) && al(a.dx) && al(a.w) && al(a.b) &&
-        (!a.mod || (al(a.mod) && a.mod_stride % 4 == 0 && (a.scale_off < 0 || a.scale_off % 4 == 0)))) {
-        hipLaunchKernelGGL(k_ln_bwd4, dim3(a.B, chunks), dim3(256), (size_t)16 * a.D * sizeof(float), s, a);
+    if (ln_bwd_vec_ok(a)) {
+        launch_ln_bwd4<false>(a, mdt_merge_args{}, chunks, s);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_ln_bwd, dim3(a.B, chunks), dim3(256), (size_t)16 * a.D * sizeof(float), s, a);
     return hipGetLastError();
+}
+
+static bool merge_vec_ok(const mdt_merge_args& a, bool bwd);
+hipError_t mdt_launch_merge_bwd(const mdt_merge_args& a, hipStream_t s);
+// LayerNorm backward, then the backward of the branch merge `g` on the gradient it leaves in a.dx (g.x is ignored): one launch
+// where both take 16-byte accesses and a sample is one workgroup, else the two kernels one after the other
+hipError_t mdt_launch_ln_bwd_merge(const mdt_ln_bwd_args& a, const mdt_merge_args& g, hipStream_t s) {
+    mdt_merge_args gg = g;
+    gg.x = a.dx;
+    const int chunks = a.row_chunks > 1 ? a.row_chunks : 1;
+    if (a.D > 64 * LN_MAXC || a.D < 1 || a.rows_per_sample < 1) return hipErrorInvalidValue;
+    if (chunks == 1 && ln_bwd_vec_ok(a) && merge_vec_ok(gg, true) && gg.B == a.B && gg.rows_per_sample == a.rows_per_sample &&
+        gg.D == a.D) {
+        launch_ln_bwd4<true>(a, gg, 1, s);
+        return hipGetLastError();
+    }
+    hipError_t e = mdt_launch_ln_bwd(a, s);
+    return e != hipSuccess ? e : mdt_launch_merge_bwd(gg, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,10 +626,6 @@ __global__ __launch_bounds__(256) void k_merge_bwd(mdt_merge_args a) {
 // rl, rl + RL, ... (at most MERGE_U of them) are all in flight at once.  Same arithmetic per element, so the forward is bit
 // for bit the kernel above; the gate gradient sums a sample's rows as (rows of lane 0) + (rows of lane 1) + ...
 constexpr int MERGE_U = 8;
-__device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, uint32_t site, uint64_t idx, float p) {
-    return (f32x4){dropout_scale(seed, site, idx, p), dropout_scale(seed, site, idx + 1, p), dropout_scale(seed, site, idx + 2, p),
-                   dropout_scale(seed, site, idx + 3, p)};
-}
 __global__ __launch_bounds__(256) void k_merge_fwd4(mdt_merge_args a) {
     const int b = blockIdx.x, D4 = a.D >> 2, rps = a.rows_per_sample, RL = 256 / D4;
     const int c4 = threadIdx.x % D4, rl = threadIdx.x / D4;
@@ -774,14 +932,35 @@ __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
     return fmaf(a.w, b.w, acc);
 }
 
+// Dropout multipliers of one (sample, head)'s Tq x Tk probabilities into LDS, by ALL lanes: element (i, j) has index base0 + i Tk + j
+// and takes word idx & 3 of Philox block idx >> 2, so the ~Tq Tk / 4 blocks go one per lane (round 6; before, lane i < Tq ran
+// Tk whole blocks one after the other inside its softmax loop -- ~1000 integer instructions on 10 of 64 lanes, more than the
+// rest of the kernel).  No barrier inside: the caller's next __syncthreads() publishes the table.
+__device__ __forceinline__ void attn_dropout_table(float (*mk)[17], uint64_t seed, uint32_t site, uint64_t base0, int Tq, int Tk,
+                                                   float p, int lane) {
+    const int n = Tq * Tk;
+    const uint64_t blk0 = base0 >> 2;
+    const int nblk = (int)(((base0 + n - 1) >> 2) - blk0) + 1;
+    for (int q = lane; q < nblk; q += 64) {
+        const philox4_t r = philox4(seed, site, blk0 + q);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int64_t e = (int64_t)(((blk0 + q) << 2) + w) - (int64_t)base0;
+            if (e >= 0 && e < n) mk[e / Tk][e % Tk] = dropout_keep(r.w[w], p);
+        }
+    }
+}
+
 // training forward with dropout on the probabilities: out = (mask/(1-p) * softmax(q k^T / sqrt(hd))) v
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, float scale) {
     __shared__ __attribute__((aligned(16))) float qs[16][HD + 4], ks[16][HD + 4], vs[16][HD + 4];
-    __shared__ float P[16][17];
+    __shared__ float P[16][17], Mk[16][17];
     constexpr int H4 = HD / 4;
     const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const int Tq = a.Tq, Tk = a.Tk;
+    const bool drop = a.p > 0.f && a.seed != 0;
+    if (drop) attn_dropout_table(Mk, a.seed, a.site, ((uint64_t)b * a.H + h) * Tq * Tk, Tq, Tk, a.p, lane);
     {
         const float* const src[3] = {a.q + (int64_t)b * Tq * a.ldq + h * HD, a.k + (int64_t)b * Tk * a.ldkv + h * HD,
                                      a.v + (int64_t)b * Tk * a.ldkv + h * HD};
@@ -813,8 +992,7 @@ __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, fl
         float sum = 0.f;
         for (int j = 0; j < Tk; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
         const float inv = 1.f / sum;
-        const uint64_t base = (((uint64_t)b * a.H + h) * Tq + i) * Tk;
-        for (int j = 0; j < Tk; ++j) P[i][j] = sc[j] * inv * dropout_scale(a.seed, a.site, base + j, a.p);
+        for (int j = 0; j < Tk; ++j) P[i][j] = sc[j] * inv * (drop ? Mk[i][j] : 1.f);
     }
     __syncthreads();
     for (int e = lane; e < Tq * H4; e += 64) {  // (row, four features) per lane
@@ -845,10 +1023,12 @@ hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scale) {
     __shared__ __attribute__((aligned(16))) float qs[16][HD + 4], ks[16][HD + 4], vs[16][HD + 4], os[16][HD + 4];
-    __shared__ float P[16][17], dS[16][17];
+    __shared__ float P[16][17], dS[16][17], Mk[16][17];
     constexpr int H4 = HD / 4;
     const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const int Tq = a.Tq, Tk = a.Tk;
+    const bool drop = a.p > 0.f && a.seed != 0;
+    if (drop) attn_dropout_table(Mk, a.seed, a.site, ((uint64_t)b * a.H + h) * Tq * Tk, Tq, Tk, a.p, lane);
     {   // q / k / v / dO tiles (rows are 16-byte aligned: HD and the leading dimensions are multiples of 4)
         const float* const src[4] = {a.q + (int64_t)b * Tq * a.ldq + h * HD, a.k + (int64_t)b * Tk * a.ldkv + h * HD,
                                      a.v + (int64_t)b * Tk * a.ldkv + h * HD, a.d_out + (int64_t)b * Tq * a.ld_do + h * HD};
@@ -890,10 +1070,9 @@ __global__ __launch_bounds__(64) void k_attn_bwd(mdt_attn_bwd_args a, float scal
         for (int j = 0; j < Tk; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
         const float inv = 1.f / sum;
         // with dropout: out = (m * P) V, m = mask/(1-p)  =>  dP = m * (dO V^T), dV uses m * P
-        const uint64_t base = (((uint64_t)b * a.H + h) * Tq + i) * Tk;
         float delta = 0.f;
         for (int j = 0; j < Tk; ++j) {
-            const float mk = dropout_scale(a.seed, a.site, base + j, a.p);
+            const float mk = drop ? Mk[i][j] : 1.f;
             sc[j] *= inv;
             dp[j] *= mk;
             delta = fmaf(sc[j], dp[j], delta);
@@ -1491,7 +1670,7 @@ hipError_t mdt_launch_multi_axpby(const mdt_opt_tensor* tab, const int2* blocks,
 template <int KT, int WN>
 __global__ __launch_bounds__(256 * WN) void k_gemm_tn(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
                                                  float* __restrict__ out, int64_t slice_stride, int M, int N, int K, int L,
-                                                 int accumulate, float* __restrict__ bpart) {
+                                                 int accumulate, float* __restrict__ bpart, int xcd) {
     constexpr int CM = 32, TN_ = 64 * WN, TK = 64 * KT, SY = TN_ + 4, SX = TK + 4, NTHR = 256 * WN, X4 = TK / 4, Y4 = TN_ / 4,
                   XU = CM * X4 / NTHR, YU = CM * Y4 / NTHR;
     static_assert(CM * X4 % NTHR == 0 && CM * Y4 % NTHR == 0, "staging does not split evenly");
@@ -1500,9 +1679,19 @@ __global__ __launch_bounds__(256 * WN) void k_gemm_tn(const float* __restrict__ 
     float (*xs)[CM * SX] = (float (*)[CM * SX])(tn_lds + 2 * CM * SY);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave & 3, wn = wave >> 2;
     const int gk = (K + TK - 1) / TK;
-    const int bn = blockIdx.x / gk, bk = blockIdx.x - bn * gk;
+    // Which (slice, tile) this workgroup takes.  The dispatcher places workgroup b on XCD b % 8 (speed-only assumption).  As
+    // launched -- tile fastest -- XCD x got k-tile x of EVERY slice: each of the 8 L2s pulled all of dY and an eighth of X's
+    // columns over all rows (k_gemm_tn<3, 3> at 10240 x 384 x 1536: 113 MB from the fabric for 79 MB of operands, L2 hit 0.30).
+    // Round 6: every XCD gets a contiguous range of (slice-major) ids, i.e. whole slices -- all tiles that share a slice's rows
+    // of X and dY run behind one L2 (xcd = 0: the launch order, A/B runs).
+    int id = blockIdx.x + gridDim.x * blockIdx.z;
+    if (xcd) {
+        const int nb = gridDim.x * gridDim.z, q = nb >> 3, r = nb & 7, x8 = id & 7, idx = id >> 3;
+        id = (x8 < r ? x8 * (q + 1) : r * (q + 1) + (x8 - r) * q) + idx;
+    }
+    const int z = id / (int)gridDim.x, tile = id - z * (int)gridDim.x;
+    const int bn = tile / gk, bk = tile - bn * gk;
     const int n0 = bn * TN_, k0 = bk * TK;
-    const int z = blockIdx.z;
     const int m_lo = z * L, m_hi = min(M, m_lo + L);
     out += (int64_t)z * slice_stride;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1658,8 +1847,10 @@ static hipError_t launch_gemm_tn_t(const float* dY, int64_t ldy, const float* X,
         if (e != hipSuccess) return e;
         attr_dev[dev] = true;
     }
+    static int xcd = -1;  // MDT_HIP_TN_XCD=0: workgroups take (slice, tile) in launch order (A/B runs)
+    if (xcd < 0) { const char* e = getenv("MDT_HIP_TN_XCD"); xcd = e ? atoi(e) : 1; }
     hipLaunchKernelGGL((k_gemm_tn<KT, WN>), dim3(((N + TN_ - 1) / TN_) * ((K + TK - 1) / TK), 1, S), dim3(256 * WN), lds, s, dY, ldy, X, ldx,
-                       out, slice_stride, M, N, K, L, accumulate, bpart);
+                       out, slice_stride, M, N, K, L, accumulate, bpart, S > 1 ? xcd : 0);
     return hipGetLastError();
 }
 hipError_t mdt_launch_gemm_tn(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,

@@ -251,6 +251,22 @@ extern "C" mdt_status mdt_op_merge_bwd(const mdt_merge_args* a, void* stream) {
     return MDT_OK;
 }
 
+extern "C" mdt_status mdt_op_merge_ln_fwd(const mdt_merge_args* g, const mdt_ln_train_args* l, void* stream) {
+    if (!g || !l || !g->x || !g->a || !g->out || !l->w || !l->out || g->B < 1 || g->rows_per_sample < 1 ||
+        (int64_t)g->B * g->rows_per_sample != l->M || g->D != l->D)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_merge_ln_fwd: bad argument");
+    LAUNCH(mdt_launch_merge_ln_fwd(*g, *l, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_ln_bwd_merge(const mdt_ln_bwd_args* a, const mdt_merge_args* g, void* stream) {
+    if (!a || !g || !a->x || !a->stats || !a->w || !a->dh || !a->dx || !a->pw || a->B < 1 || !g->a || !g->out ||
+        g->B != a->B || g->rows_per_sample != a->rows_per_sample || g->D != a->D)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_ln_bwd_merge: bad argument");
+    LAUNCH(mdt_launch_ln_bwd_merge(*a, *g, (hipStream_t)stream));
+    return MDT_OK;
+}
+
 extern "C" mdt_status mdt_op_attn_fwd_train(const mdt_attn_train_args* a, void* stream) {
     if (!a || !a->q || !a->k || !a->v || !a->out) return fail(MDT_ERR_INVALID_ARG, "mdt_op_attn_fwd_train: null argument");
     LAUNCH(mdt_launch_attn_fwd_train(*a, (hipStream_t)stream));

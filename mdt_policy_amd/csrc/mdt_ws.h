@@ -21,7 +21,15 @@
 //
 // Same transposed MFMA form and the same K order as gemm_tile / gemm_tall_tile: results are BIT-IDENTICAL to both.
 //   out = epilogue(A @ W^T + bias): GLU = 0 plain rows (aux_mode 0, no activation, no residual / row remap),
+//   GLU = 1 the activation + the training hooks of gemm_tile's plain kernels (mdt_gemm_args.act; aux_mode 1: the pre-activation
+//   kept beside the activated value; aux_mode 2: the product times act'(u) of the layer below),
 //   GLU = 3 / 4 the SwishGLU forward / backward epilogues of gemm_tile (mdt_gemm_args.aux_mode 3 / 4).
+//
+// Round 6: K = 384 (K16 = 24, ONE column tile per wave: the same 24 fragment quads = 96 VGPRs) for the denoiser's training step
+// at B = 1024 (M = 10240 rows): every d x d product of its forward and input-gradient pass (24 launches a step), qkv (N = 3d)
+// and c_fc / c_proj's input gradient with their GELU hooks (N = 4d).  The 32 x 128 row tiles pulled the whole 196 KB column
+// panel from L2 for every 32 rows (960 workgroups x 196 KB = 188 MB per launch of a 3 GFLOP product, MFMA-busy 0.58); here a
+// workgroup pulls it once for its 4 - 10 tiles.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -185,6 +193,20 @@ __device__ __forceinline__ void gemm_ws_tile(const mdt_gemm_args& a, int panel, 
                         *(f32x4*)(a.out + oo[i] + a.N + ncol[j]) = dg;
                         *(f32x4*)(a.out + oo[i] + ncol[j]) = v;
                     }
+                }
+            } else if constexpr (GLU == 1) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    f32x4 v = acc[i][j] + bias_v[j];
+                    if (a.aux_mode == 2) {
+                        const f32x4 u = ldg4(a.aux + oo[i] + ncol[j]);   // rows clamped above: in bounds
+                        v.x *= apply_act_grad1(u.x, a.act); v.y *= apply_act_grad1(u.y, a.act);
+                        v.z *= apply_act_grad1(u.z, a.act); v.w *= apply_act_grad1(u.w, a.act);
+                    } else {
+                        if (a.aux_mode == 1 && okr[i]) *(f32x4*)(const_cast<float*>(a.aux) + oo[i] + ncol[j]) = v;
+                        v = apply_act(v, a.act);
+                    }
+                    if (okr[i]) *(f32x4*)(a.out + oo[i] + ncol[j]) = v;
                 }
             } else {
 #pragma unroll

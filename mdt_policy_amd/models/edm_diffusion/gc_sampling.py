@@ -178,11 +178,11 @@ def _graphed(model, state, action, goal, sigmas):
     cache = model.__dict__.setdefault("_graphed_samplers", [])
     for gsamp in cache:
         if gsamp.matches(state, action, goal, sigmas):
-            return gsamp(state, action, goal, sigmas).clone()
+            return gsamp(state, action, goal, sigmas)
     gsamp = GraphedDDIM(model, state, action, goal, sigmas if torch.is_tensor(sigmas) else torch.as_tensor(sigmas))
     cache.append(gsamp)
     del cache[:-4]
-    return gsamp(state, action, goal, sigmas).clone()
+    return gsamp(state, action, goal, sigmas)
 
 
 @torch.no_grad()

@@ -76,9 +76,10 @@ class GraphedDDIM:
         return set(state) == set(self._static_state)
 
     @torch.no_grad()
-    def __call__(self, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas=None) -> torch.Tensor:
-        """Same result as ``model.sample_ddim(state, x_T, goal, sigmas)``.  The returned tensor is the graph's output buffer:
-        valid until the next call (clone it to keep it)."""
+    def __call__(self, state: dict, x_T: torch.Tensor, goal: torch.Tensor, sigmas=None, fresh: bool = True) -> torch.Tensor:
+        """Same result as ``model.sample_ddim(state, x_T, goal, sigmas)``, including ``inner_model.latent_encoder_emb``: both are
+        fresh tensors the next call does not touch.  ``fresh=False`` hands out the graph's own static buffers instead (valid
+        until the next call; one copy launch less)."""
         eng = self._eng
         im = self.model.inner_model
         if im._engines.get(self._eng_key) is not eng:  # the module was moved / re-created its handle
@@ -108,12 +109,21 @@ class GraphedDDIM:
                 dst.append(self._sig); src.append(sg.detach())
                 self._last_sig = None
         fast = all(torch.is_tensor(b) and b.device == a.device and b.dtype == a.dtype and b.shape == a.shape for a, b in zip(dst, src))
-        if fast:
-            torch._foreach_copy_(dst, src)
+        foreach_copy = getattr(torch, "_foreach_copy_", None)  # private torch API: absent in older wheels -> per-tensor copies
+        if fast and foreach_copy is not None:
+            foreach_copy(dst, src)
         else:
             for a, b in zip(dst, src):
                 a.copy_(b)
         self._graph.replay()
         eng.ctx_generation += 1
-        self.model.inner_model.latent_encoder_emb = self._ctx
-        return self._out
+        if not fresh:
+            self.model.inner_model.latent_encoder_emb = self._ctx
+            return self._out
+        # Fresh tensors for the caller, as the reference leaves them (mdtv_transformer.py:221 assigns a new tensor at every forward;
+        # the agent reads it at mdtv_agent.py:256,330,445): the graph's static action and context buffers leave through ONE
+        # concatenating copy launch; the two results are views of that one fresh allocation, so the next replay overwrites neither.
+        n = self._out.numel()
+        both = torch.cat((self._out.reshape(-1), self._ctx.reshape(-1)))
+        self.model.inner_model.latent_encoder_emb = both[n:].view(self._ctx.shape)
+        return both[:n].view(self._out.shape)

@@ -270,13 +270,6 @@ class HipEngine:
                                             _ptr(x_), arr, n, B, _ptr(out), _ptr(ctx), self._stream())
         return out, ctx
 
-    def persist_status(self) -> int:
-        """Error word of the persistent decoder kernel (0 = fine); meaningful after the stream was synchronised."""
-        return int(self.lib.mdt_persist_status(self.handle))
-
-    def persist_launches(self) -> int:
-        return int(self.lib.mdt_persist_launches(self.handle))
-
     def loss_fwd(self, state: dict, action: torch.Tensor, goal: torch.Tensor, noise: torch.Tensor, sigma: torch.Tensor):
         self.sync_params()
         tok, tok2, B = self._tokens(state)

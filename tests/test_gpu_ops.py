@@ -172,6 +172,53 @@ def test_gemm_weight_stationary_body_bit_equals_the_row_tile_body(lib, M, N):
     assert torch.equal(got, ref), "weight-stationary body and row-tile body disagree bitwise"
 
 
+@pytest.mark.parametrize("M,N", [(32, 384), (33, 128), (1000, 384), (10240 + 13, 384), (2560, 1152), (8192 + 45, 1536), (70, 192),
+                                 (4096, 384)])
+def test_gemm_weight_stationary_body_at_k384_with_the_training_hooks(lib, M, N):
+    """Round 6: the weight-stationary body with ONE column tile per wave over K = 384 (24 fragment quads in registers) -- the d x d,
+    qkv and c_fc / c_proj-gradient products of the B = 1024 training step.  Plain rows, bias + GELU, and the two training hooks
+    (aux_mode 1: pre-activation kept beside the activated value; 2: product times act'(aux)), each BITWISE against the row-tile
+    body and against float64; 8- and 12-wave shapes, ragged last tiles, workgroups without a tile."""
+    L = lib.load()
+    K = 384
+    g = torch.Generator().manual_seed(M + N)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    y0 = torch.randn(M, N, generator=g)
+    Ad, Pd, bd = dev(A), pack(lib, W), dev(b)
+    outs = {}
+    try:
+        for gsel in (1, 30):
+            L.mdt_op_set_gemm_geometry(gsel)
+            o = {"plain": run_gemm(lib, A, W, bias=b), "gelu": run_gemm(lib, A, W, bias=b, act="gelu")}
+            for mode in (1, 2):
+                out = torch.full((M, N), float("nan"), device="cuda")
+                aux = torch.full((M, N), float("nan"), device="cuda") if mode == 1 else dev(y0)
+                a = lib.GemmArgs()
+                a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = Ad.data_ptr(), K, Pd.data_ptr(), out.data_ptr(), N, M, N, K
+                a.bias = bd.data_ptr() if mode == 1 else None
+                a.shift_off = a.scale_off = a.gate_off = -1
+                a.rows_per_sample = a.gin = a.gout = 1
+                a.act, a.aux, a.aux_mode = lib.ACT["gelu"], aux.data_ptr(), mode
+                lib.check(L.mdt_op_gemm(C.byref(a), stream()))
+                torch.cuda.synchronize()
+                o[f"aux{mode}"] = out.cpu()
+                if mode == 1:
+                    o["aux1_pre"] = aux.cpu()
+            outs[gsel] = o
+    finally:
+        L.mdt_op_set_gemm_geometry(0)
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[30][k]), f"{k}: weight-stationary body differs from the row-tile body"
+    u = A.double() @ W.double().T
+    assert_close(outs[30]["plain"], (u + b.double()).float(), rtol=1e-4, atol=1e-4, what="plain rows")
+    assert_close(outs[30]["gelu"], F.gelu(u + b.double()).float(), rtol=1e-4, atol=1e-4, what="bias + GELU")
+    assert_close(outs[30]["aux1_pre"], (u + b.double()).float(), rtol=1e-4, atol=1e-4, what="aux_mode 1: pre-activation")
+    assert_close(outs[30]["aux1"], F.gelu(u + b.double()).float(), rtol=1e-4, atol=1e-4, what="aux_mode 1: activated")
+    y64 = y0.double().requires_grad_()
+    F.gelu(y64).sum().backward()
+    assert_close(outs[30]["aux2"], (u * y64.grad).float(), rtol=1e-4, atol=2e-4, what="aux_mode 2: value * act'(aux)")
+
+
 @pytest.mark.parametrize("geo", [23])
 def test_gemm_tall_body_epilogues(lib, geo):
     """Every epilogue the tall body carries, against the row-tile body (bitwise) and float64: bias + GELU, per-sample gate +

@@ -351,6 +351,46 @@ def test_rollout_batch_one_matches_the_oracle_at_the_default_size():
     assert_close(got.cpu(), want, what="B = 1 actions")
 
 
+def test_replayed_rollout_calls_leave_fresh_actions_and_context():
+    """Rollout-sized calls switch to a HIP-graph replay from the third call with the same shapes on (gc_sampling._graph_wanted).
+    The replay owns static output buffers; what the caller gets -- the actions AND inner_model.latent_encoder_emb, which the
+    reference assigns afresh at every forward (mdtv_transformer.py:221; read at mdtv_agent.py:256,330,445) -- must be tensors
+    the next call does not overwrite, bit-equal to the eager call on the same inputs."""
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    cfg = configs.mdtv_default()
+    model = GCDenoiser(cfg, 0.5)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 5, "rich").items()}
+    model.load_state_dict(P, strict=False)
+    model = model.cuda().eval()
+    sig = gs.get_sigmas_exponential(5, 0.001, 80.0).cuda()
+    calls = []
+    for seed in range(6):  # six different observations, one chunk each
+        inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(1, cfg, 20 + seed).items()}
+        calls.append(({"state_images": inp["state_images"], "modality": "lang"}, inp["noise"] * 80.0, inp["goal"]))
+    eager = []
+    with torch.no_grad():
+        for st, x, g in calls:  # the eager native loop (the facade method never replays)
+            a = model.sample_ddim(st, x, g, sig)
+            eager.append((a.clone(), model.inner_model.latent_encoder_emb.clone()))
+        got = []
+        for st, x, g in calls:
+            a = gs.sample_ddim(model, st, x, g, sig)
+            got.append((a, model.inner_model.latent_encoder_emb))
+    torch.cuda.synchronize()
+    assert getattr(model, "_graphed_samplers", None), "the replay path was not taken"
+    for i, ((a, c), (ea, ec)) in enumerate(zip(got, eager)):
+        assert torch.equal(a, ea), f"call {i}: actions differ from the eager call (or were overwritten by a later call)"
+        assert torch.equal(c, ec), f"call {i}: latent_encoder_emb differs from the eager call (or was overwritten by a later call)"
+    ptrs = {t.data_ptr() for a, c in got for t in (a, c)}
+    assert len(ptrs) == 2 * len(got), "two calls handed out the same buffer"
+    inp0 = {k: torch.from_numpy(v) for k, v in synthetic.sampler_inputs(1, cfg, 25).items()}
+    want = O.sample_ddim(P, cfg, {"state_images": inp0["state_images"], "modality": "lang"}, inp0["noise"] * 80.0, inp0["goal"], sig.cpu())
+    assert_close(got[5][0].cpu(), want, what="replayed B = 1 actions")
+
+
 def test_collapsed_and_explicit_cross_attention_paths_agree(monkeypatch):
     """MDT_HIP_XFOLD=0 keeps the q-GEMM / attention / c_proj-GEMM sequence; both must match the reference golden."""
     from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
