@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense FP32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+SPEC_MHZ = 2400.0              # the shader clock the FP32-matrix peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 T_START = time.perf_counter()
 
 
@@ -255,6 +256,52 @@ def other_configs(device):
                                          "host-synchronised after every call (rollout latency)"}
     out["roofline_lowbatch"] = {"bound": "hbm", "bytes": f"decoder weights {dec_b} B x 10 steps + encoder weights {enc_b} B once "
                                                           "(SURVEY.md 8(d); activations negligible)", **low}
+    # BASELINE configs[4] stand-in (the real one needs CALVIN, the simulator and the Voltron / CLIP weights): what MDTVAgent.forward
+    # runs per replan behind its frozen encoders, composed as the agent composes it (mdtv_agent.py:392-403, 688-719) --
+    # Voltron-shaped patch tokens of both cameras (1, 1, 2 x 196, 384) -> PerceiverResampler (6 layers, 3 latents) -> state_images
+    # (1, 3, 384) + CLIP-shaped language goal (1, 1, 512) -> x_T = randn * sigma_max -> sample_ddim, host-synchronised per call
+    try:
+        from mdt_policy_amd.models.networks.transformers.perceiver_resampler import PerceiverResampler
+        perc = PerceiverResampler(dim=384, depth=6, dim_head=64, heads=8, num_latents=3, num_time_embeds=1).to(device).eval()
+        tokens = torch.randn(1, 2 * 196, 384, device=device)
+        goal1 = torch.randn(1, 512, device=device)
+
+        def replan():
+            perceptual_emb = {"state_images": perc(tokens.unsqueeze(1)), "modality": "lang"}
+            latent_goal = goal1.unsqueeze(1)
+            x = torch.randn((1, 10, 7), device=device) * 80.0
+            act = gs.sample_ddim(model, perceptual_emb, x, latent_goal, sig)
+            torch.cuda.synchronize(device)
+            return act
+
+        with torch.no_grad():
+            dt_r = timed(replan, 8, 50)
+
+            def perc_only():
+                perc(tokens.unsqueeze(1))
+                torch.cuda.synchronize(device)
+            dt_pc = timed(perc_only, 5, 50)
+        out["rollout_e2e_synthetic_B1"] = {"ms_per_replan": round(dt_r * 1e3, 3), "ms_perceiver_alone": round(dt_pc * 1e3, 3),
+                                           "what": "BASELINE configs[4] stand-in: synthetic Voltron-shaped tokens (1, 1, 392, 384) -> HIP "
+                                                   "PerceiverResampler -> (1, 3, 384) + goal (1, 1, 512) -> randn x_T -> sample_ddim "
+                                                   "(10 steps), composed as MDTVAgent.forward does, host-synchronised per replan; the "
+                                                   "frozen image / language encoders in front of it are not part of this repository"}
+    except Exception as e:  # diagnostic leg
+        out["rollout_e2e_synthetic_B1"] = {"error": repr(e)}
+    # the other samplers of the agent's dispatch table at the metric's own batch: 10 sigma steps each
+    try:
+        B2 = 256
+        st2 = {"state_images": inp["state_images"][:B2].contiguous(), "modality": "lang"}
+        g2, x2 = inp["goal"][:B2].contiguous(), inp["noise"][:B2].contiguous() * 80.0
+        sig_h = gs.get_sigmas_exponential(10, 0.001, 80.0)
+        for name, fn, evals in (("sample_heun", gs.sample_heun, 19), ("sample_dpmpp_2m", gs.sample_dpmpp_2m, 10), ("sample_euler", gs.sample_euler, 10)):
+            with torch.no_grad():
+                dt_s = timed(lambda: fn(model, st2, x2, g2, sig_h), 3, 10)
+            out[f"{name}_B256"] = {"ms_per_call": round(dt_s * 1e3, 3), "chunks_per_s": round(B2 / dt_s, 1), "model_evals": evals,
+                                   "what": f"gc_sampling.{name} over 10 exponential sigma steps, B = 256, encoder hoisted, one denoiser "
+                                           "evaluation per launch sequence (host-driven step loop)"}
+    except Exception as e:  # diagnostic leg
+        out["other_samplers_B256"] = {"error": repr(e)}
     return out
 
 
@@ -472,10 +519,17 @@ def main():
         dist.barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     timing_gather[0] = True
+    # shader-clock / 100 MHz counter pairs of one wave in front of and behind the timed region (mdt_op_clock_stamp): the clock the
+    # chip SUSTAINED over exactly these steps -- `frac` is quoted against the peak at the 2.4 GHz specification clock
+    from mdt_policy_amd import _lib as _mdt_lib
+    stamps = torch.zeros(2, 2, dtype=torch.int64, device=device)
+    lstream = torch.cuda.current_stream(device).cuda_stream
     t0 = time.perf_counter()
     e0.record()
+    _mdt_lib.check(_mdt_lib.load().mdt_op_clock_stamp(stamps[0].data_ptr(), lstream))
     for _ in range(args.steps):
         out = step()
+    _mdt_lib.check(_mdt_lib.load().mdt_op_clock_stamp(stamps[1].data_ptr(), lstream))
     e1.record()
     torch.cuda.synchronize(device)
     own_wall = time.perf_counter() - t0  # this rank's own clock, before it waits for the others
@@ -577,6 +631,19 @@ def main():
                                   f"{flops_chunk / 1e9:.3f} GFLOP/chunk, HIP-event time of the timed region",
                          "gpu_ms_per_step": round(gpu_s / args.steps * 1e3, 4)},
         }
+        try:  # the sustained clock of the timed region and the fraction of the peak AT that clock
+            st = stamps.cpu()
+            d_clk, d_ref = int(st[1, 0] - st[0, 0]), int(st[1, 1] - st[0, 1])
+            if d_clk > 0 and d_ref > 0:
+                mhz = d_clk / d_ref * 100.0
+                res["roofline"]["sustained_mhz"] = round(mhz, 1)
+                res["roofline"]["spec_mhz"] = SPEC_MHZ
+                res["roofline"]["frac_at_sustained_clock"] = round(achieved / (PEAK_FP32_MFMA_TFLOPS * mhz / SPEC_MHZ), 4)
+                res["roofline"]["clock_scope"] = ("s_memtime / s_memrealtime (100 MHz) of one wave stamped in front of and behind the timed "
+                                                  f"region on the launch stream ({d_ref / 100.0:.0f} us apart): the average shader clock over "
+                                                  "exactly the timed steps; `frac` stays quoted at the 2.4 GHz the 157.3 TFLOP/s peak assumes")
+        except Exception as e:  # diagnostic only
+            res["roofline"]["sustained_mhz_error"] = repr(e)
         try:
             dk = time_dominant_kernel(device, B * 10)
             chain = time_dominant_kernel_in_chain(step, device) if world == 1 else None

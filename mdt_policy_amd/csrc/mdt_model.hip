@@ -800,6 +800,20 @@ extern "C" int32_t mdt_op_trace_mlp_read_empty(float* us, int32_t cap) {
     return n;
 }
 
+// mdt_op_clock_stamp: the two clock counters of the wave that runs it, in stream order (include/mdt_hip_ops.h)
+__global__ void k_clock_stamp(uint64_t* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        out[0] = __builtin_amdgcn_s_memtime();
+        out[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+extern "C" mdt_status mdt_op_clock_stamp(uint64_t* out2, void* stream) {
+    if (!out2) return fail(MDT_ERR_INVALID_ARG, "mdt_op_clock_stamp: null output");
+    hipLaunchKernelGGL(k_clock_stamp, dim3(1), dim3(64), 0, (hipStream_t)stream, out2);
+    HIP_TRY(hipGetLastError());
+    return MDT_OK;
+}
+
 // `out` (optional): when given and the fused launch applies, the sublayer's output is left as slabs in V.hid (described in
 // *out) and V.y is NOT updated -- the caller hands *out to the next reader; otherwise V.y is updated in place.
 // `pre_x` (optional; rollout batches): the collapsed cross-attention that is still to run on these rows -- it goes into the

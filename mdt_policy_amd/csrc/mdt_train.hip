@@ -85,17 +85,21 @@ struct mdt_train_state {
     // while the chain (dX products, LayerNorm / attention backward) goes on.  Their dY operands then must outlive the chain's reuse
     // of its scratch: in this mode every dY of a block lives in its own piece of `dy_arena` (no reuse inside one backward;
     // ~1 GB at B = 1024, of 288).  The side stream has its own partial-product scratch.
-    hipStream_t side = nullptr;
-    hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, side_done = nullptr;
-    int side_ev_next = 0;
-    bool side_used = false;
-    float *dy_arena = nullptr, *lin_scratch2 = nullptr;
+    static const int MAX_SIDE = 3;
+    hipStream_t side[MAX_SIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_done[MAX_SIDE] = {nullptr, nullptr, nullptr};
+    int side_ev_next = 0, side_rr = 0;
+    bool side_used[MAX_SIDE] = {false, false, false};
+    float *dy_arena = nullptr, *lin_scratch2[MAX_SIDE] = {nullptr, nullptr, nullptr};
     int64_t dy_cap = 0, dy_off = 0;
 };
 
+// MDT_HIP_DW_STREAM = number of side streams the blocks' weight gradients rotate over (0: everything in the chain's stream, as in
+// rounds 1-5; default 1; measured at B = 1024, train mode: 0 -> 9.43 ms per step, 1 -> 9.15)
 static int dw_stream_mode() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MDT_HIP_DW_STREAM"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = getenv("MDT_HIP_DW_STREAM"); v = e ? atoi(e) : 1; v = v < 0 ? 0 : (v > mdt_train_state::MAX_SIDE ? mdt_train_state::MAX_SIDE : v); }
     return v;
 }
 // a dY buffer of n floats: its own piece of the arena when the weight gradients run beside the chain, else `shared`
@@ -134,11 +138,12 @@ static mdt_status scratch_leave(mdt_model* m, hipStream_t s) {
 
 static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
     mdt_train_state* ts = m->train;
-    if (ts->side_used) {  // the weight gradients that ran beside the chain (and their bias partials) before anything reads them
-        if (!ts->side_done) HIP_TRY(hipEventCreateWithFlags(&ts->side_done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ts->side_done, ts->side));
-        HIP_TRY(hipStreamWaitEvent(s, ts->side_done, 0));
-        ts->side_used = false;
+    for (int i = 0; i < mdt_train_state::MAX_SIDE; ++i) {
+        if (!ts->side_used[i]) continue;  // the weight gradients that ran beside the chain (and their bias partials) before anything reads them
+        if (!ts->side_done[i]) HIP_TRY(hipEventCreateWithFlags(&ts->side_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ts->side_done[i], ts->side[i]));
+        HIP_TRY(hipStreamWaitEvent(s, ts->side_done[i], 0));
+        ts->side_used[i] = false;
     }
     // entries of one launch run concurrently: two sums into the same gradient (a parameter read twice) go to successive launches
     std::vector<mdt_colsum_entry>& d = ts->deferred;
@@ -207,8 +212,8 @@ void mdt_train_free(mdt_model* m) {
     (void)mdt_dev_free(t->scratch);
     if (t->scratch_done) (void)hipEventDestroy(t->scratch_done);
     for (hipEvent_t e : t->side_ev) if (e) (void)hipEventDestroy(e);
-    if (t->side_done) (void)hipEventDestroy(t->side_done);
-    if (t->side) (void)hipStreamDestroy(t->side);
+    for (hipEvent_t e : t->side_done) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : t->side) if (q) (void)hipStreamDestroy(q);
     (void)hipFree(t->wt_arena);
     for (const LinPart& p : m->parts) p.lin->wt = nullptr;
     delete t;
@@ -345,12 +350,13 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
     if (m->HP) need = std::max(need, mdt_linear_bwd_scratch(Ma, m->HP, D));
     ts->lin_scratch = b.take(need);
     if (dw_stream_mode()) {
-        ts->lin_scratch2 = b.take(need);
+        for (int i = 0; i < mdt_train_state::MAX_SIDE; ++i) ts->lin_scratch2[i] = i < dw_stream_mode() ? b.take(need) : nullptr;
         // every dY of every block once: (3 + dec) x (M, D) merged gradients / dq, (M, 4D), (M, 3D) per block
         ts->dy_cap = (int64_t)m->Le * Me * (3 + 4 + 3) * D + (int64_t)m->Ld * Ma * (4 + 4 + 3) * D + 64 * (int64_t)(m->Le + m->Ld) * 8 + 1024;
         ts->dy_arena = b.take(ts->dy_cap);
     } else {
-        ts->lin_scratch2 = nullptr; ts->dy_arena = nullptr; ts->dy_cap = 0;
+        for (float*& q : ts->lin_scratch2) q = nullptr;
+        ts->dy_arena = nullptr; ts->dy_cap = 0;
     }
     ts->dF = b.take(Ma * m->A);
     ts->small = b.take(std::max<int64_t>({B * 2 * D, Mx * (int64_t)std::max(m->O, m->G), (int64_t)16 * m->HP}));
@@ -729,16 +735,17 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     float* space = a.dbias ? defer_take(ts, (int64_t)256 * l.N) : nullptr;
     if (beside && a.dW && ts->dy_arena) {
         // dW (+ bias partials) on the side stream behind "dY exists"; dX stays in the chain
-        if (!ts->side) HIP_TRY(hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking));
+        const int q = ts->side_rr++ % dw_stream_mode();
+        if (!ts->side[q]) HIP_TRY(hipStreamCreateWithFlags(&ts->side[q], hipStreamNonBlocking));
         hipEvent_t& ev = ts->side_ev[ts->side_ev_next++ & 7];
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev, s));
-        HIP_TRY(hipStreamWaitEvent(ts->side, ev, 0));
+        HIP_TRY(hipStreamWaitEvent(ts->side[q], ev, 0));
         mdt_linear_bwd_args w = a;
-        w.dX = nullptr; w.scratch = ts->lin_scratch2;
-        MDT_TRY(mdt_linear_bwd(w, ts->side, space ? &be : nullptr, space));
+        w.dX = nullptr; w.scratch = ts->lin_scratch2[q];
+        MDT_TRY(mdt_linear_bwd(w, ts->side[q], space ? &be : nullptr, space));
         if (space && be.src) ts->deferred.push_back(be);
-        ts->side_used = true;
+        ts->side_used[q] = true;
         if (a.dX) {
             mdt_linear_bwd_args x = a;
             x.dW = nullptr; x.dbias = nullptr;
