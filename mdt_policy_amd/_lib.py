@@ -206,6 +206,9 @@ SYMBOLS = [
     ("mdt_train_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, C.POINTER(Dropout), _VP, _VP, _VP,
                                   C.POINTER(_I32), _VP]),
     ("mdt_train_loss_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("mdt_train_loss_bwd_stages", _I32, [_VP]),
+    ("mdt_train_loss_bwd_stage", _I32, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("mdt_train_param_stage", _I32, [_VP, _I64]),
     ("mdt_train_encode_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I64, C.POINTER(Dropout), _VP, C.POINTER(_I32),
                                     _VP]),
     ("mdt_train_encode_bwd", _I32, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -93,6 +93,10 @@ struct mdt_train_state {
     bool side_used[MAX_SIDE] = {false, false, false};
     float *dy_arena = nullptr, *lin_scratch2[MAX_SIDE] = {nullptr, nullptr, nullptr};
     int64_t dy_cap = 0, dy_off = 0;
+    // a backward in stages (mdt_train_loss_bwd_stage): the stage expected next, and the MLP-merged gradient of the block about to run
+    int bwd_next = 0;
+    mdt_tape_id bwd_tape = -1;
+    const float* gm = nullptr;
 };
 
 // MDT_HIP_DW_STREAM = number of side streams the blocks' weight gradients rotate over (0: everything in the chain's stream, as in
@@ -136,7 +140,9 @@ static mdt_status scratch_leave(mdt_model* m, hipStream_t s) {
     return MDT_OK;
 }
 
-static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
+// End of a stage of a backward: the side streams' weight gradients joined into `s`, the small column sums collected so far
+// launched -- every gradient the stage completes is complete in the order of `s` behind this.  last: the scratch is handed on.
+static mdt_status stage_finish(mdt_model* m, hipStream_t s, bool last) {
     mdt_train_state* ts = m->train;
     for (int i = 0; i < mdt_train_state::MAX_SIDE; ++i) {
         if (!ts->side_used[i]) continue;  // the weight gradients that ran beside the chain (and their bias partials) before anything reads them
@@ -154,9 +160,11 @@ static mdt_status flush_deferred(mdt_model* m, hipStream_t s) {
         if (cut && i > lo) { LAUNCH(mdt_launch_colsum_batched(d.data() + lo, (int)(i - lo), s)); lo = i; }
     }
     ts->deferred.clear();
+    if (!last) return MDT_OK;   // (the partial tables stay where they are: defer_off only grows inside one backward)
     ts->defer_off = 0;
     return scratch_leave(m, s);
 }
+static mdt_status flush_deferred(mdt_model* m, hipStream_t s) { return stage_finish(m, s, true); }
 
 static const int NARROW_SLICES = 512;  // row slices of the narrow (A x D) weight gradients: 512 x 2 workgroups of 20 rows at B = 1024 (128 slices: 80 dependent row trips per thread, 42 us per launch)
 
@@ -893,28 +901,37 @@ static mdt_status sigma_bwd(mdt_model* m, Tape& t, float* grads, float* dc, hipS
 }
 
 // encoder backward: dxe holds d(ctx) on entry
-static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, float* d_tokens2, float* d_goal,
-                          hipStream_t s) {
+// The encoder backward in the pieces a staged backward runs one by one (ts->gm: the MLP-merged gradient of the block about to run):
+// head = the final LayerNorm, one piece per block, tail = the token embeddings.  ts->dxe holds d(ctx) on entry.
+static mdt_merge_args enc_merge_bwd(mdt_model* m, Tape& t, int l) {
+    return block_mlp_merge_bwd(m, t.enc[l], t.B, m->Te, COND_TOKEN, nullptr, nullptr, 0, m->train->dxe, t.drop, l);
+}
+static mdt_status enc_bwd_head(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
     mdt_train_state* ts = m->train;
-    const mdt_config& c = m->cfg;
     const int D = m->D, Te = m->Te;
     const int64_t B = t.B, Me = B * Te;
     // final LayerNorm: ctx = ln(x_L)
     HIP_TRY(hipMemcpyAsync(ts->t_d, ts->dxe, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    auto enc_merge = [&](int l) { return block_mlp_merge_bwd(m, t.enc[l], B, Te, COND_TOKEN, nullptr, nullptr, 0, ts->dxe, t.drop, l); };
-    const float* gm = nullptr;  // the MLP-merged gradient of the block about to run
-    {
-        const mdt_merge_args g = m->Le > 0 ? enc_merge(m->Le - 1) : mdt_merge_args{};
-        MDT_TRY(ln_bwd(m, grads, enc_last_output(m, t), t.st_f, m->enc_ln_w, m->enc_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dxe, 0,
-                       nullptr, B, Te, s, 0, m->Le > 0 ? &g : nullptr));
-        gm = g.out;
-    }
-    for (int l = m->Le - 1; l >= 0; --l) {
-        const mdt_merge_args g = l > 0 ? enc_merge(l - 1) : mdt_merge_args{};
-        MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], B, Te, false, COND_TOKEN, nullptr, nullptr, 0, nullptr, nullptr,
-                          ts->dxe, t.drop, l, s, gm, l > 0 ? &g : nullptr));
-        gm = g.out;
-    }
+    const mdt_merge_args g = m->Le > 0 ? enc_merge_bwd(m, t, m->Le - 1) : mdt_merge_args{};
+    MDT_TRY(ln_bwd(m, grads, enc_last_output(m, t), t.st_f, m->enc_ln_w, m->enc_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dxe, 0,
+                   nullptr, B, Te, s, 0, m->Le > 0 ? &g : nullptr));
+    ts->gm = g.out;
+    return MDT_OK;
+}
+static mdt_status enc_bwd_block(mdt_model* m, Tape& t, float* grads, int l, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const mdt_merge_args g = l > 0 ? enc_merge_bwd(m, t, l - 1) : mdt_merge_args{};
+    MDT_TRY(block_bwd(m, grads, m->enc[l], nullptr, t.enc[l], t.B, m->Te, false, COND_TOKEN, nullptr, nullptr, 0, nullptr, nullptr,
+                      ts->dxe, t.drop, l, s, ts->gm, l > 0 ? &g : nullptr));
+    ts->gm = g.out;
+    return MDT_OK;
+}
+static mdt_status enc_bwd_tail(mdt_model* m, Tape& t, float* grads, float* d_tokens, float* d_tokens2, float* d_goal,
+                               hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const mdt_config& c = m->cfg;
+    const int D = m->D, Te = m->Te;
+    const int64_t B = t.B, Me = B * Te;
     const int t0 = m->sig_tok;
     const int drop_lo = embed_drop_from(m);
     if (drop_lo >= 0)
@@ -970,6 +987,11 @@ static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, 
     }
     return MDT_OK;
 }
+static mdt_status enc_bwd(mdt_model* m, Tape& t, float* grads, float* d_tokens, float* d_tokens2, float* d_goal, hipStream_t s) {
+    MDT_TRY(enc_bwd_head(m, t, grads, s));
+    for (int l = m->Le - 1; l >= 0; --l) MDT_TRY(enc_bwd_block(m, t, grads, l, s));
+    return enc_bwd_tail(m, t, grads, d_tokens, d_tokens2, d_goal, s);
+}
 
 extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const float* g_ctx, float* grads, float* d_tokens,
                                            float* d_tokens2, float* d_goal, void* stream) {
@@ -986,41 +1008,26 @@ extern "C" mdt_status mdt_train_encode_bwd(mdt_model* m, mdt_tape_id tape, const
     return flush_deferred(m, s);
 }
 
-static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s);
-
-extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const float* g_loss, const float* g_ctx, float* grads,
-                                         float* d_tokens, float* d_tokens2, float* d_goal, void* stream) {
-    Tape* tp;
-    MDT_TRY(get_tape(m, tape, &tp));
-    Tape& t = *tp;
-    if (!grads) return fail(MDT_ERR_INVALID_ARG, "mdt_train_loss_bwd: null gradient buffer");
-    if (!t.has_decoder) return fail(MDT_ERR_STATE, "tape %d holds an encoder-only forward: use mdt_train_encode_bwd", tape);
-    hipStream_t s = (hipStream_t)stream;
-    t.stream = s;
-    mdt_train_state* ts = m->train;
-    MDT_TRY(scratch_enter(m, s));
-    MDT_TRY(reserve_scratch(m, t.B));
-    ts->deferred.clear(); ts->defer_off = 0; ts->dy_off = 0;
-    const int D = m->D, Ta = m->Ta, A = m->A;
-    const int64_t B = t.B, Ma = B * Ta, Me = B * m->Te;
-    // ---- loss and action head: F = action_pred(ln(x_L))
-    LAUNCH(mdt_launch_loss_grad(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, Ta * A, g_loss, ts->dF, s));
-    MDT_TRY(dec_bwd(m, t, grads, s));
-    // ---- context: K|V projections of all blocks, plus whatever other losses hung onto latent_encoder_emb
-    if (g_ctx) HIP_TRY(hipMemcpyAsync(ts->dxe, g_ctx, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    MDT_TRY(lin_bwd(m, grads, m->kv_all, t.ctx, D, ts->d_kvx, (int64_t)m->Ld * 2 * D, (int)Me, ts->dxe, D, g_ctx ? 1 : 0, s));
-    MDT_TRY(enc_bwd(m, t, grads, d_tokens, d_tokens2, d_goal, s));
-    return flush_deferred(m, s);
-}
-
 // Decoder backward from ts->dF = d(raw network output F) down to ts->dx = d(action embedding rows y0); the K|V gradient of
 // every block is left in ts->d_kvx.  grads == nullptr: input gradients only (no parameter gradient, no sigma path).
-static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
+// In the pieces a staged backward runs one by one: head = action head + final LayerNorm, one piece per block, tail = action
+// embedding + sigma path.
+struct DecCond {
+    int64_t modw, mod_blk;
+    bool rows;
+};
+static DecCond dec_cond(const mdt_model* m) {
+    return {m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * m->D : m->D, m->cond == COND_ADALN ? 6 * (int64_t)m->D : 0, m->cond != COND_TOKEN};
+}
+static mdt_merge_args dec_merge_bwd(mdt_model* m, Tape& t, int l) {
+    const DecCond dc = dec_cond(m);
+    return block_mlp_merge_bwd(m, t.dec[l], t.B, m->Ta, m->cond, dc.rows ? t.mod + l * dc.mod_blk : nullptr,
+                               dc.rows ? m->train->d_mod + l * dc.mod_blk : nullptr, dc.modw, m->train->dx, t.drop, m->Le + l);
+}
+static mdt_status dec_bwd_head(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
     mdt_train_state* ts = m->train;
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta;
-    const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * D : D;
-    const int64_t mod_blk = m->cond == COND_ADALN ? 6 * D : 0;
     if (grads) LAUNCH(mdt_launch_colsum(ts->dF, A, (int)Ma, A, grad_of(m, grads, m->bp), 1, s));
     if (m->HP) {
         // F = action_pred.2(gelu(action_pred.0(ln))): the narrow layer on the (rows, HP) hidden rows, whose gradient
@@ -1042,27 +1049,29 @@ static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
         LAUNCH(mdt_launch_narrow_dx(ts->dF, m->Wp, ts->t_d, (int)Ma, A, D, s));
     }
     if (m->cond == COND_NOISE) HIP_TRY(hipMemsetAsync(ts->d_mod, 0, (size_t)B * D * sizeof(float), s));  // d_c accumulates
-    const bool rows = m->cond != COND_TOKEN;
-    auto mod_of = [&](int l) { return rows ? (const float*)(t.mod + l * mod_blk) : (const float*)nullptr; };
-    auto dmod_of = [&](int l) { return rows ? ts->d_mod + l * mod_blk : (float*)nullptr; };
-    auto dec_merge = [&](int l) {
-        return block_mlp_merge_bwd(m, t.dec[l], B, Ta, m->cond, mod_of(l), dmod_of(l), modw, ts->dx, t.drop, m->Le + l);
-    };
-    const float* gm = nullptr;  // the MLP-merged gradient of the block about to run
-    {   // the final LayerNorm's backward also runs the last block's MLP merge backward
-        const mdt_merge_args g = dec_merge(m->Ld - 1);
-        MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
-                       B, Ta, s, 0, &g));
-        gm = g.out;
-    }
-    // ---- decoder blocks
-    for (int l = m->Ld - 1; l >= 0; --l) {
-        const mdt_merge_args g = l > 0 ? dec_merge(l - 1) : mdt_merge_args{};
-        MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond, mod_of(l), dmod_of(l), modw,
-                          t.kvx + (int64_t)l * 2 * D, ts->d_kvx + (int64_t)l * 2 * D, ts->dx, t.drop, m->Le + l, s, gm,
-                          l > 0 ? &g : nullptr));
-        gm = g.out;
-    }
+    // the final LayerNorm's backward also runs the last block's MLP merge backward
+    const mdt_merge_args g = dec_merge_bwd(m, t, m->Ld - 1);
+    MDT_TRY(ln_bwd(m, grads, t.dec[m->Ld - 1].x3, t.st_h, m->dec_ln_w, m->dec_ln_b, nullptr, 0, -1, -1, ts->t_d, ts->dx, 0, nullptr,
+                   B, Ta, s, 0, &g));
+    ts->gm = g.out;
+    return MDT_OK;
+}
+static mdt_status dec_bwd_block(mdt_model* m, Tape& t, float* grads, int l, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const int D = m->D;
+    const DecCond dc = dec_cond(m);
+    const mdt_merge_args g = l > 0 ? dec_merge_bwd(m, t, l - 1) : mdt_merge_args{};
+    MDT_TRY(block_bwd(m, grads, m->dec[l], &m->dec[l], t.dec[l], t.B, m->Ta, true, m->cond, dc.rows ? t.mod + l * dc.mod_blk : nullptr,
+                      dc.rows ? ts->d_mod + l * dc.mod_blk : nullptr, dc.modw, t.kvx + (int64_t)l * 2 * D,
+                      ts->d_kvx + (int64_t)l * 2 * D, ts->dx, t.drop, m->Le + l, s, ts->gm, l > 0 ? &g : nullptr));
+    ts->gm = g.out;
+    return MDT_OK;
+}
+static mdt_status dec_bwd_tail(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
+    mdt_train_state* ts = m->train;
+    const int D = m->D, Ta = m->Ta, A = m->A;
+    const int64_t B = t.B, Ma = B * Ta;
+    const DecCond dc = dec_cond(m);
     // ---- action embedding: y0 = drop(action_emb(xin)); no gradient flows to the noisy actions
     LAUNCH(mdt_launch_dropout_rows(ts->dx, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed,
                                    s));
@@ -1073,13 +1082,109 @@ static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
     // ---- sigma path.  adaLN: mod = modulation(silu(c)), c = sigma_emb(sigma); NoiseBlock: the rows are c itself;
     //      sigma token: its gradient arrives with the context's (enc_bwd)
     if (m->cond == COND_ADALN) {
-        MDT_TRY(lin_bwd(m, grads, m->mod_all, t.sig_s, D, ts->d_mod, modw, (int)B, ts->small, D, 0, s));
+        MDT_TRY(lin_bwd(m, grads, m->mod_all, t.sig_s, D, ts->d_mod, dc.modw, (int)B, ts->small, D, 0, s));
         LAUNCH(mdt_launch_act_bwd(t.sig_cpre, ts->small, ts->small, B * D, MDT_ACT_SILU, s));
         MDT_TRY(sigma_bwd(m, t, grads, ts->small, s));
     } else if (m->cond == COND_NOISE) {
         MDT_TRY(sigma_bwd(m, t, grads, ts->d_mod, s));
     }
     return MDT_OK;
+}
+static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
+    MDT_TRY(dec_bwd_head(m, t, grads, s));
+    for (int l = m->Ld - 1; l >= 0; --l) MDT_TRY(dec_bwd_block(m, t, grads, l, s));
+    return dec_bwd_tail(m, t, grads, s);
+}
+
+// The backward of mdt_train_loss_fwd in STAGES (round 6): stage k completes the gradients of a known set of parameters
+// (mdt_train_param_stage) in the order of `stream`, so that a caller -- torch's DistributedDataParallel behind one autograd node
+// per stage -- can start reducing them while the later stages still run.
+//   0               : loss, action head, final LayerNorm, decoder block Ld - 1
+//   1 .. Ld - 1     : decoder blocks Ld - 2 .. 0
+//   Ld              : action embedding, sigma path (sigma MLP, the stacked adaLN Linear), the stacked cross K|V Linear, the
+//                     encoder's final LayerNorm
+//   Ld + 1 .. Ld + Le : encoder blocks Le - 1 .. 0
+//   Ld + Le + 1     : token / goal embeddings (and the gradients of the encoder inputs)
+extern "C" int32_t mdt_train_loss_bwd_stages(const mdt_model* m) { return m ? m->Ld + m->Le + 2 : -1; }
+
+extern "C" mdt_status mdt_train_loss_bwd_stage(mdt_model* m, mdt_tape_id tape, int32_t stage, const float* g_loss, const float* g_ctx,
+                                               float* grads, float* d_tokens, float* d_tokens2, float* d_goal, void* stream) {
+    Tape* tp;
+    MDT_TRY(get_tape(m, tape, &tp));
+    Tape& t = *tp;
+    if (!grads) return fail(MDT_ERR_INVALID_ARG, "mdt_train_loss_bwd: null gradient buffer");
+    if (!t.has_decoder) return fail(MDT_ERR_STATE, "tape %d holds an encoder-only forward: use mdt_train_encode_bwd", tape);
+    hipStream_t s = (hipStream_t)stream;
+    mdt_train_state* ts = m->train;
+    const int Ld = m->Ld, Le = m->Le, n = Ld + Le + 2;
+    if (stage < 0 || stage >= n) return fail(MDT_ERR_INVALID_ARG, "mdt_train_loss_bwd_stage: stage %d of %d", stage, n);
+    if (stage == 0) {
+        t.stream = s;
+        MDT_TRY(scratch_enter(m, s));
+        MDT_TRY(reserve_scratch(m, t.B));
+        ts->deferred.clear(); ts->defer_off = 0; ts->dy_off = 0;
+        ts->bwd_tape = tape;
+    } else if (ts->bwd_next != stage || ts->bwd_tape != tape) {
+        return fail(MDT_ERR_STATE, "mdt_train_loss_bwd_stage: stage %d of tape %d out of order (expected stage %d of tape %d)", stage,
+                    tape, ts->bwd_next, ts->bwd_tape);
+    }
+    ts->bwd_next = -1;  // (an error below leaves the run unusable)
+    const int D = m->D, Ta = m->Ta, A = m->A;
+    const int64_t B = t.B, Ma = B * Ta, Me = B * m->Te;
+    if (stage == 0) {
+        // ---- loss and action head: F = action_pred(ln(x_L))
+        LAUNCH(mdt_launch_loss_grad(t.F, t.action, t.noised, t.sigma, m->cfg.sigma_data, Ma * A, Ta * A, g_loss, ts->dF, s));
+        MDT_TRY(dec_bwd_head(m, t, grads, s));
+        MDT_TRY(dec_bwd_block(m, t, grads, Ld - 1, s));
+    } else if (stage < Ld) {
+        MDT_TRY(dec_bwd_block(m, t, grads, Ld - 1 - stage, s));
+    } else if (stage == Ld) {
+        MDT_TRY(dec_bwd_tail(m, t, grads, s));
+        // ---- context: K|V projections of all blocks, plus whatever other losses hung onto latent_encoder_emb
+        if (g_ctx) HIP_TRY(hipMemcpyAsync(ts->dxe, g_ctx, (size_t)Me * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        MDT_TRY(lin_bwd(m, grads, m->kv_all, t.ctx, D, ts->d_kvx, (int64_t)Ld * 2 * D, (int)Me, ts->dxe, D, g_ctx ? 1 : 0, s));
+        MDT_TRY(enc_bwd_head(m, t, grads, s));
+    } else if (stage <= Ld + Le) {
+        MDT_TRY(enc_bwd_block(m, t, grads, Le - 1 - (stage - Ld - 1), s));
+    } else {
+        MDT_TRY(enc_bwd_tail(m, t, grads, d_tokens, d_tokens2, d_goal, s));
+    }
+    MDT_TRY(stage_finish(m, s, stage == n - 1));
+    ts->bwd_next = stage == n - 1 ? 0 : stage + 1;
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const float* g_loss, const float* g_ctx, float* grads,
+                                         float* d_tokens, float* d_tokens2, float* d_goal, void* stream) {
+    if (!m || !m->train) return fail(MDT_ERR_STATE, "training was not prepared (mdt_train_prepare)");
+    const int n = m->Ld + m->Le + 2;
+    for (int k = 0; k < n; ++k)
+        MDT_TRY(mdt_train_loss_bwd_stage(m, tape, k, g_loss, g_ctx, grads, d_tokens, d_tokens2, d_goal, stream));
+    return MDT_OK;
+}
+
+// The stage of mdt_train_loss_bwd_stage behind which parameter slot i's gradient is complete (by its reference name).
+extern "C" int32_t mdt_train_param_stage(const mdt_model* m, int64_t i) {
+    if (!m || i < 0 || i >= (int64_t)m->slots.size()) return -1;
+    const std::string& nm = m->slots[i].name;
+    const int Ld = m->Ld, Le = m->Le, last = Ld + Le + 1;
+    auto block_of = [&](const char* key) -> int {
+        const size_t p = nm.find(key);
+        return p == std::string::npos ? -1 : atoi(nm.c_str() + p + strlen(key));
+    };
+    const int dl = block_of("decoder.blocks."), el = block_of("encoder.blocks.");
+    if (dl >= 0 && dl < Ld) {
+        // the stacked Linears of all blocks (adaLN modulation, cross-attention K | V) get their gradient in ONE product at stage Ld
+        if (nm.find("adaLN_zero") != std::string::npos || nm.find("cross_att.key") != std::string::npos ||
+            nm.find("cross_att.value") != std::string::npos)
+            return Ld;
+        return Ld - 1 - dl;
+    }
+    if (el >= 0 && el < Le) return Ld + 1 + (Le - 1 - el);
+    if (nm.find("action_pred") != std::string::npos || nm.find("decoder.ln") != std::string::npos) return 0;
+    if (nm.find("action_emb") != std::string::npos || nm.find("encoder.ln") != std::string::npos) return Ld;
+    if (nm.find("sigma_emb") != std::string::npos) return m->cond == COND_TOKEN ? last : Ld;  // sigma token: with the embeddings
+    return last;  // tok_emb, goal_emb / lang_emb, pos_emb, incam_embed, proprio_emb
 }
 
 // ------------------------------------------------------------------------------------------------

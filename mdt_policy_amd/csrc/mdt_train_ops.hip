@@ -52,13 +52,15 @@ static void split_rows_tn(int64_t M, int64_t N, int64_t K, int* S, int* L) {
     // in units of 64-column tiles whatever the n-tile: a 128- / 192-wide workgroup counts two / three times (it has as many waves)
     const int64_t tiles = ((N + 63) / 64) * ((K + tk - 1) / tk);
     static int64_t target = -1;
-    if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 1536; }  // measured at B = 1024: 768 -> 11.27 ms step / 42.1 ms head, 1536 -> 11.18 / 41.4, 2304 -> 11.22 / 41.4
+    if (target < 0) { const char* e = getenv("MDT_HIP_TN_TARGET"); target = e ? atoll(e) : 512; }  // measured at B = 1024: round 2, everything in one stream: 768 -> 11.27 ms step / 42.1 ms head, 1536 -> 11.18 / 41.4, 2304 -> 11.22 / 41.4; round 6, the weight gradients beside the chain on a side stream: 1536 -> 9.34, 768 -> 9.25, 512 -> 9.23 (fewer, deeper slices: less partial-sum traffic beside the chain)
     int64_t s = std::max<int64_t>(1, std::min<int64_t>((target + tiles - 1) / tiles, M / 128));
     if (tn == 192) {
         // twelve-wave workgroups, one per CU: ONE round of them (tools/dw_bench.py at M = 104448, us at 32 / 64 / 128 slices:
         // 1536 x 192 (8 tiles) 597 / 624 / 616, 192 x 768 (4) 495 / 280 / 302, 576 x 192 (3) 483 / 263 / 281)
         const int64_t tiles192 = (N / 192) * (K / 192);
-        s = std::max<int64_t>(1, std::min<int64_t>((256 + tiles192 / 2) / tiles192, M / 128));
+        static int64_t round = -1;  // MDT_HIP_TN_ROUND: workgroups aimed for (A/B runs; beside the backward chain fewer may pay)
+        if (round < 0) { const char* e = getenv("MDT_HIP_TN_ROUND"); round = e ? atoll(e) : 256; if (round < 1 || round > 256) round = 256; }
+        s = std::max<int64_t>(1, std::min<int64_t>((round + tiles192 / 2) / tiles192, M / 128));
     }
     static int64_t cap = -1;
     if (cap < 0) { const char* e = getenv("MDT_HIP_TN_SLICES"); cap = e ? atoll(e) : 128; }  // measured: masked-image head 37.7 ms (64) -> 37.2 (128) = (192, 256); denoiser step unchanged

@@ -17,6 +17,21 @@ from torch import nn
 from ..networks._engine import HipScoreNetwork
 
 
+def _staged_backward() -> bool:
+    """One autograd node per stage of the HIP backward (``_autograd.staged_diffusion_loss``) instead of one for all of it:
+    MDT_HIP_BWD_STAGES=1 always, 0 never, unset: whenever a process group with more than one rank exists -- the case in which
+    gradients that appear block by block let DistributedDataParallel reduce them behind the backward."""
+    import os
+    v = os.environ.get("MDT_HIP_BWD_STAGES", "auto")
+    if v != "auto":
+        return v not in ("", "0")
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def _instantiate(cfg):
     """hydra.utils.instantiate when Hydra is installed, else the same thing for a flat kwargs mapping."""
     if isinstance(cfg, nn.Module):
@@ -103,12 +118,17 @@ class GCDenoiser(nn.Module):
         im = self.inner_model
         if self._wants_grad(goal, *[v for v in state.values() if torch.is_tensor(v)]):
             # training step: HIP forward with a tape + HIP backward behind torch.autograd
-            from ._autograd import HipDiffusionLoss
+            from ._autograd import HipDiffusionLoss, staged_diffusion_loss
             eng = self._engine(allow_grad=True, state=state)
             tok, tok2, g, B, names, params = self._train_inputs(eng, state, goal, im._arch == "mdtv")
             a, nz = eng._in(action, (B, eng.Ta, eng.A)), eng._in(noise, (B, eng.Ta, eng.A))
-            loss, model_output, ctx = HipDiffusionLoss.apply(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)),
-                                                             im.train_dropout(), names, *params)
+            if _staged_backward():  # one autograd node per stage of the backward: gradients appear block by block (DDP overlap)
+                eng.train_prepare()
+                loss, model_output, ctx = staged_diffusion_loss(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)),
+                                                                im.train_dropout(), names, params)
+            else:
+                loss, model_output, ctx = HipDiffusionLoss.apply(eng, state, tok, tok2, g, a, nz, eng._in(sigma, (B,)),
+                                                                 im.train_dropout(), names, *params)
             im.latent_encoder_emb = ctx
             return loss, model_output
         loss, model_output, ctx = self._engine(state=state).loss_fwd(state, action, im._goals(goal, False), noise, sigma)

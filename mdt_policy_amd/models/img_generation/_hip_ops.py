@@ -113,17 +113,74 @@ class PackedWeights:
         return wp, wt
 
 
-def _linear_bwd(lib, x2, dY, N, K, wt, need_x, need_w, need_b, dx_cols=None, act_u=None, act=0):
+# ---- weight gradients beside the backward chain (round 6) -----------------------------------------------------------------
+# dW = dY^T X (and the bias gradient) of a Linear is a leaf of the backward: nothing reads it before the optimizer.  As in the
+# denoiser's own backward (csrc/mdt_train.hip, MDT_HIP_DW_STREAM) it runs on a side stream behind "dY exists" while the chain
+# -- the input-gradient products, the norm / attention backward -- goes on; ONE join, queued as an end-of-backward callback of
+# the autograd engine, puts the side stream back in front of whatever follows loss.backward().  Only where nothing can look at
+# the gradient earlier: the parameters carry no .grad yet (AccumulateGrad then adopts the tensor without a kernel) and no tensor
+# hooks, and no multi-rank process group exists (DistributedDataParallel copies a gradient into its bucket the moment it appears).
+_SIDE = {}
+
+
+def _dw_beside(params) -> bool:
+    import os
+    if os.environ.get("MDT_HIP_MAE_DW_STREAM", "1") in ("", "0"):
+        return False
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+    except Exception:  # noqa: BLE001
+        pass
+    return all(p is None or (p.grad is None and not p._backward_hooks) for p in params)
+
+
+def _side_stream(dev: torch.device):
+    st = _SIDE.get(dev.index)
+    if st is None:
+        st = _SIDE[dev.index] = {"stream": torch.cuda.Stream(dev), "pending": False, "keep": []}
+    side = st["stream"]
+    side.wait_stream(torch.cuda.current_stream(dev))  # the operands (dY, X) exist
+    if not st["pending"]:
+        st["pending"] = True
+
+        def join():  # end of this backward pass, in the caller's thread and stream
+            torch.cuda.current_stream(dev).wait_stream(side)
+            st["pending"] = False
+            del st["keep"][:]  # released BEHIND the join: whoever reuses their memory is ordered behind the side stream's reads
+
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+    return side, st["keep"]
+
+
+def _linear_bwd(lib, x2, dY, N, K, wt, need_x, need_w, need_b, dx_cols=None, act_u=None, act=0, beside=False):
     """mdt_op_linear_bwd on contiguous (M, K) x2 / (M, N) dY -> (dX, dW, db); dx_cols / act_u / act: the activation below
-    rides on the input-gradient product (SwishGLU: dX has 2 K columns)."""
+    rides on the input-gradient product (SwishGLU: dX has 2 K columns).  beside: dW / db on the side stream (above)."""
     M = x2.shape[0]
     dW = torch.empty((N, K), device=dY.device, dtype=torch.float32) if need_w else None
     db = torch.empty((N,), device=dY.device, dtype=torch.float32) if need_b else None
     xc = K if dx_cols is None else dx_cols
     dX = torch.empty((M, xc), device=dY.device, dtype=torch.float32) if need_x else None
     scratch = torch.empty(max(1, lib.mdt_op_linear_bwd_scratch(M, N, K)), device=dY.device, dtype=torch.float32)
+    if beside and (need_w or need_b):
+        side, keep = _side_stream(dY.device)
+        w = _lib.LinearBwdArgs(X=x2.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None, dW=None if dW is None else dW.data_ptr(),
+                               dbias=None if db is None else db.data_ptr(), dX=None, ldxo=xc, accumulate_dw=0, accumulate_dx=0,
+                               M=M, N=N, K=K, scratch=scratch.data_ptr(), dx_act_u=None, dx_act=0)
+        _lib.check(lib.mdt_op_linear_bwd(C.byref(w), side.cuda_stream))
+        # torch's allocator must not hand their memory on while the side stream uses it: held until the join (not record_stream --
+        # blocks that come free at event-dependent moments made the caching allocator grow by fresh hipMallocs now and then: one
+        # run in three of tools/mae_bench.py took 219 instead of 26 ms per step)
+        # (NOT dW / db: a second reference would make AccumulateGrad clone the gradient -- on the chain's stream, before the side
+        #  stream has written it -- instead of adopting the tensor; they stay alive as the parameters' .grad)
+        keep.extend(t for t in (x2, dY, scratch) if t is not None)
+        if dX is None:
+            return dX, dW, db
+        need_w = need_b = False
+        scratch = torch.empty(max(1, lib.mdt_op_linear_bwd_scratch(M, N, K)), device=dY.device, dtype=torch.float32)
     a = _lib.LinearBwdArgs(X=x2.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None if wt is None else wt.data_ptr(),
-                           dW=None if dW is None else dW.data_ptr(), dbias=None if db is None else db.data_ptr(),
+                           dW=dW.data_ptr() if need_w else None, dbias=db.data_ptr() if need_b else None,
                            dX=None if dX is None else dX.data_ptr(), ldxo=xc, accumulate_dw=0, accumulate_dx=0, M=M, N=N, K=K,
                            scratch=scratch.data_ptr(), dx_act_u=None if (act_u is None or dX is None) else act_u.data_ptr(), dx_act=act)
     _lib.check(lib.mdt_op_linear_bwd(C.byref(a), _stream(dY)))
@@ -179,11 +236,13 @@ class HipSwiGLUMLP(torch.autograd.Function):
         need_u = nx or nw0 or (b0 is not None and nb0)
         w1t = ctx.packs.get(w1, w1, True)[1] if need_u else None
         # mlp.1: dW1 = dY^T h, db1, and d_u = swiglu'(u) (dY W1) in the same launch sequence
-        du, dW1, db1 = _linear_bwd(lib, h, dY, N1, H, w1t, need_u, nw1, b1 is not None and nb1, dx_cols=H2, act_u=u, act=_lib.ACT["swiglu"])
+        beside = _dw_beside((w0, b0, w1, b1))
+        du, dW1, db1 = _linear_bwd(lib, h, dY, N1, H, w1t, need_u, nw1, b1 is not None and nb1, dx_cols=H2, act_u=u, act=_lib.ACT["swiglu"],
+                                   beside=beside)
         dX = dW0 = db0 = None
         if need_u:
             w0t = ctx.packs.get(w0, w0, True)[1] if nx else None
-            dX, dW0, db0 = _linear_bwd(lib, x2, du, H2, K, w0t, nx, nw0, b0 is not None and nb0)
+            dX, dW0, db0 = _linear_bwd(lib, x2, du, H2, K, w0t, nx, nw0, b0 is not None and nb0, beside=beside)
         return (None if dX is None else dX.reshape(ctx.xshape), dW0, db0, dW1, db1, None)
 
 
@@ -220,15 +279,7 @@ class HipLinear(torch.autograd.Function):
         dY = _c(g).reshape(M, N)
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
         wt = ctx.packs.get(w2d, weight, True)[1] if need_x else None
-        dW = torch.empty((N, K), device=dY.device, dtype=torch.float32) if need_w else None
-        db = torch.empty((N,), device=dY.device, dtype=torch.float32) if need_b else None
-        dX = torch.empty((M, K), device=dY.device, dtype=torch.float32) if need_x else None
-        scratch = torch.empty(max(1, lib.mdt_op_linear_bwd_scratch(M, N, K)), device=dY.device, dtype=torch.float32)
-        a = _lib.LinearBwdArgs(X=x2.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None if wt is None else wt.data_ptr(),
-                               dW=None if dW is None else dW.data_ptr(), dbias=None if db is None else db.data_ptr(),
-                               dX=None if dX is None else dX.data_ptr(), ldxo=K, accumulate_dw=0, accumulate_dx=0, M=M, N=N, K=K,
-                               scratch=scratch.data_ptr())
-        _lib.check(lib.mdt_op_linear_bwd(C.byref(a), _stream(dY)))
+        dX, dW, db = _linear_bwd(lib, x2, dY, N, K, wt, need_x, need_w, need_b, beside=_dw_beside((weight, bias)))
         return (None if dX is None else dX.reshape(ctx.xshape), None if dW is None else dW.reshape(weight.shape), db, None)
 
 

@@ -300,6 +300,11 @@ class HipEngine:
                              (int(self.lib.mdt_grad_offset(self.handle, i)), int(self.lib.mdt_param_numel(self.handle, i)))
                              for i in range(n)}
         self._grad_numel = int(self.lib.mdt_grad_numel(self.handle))
+        # the stage of the staged backward (mdt_train_loss_bwd_stage) that completes each parameter's gradient
+        self._n_stages = int(self.lib.mdt_train_loss_bwd_stages(self.handle))
+        self._param_stage = {self.lib.mdt_param_name(self.handle, i).decode(): int(self.lib.mdt_train_param_stage(self.handle, i))
+                             for i in range(n)}
+        self.stages_enqueued = 0  # stages of staged backwards enqueued so far (tests read it from DDP communication hooks)
 
     def train_loss_fwd(self, state: dict, tok, tok2, goal, action, noise, sigma, drop=None):
         self.train_prepare()
@@ -345,6 +350,20 @@ class HipEngine:
         _lib.call(self.lib.mdt_train_loss_bwd, self.handle, tape, _ptr(gl), _ptr(gc), _ptr(grads), _ptr(d_tok),
                                                _ptr(d_tok2), _ptr(d_goal), self._stream())
         return grads, d_tok, d_tok2, d_goal
+
+    def train_loss_bwd_begin(self, g_loss, g_ctx, tok, tok2, goal, needs):
+        """Buffers of one staged backward: (flat gradient buffer, input gradients, argument tuple of every stage call)."""
+        grads = torch.zeros(self._grad_numel, device=self.device, dtype=torch.float32)
+        d_tok, d_tok2, d_goal = self._input_grads(tok, tok2, goal, needs)
+        gl = None if g_loss is None else self._in(g_loss, ())
+        gc = None if g_ctx is None else self._in(g_ctx)
+        return grads, (d_tok, d_tok2, d_goal), (gl, gc)
+
+    def train_loss_bwd_stage(self, tape: int, stage: int, grads, dins, gs) -> None:
+        """Enqueue stage `stage`; behind it (stream order) the gradients of the parameters of that stage are complete."""
+        _lib.call(self.lib.mdt_train_loss_bwd_stage, self.handle, tape, int(stage), _ptr(gs[0]), _ptr(gs[1]), _ptr(grads),
+                                                     _ptr(dins[0]), _ptr(dins[1]), _ptr(dins[2]), self._stream())
+        self.stages_enqueued += 1
 
     def train_encode_bwd(self, tape: int, g_ctx, tok, tok2, goal, needs):
         grads = torch.zeros(self._grad_numel, device=self.device, dtype=torch.float32)

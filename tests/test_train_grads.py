@@ -296,15 +296,31 @@ def _ddp_worker(rank, world, port, q):
         model = model.cuda().eval()
         B = meta["B"]
         lo, hi = rank * B // world, (rank + 1) * B // world
-        ddp = DDP(_LossModule(model), find_unused_parameters=True)
+        # find_unused_parameters: what Lightning 1.x's strategy "ddp" (reference mdt/training.py:74-79) passes, and what the reference
+        # model needs as well -- pos_emb, proprio_emb and the other modality's goal embedder take no part in a forward
+        # (their gradient stays None, and AdamW skips them instead of decaying them)
+        ddp = DDP(_LossModule(model), find_unused_parameters=True, bucket_cap_mb=0.05)
+        eng_of = lambda: next(iter(model.inner_model._engines.values()))
+        log = []  # (bucket index, stages of the HIP backward enqueued when the bucket's reduction was launched)
+
+        def hook(state_, bucket):
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            log.append((bucket.index(), eng_of().stages_enqueued))
+            return default_hooks.allreduce_hook(None, bucket)
+
+        ddp.register_comm_hook(None, hook)
         st = {k: (v[lo:hi].cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+        per_iter = []
         for _ in range(2):  # a second iteration: the reducer must have seen every bucket of the first one complete
             ddp.zero_grad()
             loss = ddp(st, li["actions"][lo:hi].cuda(), goal[lo:hi].cuda(), li["noise_train"][lo:hi].cuda(),
                        li["sigma"][lo:hi].cuda())
+            s0 = eng_of().stages_enqueued
+            del log[:]
             loss.backward()
+            per_iter.append([(b, n - s0) for b, n in log])
         g = {k: p.grad.cpu().numpy() for k, p in model.inner_model.named_parameters() if p.grad is not None}
-        q.put((rank, g if rank == 0 else None))
+        q.put((rank, (g, per_iter, eng_of()._n_stages) if rank == 0 else None))
     finally:
         dist.destroy_process_group()
 
@@ -346,9 +362,73 @@ def test_hip_gradients_under_distributed_data_parallel():
     loss, _ = model.loss(st, li["actions"].cuda(), goal.cuda(), li["noise_train"].cuda(), li["sigma"].cuda())
     loss.backward()
     full = {k: p.grad.cpu() for k, p in model.inner_model.named_parameters() if p.grad is not None}
-    assert set(full) == set(got[0])
+    grads, per_iter, n_stages = got[0]
+    assert set(full) == set(grads)
     for k, ref in full.items():
-        assert_close(got[0][k], ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-7, what=k)
+        assert_close(grads[k], ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-7, what=k)
+    # The backward ran in stages (a process group with two ranks exists: score_wrappers._staged_backward), one autograd node per
+    # stage, so DDP launched bucket reductions while later stages had not been enqueued yet: at least six of them before the last
+    # stage, in every iteration -- with the one-node backward of rounds 1-5 every hook saw the whole backward enqueued.
+    for it in per_iter:
+        early = [b for b, n in it if n < n_stages]
+        assert len(it) >= 8 and len(early) >= 6, (n_stages, it)
+        # Bucket 0 holds the LAST registered parameters (action_pred, action_emb, sigma_emb, decoder.ln, the last decoder
+        # blocks) and DDP launches buckets in order: sigma_emb / action_emb need the whole decoder's backward, so the first
+        # reduction leaves with the decoder's last stage (Ld + 1 stages enqueued) -- the encoder's stages and the embeddings
+        # (a quarter of the backward) run under the reductions
+        Ld = cfg["n_dec_layers"]
+        assert min(n for _, n in it) <= Ld + 1, it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mdtv_tiny", "mdtv_default", "mdt_tiny", "mdtv_noise_block", "mdtv_no_ada", "mdt_no_ada", "mdtv_mlp_head",
+                                  "mdtv_bias_plain_goal", "mdt_no_goal_cond"])
+def test_staged_backward_equals_the_one_call_backward_and_completes_parameters_stage_by_stage(name, monkeypatch):
+    """mdt_train_loss_bwd_stage (round 6): (i) the chain of per-stage autograd nodes leaves the gradients of the one-node
+    backward, bit for bit, including the input gradients and a gradient arriving at latent_encoder_emb; (ii) after stage k the
+    gradient slots of every parameter with mdt_train_param_stage == k hold their final value (what a DDP bucket reads)."""
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    meta, fx, cfg, state, goal, li = case(name)
+    res = {}
+    for staged in ("0", "1"):
+        monkeypatch.setenv("MDT_HIP_BWD_STAGES", staged)
+        model = GCDenoiser(cfg, 0.5)
+        model.load_state_dict(params_of(meta))
+        model = model.cuda().eval()
+        st = {k: (v.cuda().requires_grad_() if torch.is_tensor(v) else v) for k, v in state.items()}
+        g = goal.cuda().requires_grad_()
+        loss, _ = model.loss(st, li["actions"].cuda(), g, li["noise_train"].cuda(), li["sigma"].cuda())
+        extra = (model.inner_model.latent_encoder_emb * 0.37).sum()   # another loss hanging on the context
+        (loss + extra).backward()
+        res[staged] = ({k: p.grad.clone() for k, p in model.inner_model.named_parameters() if p.grad is not None},
+                       {k: v.grad.clone() for k, v in st.items() if torch.is_tensor(v) and v.grad is not None}, g.grad.clone())
+    (p0, i0, g0), (p1, i1, g1) = res["0"], res["1"]
+    assert set(p0) == set(p1) and set(i0) == set(i1)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), f"{k}: staged and one-call gradients differ"
+    for k in i0:
+        assert torch.equal(i0[k], i1[k]), f"input gradient {k} differs"
+    assert torch.equal(g0, g1)
+    # (ii) stage by stage through the engine
+    st = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    eng = model._engine(allow_grad=True, state=st)
+    tok, tok2, gg, B, _, _ = model._train_inputs(eng, st, goal.cuda(), model.inner_model._arch == "mdtv")
+    a, nz = eng._in(li["actions"].cuda(), (B, eng.Ta, eng.A)), eng._in(li["noise_train"].cuda(), (B, eng.Ta, eng.A))
+    _, _, _, tape = eng.train_loss_fwd(st, tok, tok2, gg, a, nz, eng._in(li["sigma"].cuda(), (B,)), None)
+    buf = eng.train_loss_bwd_begin(torch.ones((), device="cuda"), None, tok, tok2, gg, (False, False, False))
+    snaps = []
+    for k in range(eng._n_stages):
+        eng.train_loss_bwd_stage(tape, k, *buf)
+        torch.cuda.synchronize()
+        snaps.append(buf[0].clone())
+    eng.tape_release(tape)
+    final = snaps[-1]
+    stages_seen = set()
+    for nm, (off, n) in eng._grad_layout.items():
+        k = eng._param_stage[nm]
+        stages_seen.add(k)
+        assert torch.equal(snaps[k][off:off + n], final[off:off + n]), f"{nm}: not complete behind its stage {k}"
+    assert len(stages_seen) >= eng._n_stages - 1   # every stage (but possibly one) completes some parameter
 
 
 def _dropout_stats(overrides, fixture="g13_dropout_stats.npz"):
