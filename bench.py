@@ -163,15 +163,28 @@ def other_configs(device):
     torch.manual_seed(0)
     model = GCDenoiser(cfg, 0.5).to(device)
 
+    from mdt_policy_amd import _lib as _L
+    stamps = torch.zeros(2, 2, dtype=torch.int64, device=device)
+    last_mhz = [None]
+
     def timed(fn, warm, n):
+        """Mean seconds per call of n calls behind `warm` warm-ups; last_mhz[0]: the shader clock sustained over the timed calls
+        (mdt_op_clock_stamp in front of and behind them on the launch stream)."""
         for _ in range(warm):
             fn()
         torch.cuda.synchronize(device)
+        ls = torch.cuda.current_stream(device).cuda_stream
         t0 = time.perf_counter()
+        _L.check(_L.load().mdt_op_clock_stamp(stamps[0].data_ptr(), ls))
         for _ in range(n):
             fn()
+        _L.check(_L.load().mdt_op_clock_stamp(stamps[1].data_ptr(), ls))
         torch.cuda.synchronize(device)
-        return (time.perf_counter() - t0) / n
+        dt = (time.perf_counter() - t0) / n
+        st = stamps.cpu()
+        d_clk, d_ref = int(st[1, 0] - st[0, 0]), int(st[1, 1] - st[0, 1])
+        last_mhz[0] = round(d_clk / d_ref * 100.0, 1) if d_clk > 0 and d_ref > 0 else None
+        return dt
 
     B = 1024
     inp = {k: torch.from_numpy(v).to(device) for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
@@ -191,7 +204,7 @@ def other_configs(device):
     # 242.8 MFLOP / sample = mdt_flops_per_chunk(1)) + backward ~ 2x forward
     fwd = model.inner_model.hip_engine(0.5).flops_per_chunk(1)
     tf = 3.0 * fwd * B / dt / 1e12
-    out["train_step_mdtv_B1024"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1),
+    out["train_step_mdtv_B1024"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1), "sustained_mhz": last_mhz[0],
                                     "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                                                  "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                                                  "flops_per_sample": round(3.0 * fwd)},
@@ -218,7 +231,7 @@ def other_configs(device):
 
         dt3 = timed(step_c3, 2, 5)
         tf3 = (3.0 * fwd * B + mae_flops(B)) / dt3 / 1e12
-        out["train_step_c3_mdtv_B1024"] = {"ms_per_step": round(dt3 * 1e3, 3), "samples_per_s": round(B / dt3, 1),
+        out["train_step_c3_mdtv_B1024"] = {"ms_per_step": round(dt3 * 1e3, 3), "samples_per_s": round(B / dt3, 1), "sustained_mhz": last_mhz[0],
                                            "roofline": {"bound": "mfma", "achieved": round(tf3, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                                                         "unit": "TFLOP/s", "frac": round(tf3 / PEAK_FP32_MFMA_TFLOPS, 4),
                                                         "flops_per_sample": round(3.0 * fwd + mae_flops(1))},

@@ -386,13 +386,9 @@ extern "C" mdt_status mdt_create(const mdt_config* cfg, mdt_model** out) {
     m->xfold = cond == COND_ADALN && !c.use_rot_embed && mdt_xattn_apply_supported(m->D, m->H, m->Te, m->Ta);
     if (const char* x = getenv("MDT_HIP_XFOLD")) m->xfold = m->xfold && atoi(x) != 0;
     if (const char* w = getenv("MDT_HIP_WAYS")) m->ways = std::max(1, std::min(MAX_WAYS, atoi(w)));
-    for (int i = 0; i < MAX_WAYS - 1; ++i) {
-        if (hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) != hipSuccess) {
-            mdt_destroy(m);
-            return fail(MDT_ERR_HIP, "could not create the sampler's auxiliary streams/events");
-        }
-    }
+    // (the auxiliary streams of MDT_HIP_WAYS > 1 are created on first use: every stream a process creates takes a slot in the
+    //  runtime's small pool of hardware queues, and three idle ones per handle pushed the training path's side stream onto a
+    //  queue it shares -- the B = 1024 step read 9.75 ms inside bench.py, where two handles exist, against 9.19 alone)
     if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) {
         mdt_destroy(m);
         return fail(MDT_ERR_HIP, "could not create the sampler's fork event");
@@ -1220,6 +1216,10 @@ static mdt_status sample_ddim_impl(mdt_model* m, const float* tokens, const floa
     hipStream_t st[MAX_WAYS];
     st[0] = s;
     if (ways > 1) {
+        for (int w = 1; w < ways; ++w) {
+            if (!m->aux[w - 1]) HIP_TRY(hipStreamCreateWithFlags(&m->aux[w - 1], hipStreamNonBlocking));
+            if (!m->ev_join[w - 1]) HIP_TRY(hipEventCreateWithFlags(&m->ev_join[w - 1], hipEventDisableTiming));
+        }
         HIP_TRY(hipEventRecord(m->ev_fork, s));
         for (int w = 1; w < ways; ++w) {
             st[w] = m->aux[w - 1];

@@ -744,7 +744,17 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     if (beside && a.dW && ts->dy_arena) {
         // dW (+ bias partials) on the side stream behind "dY exists"; dX stays in the chain
         const int q = ts->side_rr++ % dw_stream_mode();
-        if (!ts->side[q]) HIP_TRY(hipStreamCreateWithFlags(&ts->side[q], hipStreamNonBlocking));
+        if (!ts->side[q]) {
+            // MDT_HIP_DW_PRIO (A/B runs): 0 = default priority, 1 = the LOWEST the device offers (the chain's kernels first, the
+            // weight gradients in what is left), 2 = the highest
+            static int prio = -1;
+            if (prio < 0) { const char* e = getenv("MDT_HIP_DW_PRIO"); prio = e ? atoi(e) : 0; }
+            int least = 0, greatest = 0;
+            if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+                HIP_TRY(hipStreamCreateWithPriority(&ts->side[q], hipStreamNonBlocking, prio == 1 ? least : greatest));
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&ts->side[q], hipStreamNonBlocking));
+        }
         hipEvent_t& ev = ts->side_ev[ts->side_ev_next++ & 7];
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev, s));

@@ -17,7 +17,11 @@ model = GCDenoiser(cfg, 0.5).cuda()
 inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
 li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
 state = {"state_images": inp["state_images"], "modality": "lang"}
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+if os.environ.get("MDT_TRAIN_BENCH_OPT", "torch") == "fused":  # this package's one-launch AdamW (what bench.py's step uses)
+    from mdt_policy_amd.optim import FusedAdamW
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+else:
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
 n_params = sum(p.numel() for p in model.parameters())
 for mode in os.environ.get("MDT_TRAIN_BENCH_MODES", "eval,train").split(","):
     model.train(mode == "train")
