@@ -93,6 +93,8 @@ struct mdt_train_state {
     bool side_used[MAX_SIDE] = {false, false, false};
     float *dy_arena = nullptr, *lin_scratch2[MAX_SIDE] = {nullptr, nullptr, nullptr};
     int64_t dy_cap = 0, dy_off = 0;
+    float *narrow2 = nullptr, *small2 = nullptr;  // the decoder tail's own scratch when it runs beside the encoder's backward
+    hipEvent_t fwd_fork = nullptr, fwd_join = nullptr;  // forward: the sigma path / action embedding beside the encoder
     // a backward in stages (mdt_train_loss_bwd_stage): the stage expected next, and the MLP-merged gradient of the block about to run
     int bwd_next = 0;
     mdt_tape_id bwd_tape = -1;
@@ -106,6 +108,7 @@ static int dw_stream_mode() {
     if (v < 0) { const char* e = getenv("MDT_HIP_DW_STREAM"); v = e ? atoi(e) : 1; v = v < 0 ? 0 : (v > mdt_train_state::MAX_SIDE ? mdt_train_state::MAX_SIDE : v); }
     return v;
 }
+static mdt_status side_fork(mdt_train_state* ts, int q, hipStream_t s, hipStream_t* out);  // (defined with the backward)
 // a dY buffer of n floats: its own piece of the arena when the weight gradients run beside the chain, else `shared`
 static float* dy_take(mdt_train_state* ts, int64_t n, float* shared) {
     if (!ts->dy_arena) return shared;
@@ -221,6 +224,8 @@ void mdt_train_free(mdt_model* m) {
     if (t->scratch_done) (void)hipEventDestroy(t->scratch_done);
     for (hipEvent_t e : t->side_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : t->side_done) if (e) (void)hipEventDestroy(e);
+    if (t->fwd_fork) (void)hipEventDestroy(t->fwd_fork);
+    if (t->fwd_join) (void)hipEventDestroy(t->fwd_join);
     for (hipStream_t q : t->side) if (q) (void)hipStreamDestroy(q);
     (void)hipFree(t->wt_arena);
     for (const LinPart& p : m->parts) p.lin->wt = nullptr;
@@ -362,7 +367,10 @@ static void carve_scratch(const mdt_model* m, Bump& b, mdt_train_state* ts, int6
         // every dY of every block once: (3 + dec) x (M, D) merged gradients / dq, (M, 4D), (M, 3D) per block
         ts->dy_cap = (int64_t)m->Le * Me * (3 + 4 + 3) * D + (int64_t)m->Ld * Ma * (4 + 4 + 3) * D + 64 * (int64_t)(m->Le + m->Ld) * 8 + 1024;
         ts->dy_arena = b.take(ts->dy_cap);
+        ts->narrow2 = b.take((size_t)NARROW_SLICES * 16 * std::max({D, m->HP, m->p_row >= 0 ? 2 * D : 0}));
+        ts->small2 = b.take(B * 3 * D + 64);
     } else {
+        ts->narrow2 = ts->small2 = nullptr;
         for (float*& q : ts->lin_scratch2) q = nullptr;
         ts->dy_arena = nullptr; ts->dy_cap = 0;
     }
@@ -611,16 +619,14 @@ static mdt_status enc_fwd(mdt_model* m, Tape& t, const float* tokens, const floa
     return MDT_OK;
 }
 
-static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const float* noise, const float* sigma, float* loss_out,
-                          float* model_output, hipStream_t s) {
+// What the decoder needs that does NOT depend on the context: the conditioning rows (sigma MLP, stacked adaLN Linear), the noised /
+// preconditioned actions and their embedding.  With the sigma token (COND_TOKEN) the encoder has run the sigma MLP itself (and
+// filled t.sigma), so this runs behind it; otherwise it is independent of the encoder and may run beside it (mdt_train_loss_fwd).
+static mdt_status dec_fwd_pre(mdt_model* m, Tape& t, const float* action, const float* noise, const float* sigma, hipStream_t s) {
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta;
-    // conditioning rows of the decoder blocks: adaLN-Zero (B, Ld*6D), NoiseBlock (B, D) = c, sigma token: none
     const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * D : D;
-    const int64_t mod_blk = m->cond == COND_ADALN ? 6 * D : 0;  // a block's offset in the row
     HIP_TRY(hipMemcpyAsync(t.action, action, (size_t)Ma * A * sizeof(float), hipMemcpyDeviceToDevice, s));
-    // cross-attention K|V of all decoder blocks
-    LAUNCH(mdt_launch_gemm(gemm_args(t.ctx, D, m->kv_all, t.kvx, (int64_t)m->Ld * 2 * D, (int)(B * m->Te)), s));
     if (m->cond == COND_ADALN) {  // sigma embedding -> SiLU -> the stacked modulation Linear of every block
         MDT_TRY(sigma_fwd(m, t, sigma, t.sig_cpre, 1, s));
         LAUNCH(mdt_launch_act_fwd(t.sig_cpre, t.sig_s, B * D, MDT_ACT_SILU, s));
@@ -634,6 +640,20 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     LAUNCH(mdt_launch_scaled_input(t.noised, t.sigma, m->cfg.sigma_data, Ma * A, per, t.xin, s));
     LAUNCH(mdt_launch_action_embed(t.xin, nullptr, 0, m->cfg.sigma_data, m->Wa, m->ba, t.y0, (int)Ma, A, D, Ta, s));
     LAUNCH(mdt_launch_dropout_rows(t.y0, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed, s));
+    return MDT_OK;
+}
+
+static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const float* noise, const float* sigma, float* loss_out,
+                          float* model_output, hipStream_t s, bool pre_done = false) {
+    const int D = m->D, Ta = m->Ta, A = m->A;
+    const int64_t B = t.B, Ma = B * Ta;
+    // conditioning rows of the decoder blocks: adaLN-Zero (B, Ld*6D), NoiseBlock (B, D) = c, sigma token: none
+    const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * D : D;
+    const int64_t mod_blk = m->cond == COND_ADALN ? 6 * D : 0;  // a block's offset in the row
+    if (!pre_done) MDT_TRY(dec_fwd_pre(m, t, action, noise, sigma, s));
+    const int per = Ta * A;
+    // cross-attention K|V of all decoder blocks
+    LAUNCH(mdt_launch_gemm(gemm_args(t.ctx, D, m->kv_all, t.kvx, (int64_t)m->Ld * 2 * D, (int)(B * m->Te)), s));
     for (int l = 0; l < m->Ld; ++l) t.dec[l].x_in = l == 0 ? t.y0 : t.dec[l - 1].x3;
     float* xl = t.dec[m->Ld - 1].x3;
     const mdt_ln_train_args lh = ln_args(xl, m->dec_ln_w, m->dec_ln_b, t.lnout, t.st_h, (int)Ma, D);
@@ -710,8 +730,22 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
     Tape& t = m->train->tapes[*tape];
     t.drop = effective_dropout(drop);
     const int honour = m->cfg.arch == MDT_ARCH_MDTV;  // MDTTransformer.forward always uses goal_emb (mdt_transformer.py:215)
-    mdt_status st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, sigma, ctx_out, s);
-    if (st == MDT_OK) st = dec_fwd(m, t, action, noise, sigma, loss_out, model_output, s);
+    // The decoder's context-independent preparation (sigma MLP, stacked adaLN Linear, action embedding: ~10 small launches) on the
+    // side stream beside the encoder (round 6, MDT_HIP_DW_STREAM); the chain waits for it in front of the first decoder kernel
+    mdt_train_state* ts = m->train;
+    const bool pre_beside = dw_stream_mode() > 0 && m->cond != COND_TOKEN;
+    mdt_status st = MDT_OK;
+    if (pre_beside) {
+        hipStream_t sq = nullptr;
+        st = side_fork(ts, 0, s, &sq);
+        if (st == MDT_OK) st = dec_fwd_pre(m, t, action, noise, sigma, sq);
+        if (st == MDT_OK && !ts->fwd_join && hipEventCreateWithFlags(&ts->fwd_join, hipEventDisableTiming) != hipSuccess)
+            st = fail(MDT_ERR_HIP, "could not create the forward join event");
+        if (st == MDT_OK && hipEventRecord(ts->fwd_join, sq) != hipSuccess) st = fail(MDT_ERR_HIP, "event record failed");
+    }
+    if (st == MDT_OK) st = enc_fwd(m, t, tokens, tokens2, goal, modality, honour, sigma, ctx_out, s);
+    if (st == MDT_OK && pre_beside && hipStreamWaitEvent(s, ts->fwd_join, 0) != hipSuccess) st = fail(MDT_ERR_HIP, "stream wait failed");
+    if (st == MDT_OK) st = dec_fwd(m, t, action, noise, sigma, loss_out, model_output, s, pre_beside);
     if (st != MDT_OK) t.in_use = false;
     return st;
 }
@@ -719,11 +753,37 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// side stream q of the handle (created on first use)
+static mdt_status side_stream(mdt_train_state* ts, int q, hipStream_t* out) {
+    if (!ts->side[q]) {
+        // MDT_HIP_DW_PRIO (A/B runs): 0 = default priority, 1 = the LOWEST the device offers (the chain's kernels first, the
+        // weight gradients in what is left: measured 9.17 against 9.08 ms), 2 = the highest (9.08)
+        static int prio = -1;
+        if (prio < 0) { const char* e = getenv("MDT_HIP_DW_PRIO"); prio = e ? atoi(e) : 0; }
+        int least = 0, greatest = 0;
+        if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+            HIP_TRY(hipStreamCreateWithPriority(&ts->side[q], hipStreamNonBlocking, prio == 1 ? least : greatest));
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&ts->side[q], hipStreamNonBlocking));
+    }
+    *out = ts->side[q];
+    return MDT_OK;
+}
+// side stream q ordered behind everything enqueued on `s` so far
+static mdt_status side_fork(mdt_train_state* ts, int q, hipStream_t s, hipStream_t* out) {
+    MDT_TRY(side_stream(ts, q, out));
+    hipEvent_t& ev = ts->side_ev[ts->side_ev_next++ & 7];
+    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, s));
+    HIP_TRY(hipStreamWaitEvent(*out, ev, 0));
+    return MDT_OK;
+}
+
 // gradient slots of a (possibly stacked) Linear: every reference Linear inside `l`
 // beside: this product's dY lives in the arena (dy_take) -- its weight gradient may run on the side stream
 static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float* X, int64_t ldx, const float* dY, int64_t ldy,
                           int M, float* dX, int64_t ldxo, int acc_dx, hipStream_t s, const float* act_u = nullptr, int act = 0,
-                          bool beside = false) {
+                          bool beside = false, float* scratch_override = nullptr) {
     mdt_train_state* ts = m->train;
     const LinPart* first = nullptr;  // the part at row 0: the stack's gradient region starts at its slot
     for (const LinPart& p : m->parts)
@@ -737,31 +797,18 @@ static mdt_status lin_bwd(mdt_model* m, float* grads, const Lin& l, const float*
     a.dbias = (grads && first->b_slot >= 0) ? grads + ts->grad_off[first->b_slot] : nullptr;
     a.accumulate_dw = 1;
     a.Wt = l.wt; a.dX = dX; a.ldxo = ldxo; a.accumulate_dx = acc_dx;
-    a.M = M; a.N = l.N; a.K = l.K; a.scratch = ts->lin_scratch;
+    a.M = M; a.N = l.N; a.K = l.K; a.scratch = scratch_override ? scratch_override : ts->lin_scratch;
     a.dx_act_u = act_u; a.dx_act = act;
     mdt_colsum_entry be;
     float* space = a.dbias ? defer_take(ts, (int64_t)256 * l.N) : nullptr;
     if (beside && a.dW && ts->dy_arena) {
         // dW (+ bias partials) on the side stream behind "dY exists"; dX stays in the chain
         const int q = ts->side_rr++ % dw_stream_mode();
-        if (!ts->side[q]) {
-            // MDT_HIP_DW_PRIO (A/B runs): 0 = default priority, 1 = the LOWEST the device offers (the chain's kernels first, the
-            // weight gradients in what is left), 2 = the highest
-            static int prio = -1;
-            if (prio < 0) { const char* e = getenv("MDT_HIP_DW_PRIO"); prio = e ? atoi(e) : 0; }
-            int least = 0, greatest = 0;
-            if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
-                HIP_TRY(hipStreamCreateWithPriority(&ts->side[q], hipStreamNonBlocking, prio == 1 ? least : greatest));
-            else
-                HIP_TRY(hipStreamCreateWithFlags(&ts->side[q], hipStreamNonBlocking));
-        }
-        hipEvent_t& ev = ts->side_ev[ts->side_ev_next++ & 7];
-        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ev, s));
-        HIP_TRY(hipStreamWaitEvent(ts->side[q], ev, 0));
+        hipStream_t sq;
+        MDT_TRY(side_fork(ts, q, s, &sq));
         mdt_linear_bwd_args w = a;
         w.dX = nullptr; w.scratch = ts->lin_scratch2[q];
-        MDT_TRY(mdt_linear_bwd(w, ts->side[q], space ? &be : nullptr, space));
+        MDT_TRY(mdt_linear_bwd(w, sq, space ? &be : nullptr, space));
         if (space && be.src) ts->deferred.push_back(be);
         ts->side_used[q] = true;
         if (a.dX) {
@@ -900,13 +947,16 @@ static mdt_status block_bwd(mdt_model* m, float* grads, const EncBlock& e, const
 }
 
 // backward of sigma_fwd given d(c) (B, D) in `dc` (consumed); sigma itself takes no gradient
-static mdt_status sigma_bwd(mdt_model* m, Tape& t, float* grads, float* dc, hipStream_t s) {
+// tmp (B, 2D) / scratch: the caller's own buffers when this runs beside the chain (else the shared ones)
+static mdt_status sigma_bwd(mdt_model* m, Tape& t, float* grads, float* dc, hipStream_t s, float* tmp = nullptr,
+                            float* scratch = nullptr) {
     mdt_train_state* ts = m->train;
     const int D = m->D;
     const int64_t B = t.B;
-    MDT_TRY(lin_bwd(m, grads, m->sig3, t.sig_t, 2 * D, dc, D, (int)B, ts->t_d2, 2 * D, 0, s));
-    LAUNCH(mdt_launch_act_bwd(t.sig_tpre, ts->t_d2, ts->t_d2, B * 2 * D, MDT_ACT_MISH, s));
-    MDT_TRY(lin_bwd(m, grads, m->sig1, t.sig_e, D, ts->t_d2, 2 * D, (int)B, nullptr, 0, 0, s));
+    if (!tmp) tmp = ts->t_d2;
+    MDT_TRY(lin_bwd(m, grads, m->sig3, t.sig_t, 2 * D, dc, D, (int)B, tmp, 2 * D, 0, s, nullptr, 0, false, scratch));
+    LAUNCH(mdt_launch_act_bwd(t.sig_tpre, tmp, tmp, B * 2 * D, MDT_ACT_MISH, s));
+    MDT_TRY(lin_bwd(m, grads, m->sig1, t.sig_e, D, tmp, 2 * D, (int)B, nullptr, 0, 0, s, nullptr, 0, false, scratch));
     return MDT_OK;
 }
 
@@ -1077,26 +1127,37 @@ static mdt_status dec_bwd_block(mdt_model* m, Tape& t, float* grads, int l, hipS
     ts->gm = g.out;
     return MDT_OK;
 }
+// The tail's gradients (action_emb, the sigma MLP, the stacked adaLN Linear) are leaves: nothing in the rest of the backward --
+// the cross K|V Linear and the encoder -- reads them or the buffers they come from (ts->dx, ts->d_mod are final).  With the
+// weight gradients beside the chain (MDT_HIP_DW_STREAM) the whole tail therefore runs on the side stream, with its own scratch,
+// while the chain goes on into the encoder (~0.25 ms of small launches at B = 1024).
 static mdt_status dec_bwd_tail(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
     mdt_train_state* ts = m->train;
     const int D = m->D, Ta = m->Ta, A = m->A;
     const int64_t B = t.B, Ma = B * Ta;
     const DecCond dc = dec_cond(m);
+    const bool beside = grads && ts->dy_arena && ts->small2;
+    float *narrow = ts->narrow, *small = ts->small, *tmp = nullptr, *scratch = nullptr;
+    if (beside) {
+        MDT_TRY(side_fork(ts, 0, s, &s));  // from here on `s` is the side stream
+        ts->side_used[0] = true;
+        narrow = ts->narrow2; small = ts->small2; tmp = ts->small2 + B * D; scratch = ts->lin_scratch2[0];
+    }
     // ---- action embedding: y0 = drop(action_emb(xin)); no gradient flows to the noisy actions
     LAUNCH(mdt_launch_dropout_rows(ts->dx, Ma, D, Ta, 0, t.drop.embed_p, site_id(m->Le + m->Ld, SITE_EMBED_ACTION), t.drop.seed,
                                    s));
     if (!grads) return MDT_OK;
     LAUNCH(mdt_launch_colsum(ts->dx, D, (int)Ma, D, grad_of(m, grads, m->ba), 1, s));
-    LAUNCH(mdt_launch_narrow_dw(t.xin, ts->dx, D, ts->narrow, NARROW_SLICES, (int)Ma, A, D, 1, s));
-    LAUNCH(mdt_launch_colsum(ts->narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wa), 1, s));
+    LAUNCH(mdt_launch_narrow_dw(t.xin, ts->dx, D, narrow, NARROW_SLICES, (int)Ma, A, D, 1, s));
+    LAUNCH(mdt_launch_colsum(narrow, (int64_t)A * D, NARROW_SLICES, A * D, grad_of(m, grads, m->Wa), 1, s));
     // ---- sigma path.  adaLN: mod = modulation(silu(c)), c = sigma_emb(sigma); NoiseBlock: the rows are c itself;
     //      sigma token: its gradient arrives with the context's (enc_bwd)
     if (m->cond == COND_ADALN) {
-        MDT_TRY(lin_bwd(m, grads, m->mod_all, t.sig_s, D, ts->d_mod, dc.modw, (int)B, ts->small, D, 0, s));
-        LAUNCH(mdt_launch_act_bwd(t.sig_cpre, ts->small, ts->small, B * D, MDT_ACT_SILU, s));
-        MDT_TRY(sigma_bwd(m, t, grads, ts->small, s));
+        MDT_TRY(lin_bwd(m, grads, m->mod_all, t.sig_s, D, ts->d_mod, dc.modw, (int)B, small, D, 0, s, nullptr, 0, false, scratch));
+        LAUNCH(mdt_launch_act_bwd(t.sig_cpre, small, small, B * D, MDT_ACT_SILU, s));
+        MDT_TRY(sigma_bwd(m, t, grads, small, s, tmp, scratch));
     } else if (m->cond == COND_NOISE) {
-        MDT_TRY(sigma_bwd(m, t, grads, ts->d_mod, s));
+        MDT_TRY(sigma_bwd(m, t, grads, ts->d_mod, s, tmp, scratch));
     }
     return MDT_OK;
 }
@@ -1117,8 +1178,10 @@ static mdt_status dec_bwd(mdt_model* m, Tape& t, float* grads, hipStream_t s) {
 //   Ld + Le + 1     : token / goal embeddings (and the gradients of the encoder inputs)
 extern "C" int32_t mdt_train_loss_bwd_stages(const mdt_model* m) { return m ? m->Ld + m->Le + 2 : -1; }
 
-extern "C" mdt_status mdt_train_loss_bwd_stage(mdt_model* m, mdt_tape_id tape, int32_t stage, const float* g_loss, const float* g_ctx,
-                                               float* grads, float* d_tokens, float* d_tokens2, float* d_goal, void* stream) {
+// sync: make the stage's gradients complete in the order of `stream` before returning (what the staged entry point promises);
+// the one-call backward only needs that at its end -- its side-stream work then overlaps across the stages
+static mdt_status loss_bwd_stage_impl(mdt_model* m, mdt_tape_id tape, int32_t stage, const float* g_loss, const float* g_ctx,
+                                      float* grads, float* d_tokens, float* d_tokens2, float* d_goal, void* stream, bool sync) {
     Tape* tp;
     MDT_TRY(get_tape(m, tape, &tp));
     Tape& t = *tp;
@@ -1159,9 +1222,14 @@ extern "C" mdt_status mdt_train_loss_bwd_stage(mdt_model* m, mdt_tape_id tape, i
     } else {
         MDT_TRY(enc_bwd_tail(m, t, grads, d_tokens, d_tokens2, d_goal, s));
     }
-    MDT_TRY(stage_finish(m, s, stage == n - 1));
+    if (sync || stage == n - 1) MDT_TRY(stage_finish(m, s, stage == n - 1));
     ts->bwd_next = stage == n - 1 ? 0 : stage + 1;
     return MDT_OK;
+}
+
+extern "C" mdt_status mdt_train_loss_bwd_stage(mdt_model* m, mdt_tape_id tape, int32_t stage, const float* g_loss, const float* g_ctx,
+                                               float* grads, float* d_tokens, float* d_tokens2, float* d_goal, void* stream) {
+    return loss_bwd_stage_impl(m, tape, stage, g_loss, g_ctx, grads, d_tokens, d_tokens2, d_goal, stream, true);
 }
 
 extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const float* g_loss, const float* g_ctx, float* grads,
@@ -1169,7 +1237,7 @@ extern "C" mdt_status mdt_train_loss_bwd(mdt_model* m, mdt_tape_id tape, const f
     if (!m || !m->train) return fail(MDT_ERR_STATE, "training was not prepared (mdt_train_prepare)");
     const int n = m->Ld + m->Le + 2;
     for (int k = 0; k < n; ++k)
-        MDT_TRY(mdt_train_loss_bwd_stage(m, tape, k, g_loss, g_ctx, grads, d_tokens, d_tokens2, d_goal, stream));
+        MDT_TRY(loss_bwd_stage_impl(m, tape, k, g_loss, g_ctx, grads, d_tokens, d_tokens2, d_goal, stream, false));
     return MDT_OK;
 }
 
