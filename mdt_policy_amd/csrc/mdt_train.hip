@@ -487,22 +487,29 @@ static mdt_status merge_then_ln(const mdt_merge_args& g, const mdt_ln_train_args
 // that reads this block's output (the next block's ln_1 or the stack's final LayerNorm) -- it rides in the last merge's launch.
 static mdt_status block_fwd(mdt_model* m, const EncBlock& e, const DecBlock* d, BlockTape& t, int64_t B, int T, bool causal,
                             int cond, const float* mod, int64_t modw, const float* kv, const mdt_dropout& dr, int blk,
-                            hipStream_t s, bool ln1_done = false, const mdt_ln_train_args* tail_ln = nullptr) {
+                            hipStream_t s, bool ln1_done = false, const mdt_ln_train_args* tail_ln = nullptr, int half = 0) {
+    // half (decoder blocks): 1 = only the self-attention half, which needs no context (through the merge + ln3 launch and the
+    // cross-attention's query product); 2 = the rest; 0 = the whole block
     const int D = m->D, M = (int)(B * T);
     const CondLayout c = cond_layout(mod ? cond : COND_TOKEN, D);
-    if (!ln1_done) LAUNCH(mdt_launch_ln_fwd_train(block_ln1_args(m, e, t, B, T, cond, mod, modw), s));
-    LAUNCH(mdt_launch_gemm(gemm_args(t.h1, D, e.qkv, t.qkv, 3 * D, M), s));
-    MDT_TRY(attn_fwd(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, t.att, B, T, T, causal, dr, site_id(blk, SITE_ATTN), s));
-    LAUNCH(mdt_launch_gemm(gemm_args(t.att, D, e.proj, t.a1, D, M), s));
     const mdt_merge_args g1 = merge_args(t.x_in, t.a1, c.g1 >= 0 ? mod + c.g1 : nullptr, modw, t.x1, B, T, D, dr.resid_p,
                                          site_id(blk, SITE_RESID), dr.seed);
     mdt_ln_train_args l2 = ln_args(t.x2, e.ln2_w, e.ln2_b, t.h2, t.st2, M, D);
     ln_cond(l2, mod, modw, c.sh2, c.sc2, T);
+    if (half != 2) {
+        if (!ln1_done) LAUNCH(mdt_launch_ln_fwd_train(block_ln1_args(m, e, t, B, T, cond, mod, modw), s));
+        LAUNCH(mdt_launch_gemm(gemm_args(t.h1, D, e.qkv, t.qkv, 3 * D, M), s));
+        MDT_TRY(attn_fwd(m, t.qkv, 3 * D, t.qkv + D, t.qkv + 2 * D, 3 * D, t.att, B, T, T, causal, dr, site_id(blk, SITE_ATTN), s));
+        LAUNCH(mdt_launch_gemm(gemm_args(t.att, D, e.proj, t.a1, D, M), s));
+    }
     if (d) {
-        mdt_ln_train_args l3 = ln_args(t.x1, d->ln3_w, d->ln3_b, t.h3, t.st3, M, D);
-        ln_cond(l3, mod, modw, c.sh3, -1, T);
-        MDT_TRY(merge_then_ln(g1, l3, s));
-        LAUNCH(mdt_launch_gemm(gemm_args(t.h3, D, d->xq, t.q, D, M), s));
+        if (half != 2) {
+            mdt_ln_train_args l3 = ln_args(t.x1, d->ln3_w, d->ln3_b, t.h3, t.st3, M, D);
+            ln_cond(l3, mod, modw, c.sh3, -1, T);
+            MDT_TRY(merge_then_ln(g1, l3, s));
+            LAUNCH(mdt_launch_gemm(gemm_args(t.h3, D, d->xq, t.q, D, M), s));
+        }
+        if (half == 1) return MDT_OK;
         // SDPA is_causal on a Ta x Te matrix: top-left aligned (transformer_blocks.py:204,142)
         MDT_TRY(attn_fwd(m, t.q, D, kv, kv + D, (int64_t)m->Ld * 2 * D, t.att2, B, T, m->Te, true, dr, site_id(blk, SITE_XATTN), s));
         LAUNCH(mdt_launch_gemm(gemm_args(t.att2, D, d->xproj, t.a2, D, M), s));
@@ -661,7 +668,7 @@ static mdt_status dec_fwd(mdt_model* m, Tape& t, const float* action, const floa
     for (int l = 0; l < m->Ld; ++l) {
         const mdt_ln_train_args tail = l + 1 < m->Ld ? block_ln1_args(m, m->dec[l + 1], t.dec[l + 1], B, Ta, m->cond, mod_of(l + 1), modw) : lh;
         MDT_TRY(block_fwd(m, m->dec[l], &m->dec[l], t.dec[l], B, Ta, true, m->cond, mod_of(l), modw, t.kvx + (int64_t)l * 2 * D,
-                          t.drop, m->Le + l, s, l > 0, &tail));
+                          t.drop, m->Le + l, s, l > 0, &tail, (l == 0 && pre_done) ? 2 : 0));
     }
     mdt_head_args h;
     memset(&h, 0, sizeof h);
@@ -739,6 +746,12 @@ extern "C" mdt_status mdt_train_loss_fwd(mdt_model* m, const float* tokens, cons
         hipStream_t sq = nullptr;
         st = side_fork(ts, 0, s, &sq);
         if (st == MDT_OK) st = dec_fwd_pre(m, t, action, noise, sigma, sq);
+        if (st == MDT_OK) {  // ... and the first decoder block's self-attention half (it reads the action embedding, not the context)
+            const int64_t modw = m->cond == COND_ADALN ? (int64_t)m->Ld * 6 * m->D : m->D;
+            t.dec[0].x_in = t.y0;
+            st = block_fwd(m, m->dec[0], &m->dec[0], t.dec[0], batch, m->Ta, true, m->cond, t.mod, modw, nullptr, t.drop, m->Le, sq,
+                           false, nullptr, 1);
+        }
         if (st == MDT_OK && !ts->fwd_join && hipEventCreateWithFlags(&ts->fwd_join, hipEventDisableTiming) != hipSuccess)
             st = fail(MDT_ERR_HIP, "could not create the forward join event");
         if (st == MDT_OK && hipEventRecord(ts->fwd_join, sq) != hipSuccess) st = fail(MDT_ERR_HIP, "event record failed");
