@@ -162,6 +162,7 @@ hipError_t mdt_launch_colsum2(const float* X0, const float* X1, int64_t ldx, int
 hipError_t mdt_launch_ln_fwd_train(const mdt_ln_train_args& a, hipStream_t s);
 hipError_t mdt_launch_ln_bwd(const mdt_ln_bwd_args& a, hipStream_t s);
 // fused pairs of the training path (round 6): LayerNorm backward + the merge backward behind it; merge + the LayerNorm of its result
+bool mdt_attn_train_mfma_supported(int hd, int H, int rope);  // the MFMA form of the training attention kernels takes this shape
 hipError_t mdt_launch_ln_bwd_merge(const mdt_ln_bwd_args& a, const mdt_merge_args& g, hipStream_t s);
 hipError_t mdt_launch_merge_ln_fwd(const mdt_merge_args& g, const mdt_ln_train_args& l, hipStream_t s);
 hipError_t mdt_launch_act_fwd(const float* u, float* out, int64_t n, int act, hipStream_t s);

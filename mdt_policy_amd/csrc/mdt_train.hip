@@ -420,12 +420,13 @@ static mdt_merge_args merge_args(const float* x, const float* a, const float* ga
 
 static mdt_status attn_fwd(mdt_model* m, const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out,
                            int64_t B, int Tq, int Tk, bool causal, const mdt_dropout& dr, uint32_t site, hipStream_t s) {
-    if (dr.seed != 0 && dr.attn_p > 0.f) {
+    // (without dropout too where the MFMA form of the training kernel applies: it is the faster of the two at training batches)
+    if ((dr.seed != 0 && dr.attn_p > 0.f) || mdt_attn_train_mfma_supported(m->hd, m->H, m->cfg.use_rot_embed)) {
         mdt_attn_train_args a;
         memset(&a, 0, sizeof a);
         a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv; a.out = out; a.ldo = m->D;
         a.B = (int)B; a.H = m->H; a.hd = m->hd; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
-        a.p = dr.attn_p; a.site = site; a.seed = dr.seed;
+        a.p = dr.seed ? dr.attn_p : 0.f; a.site = site; a.seed = dr.seed;
         a.rope = m->cfg.use_rot_embed; a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
         LAUNCH(mdt_launch_attn_fwd_train(a, s));
         return MDT_OK;

@@ -1003,12 +1003,268 @@ __global__ __launch_bounds__(64) void k_attn_fwd_train(mdt_attn_train_args a, fl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two kernels on the MFMA pipe (round 6): one workgroup per (sample, group of HG heads), wave = head.
+// k_attn_fwd_train / k_attn_bwd above give every (sample, head) its own one-wave workgroup: 8192 of them at B = 1024, each
+// loading 192-byte row pieces and walking ~100 (query, key) pairs with vector FMAs out of 4- and 16-byte LDS reads.  Here the
+// HG heads of a sample share coalesced row loads (HG * hd contiguous floats per row), and every product is a handful of
+// v_mfma_f32_16x16x4_f32 on fragments read from LDS, the way attn_sample_tile (mdt_tiles.h) runs the sampler's attention:
+//   scores with TRANSPOSED operand roles (A = key rows, B = query rows): the lane ends with S[query m][keys 4 g .. 4 g + 3],
+//   m = lane % 16, g = lane / 16; the masked softmax of a query runs over the lane's four values and the wave's four 16-lane
+//   rows (v_permlane swaps); P (times its dropout multipliers), still in those registers, is the B operand of O^T = V^T P^T.
+// Backward, same orientation: dP = dO V^T like the scores; dS = P (m dP - delta) scale; dQ = dS K like O; dK = dS^T Q and
+// dV = (m P)^T dO contract over the QUERY index, which the registers hold the wrong way round: the two 16 x 16 tiles go through
+// LDS once (one 16-byte store, four 4-byte reads per lane).  12 MFMAs per product: 24 forward, 72 backward per head.
+// No RoPE (those models keep the kernels above); head dims that are multiples of 16; Tq, Tk <= 16; H a multiple of HG.
+// ------------------------------------------------------------------------------------------------
+template <int HD, int HG>
+struct AttnMfma {
+    static constexpr int W = HG * HD, RS = W + 16, W4 = W / 4, NT = 64 * HG, KH = HD / 16;
+    static constexpr int NL = (16 * W4 + NT - 1) / NT;   // float4 items of one 16-row set per thread
+    // T rows of W floats (row r at src + r * ld) -> dst rows of RS floats; loads first, stores by the caller's second call
+    __device__ static __forceinline__ void request(const float* src, int64_t ld, int T, int tid, f32x4 (&t)[NL]) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int i = min(tid + NT * u, T * W4 - 1), r = i / W4, c = i - r * W4;
+            t[u] = ldg4(src + (int64_t)r * ld + 4 * c);
+        }
+    }
+    __device__ static __forceinline__ void commit(float* dst, int T, int tid, const f32x4 (&t)[NL]) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int i = tid + NT * u, r = i / W4, c = i - r * W4;
+            if (i < T * W4) *(f32x4*)(dst + r * RS + 4 * c) = t[u];
+        }
+    }
+    // S^T-form product of two row sets: acc[e] = sum_f A[row 4 g + e][f] * B[row m][f] over the head's HD features
+    __device__ static __forceinline__ f32x4 rows_dot(const float* a_rows, int ta, const float* b_rows, int tb, int hoff, int m, int g) {
+        const float* ap = a_rows + min(m, ta - 1) * RS + hoff + 4 * g;
+        const float* bp = b_rows + min(m, tb - 1) * RS + hoff + 4 * g;
+        f32x4 af[KH], bf[KH];
+#pragma unroll
+        for (int kc = 0; kc < KH; ++kc) { af[kc] = *(const f32x4*)(ap + 16 * kc); bf[kc] = *(const f32x4*)(bp + 16 * kc); }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KH; ++kc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc][e], bf[kc][e], acc, 0, 0, 0);
+        return acc;
+    }
+    // out[row m][16 nt + 4 g .. + 3] = sum over rows r = 4 g' + e of `rows` (T of them) of rows[r][16 nt + .] * coef[.][r]:
+    // coef[e] is the lane's B operand (value for row 4 g + e against column m)
+    __device__ static __forceinline__ void rows_combine(const float* rows, int T, int hoff, int m, int g, const f32x4& coef,
+                                                        f32x4 (&o)[KH]) {
+        float rt[KH][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* rp = rows + min(4 * g + e, T - 1) * RS + hoff + m;
+#pragma unroll
+            for (int nt = 0; nt < KH; ++nt) rt[nt][e] = rp[16 * nt];
+        }
+#pragma unroll
+        for (int nt = 0; nt < KH; ++nt) {
+            o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[nt][e], coef[e], o[nt], 0, 0, 0);
+        }
+    }
+};
+
+// the lane's four probabilities P[query m][keys 4 g + e] from its four scores; rc = the query row (clamped), invisible keys -> 0
+__device__ __forceinline__ f32x4 attn_softmax4(f32x4 sc, float scale, int rc, int g, int Tk, bool causal) {
+    float mx = -INFINITY;
+    bool vis[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        vis[e] = 4 * g + e < Tk && (!causal || 4 * g + e <= rc);
+        sc[e] = vis[e] ? sc[e] * scale : -INFINITY;
+        mx = fmaxf(mx, sc[e]);
+    }
+    mx = xrow_max(mx);   // key 0 is visible to every query: finite
+    f32x4 pr;
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pr[e] = vis[e] ? expf(sc[e] - mx) : 0.f; sum += pr[e]; }
+    return pr * (1.0f / xrow_sum(sum));
+}
+
+template <int HD, int HG>
+__global__ __launch_bounds__(64 * HG) void k_attn_fwd_train_mfma(mdt_attn_train_args a, float scale) {
+    using AM = AttnMfma<HD, HG>;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Tq = a.Tq, Tk = a.Tk, tid = threadIdx.x, lane = tid & 63, hl = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x, h = blockIdx.y * HG + hl, hoff = hl * HD;
+    float* qs = sm;
+    float* ks = qs + Tq * AM::RS;
+    float* vs = ks + Tk * AM::RS;
+    float (*mk)[17] = (float (*)[17])(vs + Tk * AM::RS + hl * 16 * 17);
+    const bool drop = a.p > 0.f && a.seed != 0;
+    const int64_t c0 = (int64_t)blockIdx.y * AM::W;
+    f32x4 tq[AM::NL], tk[AM::NL], tv[AM::NL];
+    AM::request(a.q + (int64_t)b * Tq * a.ldq + c0, a.ldq, Tq, tid, tq);
+    AM::request(a.k + (int64_t)b * Tk * a.ldkv + c0, a.ldkv, Tk, tid, tk);
+    AM::request(a.v + (int64_t)b * Tk * a.ldkv + c0, a.ldkv, Tk, tid, tv);
+    if (drop) attn_dropout_table(mk, a.seed, a.site, ((uint64_t)b * a.H + h) * Tq * Tk, Tq, Tk, a.p, lane);  // under the loads
+    AM::commit(qs, Tq, tid, tq);
+    AM::commit(ks, Tk, tid, tk);
+    AM::commit(vs, Tk, tid, tv);
+    __syncthreads();
+    const int rc = min(m, Tq - 1);
+    f32x4 pr = attn_softmax4(AM::rows_dot(ks, Tk, qs, Tq, hoff, m, g), scale, rc, g, Tk, a.causal != 0);
+    if (drop) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pr[e] *= mk[rc][min(4 * g + e, Tk - 1)];
+    }
+    f32x4 o[AM::KH];
+    AM::rows_combine(vs, Tk, hoff, m, g, pr, o);
+    if (m < Tq) {
+        float* op = a.out + ((int64_t)b * Tq + m) * a.ldo + (int64_t)h * HD + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < AM::KH; ++nt) *(f32x4*)(op + 16 * nt) = o[nt];
+    }
+}
+
+template <int HD, int HG>
+__global__ __launch_bounds__(64 * HG) void k_attn_bwd_mfma(mdt_attn_bwd_args a, float scale) {
+    using AM = AttnMfma<HD, HG>;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Tq = a.Tq, Tk = a.Tk, tid = threadIdx.x, lane = tid & 63, hl = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x, h = blockIdx.y * HG + hl, hoff = hl * HD;
+    float* qs = sm;
+    float* ks = qs + Tq * AM::RS;
+    float* vs = ks + Tk * AM::RS;
+    float* os = vs + Tk * AM::RS;                       // d_out rows
+    float* wv = os + Tq * AM::RS + hl * (16 * 17 + 2 * 16 * 20);
+    float (*mk)[17] = (float (*)[17])wv;                // this head's dropout multipliers
+    float (*tp)[20] = (float (*)[20])(wv + 16 * 17);    // (m P) tile, [query][key]
+    float (*td)[20] = tp + 16;                          // dS tile
+    const bool drop = a.p > 0.f && a.seed != 0;
+    const int64_t c0 = (int64_t)blockIdx.y * AM::W;
+    {
+        f32x4 tq[AM::NL], tk[AM::NL], tv[AM::NL], to[AM::NL];
+        AM::request(a.q + (int64_t)b * Tq * a.ldq + c0, a.ldq, Tq, tid, tq);
+        AM::request(a.k + (int64_t)b * Tk * a.ldkv + c0, a.ldkv, Tk, tid, tk);
+        AM::request(a.v + (int64_t)b * Tk * a.ldkv + c0, a.ldkv, Tk, tid, tv);
+        AM::request(a.d_out + (int64_t)b * Tq * a.ld_do + c0, a.ld_do, Tq, tid, to);
+        if (drop) attn_dropout_table(mk, a.seed, a.site, ((uint64_t)b * a.H + h) * Tq * Tk, Tq, Tk, a.p, lane);
+        AM::commit(qs, Tq, tid, tq);
+        AM::commit(ks, Tk, tid, tk);
+        AM::commit(vs, Tk, tid, tv);
+        AM::commit(os, Tq, tid, to);
+    }
+    __syncthreads();
+    const int rc = min(m, Tq - 1);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pr = attn_softmax4(AM::rows_dot(ks, Tk, qs, Tq, hoff, m, g), scale, rc, g, Tk, a.causal != 0);
+    f32x4 dp = AM::rows_dot(vs, Tk, os, Tq, hoff, m, g);   // dP[query m][keys 4 g + e] = dO[m] . V[key]
+    f32x4 pm = pr, ds;
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mul = drop ? mk[rc][min(4 * g + e, Tk - 1)] : 1.f;
+            pm[e] = pr[e] * mul;                            // what multiplied V in the forward
+            dp[e] *= mul;                                   // out = (m P) V  =>  dP = m (dO V^T)
+            part = fmaf(pr[e], dp[e], part);
+        }
+        const float delta = xrow_sum(part);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ds[e] = pr[e] * (dp[e] - delta) * scale;
+    }
+    if (m >= Tq) { pm = zero4; ds = zero4; }               // lanes past the last query repeated its row: they contribute nothing
+    // dQ[query m][.] = sum_keys dS[m][key] K[key][.]
+    {
+        f32x4 o[AM::KH];
+        AM::rows_combine(ks, Tk, hoff, m, g, ds, o);
+        if (m < Tq) {
+            float* op = a.dq + ((int64_t)b * Tq + m) * a.ld_dq + (int64_t)h * HD + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < AM::KH; ++nt) *(f32x4*)(op + 16 * nt) = o[nt];
+        }
+    }
+    // the two tiles the other way round: lane (m, g) needs [query 4 g + e][key m]
+    *(f32x4*)&tp[m][4 * g] = pm;
+    *(f32x4*)&td[m][4 * g] = ds;
+    __syncthreads();
+    f32x4 pmT, dsT;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pmT[e] = tp[4 * g + e][m]; dsT[e] = td[4 * g + e][m]; }
+    {
+        f32x4 ov[AM::KH], ok[AM::KH];
+        AM::rows_combine(os, Tq, hoff, m, g, pmT, ov);     // dV[key m][.] = sum_queries (m P)[query][m] dO[query][.]
+        AM::rows_combine(qs, Tq, hoff, m, g, dsT, ok);     // dK[key m][.] = sum_queries dS[query][m] Q[query][.]
+        if (m < Tk) {
+            float* vp = a.dv + ((int64_t)b * Tk + m) * a.ld_dkv + (int64_t)h * HD + 4 * g;
+            float* kp = a.dk + ((int64_t)b * Tk + m) * a.ld_dkv + (int64_t)h * HD + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < AM::KH; ++nt) {
+                f32x4* pv = (f32x4*)(vp + 16 * nt);
+                f32x4* pk = (f32x4*)(kp + 16 * nt);
+                *pv = a.accumulate_kv ? *pv + ov[nt] : ov[nt];
+                *pk = a.accumulate_kv ? *pk + ok[nt] : ok[nt];
+            }
+        }
+    }
+}
+
+// which (hd, H) the MFMA kernels take, and MDT_HIP_ATTN_TRAIN_MFMA=0 (A/B runs: the one-wave-per-head kernels everywhere)
+static int attn_train_mfma_group(int hd, int H, int rope) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MDT_HIP_ATTN_TRAIN_MFMA"); on = e ? atoi(e) : 1; }
+    if (!on || rope || (hd != 16 && hd != 32 && hd != 48 && hd != 64)) return 0;
+    return H % 4 == 0 ? 4 : (H % 2 == 0 ? 2 : 1);
+}
+template <int HD, int HG>
+static hipError_t launch_attn_fwd_mfma(const mdt_attn_train_args& a, float scale, hipStream_t s) {
+    using AM = AttnMfma<HD, HG>;
+    const size_t lds = ((size_t)(a.Tq + 2 * a.Tk) * AM::RS + (size_t)HG * 16 * 17) * sizeof(float);
+    static bool attr_dev[32] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_fwd_train_mfma<HD, HG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_dev[dev] = true;
+    }
+    hipLaunchKernelGGL((k_attn_fwd_train_mfma<HD, HG>), dim3(a.B, a.H / HG), dim3(64 * HG), lds, s, a, scale);
+    return hipGetLastError();
+}
+template <int HD, int HG>
+static hipError_t launch_attn_bwd_mfma(const mdt_attn_bwd_args& a, float scale, hipStream_t s) {
+    using AM = AttnMfma<HD, HG>;
+    const size_t lds = ((size_t)(2 * a.Tq + 2 * a.Tk) * AM::RS + (size_t)HG * (16 * 17 + 2 * 16 * 20)) * sizeof(float);
+    static bool attr_dev[32] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd_mfma<HD, HG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_dev[dev] = true;
+    }
+    hipLaunchKernelGGL((k_attn_bwd_mfma<HD, HG>), dim3(a.B, a.H / HG), dim3(64 * HG), lds, s, a, scale);
+    return hipGetLastError();
+}
+bool mdt_attn_train_mfma_supported(int hd, int H, int rope) { return attn_train_mfma_group(hd, H, rope) != 0; }
+#define ATTN_MFMA_DISPATCH(FN, a, scale, s, hg)                                                         \
+    switch ((a).hd * 8 + (hg)) {                                                                         \
+        case 16 * 8 + 4: return FN<16, 4>(a, scale, s); case 16 * 8 + 2: return FN<16, 2>(a, scale, s); \
+        case 16 * 8 + 1: return FN<16, 1>(a, scale, s);                                                  \
+        case 32 * 8 + 4: return FN<32, 4>(a, scale, s); case 32 * 8 + 2: return FN<32, 2>(a, scale, s); \
+        case 32 * 8 + 1: return FN<32, 1>(a, scale, s);                                                  \
+        case 48 * 8 + 4: return FN<48, 4>(a, scale, s); case 48 * 8 + 2: return FN<48, 2>(a, scale, s); \
+        case 48 * 8 + 1: return FN<48, 1>(a, scale, s);                                                  \
+        case 64 * 8 + 4: return FN<64, 4>(a, scale, s); case 64 * 8 + 2: return FN<64, 2>(a, scale, s); \
+        case 64 * 8 + 1: return FN<64, 1>(a, scale, s);                                                  \
+        default: break;                                                                                  \
+    }
+
 hipError_t mdt_launch_attn_fwd_train(const mdt_attn_train_args& a, hipStream_t s) {
     if (a.Tq < 1 || a.Tq > 16 || a.Tk < 1 || a.Tk > 16) return hipErrorInvalidValue;
     if (((a.ldq | a.ldkv | a.ldo) & 3) || (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.out) & 15))
         return hipErrorInvalidValue;  // 16-byte loads / stores of the head slices
     if (a.rope && (a.hd < 32 || !a.rope_cos || !a.rope_sin)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)a.hd);
+    if (const int hg = attn_train_mfma_group(a.hd, a.H, a.rope)) { ATTN_MFMA_DISPATCH(launch_attn_fwd_mfma, a, scale, s, hg) }
     const dim3 grid(a.B, a.H);
     switch (a.hd) {
         case 16: hipLaunchKernelGGL((k_attn_fwd_train<16>), grid, dim3(64), 0, s, a, scale); break;
@@ -1153,6 +1409,7 @@ hipError_t mdt_launch_attn_bwd(const mdt_attn_bwd_args& a, hipStream_t s) {
         return hipErrorInvalidValue;  // 16-byte loads / stores of the head slices
     if (a.rope && (a.hd < 32 || !a.rope_cos || !a.rope_sin)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)a.hd);
+    if (const int hg = attn_train_mfma_group(a.hd, a.H, a.rope)) { ATTN_MFMA_DISPATCH(launch_attn_bwd_mfma, a, scale, s, hg) }
     const dim3 grid(a.B, a.H);
     switch (a.hd) {
         case 16: hipLaunchKernelGGL((k_attn_bwd<16>), grid, dim3(64), 0, s, a, scale); break;

@@ -178,3 +178,53 @@ def test_hip_resampler_trains_end_to_end_with_the_denoiser():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3])
+def test_composed_rollout_path_perceiver_then_sampler_against_the_oracles(B):
+    """What MDTVAgent.forward runs per replan behind its frozen encoders, composed as the agent composes it
+    (mdtv_agent.py:392-403 compute_voltron_embeddings, :688-719 forward, :523-550 denoise_actions): Voltron-shaped patch tokens of
+    both cameras (B, 392, 384) -> unsqueeze(1) -> PerceiverResampler (6 layers, 3 latents) -> state_images (B, 3, 384), language
+    goal (B, 1, 512), x_T = noise * sigma_max, sigmas on the device -> sample_ddim.  HIP (facade modules) against
+    perceiver_oracle o mdt_oracle on the same seeded inputs; bench.py times the same composition (rollout_e2e_synthetic_B1)."""
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    from mdt_policy_amd.models.networks.transformers.perceiver_resampler import PerceiverResampler
+    from oracle import mdt_oracle as O
+    cfg = configs.mdtv_default()
+    model = GCDenoiser(cfg, 0.5)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 5, "rich").items()}
+    model.load_state_dict(P, strict=False)
+    model = model.cuda().eval()
+    perc = PerceiverResampler(dim=384, depth=6, dim_head=64, heads=8, num_latents=3, num_time_embeds=1)
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for n, p in perc.named_parameters():  # a spread of values, not the constructor's init (LayerNorm gains 1, biases 0)
+            r = torch.randn(p.shape, generator=g)
+            if n in ("latents", "time_pos_emb"):
+                p.copy_(r)
+            elif p.dim() == 1:
+                p.copy_(1.0 + 0.1 * r if n.endswith("weight") else 0.1 * r)
+            else:
+                p.copy_(0.05 * r)
+    PP = {k: v.detach().clone() for k, v in perc.state_dict().items()}
+    perc = perc.cuda().eval()
+    tokens = torch.randn(B, 2 * 196, 384, generator=g)
+    goal = torch.randn(B, 512, generator=g)
+    noise = torch.randn(B, 10, 7, generator=g)
+    sig = gs.get_sigmas_exponential(10, 0.001, 80.0)
+    # oracle composition
+    st_o = PO.perceiver_resampler(PP, tokens.unsqueeze(1), 8)
+    want = O.sample_ddim(P, cfg, {"state_images": st_o, "modality": "lang"}, noise * 80.0, goal.unsqueeze(1), sig)
+    # HIP composition, as the agent's forward()
+    with torch.no_grad():
+        perceptual_emb = {"state_images": perc(tokens.cuda().unsqueeze(1))}
+        perceptual_emb["modality"] = "lang"
+        latent_goal = goal.cuda().unsqueeze(1)
+        x = noise.cuda() * 80.0
+        got = gs.sample_ddim(model, perceptual_emb, x, latent_goal, sig.cuda())
+    assert_close(perceptual_emb["state_images"].cpu(), st_o, what="resampled state tokens")
+    assert_close(got.cpu(), want, what="composed rollout actions")
