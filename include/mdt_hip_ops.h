@@ -127,11 +127,12 @@ int32_t mdt_op_trace_mlp_read(float *us, int32_t cap);
  * those empty brackets (microseconds; same order and count as the last mdt_op_trace_mlp_read) -- what the bracket itself costs
  * on the stream.  Launch bracket minus empty bracket = the kernel as a kernel trace's row reports it. */
 int32_t mdt_op_trace_mlp_read_empty(float *us, int32_t cap);
-/* Measurement hook (round 6): ONE wave writes {shader-clock counter (s_memtime), constant 100 MHz counter (s_memrealtime)} to
- * out2[0..1] (device memory) in stream order.  Two stamps around a span of launches give the average shader clock the chip
- * sustained over it: (d memtime / d memrealtime) x 100 MHz -- what bench.py reports as roofline.sustained_mhz beside the
+/* Measurement hook (round 6): in stream order, one wave per XCD writes {shader-clock counter (s_memtime), constant 100 MHz counter
+ * (s_memrealtime)} to out16[2 x + 0 .. 1] (device memory, 16 values, zero them first; x = the XCD the wave ran on: the shader-clock
+ * counters of the eight XCDs are not synchronised).  Two stamps around a span of launches give, XCD by XCD, the average shader clock
+ * the chip sustained over it: (d memtime / d memrealtime) x 100 MHz -- what bench.py reports as roofline.sustained_mhz beside the
  * 2.4 GHz the peak is quoted at. */
-mdt_status mdt_op_clock_stamp(uint64_t *out2, void *stream);
+mdt_status mdt_op_clock_stamp(uint64_t *out16, void *stream);
 
 /* Tuning / test hook: wave schedule inside mdt_op_mlp's kernel.  Low byte = number of k-steps the second wave of every
  * SIMD starts behind the first (0 = lockstep with a workgroup barrier between the two products), | 256 = MFMA loops at

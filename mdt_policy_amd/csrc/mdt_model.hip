@@ -797,15 +797,21 @@ extern "C" int32_t mdt_op_trace_mlp_read_empty(float* us, int32_t cap) {
 }
 
 // mdt_op_clock_stamp: the two clock counters of the wave that runs it, in stream order (include/mdt_hip_ops.h)
+// The shader-clock counter is per XCD (eight of them, not synchronised with each other): 64 one-wave workgroups go out, each
+// writes its pair into the slot of the XCD it landed on (the last writer of a slot wins: all within a microsecond), so that a
+// caller can difference two stamps XCD by XCD whatever else shares the chip.
 __global__ void k_clock_stamp(uint64_t* __restrict__ out) {
     if (threadIdx.x == 0) {
-        out[0] = __builtin_amdgcn_s_memtime();
-        out[1] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        out[2 * xcc] = __builtin_amdgcn_s_memtime();
+        out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
-extern "C" mdt_status mdt_op_clock_stamp(uint64_t* out2, void* stream) {
-    if (!out2) return fail(MDT_ERR_INVALID_ARG, "mdt_op_clock_stamp: null output");
-    hipLaunchKernelGGL(k_clock_stamp, dim3(1), dim3(64), 0, (hipStream_t)stream, out2);
+extern "C" mdt_status mdt_op_clock_stamp(uint64_t* out16, void* stream) {
+    if (!out16) return fail(MDT_ERR_INVALID_ARG, "mdt_op_clock_stamp: null output");
+    hipLaunchKernelGGL(k_clock_stamp, dim3(64), dim3(64), 0, (hipStream_t)stream, out16);
     HIP_TRY(hipGetLastError());
     return MDT_OK;
 }
