@@ -15,11 +15,12 @@ find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collectio
 echo "== rollout batch 1"
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/lat -o lat -- python $R/tools/latency.py 1 > $OUT/lat_run.txt 2> $OUT/lat.err )
 DB=$(find $OUT/lat -name "*.db" | head -1); python tools/prof_summary.py $DB > $OUT/lat_kernel_stats.txt; python tools/prof_gaps.py $DB 250 > $OUT/lat_gaps.txt; head -9 $OUT/lat_gaps.txt | cut -c1-150
+python tools/prof_call.py $DB 250 > $OUT/lat_call.txt   # the last call launch by launch (profiles/rNN_rollout_floor.txt reads it)
 echo "== batch sweep"; timeout 300 python tools/latency.py 1 2 4 8 16 32 64 128 256 512 1024 2>&1 | grep B= | tee $OUT/sweep.txt
 echo "== training step B=1024"
-( cd /tmp && MDT_TRAIN_BENCH_MODES=eval timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/train -o train -- python $R/tools/train_bench.py 1024 > $OUT/train_run.txt 2> $OUT/train.err )
+( cd /tmp && MDT_TRAIN_BENCH_MODES=train MDT_TRAIN_BENCH_OPT=fused timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/train -o train -- python $R/tools/train_bench.py 1024 > $OUT/train_run.txt 2> $OUT/train.err )
 DB=$(find $OUT/train -name "*.db" | head -1); python tools/prof_summary.py $DB > $OUT/train_kernel_stats.txt; cat $OUT/train_run.txt | tail -2
-( timeout 200 python tools/train_bench.py 128; timeout 200 python tools/train_bench.py 1024 ) 2>&1 | grep "B=" | tee $OUT/train_bench.txt
+( export MDT_TRAIN_BENCH_OPT=fused; timeout 200 python tools/train_bench.py 128; timeout 200 python tools/train_bench.py 1024 ) 2>&1 | grep "B=" | tee $OUT/train_bench.txt
 echo "== MGF head"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/mae -o mae -- python $R/tools/mae_bench.py 1024 > $OUT/mae_run.txt 2> $OUT/mae.err )
 DB=$(find $OUT/mae -name "*.db" | head -1); python tools/prof_summary.py $DB > $OUT/mae_kernel_stats.txt

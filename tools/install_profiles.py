@@ -47,27 +47,30 @@ write("rollout_b1_kernel_stats.txt",
       "profiler), MI355X\n" + lines("lat_run.txt", "B=") + "# per-kernel summary of the whole run\n" + "".join(lat[:17]) +
       "# the LAST call (250 dispatches): durations and the idle gap in front of each kernel (tools/prof_gaps.py)\n" +
       "".join(read("lat_gaps.txt").splitlines(True)[:16]))
+if os.path.exists(os.path.join(src, "lat_call.txt")):
+    write("rollout_b1_call.txt", head + "rollout batch B = 1: the LAST sampler call of 'python tools/latency.py 1' under rocprofv3 --kernel-trace, launch "
+          "by launch (tools/prof_call.py): start, duration, idle gap in front, workgroups x threads, kernel\n" + read("lat_call.txt"))
 write("batch_sweep.txt",
       f"# tools/latency.py on MI355X (end of round {rnd}, commit {commit}): one sample_ddim call = encoder + 10 DDIM steps, MDT-V "
       "default, fp32\n" + read("sweep.txt"))
 tr = read("train_kernel_stats.txt").splitlines(True)
 write("train_step_kernel_stats.txt",
-      head + "rocprofv3 --kernel-trace --stats of 'MDT_TRAIN_BENCH_MODES=eval python tools/train_bench.py 1024' (loss forward + "
-      "backward + torch fused AdamW at B = 1024; times under the profiler), MI355X\n" + lines("train_run.txt", "B=") +
+      head + "rocprofv3 --kernel-trace --stats of 'MDT_TRAIN_BENCH_MODES=train MDT_TRAIN_BENCH_OPT=fused python tools/train_bench.py 1024' (loss "
+      "forward + backward + FusedAdamW at B = 1024, train mode; times under the profiler; the weight gradients run on a side stream: per-kernel durations overlap), MI355X\n" + lines("train_run.txt", "B=") +
       "# without the profiler (same box):\n" + "".join("# " + l for l in read("train_bench.txt").splitlines(True)) + "".join(tr[:36]))
 mae = read("mae_kernel_stats.txt").splitlines(True)
 write("mae_kernel_stats.txt",
       head + "masked generative foresight head: rocprofv3 --kernel-trace --stats of 'python tools/mae_bench.py 1024' (forward + "
       "backward, B = 1024), MI355X\n# without the profiler (same box):\n" + read("mae_bench.txt") + "".join(mae[:34]))
 # PMC passes of the training step and of the masked-image head (tools/gpu_train_pmc.sh: MFMA-busy | HBM-side requests + L2 hit)
-for name, what in (("train", "MDT_TRAIN_BENCH_MODES=train python tools/train_bench.py 1024' (denoiser training step, B = 1024, train mode, torch fused AdamW"),
+for name, what in (("train", "MDT_TRAIN_BENCH_MODES=train MDT_TRAIN_BENCH_OPT=fused python tools/train_bench.py 1024' (denoiser training step, B = 1024, train mode, FusedAdamW; weight gradients on the side stream"),
                    ("mae", "python tools/mae_bench.py 1024' (masked-image head, forward + backward, B = 1024: 104448 decoder rows")):
     fn = os.path.join("trainpmc", f"{name}_pmc.txt")
     if os.path.exists(os.path.join(src, fn)):
         write(f"{'train_step' if name == 'train' else 'mae'}_pmc.txt",
               head + f"rocprofv3 --pmc over '{what}), two separate passes with kernel-trace only (tools/gpu_train_pmc.sh):\n"
               "# SQ_VALU_MFMA_BUSY_CYCLES | TCC_EA0_RDREQ / WRREQ + TCC_HIT / MISS; HBM-side MB = RDREQ x 128 B / WRREQ x 64 B per launch "
-              "(MI355X_MICROARCH.md, gfx950 corrections).  Reading and algorithmic bytes: DESIGN.md section 5e.\n" + read(fn))
+              "(MI355X_MICROARCH.md, gfx950 corrections).  Reading: DESIGN.md section 5a.\n" + read(fn))
 # the dominant kernel's HBM-side traffic per launch, for bench.py's roofline.traffic (PMC counters cannot be read from inside
 # the bench process): the fused MLP launch's row of the PMC table above
 import json
