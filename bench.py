@@ -329,6 +329,33 @@ def other_configs(device):
                                            "evaluation per launch sequence (host-driven step loop)"}
     except Exception as e:  # diagnostic leg
         out["other_samplers_B256"] = {"error": repr(e)}
+    # the contrastive (CLA) auxiliary head at the training batch (mdtv_agent.py:440-484): the MAP pooling
+    # block over latent_encoder_emb, forward + backward, and the InfoNCE op (value + gradients)
+    try:
+        from mdt_policy_amd.models.contrastive import clip_auxiliary_loss
+        from mdt_policy_amd.models.networks.transformers.transformer_blocks import ClipStyleProjection
+        clip = ClipStyleProjection("map", 384, 1, 4).to(device)
+        xg = torch.randn(1024, 4, 384, device=device, requires_grad=True)
+
+        def map_fb():
+            clip.zero_grad(set_to_none=True)
+            xg.grad = None
+            clip(xg).square().mean().backward()
+
+        ia = torch.randn(1024, 384, device=device, requires_grad=True)
+        ib = torch.randn(1024, 384, device=device, requires_grad=True)
+        ls = torch.tensor(2.659, device=device, requires_grad=True)
+
+        def nce():
+            ia.grad = ib.grad = ls.grad = None
+            clip_auxiliary_loss(ia, ib, ls).backward()
+
+        out["cla_head_B1024"] = {"ms_map_block_fwd_bwd": round(timed(map_fb, 5, 30) * 1e3, 3),
+                                 "ms_infonce_value_and_grads": round(timed(nce, 5, 30) * 1e3, 3),
+                                 "what": "ClipStyleProjection('map') forward + backward on (1024, 4, 384) context tokens, and the InfoNCE op "
+                                         "(value + gradients of both embeddings and the logit scale) at B = 1024"}
+    except Exception as e:  # diagnostic leg
+        out["cla_head_B1024"] = {"error": repr(e)}
     return out
 
 

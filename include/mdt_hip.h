@@ -167,7 +167,11 @@ mdt_status mdt_forward(mdt_model *m, const float *tokens, const float *tokens2, 
  * ctx_out then receives the LAST step's context, which is what the reference leaves in latent_encoder_emb.)
  *   x_T    : (B, Ta, A) initial noisy actions (already multiplied by sigma_max, mdtv_agent.py:546)
  *   sigmas : HOST array of n_steps+1 floats (get_sigmas_* output, last entry normally 0)
- *   out    : (B, Ta, A) sampled actions;  ctx_out: optional (B,Te,d) latent_encoder_emb */
+ *   out    : (B, Ta, A) sampled actions;  ctx_out: optional (B,Te,d) latent_encoder_emb
+ * Arguments are checked before anything is enqueued (an invalid-argument return leaves no device work behind).
+ * Under stream capture: the HOST schedule travels by value in the first kernel's arguments, so a captured call bakes the
+ * schedule of capture time into the graph (a replay does not re-read `sigmas`); capture mdt_sample_ddim_dev, whose schedule is
+ * read from device memory at every replay, when the schedule may change between replays. */
 mdt_status mdt_sample_ddim(mdt_model *m, const float *tokens, const float *tokens2, const float *goal,
                            int32_t modality, const float *x_T, const float *sigmas_host, int32_t n_steps,
                            int64_t batch, float *out, float *ctx_out, void *stream);

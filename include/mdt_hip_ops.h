@@ -171,7 +171,11 @@ mdt_status mdt_op_attention(const mdt_attn_args *args, void *stream);
  * latency): out (+)= gate * (softmax(q k^T / sqrt(hd)) v @ W^T + bias) for the T <= 16 rows of qkv (T, 3*K), q | k | v
  * column blocks of K = 8 * hd each.  `proj` describes the projection as for mdt_op_gemm (A is ignored, M = T; bias /
  * residual / gate as there; no LayerNorm prologue, activation or row remap).  8 heads, hd in {16,32,48,64}, no RoPE.
- * Replaces Attention.forward's SDPA + c_proj (transformer_blocks.py:142-157) for one sample. */
+ * Replaces Attention.forward's SDPA + c_proj (transformer_blocks.py:142-157) for one sample.
+ * Summation order: since round 5 both attention products run on the MFMA pipe inside this launch (wave = head, k order of the
+ * matrix instruction), so its results differ from mdt_op_attention + mdt_op_gemm on the same operands in the last bits: within
+ * 2e-5 absolute + 1e-4 relative on values of order one (tests/test_gpu_ops.py::test_fused_attention_projection_against_the_two_
+ * launches_at_rollout_batches, B = 1 .. 8); the model-level entry points use it up to 32 samples (MDT_HIP_ATTN_PROJ_MAX). */
 mdt_status mdt_op_attn_proj(const mdt_gemm_args *proj, const float *qkv, int64_t ldq, int32_t hd, int32_t T, int32_t causal,
                             void *stream);
 /* (More than 64 samples: the same contract for a LARGE batch, M = samples * T rows, causal, residual, hd in {16, 32, 48} --

@@ -478,6 +478,41 @@ def test_attention_fused_into_projection_per_sample(lib, hd, T, causal, gated, B
         assert lib.load().mdt_op_attn_proj(C.byref(a), qd.data_ptr(), 3 * D, hd, T, int(causal), stream()) == 2
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_fused_attention_projection_against_the_two_launches_at_rollout_batches(lib, B):
+    """since round 5 the model-level entry points run the self-attention of batches 1 .. 32 inside its output projection
+    (k_attn_proj_smallm, both attention products on the MFMA pipe), so those batches no longer have the summation order of the
+    attention launch + projection GEMM pair.  The fused launch against that pair on the same operands at B = 1 .. 8 (the rollout
+    batches), with the tolerance the header states for it: 2e-5 absolute + 1e-4 relative on values of order one."""
+    hd, T, H = 48, 10, 8
+    D = N = H * hd
+    g = torch.Generator().manual_seed(900 + B)
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    W = torch.randn(N, D, generator=g) / math.sqrt(D)
+    gate, y0 = torch.randn(B, 6 * N, generator=g), torch.randn(B * T, N, generator=g)
+    qd, Pd, gd = dev(qkv), pack(lib, W), dev(gate)
+    L = lib.load()
+
+    def proj_args(A, out):
+        a = lib.GemmArgs()
+        a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = (A.data_ptr() if A is not None else None), D, Pd.data_ptr(), out.data_ptr(), N, B * T, N, D
+        a.shift_off = a.scale_off = -1
+        a.gate_off, a.mod, a.mod_stride = 2 * N, gd.data_ptr(), 6 * N
+        a.residual, a.rows_per_sample, a.gin, a.gout = 1, T, 1, 1
+        return a
+
+    fused = dev(y0).clone()
+    lib.check(L.mdt_op_attn_proj(C.byref(proj_args(None, fused)), qd.data_ptr(), 3 * D, hd, T, 1, stream()))
+    att = torch.empty(B * T, D, device="cuda")
+    aa = lib.AttnArgs(q=qd.data_ptr(), ldq=3 * D, k=qd.data_ptr() + 4 * D, v=qd.data_ptr() + 8 * D, ldkv=3 * D, out=att.data_ptr(), ldo=D,
+                      B=B, H=H, hd=hd, Tq=T, Tk=T, causal=1, rope=0)
+    lib.check(L.mdt_op_attention(C.byref(aa), stream()))
+    pair = dev(y0).clone()
+    lib.check(L.mdt_op_gemm(C.byref(proj_args(att, pair)), stream()))
+    torch.cuda.synchronize()
+    assert_close(fused.cpu(), pair.cpu().double(), rtol=1e-4, atol=2e-5, what=f"fused attention + projection vs the two launches, B = {B}")
+
+
 @pytest.mark.parametrize("hd,T,gated,B", [(48, 10, True, 256), (48, 10, False, 77), (32, 16, True, 70), (16, 7, True, 201),
                                           (48, 1, True, 100), (32, 13, True, 65)])
 def test_attention_in_the_projection_prologue_for_large_batches(lib, hd, T, gated, B):
