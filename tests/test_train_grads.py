@@ -684,3 +684,35 @@ def test_library_allocations_succeed_while_torch_caches_the_free_memory():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     grown = torch.cuda.memory_allocated() - allocated
     assert grown > keep, f"the library's buffers are not in torch's pool (memory_allocated grew by {grown >> 20} MiB only)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,mode", [(37, "train"), (128, "eval"), (256, "train")])
+def test_training_step_with_its_side_stream_is_bit_reproducible(B, mode):
+    """Round 6: the blocks' weight gradients, the decoder tail and the forward's context-independent preparation run on a side
+    stream beside the chain.  Every kernel is deterministic, so the same seeded step must leave the same BITS in the loss and in
+    every gradient every time -- a difference is a race between the streams (tools/train_soak.py runs 1200 such steps)."""
+    from mdt_policy_amd import configs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    cfg = configs.mdtv_default()
+    torch.manual_seed(0)
+    model = GCDenoiser(cfg, 0.5).cuda()
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
+    li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
+    state = {"state_images": inp["state_images"].requires_grad_(), "modality": "lang"}
+    goal = inp["goal"].requires_grad_()
+    model.train(mode == "train")
+    ref = None
+    for it in range(25):
+        torch.manual_seed(1234)
+        model.zero_grad(set_to_none=True)
+        state["state_images"].grad = None
+        goal.grad = None
+        loss, _ = model.loss(state, li["actions"], goal, li["noise_train"], li["sigma"])
+        (loss + 0.1 * model.inner_model.latent_encoder_emb.square().mean()).backward()
+        got = [loss.detach().clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None] + \
+              [state["state_images"].grad.clone(), goal.grad.clone()]
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), f"step {it} differs from the first one"
