@@ -137,20 +137,23 @@ def _dw_beside(params) -> bool:
 
 
 def _side_stream(dev: torch.device):
+    """(side stream ordered behind the caller's stream as it stands, list that keeps operands alive until the join) -- or
+    (None, None) when no end-of-backward callback can be queued (not inside the autograd engine)."""
     st = _SIDE.get(dev.index)
     if st is None:
-        st = _SIDE[dev.index] = {"stream": torch.cuda.Stream(dev), "pending": False, "keep": []}
+        st = _SIDE[dev.index] = {"stream": torch.cuda.Stream(dev), "keep": []}
     side = st["stream"]
-    side.wait_stream(torch.cuda.current_stream(dev))  # the operands (dY, X) exist
-    if not st["pending"]:
-        st["pending"] = True
 
-        def join():  # end of this backward pass, in the caller's thread and stream
+    def join():  # end of this backward pass, in the caller's thread and stream; one per Linear, all but the first find nothing to do
+        if st["keep"]:  # (every side launch leaves its operands here: empty = an earlier callback of this pass has joined already)
             torch.cuda.current_stream(dev).wait_stream(side)
-            st["pending"] = False
             del st["keep"][:]  # released BEHIND the join: whoever reuses their memory is ordered behind the side stream's reads
 
+    try:
         torch.autograd.Variable._execution_engine.queue_callback(join)
+    except Exception:  # noqa: BLE001 -- not inside a backward pass of the engine (or a torch without the hook): no deferral
+        return None, None
+    side.wait_stream(torch.cuda.current_stream(dev))  # the operands (dY, X) exist
     return side, st["keep"]
 
 
@@ -163,8 +166,10 @@ def _linear_bwd(lib, x2, dY, N, K, wt, need_x, need_w, need_b, dx_cols=None, act
     xc = K if dx_cols is None else dx_cols
     dX = torch.empty((M, xc), device=dY.device, dtype=torch.float32) if need_x else None
     scratch = torch.empty(max(1, lib.mdt_op_linear_bwd_scratch(M, N, K)), device=dY.device, dtype=torch.float32)
+    side = keep = None
     if beside and (need_w or need_b):
         side, keep = _side_stream(dY.device)
+    if side is not None:
         w = _lib.LinearBwdArgs(X=x2.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None, dW=None if dW is None else dW.data_ptr(),
                                dbias=None if db is None else db.data_ptr(), dX=None, ldxo=xc, accumulate_dw=0, accumulate_dx=0,
                                M=M, N=N, K=K, scratch=scratch.data_ptr(), dx_act_u=None, dx_act=0)
