@@ -494,6 +494,17 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws(mdt_gemm_args a, int ti
     const int panel = i % panels, chunk = (i / panels) * 8 + xcd;
     gemm_ws_tile<K16, NTW, NWAVES, GLU>(a, panel, chunk, tiles, lds, zeros, threadIdx.x);
 }
+template <int K16, int NWAVES, int GLU>
+__global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws_split(mdt_gemm_args a, int tiles, int panels, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) char lds_b[];
+    // 256 blocks, one per CU: block b runs on XCD b % 8, and XCD x takes the 32 consecutive (chunk, panel) pairs 32 x .. 32 x + 31 of
+    // the chunk-major order, so the panels of a chunk (the readers of one A tile) share an L2 -- or two, where a chunk straddles --
+    // whatever the panel count divides (12 panels: 21 chunks of 19 tiles on 252 CUs, not 16 chunks of 24 on 192)
+    const int b = blockIdx.x, w = (b & 7) * 32 + (b >> 3);
+    const int chunk = w / panels, panel = w - chunk * panels;
+    if (chunk * tiles >= ((a.M + 31) >> 5)) return;
+    gemm_ws_split_tile<K16, NWAVES, GLU>(a, panel, chunk, tiles, lds_b, zeros, threadIdx.x);
+}
 // Workgroup = 8 waves x 2 column tiles (256-column panels), one per CU.  Measured and dropped (profiles/r05_ws_ab.txt): 4 waves x 2
 // tiles as two independent workgroups per CU (27.6 vs 27.5 ms per head step), 4 waves x 3 tiles for the N = 576 / 192 products
 // (272 VGPRs: qkv 225 -> 215 us against the tall body, c_proj 81.6 -> 81.0 against the row tiles: not worth a shape).
@@ -548,7 +559,34 @@ static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_ws<K16, NTW, NW, GLU>), dim3(chunks * panels), dim3(64 * NW), lds, s, a, tiles, panels, g_zeros);
     return hipGetLastError();
 }
+// the three-way bf16 split of the weight-stationary body (mdt_ws.h): K = 384, 128-column panels (8 waves, one column tile each)
+static int g_ws_split = -1;
+static bool ws_split_on() {
+    if (g_ws_split < 0) { const char* e = getenv("MDT_HIP_WS_SPLIT"); g_ws_split = e ? atoi(e) : 0; }
+    return g_ws_split != 0;
+}
+extern "C" void mdt_op_set_ws_split(int32_t on) { g_ws_split = on < 0 ? -1 : (on != 0); }
+template <int GLU>
+static hipError_t launch_gemm_ws_split(const mdt_gemm_args& a, hipStream_t s) {
+    constexpr int K16 = 24, NW = 8;
+    const int panels = a.N / (NW * 16), ntiles = (a.M + 31) / 32;
+    const int chunks = std::max(1, std::min(256 / panels, ntiles)), tiles = (ntiles + chunks - 1) / chunks;
+    const size_t lds = (size_t)2 * 3 * 32 * (2 * K16 * 16 + 32);
+    static bool attr_dev[MAX_DEVICES] = {false};
+    bool& done = attr_dev[current_device()];
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_ws_split<K16, NW, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL((k_gemm_ws_split<K16, NW, GLU>), dim3(256), dim3(64 * NW), lds, s, a, tiles, panels, g_zeros);
+    return hipGetLastError();
+}
 static hipError_t launch_gemm_ws(const mdt_gemm_args& a, hipStream_t s) {
+    if (a.K == 384 && ws_split_on() && a.N % 128 == 0 && a.N / 128 <= 32) {
+        const bool hooks = a.aux_mode != 0 || a.act != MDT_ACT_NONE;
+        return hooks ? launch_gemm_ws_split<1>(a, s) : launch_gemm_ws_split<0>(a, s);
+    }
     if (a.K == 384) {
         const bool hooks = a.aux_mode != 0 || a.act != MDT_ACT_NONE;
         if (ws_shape(a) == 12) return hooks ? launch_gemm_ws_t<24, 1, 12, 1>(a, s) : launch_gemm_ws_t<24, 0, 12, 1>(a, s);

@@ -218,3 +218,177 @@ __device__ __forceinline__ void gemm_ws_tile(const mdt_gemm_args& a, int panel, 
         __syncthreads();                                   // tile t + 1 is in LDS; everybody is done reading tile t
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same body with every operand SPLIT THREE WAYS into bf16 (round 6, second half): x = x1 + x2 + x3 with 8 mantissa bits each,
+// and a k32 step = six v_mfma_f32_16x16x32_bf16 products (x1 w1, x1 w2, x2 w1, x1 w3, x2 w2, x3 w1; fp32 accumulation) instead of
+// eight v_mfma_f32_16x16x4_f32: fp32's 24 bits of product accuracy (profiles/r06_bf16_split_probe.txt: error 7e-7 against the
+// fp32 product's own 1.1e-6 at K = 1536) at 6 x 16 = 96 matrix-pipe clocks per k32 instead of 8 x 32 = 256.
+// Why this body and not the row tiles: the split form wants 2.7x the operand bytes per clock; here the weights are split ONCE per
+// workgroup into registers (the fp32 fragments of the existing packed image: lane l of fragment kc holds k = 16 kc + 4 (l / 16) + e,
+// and the eight bf16 a lane feeds to one MFMA are its quads of fragments 2 kk and 2 kk + 1 -- the MFMA's k order is a free
+// permutation as long as both operands agree), and the A tile is split by the threads that stage it, on its way into LDS
+// (three 8-byte stores per 16-byte load, in the slot order the MFMA reads: one ds_read_b128 per part, row tile and k32 step).
+// K16 even, ONE column tile per wave, 8 waves.  LDS: 2 buffers x 3 parts x 32 rows x (2 K + 32) bytes (150 KB at K = 384).
+// NOT bit-identical to the fp32 bodies (other products, other order): the tests hold it to float64 with the fp32 bodies' tolerance.
+typedef __bf16 mdt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mdt_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_bf16(const f32x4& x, mdt_bf16x4& p1, mdt_bf16x4& p2, mdt_bf16x4& p3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 a = (__bf16)x[e];
+        const float r = x[e] - (float)a;
+        const __bf16 b = (__bf16)r;
+        const float r2 = r - (float)b;
+        p1[e] = a; p2[e] = b; p3[e] = (__bf16)r2;
+    }
+}
+
+template <int K16, int NWAVES, int GLU>
+__device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int panel, int chunk, int tiles, char* lds,
+                                                   const float* __restrict__ zeros, int tid) {
+    static_assert(K16 % 2 == 0, "a k32 step is two fragments of the fp32 image");
+    static_assert((32 * (K16 * 4) + 64 * NWAVES - 1) / (64 * NWAVES) <= K16 / 2, "one staged item per k32 step");
+    constexpr int K = K16 * 16, K32 = K16 / 2, K4 = K / 4, NT = 64 * NWAVES;
+    constexpr int ROWB = 2 * K + 32, PART = 32 * ROWB, TILEB = 3 * PART;       // bytes; + 32: ds_read_b128's 16-lane groups hit 64 banks
+    constexpr int NLD = (32 * K4 + NT - 1) / NT;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, m16 = lane & 15;
+    const int nt0 = panel * NWAVES + wave;
+    const int ntiles = (a.M + 31) >> 5;
+    const int t0 = chunk * tiles, t1 = min(t0 + tiles, ntiles);
+    if (t0 >= t1) return;
+
+    const int nq = 4 * g;
+    const int ncol = nt0 * 16 + nq;
+    const f32x4 bias_v = ldg4((a.bias != nullptr ? a.bias : zeros) + ncol);
+
+    // ---- A tile t: item idx = tid + NT * u -> row idx / K4, float4 column idx % K4 ----
+    // (row and column are recomputed from tid at each use: twelve registers this body does not have)
+    f32x4 stage[NLD];
+    auto request = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = min(tid + NT * u, 32 * K4 - 1), r = idx / K4, c = 4 * (idx - r * K4);
+            const int64_t m = min(32 * t + r, a.M - 1);
+            stage[u] = ldg4(a.A + m * a.lda + c);
+        }
+    };
+    // the four values at columns c .. c + 3 of a row are slots (half, j) = ((c % 32) / 16, 0 .. 3) of lane group (c % 16) / 4 in k32
+    // step c / 32: eight bytes per part at  row * ROWB + (c / 32) * 64 + ((c % 16) / 4) * 16 + ((c % 32) / 16) * 8
+    auto commit = [&](char* buf, int u) __attribute__((always_inline)) {
+        {
+            if (tid + NT * u < 32 * K4) {
+                mdt_bf16x4 p1, p2, p3;
+                split3_bf16(stage[u], p1, p2, p3);
+                const int idx = tid + NT * u, r = idx / K4, c = 4 * (idx - r * K4);
+                char* q = buf + r * ROWB + (c >> 5) * 64 + ((c & 15) >> 2) * 16 + ((c & 31) >> 4) * 8;
+                *(mdt_bf16x4*)q = p1;
+                *(mdt_bf16x4*)(q + PART) = p2;
+                *(mdt_bf16x4*)(q + 2 * PART) = p3;
+            }
+        }
+    };
+    request(t0);                                           // travels under the weights' split
+    // ---- this wave's weights, once: K16 fp32 fragments -> three bf16 parts of K32 eight-value operands ----
+    mdt_bf16x8 w1[K32], w2[K32], w3[K32];
+    {
+        const float* wp = a.Wp + ((int64_t)nt0 * K16 * 64 + lane) * 4;
+#pragma unroll
+        for (int kk = 0; kk < K32; ++kk) {
+            const f32x4 lo = ldg4(wp + (int64_t)(2 * kk) * 256), hi = ldg4(wp + (int64_t)(2 * kk + 1) * 256);
+            mdt_bf16x4 l1, l2, l3, h1, h2, h3;
+            split3_bf16(lo, l1, l2, l3);
+            split3_bf16(hi, h1, h2, h3);
+            w1[kk] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            w2[kk] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+            w3[kk] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) commit(lds, u);
+    __syncthreads();
+
+    const int aoff = m16 * ROWB + g * 16;
+    for (int t = t0; t < t1; ++t) {
+        const char* cur = lds + ((t - t0) & 1) * TILEB;
+        char* nxt = lds + ((t - t0 + 1) & 1) * TILEB;
+        const bool more = t + 1 < t1;
+        if (more) request(t + 1);                          // travels under this tile's MFMAs
+        int64_t oo[2];
+        bool okr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mr = 32 * t + 16 * i + m16;
+            okr[i] = mr < a.M;
+            oo[i] = (int64_t)min(mr, a.M - 1) * a.ldo;
+        }
+        f32x4 acc[2] = {zero4, zero4};
+        mdt_bf16x8 x1[2], x2[2], x3[2];
+        f32x4 auxv[2] = {zero4, zero4};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* p = cur + aoff + i * 16 * ROWB;
+            x1[i] = *(const mdt_bf16x8*)p; x2[i] = *(const mdt_bf16x8*)(p + PART); x3[i] = *(const mdt_bf16x8*)(p + 2 * PART);
+        }
+#pragma unroll
+        for (int kk = 0; kk < K32; ++kk) {
+            // the six products of this k32 step, smallest first, the two row tiles alternating (a dependent MFMA sits two issue slots
+            // behind its producer); each part of the next step is read into the registers of this step's right behind its last use,
+            // so no second operand set is live (256 registers hold the 144 of the weights, the staged tile and this)
+            const bool nx = kk + 1 < K32;
+            const char* p0 = cur + aoff + (kk + 1) * 64;
+            const char* p1 = p0 + 16 * ROWB;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x3[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x3[1], acc[1], 0, 0, 0);
+            MDT_SCHED_PIN
+            if (nx) { x3[0] = *(const mdt_bf16x8*)(p0 + 2 * PART); x3[1] = *(const mdt_bf16x8*)(p1 + 2 * PART); }
+            if constexpr (GLU == 1) {
+                // the backward hook's second operand: asked for a k32 step before the epilogue wants it, not inside it
+                // (the last step, behind its x3 products: their eight registers are free from here on; earlier it spills)
+                if (kk == K32 - 1 && a.aux_mode == 2) {
+                    auxv[0] = ldg4(a.aux + oo[0] + ncol);          // rows clamped above: in bounds
+                    auxv[1] = ldg4(a.aux + oo[1] + ncol);
+                }
+            }
+            MDT_SCHED_PIN
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x2[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x2[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x2[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x2[1], acc[1], 0, 0, 0);
+            MDT_SCHED_PIN
+            if (nx) { x2[0] = *(const mdt_bf16x8*)(p0 + PART); x2[1] = *(const mdt_bf16x8*)(p1 + PART); }
+            MDT_SCHED_PIN
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[kk], x1[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[kk], x1[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x1[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x1[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x1[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x1[1], acc[1], 0, 0, 0);
+            MDT_SCHED_PIN
+            if (nx) { x1[0] = *(const mdt_bf16x8*)p0; x1[1] = *(const mdt_bf16x8*)p1; }
+            // one staged item of tile t + 1 per step of the second half: its split and its three LDS stores issue between this
+            // tile's MFMAs instead of in a phase of their own (all eight waves would sit in that phase together, matrix pipe idle)
+            if (more && kk >= K32 - NLD) commit(nxt, kk - (K32 - NLD));
+            MDT_SCHED_PIN
+        }
+        // ---- epilogue of tile t: lane holds out[32 t + 16 i + lane % 16][ncol .. + 3] ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 v = acc[i] + bias_v;
+            if constexpr (GLU == 1) {
+                if (a.aux_mode == 2) {
+                    const f32x4 u = auxv[i];
+                    v.x *= apply_act_grad1(u.x, a.act); v.y *= apply_act_grad1(u.y, a.act);
+                    v.z *= apply_act_grad1(u.z, a.act); v.w *= apply_act_grad1(u.w, a.act);
+                } else {
+                    if (a.aux_mode == 1 && okr[i]) *(f32x4*)(const_cast<float*>(a.aux) + oo[i] + ncol) = v;
+                    v = apply_act(v, a.act);
+                }
+            }
+            if (okr[i]) *(f32x4*)(a.out + oo[i] + ncol) = v;
+        }
+        __syncthreads();                                   // tile t + 1 is in LDS; everybody is done reading tile t
+    }
+}

@@ -219,6 +219,57 @@ def test_gemm_weight_stationary_body_at_k384_with_the_training_hooks(lib, M, N):
     assert_close(outs[30]["aux2"], (u * y64.grad).float(), rtol=1e-4, atol=2e-4, what="aux_mode 2: value * act'(aux)")
 
 
+@pytest.mark.parametrize("M,N", [(8192, 384), (8192 + 77, 1152), (12288, 1536), (33, 384)])
+def test_gemm_weight_stationary_body_split_three_ways_into_bf16_keeps_fp32_accuracy(lib, M, N):
+    """Round 6: the K = 384 weight-stationary body with every operand as three bf16 parts and six bf16 MFMA products per k32 step
+    (mdt_ws.h gemm_ws_split_tile).  Not the fp32 bodies' bits -- so: against float64, the split form's error must stay within
+    1.5x the fp32 MFMA body's own on the same inputs (and inside the fp32 bodies' test tolerance), for plain rows, bias + GELU
+    and the two training hooks; inputs with a wide dynamic range included (the parts' exponents follow the value's)."""
+    L = lib.load()
+    K = 384
+    g = torch.Generator().manual_seed(M * 3 + N)
+    A = torch.randn(M, K, generator=g) * torch.exp(2.0 * torch.randn(M, 1, generator=g))   # rows of very different scale
+    W, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    y0 = torch.randn(M, N, generator=g)
+    Ad, Pd, bd = dev(A), pack(lib, W), dev(b)
+    outs = {}
+    try:
+        L.mdt_op_set_gemm_geometry(30)
+        for split in (0, 1):
+            L.mdt_op_set_ws_split(split)
+            o = {"plain": run_gemm(lib, A, W, bias=b), "gelu": run_gemm(lib, A, W, bias=b, act="gelu")}
+            for mode in (1, 2):
+                out = torch.full((M, N), float("nan"), device="cuda")
+                aux = torch.full((M, N), float("nan"), device="cuda") if mode == 1 else dev(y0)
+                a = lib.GemmArgs()
+                a.A, a.lda, a.Wp, a.out, a.ldo, a.M, a.N, a.K = Ad.data_ptr(), K, Pd.data_ptr(), out.data_ptr(), N, M, N, K
+                a.bias = bd.data_ptr() if mode == 1 else None
+                a.shift_off = a.scale_off = a.gate_off = -1
+                a.rows_per_sample = a.gin = a.gout = 1
+                a.act, a.aux, a.aux_mode = lib.ACT["gelu"], aux.data_ptr(), mode
+                lib.check(L.mdt_op_gemm(C.byref(a), stream()))
+                torch.cuda.synchronize()
+                o[f"aux{mode}"] = out.cpu()
+                if mode == 1:
+                    o["aux1_pre"] = aux.cpu()
+            outs[split] = o
+    finally:
+        L.mdt_op_set_gemm_geometry(0)
+        L.mdt_op_set_ws_split(-1)
+    u = A.double() @ W.double().T
+    y64 = y0.double().requires_grad_()
+    F.gelu(y64).sum().backward()
+    want = {"plain": u + b.double(), "gelu": F.gelu(u + b.double()), "aux1_pre": u + b.double(), "aux1": F.gelu(u + b.double()),
+            "aux2": u * y64.grad}
+    scale = A.double().abs().amax(dim=1, keepdim=True)          # per-row scale of the inputs
+    for k, w in want.items():
+        e32 = ((outs[0][k].double() - w).abs() / scale).max().item()
+        e16 = ((outs[1][k].double() - w).abs() / scale).max().item()
+        assert e16 <= 1.5 * e32 + 1e-7, f"{k}: split error {e16:.3g} against the fp32 body's {e32:.3g} (per-row scaled)"
+        assert_close(outs[1][k] / scale.float(), (w / scale).float(), rtol=1e-4, atol=1e-4, what=f"split: {k}")
+    assert not torch.equal(outs[0]["plain"], outs[1]["plain"]) or M < 64, "the split form did not run (same bits as the fp32 body)"
+
+
 @pytest.mark.parametrize("geo", [23])
 def test_gemm_tall_body_epilogues(lib, geo):
     """Every epilogue the tall body carries, against the row-tile body (bitwise) and float64: bias + GELU, per-sample gate +
