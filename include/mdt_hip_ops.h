@@ -136,7 +136,7 @@ mdt_status mdt_op_clock_stamp(uint64_t *out16, void *stream);
 /* Tuning / test hook (round 6): 1 = the K = 384 products that take the weight-stationary body (from 8192 rows on: the training step at
  * B = 1024) run its THREE-WAY bf16 SPLIT form -- every fp32 operand as three bf16 parts, six v_mfma_f32_16x16x32_bf16 products per k32
  * step with fp32 accumulation: fp32's product accuracy (not its bits) at 2.7x the fp32 matrix rate; 0 = the fp32 MFMA form;
- * negative = default (MDT_HIP_WS_SPLIT from the environment). */
+ * negative = default (MDT_HIP_WS_SPLIT from the environment; unset = 1). */
 void mdt_op_set_ws_split(int32_t on);
 
 /* Tuning / test hook: wave schedule inside mdt_op_mlp's kernel.  Low byte = number of k-steps the second wave of every

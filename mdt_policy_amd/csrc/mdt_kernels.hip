@@ -562,7 +562,7 @@ static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
 // the three-way bf16 split of the weight-stationary body (mdt_ws.h): K = 384, 128-column panels (8 waves, one column tile each)
 static int g_ws_split = -1;
 static bool ws_split_on() {
-    if (g_ws_split < 0) { const char* e = getenv("MDT_HIP_WS_SPLIT"); g_ws_split = e ? atoi(e) : 0; }
+    if (g_ws_split < 0) { const char* e = getenv("MDT_HIP_WS_SPLIT"); g_ws_split = e ? atoi(e) : 1; }
     return g_ws_split != 0;
 }
 extern "C" void mdt_op_set_ws_split(int32_t on) { g_ws_split = on < 0 ? -1 : (on != 0); }

@@ -40,6 +40,13 @@
 
 // K16 = K / 16 (compile time: the fragments live in registers); NTW column tiles per wave; NWAVES waves.  `tiles` = 32-row
 // tiles per workgroup, `panels` = N / (NWAVES * NTW * 16).  lds: 2 * 32 * (K + 4) floats.
+// The per-tile barrier of both bodies: the LDS stores of tile t + 1 have landed (lgkmcnt) and everybody is done reading tile t.
+// NOT __syncthreads(): its fence also drains vmcnt, i.e. parks every wave until the epilogue stores of tile t have reached memory
+// (SQ_WAIT_ANY was 22-34 % of the wave cycles of the split body, profiles/r06_ws_split.txt) -- nothing here reads them back.
+__device__ __forceinline__ void ws_tile_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int K16, int NTW, int NWAVES, int GLU>
 __device__ __forceinline__ void gemm_ws_tile(const mdt_gemm_args& a, int panel, int chunk, int tiles, float* lds,
                                              const float* __restrict__ zeros, int tid) {
@@ -215,7 +222,7 @@ __device__ __forceinline__ void gemm_ws_tile(const mdt_gemm_args& a, int panel, 
             }
         }
         if (more) commit(nxt);
-        __syncthreads();                                   // tile t + 1 is in LDS; everybody is done reading tile t
+        ws_tile_barrier();                                 // tile t + 1 is in LDS; everybody is done reading tile t
     }
 }
 
@@ -389,6 +396,6 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
             }
             if (okr[i]) *(f32x4*)(a.out + oo[i] + ncol) = v;
         }
-        __syncthreads();                                   // tile t + 1 is in LDS; everybody is done reading tile t
+        ws_tile_barrier();                                 // tile t + 1 is in LDS; everybody is done reading tile t
     }
 }

@@ -187,6 +187,7 @@ def test_gemm_weight_stationary_body_at_k384_with_the_training_hooks(lib, M, N):
     Ad, Pd, bd = dev(A), pack(lib, W), dev(b)
     outs = {}
     try:
+        L.mdt_op_set_ws_split(0)   # the fp32 MFMA form of the body (its bf16 split form has its own test below)
         for gsel in (1, 30):
             L.mdt_op_set_gemm_geometry(gsel)
             o = {"plain": run_gemm(lib, A, W, bias=b), "gelu": run_gemm(lib, A, W, bias=b, act="gelu")}
@@ -207,6 +208,7 @@ def test_gemm_weight_stationary_body_at_k384_with_the_training_hooks(lib, M, N):
             outs[gsel] = o
     finally:
         L.mdt_op_set_gemm_geometry(0)
+        L.mdt_op_set_ws_split(-1)
     for k in outs[1]:
         assert torch.equal(outs[1][k], outs[30][k]), f"{k}: weight-stationary body differs from the row-tile body"
     u = A.double() @ W.double().T

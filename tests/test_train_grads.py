@@ -716,3 +716,52 @@ def test_training_step_with_its_side_stream_is_bit_reproducible(B, mode):
             ref = got
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, got)), f"step {it} differs from the first one"
+
+
+@pytest.mark.gpu
+def test_training_step_with_the_bf16_split_products_equals_the_fp32_products_to_fp32_rounding():
+    """Round 6: at B = 1024 the K = 384 products of the step (12 288-row d x d, qkv, c_fc and c_fc-gradient GEMMs) run the
+    weight-stationary body in its three-way bf16 split form (mdt_ws.h).  The split keeps fp32's product accuracy, not its bits:
+    the same seeded step (eval mode: no dropout) with the split on and off must agree in the loss and in EVERY gradient to a few
+    fp32 roundings of the gradient's own size -- tolerance 2e-5 of max |g| per tensor, the level at which two fp32 summation
+    orders of these 12 288-row reductions differ -- and the split must really have run (bits differ somewhere)."""
+    from mdt_policy_amd import _lib, configs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    L = _lib.load()
+    B = 1024
+    cfg = configs.mdtv_default()
+    torch.manual_seed(0)
+    model = GCDenoiser(cfg, 0.5).cuda().eval()
+    inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(B, cfg, 1).items()}
+    li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(B, cfg, 2).items()}
+    state = {"state_images": inp["state_images"].requires_grad_(), "modality": "lang"}
+    goal = inp["goal"].requires_grad_()
+    res = {}
+    try:
+        for split in (0, 1):
+            L.mdt_op_set_ws_split(split)
+            model.zero_grad(set_to_none=True)
+            state["state_images"].grad = None
+            goal.grad = None
+            loss, _ = model.loss(state, li["actions"], goal, li["noise_train"], li["sigma"])
+            loss.backward()
+            torch.cuda.synchronize()
+            res[split] = [("loss", loss.detach().clone())] + \
+                         [(n, p.grad.clone()) for n, p in model.named_parameters() if p.grad is not None] + \
+                         [("d state_images", state["state_images"].grad.clone()), ("d goal", goal.grad.clone())]
+    finally:
+        L.mdt_op_set_ws_split(-1)
+    assert len(res[0]) == len(res[1]) > 100
+    differs = False
+    # (gradients that are zero in exact arithmetic -- the key biases: softmax ignores a per-query constant -- are rounding noise of
+    # the tensors around them: the floor is taken from the largest parameter gradient of the step)
+    floor = 1e-7 * max(a.abs().max().item() for n, a in res[0] if n.startswith("inner_model."))
+    worst = 0.0
+    for (n, a), (_, b) in zip(res[0], res[1]):
+        differs |= not torch.equal(a, b)
+        scale = a.abs().max().item()
+        err = (a - b).abs().max().item()
+        worst = max(worst, err / (scale + floor / 2e-5))
+        assert err <= 2e-5 * scale + floor, f"{n}: split and fp32 products differ by {err:.3g} at max |g| = {scale:.3g}"
+    print(f"worst |split - fp32| / max |g| over {len(res[0])} tensors: {worst:.3g}")
+    assert differs, "the split form did not run: every gradient has the fp32 products' bits"
