@@ -271,31 +271,47 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
     const int ncol = nt0 * 16 + nq;
     const f32x4 bias_v = ldg4((a.bias != nullptr ? a.bias : zeros) + ncol);
 
-    // ---- A tile t: item idx = tid + NT * u -> row idx / K4, float4 column idx % K4 ----
-    // (row and column are recomputed from tid at each use: twelve registers this body does not have)
+    // ---- A tile t: wave w stages rows 4 w .. 4 w + 3 (4 x K4 = 6 x 64 float4 items): item u of lane l is element j = l + 64 u of
+    //      those rows, row j / K4, float4 column j % K4.  With K4 = 96, items u and u + 3 are the same column two rows apart, so three
+    //      (global, LDS) offset pairs per lane + constants address all six -- no index arithmetic between the MFMAs, where every
+    //      issue slot counts (SQ: 30 % of the wave cycles were non-MFMA issue with the offsets recomputed per item) ----
+    static_assert(K4 == 96 && NWAVES == 8 && NLD == 6, "the staging pattern below is written for K = 384 and eight waves");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int goff[3], loff[3];                                  // floats from the wave's first row / bytes from the buffer
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int j = lane + 64 * u, r = j / K4, c = 4 * (j - r * K4);
+        goff[u] = r * (int)a.lda + c;
+        // the four values at columns c .. c + 3 of a row are slots (half, 0 .. 3) = ((c % 32) / 16, ..) of lane group (c % 16) / 4 in
+        // k32 step c / 32: eight bytes per part at  row * ROWB + (c / 32) * 64 + ((c % 16) / 4) * 16 + ((c % 32) / 16) * 8
+        loff[u] = (4 * wave_u + r) * ROWB + (c >> 5) * 64 + ((c & 15) >> 2) * 16 + ((c & 31) >> 4) * 8;
+    }
     f32x4 stage[NLD];
     auto request = [&](int t) __attribute__((always_inline)) {
+        const int r0 = 32 * t + 4 * wave_u;                // wave-uniform
+        if (r0 + 4 <= a.M) {
+            const float* pt = a.A + (int64_t)r0 * a.lda;
+            const float* pt2 = pt + 2 * a.lda;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int idx = min(tid + NT * u, 32 * K4 - 1), r = idx / K4, c = 4 * (idx - r * K4);
-            const int64_t m = min(32 * t + r, a.M - 1);
-            stage[u] = ldg4(a.A + m * a.lda + c);
-        }
-    };
-    // the four values at columns c .. c + 3 of a row are slots (half, j) = ((c % 32) / 16, 0 .. 3) of lane group (c % 16) / 4 in k32
-    // step c / 32: eight bytes per part at  row * ROWB + (c / 32) * 64 + ((c % 16) / 4) * 16 + ((c % 32) / 16) * 8
-    auto commit = [&](char* buf, int u) __attribute__((always_inline)) {
-        {
-            if (tid + NT * u < 32 * K4) {
-                mdt_bf16x4 p1, p2, p3;
-                split3_bf16(stage[u], p1, p2, p3);
-                const int idx = tid + NT * u, r = idx / K4, c = 4 * (idx - r * K4);
-                char* q = buf + r * ROWB + (c >> 5) * 64 + ((c & 15) >> 2) * 16 + ((c & 31) >> 4) * 8;
-                *(mdt_bf16x4*)q = p1;
-                *(mdt_bf16x4*)(q + PART) = p2;
-                *(mdt_bf16x4*)(q + 2 * PART) = p3;
+            for (int u = 0; u < 3; ++u) {
+                stage[u] = ldg4(pt + goff[u]);
+                stage[u + 3] = ldg4(pt2 + goff[u]);
+            }
+        } else {                                           // the ragged end: rows past M re-read the last row (never stored)
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int j = lane + 64 * u, r = j / K4, c = 4 * (j - r * K4);
+                stage[u] = ldg4(a.A + (int64_t)min(r0 + r, a.M - 1) * a.lda + c);
             }
         }
+    };
+    auto commit = [&](char* buf, int u) __attribute__((always_inline)) {
+        mdt_bf16x4 p1, p2, p3;
+        split3_bf16(stage[u], p1, p2, p3);
+        char* q = buf + loff[u % 3] + (u / 3) * 2 * ROWB;
+        *(mdt_bf16x4*)q = p1;
+        *(mdt_bf16x4*)(q + PART) = p2;
+        *(mdt_bf16x4*)(q + 2 * PART) = p3;
     };
     request(t0);                                           // travels under the weights' split
     // ---- this wave's weights, once: K16 fp32 fragments -> three bf16 parts of K32 eight-value operands ----
