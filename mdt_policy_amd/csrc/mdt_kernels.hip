@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws(mdt_gemm_args a, int ti
     const int panel = i % panels, chunk = (i / panels) * 8 + xcd;
     gemm_ws_tile<K16, NTW, NWAVES, GLU>(a, panel, chunk, tiles, lds, zeros, threadIdx.x);
 }
-template <int K16, int NWAVES, int GLU>
+template <int K16, int NTW, int NWAVES, int GLU>
 __global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws_split(mdt_gemm_args a, int tiles, int panels, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) char lds_b[];
     // 256 blocks, one per CU: block b runs on XCD b % 8, and XCD x takes the 32 consecutive (chunk, panel) pairs 32 x .. 32 x + 31 of
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_ws_split(mdt_gemm_args a, 
     const int b = blockIdx.x, w = (b & 7) * 32 + (b >> 3);
     const int chunk = w / panels, panel = w - chunk * panels;
     if (chunk * tiles >= ((a.M + 31) >> 5)) return;
-    gemm_ws_split_tile<K16, NWAVES, GLU>(a, panel, chunk, tiles, lds_b, zeros, threadIdx.x);
+    gemm_ws_split_tile<K16, NTW, NWAVES, GLU>(a, panel, chunk, tiles, lds_b, zeros, threadIdx.x);
 }
 // Workgroup = 8 waves x 2 column tiles (256-column panels), one per CU.  Measured and dropped (profiles/r05_ws_ab.txt): 4 waves x 2
 // tiles as two independent workgroups per CU (27.6 vs 27.5 ms per head step), 4 waves x 3 tiles for the N = 576 / 192 products
@@ -566,26 +566,32 @@ static bool ws_split_on() {
     return g_ws_split != 0;
 }
 extern "C" void mdt_op_set_ws_split(int32_t on) { g_ws_split = on < 0 ? -1 : (on != 0); }
-template <int GLU>
+template <int K16, int NTW, int GLU>
 static hipError_t launch_gemm_ws_split(const mdt_gemm_args& a, hipStream_t s) {
-    constexpr int K16 = 24, NW = 8;
-    const int panels = a.N / (NW * 16), ntiles = (a.M + 31) / 32;
+    constexpr int NW = 8;
+    const int panels = a.N / (NW * NTW * 16), ntiles = (a.M + 31) / 32;
     const int chunks = std::max(1, std::min(256 / panels, ntiles)), tiles = (ntiles + chunks - 1) / chunks;
     const size_t lds = (size_t)2 * 3 * 32 * (2 * K16 * 16 + 32);
     static bool attr_dev[MAX_DEVICES] = {false};
     bool& done = attr_dev[current_device()];
     if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_ws_split<K16, NW, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_ws_split<K16, NTW, NW, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done = true;
     }
-    hipLaunchKernelGGL((k_gemm_ws_split<K16, NW, GLU>), dim3(256), dim3(64 * NW), lds, s, a, tiles, panels, g_zeros);
+    hipLaunchKernelGGL((k_gemm_ws_split<K16, NTW, NW, GLU>), dim3(256), dim3(64 * NW), lds, s, a, tiles, panels, g_zeros);
     return hipGetLastError();
 }
 static hipError_t launch_gemm_ws(const mdt_gemm_args& a, hipStream_t s) {
-    if (a.K == 384 && ws_split_on() && a.N % 128 == 0 && a.N / 128 <= 32) {
+    if (ws_split_on() && a.K == 384 && a.N % 128 == 0 && a.N / 128 <= 32) {
         const bool hooks = a.aux_mode != 0 || a.act != MDT_ACT_NONE;
-        return hooks ? launch_gemm_ws_split<1>(a, s) : launch_gemm_ws_split<0>(a, s);
+        return hooks ? launch_gemm_ws_split<24, 1, 1>(a, s) : launch_gemm_ws_split<24, 1, 0>(a, s);
+    }
+    if (ws_split_on() && a.K == 192 && a.N % 256 == 0 && a.N / 256 <= 32 && a.act == MDT_ACT_NONE &&
+        (a.aux_mode == 0 || a.aux_mode == 3 || a.aux_mode == 4)) {
+        if (a.aux_mode == 3) return launch_gemm_ws_split<12, 2, 3>(a, s);
+        if (a.aux_mode == 4) return launch_gemm_ws_split<12, 2, 4>(a, s);
+        return launch_gemm_ws_split<12, 2, 0>(a, s);
     }
     if (a.K == 384) {
         const bool hooks = a.aux_mode != 0 || a.act != MDT_ACT_NONE;

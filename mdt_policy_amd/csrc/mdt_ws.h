@@ -252,30 +252,41 @@ __device__ __forceinline__ void split3_bf16(const f32x4& x, mdt_bf16x4& p1, mdt_
     }
 }
 
-template <int K16, int NWAVES, int GLU>
+template <int K16, int NTW, int NWAVES, int GLU>
 __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int panel, int chunk, int tiles, char* lds,
                                                    const float* __restrict__ zeros, int tid) {
     static_assert(K16 % 2 == 0, "a k32 step is two fragments of the fp32 image");
-    static_assert((32 * (K16 * 4) + 64 * NWAVES - 1) / (64 * NWAVES) <= K16 / 2, "one staged item per k32 step");
+    static_assert(K16 * NTW == 24, "144 registers of weights: K = 384 with one column tile per wave, or K = 192 with two");
+    static_assert(GLU != 3 || NTW % 2 == 0, "SwishGLU forward pairs tiles");
+    static_assert(GLU != 1 || NTW == 1, "the activation hooks are written for one column tile");
     constexpr int K = K16 * 16, K32 = K16 / 2, K4 = K / 4, NT = 64 * NWAVES;
     constexpr int ROWB = 2 * K + 32, PART = 32 * ROWB, TILEB = 3 * PART;       // bytes; + 32: ds_read_b128's 16-lane groups hit 64 banks
     constexpr int NLD = (32 * K4 + NT - 1) / NT;
+    static_assert(NLD <= K32, "one staged item per k32 step");
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, m16 = lane & 15;
-    const int nt0 = panel * NWAVES + wave;
+    const int nt0 = (panel * NWAVES + wave) * NTW;
     const int ntiles = (a.M + 31) >> 5;
     const int t0 = chunk * tiles, t1 = min(t0 + tiles, ntiles);
     if (t0 >= t1) return;
 
     const int nq = 4 * g;
-    const int ncol = nt0 * 16 + nq;
-    const f32x4 bias_v = ldg4((a.bias != nullptr ? a.bias : zeros) + ncol);
+    const float* biasp = a.bias != nullptr ? a.bias : zeros;
+    int ncol[NTW];
+    f32x4 bias_v[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int T = nt0 + j;
+        // (SwishGLU forward: the image interleaves the projected / gate halves tile by tile; bias and output columns are the natural ones)
+        ncol[j] = (GLU == 3 ? (T & 1) * (a.N >> 1) + (T >> 1) * 16 : T * 16) + nq;
+        bias_v[j] = ldg4(biasp + ncol[j]);
+    }
 
-    // ---- A tile t: wave w stages rows 4 w .. 4 w + 3 (4 x K4 = 6 x 64 float4 items): item u of lane l is element j = l + 64 u of
-    //      those rows, row j / K4, float4 column j % K4.  With K4 = 96, items u and u + 3 are the same column two rows apart, so three
-    //      (global, LDS) offset pairs per lane + constants address all six -- no index arithmetic between the MFMAs, where every
-    //      issue slot counts (SQ: 30 % of the wave cycles were non-MFMA issue with the offsets recomputed per item) ----
-    static_assert(K4 == 96 && NWAVES == 8 && NLD == 6, "the staging pattern below is written for K = 384 and eight waves");
+    // ---- A tile t: wave w stages rows 4 w .. 4 w + 3 (4 x K4 float4 items, NLD = K4 / 16 per lane): item u of lane l is element
+    //      j = l + 64 u of those rows, row j / K4, float4 column j % K4.  With K4 = 96, items u and u + 3 are the same column two rows
+    //      apart (K4 = 48 has three items), so three (global, LDS) offset pairs per lane + constants address all of them -- no index
+    //      arithmetic between the MFMAs ----
+    static_assert(NWAVES == 8 && ((K4 == 96 && NLD == 6) || (K4 == 48 && NLD == 3)), "the staging pattern is written for K = 384 / 192, 8 waves");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int goff[3], loff[3];                                  // floats from the wave's first row / bytes from the buffer
 #pragma unroll
@@ -291,12 +302,8 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
         const int r0 = 32 * t + 4 * wave_u;                // wave-uniform
         if (r0 + 4 <= a.M) {
             const float* pt = a.A + (int64_t)r0 * a.lda;
-            const float* pt2 = pt + 2 * a.lda;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                stage[u] = ldg4(pt + goff[u]);
-                stage[u + 3] = ldg4(pt2 + goff[u]);
-            }
+            for (int u = 0; u < NLD; ++u) stage[u] = ldg4(pt + (u / 3) * 2 * a.lda + goff[u % 3]);
         } else {                                           // the ragged end: rows past M re-read the last row (never stored)
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
@@ -314,19 +321,20 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
         *(mdt_bf16x4*)(q + 2 * PART) = p3;
     };
     request(t0);                                           // travels under the weights' split
-    // ---- this wave's weights, once: K16 fp32 fragments -> three bf16 parts of K32 eight-value operands ----
-    mdt_bf16x8 w1[K32], w2[K32], w3[K32];
-    {
-        const float* wp = a.Wp + ((int64_t)nt0 * K16 * 64 + lane) * 4;
+    // ---- this wave's weights, once: NTW x K16 fp32 fragments -> three bf16 parts of NTW x K32 eight-value operands ----
+    mdt_bf16x8 w1[NTW][K32], w2[NTW][K32], w3[NTW][K32];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const float* wp = a.Wp + ((int64_t)(nt0 + j) * K16 * 64 + lane) * 4;
 #pragma unroll
         for (int kk = 0; kk < K32; ++kk) {
             const f32x4 lo = ldg4(wp + (int64_t)(2 * kk) * 256), hi = ldg4(wp + (int64_t)(2 * kk + 1) * 256);
             mdt_bf16x4 l1, l2, l3, h1, h2, h3;
             split3_bf16(lo, l1, l2, l3);
             split3_bf16(hi, h1, h2, h3);
-            w1[kk] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            w2[kk] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
-            w3[kk] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+            w1[j][kk] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            w2[j][kk] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+            w3[j][kk] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     }
 #pragma unroll
@@ -347,9 +355,19 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
             okr[i] = mr < a.M;
             oo[i] = (int64_t)min(mr, a.M - 1) * a.ldo;
         }
-        f32x4 acc[2] = {zero4, zero4};
+        f32x4 acc[2][NTW];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
+        // the epilogue's second operands (backward hooks), asked for inside the last k32 step: the registers of the next step's
+        // x3 / x2 operands are free from their last products on (earlier the body spills), and the epilogue does not start with a
+        // memory round trip.  GLU == 1: act'(aux); GLU == 4: projected value and gate of the SwishGLU forward, row tile 0.
+        constexpr int NAUX = GLU == 1 ? 2 : (GLU == 4 ? 2 * NTW : 1);
+        f32x4 auxv[NAUX];
+#pragma unroll
+        for (int q = 0; q < NAUX; ++q) auxv[q] = zero4;
         mdt_bf16x8 x1[2], x2[2], x3[2];
-        f32x4 auxv[2] = {zero4, zero4};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const char* p = cur + aoff + i * 16 * ROWB;
@@ -357,60 +375,120 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
         }
 #pragma unroll
         for (int kk = 0; kk < K32; ++kk) {
-            // the six products of this k32 step, smallest first, the two row tiles alternating (a dependent MFMA sits two issue slots
-            // behind its producer); each part of the next step is read into the registers of this step's right behind its last use,
-            // so no second operand set is live (256 registers hold the 144 of the weights, the staged tile and this)
+            // the six products of this k32 step, smallest first, row and column tiles alternating (a dependent MFMA sits at least two
+            // issue slots behind its producer); each part of the next step is read into the registers of this step's right behind its
+            // last use, so no second operand set is live (256 registers hold the 144 of the weights, the staged tile and this)
             const bool nx = kk + 1 < K32;
             const char* p0 = cur + aoff + (kk + 1) * 64;
             const char* p1 = p0 + 16 * ROWB;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x3[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x3[1], acc[1], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][kk], x3[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][kk], x3[1], acc[1][j], 0, 0, 0);
+            }
             MDT_SCHED_PIN
             if (nx) { x3[0] = *(const mdt_bf16x8*)(p0 + 2 * PART); x3[1] = *(const mdt_bf16x8*)(p1 + 2 * PART); }
-            if constexpr (GLU == 1) {
-                // the backward hook's second operand: asked for a k32 step before the epilogue wants it, not inside it
-                // (the last step, behind its x3 products: their eight registers are free from here on; earlier it spills)
-                if (kk == K32 - 1 && a.aux_mode == 2) {
-                    auxv[0] = ldg4(a.aux + oo[0] + ncol);          // rows clamped above: in bounds
-                    auxv[1] = ldg4(a.aux + oo[1] + ncol);
+            if (kk == K32 - 1) {
+                if constexpr (GLU == 1) {
+                    if (a.aux_mode == 2) {
+                        auxv[0] = ldg4(a.aux + oo[0] + ncol[0]);       // rows clamped above: in bounds
+                        auxv[1] = ldg4(a.aux + oo[1] + ncol[0]);
+                    }
+                } else if constexpr (GLU == 4) {
+                    auxv[0] = ldg4(a.aux + oo[0] + ncol[0]);
+                    auxv[1] = ldg4(a.aux + oo[0] + a.N + ncol[0]);
                 }
             }
             MDT_SCHED_PIN
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x2[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x2[1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x2[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x2[1], acc[1], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][kk], x2[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][kk], x2[1], acc[1][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][kk], x2[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][kk], x2[1], acc[1][j], 0, 0, 0);
+            }
             MDT_SCHED_PIN
             if (nx) { x2[0] = *(const mdt_bf16x8*)(p0 + PART); x2[1] = *(const mdt_bf16x8*)(p1 + PART); }
+            if constexpr (GLU == 4 && NTW > 1) {
+                if (kk == K32 - 1) {
+                    auxv[2] = ldg4(a.aux + oo[0] + ncol[1]);
+                    auxv[3] = ldg4(a.aux + oo[0] + a.N + ncol[1]);
+                }
+            }
             MDT_SCHED_PIN
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[kk], x1[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[kk], x1[1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x1[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[kk], x1[1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x1[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[kk], x1[1], acc[1], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[j][kk], x1[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[j][kk], x1[1], acc[1][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][kk], x1[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][kk], x1[1], acc[1][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][kk], x1[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][kk], x1[1], acc[1][j], 0, 0, 0);
+            }
             MDT_SCHED_PIN
             if (nx) { x1[0] = *(const mdt_bf16x8*)p0; x1[1] = *(const mdt_bf16x8*)p1; }
-            // one staged item of tile t + 1 per step of the second half: its split and its three LDS stores issue between this
-            // tile's MFMAs instead of in a phase of their own (all eight waves would sit in that phase together, matrix pipe idle)
+            // one staged item of tile t + 1 per step of the last ones: its split and its three LDS stores issue between this tile's
+            // MFMAs instead of in a phase of their own (all eight waves would sit in that phase together, matrix pipe idle)
             if (more && kk >= K32 - NLD) commit(nxt, kk - (K32 - NLD));
             MDT_SCHED_PIN
         }
-        // ---- epilogue of tile t: lane holds out[32 t + 16 i + lane % 16][ncol .. + 3] ----
+        // ---- epilogue of tile t: lane holds out[32 t + 16 i + lane % 16][ncol[j] .. + 3] ----
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            f32x4 v = acc[i] + bias_v;
-            if constexpr (GLU == 1) {
+            if constexpr (GLU == 3) {
+                float* up = const_cast<float*>(a.aux) + 2 * oo[i];
+#pragma unroll
+                for (int j = 0; j < NTW; j += 2) {
+                    f32x4 v = acc[i][j] + bias_v[j];
+                    const f32x4 gv = acc[i][j + 1] + bias_v[j + 1];
+                    if (okr[i]) {
+                        *(f32x4*)(up + ncol[j]) = v;
+                        *(f32x4*)(up + ncol[j + 1]) = gv;
+                    }
+                    v.x *= glu_silu(gv.x); v.y *= glu_silu(gv.y); v.z *= glu_silu(gv.z); v.w *= glu_silu(gv.w);
+                    if (okr[i]) *(f32x4*)(a.out + oo[i] + ncol[j]) = v;
+                }
+            } else if constexpr (GLU == 4) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    f32x4 v = acc[i][j] + bias_v[j];
+                    f32x4 gv, pv;
+                    if (i == 0) { pv = auxv[2 * j]; gv = auxv[2 * j + 1]; }
+                    else { pv = ldg4(a.aux + oo[i] + ncol[j]); gv = ldg4(a.aux + oo[i] + a.N + ncol[j]); }
+                    f32x4 dg;
+                    dg.x = v.x * pv.x * glu_silu_grad(gv.x); dg.y = v.y * pv.y * glu_silu_grad(gv.y);
+                    dg.z = v.z * pv.z * glu_silu_grad(gv.z); dg.w = v.w * pv.w * glu_silu_grad(gv.w);
+                    v.x *= glu_silu(gv.x); v.y *= glu_silu(gv.y); v.z *= glu_silu(gv.z); v.w *= glu_silu(gv.w);
+                    if (okr[i]) {
+                        *(f32x4*)(a.out + oo[i] + a.N + ncol[j]) = dg;
+                        *(f32x4*)(a.out + oo[i] + ncol[j]) = v;
+                    }
+                }
+            } else if constexpr (GLU == 1) {
+                f32x4 v = acc[i][0] + bias_v[0];
                 if (a.aux_mode == 2) {
                     const f32x4 u = auxv[i];
                     v.x *= apply_act_grad1(u.x, a.act); v.y *= apply_act_grad1(u.y, a.act);
                     v.z *= apply_act_grad1(u.z, a.act); v.w *= apply_act_grad1(u.w, a.act);
                 } else {
-                    if (a.aux_mode == 1 && okr[i]) *(f32x4*)(const_cast<float*>(a.aux) + oo[i] + ncol) = v;
+                    if (a.aux_mode == 1 && okr[i]) *(f32x4*)(const_cast<float*>(a.aux) + oo[i] + ncol[0]) = v;
                     v = apply_act(v, a.act);
                 }
+                if (okr[i]) *(f32x4*)(a.out + oo[i] + ncol[0]) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    if (okr[i]) *(f32x4*)(a.out + oo[i] + ncol[j]) = acc[i][j] + bias_v[j];
             }
-            if (okr[i]) *(f32x4*)(a.out + oo[i] + ncol) = v;
         }
         ws_tile_barrier();                                 // tile t + 1 is in LDS; everybody is done reading tile t
     }

@@ -359,16 +359,32 @@ def test_swiglu_on_the_gemm_epilogues(M, K, H):
         assert_close(got.grad.cpu(), want.grad, rtol=2e-3, atol=2e-3 * sc, what=name)
     if M >= 8192:
         # from 8192 rows on the K = 192 SwishGLU products run on the weight-stationary body (mdt_ws.h; the last 32-row tile here is
-        # ragged): same MFMA form and K order as the 32-row tiles, so the geometry hook that forces those must give the same bits
+        # ragged).  Its fp32 MFMA form has the MFMA form and K order of the 32-row tiles: the geometry hook that forces those must
+        # give the same bits.  Its default form splits every operand into three bf16 parts (six bf16 MFMA products per k32 step,
+        # round 6): fp32 accuracy, other bits -- held to a few fp32 roundings of the fp32 form.
         from mdt_policy_amd import _lib
         lib = _lib.load()
-        x2, w02, b02, w12, b12 = (t.detach().clone().requires_grad_() for t in (x, w0, b0, w1, b1))
-        lib.mdt_op_set_gemm_geometry(9)
-        try:
-            y2 = ops.HipSwiGLUMLP.apply(x2, w02, b02, w12, b12, ops.PackedWeights())
-            (y2 * wy.cuda()).sum().backward()
-            torch.cuda.synchronize()
-        finally:
-            lib.mdt_op_set_gemm_geometry(0)
-        assert torch.equal(y2, y), "weight-stationary SwishGLU forward differs from the 32-row tiles"
-        assert torch.equal(x2.grad, x.grad), "weight-stationary SwishGLU backward (dx) differs from the 32-row tiles"
+
+        def run(geometry, split):
+            t = [v.detach().clone().requires_grad_() for v in (x, w0, b0, w1, b1)]
+            lib.mdt_op_set_gemm_geometry(geometry)
+            lib.mdt_op_set_ws_split(split)
+            try:
+                yy = ops.HipSwiGLUMLP.apply(*t, ops.PackedWeights())
+                (yy * wy.cuda()).sum().backward()
+                torch.cuda.synchronize()
+            finally:
+                lib.mdt_op_set_gemm_geometry(0)
+                lib.mdt_op_set_ws_split(-1)
+            return yy.detach(), t[0].grad
+        y_ws, dx_ws = run(0, 0)
+        y_rt, dx_rt = run(9, 0)
+        assert torch.equal(y_rt, y_ws), "weight-stationary SwishGLU forward differs from the 32-row tiles"
+        assert torch.equal(dx_rt, dx_ws), "weight-stationary SwishGLU backward (dx) differs from the 32-row tiles"
+        y_sp, dx_sp = run(0, 1)
+        if K == 192:   # (other K: the products are not on the weight-stationary body at all)
+            assert not torch.equal(y_sp, y_ws) and not torch.equal(dx_sp, dx_ws), "the bf16 split form did not run"
+        assert torch.equal(y_sp, y.detach()) and torch.equal(dx_sp, x.grad), "the split form is not the default"
+        for name, got, want in (("y", y_sp, y_ws), ("dx", dx_sp, dx_ws)):
+            err, sc = float((got - want).abs().max()), float(want.abs().max())
+            assert err <= 1e-5 * sc, f"{name}: split against fp32 products {err:.3g} at max {sc:.3g}"
