@@ -155,8 +155,9 @@ void mdt_op_set_mlp_skew(int32_t v);
  * 10 / 12 / 16 = the TALL body (128-row tiles, both operands staged in LDS by LDS-DMA; plain prologue, K % 32 == 0;
  * anything else falls back to the heuristic): 4 waves 128x128 / 128x64 / 128x96; 23 = 128x64 with a loader wave, 3 stages;
  * -1 = the split-K small-M kernel wherever it applies.
- * Row-tile and tall geometries compute bit-identical results (same k order per output element); the small-M kernel agrees
- * to rounding.  MDT_HIP_SMALLM_MAX / MDT_HIP_SMALLM_TILES / MDT_HIP_SMALLM_ROWS / MDT_HIP_MID_MAX (environment) move the
+ * 30 = the weight-stationary body wherever it is supported, whatever the row count.
+ * Row-tile, tall and (fp32 form, mdt_op_set_ws_split(0)) weight-stationary geometries compute bit-identical results (same k order
+ * per output element); the small-M kernel and the weight-stationary body's bf16 split form (the default) agree to fp32 rounding.  MDT_HIP_SMALLM_MAX / MDT_HIP_SMALLM_TILES / MDT_HIP_SMALLM_ROWS / MDT_HIP_MID_MAX (environment) move the
  * thresholds. */
 void mdt_op_set_gemm_geometry(int32_t geometry);
 
