@@ -532,6 +532,19 @@ static int ws_shape(const mdt_gemm_args& a) {
     if (w12 && a.N % 384 == 0 && a.aux_mode != 4) return 12;
     return a.N % 256 == 0 ? 8 : 0;
 }
+// the three-way bf16 split of the weight-stationary body (mdt_ws.h): K = 384, 128-column panels (8 waves, one column tile each)
+static int g_ws_split = -1;
+static bool ws_split_on() {
+    if (g_ws_split < 0) { const char* e = getenv("MDT_HIP_WS_SPLIT"); g_ws_split = e ? atoi(e) : 1; }
+    return g_ws_split != 0;
+}
+extern "C" void mdt_op_set_ws_split(int32_t on) { g_ws_split = on < 0 ? -1 : (on != 0); }
+// split form only: plain K = 192 products whose N is a multiple of 192 but not of 256 (the masked-image head's qkv and output
+// projections, N = 576 / 192) -- twelve waves (three per SIMD) x one column tile.  (Their fp32 form was measured and dropped, above: no gain over the
+// tall body; the split form is 1.4x.)
+static bool ws_split_192(const mdt_gemm_args& a) {
+    return ws_split_on() && a.K == 192 && a.N % 192 == 0 && a.N % 256 != 0 && a.N / 192 <= 32 && a.aux_mode == 0 && a.act == MDT_ACT_NONE;
+}
 bool mdt_gemm_ws_supported(const mdt_gemm_args& a) {
     static int k384 = -1;  // MDT_HIP_WS384=0: the K = 384 products stay on the row tiles / the tall body (A/B runs)
     if (k384 < 0) { const char* e = getenv("MDT_HIP_WS384"); k384 = e ? atoi(e) : 1; }
@@ -540,7 +553,7 @@ bool mdt_gemm_ws_supported(const mdt_gemm_args& a) {
     if (a.K == 384)   // plain rows, or an activation / the training hooks on the epilogue (GLU = 1 instantiation)
         return k384 && common && (a.aux_mode == 0 || ((a.aux_mode == 1 || a.aux_mode == 2) && a.aux != nullptr)) && ws_shape(a) != 0;
     const bool mode_ok = a.aux_mode == 0 || ((a.aux_mode == 3 || a.aux_mode == 4) && a.aux != nullptr);
-    return common && a.K == 192 && ws_shape(a) != 0 && a.act == MDT_ACT_NONE && mode_ok;
+    return common && a.K == 192 && (ws_shape(a) != 0 || ws_split_192(a)) && a.act == MDT_ACT_NONE && mode_ok;
 }
 template <int K16, int GLU, int NW, int NTW>
 static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
@@ -559,16 +572,8 @@ static hipError_t launch_gemm_ws_t(const mdt_gemm_args& a, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_ws<K16, NTW, NW, GLU>), dim3(chunks * panels), dim3(64 * NW), lds, s, a, tiles, panels, g_zeros);
     return hipGetLastError();
 }
-// the three-way bf16 split of the weight-stationary body (mdt_ws.h): K = 384, 128-column panels (8 waves, one column tile each)
-static int g_ws_split = -1;
-static bool ws_split_on() {
-    if (g_ws_split < 0) { const char* e = getenv("MDT_HIP_WS_SPLIT"); g_ws_split = e ? atoi(e) : 1; }
-    return g_ws_split != 0;
-}
-extern "C" void mdt_op_set_ws_split(int32_t on) { g_ws_split = on < 0 ? -1 : (on != 0); }
-template <int K16, int NTW, int GLU>
+template <int K16, int NTW, int GLU, int NW = 8>
 static hipError_t launch_gemm_ws_split(const mdt_gemm_args& a, hipStream_t s) {
-    constexpr int NW = 8;
     const int panels = a.N / (NW * NTW * 16), ntiles = (a.M + 31) / 32;
     const int chunks = std::max(1, std::min(256 / panels, ntiles)), tiles = (ntiles + chunks - 1) / chunks;
     const size_t lds = (size_t)2 * 3 * 32 * (2 * K16 * 16 + 32);
@@ -593,6 +598,7 @@ static hipError_t launch_gemm_ws(const mdt_gemm_args& a, hipStream_t s) {
         if (a.aux_mode == 4) return launch_gemm_ws_split<12, 2, 4>(a, s);
         return launch_gemm_ws_split<12, 2, 0>(a, s);
     }
+    if (ws_split_192(a)) return launch_gemm_ws_split<12, 1, 0, 12>(a, s);   // N = 192 / 576 ...: 192-column panels, twelve waves x one column tile
     if (a.K == 384) {
         const bool hooks = a.aux_mode != 0 || a.act != MDT_ACT_NONE;
         if (ws_shape(a) == 12) return hooks ? launch_gemm_ws_t<24, 1, 12, 1>(a, s) : launch_gemm_ws_t<24, 0, 12, 1>(a, s);

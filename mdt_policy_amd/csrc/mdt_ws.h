@@ -256,7 +256,7 @@ template <int K16, int NTW, int NWAVES, int GLU>
 __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int panel, int chunk, int tiles, char* lds,
                                                    const float* __restrict__ zeros, int tid) {
     static_assert(K16 % 2 == 0, "a k32 step is two fragments of the fp32 image");
-    static_assert(K16 * NTW == 24, "144 registers of weights: K = 384 with one column tile per wave, or K = 192 with two");
+    static_assert(K16 * NTW == 24 || (K16 == 12 && NTW == 1 && NWAVES == 12), "144 registers of weights: K = 384 with one column tile per wave, or K = 192 with two (72 with one: twelve waves)");
     static_assert(GLU != 3 || NTW % 2 == 0, "SwishGLU forward pairs tiles");
     static_assert(GLU != 1 || NTW == 1, "the activation hooks are written for one column tile");
     constexpr int K = K16 * 16, K32 = K16 / 2, K4 = K / 4, NT = 64 * NWAVES;
@@ -282,32 +282,36 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
         bias_v[j] = ldg4(biasp + ncol[j]);
     }
 
-    // ---- A tile t: wave w stages rows 4 w .. 4 w + 3 (4 x K4 float4 items, NLD = K4 / 16 per lane): item u of lane l is element
-    //      j = l + 64 u of those rows, row j / K4, float4 column j % K4.  With K4 = 96, items u and u + 3 are the same column two rows
-    //      apart (K4 = 48 has three items), so three (global, LDS) offset pairs per lane + constants address all of them -- no index
-    //      arithmetic between the MFMAs ----
-    static_assert(NWAVES == 8 && ((K4 == 96 && NLD == 6) || (K4 == 48 && NLD == 3)), "the staging pattern is written for K = 384 / 192, 8 waves");
+    // ---- A tile t.  Eight waves: wave w stages rows 4 w .. 4 w + 3 (4 x K4 float4 items, NLD = K4 / 16 per lane): item u of lane l is
+    //      element j = l + 64 u of those rows, row j / K4, float4 column j % K4.  With K4 = 96, items u and u + 3 are the same column two
+    //      rows apart (K4 = 48 has three items), so three (global, LDS) offset pairs per lane + constants address all of them -- no
+    //      index arithmetic between the MFMAs.  Other wave counts (twelve: the 192-column panels of N = 192 / 576): item u of thread i is
+    //      element i + NT u of the tile, one offset pair per item ----
+    constexpr bool WAVE_LOCAL = NWAVES == 8;
+    static_assert(!WAVE_LOCAL || (K4 == 96 && NLD == 6) || (K4 == 48 && NLD == 3), "the wave-local staging pattern is written for K = 384 / 192");
+    static_assert(WAVE_LOCAL || 32 * K4 % NT == 0, "the tile's items divide over the threads");
+    constexpr int NP = WAVE_LOCAL ? 3 : NLD;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int goff[3], loff[3];                                  // floats from the wave's first row / bytes from the buffer
+    int goff[NP], loff[NP];                                // floats from the first row (of the wave / of the tile), bytes from the buffer
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int j = lane + 64 * u, r = j / K4, c = 4 * (j - r * K4);
+    for (int u = 0; u < NP; ++u) {
+        const int j = WAVE_LOCAL ? lane + 64 * u : tid + NT * u, r = j / K4, c = 4 * (j - r * K4);
         goff[u] = r * (int)a.lda + c;
         // the four values at columns c .. c + 3 of a row are slots (half, 0 .. 3) = ((c % 32) / 16, ..) of lane group (c % 16) / 4 in
         // k32 step c / 32: eight bytes per part at  row * ROWB + (c / 32) * 64 + ((c % 16) / 4) * 16 + ((c % 32) / 16) * 8
-        loff[u] = (4 * wave_u + r) * ROWB + (c >> 5) * 64 + ((c & 15) >> 2) * 16 + ((c & 31) >> 4) * 8;
+        loff[u] = ((WAVE_LOCAL ? 4 * wave_u : 0) + r) * ROWB + (c >> 5) * 64 + ((c & 15) >> 2) * 16 + ((c & 31) >> 4) * 8;
     }
     f32x4 stage[NLD];
     auto request = [&](int t) __attribute__((always_inline)) {
-        const int r0 = 32 * t + 4 * wave_u;                // wave-uniform
-        if (r0 + 4 <= a.M) {
+        const int r0 = 32 * t + (WAVE_LOCAL ? 4 * wave_u : 0), rows = WAVE_LOCAL ? 4 : 32;   // wave-uniform
+        if (r0 + rows <= a.M) {
             const float* pt = a.A + (int64_t)r0 * a.lda;
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) stage[u] = ldg4(pt + (u / 3) * 2 * a.lda + goff[u % 3]);
+            for (int u = 0; u < NLD; ++u) stage[u] = WAVE_LOCAL ? ldg4(pt + (u / 3) * 2 * a.lda + goff[u % 3]) : ldg4(pt + goff[u % NP]);
         } else {                                           // the ragged end: rows past M re-read the last row (never stored)
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
-                const int j = lane + 64 * u, r = j / K4, c = 4 * (j - r * K4);
+                const int j = WAVE_LOCAL ? lane + 64 * u : tid + NT * u, r = j / K4, c = 4 * (j - r * K4);
                 stage[u] = ldg4(a.A + (int64_t)min(r0 + r, a.M - 1) * a.lda + c);
             }
         }
@@ -315,7 +319,7 @@ __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int p
     auto commit = [&](char* buf, int u) __attribute__((always_inline)) {
         mdt_bf16x4 p1, p2, p3;
         split3_bf16(stage[u], p1, p2, p3);
-        char* q = buf + loff[u % 3] + (u / 3) * 2 * ROWB;
+        char* q = WAVE_LOCAL ? buf + loff[u % 3] + (u / 3) * 2 * ROWB : buf + loff[u % NP];
         *(mdt_bf16x4*)q = p1;
         *(mdt_bf16x4*)(q + PART) = p2;
         *(mdt_bf16x4*)(q + 2 * PART) = p3;

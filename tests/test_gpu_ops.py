@@ -224,7 +224,8 @@ def test_gemm_weight_stationary_body_at_k384_with_the_training_hooks(lib, M, N):
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 384, 384), (8192 + 77, 1152, 384), (12288, 1536, 384), (33, 384, 384),
-                                   (8192 + 45, 1536, 192), (70, 768, 192), (20000, 256, 192)])
+                                   (8192 + 45, 1536, 192), (70, 768, 192), (20000, 256, 192), (9000, 576, 192), (8192 + 45, 192, 192),
+                                   (70, 192, 192)])
 def test_gemm_weight_stationary_body_split_three_ways_into_bf16_keeps_fp32_accuracy(lib, M, N, K):
     """Round 6: the K = 384 / K = 192 weight-stationary body with every operand as three bf16 parts and six bf16 MFMA products per k32 step
     (mdt_ws.h gemm_ws_split_tile).  Not the fp32 bodies' bits -- so: against float64, the split form's error must stay within
