@@ -106,6 +106,15 @@ mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);
  * parts (S * part_stride floats, part_stride >= M * D) not aliasing x -- except S == 1, where parts may be x itself. */
 mdt_status mdt_op_mlp(const mdt_gemm_args *fc, const mdt_gemm_args *proj, float *parts, int64_t part_stride,
                       int32_t *n_parts, void *stream);
+/* The same launch with every contraction as a THREE-WAY bf16 SPLIT (round 6): each fp32 operand as three bf16 parts, six
+ * v_mfma_f32_16x16x32_bf16 products per 32-deep step, fp32 accumulation -- fp32's product accuracy (not the bits of mdt_op_mlp) at a
+ * third of its matrix-pipe time.  fc_split / proj_split: images of the two weights made by mdt_op_pack_weight_split ((4 D, D) and
+ * (D, 4 D) row-major sources; 6 bytes per weight); fc->Wp / proj->Wp are not read.  D <= 384.  The model-level entry points use it
+ * from the row count of mdt_op_set_mlp_fuse_min on unless mdt_op_set_mlp_split(0) / MDT_HIP_MLP_SPLIT=0 (negative: default). */
+mdt_status mdt_op_pack_weight_split(const float *w, int64_t n_rows, int64_t K, void *image, void *stream);
+mdt_status mdt_op_mlp_split(const mdt_gemm_args *fc, const mdt_gemm_args *proj, const void *fc_split, const void *proj_split,
+                            float *parts, int64_t part_stride, int32_t *n_parts, void *stream);
+void mdt_op_set_mlp_split(int32_t on);
 /* Tuning / test hook: the model-level entry points run the MLP sublayer through mdt_op_mlp from `rows` rows (B * horizon)
  * on; 0 = never (the two-GEMM sequence), -1 = default (1401, or MDT_HIP_MLP_FUSE_MIN from the environment). */
 void mdt_op_set_mlp_fuse_min(int32_t rows);

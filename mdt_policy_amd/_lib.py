@@ -185,6 +185,9 @@ SYMBOLS = [
     ("mdt_op_pack_weight_glu", _I32, [_VP, _I64, _I64, _VP, _VP]),
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
     ("mdt_op_mlp", _I32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _VP, _I64, C.POINTER(_I32), _VP]),
+    ("mdt_op_pack_weight_split", _I32, [_VP, _I64, _I64, _VP, _VP]),
+    ("mdt_op_mlp_split", _I32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _VP, _VP, _VP, _I64, C.POINTER(_I32), _VP]),
+    ("mdt_op_set_mlp_split", None, [_I32]),
     ("mdt_op_set_gemm_geometry", None, [_I32]),
     ("mdt_op_set_mlp_fuse_min", None, [_I32]),
     ("mdt_op_set_side_jobs", None, [_I32]),

@@ -38,6 +38,7 @@ struct Lin {
     float* bias = nullptr;  // (N) or nullptr
     int N = 0, K = 0;
     float* wt = nullptr;    // training only: fragment-packed image of W^T (N' = K, K' = N), for dX = dY W
+    void* ws = nullptr;     // the MLP's two Linears: three-way bf16 split fragment image (6 N K bytes; mdt_mlp_split.h)
 };
 
 // bump allocator over one hipMalloc'ed block (count pass with base == nullptr, then the real pass)
@@ -73,6 +74,13 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s);
 bool mdt_mlp_supported(const mdt_gemm_args& fc, const mdt_gemm_args& proj);
 int mdt_mlp_slices(int D);
 hipError_t mdt_launch_mlp(const mdt_gemm_args& fc, const mdt_gemm_args& proj, float* parts, int64_t part_stride, hipStream_t s);
+// the same launch in the three-way bf16 split form (mdt_mlp_split.h): w1s / w2s = split images of fc / proj (mdt_launch_pack_weight_split)
+bool mdt_mlp_split_supported(const mdt_gemm_args& fc, const mdt_gemm_args& proj);
+bool mdt_mlp_split_enabled();
+hipError_t mdt_launch_mlp_split(const mdt_gemm_args& fc, const mdt_gemm_args& proj, const void* w1s, const void* w2s, float* parts,
+                                int64_t part_stride, hipStream_t s);
+// (n_rows, K) row-major fp32 -> split image of 6 n_rows K bytes (n_rows % 16 == 0, K % 32 == 0)
+hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void* image, hipStream_t s);
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin, hipStream_t s);
 // one sample's self-attention fused into its output projection p (rollout batch 1); see mdt_kernels.hip
 bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope);
@@ -115,7 +123,8 @@ hipError_t mdt_launch_loss_reduce(const float* F, const float* act, const float*
 hipError_t mdt_launch_pack_weight(const float* w, int n_rows, int K, float* packed, int n_off, hipStream_t s);
 hipError_t mdt_launch_pack_weight_glu(const float* w, int H, int K, float* packed, hipStream_t s);
 // one move of a batched parameter upload (k_multi_load): src is (rows, K) row-major on the device
-enum { MDT_LOAD_RAW = 0, MDT_LOAD_PACK = 1, MDT_LOAD_PACK_T = 2, MDT_LOAD_TRANSPOSE = 3, MDT_LOAD_PAD_COLS = 4 };
+enum { MDT_LOAD_RAW = 0, MDT_LOAD_PACK = 1, MDT_LOAD_PACK_T = 2, MDT_LOAD_TRANSPOSE = 3, MDT_LOAD_PAD_COLS = 4,
+       MDT_LOAD_PACK_SPLIT = 5 };  // PACK_SPLIT: the three-way bf16 split fragment image (mdt_mlp_split.h); dst is a byte image of 6 rows K bytes
 struct mdt_load_entry {
     const float* src;
     float* dst;

@@ -33,6 +33,7 @@
 #include "mdt_tiles.h"  // the tile bodies
 #include "mdt_tall.h"  // the tall LDS-staged GEMM body (round 4)
 #include "mdt_ws.h"    // the weight-stationary GEMM body (round 5)
+#include "mdt_mlp_split.h"  // the fused MLP launch in the three-way bf16 split form (round 6)
 
 // ------------------------------------------------------------------------------------------------
 // weight packing
@@ -63,6 +64,30 @@ hipError_t mdt_launch_pack_weight_glu(const float* w, int H, int K, float* packe
     return hipGetLastError();
 }
 
+// three-way bf16 split fragment image (mdt_mlp_split.h): thread = 4 consecutive k of one row -> eight bytes in each of the three
+// parts of fragment (row tile r / 16, k32 step c / 32): lane (r % 16) + 16 ((c % 16) / 4), half (c % 32) / 16
+__device__ __forceinline__ void pack_split_quad(const float* __restrict__ src, char* __restrict__ image, int r, int c, int K) {
+    mdt_bf16x4 p1, p2, p3;
+    split3_bf16(*(const f32x4*)(src + (int64_t)r * K + c), p1, p2, p3);
+    char* q = image + (((int64_t)(r >> 4) * (K >> 5) + (c >> 5)) * 3) * 1024 + ((r & 15) + 16 * ((c & 15) >> 2)) * 16 + ((c & 31) >> 4) * 8;
+    *(mdt_bf16x4*)q = p1;
+    *(mdt_bf16x4*)(q + 1024) = p2;
+    *(mdt_bf16x4*)(q + 2048) = p3;
+}
+__global__ void k_pack_weight_split(const float* __restrict__ w, int n_rows, int K, char* __restrict__ image) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K4 = K >> 2;
+    if (idx >= (int64_t)n_rows * K4) return;
+    const int r = (int)(idx / K4), c = 4 * (int)(idx - (int64_t)r * K4);
+    pack_split_quad(w, image, r, c, K);
+}
+hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void* image, hipStream_t s) {
+    if (n_rows % 16 || K % 32) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)n_rows * (K >> 2);
+    hipLaunchKernelGGL(k_pack_weight_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n_rows, K, (char*)image);
+    return hipGetLastError();
+}
+
 // Every parameter image of one load_state_dict / optimizer step in ONE launch (mdt_load_params): a table of moves --
 // raw copies, fragment packs, transposed fragment packs (training), transposes, column pads -- and a (move, chunk) list,
 // one workgroup per 1024 source elements.  The per-parameter launches this replaces (~230 of 3-6 us for MDT-V) were
@@ -88,6 +113,13 @@ __global__ __launch_bounds__(256) void k_multi_load(const mdt_load_entry* __rest
             const int k = e.p0 + 4 * r4;
             const int nt = c >> 4, ni = c & 15, kc = k >> 4, h = (k & 15) >> 2;
             *(f32x4*)(e.dst + (((int64_t)nt * e.p1 + kc) * 64 + (ni + 16 * h)) * 4) = v;
+            continue;
+        }
+        if (e.kind == MDT_LOAD_PACK_SPLIT) {
+            const int K4 = e.K >> 2;
+            if (idx >= (int64_t)e.rows * K4) continue;
+            const int r = (int)(idx / K4), c = 4 * (int)(idx - (int64_t)r * K4);
+            pack_split_quad(e.src, (char*)e.dst, r, c, e.K);
             continue;
         }
         if (e.kind == MDT_LOAD_PACK) {
@@ -170,6 +202,21 @@ __global__ __launch_bounds__(512) void k_mlp(mdt_gemm_args f, mdt_gemm_args p, f
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int by = logical / n_slices, s = logical - by * n_slices;
     mlp_tile<NTW2, PRO>(f, p, parts, part_stride, by, s, lds, zeros, threadIdx.x, skew);
+}
+
+// k_mlp_split: the same launch in the three-way bf16 split form (mdt_mlp_split.h).  Workgroups in SLICE-major order, XCD x taking a
+// contiguous range of it (block b runs on XCD b % 8): an XCD's L2 then holds one or two slices of the split weight images (2.4 MB
+// each at d = 384) instead of all of them.  grid = 8 * ceil(tiles * slices / 8).
+template <int NTW2, int PRO>
+__global__ __launch_bounds__(512) void k_mlp_split(mdt_gemm_args f, mdt_gemm_args p, const char* __restrict__ w1s, const char* __restrict__ w2s,
+                                                   float* __restrict__ parts, int64_t part_stride, int n_slices, int gm,
+                                                   const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) char lds_c[];
+    const int total = gm * n_slices, per = (total + 7) >> 3;
+    const int i = blockIdx.x >> 3, w = (blockIdx.x & 7) * per + i;
+    if (i >= per || w >= total) return;
+    const int s = w / gm, by = w - s * gm;
+    mlp_split_tile<NTW2, PRO>(f, p, w1s, w2s, parts, part_stride, by, s, lds_c, zeros, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1096,6 +1143,53 @@ hipError_t mdt_launch_mlp(const mdt_gemm_args& f, const mdt_gemm_args& p, float*
         case 2: return launch_mlp_pro<2>(f, p, parts, part_stride, s);
         case 3: return launch_mlp_pro<3>(f, p, parts, part_stride, s);
         default: return launch_mlp_pro<4>(f, p, parts, part_stride, s);
+    }
+}
+
+// ---- the fused MLP sublayer in the three-way bf16 split form (k_mlp_split) ----
+static int g_mlp_split = -1;   // MDT_HIP_MLP_SPLIT / mdt_op_set_mlp_split: 0 = the fp32 launch everywhere
+bool mdt_mlp_split_enabled() {
+    if (g_mlp_split < 0) { const char* e = getenv("MDT_HIP_MLP_SPLIT"); g_mlp_split = e ? atoi(e) : 1; }
+    return g_mlp_split != 0;
+}
+extern "C" void mdt_op_set_mlp_split(int32_t on) { g_mlp_split = on < 0 ? -1 : (on != 0); }
+bool mdt_mlp_split_supported(const mdt_gemm_args& f, const mdt_gemm_args& p) {
+    return mdt_mlp_supported(f, p) && f.K <= 384;   // D = 512: the split x tile + its staging do not fit LDS
+}
+template <int NTW2, int PRO>
+static hipError_t launch_mlp_split_t(const mdt_gemm_args& f, const mdt_gemm_args& p, const void* w1s, const void* w2s, float* parts,
+                                     int64_t part_stride, hipStream_t s) {
+    const int S = mdt_mlp_slices(f.K), gm = (f.M + 31) / 32;
+    const int lds = mlp_split_lds_bytes(128 * NTW2);
+    static bool attr_dev[MAX_DEVICES] = {false};
+    bool& done = attr_dev[current_device()];
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_split<NTW2, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    const int per = (gm * S + 7) / 8;
+    hipLaunchKernelGGL((k_mlp_split<NTW2, PRO>), dim3(8 * per), dim3(512), lds, s, f, p, (const char*)w1s, (const char*)w2s, parts,
+                       part_stride, S, gm, g_zeros);
+    return hipGetLastError();
+}
+template <int NTW2>
+static hipError_t launch_mlp_split_pro(const mdt_gemm_args& f, const mdt_gemm_args& p, const void* w1s, const void* w2s, float* parts,
+                                       int64_t part_stride, hipStream_t s) {
+    if (f.mod != nullptr && f.shift_off >= 0)
+        return f.mod_stride == 0 ? launch_mlp_split_t<NTW2, PRO_LN_MOD_BCAST>(f, p, w1s, w2s, parts, part_stride, s)
+                                 : launch_mlp_split_t<NTW2, PRO_LN_MOD_ROWS>(f, p, w1s, w2s, parts, part_stride, s);
+    return launch_mlp_split_t<NTW2, PRO_LN>(f, p, w1s, w2s, parts, part_stride, s);
+}
+hipError_t mdt_launch_mlp_split(const mdt_gemm_args& f, const mdt_gemm_args& p, const void* w1s, const void* w2s, float* parts,
+                                int64_t part_stride, hipStream_t s) {
+    if (!mdt_mlp_split_supported(f, p) || !w1s || !w2s) return hipErrorInvalidValue;
+    hipError_t ze = ensure_zeros();
+    if (ze != hipSuccess) return ze;
+    switch (f.K / 128) {
+        case 1: return launch_mlp_split_pro<1>(f, p, w1s, w2s, parts, part_stride, s);
+        case 2: return launch_mlp_split_pro<2>(f, p, w1s, w2s, parts, part_stride, s);
+        default: return launch_mlp_split_pro<3>(f, p, w1s, w2s, parts, part_stride, s);
     }
 }
 

@@ -221,6 +221,12 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         lin_part(e.fc, pre + ".mlp.c_fc", 4 * D, 0, xb);
         lin_begin(e.proj2, D, 4 * D, xb);
         lin_part(e.proj2, pre + ".mlp.c_proj", D, 0, xb);
+        if (D % 128 == 0 && D <= 384) {   // the fused MLP launch's split form (mdt_mlp_split.h): 6 bytes per weight
+            e.fc.ws = b.take((size_t)4 * D * D * 6 / 4);
+            e.proj2.ws = b.take((size_t)4 * D * D * 6 / 4);
+            add_extra(pre + ".mlp.c_fc.weight", (int64_t)4 * D * D, SLOT_PACK_SPLIT, (float*)e.fc.ws, 4 * D, D);
+            add_extra(pre + ".mlp.c_proj.weight", (int64_t)4 * D * D, SLOT_PACK_SPLIT, (float*)e.proj2.ws, D, 4 * D);
+        }
     };
     if (!fill_slots) { m->enc.assign(m->Le, EncBlock()); m->dec.assign(m->Ld, DecBlock()); }
     for (int l = 0; l < m->Le; ++l) {
@@ -469,6 +475,7 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
                 dev_src = m->staging;
             }
         }
+        if (t->kind == SLOT_PACK_SPLIT) { HIP_TRY(mdt_launch_pack_weight_split(dev_src, t->rows, t->K, t->dst, s)); continue; }
         if (t->kind == SLOT_TRANSPOSE) HIP_TRY(mdt_launch_transpose(dev_src, t->dst, t->rows, t->K, s));
         else if (t->kind == SLOT_PACK_T) HIP_TRY(mdt_launch_pack_weight_t(dev_src, t->rows, t->K, t->K, t->dst, 0, t->rows / 16, s));  // image of the transpose
         else HIP_TRY(mdt_launch_pack_weight(dev_src, t->rows, t->K, t->dst, t->n_off, s));
@@ -494,7 +501,7 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
         memset(&e, 0, sizeof e);
         e.src = src; e.dst = dst; e.kind = kind; e.rows = rows; e.K = K; e.p0 = p0; e.p1 = p1;
         const int64_t work = kind == MDT_LOAD_PACK_T ? (int64_t)((rows + 3) / 4) * K
-                             : kind == MDT_LOAD_PACK ? (int64_t)rows * (K / 4) : (int64_t)rows * K;
+                             : (kind == MDT_LOAD_PACK || kind == MDT_LOAD_PACK_SPLIT) ? (int64_t)rows * (K / 4) : (int64_t)rows * K;
         for (int64_t c = 0; c * 1024 < work; ++c) blocks.push_back(make_int2((int)tab.size(), (int)c));
         tab.push_back(e);
     };
@@ -529,6 +536,7 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
             else if (t->kind == SLOT_PAD_COLS) add(srcs[i], t->dst, MDT_LOAD_PAD_COLS, t->rows, t->K, t->n_off, 0);
             else if (t->kind == SLOT_TRANSPOSE) add(srcs[i], t->dst, MDT_LOAD_TRANSPOSE, t->rows, t->K, 0, 0);
             else if (t->kind == SLOT_PACK_T) add(srcs[i], t->dst, MDT_LOAD_PACK_T, t->rows, t->K, 0, t->rows / 16);
+            else if (t->kind == SLOT_PACK_SPLIT) add(srcs[i], t->dst, MDT_LOAD_PACK_SPLIT, t->rows, t->K, 0, 0);
             else {
                 add(srcs[i], t->dst, MDT_LOAD_PACK, t->rows, t->K, t->n_off, 0);
                 if (t->lin && t->lin->wt) add(srcs[i], t->lin->wt, MDT_LOAD_PACK_T, t->rows, t->K, t->n_off, t->lin->N / 16);
@@ -837,16 +845,22 @@ static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_
         // the hidden buffer (M x 4D) is free in this form: it holds the S <= 4 slabs of (M x D)
         p.ldo = D;
         const int64_t stride = (int64_t)M * D;
+        // the three-way bf16 split form of the launch (mdt_mlp_split.h) wherever its images exist and it is not switched off
+        const bool split = e.fc.ws && e.proj2.ws && mdt_mlp_split_enabled() && mdt_mlp_split_supported(g, p);
         if (g_trace_mlp) {  // measurement hook (mdt_op_trace_mlp): this launch between its own pair of HIP events, inside the chain
             TraceEv ev;
             HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1)); HIP_TRY(hipEventCreate(&ev.e2));
             HIP_TRY(hipEventRecord(ev.e0, s));
-            LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
+            if (split) LAUNCH(mdt_launch_mlp_split(g, p, e.fc.ws, e.proj2.ws, V.hid, stride, s));
+            else LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
             HIP_TRY(hipEventRecord(ev.e1, s));
             HIP_TRY(hipEventRecord(ev.e2, s));
             g_trace_mlp_events.push_back(ev);
-        } else
-        LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
+        } else if (split) {
+            LAUNCH(mdt_launch_mlp_split(g, p, e.fc.ws, e.proj2.ws, V.hid, stride, s));
+        } else {
+            LAUNCH(mdt_launch_mlp(g, p, V.hid, stride, s));
+        }
         out->base = V.hid; out->parts = mdt_mlp_slices(D); out->stride = stride;
         return MDT_OK;
     }
@@ -1359,6 +1373,32 @@ extern "C" mdt_status mdt_op_mlp(const mdt_gemm_args* fc, const mdt_gemm_args* p
         misaligned(proj->bias) || misaligned(fc->mod) || misaligned(proj->mod) || (part_stride & 3))
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp: pointers must be 16-byte aligned");
     LAUNCH(mdt_launch_mlp(*fc, *proj, parts, part_stride, (hipStream_t)stream));
+    if (n_parts) *n_parts = mdt_mlp_slices(fc->K);
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_pack_weight_split(const float* w, int64_t n_rows, int64_t K, void* image, void* stream) {
+    if (!w || !image) return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split: null pointer");
+    if (n_rows < 16 || n_rows % 16 || K < 32 || K % 32 || n_rows * K >= ((int64_t)1 << 30))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split: n_rows a multiple of 16, K a multiple of 32");
+    if (misaligned(w) || misaligned(image)) return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split: pointers must be 16-byte aligned");
+    LAUNCH(mdt_launch_pack_weight_split(w, (int)n_rows, (int)K, image, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_mlp_split(const mdt_gemm_args* fc, const mdt_gemm_args* proj, const void* fc_split, const void* proj_split,
+                                       float* parts, int64_t part_stride, int32_t* n_parts, void* stream) {
+    if (!fc || !proj || !fc->A || !fc_split || !proj_split || !parts || !fc->ln_w)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp_split: null pointer");
+    if (!mdt_mlp_split_supported(*fc, *proj))
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_mlp_split: needs D = fc.K a multiple of 128 (<= 384), fc.N = proj.K = 4 D, proj.N = D, "
+                                         "a LayerNorm prologue and plain output rows");
+    if (fc->lda % 4 || proj->ldo % 4 || proj->ldo < proj->N || part_stride < (int64_t)fc->M * proj->ldo)
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp_split: lda / ldo multiples of 4, part_stride >= M * ldo required");
+    if (misaligned(fc->A) || misaligned(fc_split) || misaligned(proj_split) || misaligned(parts) || misaligned(fc->bias) ||
+        misaligned(proj->bias) || misaligned(fc->mod) || misaligned(proj->mod) || (part_stride & 3))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp_split: pointers must be 16-byte aligned");
+    LAUNCH(mdt_launch_mlp_split(*fc, *proj, fc_split, proj_split, parts, part_stride, (hipStream_t)stream));
     if (n_parts) *n_parts = mdt_mlp_slices(fc->K);
     return MDT_OK;
 }

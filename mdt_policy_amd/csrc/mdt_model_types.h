@@ -10,7 +10,8 @@
 // model description
 // ------------------------------------------------------------------------------------------------
 // TRANSPOSE: (rows, K) -> (K, rows);  PAD_COLS: (rows, K) -> (rows, n_off) row-major, columns K.. stay zero
-enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2, SLOT_PAD_COLS = 3, SLOT_PACK_T = 4 };  // PACK_T: fragment image of the TRANSPOSE of a (rows, K) matrix
+enum SlotKind { SLOT_PACK = 0, SLOT_RAW = 1, SLOT_TRANSPOSE = 2, SLOT_PAD_COLS = 3, SLOT_PACK_T = 4,  // PACK_T: fragment image of the TRANSPOSE of a (rows, K) matrix
+                SLOT_PACK_SPLIT = 5 };  // three-way bf16 split fragment image of a (rows, K) matrix (mdt_mlp_split.h): 6 rows K bytes at dst
 
 struct Slot {
     std::string name;

@@ -879,8 +879,18 @@ def _gemm_args(lib, keep, A, lda, Wp, N, K, M, out=None, ldo=0, bias=None):
     return a
 
 
-def run_mlp(lib, x, W1, W2, ln_w, ln_b=None, b1=None, b2=None, mod=None, mod_stride=0, offs=None, rps=1):
-    """-> (slabs (S, M, D) on the host, S).  offs = (shift, scale, gate) offsets inside a mod row or None."""
+def pack_split(lib, W):
+    """Three-way bf16 split fragment image of a (N, K) weight through the library (6 N K bytes)."""
+    N, K = W.shape
+    Wd = dev(W)
+    P = torch.zeros(N * K * 6, dtype=torch.uint8, device="cuda")
+    lib.check(lib.load().mdt_op_pack_weight_split(Wd.data_ptr(), N, K, P.data_ptr(), stream()))
+    return P
+
+
+def run_mlp(lib, x, W1, W2, ln_w, ln_b=None, b1=None, b2=None, mod=None, mod_stride=0, offs=None, rps=1, split=False):
+    """-> (slabs (S, M, D) on the host, S).  offs = (shift, scale, gate) offsets inside a mod row or None.
+    split: the launch in its three-way bf16 split form (mdt_op_mlp_split)."""
     M, D = x.shape
     keep = []
     xd, P1, P2 = dev(x), pack(lib, W1), pack(lib, W2)
@@ -900,7 +910,12 @@ def run_mlp(lib, x, W1, W2, ln_w, ln_b=None, b1=None, b2=None, mod=None, mod_str
         f.shift_off, f.scale_off, p.gate_off = offs
         f.rows_per_sample = p.rows_per_sample = rps
     n = C.c_int32(0)
-    lib.check(lib.load().mdt_op_mlp(C.byref(f), C.byref(p), parts.data_ptr(), M * D, C.byref(n), stream()))
+    if split:
+        S1, S2 = pack_split(lib, W1), pack_split(lib, W2)
+        lib.check(lib.load().mdt_op_mlp_split(C.byref(f), C.byref(p), S1.data_ptr(), S2.data_ptr(), parts.data_ptr(), M * D, C.byref(n),
+                                              stream()))
+    else:
+        lib.check(lib.load().mdt_op_mlp(C.byref(f), C.byref(p), parts.data_ptr(), M * D, C.byref(n), stream()))
     torch.cuda.synchronize()
     assert n.value == S
     return parts, S
@@ -943,6 +958,73 @@ def test_fused_mlp_slabs_sum_to_the_sublayer(lib, M, D, case):
         got += parts[s]
     want = ref_mlp(x, W1, W2, lw, lb, b1, b2, **ref).float()
     assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4, what=f"fused mlp {M}x{D} {case}")
+
+
+def expected_pack_split(W):
+    """The split image as mdt_mlp_split.h documents it: fragment (nt, kk, part) = 1 KiB at ((nt K/32 + kk) 3 + part) 1024, lane l's
+    eight bf16 = part of W[16 nt + l % 16][32 kk + 16 h + 4 (l / 16) + e] at slot 4 h + e; parts by round-to-nearest bf16 of the
+    running remainder."""
+    N, K = W.shape
+    x = W.clone()
+    parts = []
+    for _ in range(3):
+        b = x.to(torch.bfloat16)
+        parts.append(b)
+        x = x - b.float()
+    out = torch.zeros(N // 16, K // 32, 3, 64, 8, dtype=torch.bfloat16)
+    for pi, P in enumerate(parts):
+        t = P.reshape(N // 16, 16, K // 32, 2, 4, 4)           # nt, ni, kk, h, g, e
+        out[:, :, pi] = t.permute(0, 2, 4, 1, 3, 5).reshape(N // 16, K // 32, 64, 8)   # lane = ni + 16 g, slot = 4 h + e
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("N,K", [(1536, 384), (384, 1536), (16, 32)])
+def test_pack_weight_split_layout_and_exactness(lib, N, K):
+    """mdt_op_pack_weight_split: the documented fragment layout, bit for bit; and the three parts add up to the weight EXACTLY
+    (each part is the bf16 rounding of what the ones before it left)."""
+    g = torch.Generator().manual_seed(N + K)
+    W = torch.randn(N, K, generator=g) * torch.exp(3.0 * torch.randn(N, 1, generator=g))
+    got = pack_split(lib, W).cpu().view(torch.bfloat16)
+    want = expected_pack_split(W)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), "split image differs from the documented layout"
+    im = got.reshape(N // 16, K // 32, 3, 64, 8).double().sum(dim=2)          # nt, kk, lane, slot
+    back = im.reshape(N // 16, K // 32, 4, 16, 2, 4).permute(0, 3, 1, 4, 2, 5).reshape(N, K)   # nt, ni, kk, h, g, e
+    assert torch.equal(back.float(), W), "the three parts do not add up to the fp32 weight"
+
+
+@pytest.mark.parametrize("M,D,case", [(2560, 384, "bcast"), (2560, 384, "rows"), (2560, 384, "plain_bias"), (1777, 384, "bcast"),
+                                      (45, 384, "rows"), (200, 256, "rows"), (33, 256, "plain_bias")])
+def test_fused_mlp_in_its_bf16_split_form_keeps_fp32_accuracy(lib, M, D, case):
+    """k_mlp_split (round 6): the fused MLP launch with every contraction as six bf16 MFMA products of three-way split operands.
+    Not the fp32 launch's bits: against the float64 sublayer its error must stay within 1.5x the fp32 launch's own on the same
+    inputs (and inside that launch's test tolerance), for every prologue / epilogue variant and ragged row counts."""
+    g = torch.Generator().manual_seed(M + D + len(case))
+    T = 10 if M % 10 == 0 else (5 if M % 5 == 0 else 1)
+    x = torch.randn(M, D, generator=g) * 1.5 + 0.2
+    W1 = torch.randn(4 * D, D, generator=g) / math.sqrt(D)
+    W2 = torch.randn(D, 4 * D, generator=g) / math.sqrt(4 * D)
+    lw = torch.randn(D, generator=g) * 0.2 + 1
+    kw, ref = {}, {}
+    lb = b1 = b2 = None
+    if case == "plain_bias":
+        lb, b1, b2 = torch.randn(D, generator=g) * 0.2, torch.randn(4 * D, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    else:
+        nb = M // T if case == "rows" else 1
+        mod = torch.randn(nb, 6 * D, generator=g) * 0.5
+        kw = dict(mod=mod, mod_stride=6 * D if case == "rows" else 0, offs=(3 * D, 4 * D, 5 * D), rps=T)
+        pick = (lambda o: mod[:, o:o + D].repeat_interleave(T, 0)) if case == "rows" else (lambda o: mod[:, o:o + D])
+        ref = dict(shift=pick(3 * D), scale=pick(4 * D), gate=pick(5 * D))
+    want = ref_mlp(x, W1, W2, lw, lb, b1, b2, **ref)
+    err = {}
+    for split in (False, True):
+        parts, S = run_mlp(lib, x, W1, W2, lw, ln_b=lb, b1=b1, b2=b2, split=split, **kw)
+        got = parts[0].clone()
+        for s in range(1, S):
+            got += parts[s]
+        err[split] = (got.cpu().double() - want).abs().max().item()
+        if split:
+            assert_close(got.cpu(), want.float(), rtol=2e-4, atol=2e-4, what=f"split fused mlp {M}x{D} {case}")
+    assert err[True] <= 1.5 * err[False] + 1e-6, f"split form: max error {err[True]:.3g} against the fp32 launch's {err[False]:.3g}"
 
 
 @pytest.mark.parametrize("M,D", [(2560, 384), (1777, 384), (320, 512), (96, 128)])
