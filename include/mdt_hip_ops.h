@@ -89,6 +89,11 @@ typedef struct {
     int32_t a_parts;
     int64_t a_part_stride;
     float *a_merged;
+    /* optional (round 6): the three-way bf16 split image of the same weight (mdt_op_pack_weight_split; rows in the order of Wp's).
+     * Where it is given, the LayerNorm-prologue products on the wide tiles (K <= 384 a multiple of 128, N a multiple of 384 or
+     * 256, more than 1400 rows, plain output rows) multiply in the split form -- six bf16 MFMA products per 32-deep step, fp32
+     * accumulation: fp32's product accuracy, not the fp32 form's bits -- unless mdt_op_set_mlp_split(0).  NULL: the fp32 form. */
+    const void *Wp_split;
 } mdt_gemm_args;
 
 mdt_status mdt_op_gemm(const mdt_gemm_args *args, void *stream);
@@ -112,6 +117,8 @@ mdt_status mdt_op_mlp(const mdt_gemm_args *fc, const mdt_gemm_args *proj, float 
  * (D, 4 D) row-major sources; 6 bytes per weight); fc->Wp / proj->Wp are not read.  D <= 384.  The model-level entry points use it
  * from the row count of mdt_op_set_mlp_fuse_min on unless mdt_op_set_mlp_split(0) / MDT_HIP_MLP_SPLIT=0 (negative: default). */
 mdt_status mdt_op_pack_weight_split(const float *w, int64_t n_rows, int64_t K, void *image, void *stream);
+/* ... rows [n_off, n_off + n_rows) of a taller image (stacked weights: query | key | value); n_off a multiple of 16 */
+mdt_status mdt_op_pack_weight_split_rows(const float *w, int64_t n_rows, int64_t K, void *image, int64_t n_off, void *stream);
 mdt_status mdt_op_mlp_split(const mdt_gemm_args *fc, const mdt_gemm_args *proj, const void *fc_split, const void *proj_split,
                             float *parts, int64_t part_stride, int32_t *n_parts, void *stream);
 void mdt_op_set_mlp_split(int32_t on);

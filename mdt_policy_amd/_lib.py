@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("residual", C.c_int32), ("gate_off", C.c_int32), ("gin", C.c_int32), ("gout", C.c_int32),
         ("goff", C.c_int32), ("rowvec", C.c_void_p), ("batch", C.c_int32), ("bs_a", C.c_int64), ("bs_w", C.c_int64),
         ("bs_out", C.c_int64), ("aux", C.c_void_p), ("aux_mode", C.c_int32), ("a_parts", C.c_int32),
-        ("a_part_stride", C.c_int64), ("a_merged", C.c_void_p)]
+        ("a_part_stride", C.c_int64), ("a_merged", C.c_void_p), ("Wp_split", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -186,6 +186,7 @@ SYMBOLS = [
     ("mdt_op_gemm", _I32, [C.POINTER(GemmArgs), _VP]),
     ("mdt_op_mlp", _I32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _VP, _I64, C.POINTER(_I32), _VP]),
     ("mdt_op_pack_weight_split", _I32, [_VP, _I64, _I64, _VP, _VP]),
+    ("mdt_op_pack_weight_split_rows", _I32, [_VP, _I64, _I64, _VP, _I64, _VP]),
     ("mdt_op_mlp_split", _I32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _VP, _VP, _VP, _I64, C.POINTER(_I32), _VP]),
     ("mdt_op_set_mlp_split", None, [_I32]),
     ("mdt_op_set_gemm_geometry", None, [_I32]),

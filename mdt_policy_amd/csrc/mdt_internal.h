@@ -55,7 +55,7 @@ struct Bump {
 static inline mdt_gemm_args gemm_args(const float* A, int64_t lda, const Lin& w, float* out, int64_t ldo, int M) {
     mdt_gemm_args g;
     memset(&g, 0, sizeof g);
-    g.A = A; g.lda = lda; g.Wp = w.wp; g.bias = w.bias; g.out = out; g.ldo = ldo;
+    g.A = A; g.lda = lda; g.Wp = w.wp; g.Wp_split = w.ws; g.bias = w.bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = w.N; g.K = w.K;
     g.shift_off = -1; g.scale_off = -1; g.gate_off = -1; g.rows_per_sample = 1;
     g.gin = 1; g.gout = 1; g.goff = 0;
@@ -80,7 +80,7 @@ bool mdt_mlp_split_enabled();
 hipError_t mdt_launch_mlp_split(const mdt_gemm_args& fc, const mdt_gemm_args& proj, const void* w1s, const void* w2s, float* parts,
                                 int64_t part_stride, hipStream_t s);
 // (n_rows, K) row-major fp32 -> split image of 6 n_rows K bytes (n_rows % 16 == 0, K % 32 == 0)
-hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void* image, hipStream_t s);
+hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void* image, hipStream_t s, int n_off = 0);
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin, hipStream_t s);
 // one sample's self-attention fused into its output projection p (rollout batch 1); see mdt_kernels.hip
 bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope);

@@ -66,25 +66,26 @@ hipError_t mdt_launch_pack_weight_glu(const float* w, int H, int K, float* packe
 
 // three-way bf16 split fragment image (mdt_mlp_split.h): thread = 4 consecutive k of one row -> eight bytes in each of the three
 // parts of fragment (row tile r / 16, k32 step c / 32): lane (r % 16) + 16 ((c % 16) / 4), half (c % 32) / 16
-__device__ __forceinline__ void pack_split_quad(const float* __restrict__ src, char* __restrict__ image, int r, int c, int K) {
+__device__ __forceinline__ void pack_split_quad(const float* __restrict__ src, char* __restrict__ image, int rs, int c, int K, int n_off) {
     mdt_bf16x4 p1, p2, p3;
-    split3_bf16(*(const f32x4*)(src + (int64_t)r * K + c), p1, p2, p3);
+    split3_bf16(*(const f32x4*)(src + (int64_t)rs * K + c), p1, p2, p3);
+    const int r = rs + n_off;   // row of the image
     char* q = image + (((int64_t)(r >> 4) * (K >> 5) + (c >> 5)) * 3) * 1024 + ((r & 15) + 16 * ((c & 15) >> 2)) * 16 + ((c & 31) >> 4) * 8;
     *(mdt_bf16x4*)q = p1;
     *(mdt_bf16x4*)(q + 1024) = p2;
     *(mdt_bf16x4*)(q + 2048) = p3;
 }
-__global__ void k_pack_weight_split(const float* __restrict__ w, int n_rows, int K, char* __restrict__ image) {
+__global__ void k_pack_weight_split(const float* __restrict__ w, int n_rows, int K, char* __restrict__ image, int n_off) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int K4 = K >> 2;
     if (idx >= (int64_t)n_rows * K4) return;
     const int r = (int)(idx / K4), c = 4 * (int)(idx - (int64_t)r * K4);
-    pack_split_quad(w, image, r, c, K);
+    pack_split_quad(w, image, r, c, K, n_off);
 }
-hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void* image, hipStream_t s) {
-    if (n_rows % 16 || K % 32) return hipErrorInvalidValue;
+hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void* image, hipStream_t s, int n_off) {
+    if (K % 32) return hipErrorInvalidValue;   // (row counts / offsets that are not multiples of 16 leave the other rows of a tile alone)
     const int64_t n = (int64_t)n_rows * (K >> 2);
-    hipLaunchKernelGGL(k_pack_weight_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n_rows, K, (char*)image);
+    hipLaunchKernelGGL(k_pack_weight_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n_rows, K, (char*)image, n_off);
     return hipGetLastError();
 }
 
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_multi_load(const mdt_load_entry* __rest
             const int K4 = e.K >> 2;
             if (idx >= (int64_t)e.rows * K4) continue;
             const int r = (int)(idx / K4), c = 4 * (int)(idx - (int64_t)r * K4);
-            pack_split_quad(e.src, (char*)e.dst, r, c, e.K);
+            pack_split_quad(e.src, (char*)e.dst, r, c, e.K, e.p0);
             continue;
         }
         if (e.kind == MDT_LOAD_PACK) {
@@ -787,6 +788,8 @@ hipError_t mdt_launch_attn_proj(const mdt_gemm_args& p, const float* qkv, int64_
 }
 
 static hipError_t launch_gemm_merge(const mdt_gemm_args& a, hipStream_t s);
+static bool gemm_ln_split_applies(const mdt_gemm_args& a);
+static hipError_t launch_gemm_ln_split(const mdt_gemm_args& a, hipStream_t s);
 
 bool mdt_attn_proj_wide_supported(const mdt_gemm_args& p, int H, int hd, int T, int causal, int rope) {
     return w_image_ok(p.N, p.K) && H == 8 && (hd == 16 || hd == 32 || hd == 48) && p.K == H * hd && T >= 1 && T <= 16 && causal && !rope && p.residual &&
@@ -949,6 +952,7 @@ hipError_t mdt_launch_gemm(const mdt_gemm_args& a, hipStream_t s) {
             return (a.N % 256 == 0) ? launch_gemm_glu<2, 4, 4, 3>(a, kc, s) : launch_gemm_glu<2, 2, 4, 3>(a, kc, s);
         return (a.N % 192 == 0) ? launch_gemm_glu<2, 3, 4, 4>(a, kc, s) : launch_gemm_glu<2, 2, 4, 4>(a, kc, s);
     }
+    if (gemm_ln_split_applies(a)) return launch_gemm_ln_split(a, s);   // the wide LayerNorm-prologue products in the bf16 split form
     if (a.a_parts > 1) return launch_gemm_merge(a, s);
     // ... and beyond one row tile, the products whose half-height (16 x 64) tiling would leave most of the chip empty keep the
     // split-K kernel, which has 4x the workgroups: fewer than 60 tiles behind a LayerNorm prologue (every 16-column workgroup
@@ -1144,6 +1148,55 @@ hipError_t mdt_launch_mlp(const mdt_gemm_args& f, const mdt_gemm_args& p, float*
         case 3: return launch_mlp_pro<3>(f, p, parts, part_stride, s);
         default: return launch_mlp_pro<4>(f, p, parts, part_stride, s);
     }
+}
+
+// ---- the LayerNorm-prologue product on the wide tiles in the split form (gemm_ln_split_tile) ----
+template <int ND, int NTW, int PRO, int XP>
+__global__ __launch_bounds__(512) void k_gemm_ln_split(mdt_gemm_args a, int grid_n, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) char lds_c[];
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);   // the column panels of a row tile are neighbours: they share the rows' L2
+    const int by = logical / grid_n, bx = logical - by * grid_n;
+    gemm_ln_split_tile<ND, NTW, PRO, XP>(a, by, bx, lds_c, zeros, threadIdx.x);
+}
+template <int ND, int NTW, int PRO, int XP>
+static hipError_t launch_gemm_ln_split_t(const mdt_gemm_args& a, hipStream_t s) {
+    const int gn = a.N / (8 * NTW * 16), gm = (a.M + 31) / 32;
+    const int lds = 3 * 32 * (2 * 128 * ND + 32) + 32 * (128 * ND + 4) * 4;
+    static bool attr_dev[MAX_DEVICES] = {false};
+    bool& done = attr_dev[current_device()];
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_ln_split<ND, NTW, PRO, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL((k_gemm_ln_split<ND, NTW, PRO, XP>), dim3(gn * gm), dim3(512), lds, s, a, gn, g_zeros);
+    return hipGetLastError();
+}
+template <int ND, int NTW, int PRO>
+static hipError_t launch_gemm_ln_split_x(const mdt_gemm_args& a, hipStream_t s) {
+    switch (a.a_parts) {
+        case 2: return launch_gemm_ln_split_t<ND, NTW, PRO, 2>(a, s);
+        case 3: return launch_gemm_ln_split_t<ND, NTW, PRO, 3>(a, s);
+        case 4: return launch_gemm_ln_split_t<ND, NTW, PRO, 4>(a, s);
+        default: return launch_gemm_ln_split_t<ND, NTW, PRO, 1>(a, s);
+    }
+}
+template <int ND, int NTW>
+static hipError_t launch_gemm_ln_split_pro(const mdt_gemm_args& a, hipStream_t s) {
+    if (a.mod != nullptr && a.shift_off >= 0)
+        return a.mod_stride == 0 ? launch_gemm_ln_split_x<ND, NTW, PRO_LN_MOD_BCAST>(a, s) : launch_gemm_ln_split_x<ND, NTW, PRO_LN_MOD_ROWS>(a, s);
+    return launch_gemm_ln_split_x<ND, NTW, PRO_LN>(a, s);
+}
+// which products take it: the split image is there, LayerNorm prologue over whole rows of K = 256 / 384, column count a multiple of the
+// 384- (or 256-) wide panels, plain output rows, and enough rows that the wide tiles are the choice anyway (the fused MLP's threshold)
+static bool gemm_ln_split_applies(const mdt_gemm_args& a) {
+    return a.Wp_split != nullptr && mdt_mlp_split_enabled() && a.ln && (a.K == 256 || a.K == 384) && (a.N % 384 == 0 || a.N % 256 == 0) &&
+           a.M > 1400 && a.batch <= 1 && !a.residual && a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr && !a.aux_mode &&
+           a.a_parts <= 4 && (a.lda & 3) == 0 && (a.ldo & 3) == 0 && g_mdt_gemm_force == 0;
+}
+static hipError_t launch_gemm_ln_split(const mdt_gemm_args& a, hipStream_t s) {
+    if (a.K == 384) return a.N % 384 == 0 ? launch_gemm_ln_split_pro<3, 3>(a, s) : launch_gemm_ln_split_pro<3, 2>(a, s);
+    return a.N % 384 == 0 ? launch_gemm_ln_split_pro<2, 3>(a, s) : launch_gemm_ln_split_pro<2, 2>(a, s);
 }
 
 // ---- the fused MLP sublayer in the three-way bf16 split form (k_mlp_split) ----

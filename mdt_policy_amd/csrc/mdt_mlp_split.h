@@ -225,3 +225,59 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The LayerNorm-prologue product on the wide tiles (gemm_tile<2, NTW, 8, PRO, ...>: 32 rows x 8 waves x NTW column tiles, whole K
+// staged once) in the split form -- the decoder's qkv products (K = d = 384 -> N = 1152: 25 us a launch, 40 launches a sampler call),
+// whose rows are the sum of the fused MLP's slabs (XP > 1: gemm_stage_tile adds them on read, the column-0 tile also leaves the sum
+// in a.a_merged).  The first half of mlp_split_tile with a plain epilogue: out = act(product + bias), plain output rows.
+// LDS: split x tile + fp32 staging (126.5 KB at D = 384).
+// ------------------------------------------------------------------------------------------------
+template <int ND, int NTW, int PRO, int XP>
+__device__ __forceinline__ void gemm_ln_split_tile(const mdt_gemm_args& a, int by, int bx, char* lds, const float* __restrict__ zeros, int tid) {
+    constexpr int MTILES = 2, NWAVES = 8, MT = 32, R = 2;
+    constexpr int D = 128 * ND, K32 = D / 32, ROWB = 2 * D + 32, PART = MT * ROWB, STRIDE = D + 4, D4 = D / 4;
+    static_assert(ND >= 1 && ND <= 3, "D <= 384");
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m0 = by * MT, nq = 4 * (lane >> 4);
+    char* xs = lds;
+    float* x32 = (float*)(lds + 3 * PART);
+    const int nt0 = (bx * NWAVES + wave) * NTW;       // N is a multiple of the panel width: every wave has NTW real column tiles
+    const char* wl = (const char*)a.Wp_split + (int64_t)nt0 * K32 * 3072 + lane * 16;
+    SplitRing<NTW, R> ring;
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u) ring.request(u, wl, (int64_t)K32 * 3072, u);
+    f32x4 bias_v[NTW];
+    {
+        const float* bp = a.bias != nullptr ? a.bias : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bias_v[j] = ldg4(bp + (nt0 + j) * 16 + nq);
+    }
+    gemm_stage_tile<MTILES, NWAVES, PRO, false, XP, (NTW <= 3 && XP <= 3) ? 1 : 2>(a, x32, STRIDE, m0, 0, D, zeros, tid, lane, wave,
+                                                                                   bx == 0 ? a.a_merged : nullptr);
+    __syncthreads();
+    for (int idx = tid; idx < MT * D4; idx += 64 * NWAVES) {
+        const int r = idx / D4, c = 4 * (idx - r * D4);
+        mdt_bf16x4 p1, p2, p3;
+        split3_bf16(*(const f32x4*)(x32 + r * STRIDE + c), p1, p2, p3);
+        char* q = xs + split_slot(r, c, ROWB);
+        *(mdt_bf16x4*)q = p1;
+        *(mdt_bf16x4*)(q + PART) = p2;
+        *(mdt_bf16x4*)(q + 2 * PART) = p3;
+    }
+    __syncthreads();
+    f32x4 acc[MTILES][NTW];
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
+    split_phase<NTW, K32, R>(ring, wl, (int64_t)K32 * 3072, xs, ROWB, PART, lane, acc);
+#pragma unroll
+    for (int i = 0; i < MTILES; ++i) {
+        const int m = m0 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+            if (m < a.M) st4(a.out + (int64_t)m * a.ldo + (nt0 + j) * 16 + nq, apply_act(acc[i][j] + bias_v[j], a.act));
+    }
+}

@@ -169,10 +169,10 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         p = b.take(n);
         add_slot(name, n, SLOT_RAW, p, 0, 0, 0);
     };
-    auto add_extra = [&](const std::string& name, int64_t numel, int kind, float* dst, int rows, int K) {
+    auto add_extra = [&](const std::string& name, int64_t numel, int kind, float* dst, int rows, int K, int n_off = 0) {
         if (!fill_slots) return;
         Slot s;
-        s.name = name; s.numel = numel; s.kind = kind; s.dst = dst; s.rows = rows; s.K = K; s.n_off = 0;
+        s.name = name; s.numel = numel; s.kind = kind; s.dst = dst; s.rows = rows; s.K = K; s.n_off = n_off;
         m->extra.push_back(s);
     };
     const std::string P = "inner_model.";
@@ -206,6 +206,12 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         lin_part(qkv, pre + ".key", D, D, true);
         lin_part(qkv, pre + ".query", D, 0, true);
         lin_part(qkv, pre + ".value", D, 2 * D, true);
+        if (D % 128 == 0 && D <= 384) {   // the split form of the LayerNorm-prologue product (mdt_mlp_split.h): 6 bytes per weight
+            qkv.ws = b.take((size_t)3 * D * D * 6 / 4);
+            add_extra(pre + ".key.weight", (int64_t)D * D, SLOT_PACK_SPLIT, (float*)qkv.ws, D, D, D);
+            add_extra(pre + ".query.weight", (int64_t)D * D, SLOT_PACK_SPLIT, (float*)qkv.ws, D, D, 0);
+            add_extra(pre + ".value.weight", (int64_t)D * D, SLOT_PACK_SPLIT, (float*)qkv.ws, D, D, 2 * D);
+        }
     };
     auto block_common_a = [&](EncBlock& e, const std::string& pre) {
         raw(e.ln1_w, pre + ".ln_1.weight", D);
@@ -475,7 +481,7 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
                 dev_src = m->staging;
             }
         }
-        if (t->kind == SLOT_PACK_SPLIT) { HIP_TRY(mdt_launch_pack_weight_split(dev_src, t->rows, t->K, t->dst, s)); continue; }
+        if (t->kind == SLOT_PACK_SPLIT) { HIP_TRY(mdt_launch_pack_weight_split(dev_src, t->rows, t->K, t->dst, s, t->n_off)); continue; }
         if (t->kind == SLOT_TRANSPOSE) HIP_TRY(mdt_launch_transpose(dev_src, t->dst, t->rows, t->K, s));
         else if (t->kind == SLOT_PACK_T) HIP_TRY(mdt_launch_pack_weight_t(dev_src, t->rows, t->K, t->K, t->dst, 0, t->rows / 16, s));  // image of the transpose
         else HIP_TRY(mdt_launch_pack_weight(dev_src, t->rows, t->K, t->dst, t->n_off, s));
@@ -536,7 +542,7 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
             else if (t->kind == SLOT_PAD_COLS) add(srcs[i], t->dst, MDT_LOAD_PAD_COLS, t->rows, t->K, t->n_off, 0);
             else if (t->kind == SLOT_TRANSPOSE) add(srcs[i], t->dst, MDT_LOAD_TRANSPOSE, t->rows, t->K, 0, 0);
             else if (t->kind == SLOT_PACK_T) add(srcs[i], t->dst, MDT_LOAD_PACK_T, t->rows, t->K, 0, t->rows / 16);
-            else if (t->kind == SLOT_PACK_SPLIT) add(srcs[i], t->dst, MDT_LOAD_PACK_SPLIT, t->rows, t->K, 0, 0);
+            else if (t->kind == SLOT_PACK_SPLIT) add(srcs[i], t->dst, MDT_LOAD_PACK_SPLIT, t->rows, t->K, t->n_off, 0);
             else {
                 add(srcs[i], t->dst, MDT_LOAD_PACK, t->rows, t->K, t->n_off, 0);
                 if (t->lin && t->lin->wt) add(srcs[i], t->lin->wt, MDT_LOAD_PACK_T, t->rows, t->K, t->n_off, t->lin->N / 16);
@@ -1383,6 +1389,15 @@ extern "C" mdt_status mdt_op_pack_weight_split(const float* w, int64_t n_rows, i
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split: n_rows a multiple of 16, K a multiple of 32");
     if (misaligned(w) || misaligned(image)) return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split: pointers must be 16-byte aligned");
     LAUNCH(mdt_launch_pack_weight_split(w, (int)n_rows, (int)K, image, (hipStream_t)stream));
+    return MDT_OK;
+}
+
+extern "C" mdt_status mdt_op_pack_weight_split_rows(const float* w, int64_t n_rows, int64_t K, void* image, int64_t n_off, void* stream) {
+    if (!w || !image) return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split_rows: null pointer");
+    if (n_rows < 1 || n_off < 0 || n_off % 16 || K < 32 || K % 32 || (n_rows + n_off) * K >= ((int64_t)1 << 30))
+        return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split_rows: n_off a multiple of 16, K a multiple of 32");
+    if (misaligned(w) || misaligned(image)) return fail(MDT_ERR_INVALID_ARG, "mdt_op_pack_weight_split_rows: pointers must be 16-byte aligned");
+    LAUNCH(mdt_launch_pack_weight_split(w, (int)n_rows, (int)K, image, (hipStream_t)stream, (int)n_off));
     return MDT_OK;
 }
 

@@ -1094,6 +1094,68 @@ def test_gemm_reads_the_sum_of_slabs(lib, M, N, XP, case):
     assert torch.equal(out.cpu(), want), "merge-on-read GEMM differs from the GEMM on the summed rows"
 
 
+@pytest.mark.parametrize("M,N,D,XP,case", [(2560, 1152, 384, 3, "bcast"), (2560, 1152, 384, 1, "rows"), (1530, 1152, 384, 3, "ln"),
+                                           (1777, 768, 256, 2, "bcast"), (1500, 512, 384, 4, "ln")])
+def test_layernorm_gemm_in_its_bf16_split_form_keeps_fp32_accuracy(lib, M, N, D, XP, case):
+    """mdt_gemm_args.Wp_split (round 6): the wide LayerNorm-prologue product -- the decoder's qkv GEMM, rows = the sum of the fused
+    MLP's slabs -- as six bf16 MFMA products of three-way split operands per k32 step.  a_merged must still be the exact slab-order
+    sum; the output, against float64, within 1.5x the error of the fp32 form (Wp_split = NULL) on the same inputs; stacked weights
+    (query | key | value packed row range by row range) included."""
+    g = torch.Generator().manual_seed(M + N + XP + D)
+    T = 10 if M % 10 == 0 else 1
+    slabs = torch.randn(XP, M, D, generator=g)
+    W, b = torch.randn(N, D, generator=g) / math.sqrt(D), torch.randn(N, generator=g)
+    lw, lb = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    summed = slabs[0].clone()
+    for s in range(1, XP):
+        summed = summed + slabs[s]
+    kw = {}
+    h = F.layer_norm(summed.double(), (D,), lw.double(), lb.double(), 1e-5)
+    if case != "ln":
+        nb = M // T if case == "rows" else 1
+        mod = torch.randn(nb, 2 * D, generator=g) * 0.5
+        kw = dict(mod=mod, mod_stride=2 * D if case == "rows" else 0)
+        pick = (lambda o: mod[:, o:o + D].repeat_interleave(T, 0)) if case == "rows" else (lambda o: mod[:, o:o + D])
+        h = pick(0).double() + h * pick(D).double()
+    want = h @ W.double().T + b.double()
+    keep = []
+    sd, Pd = dev(slabs), pack(lib, W)
+    # the split image, packed in three row ranges like the model's stacked query | key | value
+    Wd = dev(W)
+    S = torch.zeros(N * D * 6, dtype=torch.uint8, device="cuda")
+    third = (N // 3) // 16 * 16
+    for lo, hi in ((0, third), (third, 2 * third), (2 * third, N)):
+        lib.check(lib.load().mdt_op_pack_weight_split_rows(Wd[lo:hi].contiguous().data_ptr(), hi - lo, D, S.data_ptr(), lo, stream()))
+    assert torch.equal(S, pack_split(lib, W)), "row-range packs differ from the one-piece image"
+    err = {}
+    for split in (False, True):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        merged = torch.full((M, D), float("nan"), device="cuda")
+        a = _gemm_args(lib, keep, sd, D, Pd, N, D, M, out=out, ldo=N, bias=b)
+        a.ln = 1
+        for name, t in (("ln_w", lw), ("ln_b", lb)):
+            td = dev(t); keep.append(td); setattr(a, name, td.data_ptr())
+        if kw:
+            md = dev(kw["mod"]); keep.append(md)
+            a.mod, a.mod_stride, a.shift_off, a.scale_off, a.rows_per_sample = md.data_ptr(), kw["mod_stride"], 0, D, T
+        if XP > 1:
+            a.a_parts, a.a_part_stride, a.a_merged = XP, M * D, merged.data_ptr()
+        if split:
+            a.Wp_split = S.data_ptr()
+        lib.check(lib.load().mdt_op_gemm(C.byref(a), stream()))
+        torch.cuda.synchronize()
+        if XP > 1:
+            assert torch.equal(merged.cpu(), summed), "a_merged is not the slab-order sum"
+        err[split] = (out.cpu().double() - want).abs().max().item()
+        if split:
+            assert_close(out.cpu(), want.float(), rtol=1e-4, atol=1e-4, what="split LayerNorm GEMM")
+            res_split = out.cpu()
+        else:
+            res_fp32 = out.cpu()
+    assert not torch.equal(res_split, res_fp32), "the split form did not run"
+    assert err[True] <= 1.5 * err[False] + 1e-6, f"split form: max error {err[True]:.3g} against the fp32 form's {err[False]:.3g}"
+
+
 @pytest.mark.parametrize("M,XP", [(2560, 3), (77, 4), (10, 2)])
 def test_head_reads_the_sum_of_slabs(lib, M, XP):
     """mdt_head_args.y_parts: identical to the head on the pre-summed rows (DDIM mode with the next step's embedding)."""
