@@ -77,6 +77,7 @@ hipError_t mdt_launch_mlp(const mdt_gemm_args& fc, const mdt_gemm_args& proj, fl
 // the same launch in the three-way bf16 split form (mdt_mlp_split.h): w1s / w2s = split images of fc / proj (mdt_launch_pack_weight_split)
 bool mdt_mlp_split_supported(const mdt_gemm_args& fc, const mdt_gemm_args& proj);
 bool mdt_mlp_split_enabled();
+int mdt_split_min_rows();   // rows from which the split forms of the sampler's launches are used (MDT_HIP_SPLIT_MIN_ROWS, default 768: B = 80 2.97 -> 2.89 ms per call, 96 3.08 -> 2.93, 120 3.54 -> 2.96, 128 3.42 -> 2.96; B = 64 loses, 2.44 -> 2.90)
 hipError_t mdt_launch_mlp_split(const mdt_gemm_args& fc, const mdt_gemm_args& proj, const void* w1s, const void* w2s, float* parts,
                                 int64_t part_stride, hipStream_t s);
 // (n_rows, K) row-major fp32 -> split image of 6 n_rows K bytes (n_rows % 16 == 0, K % 32 == 0)

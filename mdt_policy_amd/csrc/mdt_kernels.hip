@@ -1191,7 +1191,7 @@ static hipError_t launch_gemm_ln_split_pro(const mdt_gemm_args& a, hipStream_t s
 // 384- (or 256-) wide panels, plain output rows, and enough rows that the wide tiles are the choice anyway (the fused MLP's threshold)
 static bool gemm_ln_split_applies(const mdt_gemm_args& a) {
     return a.Wp_split != nullptr && mdt_mlp_split_enabled() && a.ln && (a.K == 256 || a.K == 384) && (a.N % 384 == 0 || a.N % 256 == 0) &&
-           a.M > 1400 && a.batch <= 1 && !a.residual && a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr && !a.aux_mode &&
+           a.M >= mdt_split_min_rows() && a.batch <= 1 && !a.residual && a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr && !a.aux_mode &&
            a.a_parts <= 4 && (a.lda & 3) == 0 && (a.ldo & 3) == 0 && g_mdt_gemm_force == 0;
 }
 static hipError_t launch_gemm_ln_split(const mdt_gemm_args& a, hipStream_t s) {
@@ -1206,6 +1206,11 @@ bool mdt_mlp_split_enabled() {
     return g_mlp_split != 0;
 }
 extern "C" void mdt_op_set_mlp_split(int32_t on) { g_mlp_split = on < 0 ? -1 : (on != 0); }
+int mdt_split_min_rows() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MDT_HIP_SPLIT_MIN_ROWS"); v = e ? std::max(1, atoi(e)) : 768; }
+    return v;
+}
 bool mdt_mlp_split_supported(const mdt_gemm_args& f, const mdt_gemm_args& p) {
     return mdt_mlp_supported(f, p) && f.K <= 384;   // D = 512: the split x tile + its staging do not fit LDS
 }

@@ -769,10 +769,14 @@ static mdt_status run_self_attn(mdt_model* m, const EncBlock& e, const View& V, 
 // row count from which the MLP sublayer runs as ONE launch (k_mlp) that leaves partial slabs instead of the residual
 // stream (MDT_HIP_MLP_FUSE_MIN overrides; 0 disables): below it the wide tiles do not fill the chip
 static int g_mlp_fuse_override = -1;  // mdt_op_set_mlp_fuse_min (tests / A-B runs)
-static int g_mlp_fuse_min_rows() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MDT_HIP_MLP_FUSE_MIN"); v = e ? atoi(e) : 1401; if (v == 0) v = 1 << 30; }
-    return g_mlp_fuse_override >= 0 ? (g_mlp_fuse_override == 0 ? 1 << 30 : g_mlp_fuse_override) : v;
+// (`split`: the launch would run in its bf16 split form, which pays from fewer rows -- mdt_split_min_rows(), B = 128: 1280 rows
+// per call 3.42 -> 2.96 ms with the qkv products split too (mdt_internal.h); an explicit setting, hook or environment, is taken as it is)
+static int g_mlp_fuse_min_rows(bool split = false) {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("MDT_HIP_MLP_FUSE_MIN"); v = e ? atoi(e) : -1; if (v == 0) v = 1 << 30; }
+    if (g_mlp_fuse_override >= 0) return g_mlp_fuse_override == 0 ? 1 << 30 : g_mlp_fuse_override;
+    if (v >= 0) return v;
+    return split ? std::min(1401, mdt_split_min_rows()) : 1401;
 }
 extern "C" void mdt_op_set_mlp_fuse_min(int32_t rows) { g_mlp_fuse_override = rows; }
 
@@ -847,12 +851,13 @@ static mdt_status run_mlp(mdt_model* m, const EncBlock& e, const View& V, int64_
     if (mr.mod && mr.gate >= 0) { p.mod = mr.mod; p.mod_stride = mr.stride; p.gate_off = mr.gate; }
     if (out) *out = Stream();
     // (never with `pre_x`: the caller skipped its own cross-attention launch because the c_fc launch was to run it)
-    if (out && !pre_x && M >= g_mlp_fuse_min_rows() && mdt_mlp_slices(D) >= 2 && mdt_mlp_supported(g, p)) {
+    // the three-way bf16 split form of the launch (mdt_mlp_split.h) wherever its images exist and it is not switched off; it pays
+    // from fewer rows than the fp32 launch (g_mlp_fuse_min_rows)
+    const bool split = e.fc.ws && e.proj2.ws && mdt_mlp_split_enabled() && mdt_mlp_split_supported(g, p);
+    if (out && !pre_x && M >= g_mlp_fuse_min_rows(split) && mdt_mlp_slices(D) >= 2 && mdt_mlp_supported(g, p)) {
         // the hidden buffer (M x 4D) is free in this form: it holds the S <= 4 slabs of (M x D)
         p.ldo = D;
         const int64_t stride = (int64_t)M * D;
-        // the three-way bf16 split form of the launch (mdt_mlp_split.h) wherever its images exist and it is not switched off
-        const bool split = e.fc.ws && e.proj2.ws && mdt_mlp_split_enabled() && mdt_mlp_split_supported(g, p);
         if (g_trace_mlp) {  // measurement hook (mdt_op_trace_mlp): this launch between its own pair of HIP events, inside the chain
             TraceEv ev;
             HIP_TRY(hipEventCreate(&ev.e0)); HIP_TRY(hipEventCreate(&ev.e1)); HIP_TRY(hipEventCreate(&ev.e2));
