@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense FP32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense BF16 matrix peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 SPEC_MHZ = 2400.0              # the shader clock the FP32-matrix peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 T_START = time.perf_counter()
@@ -106,9 +107,19 @@ def time_dominant_kernel(device, M):
     for a in (f, p):
         a.rows_per_sample, a.gin, a.gout, a.goff = 10, 1, 1, 0
     n = C.c_int32(0)
+    # the form the model-level calls use: the three-way bf16 split (round 6) unless MDT_HIP_MLP_SPLIT=0
+    split = os.environ.get("MDT_HIP_MLP_SPLIT", "1") != "0"
+    if split:
+        S1 = torch.zeros(N * D * 6, dtype=torch.uint8, device=device)
+        S2 = torch.zeros(N * D * 6, dtype=torch.uint8, device=device)
+        _lib.check(lib.mdt_op_pack_weight_split(W1.data_ptr(), N, D, S1.data_ptr(), s))
+        _lib.check(lib.mdt_op_pack_weight_split(W2.data_ptr(), D, N, S2.data_ptr(), s))
 
     def launch():
-        _lib.check(lib.mdt_op_mlp(C.byref(f), C.byref(p), parts.data_ptr(), M * D, C.byref(n), s))
+        if split:
+            _lib.check(lib.mdt_op_mlp_split(C.byref(f), C.byref(p), S1.data_ptr(), S2.data_ptr(), parts.data_ptr(), M * D, C.byref(n), s))
+        else:
+            _lib.check(lib.mdt_op_mlp(C.byref(f), C.byref(p), parts.data_ptr(), M * D, C.byref(n), s))
     for _ in range(10):
         launch()
     reps = 200
@@ -123,9 +134,16 @@ def time_dominant_kernel(device, M):
     tf = flops / (us * 1e-6) / 1e12
     # bytes of one launch: TRUE algorithmic = rows read once, both weight images once, the sublayer's output written once;
     # the kernel as built writes S partial slabs instead of one output (an implementation artefact, summed by the next reader)
-    alg_true = 4 * (M * D + 2 * N * D + M * D)
-    alg_slabs = 4 * (M * D + 2 * N * D + S * M * D)
-    return {"name": f"k_mlp LN+mod -> c_fc -> GELU -> c_proj -> gate ({M} rows, d={D}, hidden {N}: {flops / 1e9:.2f} GFLOP per launch)",
+    wbytes = 6 if split else 4   # the split images hold three bf16 parts per weight
+    alg_true = 4 * (M * D + M * D) + wbytes * 2 * N * D
+    alg_slabs = 4 * (M * D + S * M * D) + wbytes * 2 * N * D
+    form = ("three-way bf16 split: every fp32 operand as three bf16 parts, six v_mfma_f32_16x16x32_bf16 products per k32 step, fp32 "
+            "accumulation (fp32 product accuracy; 6 executed bf16 FLOPs per algorithmic FLOP: `frac` = algorithmic FLOPs against the "
+            "FP32 matrix peak, `frac_of_bf16_peak_executed` = executed bf16 MFMA FLOPs against the 2.5 PFLOP/s dense bf16 peak)"
+            if split else "v_mfma_f32_16x16x4_f32")
+    return {"name": f"{'k_mlp_split' if split else 'k_mlp'} LN+mod -> c_fc -> GELU -> c_proj -> gate ({M} rows, d={D}, hidden {N}: "
+                    f"{flops / 1e9:.2f} GFLOP per launch)",
+            "form": form, "executed_flops_per_algorithmic": 6 if split else 1,
             "gflop_per_launch": round(flops / 1e9, 3),
             "alone": {"avg_us": round(us, 2), "achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                       "what": f"{reps} back-to-back launches of the kernel alone through the op-level C ABI (HIP events on the launch "
@@ -656,7 +674,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",   # fp32 in, fp32 out, fp32 accumulation; the MLP / qkv launches multiply three-way bf16 splits of the fp32 operands (fp32 product accuracy)
             "data": "synthetic",
             "config": {"workload": f"MDT-V d=384 4+4 blocks 8 heads, horizon 10, action dim 7, "
                                    f"{args.denoise_steps} DDIM steps (exponential sigma 80->0.001), "
@@ -683,6 +701,11 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                          "scope": "whole sampler call (encoder + 10 decoder steps), algorithmic "
                                   f"{flops_chunk / 1e9:.3f} GFLOP/chunk, HIP-event time of the timed region",
+                         "peak_scope": "the dense FP32 matrix peak (v_mfma_f32_16x16x4_f32), the rate of the path's contract: fp32 operands, "
+                                       "fp32 results.  Since round 6 the two dominant launches (fused MLP, qkv) multiply three-way bf16 splits "
+                                       "of their fp32 operands (six bf16 MFMA products per k32 step, fp32 accumulation: fp32 product accuracy "
+                                       "at 2.7x the fp32 matrix rate), so `frac` is no longer bounded by 1; dominant_kernel."
+                                       "frac_of_bf16_peak_executed prices that launch's executed bf16 MFMA FLOPs against the 2.5 PFLOP/s bf16 peak",
                          "gpu_ms_per_step": round(gpu_s / args.steps * 1e3, 4)},
         }
         try:  # the sustained clock of the timed region and the fraction of the peak AT that clock
@@ -702,6 +725,8 @@ def main():
             chain = time_dominant_kernel_in_chain(step, device) if world == 1 else None
             if chain:  # the figure the roofline of the dominant kernel is quoted on: its launches inside one sampler call
                 tf = dk["gflop_per_launch"] * 1e9 / (chain["avg_us"] * 1e-6) / 1e12
+                if dk.get("executed_flops_per_algorithmic", 1) > 1:
+                    dk["frac_of_bf16_peak_executed"] = round(dk["executed_flops_per_algorithmic"] * tf / PEAK_BF16_MFMA_TFLOPS, 4)
                 dk.update({"avg_us": chain["avg_us"], "achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                            "in_chain": chain,
                            "what": f"mean over the {chain['launches']} launches of ONE sampler call, each between its own pair of HIP "

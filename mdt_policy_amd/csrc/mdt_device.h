@@ -269,3 +269,26 @@ __device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, uint32_t site, ui
     const philox4_t r = philox4(seed, site, idx >> 2);
     return (f32x4){dropout_keep(r.w[0], p), dropout_keep(r.w[1], p), dropout_keep(r.w[2], p), dropout_keep(r.w[3], p)};
 }
+
+// ---- three-way bf16 split of fp32 operands (round 6: mdt_ws.h, mdt_mlp_split.h) ----
+// x = p1 + p2 + p3 exactly: each part is the bf16 rounding (v_cvt_pk_bf16_f32) of what the parts before it left.
+typedef __bf16 mdt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mdt_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_bf16(const f32x4& x, mdt_bf16x4& p1, mdt_bf16x4& p2, mdt_bf16x4& p3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 a = (__bf16)x[e];
+        const float r = x[e] - (float)a;
+        const __bf16 b = (__bf16)r;
+        const float r2 = r - (float)b;
+        p1[e] = a; p2[e] = b; p3[e] = (__bf16)r2;
+    }
+}
+
+// byte offset of the four values at columns c .. c + 3 of a row inside one part of a split tile (row stride rowb bytes): slots
+// (half, 0 .. 3) = ((c % 32) / 16, ..) of lane group (c % 16) / 4 in k32 step c / 32 -- the order v_mfma_f32_16x16x32_bf16 reads
+// with one ds_read_b128 per part, row tile and k32 step
+__device__ __forceinline__ int split_slot(int row, int c, int rowb) {
+    return row * rowb + (c >> 5) * 64 + ((c & 15) >> 2) * 16 + ((c & 31) >> 4) * 8;
+}

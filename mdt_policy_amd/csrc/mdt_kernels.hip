@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(512) void k_gemm_ln_split(mdt_gemm_args a, int grid
 template <int ND, int NTW, int PRO, int XP>
 static hipError_t launch_gemm_ln_split_t(const mdt_gemm_args& a, hipStream_t s) {
     const int gn = a.N / (8 * NTW * 16), gm = (a.M + 31) / 32;
-    const int lds = 3 * 32 * (2 * 128 * ND + 32) + 32 * (128 * ND + 4) * 4;
+    const int lds = 3 * 32 * (2 * 128 * ND + 32);
     static bool attr_dev[MAX_DEVICES] = {false};
     bool& done = attr_dev[current_device()];
     if (!done) {
@@ -1212,7 +1212,7 @@ int mdt_split_min_rows() {
     return v;
 }
 bool mdt_mlp_split_supported(const mdt_gemm_args& f, const mdt_gemm_args& p) {
-    return mdt_mlp_supported(f, p) && f.K <= 384;   // D = 512: the split x tile + its staging do not fit LDS
+    return mdt_mlp_supported(f, p) && f.K <= 384;   // (instantiated for D <= 384)
 }
 template <int NTW2, int PRO>
 static hipError_t launch_mlp_split_t(const mdt_gemm_args& f, const mdt_gemm_args& p, const void* w1s, const void* w2s, float* parts,

@@ -13,11 +13,11 @@
 //               streams its fragments L2 -> registers as mlp_tile does (ring of two k32 steps): 1.5x the bytes of the fp32 image in
 //               a third of the matrix-pipe time -- 49 B per clock and CU of the vector memory path's 64 at full rate (fp32: 14);
 //               tools/micro/mlp_split_probe.hip measured the two phases with this traffic at 31 us against k_mlp's 52-58.
-//   activations the LayerNorm (+ modulate) prologue stages fp32 rows as in mlp_tile (gemm_stage_tile); one pass over that tile
-//               splits it into the MFMA slot order of mdt_ws.h (one ds_read_b128 per part, row tile and k32 step);
+//   activations the LayerNorm (+ modulate) prologue of mlp_tile (gemm_stage_tile) stores its rows as their split, in the MFMA slot
+//               order of mdt_ws.h (one ds_read_b128 per part, row tile and k32 step);
 //   hidden      the activation epilogue of the first product splits its values on the way into LDS, same slot order.
-// LDS: split x tile 3 x 32 x (2 D + 32) B | fp32 staging 32 x (D + 4) x 4 B, overlaid after the first product by the split hidden
-// slice 3 x 32 x 1056 B: 126.5 KB at D = 384 (D <= 384: D = 512 would need 167 KB and keeps the fp32 launch).
+// LDS: split x tile 3 x 32 x (2 D + 32) B, overlaid after the first product by the split hidden slice 3 x 32 x 1056 B = 101 KB
+// (instantiated for D <= 384).
 // No wave skew here (mlp_tile's flags): the hidden slice overlays the x tile, so the two products are separated by barriers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,11 +27,6 @@
 #include "mdt_internal.h"
 #include "mdt_tiles.h"
 #include "mdt_ws.h"   // mdt_bf16x8 / mdt_bf16x4, split3_bf16
-
-// byte offset of the four values at columns c .. c + 3 of a row inside one part of a split tile (row stride rowb)
-__device__ __forceinline__ int split_slot(int row, int c, int rowb) {
-    return row * rowb + (c >> 5) * 64 + ((c & 15) >> 2) * 16 + ((c & 31) >> 4) * 8;
-}
 
 __device__ __forceinline__ mdt_bf16x8 ldw_split(const char* p) { return __builtin_bit_cast(mdt_bf16x8, *(const f32x4*)p); }
 
@@ -114,8 +109,8 @@ __device__ __forceinline__ void split_phase(SplitRing<NT, R>& ring, const char* 
 
 // LDS bytes of mlp_split_tile at model width D
 __host__ __device__ constexpr int mlp_split_lds_bytes(int D) {
-    const int xs = 3 * 32 * (2 * D + 32), x32 = 32 * (D + 4) * 4, hs = 3 * 32 * (2 * 512 + 32);
-    return xs + x32 > hs ? xs + x32 : hs;
+    const int xs = 3 * 32 * (2 * D + 32), hs = 3 * 32 * (2 * 512 + 32);
+    return xs > hs ? xs : hs;
 }
 
 template <int NTW2, int PRO>
@@ -124,14 +119,13 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
                                                int s, char* lds, const float* __restrict__ zeros, int tid) {
     constexpr int MTILES = 2, NWAVES = 8, MT = 32, HS = 512, NTW1 = 4, R = 2;
     constexpr int D = 128 * NTW2, K32a = D / 32, K32b = HS / 32;
-    constexpr int ROWB1 = 2 * D + 32, PART1 = MT * ROWB1, ROWB2 = 2 * HS + 32, PART2 = MT * ROWB2, STRIDE1 = D + 4;
-    static_assert(NTW2 >= 1 && NTW2 <= 3, "D <= 384: the split x tile and its fp32 staging share 160 KB of LDS");
+    constexpr int ROWB1 = 2 * D + 32, PART1 = MT * ROWB1, ROWB2 = 2 * HS + 32, PART2 = MT * ROWB2;
+    static_assert(NTW2 >= 1 && NTW2 <= 3, "instantiated for D <= 384");
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int m0 = by * MT;
     const int nq = 4 * (lane >> 4);
     char* xs = lds;                                   // split x tile: 3 parts x [32][ROWB1]
-    float* x32 = (float*)(lds + 3 * PART1);           // fp32 staging [32][D + 4]
     char* hs = lds;                                   // split hidden slice: 3 parts x [32][ROWB2] (after the first product)
 
     // ---- first product's operands: the ring's first step and the bias travel under the prologue ----
@@ -146,19 +140,8 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
 #pragma unroll
         for (int j = 0; j < NTW1; ++j) b1[j] = ldg4(bp + (nt1 + j) * 16 + nq);
     }
-    gemm_stage_tile<MTILES, NWAVES, PRO, false>(f, x32, STRIDE1, m0, 0, D, zeros, tid, lane, wave);
-    __syncthreads();
-    // ---- split the staged rows into the MFMA slot order ----
-    constexpr int D4 = D / 4;
-    for (int idx = tid; idx < MT * D4; idx += 64 * NWAVES) {
-        const int r = idx / D4, c = 4 * (idx - r * D4);
-        mdt_bf16x4 p1, p2, p3;
-        split3_bf16(*(const f32x4*)(x32 + r * STRIDE1 + c), p1, p2, p3);
-        char* q = xs + split_slot(r, c, ROWB1);
-        *(mdt_bf16x4*)q = p1;
-        *(mdt_bf16x4*)(q + PART1) = p2;
-        *(mdt_bf16x4*)(q + 2 * PART1) = p3;
-    }
+    // LayerNorm (+ modulate) of the tile's rows, stored as their split in MFMA slot order
+    gemm_stage_tile<MTILES, NWAVES, PRO, false, 1, 2, true>(f, (float*)xs, ROWB1, m0, 0, D, zeros, tid, lane, wave);
     __syncthreads();
     f32x4 acc1[MTILES][NTW1];
 #pragma unroll
@@ -231,18 +214,17 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
 // staged once) in the split form -- the decoder's qkv products (K = d = 384 -> N = 1152: 25 us a launch, 40 launches a sampler call),
 // whose rows are the sum of the fused MLP's slabs (XP > 1: gemm_stage_tile adds them on read, the column-0 tile also leaves the sum
 // in a.a_merged).  The first half of mlp_split_tile with a plain epilogue: out = act(product + bias), plain output rows.
-// LDS: split x tile + fp32 staging (126.5 KB at D = 384).
+// LDS: the split x tile (76.8 KB at D = 384).
 // ------------------------------------------------------------------------------------------------
 template <int ND, int NTW, int PRO, int XP>
 __device__ __forceinline__ void gemm_ln_split_tile(const mdt_gemm_args& a, int by, int bx, char* lds, const float* __restrict__ zeros, int tid) {
     constexpr int MTILES = 2, NWAVES = 8, MT = 32, R = 2;
-    constexpr int D = 128 * ND, K32 = D / 32, ROWB = 2 * D + 32, PART = MT * ROWB, STRIDE = D + 4, D4 = D / 4;
+    constexpr int D = 128 * ND, K32 = D / 32, ROWB = 2 * D + 32, PART = MT * ROWB;
     static_assert(ND >= 1 && ND <= 3, "D <= 384");
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int m0 = by * MT, nq = 4 * (lane >> 4);
     char* xs = lds;
-    float* x32 = (float*)(lds + 3 * PART);
     const int nt0 = (bx * NWAVES + wave) * NTW;       // N is a multiple of the panel width: every wave has NTW real column tiles
     const char* wl = (const char*)a.Wp_split + (int64_t)nt0 * K32 * 3072 + lane * 16;
     SplitRing<NTW, R> ring;
@@ -254,18 +236,8 @@ __device__ __forceinline__ void gemm_ln_split_tile(const mdt_gemm_args& a, int b
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bias_v[j] = ldg4(bp + (nt0 + j) * 16 + nq);
     }
-    gemm_stage_tile<MTILES, NWAVES, PRO, false, XP, (NTW <= 3 && XP <= 3) ? 1 : 2>(a, x32, STRIDE, m0, 0, D, zeros, tid, lane, wave,
-                                                                                   bx == 0 ? a.a_merged : nullptr);
-    __syncthreads();
-    for (int idx = tid; idx < MT * D4; idx += 64 * NWAVES) {
-        const int r = idx / D4, c = 4 * (idx - r * D4);
-        mdt_bf16x4 p1, p2, p3;
-        split3_bf16(*(const f32x4*)(x32 + r * STRIDE + c), p1, p2, p3);
-        char* q = xs + split_slot(r, c, ROWB);
-        *(mdt_bf16x4*)q = p1;
-        *(mdt_bf16x4*)(q + PART) = p2;
-        *(mdt_bf16x4*)(q + 2 * PART) = p3;
-    }
+    gemm_stage_tile<MTILES, NWAVES, PRO, false, XP, (NTW <= 3 && XP <= 3) ? 1 : 2, true>(a, (float*)xs, ROWB, m0, 0, D, zeros, tid, lane, wave,
+                                                                                         bx == 0 ? a.a_merged : nullptr);
     __syncthreads();
     f32x4 acc[MTILES][NTW];
 #pragma unroll

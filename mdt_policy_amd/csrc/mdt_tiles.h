@@ -265,10 +265,14 @@ __device__ unsigned long long* g_dbg_ts = nullptr;
 // the fused MLP launch, mlp_tile below), added in slab order; `merge_out` (the column-0 workgroup of a row tile passes
 // a.a_merged, the others nullptr) also receives the summed rows.
 // XB (XP > 1): row batches the other slabs are requested in -- 1 where the registers allow it, else 2 (the caller knows its own load)
-template <int MTILES, int NWAVES, int PRO, bool COH, int XP = 1, int XB = 2>
+// SPLIT (round 6, LayerNorm prologues only): the rows are stored as their three-way bf16 split in MFMA slot order (mdt_device.h
+// split3_bf16 / split_slot: part q at (char*)lds + q * MT * stride, `stride` = the split tile's row stride in BYTES) instead of fp32
+// rows of `stride` floats -- the staged tile of mdt_mlp_split.h without an fp32 copy in LDS and a pass over it.
+template <int MTILES, int NWAVES, int PRO, bool COH, int XP = 1, int XB = 2, bool SPLIT = false>
 __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* lds, int stride, int m0, int k0, int klen,
                                                 const float* __restrict__ zeros, int tid, int lane, int wave,
                                                 float* merge_out = nullptr) {
+    static_assert(!SPLIT || PRO != PRO_PLAIN, "the split store belongs to the LayerNorm prologues");
     constexpr int MT = MTILES * 16;
     constexpr int NT = 64 * NWAVES;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -407,7 +411,18 @@ __device__ __forceinline__ void gemm_stage_tile(const mdt_gemm_args& a, float* l
                     y = shv + y * scv;
                 }
                 y = sel4(m < a.M, y, zero4);
-                if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
+                if constexpr (SPLIT) {
+                    if (cv[p]) {
+                        mdt_bf16x4 p1, p2, p3;
+                        split3_bf16(y, p1, p2, p3);
+                        char* q = (char*)lds + split_slot(r0 + r, cc[p], stride);
+                        *(mdt_bf16x4*)q = p1;
+                        *(mdt_bf16x4*)(q + MT * stride) = p2;
+                        *(mdt_bf16x4*)(q + 2 * MT * stride) = p3;
+                    }
+                } else {
+                    if (cv[p]) *(f32x4*)(lds + (r0 + r) * stride + cc[p]) = y;
+                }
             }
         }
     } else {

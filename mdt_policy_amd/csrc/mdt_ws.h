@@ -238,20 +238,7 @@ __device__ __forceinline__ void gemm_ws_tile(const mdt_gemm_args& a, int panel, 
 // (three 8-byte stores per 16-byte load, in the slot order the MFMA reads: one ds_read_b128 per part, row tile and k32 step).
 // K16 even, ONE column tile per wave, 8 waves.  LDS: 2 buffers x 3 parts x 32 rows x (2 K + 32) bytes (150 KB at K = 384).
 // NOT bit-identical to the fp32 bodies (other products, other order): the tests hold it to float64 with the fp32 bodies' tolerance.
-typedef __bf16 mdt_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 mdt_bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3_bf16(const f32x4& x, mdt_bf16x4& p1, mdt_bf16x4& p2, mdt_bf16x4& p3) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 a = (__bf16)x[e];
-        const float r = x[e] - (float)a;
-        const __bf16 b = (__bf16)r;
-        const float r2 = r - (float)b;
-        p1[e] = a; p2[e] = b; p3[e] = (__bf16)r2;
-    }
-}
-
+// (mdt_bf16x8 / mdt_bf16x4, split3_bf16, split_slot: mdt_device.h)
 template <int K16, int NTW, int NWAVES, int GLU>
 __device__ __forceinline__ void gemm_ws_split_tile(const mdt_gemm_args& a, int panel, int chunk, int tiles, char* lds,
                                                    const float* __restrict__ zeros, int tid) {
