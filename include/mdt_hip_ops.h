@@ -90,8 +90,8 @@ typedef struct {
     int64_t a_part_stride;
     float *a_merged;
     /* optional (round 6): the three-way bf16 split image of the same weight (mdt_op_pack_weight_split; rows in the order of Wp's).
-     * Where it is given, the LayerNorm-prologue products on the wide tiles (K <= 384 a multiple of 128, N a multiple of 384 or
-     * 256, more than 1400 rows, plain output rows) multiply in the split form -- six bf16 MFMA products per 32-deep step, fp32
+     * Where it is given, the LayerNorm-prologue products on the wide tiles (K = 384, N a multiple of 384, from 768 rows on
+     * -- MDT_HIP_SPLIT_MIN_ROWS --, plain output rows) multiply in the split form -- six bf16 MFMA products per 32-deep step, fp32
      * accumulation: fp32's product accuracy, not the fp32 form's bits -- unless mdt_op_set_mlp_split(0).  NULL: the fp32 form. */
     const void *Wp_split;
 } mdt_gemm_args;

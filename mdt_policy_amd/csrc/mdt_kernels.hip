@@ -1187,16 +1187,15 @@ static hipError_t launch_gemm_ln_split_pro(const mdt_gemm_args& a, hipStream_t s
         return a.mod_stride == 0 ? launch_gemm_ln_split_x<ND, NTW, PRO_LN_MOD_BCAST>(a, s) : launch_gemm_ln_split_x<ND, NTW, PRO_LN_MOD_ROWS>(a, s);
     return launch_gemm_ln_split_x<ND, NTW, PRO_LN>(a, s);
 }
-// which products take it: the split image is there, LayerNorm prologue over whole rows of K = 256 / 384, column count a multiple of the
-// 384- (or 256-) wide panels, plain output rows, and enough rows that the wide tiles are the choice anyway (the fused MLP's threshold)
+// which products take it: the split image is there, LayerNorm prologue over whole rows of K = 384, column count a multiple of the
+// 384-wide panels, plain output rows, and enough rows that the wide tiles are the choice anyway (the fused MLP's threshold)
 static bool gemm_ln_split_applies(const mdt_gemm_args& a) {
-    return a.Wp_split != nullptr && mdt_mlp_split_enabled() && a.ln && (a.K == 256 || a.K == 384) && (a.N % 384 == 0 || a.N % 256 == 0) &&
+    return a.Wp_split != nullptr && mdt_mlp_split_enabled() && a.ln && a.K == 384 && a.N % 384 == 0 &&
            a.M >= mdt_split_min_rows() && a.batch <= 1 && !a.residual && a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr && !a.aux_mode &&
            a.a_parts <= 4 && (a.lda & 3) == 0 && (a.ldo & 3) == 0 && g_mdt_gemm_force == 0;
 }
 static hipError_t launch_gemm_ln_split(const mdt_gemm_args& a, hipStream_t s) {
-    if (a.K == 384) return a.N % 384 == 0 ? launch_gemm_ln_split_pro<3, 3>(a, s) : launch_gemm_ln_split_pro<3, 2>(a, s);
-    return a.N % 384 == 0 ? launch_gemm_ln_split_pro<2, 3>(a, s) : launch_gemm_ln_split_pro<2, 2>(a, s);
+    return launch_gemm_ln_split_pro<3, 3>(a, s);   // (the tile is written for any D <= 384 and 256-wide panels too; instantiated for the model)
 }
 
 // ---- the fused MLP sublayer in the three-way bf16 split form (k_mlp_split) ----
