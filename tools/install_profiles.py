@@ -77,10 +77,12 @@ import json
 import re
 whole = re.search(r"whole run: MFMA busy ([0-9.]+)", read("bench_pmc.txt"))
 for l in read("bench_pmc.txt").splitlines():
-    if l.startswith("k_mlp<"):
+    if l.startswith("k_mlp<") or l.startswith("k_mlp_split<"):
         f = [x.strip() for x in l.split("|")]
         rd, wr = float(f[6]), float(f[7])
         M, D, N, S = 2560, 384, 1536, 3
+        split = l.startswith("k_mlp_split<")
+        wb = 6 if split else 4   # bytes per weight of the image the kernel reads (split: three bf16 parts)
         write("dominant_kernel_pmc.json", json.dumps({
             "commit": commit,
             "kernel": f"{f[0]} (LN + modulate -> c_fc -> GELU -> c_proj -> gate, {M} rows, d = {D}, hidden {N}; B = 256)",
@@ -91,9 +93,12 @@ for l in read("bench_pmc.txt").splitlines():
             "whole_run_mfma_busy": float(whole.group(1)) if whole else None,
             "units": "guide MI355X_MICROARCH.md 'HBM': EA read requests are 128-B requests on gfx950 (FETCH_SIZE = RDREQ x 64 B reports "
                      "half) -> x128 B; write requests x64 B (calibrated in round 1 on a GEMM whose output size is exact)",
-            "algorithmic_bytes_per_launch": 4 * (M * D + 2 * N * D + M * D),
-            "algorithmic_bytes_per_launch_with_slabs": 4 * (M * D + 2 * N * D + S * M * D),
-            "note": "reads exceed the truly algorithmic 12.6 MB (3.9 MB of rows + 4.7 MB of weights read once, 3.9 MB written) because each of the 8 XCD L2s fetches both 2.36 MB weight images once (served "
+            "algorithmic_bytes_per_launch": 4 * (M * D + M * D) + wb * 2 * N * D,
+            "algorithmic_bytes_per_launch_with_slabs": 4 * (M * D + S * M * D) + wb * 2 * N * D,
+            "note": ("split form (round 6): the two weight images are 3.5 MB each (6 bytes per weight), read by slice: the workgroups of a hidden slice "
+                     "(2.36 MB of the two images) run on neighbouring XCDs, so an L2 fetches one or two slices, not all three; every slice's "
+                     "workgroups read the 3.9 MB of rows again; the writes are exactly the three partial slabs (3 x 3.9 MB).  The hidden layer "
+                     "never leaves the CU.") if split else "reads exceed the truly algorithmic 12.6 MB (3.9 MB of rows + 4.7 MB of weights read once, 3.9 MB written) because each of the 8 XCD L2s fetches both 2.36 MB weight images once (served "
                     "by the 256 MB Infinity Cache, which these memory-side counters include): 8 x 4.7 + 3.9 MB of rows; the writes are "
                     "exactly the three partial slabs (3 x 3.9 MB).  The hidden layer (15.7 MB per launch in round 2) never leaves the CU."
         }, indent=2) + "\n")
