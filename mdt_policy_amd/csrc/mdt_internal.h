@@ -82,6 +82,8 @@ hipError_t mdt_launch_mlp_split(const mdt_gemm_args& fc, const mdt_gemm_args& pr
                                 int64_t part_stride, hipStream_t s);
 // (n_rows, K) row-major fp32 -> split image of 6 n_rows K bytes (n_rows % 16 == 0, K % 32 == 0)
 hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void* image, hipStream_t s, int n_off = 0);
+// the same image from the fp32 fragment image of the weight (mdt_launch_pack_weight's output for the whole (N, K) matrix)
+hipError_t mdt_launch_split_from_packed(const float* wp, int N, int K, void* image, hipStream_t s);
 hipError_t mdt_launch_attention(const mdt_attn_args& a, const float* rope_cos, const float* rope_sin, hipStream_t s);
 // one sample's self-attention fused into its output projection p (rollout batch 1); see mdt_kernels.hip
 bool mdt_attn_proj_supported(const mdt_gemm_args& p, int H, int hd, int T, int rope);

@@ -89,6 +89,29 @@ hipError_t mdt_launch_pack_weight_split(const float* w, int n_rows, int K, void*
     return hipGetLastError();
 }
 
+// the split image straight from the fp32 fragment image of the same weight (no raw weight needed): lane l of split fragment
+// (nt, kk, part) = the part of lane l's quads of fp32 fragments (nt, 2 kk) and (nt, 2 kk + 1)
+__global__ __launch_bounds__(256) void k_split_from_packed(const float* __restrict__ wp, int n_frag, int K32, char* __restrict__ image) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (nt * K32 + kk) * 64 + lane
+    if (idx >= (int64_t)n_frag * 64) return;
+    const int lane = (int)(idx & 63);
+    const int64_t f = idx >> 6;                                        // nt * K32 + kk
+    const f32x4 lo = *(const f32x4*)(wp + ((2 * f) * 64 + lane) * 4), hi = *(const f32x4*)(wp + ((2 * f + 1) * 64 + lane) * 4);
+    mdt_bf16x4 l1, l2, l3, h1, h2, h3;
+    split3_bf16(lo, l1, l2, l3);
+    split3_bf16(hi, h1, h2, h3);
+    char* q = image + f * 3072 + lane * 16;
+    *(mdt_bf16x8*)q = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *(mdt_bf16x8*)(q + 1024) = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+    *(mdt_bf16x8*)(q + 2048) = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+hipError_t mdt_launch_split_from_packed(const float* wp, int N, int K, void* image, hipStream_t s) {
+    if (N % 16 || K % 32) return hipErrorInvalidValue;
+    const int n_frag = (N / 16) * (K / 32);
+    hipLaunchKernelGGL(k_split_from_packed, dim3((unsigned)((n_frag * 64 + 255) / 256)), dim3(256), 0, s, wp, n_frag, K / 32, (char*)image);
+    return hipGetLastError();
+}
+
 // Every parameter image of one load_state_dict / optimizer step in ONE launch (mdt_load_params): a table of moves --
 // raw copies, fragment packs, transposed fragment packs (training), transposes, column pads -- and a (move, chunk) list,
 // one workgroup per 1024 source elements.  The per-parameter launches this replaces (~230 of 3-6 us for MDT-V) were

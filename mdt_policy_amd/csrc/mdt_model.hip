@@ -481,7 +481,11 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
                 dev_src = m->staging;
             }
         }
-        if (t->kind == SLOT_PACK_SPLIT) { HIP_TRY(mdt_launch_pack_weight_split(dev_src, t->rows, t->K, t->dst, s, t->n_off)); continue; }
+        if (t->kind == SLOT_PACK_SPLIT) {
+            if (m->train) { m->split_stale = true; continue; }   // training: re-made on demand (mdt_model_types.h)
+            HIP_TRY(mdt_launch_pack_weight_split(dev_src, t->rows, t->K, t->dst, s, t->n_off));
+            continue;
+        }
         if (t->kind == SLOT_TRANSPOSE) HIP_TRY(mdt_launch_transpose(dev_src, t->dst, t->rows, t->K, s));
         else if (t->kind == SLOT_PACK_T) HIP_TRY(mdt_launch_pack_weight_t(dev_src, t->rows, t->K, t->K, t->dst, 0, t->rows / 16, s));  // image of the transpose
         else HIP_TRY(mdt_launch_pack_weight(dev_src, t->rows, t->K, t->dst, t->n_off, s));
@@ -542,7 +546,10 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
             else if (t->kind == SLOT_PAD_COLS) add(srcs[i], t->dst, MDT_LOAD_PAD_COLS, t->rows, t->K, t->n_off, 0);
             else if (t->kind == SLOT_TRANSPOSE) add(srcs[i], t->dst, MDT_LOAD_TRANSPOSE, t->rows, t->K, 0, 0);
             else if (t->kind == SLOT_PACK_T) add(srcs[i], t->dst, MDT_LOAD_PACK_T, t->rows, t->K, 0, t->rows / 16);
-            else if (t->kind == SLOT_PACK_SPLIT) add(srcs[i], t->dst, MDT_LOAD_PACK_SPLIT, t->rows, t->K, t->n_off, 0);
+            else if (t->kind == SLOT_PACK_SPLIT) {
+                if (m->train) m->split_stale = true;   // training: re-made on demand (mdt_model_types.h)
+                else add(srcs[i], t->dst, MDT_LOAD_PACK_SPLIT, t->rows, t->K, t->n_off, 0);
+            }
             else {
                 add(srcs[i], t->dst, MDT_LOAD_PACK, t->rows, t->K, t->n_off, 0);
                 if (t->lin && t->lin->wt) add(srcs[i], t->lin->wt, MDT_LOAD_PACK_T, t->rows, t->K, t->n_off, t->lin->N / 16);
@@ -834,6 +841,22 @@ extern "C" mdt_status mdt_op_clock_stamp(uint64_t* out16, void* stream) {
     return MDT_OK;
 }
 
+// the split images of every block, re-made from the fp32 fragment images (after parameter loads that skipped them: split_stale)
+static mdt_status refresh_split(mdt_model* m, hipStream_t s) {
+    auto one = [&](const Lin& l) -> mdt_status {
+        if (l.ws) LAUNCH(mdt_launch_split_from_packed(l.wp, l.N, l.K, l.ws, s));
+        return MDT_OK;
+    };
+    for (const EncBlock& e : m->enc) { MDT_TRY(one(e.qkv)); MDT_TRY(one(e.fc)); MDT_TRY(one(e.proj2)); }
+    for (const DecBlock& d : m->dec) { MDT_TRY(one(d.qkv)); MDT_TRY(one(d.fc)); MDT_TRY(one(d.proj2)); }
+    m->split_stale = false;
+    return MDT_OK;
+}
+static inline mdt_status split_ready(mdt_model* m, int64_t rows, hipStream_t s) {
+    if (m->split_stale && mdt_mlp_split_enabled() && rows >= mdt_split_min_rows()) return refresh_split(m, s);
+    return MDT_OK;
+}
+
 // `out` (optional): when given and the fused launch applies, the sublayer's output is left as slabs in V.hid (described in
 // *out) and V.y is NOT updated -- the caller hands *out to the next reader; otherwise V.y is updated in place.
 // `pre_x` (optional; rollout batches): the collapsed cross-attention that is still to run on these rows -- it goes into the
@@ -934,6 +957,7 @@ static mdt_status run_encode(mdt_model* m, const float* tokens, const float* tok
     MDT_TRY(check_encode_args(m, tokens, tokens2, goal, ctx_out));
     MDT_TRY(check_loaded(m));
     MDT_TRY(mdt_reserve(m, B));
+    MDT_TRY(split_ready(m, B * std::max(m->Te, m->Ta), s));
     m->cached_batch = 0;
     const bool lang = honour_modality && c.use_modality_encoder && modality == MDT_MODALITY_LANG;
     const Lin& g0 = lang ? m->lang0 : m->goal0;
@@ -1054,6 +1078,7 @@ static mdt_status run_decoder_blocks(mdt_model* m, const View& V, int64_t B, con
     View W = V;  // W.y / W.att trade places whenever a block's cross-attention runs inside its c_fc launch (rollout batches)
     Stream cur;  // where the residual stream lives between blocks
     if (fin) *fin = Stream();
+    MDT_TRY(split_ready(m, M, s));
     for (int l = 0; l < m->Ld; ++l) {
         const DecBlock& d = m->dec[l];
         ModRef ma, mx, mm;  // self-attention half, cross-attention query, MLP half

@@ -65,6 +65,10 @@ struct mdt_model {
     std::vector<Slot> slots;   // one per parameter the path reads (enumerated by mdt_param_*)
     std::vector<Slot> extra;   // additional images of an already listed parameter (same name)
     std::vector<LinPart> parts;
+    // the split images (Lin.ws) are NOT rewritten by parameter loads while a training state exists (an optimizer step re-packs every
+    // fp32 image; the split ones are only read by large-batch sampling): marked stale instead, re-made from the fp32 images by the next
+    // model-level call that would read them (refresh_split, mdt_model.hip)
+    bool split_stale = false;
     mdt_train_state* train = nullptr;  // non-null after mdt_train_prepare()
     Lin tok, incam, goal0, goal2, lang0, lang2, sig1, sig3, kv_all, mod_all;
     // proprioceptive token (cfg.use_proprio, MDT-V): proprio_emb = Linear(Pd, 2D) -> Mish -> Linear(2D, D)

@@ -765,3 +765,52 @@ def test_training_step_with_the_bf16_split_products_equals_the_fp32_products_to_
         assert err <= 2e-5 * scale + floor, f"{n}: split and fp32 products differ by {err:.3g} at max |g| = {scale:.3g}"
     print(f"worst |split - fp32| / max |g| over {len(res[0])} tensors: {worst:.3g}")
     assert differs, "the split form did not run: every gradient has the fp32 products' bits"
+
+
+@pytest.mark.gpu
+def test_large_batch_sampling_after_optimizer_steps_reads_fresh_split_images():
+    """Round 6: large-batch sampling (>= 768 rows a launch) multiplies pre-split bf16 images of the MLP / qkv weights.  While a training
+    state exists, parameter loads do not rewrite those images (every optimizer step would); they are marked stale and re-made from the
+    fp32 fragment images by the next call that reads them.  After two optimizer steps a B = 128 sampler call must give the BITS of a
+    fresh model that loaded the same weights (whose images come from the raw weights), differ from the fp32 launches' bits (the split
+    form ran) and agree with them to fp32 rounding."""
+    from mdt_policy_amd import _lib, configs
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    L = _lib.load()
+    cfg = configs.mdtv_default()
+    torch.manual_seed(0)
+    model = GCDenoiser(cfg, 0.5).cuda()
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 5, "rich").items()}, strict=False)
+    sig = gs.get_sigmas_exponential(5, 0.001, 80.0).cuda()
+    big = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(128, cfg, 3).items()}
+    st_big = {"state_images": big["state_images"], "modality": "lang"}
+    with torch.no_grad():
+        model.eval()
+        before = model.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()   # images of the initial weights in use
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    tr = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(64, cfg, 1).items()}
+    li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(64, cfg, 2).items()}
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model.loss({"state_images": tr["state_images"], "modality": "lang"}, li["actions"], tr["goal"], li["noise_train"], li["sigma"])
+        loss.backward()
+        opt.step()
+    model.eval()
+    with torch.no_grad():
+        got = model.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
+        fresh = GCDenoiser(cfg, 0.5).cuda().eval()
+        fresh.load_state_dict(model.state_dict())
+        want = fresh.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
+        try:
+            L.mdt_op_set_mlp_split(0)
+            fp32 = fresh.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
+        finally:
+            L.mdt_op_set_mlp_split(-1)
+    torch.cuda.synchronize()
+    assert not torch.equal(got, before), "the optimizer steps did not change the sampler's output"
+    assert torch.equal(got, want), "sampling after optimizer steps read stale split images"
+    assert not torch.equal(want, fp32), "the split launches did not run at B = 128"
+    assert_close(want.cpu(), fp32.cpu(), rtol=1e-4, atol=1e-4, what="split against fp32 launches, B = 128 sampler call")
