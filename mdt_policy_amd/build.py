@@ -25,18 +25,18 @@ def _hipcc() -> str:
     return exe
 
 
+HEADERS = ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_tall.h", "mdt_ws.h", "mdt_mlp_split.h"]
+PUBLIC_HEADERS = ["mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h"]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_tall.h", "mdt_ws.h"]]
-    deps += [os.path.join(INCLUDE, f) for f in ("mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps += [os.path.join(INCLUDE, f) for f in PUBLIC_HEADERS]
     deps.append(os.path.abspath(__file__))
     return any(os.path.getmtime(d) > t for d in deps)
-
-
-HEADERS = ["mdt_internal.h", "mdt_device.h", "mdt_model_types.h", "mdt_tiles.h", "mdt_tall.h", "mdt_ws.h"]
-PUBLIC_HEADERS = ["mdt_hip.h", "mdt_hip_ops.h", "mdt_resampler.h", "mdt_map_pool.h", "mdt_hip_train.h", "mdt_mae.h"]
 
 
 def _compile_one(args):

@@ -28,26 +28,41 @@
 #include "mdt_tiles.h"
 #include "mdt_ws.h"   // mdt_bf16x8 / mdt_bf16x4, split3_bf16
 
-__device__ __forceinline__ mdt_bf16x8 ldw_split(const char* p) { return __builtin_bit_cast(mdt_bf16x8, *(const f32x4*)p); }
-
-// ring of R k32 steps x NT column tiles x 3 parts of weight fragments; fragment (j, kk, p) at w + j * tile_stride + (kk * 3 + p) * 1024
+// ring of R k32 steps x NT column tiles x 3 parts of weight fragments.  Fragment (j, kk, p) of the wave sits at byte
+// base + j * tile_stride + (kk * 3 + p) * 1024 of the image, lane l's 16 bytes at l * 16.  BUFFER loads (resource = the image, one
+// 32-bit per-lane offset per column tile, the step / part offset in the scalar operand): a global_load sends 64 x 8 bytes of address
+// through the SIMD's register read path, 33 clocks of matrix-pipe time against 17.7 (mdt_tiles.h WStream) -- and this form requests
+// 1.5x the fragments of the fp32 one per step.
 template <int NT, int R>
 struct SplitRing {
     mdt_bf16x8 w[R][NT][3];
-    __device__ __forceinline__ void request(int slot, const char* wl, int64_t tile_stride, int kk) {
+    __amdgpu_buffer_rsrc_t rs;
+    const char* gbase;
+    unsigned voff[NT];
+    __device__ __forceinline__ void open(const void* image, int64_t first_byte, int64_t tile_stride, int lane) {
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)image, 0, 0xffffffffu, 0x00020000);
+        gbase = (const char*)image;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) voff[j] = (unsigned)(first_byte + j * tile_stride) + 16u * (unsigned)lane;
+    }
+    __device__ __forceinline__ void request(int slot, int kk) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) w[slot][j][p] = ldw_split(wl + j * tile_stride + (kk * 3 + p) * 1024);
+            for (int p = 0; p < 3; ++p)
+#ifdef MDT_SPLIT_W_GLOBAL   // A/B build: 64-bit global loads
+                w[slot][j][p] = __builtin_bit_cast(mdt_bf16x8, *(const f32x4*)(gbase + voff[j] + (kk * 3 + p) * 1024));
+#else
+                w[slot][j][p] = __builtin_bit_cast(mdt_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], (kk * 3 + p) * 1024, 0));
+#endif
     }
 };
 
-// one product phase: acc[i][j] += sum over K32 k32 steps; `wl` = the wave's first fragment + lane * 16; ring slots 0 .. R - 2 hold
-// steps 0 .. R - 2 on entry (requested by the caller, early); activations from the split tile at `xa` (row stride rowb, part
+// one product phase: acc[i][j] += sum over K32 k32 steps; ring slots 0 .. R - 2 hold steps 0 .. R - 2 on entry (requested by the
+// caller, early); activations from the split tile at `xa` (row stride rowb, part
 // stride part)
 template <int NT, int K32, int R>
-__device__ __forceinline__ void split_phase(SplitRing<NT, R>& ring, const char* wl, int64_t tile_stride, const char* xa, int rowb, int part,
-                                            int lane, f32x4 (&acc)[2][NT]) {
+__device__ __forceinline__ void split_phase(SplitRing<NT, R>& ring, const char* xa, int rowb, int part, int lane, f32x4 (&acc)[2][NT]) {
     const int aoff = (lane & 15) * rowb + (lane >> 4) * 16;
     mdt_bf16x8 x1[2], x2[2], x3[2];
 #pragma unroll
@@ -59,7 +74,7 @@ __device__ __forceinline__ void split_phase(SplitRing<NT, R>& ring, const char* 
     for (int kk = 0; kk < K32; ++kk) {
         const int u = kk % R, un = (kk + R - 1) % R;
         const bool nx = kk + 1 < K32;
-        if (kk + R - 1 < K32) ring.request(un, wl, tile_stride, kk + R - 1);
+        if (kk + R - 1 < K32) ring.request(un, kk + R - 1);
         const char* p0 = xa + aoff + (kk + 1) * 64;
         const char* p1 = p0 + 16 * rowb;
         MDT_SCHED_PIN
@@ -130,10 +145,10 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
 
     // ---- first product's operands: the ring's first step and the bias travel under the prologue ----
     const int nt1 = (s * NWAVES + wave) * NTW1;       // hidden column tiles of this wave (global)
-    const char* wl1 = w1s + (int64_t)nt1 * K32a * 3072 + lane * 16;
     SplitRing<NTW1, R> ring1;
+    ring1.open(w1s, (int64_t)nt1 * K32a * 3072, (int64_t)K32a * 3072, lane);
 #pragma unroll
-    for (int u = 0; u < R - 1; ++u) ring1.request(u, wl1, (int64_t)K32a * 3072, u);
+    for (int u = 0; u < R - 1; ++u) ring1.request(u, u);
     f32x4 b1[NTW1];
     {
         const float* bp = f.bias != nullptr ? f.bias : zeros;
@@ -148,15 +163,15 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
     for (int i = 0; i < MTILES; ++i)
 #pragma unroll
         for (int j = 0; j < NTW1; ++j) acc1[i][j] = zero4;
-    split_phase<NTW1, K32a, R>(ring1, wl1, (int64_t)K32a * 3072, xs, ROWB1, PART1, lane, acc1);
+    split_phase<NTW1, K32a, R>(ring1, xs, ROWB1, PART1, lane, acc1);
 
     // ---- second product's operands, requested before the activation epilogue so that they travel while it runs: the first
     //      fragments of W2's K slice [512 s, 512 s + 512), then bias / gate / residual rows of the output tile ----
     const int K32p = p.K >> 5;                        // k32 steps of the whole second product (4 D / 32)
-    const char* wl2 = w2s + ((int64_t)(wave * NTW2) * K32p + (int64_t)s * K32b) * 3072 + lane * 16;
     SplitRing<NTW2, R> ring2;
+    ring2.open(w2s, ((int64_t)(wave * NTW2) * K32p + (int64_t)s * K32b) * 3072, (int64_t)K32p * 3072, lane);
 #pragma unroll
-    for (int u = 0; u < R - 1; ++u) ring2.request(u, wl2, (int64_t)K32p * 3072, u);
+    for (int u = 0; u < R - 1; ++u) ring2.request(u, u);
     f32x4 acc2[MTILES][NTW2], b2[NTW2], gate_v[MTILES][NTW2], res_v[MTILES][NTW2];
     int ncol[NTW2];
 #pragma unroll
@@ -194,7 +209,7 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
             *(mdt_bf16x4*)(q + 2 * PART2) = p3;
         }
     __syncthreads();
-    split_phase<NTW2, K32b, R>(ring2, wl2, (int64_t)K32p * 3072, hs, ROWB2, PART2, lane, acc2);
+    split_phase<NTW2, K32b, R>(ring2, hs, ROWB2, PART2, lane, acc2);
 
     float* out = parts + (int64_t)s * part_stride;
 #pragma unroll
@@ -226,10 +241,10 @@ __device__ __forceinline__ void gemm_ln_split_tile(const mdt_gemm_args& a, int b
     const int m0 = by * MT, nq = 4 * (lane >> 4);
     char* xs = lds;
     const int nt0 = (bx * NWAVES + wave) * NTW;       // N is a multiple of the panel width: every wave has NTW real column tiles
-    const char* wl = (const char*)a.Wp_split + (int64_t)nt0 * K32 * 3072 + lane * 16;
     SplitRing<NTW, R> ring;
+    ring.open(a.Wp_split, (int64_t)nt0 * K32 * 3072, (int64_t)K32 * 3072, lane);
 #pragma unroll
-    for (int u = 0; u < R - 1; ++u) ring.request(u, wl, (int64_t)K32 * 3072, u);
+    for (int u = 0; u < R - 1; ++u) ring.request(u, u);
     f32x4 bias_v[NTW];
     {
         const float* bp = a.bias != nullptr ? a.bias : zeros;
@@ -244,7 +259,7 @@ __device__ __forceinline__ void gemm_ln_split_tile(const mdt_gemm_args& a, int b
     for (int i = 0; i < MTILES; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = zero4;
-    split_phase<NTW, K32, R>(ring, wl, (int64_t)K32 * 3072, xs, ROWB, PART, lane, acc);
+    split_phase<NTW, K32, R>(ring, xs, ROWB, PART, lane, acc);
 #pragma unroll
     for (int i = 0; i < MTILES; ++i) {
         const int m = m0 + i * 16 + (lane & 15);
