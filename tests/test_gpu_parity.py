@@ -205,7 +205,9 @@ def test_against_oracle_random_batch_sizes():
 # of per-sample workgroups (B = 257 ... 512), and the first batch beyond it (B = 513: k_attn + GEMM + k_xattn_apply again)
 # (round 5: B = 9 ... 32 run the self-attention inside its projection launch like the rollout batches -- B = 12, 16, 20, 32; B = 33 is
 #  the first batch back on k_attn + projection)
-REGIME_BATCHES = (12, 16, 20, 32, 33, 64, 128, 140, 141, 257, 300, 512, 513)
+# (round 6: from 768 rows a launch the MLP sublayer runs fused and, like the qkv products, as three-way bf16 splits: the decoder from
+#  B = 77 -- 76 is the last fp32 batch --, the encoder's four-token rows from B = 192)
+REGIME_BATCHES = (12, 16, 20, 32, 33, 64, 76, 77, 128, 140, 141, 192, 257, 300, 512, 513)
 
 
 @pytest.mark.parametrize("B", REGIME_BATCHES)
