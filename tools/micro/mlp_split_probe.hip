@@ -4,7 +4,7 @@
 // a wave requests 3 parts x NT column tiles of PRE-SPLIT weight fragments (16 B per lane each) from a 2.36 MB-per-slice image all the
 // workgroups of a slice share, and reads its activation fragments (3 parts x 2 row tiles) from LDS.  No LayerNorm staging, garbage
 // data; the GELU + re-split epilogue between the phases is there (VALU + LDS stores).  Compare with k_mlp's 51-55 us.
-// build + run: hipcc --offload-arch=gfx950 -O3 tools/micro/mlp_split_probe.hip -o /tmp/p && /tmp/p
+// build + run: hipcc --offload-arch=gfx950 -O3 tools/micro/mlp_split_probe.hip -o tools/micro/bin/mlp_split_probe && tools/micro/bin/mlp_split_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
