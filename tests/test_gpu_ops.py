@@ -1128,6 +1128,7 @@ def test_layernorm_gemm_in_its_bf16_split_form_keeps_fp32_accuracy(lib, M, N, D,
         lib.check(lib.load().mdt_op_pack_weight_split_rows(Wd[lo:hi].contiguous().data_ptr(), hi - lo, D, S.data_ptr(), lo, stream()))
     assert torch.equal(S, pack_split(lib, W)), "row-range packs differ from the one-piece image"
     err = {}
+    lib.load().mdt_op_set_mlp_split(1)   # (whatever MDT_HIP_MLP_SPLIT says: this test is about the split form)
     for split in (False, True):
         out = torch.full((M, N), float("nan"), device="cuda")
         merged = torch.full((M, D), float("nan"), device="cuda")
@@ -1152,6 +1153,7 @@ def test_layernorm_gemm_in_its_bf16_split_form_keeps_fp32_accuracy(lib, M, N, D,
             res_split = out.cpu()
         else:
             res_fp32 = out.cpu()
+    lib.load().mdt_op_set_mlp_split(-1)
     assert not torch.equal(res_split, res_fp32), "the split form did not run"
     assert err[True] <= 1.5 * err[False] + 1e-6, f"split form: max error {err[True]:.3g} against the fp32 form's {err[False]:.3g}"
 

@@ -5,6 +5,8 @@ oracle's restatement -- block internals parity-unpinned, see oracle/mae_oracle.p
 GPU: the HIP ops against float64 PyTorch, the facade against the goldens and against float64 autograd through the oracle."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -384,7 +386,8 @@ def test_swiglu_on_the_gemm_epilogues(M, K, H):
         y_sp, dx_sp = run(0, 1)
         if K == 192:   # (other K: the products are not on the weight-stationary body at all)
             assert not torch.equal(y_sp, y_ws) and not torch.equal(dx_sp, dx_ws), "the bf16 split form did not run"
-        assert torch.equal(y_sp, y.detach()) and torch.equal(dx_sp, x.grad), "the split form is not the default"
+        if os.environ.get("MDT_HIP_WS_SPLIT", "1") != "0":
+            assert torch.equal(y_sp, y.detach()) and torch.equal(dx_sp, x.grad), "the split form is not the default"
         for name, got, want in (("y", y_sp, y_ws), ("dx", dx_sp, dx_ws)):
             err, sc = float((got - want).abs().max()), float(want.abs().max())
             assert err <= 1e-5 * sc, f"{name}: split against fp32 products {err:.3g} at max {sc:.3g}"

@@ -786,6 +786,7 @@ def test_large_batch_sampling_after_optimizer_steps_reads_fresh_split_images():
     sig = gs.get_sigmas_exponential(5, 0.001, 80.0).cuda()
     big = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(128, cfg, 3).items()}
     st_big = {"state_images": big["state_images"], "modality": "lang"}
+    L.mdt_op_set_mlp_split(1)   # (whatever MDT_HIP_MLP_SPLIT says: this test is about the split images)
     with torch.no_grad():
         model.eval()
         before = model.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()   # images of the initial weights in use
@@ -803,8 +804,8 @@ def test_large_batch_sampling_after_optimizer_steps_reads_fresh_split_images():
         got = model.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
         fresh = GCDenoiser(cfg, 0.5).cuda().eval()
         fresh.load_state_dict(model.state_dict())
-        want = fresh.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
         try:
+            want = fresh.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
             L.mdt_op_set_mlp_split(0)
             fp32 = fresh.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
         finally:
