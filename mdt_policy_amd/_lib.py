@@ -177,6 +177,7 @@ SYMBOLS = [
     ("mdt_op_trace_mlp_read_empty", _I32, [_VP, _I32]),
     ("mdt_op_clock_stamp", _I32, [_VP, _VP]),
     ("mdt_op_set_ws_split", None, [_I32]),
+    ("mdt_op_set_tn_split", None, [_I32]),
     ("mdt_loss_fwd", _I32, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     ("mdt_flops_per_chunk", C.c_double, [_VP, _I32]),
     ("mdt_fnv1_32", C.c_uint32, [C.c_char_p, C.c_uint64, C.c_uint32]),

@@ -2070,6 +2070,196 @@ __global__ __launch_bounds__(256 * WN) void k_gemm_tn(const float* __restrict__ 
     if (do_bias && n0 + tid < N) bpart[(int64_t)z * N + n0 + tid] = bsum;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gemm_tn_split: the same product with every operand as a THREE-WAY bf16 SPLIT (round 6; mdt_ws.h):
+// six v_mfma_f32_16x16x32_bf16 products per 32 rows of m instead of eight v_mfma_f32_16x16x4_f32 per 4 -- fp32 product accuracy,
+// a third of the matrix-pipe time.  The reduction index m is the slow index of both operands, and a bf16 MFMA wants EIGHT
+// consecutive m of one column per lane: the staging threads transpose on the way into LDS.  Thread = (column quad q, four rows
+// 4 h .. 4 h + 3 of the 32-row chunk): four 16-byte loads (rows of one 128-byte line per eight lanes), per column the four m-values
+// split into three bf16x4 and stored as 8 bytes at [part][column][8 h]; a fragment read is one ds_read_b128 at [part][column][16 g].
+// Column stride 80 bytes: the 8-byte stores of a 16-lane group (two column quads x 8 h) are conflict-free, the reads two-way.
+//   workgroup = 8 waves, tile = 128 (n) x TK (k: 128 or 192); wave (wn, wk) = (n half of 64, k quarter of TK / 4): 4 x TK / 64
+//   accumulators; chunks of 32 rows double-buffered through registers (next chunk's loads in flight during the MFMAs).
+//   MFMA roles: A <- X (i = k column), B <- dY (j = n column): a lane ends with 4 consecutive k of one n, 16-byte stores.
+//   Slices, partial outputs and the bias gradient's per-slice column sums as in k_gemm_tn.
+// ------------------------------------------------------------------------------------------------
+template <int KTW>   // 16-wide k-tiles per wave: 2 (TK = 128) or 3 (TK = 192)
+__global__ __launch_bounds__(512) void k_gemm_tn_split(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
+                                                       float* __restrict__ out, int64_t slice_stride, int M, int N, int K, int L,
+                                                       int accumulate, float* __restrict__ bpart, int xcd) {
+    constexpr int CM = 32, TN_ = 128, TK = 64 * KTW, NC = TN_ + TK, S = 80, PART = NC * S, BUF = 3 * PART;
+    constexpr int NQ = NC / 4, NI = NQ * 8, NU = (NI + 511) / 512;   // column quads, staging items (quad, 4-row group), items per thread
+    extern __shared__ __attribute__((aligned(16))) char tns_lds[];      // 2 buffers x 3 parts x NC columns x 80 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave & 3, wn = wave >> 2;
+    const int gk = (K + TK - 1) / TK;
+    int id = blockIdx.x + gridDim.x * blockIdx.z;
+    if (xcd) {   // whole slices behind one L2 (k_gemm_tn)
+        const int nb = gridDim.x * gridDim.z, q = nb >> 3, r = nb & 7, x8 = id & 7, idx = id >> 3;
+        id = (x8 < r ? x8 * (q + 1) : r * (q + 1) + (x8 - r) * q) + idx;
+    }
+    const int z = id / (int)gridDim.x, tile = id - z * (int)gridDim.x;
+    const int bn = tile / gk, bk = tile - bn * gk;
+    const int n0 = bn * TN_, k0 = bk * TK;
+    const int m_lo = z * L, m_hi = min(M, m_lo + L);
+    out += (int64_t)z * slice_stride;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- staging items of this thread: item t = tid + 512 u -> rows 4 (t % 8) .. + 3 of the chunk, column quad t / 8 (dY quads first) ----
+    int ih[NU], icol[NU];          // first row of the group; LDS column of the quad's first column (-1: no item)
+    const float* isrc[NU];         // global address of (row 0 of the chunk's group, quad) at chunk 0
+    int64_t ild[NU];
+    bool iy[NU], ivalid[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int t = tid + 512 * u, h = t & 7, q = t >> 3;
+        ivalid[u] = t < NI;
+        ih[u] = 4 * h;
+        const bool y = q < TN_ / 4;
+        iy[u] = y;
+        const int c = y ? 4 * q : 4 * (q - TN_ / 4);            // column inside the tile's dY / X part
+        icol[u] = y ? c : TN_ + c;
+        const int gc = y ? min(n0 + c, N - 4) : min(k0 + c, K - 4);   // clamped global column (zeros are selected at the store)
+        ild[u] = y ? ldy : ldx;
+        isrc[u] = (y ? dY : X) + gc;
+        ivalid[u] = ivalid[u] && (y ? n0 + c < N : k0 + c < K);
+    }
+    f32x4 stg[NU][4];
+    auto fetch = [&](int mb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = min(mb + ih[u] + r, m_hi - 1);
+                stg[u][r] = ldg4(isrc[u] + m * ild[u]);
+            }
+    };
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};   // dY items of k-tile-0 workgroups: column sums of this thread's rows (bias gradient)
+    const bool do_bias = bpart != nullptr && bk == 0;
+    auto stash = [&](char* buf, int mb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (tid + 512 * u >= NI) continue;
+            f32x4 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (ivalid[u] && mb + ih[u] + r < m_hi) ? stg[u][r] : zero4;
+            if (u == 0 && do_bias && iy[0]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mdt_bf16x4 p1, p2, p3;
+                split3_bf16((f32x4){v[0][e], v[1][e], v[2][e], v[3][e]}, p1, p2, p3);
+                char* q = buf + (icol[u] + e) * S + 2 * ih[u];
+                *(mdt_bf16x4*)q = p1;
+                *(mdt_bf16x4*)(q + PART) = p2;
+                *(mdt_bf16x4*)(q + 2 * PART) = p3;
+            }
+        }
+    };
+    f32x4 acc[KTW][4];
+#pragma unroll
+    for (int i = 0; i < KTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int nchunks = (m_hi - m_lo + CM - 1) / CM;
+    if (nchunks > 0) {
+        fetch(m_lo);
+        stash(tns_lds, m_lo);
+    }
+    __syncthreads();
+    const int xoff = (TN_ + 16 * (KTW * wk) + l16) * S + 16 * g;   // + 16 it * S
+    const int yoff = (16 * (4 * wn) + l16) * S + 16 * g;           // + 16 jt * S
+    for (int c = 0; c < nchunks; ++c) {
+        const char* cur = tns_lds + (c & 1) * BUF;
+        if (c + 1 < nchunks) fetch(m_lo + (c + 1) * CM);
+        mdt_bf16x8 xf[3][KTW], yf[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < KTW; ++i) xf[p][i] = *(const mdt_bf16x8*)(cur + p * PART + xoff + 16 * i * S);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yf[p][j] = *(const mdt_bf16x8*)(cur + p * PART + yoff + 16 * j * S);
+        }
+        // the six products, smallest first: x3 y1, x2 y2, x2 y1, x1 y3, x1 y2, x1 y1
+#define MDT_TNS_PROD(PX, PY)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < KTW; ++i)                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[PX][i], yf[PY][j], acc[i][j], 0, 0, 0);
+        MDT_TNS_PROD(2, 0)
+        MDT_TNS_PROD(1, 1)
+        MDT_TNS_PROD(1, 0)
+        MDT_TNS_PROD(0, 2)
+        MDT_TNS_PROD(0, 1)
+        MDT_TNS_PROD(0, 0)
+#undef MDT_TNS_PROD
+        if (c + 1 < nchunks) stash(tns_lds + ((c + 1) & 1) * BUF, m_lo + (c + 1) * CM);
+        __syncthreads();
+    }
+    // lane holds out[n0 + 16 (4 wn + j) + l16][k0 + 16 (KTW wk + i) + 4 g .. + 3]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 16 * (4 * wn + j) + l16;
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) {
+            const int k = k0 + 16 * (KTW * wk + i) + 4 * g;
+            if (n < N && k < K) {
+                float* p = out + (int64_t)n * K + k;
+                f32x4 v = acc[i][j];
+                if (accumulate) v += *(const f32x4*)p;
+                *(f32x4*)p = v;
+            }
+        }
+    }
+    if (do_bias && iy[0]) {   // the eight row groups of a column quad are eight consecutive lanes: add them in a fixed order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = bs[e];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            bs[e] = v;
+        }
+        const int q = tid >> 3, n = n0 + 4 * q;
+        if ((tid & 7) == 0 && tid + 0 < NI) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < N) bpart[(int64_t)z * N + n + e] = bs[e];
+        }
+    }
+}
+static int g_tn_split = -1;   // MDT_HIP_TN_SPLIT / mdt_op_set_tn_split: 0 = the fp32 MFMA kernel everywhere
+bool mdt_gemm_tn_split_on() {
+    if (g_tn_split < 0) { const char* e = getenv("MDT_HIP_TN_SPLIT"); g_tn_split = e ? atoi(e) : 1; }
+    return g_tn_split != 0;
+}
+extern "C" void mdt_op_set_tn_split(int32_t on) { g_tn_split = on < 0 ? -1 : (on != 0); }
+// k-tile of the split kernel for a K-column product: 192 where that pads K less
+int mdt_gemm_tn_split_ktile(int K) { return (K + 191) / 192 * 192 < (K + 127) / 128 * 128 ? 192 : 128; }
+template <int KTW>
+static hipError_t launch_gemm_tn_split_t(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M,
+                                         int N, int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
+    constexpr int TK = 64 * KTW;
+    constexpr size_t lds = (size_t)2 * 3 * (128 + TK) * 80;
+    static bool attr_dev[32] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (!attr_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_dev[dev] = true;
+    }
+    hipLaunchKernelGGL((k_gemm_tn_split<KTW>), dim3(((N + 127) / 128) * ((K + TK - 1) / TK), 1, S), dim3(512), lds, s, dY, ldy, X, ldx, out,
+                       slice_stride, M, N, K, L, accumulate, bpart, S > 1 ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t mdt_launch_gemm_tn_split(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
+                                    int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
+    if (M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || S < 1) return hipErrorInvalidValue;
+    return mdt_gemm_tn_split_ktile(K) == 192 ? launch_gemm_tn_split_t<3>(dY, ldy, X, ldx, out, slice_stride, M, N, K, S, L, accumulate, bpart, s)
+                                              : launch_gemm_tn_split_t<2>(dY, ldy, X, ldx, out, slice_stride, M, N, K, S, L, accumulate, bpart, s);
+}
+
 // dW partials of S row slices of L rows: out + z * slice_stride is slice z's (N, K) product; N, K multiples of 16
 // (16-byte aligned rows).  bpart: nullptr or (S, N) per-slice column sums of dY.
 // (KT, WN) instantiation behind a shape.  n-tile: 192 wide (12 waves, needs N and K multiples of 192: every Linear of this model)

@@ -136,9 +136,24 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsu
         // the bias gradient's per-slice column sums added up in a fixed order afterwards
         int S, L;
         split_rows_tn(a.M, a.N, a.K, &S, &L);
+        // from 8192 rows on: the bf16 split kernel, ONE round of its one-per-CU workgroups (never more slices than the fp32 tiling
+        // takes: the scratch bound is that tiling's)
+        const bool tn_split = a.M >= 8192 && mdt_gemm_tn_split_on();
+        if (tn_split) {
+            const int64_t tiles = ((a.N + 127) / 128) * ((a.K + mdt_gemm_tn_split_ktile(a.K) - 1) / mdt_gemm_tn_split_ktile(a.K));
+            int64_t s2 = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((256 + tiles / 2) / tiles, S), a.M / 256));
+            if (no_splitk()) s2 = 1;
+            const int64_t l2 = ((a.M + s2 - 1) / s2 + 31) / 32 * 32;
+            S = (int)((a.M + l2 - 1) / l2);
+            L = (int)l2;
+        }
         float* parts = a.scratch;                              // [S][N][K] (S > 1)
         const bool defer = a.dbias && defer_bias && bias_space && S <= 256;
         float* bpart = defer ? bias_space : parts + (int64_t)S * a.N * a.K;  // [S][N]
+        if (tn_split)
+            LAUNCH(mdt_launch_gemm_tn_split(a.dY, a.ldy, a.X, a.ldx, S > 1 ? parts : a.dW, (int64_t)a.N * a.K, a.M, a.N, a.K, S, L,
+                                            S > 1 ? 0 : a.accumulate_dw, a.dbias ? bpart : nullptr, s));
+        else
         LAUNCH(mdt_launch_gemm_tn(a.dY, a.ldy, a.X, a.ldx, S > 1 ? parts : a.dW, (int64_t)a.N * a.K, a.M, a.N, a.K, S, L,
                                   S > 1 ? 0 : a.accumulate_dw, a.dbias ? bpart : nullptr, s));
         if (S > 1) LAUNCH(mdt_launch_colsum(parts, (int64_t)a.N * a.K, S, a.N * a.K, a.dW, a.accumulate_dw, s));

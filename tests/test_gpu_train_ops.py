@@ -427,6 +427,41 @@ def test_weight_gradient_wide_tiles(lib, M, N, K):
     assert_close(db.cpu(), dY.double().sum(0).cpu(), what="dbias", **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(8200, 384, 384), (12288, 1536, 384), (12288, 384, 1536), (33000, 192, 768), (40000, 1536, 192),
+                                   (33000, 576, 192), (8192 + 31, 208, 80), (10000, 64, 128)])
+def test_weight_gradient_as_bf16_splits_keeps_fp32_accuracy(lib, M, N, K):
+    """Round 6: from 8192 reduction rows on dW = dY^T X runs as three-way bf16 splits of both operands (k_gemm_tn_split: six bf16
+    MFMA products per 32 rows, operands transposed into m-contiguous octets on their way into LDS).  Against float64: the error
+    of dW and of the bias gradient within 2.5x the fp32 MFMA kernel's on the same inputs (rows of very different scale), ragged
+    slices and tiles (N, K not multiples of the 128 x 128 / 128 x 192 tile), accumulation into dW."""
+    L = lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    X = torch.randn(M, K, device="cuda", generator=g) * torch.exp(1.5 * torch.randn(M, 1, device="cuda", generator=g))
+    dY = torch.randn(M, N, device="cuda", generator=g)
+    dW0 = torch.randn(N, K, device="cuda", generator=g)
+    ref_W, ref_b = dY.double().T @ X.double(), dY.double().sum(0)
+    err = {}
+    try:
+        for split in (0, 1):
+            L.mdt_op_set_tn_split(split)
+            dW, db = dW0.clone(), torch.zeros(N, device="cuda")
+            scratch = torch.empty(L.mdt_op_linear_bwd_scratch(M, N, K), device="cuda")
+            a = lib.LinearBwdArgs(X=X.data_ptr(), ldx=K, dY=dY.data_ptr(), ldy=N, Wt=None, dW=dW.data_ptr(), dbias=db.data_ptr(), dX=None,
+                                  ldxo=K, accumulate_dw=1, accumulate_dx=0, M=M, N=N, K=K, scratch=scratch.data_ptr())
+            lib.check(L.mdt_op_linear_bwd(C.byref(a), stream()))
+            torch.cuda.synchronize()
+            err[split] = (((dW - dW0).double() - ref_W).abs().max().item(), (db.double() - ref_b).abs().max().item(), (dW - dW0).clone())
+            tol = dict(rtol=1e-3, atol=1e-4 * (M / 64) ** 0.5 * float(X.abs().max()))
+            assert_close((dW - dW0).cpu(), ref_W.cpu(), what=f"dW (split {split})", **tol)
+    finally:
+        L.mdt_op_set_tn_split(-1)
+    assert not torch.equal(err[0][2], err[1][2]), "the split kernel did not run (same bits as the fp32 kernel)"
+    # (2.5x, not the 1.5x of the other split forms: the split kernel also reduces over fewer, deeper row slices -- one round of its
+    #  one-per-CU workgroups -- and a deeper fp32 accumulation chain has the larger rounding error whatever the products are)
+    assert err[1][0] <= 2.5 * err[0][0] + 1e-6, f"dW: split error {err[1][0]:.3g} against the fp32 kernel's {err[0][0]:.3g}"
+    assert err[1][1] <= 2.5 * err[0][1] + 1e-4, f"dbias: split path {err[1][1]:.3g} against the fp32 kernel's {err[0][1]:.3g}"
+
+
 @pytest.mark.parametrize("M,N,K", [(2560, 1536, 384), (1280, 384, 1536), (1024, 1152, 384), (250, 384, 384), (37, 768, 512),
                                    (3, 64, 128), (128, 9216, 384)])
 def test_linear_backward_through_the_forward_gemm(lib, M, N, K):
