@@ -11,8 +11,8 @@ from mdt_policy_amd import _lib
 
 lib = _lib.load()
 s = torch.cuda.current_stream().cuda_stream
-shapes = [(104448, 1536, 192), (104448, 192, 768), (104448, 576, 192), (104448, 192, 192), (10240, 1536, 384), (10240, 384, 1536),
-          (10240, 1152, 384), (10240, 384, 384), (4096, 1536, 384), (4096, 384, 384)]
+shapes = [(104448, 1536, 192), (104448, 192, 768), (104448, 576, 192), (104448, 192, 192), (104448, 192, 1536), (104448, 192, 576), (12288, 1536, 384), (12288, 384, 1536),
+          (12288, 1152, 384), (12288, 384, 384), (4096, 1536, 384), (4096, 384, 384)]
 for (M, N, K) in shapes:
     X = torch.randn(M, K, device="cuda")
     dY = torch.randn(M, N, device="cuda")
