@@ -693,3 +693,36 @@ def test_batched_parameter_upload_matches_the_per_parameter_path():
     srcs = (C.c_void_p * 1)(t.data_ptr())
     numels = (C.c_int64 * 1)(4)
     assert lib.mdt_load_params(eng.handle, 1, names, srcs, numels, torch.cuda.current_stream().cuda_stream) != 0
+
+
+def test_split_sampler_launches_are_bit_reproducible_call_after_call():
+    """Round 6: from 768 rows a launch the MLP sublayer and the qkv products run as three-way bf16 splits (k_mlp_split,
+    k_gemm_ln_split).  No atomics, fixed summation orders: the same inputs must give the same BITS call after call, on the default
+    stream and on a side stream, at a batch that uses them in the decoder only (B = 100) and one that uses them in the encoder too
+    (B = 200)."""
+    from mdt_policy_amd import configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    cfg = configs.mdtv_default()
+    torch.manual_seed(0)
+    model = GCDenoiser(cfg, 0.5).cuda().eval()
+    sig = gs.get_sigmas_exponential(4, 0.001, 80.0).cuda()
+    side = torch.cuda.Stream()
+    for B in (100, 200):
+        inp = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(B, cfg, 11).items()}
+        st = {"state_images": inp["state_images"], "modality": "lang"}
+        ref = None
+        with torch.no_grad():
+            for i in range(12):
+                if i % 3 == 2:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        a = model.sample_ddim(st, inp["noise"] * 80.0, inp["goal"], sig).clone()
+                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    a = model.sample_ddim(st, inp["noise"] * 80.0, inp["goal"], sig).clone()
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = a
+                else:
+                    assert torch.equal(a, ref), f"B = {B}: call {i} differs from the first one"
