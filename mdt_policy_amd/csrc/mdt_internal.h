@@ -171,6 +171,7 @@ int mdt_gemm_tn_ktile(int K);  // 128 or 192: the k-tile width k_gemm_tn picks f
 // the same product as three-way bf16 splits of both operands (k_gemm_tn_split: 128 x 128 / 128 x 192 tiles, 8 waves, 123 / 154 KB of LDS)
 bool mdt_gemm_tn_split_on();
 int mdt_gemm_tn_split_ktile(int K);
+void mdt_gemm_tn_split_tile(int N, int K, int* tn, int* tk);   // its (n, k) tile: 128 x 128 / 128 x 192 / 192 x 128
 hipError_t mdt_launch_gemm_tn_split(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
                                     int K, int S, int L, int accumulate, float* bpart, hipStream_t s);
 void mdt_gemm_tn_tile(int64_t M, int N, int K, int* tn, int* tk);  // its (n, k) tile for an M-deep product: n 64 / 128 / 192 (4 / 8 / 12 waves)

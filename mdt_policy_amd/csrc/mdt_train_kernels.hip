@@ -2083,14 +2083,17 @@ __global__ __launch_bounds__(256 * WN) void k_gemm_tn(const float* __restrict__ 
 //   MFMA roles: A <- X (i = k column), B <- dY (j = n column): a lane ends with 4 consecutive k of one n, 16-byte stores.
 //   Slices, partial outputs and the bias gradient's per-slice column sums as in k_gemm_tn.
 // ------------------------------------------------------------------------------------------------
-template <int KTW>   // 16-wide k-tiles per wave: 2 (TK = 128) or 3 (TK = 192)
-__global__ __launch_bounds__(512) void k_gemm_tn_split(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
+// TNW = 64-column n-groups of the tile (2: 128 wide, 8 waves; 3: 192 wide, 6 waves -- N = 192 / 576 ...), KTW = 16-wide k-tiles per wave:
+// waves = (n group, k group of KTW tiles); TK = 16 KTW x (waves / TNW): 128 x 128, 128 x 192 (KTW = 2, 3 with TNW = 2), 192 x 128 (4 with 3)
+template <int KTW, int TNW = 2>
+__global__ __launch_bounds__(TNW == 2 ? 512 : 384) void k_gemm_tn_split(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ X, int64_t ldx,
                                                        float* __restrict__ out, int64_t slice_stride, int M, int N, int K, int L,
                                                        int accumulate, float* __restrict__ bpart, int xcd) {
-    constexpr int CM = 32, TN_ = 128, TK = 64 * KTW, NC = TN_ + TK, S = 80, PART = NC * S, BUF = 3 * PART;
-    constexpr int NQ = NC / 4, NI = NQ * 8, NU = (NI + 511) / 512;   // column quads, staging items (quad, 4-row group), items per thread
+    constexpr int NWV = TNW == 2 ? 8 : 6, NTH = 64 * NWV, WKG = NWV / TNW;   // waves, threads, k groups
+    constexpr int CM = 32, TN_ = 64 * TNW, TK = 16 * KTW * WKG, NC = TN_ + TK, S = 80, PART = NC * S, BUF = 3 * PART;
+    constexpr int NQ = NC / 4, NI = NQ * 8, NU = (NI + NTH - 1) / NTH;   // column quads, staging items (quad, 4-row group), items per thread
     extern __shared__ __attribute__((aligned(16))) char tns_lds[];      // 2 buffers x 3 parts x NC columns x 80 bytes
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave & 3, wn = wave >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave % WKG, wn = wave / WKG;
     const int gk = (K + TK - 1) / TK;
     int id = blockIdx.x + gridDim.x * blockIdx.z;
     if (xcd) {   // whole slices behind one L2 (k_gemm_tn)
@@ -2103,14 +2106,14 @@ __global__ __launch_bounds__(512) void k_gemm_tn_split(const float* __restrict__
     const int m_lo = z * L, m_hi = min(M, m_lo + L);
     out += (int64_t)z * slice_stride;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // ---- staging items of this thread: item t = tid + 512 u -> rows 4 (t % 8) .. + 3 of the chunk, column quad t / 8 (dY quads first) ----
+    // ---- staging items of this thread: item t = tid + NTH u -> rows 4 (t % 8) .. + 3 of the chunk, column quad t / 8 (dY quads first) ----
     int ih[NU], icol[NU];          // first row of the group; LDS column of the quad's first column (-1: no item)
     const float* isrc[NU];         // global address of (row 0 of the chunk's group, quad) at chunk 0
     int64_t ild[NU];
     bool iy[NU], ivalid[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int t = tid + 512 * u, h = t & 7, q = t >> 3;
+        const int t = tid + NTH * u, h = t & 7, q = t >> 3;
         ivalid[u] = t < NI;
         ih[u] = 4 * h;
         const bool y = q < TN_ / 4;
@@ -2137,7 +2140,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_split(const float* __restrict__
     auto stash = [&](char* buf, int mb) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            if (tid + 512 * u >= NI) continue;
+            if (tid + NTH * u >= NI) continue;
             f32x4 v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (ivalid[u] && mb + ih[u] + r < m_hi) ? stg[u][r] : zero4;
@@ -2236,28 +2239,39 @@ bool mdt_gemm_tn_split_on() {
 extern "C" void mdt_op_set_tn_split(int32_t on) { g_tn_split = on < 0 ? -1 : (on != 0); }
 // k-tile of the split kernel for a K-column product: 192 where that pads K less
 int mdt_gemm_tn_split_ktile(int K) { return (K + 191) / 192 * 192 < (K + 127) / 128 * 128 ? 192 : 128; }
-template <int KTW>
+// tile of the split kernel for an (N, K) product: (n, k) = 192 x 128 where 128-wide n-tiles would pad N by more than an eighth and
+// 192-wide ones do not (N = 192, 576 ...), else 128 x (192 where that pads K less, else 128)
+void mdt_gemm_tn_split_tile(int N, int K, int* tn, int* tk) {
+    const bool n192 = 8 * ((N + 127) / 128 * 128) > 9 * N && 8 * ((N + 191) / 192 * 192) <= 9 * N;
+    *tn = n192 ? 192 : 128;
+    *tk = n192 ? 128 : mdt_gemm_tn_split_ktile(K);
+}
+template <int KTW, int TNW>
 static hipError_t launch_gemm_tn_split_t(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M,
                                          int N, int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
-    constexpr int TK = 64 * KTW;
-    constexpr size_t lds = (size_t)2 * 3 * (128 + TK) * 80;
+    constexpr int NWV = TNW == 2 ? 8 : 6, TN_ = 64 * TNW, TK = 16 * KTW * (NWV / TNW);
+    constexpr size_t lds = (size_t)2 * 3 * (TN_ + TK) * 80;
     static bool attr_dev[32] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
     if (!attr_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KTW, TNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_dev[dev] = true;
     }
-    hipLaunchKernelGGL((k_gemm_tn_split<KTW>), dim3(((N + 127) / 128) * ((K + TK - 1) / TK), 1, S), dim3(512), lds, s, dY, ldy, X, ldx, out,
-                       slice_stride, M, N, K, L, accumulate, bpart, S > 1 ? 1 : 0);
+    hipLaunchKernelGGL((k_gemm_tn_split<KTW, TNW>), dim3(((N + TN_ - 1) / TN_) * ((K + TK - 1) / TK), 1, S), dim3(64 * NWV), lds, s, dY, ldy, X,
+                       ldx, out, slice_stride, M, N, K, L, accumulate, bpart, S > 1 ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t mdt_launch_gemm_tn_split(const float* dY, int64_t ldy, const float* X, int64_t ldx, float* out, int64_t slice_stride, int M, int N,
                                     int K, int S, int L, int accumulate, float* bpart, hipStream_t s) {
     if (M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || S < 1) return hipErrorInvalidValue;
-    return mdt_gemm_tn_split_ktile(K) == 192 ? launch_gemm_tn_split_t<3>(dY, ldy, X, ldx, out, slice_stride, M, N, K, S, L, accumulate, bpart, s)
-                                              : launch_gemm_tn_split_t<2>(dY, ldy, X, ldx, out, slice_stride, M, N, K, S, L, accumulate, bpart, s);
+    int tn, tk;
+    mdt_gemm_tn_split_tile(N, K, &tn, &tk);
+#define TNS_ARGS dY, ldy, X, ldx, out, slice_stride, M, N, K, S, L, accumulate, bpart, s
+    if (tn == 192) return launch_gemm_tn_split_t<4, 3>(TNS_ARGS);
+    return tk == 192 ? launch_gemm_tn_split_t<3, 2>(TNS_ARGS) : launch_gemm_tn_split_t<2, 2>(TNS_ARGS);
+#undef TNS_ARGS
 }
 
 // dW partials of S row slices of L rows: out + z * slice_stride is slice z's (N, K) product; N, K multiples of 16

@@ -141,9 +141,11 @@ mdt_status mdt_linear_bwd(const mdt_linear_bwd_args& a, hipStream_t s, mdt_colsu
         // ... where its 128-wide n-tiles pad N by at most an eighth (tools/dw_bench.py, us fp32 / split: 12288 x 1536 x 384 127 / 101,
         // x 384 x 1536 128 / 100, x 1152 x 384 105 / 80, x 384 x 384 47 / 36; 104448 x 1536 x 192 598 / 510, x 576 x 192 217 / 185;
         // N = 192 -- a quarter of its second tile empty -- loses: x 192 x 768 286 / 311, x 192 x 1536 507 / 590)
-        const bool tn_split = a.M >= 8192 && mdt_gemm_tn_split_on() && 8 * ((a.N + 127) / 128 * 128) <= 9 * a.N;
+        int stn = 128, stk = 128;
+        mdt_gemm_tn_split_tile(a.N, a.K, &stn, &stk);
+        const bool tn_split = a.M >= 8192 && mdt_gemm_tn_split_on() && 8 * ((a.N + stn - 1) / stn * stn) <= 9 * a.N;
         if (tn_split) {
-            const int64_t tiles = ((a.N + 127) / 128) * ((a.K + mdt_gemm_tn_split_ktile(a.K) - 1) / mdt_gemm_tn_split_ktile(a.K));
+            const int64_t tiles = ((a.N + stn - 1) / stn) * ((a.K + stk - 1) / stk);
             int64_t s2 = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(256 / tiles, S), a.M / 256));   // never a second round
             if (no_splitk()) s2 = 1;
             const int64_t l2 = ((a.M + s2 - 1) / s2 + 31) / 32 * 32;

@@ -428,12 +428,13 @@ def test_weight_gradient_wide_tiles(lib, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(8200, 384, 384), (12288, 1536, 384), (12288, 384, 1536), (33000, 768, 208), (40000, 1536, 192),
-                                   (33000, 576, 192), (8192 + 31, 240, 80), (10000, 128, 128)])
+                                   (33000, 576, 192), (8192 + 31, 240, 80), (10000, 128, 128), (33000, 192, 768), (20000, 192, 1536),
+                                   (9000, 192, 576), (9000, 192, 192), (8300, 384, 208)])
 def test_weight_gradient_as_bf16_splits_keeps_fp32_accuracy(lib, M, N, K):
     """Round 6: from 8192 reduction rows on dW = dY^T X runs as three-way bf16 splits of both operands (k_gemm_tn_split: six bf16
     MFMA products per 32 rows, operands transposed into m-contiguous octets on their way into LDS).  Against float64: the error
     of dW and of the bias gradient within 2.5x the fp32 MFMA kernel's on the same inputs (rows of very different scale), ragged
-    slices and tiles (N, K not multiples of the 128 x 128 / 128 x 192 tile), accumulation into dW."""
+    slices and tiles (N, K not multiples of the 128 x 128 / 128 x 192 / 192 x 128 tile), accumulation into dW."""
     L = lib.load()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     X = torch.randn(M, K, device="cuda", generator=g) * torch.exp(1.5 * torch.randn(M, 1, device="cuda", generator=g))
