@@ -123,7 +123,9 @@ mdt_status mdt_load_params(mdt_model *m, int32_t n, const char *const *names, co
 mdt_status mdt_reserve(mdt_model *m, int64_t max_batch);
 
 /* Number of times the workspace was (re)allocated.  A captured HIP graph of a sampler call holds workspace addresses: it
- * stays valid while this number does not change (mdt_reserve the largest batch first, capture afterwards). */
+ * stays valid while this number does not change (mdt_reserve the largest batch first, capture afterwards).  It also moves when a
+ * parameter load during training leaves the bf16 split weight images of the large-batch launches stale (round 6): a graph captured
+ * before that would replay those launches without the refresh they need. */
 int64_t mdt_ws_generation(const mdt_model *m);
 
 /* inner_model.forward_enc_only(state, action, goal, sigma)

@@ -439,6 +439,13 @@ extern "C" int64_t mdt_param_numel(const mdt_model* m, int64_t i) {
     return (m && i >= 0 && i < (int64_t)m->slots.size()) ? m->slots[i].numel : -1;
 }
 
+// A captured HIP graph of a large-batch call replays the split launches WITHOUT the refresh that a stale image needs: the first
+// load that makes the images stale also bumps the generation the graph owners compare (mdt_ws_generation), so they capture again --
+// with the refresh inside, which a replay then repeats (correct; 24 small launches) until the next capture.
+static inline void mark_split_stale(mdt_model* m) {
+    if (!m->split_stale) { m->split_stale = true; ++m->ws_generation; }
+}
+
 extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float* src, int64_t numel, void* stream) {
     if (!m || !name || !src) return fail(MDT_ERR_INVALID_ARG, "mdt_load_param: null argument");
     hipStream_t s = (hipStream_t)stream;
@@ -482,7 +489,7 @@ extern "C" mdt_status mdt_load_param(mdt_model* m, const char* name, const float
             }
         }
         if (t->kind == SLOT_PACK_SPLIT) {
-            if (m->train) { m->split_stale = true; continue; }   // training: re-made on demand (mdt_model_types.h)
+            if (m->train) { mark_split_stale(m); continue; }   // training: re-made on demand (mdt_model_types.h)
             HIP_TRY(mdt_launch_pack_weight_split(dev_src, t->rows, t->K, t->dst, s, t->n_off));
             continue;
         }
@@ -547,7 +554,7 @@ extern "C" mdt_status mdt_load_params(mdt_model* m, int32_t n, const char* const
             else if (t->kind == SLOT_TRANSPOSE) add(srcs[i], t->dst, MDT_LOAD_TRANSPOSE, t->rows, t->K, 0, 0);
             else if (t->kind == SLOT_PACK_T) add(srcs[i], t->dst, MDT_LOAD_PACK_T, t->rows, t->K, 0, t->rows / 16);
             else if (t->kind == SLOT_PACK_SPLIT) {
-                if (m->train) m->split_stale = true;   // training: re-made on demand (mdt_model_types.h)
+                if (m->train) mark_split_stale(m);   // training: re-made on demand (mdt_model_types.h)
                 else add(srcs[i], t->dst, MDT_LOAD_PACK_SPLIT, t->rows, t->K, t->n_off, 0);
             }
             else {

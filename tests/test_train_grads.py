@@ -815,3 +815,50 @@ def test_large_batch_sampling_after_optimizer_steps_reads_fresh_split_images():
     assert torch.equal(got, want), "sampling after optimizer steps read stale split images"
     assert not torch.equal(want, fp32), "the split launches did not run at B = 128"
     assert_close(want.cpu(), fp32.cpu(), rtol=1e-4, atol=1e-4, what="split against fp32 launches, B = 128 sampler call")
+
+
+@pytest.mark.gpu
+def test_graph_replayed_large_batch_sampling_after_optimizer_steps_is_recaptured(monkeypatch):
+    """The same with the sampler call replayed from a HIP graph (MDT_HIP_GRAPH=1 forces the replay at any batch): a graph captured
+    before the optimizer steps holds the split launches but not the refresh of their images -- the library moves the generation
+    the graph owner compares when a load leaves the images stale, so the call is captured again and reads fresh images."""
+    from mdt_policy_amd import _lib, configs
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    L = _lib.load()
+    monkeypatch.setattr(gs, "_GRAPH_MODE", "1", raising=False)
+    monkeypatch.setattr(gs, "_GRAPH_SAMPLER", True, raising=False)
+    cfg = configs.mdtv_default()
+    torch.manual_seed(0)
+    model = GCDenoiser(cfg, 0.5).cuda()
+    sig = gs.get_sigmas_exponential(4, 0.001, 80.0).cuda()
+    big = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(100, cfg, 3).items()}
+    st_big = {"state_images": big["state_images"], "modality": "lang"}
+    L.mdt_op_set_mlp_split(1)
+    try:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(4):   # capture + replays on the initial weights
+                before = gs.sample_ddim(model, st_big, big["noise"] * 80.0, big["goal"], sig).clone()
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        tr = {k: torch.from_numpy(v).cuda() for k, v in synthetic.sampler_inputs(32, cfg, 1).items()}
+        li = {k: torch.from_numpy(v).cuda() for k, v in synthetic.loss_inputs(32, cfg, 2).items()}
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss, _ = model.loss({"state_images": tr["state_images"], "modality": "lang"}, li["actions"], tr["goal"], li["noise_train"], li["sigma"])
+            loss.backward()
+            opt.step()
+        model.eval()
+        with torch.no_grad():
+            got = [gs.sample_ddim(model, st_big, big["noise"] * 80.0, big["goal"], sig).clone() for _ in range(3)]
+            fresh = GCDenoiser(cfg, 0.5).cuda().eval()
+            fresh.load_state_dict(model.state_dict())
+            want = fresh.sample_ddim(st_big, big["noise"] * 80.0, big["goal"], sig).clone()
+    finally:
+        L.mdt_op_set_mlp_split(-1)
+    torch.cuda.synchronize()
+    assert getattr(model, "_graphed_samplers", None), "the replay path was not taken"
+    assert not torch.equal(got[0], before), "the optimizer steps did not change the sampler's output"
+    for i, g in enumerate(got):
+        assert torch.equal(g, want), f"replayed call {i} after the optimizer steps read stale split images"
