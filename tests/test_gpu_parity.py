@@ -726,3 +726,37 @@ def test_split_sampler_launches_are_bit_reproducible_call_after_call():
                     ref = a
                 else:
                     assert torch.equal(a, ref), f"B = {B}: call {i} differs from the first one"
+
+
+@pytest.mark.parametrize("over", [dict(embed_dim=256), dict(embed_dim=128, n_heads=4)])
+def test_other_model_widths_at_a_split_batch_against_the_oracle(over):
+    """d = 256: the fused MLP launch has a split instantiation (two hidden slices), the qkv products keep the fp32 launch (the split
+    one is instantiated for d = 384); d = 128: one hidden slice, nothing fused, nothing split.  B = 100 (1000 decoder rows: above
+    the split forms' row count), 3-step sample_ddim against the CPU oracle, split on and off."""
+    from mdt_policy_amd import _lib, configs, synthetic
+    from mdt_policy_amd.models.edm_diffusion import gc_sampling as gs
+    from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser
+    L = _lib.load()
+    cfg = dict(configs.mdtv_default(), **over)
+    torch.manual_seed(0)
+    m = GCDenoiser(cfg, 0.5)
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    P = {k: torch.from_numpy(v) for k, v in synthetic.fill_state_dict(shapes, 5, "rich").items()}
+    m.load_state_dict(P, strict=False)
+    m = m.cuda().eval()
+    sig = gs.get_sigmas_exponential(3, 0.01, 80.0)
+    inp = {k: torch.from_numpy(v) for k, v in synthetic.sampler_inputs(100, cfg, 7).items()}
+    st = {"state_images": inp["state_images"], "modality": "lang"}
+    want = O.sample_ddim(P, cfg, st, inp["noise"] * 80.0, inp["goal"], sig, hoist=True)
+    res = {}
+    try:
+        with torch.no_grad():
+            for split in (1, 0):
+                L.mdt_op_set_mlp_split(split)
+                res[split] = m.sample_ddim({"state_images": inp["state_images"].cuda(), "modality": "lang"}, inp["noise"].cuda() * 80.0,
+                                           inp["goal"].cuda(), sig.cuda()).cpu()
+    finally:
+        L.mdt_op_set_mlp_split(-1)
+    for split in (1, 0):
+        assert_close(res[split], want, what=f"d = {cfg['embed_dim']}, split {split}")
+    assert torch.equal(res[0], res[1]) == (cfg["embed_dim"] == 128), "which widths run the split MLP launch changed"
