@@ -90,7 +90,7 @@ typedef struct {
     int64_t a_part_stride;
     float *a_merged;
     /* optional (round 6): the three-way bf16 split image of the same weight (mdt_op_pack_weight_split; rows in the order of Wp's).
-     * Where it is given, the LayerNorm-prologue products on the wide tiles (K = 384, N a multiple of 384, from 768 rows on
+     * Where it is given, the LayerNorm-prologue products on the wide tiles (K = 384 or 512, N a multiple of 384, from 768 rows on
      * -- MDT_HIP_SPLIT_MIN_ROWS --, plain output rows) multiply in the split form -- six bf16 MFMA products per 32-deep step, fp32
      * accumulation: fp32's product accuracy, not the fp32 form's bits -- unless mdt_op_set_mlp_split(0).  NULL: the fp32 form. */
     const void *Wp_split;
@@ -114,7 +114,7 @@ mdt_status mdt_op_mlp(const mdt_gemm_args *fc, const mdt_gemm_args *proj, float 
 /* The same launch with every contraction as a THREE-WAY bf16 SPLIT (round 6): each fp32 operand as three bf16 parts, six
  * v_mfma_f32_16x16x32_bf16 products per 32-deep step, fp32 accumulation -- fp32's product accuracy (not the bits of mdt_op_mlp) at a
  * third of its matrix-pipe time.  fc_split / proj_split: images of the two weights made by mdt_op_pack_weight_split ((4 D, D) and
- * (D, 4 D) row-major sources; 6 bytes per weight); fc->Wp / proj->Wp are not read.  D <= 384.  The model-level entry points use it
+ * (D, 4 D) row-major sources; 6 bytes per weight); fc->Wp / proj->Wp are not read.  The model-level entry points use it
  * from the row count of mdt_op_set_mlp_fuse_min on unless mdt_op_set_mlp_split(0) / MDT_HIP_MLP_SPLIT=0 (negative: default). */
 mdt_status mdt_op_pack_weight_split(const float *w, int64_t n_rows, int64_t K, void *image, void *stream);
 /* ... rows [n_off, n_off + n_rows) of a taller image (stacked weights: query | key | value); n_off a multiple of 16 */

@@ -1213,12 +1213,13 @@ static hipError_t launch_gemm_ln_split_pro(const mdt_gemm_args& a, hipStream_t s
 // which products take it: the split image is there, LayerNorm prologue over whole rows of K = 384, column count a multiple of the
 // 384-wide panels, plain output rows, and enough rows that the wide tiles are the choice anyway (the fused MLP's threshold)
 static bool gemm_ln_split_applies(const mdt_gemm_args& a) {
-    return a.Wp_split != nullptr && mdt_mlp_split_enabled() && a.ln && a.K == 384 && a.N % 384 == 0 &&
+    return a.Wp_split != nullptr && mdt_mlp_split_enabled() && a.ln && (a.K == 384 || a.K == 512) && a.N % 384 == 0 &&
            a.M >= mdt_split_min_rows() && a.batch <= 1 && !a.residual && a.gin == 1 && a.gout == 1 && a.goff == 0 && a.rowvec == nullptr && !a.aux_mode &&
            a.a_parts <= 4 && (a.lda & 3) == 0 && (a.ldo & 3) == 0 && g_mdt_gemm_force == 0;
 }
 static hipError_t launch_gemm_ln_split(const mdt_gemm_args& a, hipStream_t s) {
-    return launch_gemm_ln_split_pro<3, 3>(a, s);   // (the tile is written for any D <= 384 and 256-wide panels too; instantiated for the model)
+    // (the tile is written for any D <= 512 and 256-wide panels too; instantiated for the two shipped widths: MDT-V d = 384, MDT d = 512)
+    return a.K == 512 ? launch_gemm_ln_split_pro<4, 3>(a, s) : launch_gemm_ln_split_pro<3, 3>(a, s);
 }
 
 // ---- the fused MLP sublayer in the three-way bf16 split form (k_mlp_split) ----
@@ -1234,7 +1235,7 @@ int mdt_split_min_rows() {
     return v;
 }
 bool mdt_mlp_split_supported(const mdt_gemm_args& f, const mdt_gemm_args& p) {
-    return mdt_mlp_supported(f, p) && f.K <= 384;   // (instantiated for D <= 384)
+    return mdt_mlp_supported(f, p);
 }
 template <int NTW2, int PRO>
 static hipError_t launch_mlp_split_t(const mdt_gemm_args& f, const mdt_gemm_args& p, const void* w1s, const void* w2s, float* parts,
@@ -1269,7 +1270,8 @@ hipError_t mdt_launch_mlp_split(const mdt_gemm_args& f, const mdt_gemm_args& p, 
     switch (f.K / 128) {
         case 1: return launch_mlp_split_pro<1>(f, p, w1s, w2s, parts, part_stride, s);
         case 2: return launch_mlp_split_pro<2>(f, p, w1s, w2s, parts, part_stride, s);
-        default: return launch_mlp_split_pro<3>(f, p, w1s, w2s, parts, part_stride, s);
+        case 3: return launch_mlp_split_pro<3>(f, p, w1s, w2s, parts, part_stride, s);
+        default: return launch_mlp_split_pro<4>(f, p, w1s, w2s, parts, part_stride, s);
     }
 }
 

@@ -17,7 +17,7 @@
 //               order of mdt_ws.h (one ds_read_b128 per part, row tile and k32 step);
 //   hidden      the activation epilogue of the first product splits its values on the way into LDS, same slot order.
 // LDS: split x tile 3 x 32 x (2 D + 32) B, overlaid after the first product by the split hidden slice 3 x 32 x 1056 B = 101 KB
-// (instantiated for D <= 384).
+// (D <= 512: 101 KB either way).
 // No wave skew here (mlp_tile's flags): the hidden slice overlays the x tile, so the two products are separated by barriers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -135,7 +135,7 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
     constexpr int MTILES = 2, NWAVES = 8, MT = 32, HS = 512, NTW1 = 4, R = 2;
     constexpr int D = 128 * NTW2, K32a = D / 32, K32b = HS / 32;
     constexpr int ROWB1 = 2 * D + 32, PART1 = MT * ROWB1, ROWB2 = 2 * HS + 32, PART2 = MT * ROWB2;
-    static_assert(NTW2 >= 1 && NTW2 <= 3, "instantiated for D <= 384");
+    static_assert(NTW2 >= 1 && NTW2 <= 4, "D <= 512");
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int m0 = by * MT;
@@ -172,15 +172,15 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
     ring2.open(w2s, ((int64_t)(wave * NTW2) * K32p + (int64_t)s * K32b) * 3072, (int64_t)K32p * 3072, lane);
 #pragma unroll
     for (int u = 0; u < R - 1; ++u) ring2.request(u, u);
+    // (d = 512, four column tiles per wave: gate and residual rows are requested behind the second product instead -- 64 registers
+    //  the product's ring and accumulators need, 116 bytes of scratch otherwise)
+    constexpr bool EARLY = NTW2 <= 3;
     f32x4 acc2[MTILES][NTW2], b2[NTW2], gate_v[MTILES][NTW2], res_v[MTILES][NTW2];
     int ncol[NTW2];
 #pragma unroll
     for (int j = 0; j < NTW2; ++j) ncol[j] = (wave * NTW2 + j) * 16 + nq;
     const bool gated = p.mod != nullptr && p.gate_off >= 0;
-    {
-        const float* bp = (s == 0 && p.bias != nullptr) ? p.bias : zeros;
-#pragma unroll
-        for (int j = 0; j < NTW2; ++j) b2[j] = ldg4(bp + ncol[j]);
+    auto load_gate_res = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MTILES; ++i) {
             const int64_t m = min(m0 + i * 16 + (lane & 15), f.M - 1);
@@ -191,9 +191,18 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
             for (int j = 0; j < NTW2; ++j) {
                 gate_v[i][j] = ldg4(gp + ncol[j]);
                 res_v[i][j] = ldg4(rp + ncol[j]);
-                acc2[i][j] = zero4;
             }
         }
+    };
+    {
+        const float* bp = (s == 0 && p.bias != nullptr) ? p.bias : zeros;
+#pragma unroll
+        for (int j = 0; j < NTW2; ++j) b2[j] = ldg4(bp + ncol[j]);
+#pragma unroll
+        for (int i = 0; i < MTILES; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW2; ++j) acc2[i][j] = zero4;
+        if constexpr (EARLY) load_gate_res();
     }
     __syncthreads();                                  // everybody has read the x tile: the hidden slice overwrites it
     // ---- activation epilogue of the first product -> split hidden slice (lane holds hidden[16 i + lane % 16][tile * 16 + nq .. + 3]) ----
@@ -211,6 +220,7 @@ __device__ __forceinline__ void mlp_split_tile(const mdt_gemm_args& f, const mdt
     __syncthreads();
     split_phase<NTW2, K32b, R>(ring2, hs, ROWB2, PART2, lane, acc2);
 
+    if constexpr (!EARLY) load_gate_res();
     float* out = parts + (int64_t)s * part_stride;
 #pragma unroll
     for (int i = 0; i < MTILES; ++i) {
@@ -235,7 +245,7 @@ template <int ND, int NTW, int PRO, int XP>
 __device__ __forceinline__ void gemm_ln_split_tile(const mdt_gemm_args& a, int by, int bx, char* lds, const float* __restrict__ zeros, int tid) {
     constexpr int MTILES = 2, NWAVES = 8, MT = 32, R = 2;
     constexpr int D = 128 * ND, K32 = D / 32, ROWB = 2 * D + 32, PART = MT * ROWB;
-    static_assert(ND >= 1 && ND <= 3, "D <= 384");
+    static_assert(ND >= 1 && ND <= 4, "D <= 512");
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = tid & 63, wave = tid >> 6;
     const int m0 = by * MT, nq = 4 * (lane >> 4);

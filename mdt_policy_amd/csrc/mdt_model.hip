@@ -206,7 +206,7 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         lin_part(qkv, pre + ".key", D, D, true);
         lin_part(qkv, pre + ".query", D, 0, true);
         lin_part(qkv, pre + ".value", D, 2 * D, true);
-        if (D % 128 == 0 && D <= 384) {   // the split form of the LayerNorm-prologue product (mdt_mlp_split.h): 6 bytes per weight
+        if (D % 128 == 0 && D <= 512) {   // the split form of the LayerNorm-prologue product (mdt_mlp_split.h): 6 bytes per weight
             qkv.ws = b.take((size_t)3 * D * D * 6 / 4);
             add_extra(pre + ".key.weight", (int64_t)D * D, SLOT_PACK_SPLIT, (float*)qkv.ws, D, D, D);
             add_extra(pre + ".query.weight", (int64_t)D * D, SLOT_PACK_SPLIT, (float*)qkv.ws, D, D, 0);
@@ -227,7 +227,7 @@ static void build_params(mdt_model* m, Bump& b, bool fill_slots) {
         lin_part(e.fc, pre + ".mlp.c_fc", 4 * D, 0, xb);
         lin_begin(e.proj2, D, 4 * D, xb);
         lin_part(e.proj2, pre + ".mlp.c_proj", D, 0, xb);
-        if (D % 128 == 0 && D <= 384) {   // the fused MLP launch's split form (mdt_mlp_split.h): 6 bytes per weight
+        if (D % 128 == 0 && D <= 512) {   // the fused MLP launch's split form (mdt_mlp_split.h): 6 bytes per weight
             e.fc.ws = b.take((size_t)4 * D * D * 6 / 4);
             e.proj2.ws = b.take((size_t)4 * D * D * 6 / 4);
             add_extra(pre + ".mlp.c_fc.weight", (int64_t)4 * D * D, SLOT_PACK_SPLIT, (float*)e.fc.ws, 4 * D, D);
@@ -1443,7 +1443,7 @@ extern "C" mdt_status mdt_op_mlp_split(const mdt_gemm_args* fc, const mdt_gemm_a
     if (!fc || !proj || !fc->A || !fc_split || !proj_split || !parts || !fc->ln_w)
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp_split: null pointer");
     if (!mdt_mlp_split_supported(*fc, *proj))
-        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_mlp_split: needs D = fc.K a multiple of 128 (<= 384), fc.N = proj.K = 4 D, proj.N = D, "
+        return fail(MDT_ERR_UNSUPPORTED, "mdt_op_mlp_split: needs D = fc.K a multiple of 128 (<= 512), fc.N = proj.K = 4 D, proj.N = D, "
                                          "a LayerNorm prologue and plain output rows");
     if (fc->lda % 4 || proj->ldo % 4 || proj->ldo < proj->N || part_stride < (int64_t)fc->M * proj->ldo)
         return fail(MDT_ERR_INVALID_ARG, "mdt_op_mlp_split: lda / ldo multiples of 4, part_stride >= M * ldo required");

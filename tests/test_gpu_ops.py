@@ -993,7 +993,8 @@ def test_pack_weight_split_layout_and_exactness(lib, N, K):
 
 
 @pytest.mark.parametrize("M,D,case", [(2560, 384, "bcast"), (2560, 384, "rows"), (2560, 384, "plain_bias"), (1777, 384, "bcast"),
-                                      (45, 384, "rows"), (200, 256, "rows"), (33, 256, "plain_bias")])
+                                      (45, 384, "rows"), (200, 256, "rows"), (33, 256, "plain_bias"), (320, 512, "bcast"),
+                                      (1000, 512, "rows"), (77, 512, "plain_bias")])
 def test_fused_mlp_in_its_bf16_split_form_keeps_fp32_accuracy(lib, M, D, case):
     """k_mlp_split (round 6): the fused MLP launch with every contraction as six bf16 MFMA products of three-way split operands.
     Not the fp32 launch's bits: against the float64 sublayer its error must stay within 1.5x the fp32 launch's own on the same
@@ -1095,7 +1096,8 @@ def test_gemm_reads_the_sum_of_slabs(lib, M, N, XP, case):
 
 
 @pytest.mark.parametrize("M,N,D,XP,case", [(2560, 1152, 384, 3, "bcast"), (2560, 1152, 384, 1, "rows"), (1530, 1152, 384, 3, "ln"),
-                                           (1777, 768, 384, 2, "bcast"), (800, 384, 384, 4, "ln")])
+                                           (1777, 768, 384, 2, "bcast"), (800, 384, 384, 4, "ln"), (1000, 1536, 512, 4, "bcast"),
+                                           (900, 384, 512, 1, "ln")])
 def test_layernorm_gemm_in_its_bf16_split_form_keeps_fp32_accuracy(lib, M, N, D, XP, case):
     """mdt_gemm_args.Wp_split (round 6): the wide LayerNorm-prologue product -- the decoder's qkv GEMM, rows = the sum of the fused
     MLP's slabs -- as six bf16 MFMA products of three-way split operands per k32 step.  a_merged must still be the exact slab-order

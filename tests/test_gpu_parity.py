@@ -760,3 +760,30 @@ def test_other_model_widths_at_a_split_batch_against_the_oracle(over):
     for split in (1, 0):
         assert_close(res[split], want, what=f"d = {cfg['embed_dim']}, split {split}")
     assert torch.equal(res[0], res[1]) == (cfg["embed_dim"] == 128), "which widths run the split MLP launch changed"
+
+
+def test_mdt_architecture_at_a_split_batch_against_the_oracle():
+    """The MDT architecture (d = 512, six decoder blocks; g3_b8_mdt's weights and configuration) at B = 100: its fused MLP launch
+    (four hidden slices, four column tiles per wave in the second product) and its qkv products (N = 1536: four 384-wide panels)
+    run as three-way bf16 splits too.  3-step sample_ddim against the CPU oracle with the split forms on and off; the split must
+    really have run."""
+    from mdt_policy_amd import _lib
+    L = _lib.load()
+    meta, _ = load_fixture("g3_b8_mdt.npz")
+    model = build(meta)
+    cfg, P = cfg_of(meta), params_of(meta)
+    sig = O.get_sigmas_exponential(3, 0.01, 80.0)
+    state, goal, noise = inputs_of(dict(meta, input_seed=731), batch=100)
+    want = O.sample_ddim(P, cfg, state, noise * 80.0, goal, sig, arch="mdt", hoist=True)
+    gstate = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in state.items()}
+    res = {}
+    try:
+        with torch.no_grad():
+            for split in (1, 0):
+                L.mdt_op_set_mlp_split(split)
+                res[split] = sampling().sample_ddim(model, gstate, noise.cuda() * 80.0, goal.cuda(), sig).cpu()
+    finally:
+        L.mdt_op_set_mlp_split(-1)
+    for split in (1, 0):
+        assert_close(res[split], want, what=f"MDT, B = 100, split {split}")
+    assert not torch.equal(res[0], res[1]), "the split launches did not run for the d = 512 model"
