@@ -347,6 +347,24 @@ def other_configs(device):
                                            "evaluation per launch sequence (host-driven step loop)"}
     except Exception as e:  # diagnostic leg
         out["other_samplers_B256"] = {"error": repr(e)}
+    # the other shipped architecture: MDTTransformer (d = 512, 4 + 6 blocks; configs.mdt_default), the same fused sampler call at B = 256
+    try:
+        from mdt_policy_amd import configs as _cfgs
+        from mdt_policy_amd.models.edm_diffusion.score_wrappers import GCDenoiser as _GCD
+        cfg_m = _cfgs.mdt_default()
+        torch.manual_seed(0)
+        m_mdt = _GCD(cfg_m, 0.5).to(device).eval()
+        inp_m = {k: torch.from_numpy(v).to(device) for k, v in synthetic.sampler_inputs(256, cfg_m, 3, "mdt").items()}
+        st_m = {"static": inp_m["static"], "gripper": inp_m["gripper"], "modality": "lang"}
+        sig_m = gs.get_sigmas_exponential(10, 0.001, 80.0).to(device)
+        with torch.no_grad():
+            dt_m = timed(lambda: m_mdt.sample_ddim(st_m, inp_m["noise"] * 80.0, inp_m["goal"], sig_m), 3, 10)
+        out["sample_ddim_mdt_arch_B256"] = {"ms_per_call": round(dt_m * 1e3, 3), "chunks_per_s": round(256 / dt_m, 1),
+                                            "what": "MDTTransformer (d = 512, 4 encoder + 6 decoder blocks, configs.mdt_default), fused sample_ddim, "
+                                                    "10 steps, B = 256, random-init weights"}
+        del m_mdt
+    except Exception as e:  # diagnostic leg
+        out["sample_ddim_mdt_arch_B256"] = {"error": repr(e)}
     # the contrastive (CLA) auxiliary head at the training batch (mdtv_agent.py:440-484): the MAP pooling
     # block over latent_encoder_emb, forward + backward, and the InfoNCE op (value + gradients)
     try:
